@@ -1,0 +1,326 @@
+"""CPU oracle for the Hourglass (encoder + critic head + decoder/mask head) hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only
+``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker / the timed CPU baseline.  The shipped path
+(``cgs_amd``) never imports this module and fails loudly when its HIP library is missing.
+
+What this is: a restatement, in this repo's own words, of the arithmetic the reference
+performs on its training / inference path, written against stock PyTorch **CPU** fp32 ops
+(the reference's own numeric backend, ``requirements.txt:79``).  It is functional (no
+``nn.Module``): parameters are plain ``dict[str, Tensor]`` using the reference's
+``state_dict`` key names and OIHW shapes, so a reference checkpoint can be fed in as is.
+
+Parity pin: every function here is checked against fixtures captured from the reference's
+own ``nets.py`` classes imported in the build container (``tests/golden/make_golden.py`` ->
+``tests/golden/*.npz``; checked by ``tests/test_oracle_golden.py``).  The reference ships no
+tests or golden vectors of its own, so those captures are the pin.
+
+Reference lines restated (relative to /root/reference):
+  critic_apply      nets.py:160-212   (NewCritic.__init__/forward)
+  masker_apply      nets.py:452-523   (UnetDecoder.__init__/forward)
+  shift_batch       main.py:584-591
+  phase1_loss       main.py:189-195
+  phase2_loss       main.py:360-429
+  adam_step         main.py:178,330-334,461-463 (torch.optim.Adam defaults)
+  infer_masks       main.py:1130-1151
+  postprocess_masks main.py:1163-1167,1212-1223
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+ENC_CONV_KEYS = ("features.0", "features.3", "features.6", "features.10")
+BOTTLENECK_KEY = "features.14"
+HEAD_KEYS = ("crit.1", "crit.4")
+DEC_KEYS = ("dec_model.0", "dec_model.1", "dec_model.2", "dec_model.3", "dec_model.4")
+MASK_KEYS = ("masker.0", "masker.2")
+
+
+# --------------------------------------------------------------------------------------
+# parameter inventory (nets.py:161-195, 453-492)
+# --------------------------------------------------------------------------------------
+def critic_shapes(chfak: int = 1, neck: int = 32, colorchs: int = 3) -> List[Tuple[str, Tuple[int, ...]]]:
+    d = [8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
+    b = neck * chfak
+    out = []
+    cin = colorchs
+    for key, cout in zip(ENC_CONV_KEYS, d):
+        out += [(key + ".weight", (cout, cin, 3, 3)), (key + ".bias", (cout,))]
+        cin = cout
+    out += [(BOTTLENECK_KEY + ".weight", (b, d[3], 4, 4)), (BOTTLENECK_KEY + ".bias", (b,))]
+    out += [("crit.1.weight", (b, b)), ("crit.1.bias", (b,))]
+    out += [("crit.4.weight", (1, b)), ("crit.4.bias", (1,))]
+    return out
+
+
+def masker_shapes(chfak: int = 1, neck: int = 32, colorchs: int = 3, masker_channels: int = 16):
+    e = [8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
+    d = list(e)
+    b = neck * chfak
+    out = [
+        ("dec_model.0.weight", (d[0], e[0] + d[1], 3, 3)), ("dec_model.0.bias", (d[0],)),
+        ("dec_model.1.weight", (d[1], e[1] + d[2], 3, 3)), ("dec_model.1.bias", (d[1],)),
+        ("dec_model.2.weight", (d[2], e[2] + d[3], 3, 3)), ("dec_model.2.bias", (d[2],)),
+        ("dec_model.3.weight", (d[3], e[3] + b, 3, 3)), ("dec_model.3.bias", (d[3],)),
+        ("dec_model.4.weight", (b, b, 1, 1)), ("dec_model.4.bias", (b,)),
+        ("masker.0.weight", (masker_channels, colorchs + d[0], 3, 3)), ("masker.0.bias", (masker_channels,)),
+        ("masker.2.weight", (1, masker_channels, 3, 3)), ("masker.2.bias", (1,)),
+    ]
+    return out
+
+
+def seeded_params(shapes, seed: int) -> Params:
+    """Reproducible stand-in weights: uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) from a numpy
+    RandomState.  (Not torch's default-init stream, which differs across torch versions --
+    SURVEY.md section 8c -- fixtures therefore always carry explicit weights or this seed.)"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for key, shp in shapes:
+        if key.endswith(".weight"):
+            fan_in = int(np.prod(shp[1:]))
+            last_bound = 1.0 / math.sqrt(fan_in)
+        bound = last_bound
+        out[key] = torch.from_numpy(rs.uniform(-bound, bound, size=shp).astype(np.float32))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# forward passes
+# --------------------------------------------------------------------------------------
+def _drop(h, p, training, mask):
+    """nn.Dropout semantics (nets.py:179,183,192): keep-mask / (1-p) in training mode."""
+    if not training or p <= 0.0:
+        return h
+    if mask is None:
+        mask = (torch.rand_like(h) >= p).to(h.dtype)
+    return h * mask.to(h.dtype) / (1.0 - p)
+
+
+def critic_apply(P: Params, X: torch.Tensor, collect: bool = False, p: float = 0.0,
+                 training: bool = False, masks: Optional[Sequence[torch.Tensor]] = None):
+    """Encoder + critic head.  X is NCHW fp32 in [0,1].  ``masks`` (optional) are the three
+    dropout keep-masks, shaped like embed2, embed3 and the first Linear's output.
+    Returns pred [N,1] (and the 5 embeds when ``collect``): embeds are the four post-pool
+    tensors taken BEFORE dropout plus the post-ReLU bottleneck (nets.py:200-205)."""
+    m = list(masks) if masks is not None else [None, None, None]
+    h = X
+    embeds = []
+    for i, key in enumerate(ENC_CONV_KEYS):
+        h = F.conv2d(h, P[key + ".weight"], P[key + ".bias"], stride=1, padding=1)
+        h = F.max_pool2d(F.relu(h), 2)
+        embeds.append(h)
+        if i >= 2:
+            h = _drop(h, p, training, m[i - 2])
+    h = F.relu(F.conv2d(h, P[BOTTLENECK_KEY + ".weight"], P[BOTTLENECK_KEY + ".bias"]))
+    embeds.append(h)
+    f = h.flatten(1)
+    f = F.relu(F.linear(f, P["crit.1.weight"], P["crit.1.bias"]))
+    f = _drop(f, p, training, m[2])
+    pred = torch.sigmoid(F.linear(f, P["crit.4.weight"], P["crit.4.bias"]))
+    return (pred, embeds) if collect else pred
+
+
+def _up2(t):
+    return F.interpolate(t, scale_factor=2, mode="nearest")
+
+
+def masker_apply(P: Params, X: torch.Tensor, embeds: Sequence[torch.Tensor], return_all: bool = False):
+    """Decoder + mask head.  Linear trunk (no activation between dec convs, nets.py:494-517),
+    concat order (skip, upsampled) and (X, upsampled) for the mask head (nets.py:504-520)."""
+    o4 = F.conv2d(embeds[4], P["dec_model.4.weight"], P["dec_model.4.bias"])
+    o3 = F.conv2d(torch.cat((embeds[3], _up2(_up2(o4))), 1), P["dec_model.3.weight"], P["dec_model.3.bias"], padding=1)
+    o2 = F.conv2d(torch.cat((embeds[2], _up2(o3)), 1), P["dec_model.2.weight"], P["dec_model.2.bias"], padding=1)
+    o1 = F.conv2d(torch.cat((embeds[1], _up2(o2)), 1), P["dec_model.1.weight"], P["dec_model.1.bias"], padding=1)
+    o0 = F.conv2d(torch.cat((embeds[0], _up2(o1)), 1), P["dec_model.0.weight"], P["dec_model.0.bias"], padding=1)
+    hm = F.leaky_relu(F.conv2d(torch.cat((X, _up2(o0)), 1), P["masker.0.weight"], P["masker.0.bias"], padding=1), 0.01)
+    Z = torch.sigmoid(F.conv2d(hm, P["masker.2.weight"], P["masker.2.bias"], padding=1))
+    if return_all:
+        return Z, dict(o4=o4, o3=o3, o2=o2, o1=o1, o0=o0, hm=hm)
+    return Z
+
+
+def u8_to_nchw(X_u8) -> torch.Tensor:
+    """NHWC uint8 -> NCHW fp32 / 255 (main.py:189,360-361)."""
+    if isinstance(X_u8, np.ndarray):
+        X_u8 = torch.from_numpy(X_u8)
+    return X_u8.permute(0, 3, 1, 2).float() / 255.0
+
+
+# --------------------------------------------------------------------------------------
+# augmentation (main.py:584-591)
+# --------------------------------------------------------------------------------------
+def shift_batch(X: torch.Tensor, shift: int, generator: Optional[torch.Generator] = None):
+    """Whole-batch circular roll along width (dim 2 of NHWC).  Two draws from the torch RNG:
+    the amount ``int(shift*u0)`` then the direction ``u1 > 0.5``.  Returns (rolled, amount, flag)."""
+    u0 = torch.rand(1, generator=generator)
+    amount = int(shift * u0)
+    u1 = torch.rand(1, generator=generator)
+    left = bool(u1 > 0.5)
+    if left:
+        out = torch.cat((X[:, :, amount:], X[:, :, :amount]), dim=2)
+    else:
+        # amount == 0: X[:, :, -0:] is all of X and X[:, :, :-0] is empty, i.e. the identity
+        out = torch.cat((X[:, :, -amount:], X[:, :, :-amount]), dim=2)
+    return out, amount, left
+
+
+# --------------------------------------------------------------------------------------
+# losses
+# --------------------------------------------------------------------------------------
+def phase1_loss(Pc: Params, XP: torch.Tensor, Y: torch.Tensor, threshrew: float = 0.0, p: float = 0.0,
+                training: bool = True, masks=None):
+    """Critic regression (main.py:189-195): mse(critic(X).squeeze(), Y) or BCE under --threshrew."""
+    pred = critic_apply(Pc, XP, p=p, training=training, masks=masks).squeeze()
+    if threshrew:
+        return F.binary_cross_entropy(pred, Y), pred
+    return F.mse_loss(pred, Y), pred
+
+
+def phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: torch.Tensor,
+                lfak: float = 5, L1: float = 0.5, L2: float = 0.0, inject: bool = True, live: bool = True,
+                threshrew: float = 0.0, p: float = 0.0, training: bool = True, masks=None):
+    """Joint mask/critic objective of one phase-2 step (main.py:364-429, staticnorm => valuefak=1).
+
+    ``masks`` (optional) = 4 lists of 3 dropout keep-masks for the passes [A, B, replaced, injected]
+    in the order the reference draws them.  Returns (total, parts dict, Z, pred)."""
+    mk = masks if masks is not None else [None, None, None, None]
+    pred, embeds = critic_apply(Pc, A, collect=True, p=p, training=training, masks=mk[0])
+    negpred = critic_apply(Pc, B, p=p, training=training, masks=mk[1])
+    pred = pred.squeeze()
+    negpred = negpred.squeeze().detach()
+    total = 0
+    parts = {}
+    if live:
+        cl = F.binary_cross_entropy(pred, Y) if threshrew else F.mse_loss(pred, Y)
+        total = total + lfak * cl
+        parts["critic"] = cl
+    Z = masker_apply(Pm, A, embeds)
+    replaced = A * (1 - Z) + Z * B
+    rv = critic_apply(Pc, replaced, p=p, training=training, masks=mk[2]).squeeze()
+    rl = F.mse_loss(rv, negpred.detach())
+    total = total + rl
+    parts["replace"] = rl
+    if inject:
+        injected = B * (1 - Z) + Z * A
+        iv = critic_apply(Pc, injected, p=p, training=training, masks=mk[3]).squeeze()
+        il = F.mse_loss(iv, pred.detach())
+        total = total + il
+        parts["inject"] = il
+    if L1:
+        nl = L1 * F.l1_loss(Z, torch.zeros_like(Z))
+        total = total + nl
+        parts["norm"] = nl
+    if L2:
+        nl2 = L2 * F.mse_loss(Z, torch.zeros_like(Z))
+        total = total + nl2
+        parts["norm2"] = nl2
+    return total, parts, Z, pred
+
+
+# --------------------------------------------------------------------------------------
+# optimiser (torch.optim.Adam defaults; main.py never reads --lr)
+# --------------------------------------------------------------------------------------
+class AdamRef:
+    """Hand-written Adam (lr 1e-3, betas (0.9,0.999), eps 1e-8, no weight decay/amsgrad),
+    checked against torch.optim.Adam in tests/test_oracle_golden.py."""
+
+    def __init__(self, params: Sequence[torch.Tensor], lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        self.params = list(params)
+        self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+        self.m = [torch.zeros_like(q) for q in self.params]
+        self.v = [torch.zeros_like(q) for q in self.params]
+        self.t = 0
+
+    @torch.no_grad()
+    def step(self, grads: Sequence[Optional[torch.Tensor]]):
+        self.t += 1
+        c1 = 1.0 - self.b1 ** self.t
+        c2 = 1.0 - self.b2 ** self.t
+        for q, g, m, v in zip(self.params, grads, self.m, self.v):
+            if g is None:
+                continue
+            m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+            denom = (v.sqrt() / math.sqrt(c2)).add_(self.eps)
+            q.addcdiv_(m, denom, value=-self.lr / c1)
+
+
+def leafify(P: Params) -> Params:
+    return {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+
+
+def train_phase2(Pc: Params, Pm: Params, batches, steps: int, live=True, **loss_kw):
+    """Runs ``steps`` optimiser steps of phase 2 on (A,B,Y) batches; returns per-step records.
+    Optimiser membership follows main.py:330-334 (critic+masker when live, masker only when frozen)."""
+    Pc, Pm = leafify(Pc), leafify(Pm)
+    keys = ([("c", k) for k in Pc] if live else []) + [("m", k) for k in Pm]
+    tensors = [(Pc if w == "c" else Pm)[k] for w, k in keys]
+    opt = AdamRef(tensors)
+    records = []
+    for s in range(steps):
+        A, B, Y = batches[s % len(batches)]
+        for t in list(Pc.values()) + list(Pm.values()):
+            t.grad = None
+        total, parts, Z, pred = phase2_loss(Pc, Pm, A, B, Y, live=live, **loss_kw)
+        total.backward()
+        rec = dict(total=float(total.detach()), parts={k: float(v.detach()) for k, v in parts.items()},
+                   grads_c={k: (v.grad.clone() if v.grad is not None else None) for k, v in Pc.items()},
+                   grads_m={k: (v.grad.clone() if v.grad is not None else None) for k, v in Pm.items()},
+                   Z=Z.detach().clone(), pred=pred.detach().clone())
+        opt.step([t.grad for t in tensors])
+        rec["params_c"] = {k: v.detach().clone() for k, v in Pc.items()}
+        rec["params_m"] = {k: v.detach().clone() for k, v in Pm.items()}
+        records.append(rec)
+    return records
+
+
+def train_phase1(Pc: Params, batches, steps: int, **loss_kw):
+    Pc = leafify(Pc)
+    tensors = list(Pc.values())
+    opt = AdamRef(tensors)
+    records = []
+    for s in range(steps):
+        XP, Y = batches[s % len(batches)]
+        for t in tensors:
+            t.grad = None
+        loss, pred = phase1_loss(Pc, XP, Y, **loss_kw)
+        loss.backward()
+        rec = dict(loss=float(loss.detach()), pred=pred.detach().clone(),
+                   grads={k: v.grad.clone() for k, v in Pc.items()})
+        opt.step([t.grad for t in tensors])
+        rec["params"] = {k: v.detach().clone() for k, v in Pc.items()}
+        records.append(rec)
+    return records
+
+
+# --------------------------------------------------------------------------------------
+# inference + mask post-processing
+# --------------------------------------------------------------------------------------
+@torch.no_grad()
+def infer_masks(Pc: Params, Pm: Params, X01: np.ndarray, batchsize: int = 128):
+    """-process loop (main.py:1130-1151): X01 is float64 NHWC in [0,1]; eval mode; returns
+    (preds [N], masks [N,1,H,W]) as float32 numpy."""
+    preds, masks = [], []
+    for b in range(0, len(X01), batchsize):
+        batch = torch.from_numpy(X01[b:b + batchsize]).permute(0, 3, 1, 2).float()
+        pred, embeds = critic_apply(Pc, batch, collect=True)
+        preds.append(pred.squeeze(1).numpy())
+        masks.append(masker_apply(Pm, batch, embeds).numpy())
+    return np.concatenate(preds, 0), np.concatenate(masks, 0)
+
+
+def postprocess_masks(X01: np.ndarray, M: np.ndarray, threshold: float = 0.5):
+    """main.py:1163-1167,1212: stack [image, raw mask x3, thresholded mask x3] -> uint8 arrays.
+    Returns (hardM bool [N,1,H,W], stack uint8 [N,3,H,W,3])."""
+    hard = M >= threshold
+    cols = [X01] + [np.concatenate((m, m, m), axis=1).transpose(0, 2, 3, 1) for m in (M, hard)]
+    stack = np.stack(cols, axis=1)
+    return hard, (stack * 255).astype(np.uint8)
