@@ -1,0 +1,96 @@
+"""ctypes binding of libcgs_hip.so (C ABI declared in include/cgs_hip.h).
+
+The product path has NO fallback: if the library is missing or was not built, importing a kernel
+raises.  PyTorch only supplies device memory (``tensor.data_ptr()``) and the current HIP stream."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcgs_hip.so")
+
+OK, ERR_UNSUPPORTED, ERR_BADARG = 0, -1, -2
+SRC_F32, SRC_U8 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+
+vp = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+
+
+class Dropout(C.Structure):
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("step", C.c_void_p)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("n", i32), ("h", i32), ("w", i32), ("ca", i32), ("cb", i32), ("co", i32), ("src_a", i32),
+                ("ups", i32), ("act", i32), ("pool", i32), ("drop_a", Dropout)]
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("dst", C.c_void_p), ("nslab", i32), ("stride", i32), ("count", i32),
+                ("accumulate", i32)]
+
+
+# name -> (restype, argtypes); mirrors include/cgs_hip.h one to one
+SIGNATURES = {
+    "cgs_conv3x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_conv3x3_bwd_data": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]),
+    "cgs_conv3x3_bwd_weight_slabs": (i32, [C.POINTER(ConvDesc)]),
+    "cgs_conv3x3_bwd_weight": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "cgs_reduce_slabs": (i32, [vp, i32, i32, vp, vp]),
+    "cgs_head_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, Dropout, Dropout, vp, vp, vp, vp]),
+    "cgs_head_bwd_slabs": (i32, [i32]),
+    "cgs_head_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, Dropout, Dropout, vp, vp, vp]),
+    "cgs_pointwise_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_pointwise_bwd_slabs": (i32, [i32]),
+    "cgs_pointwise_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_mix_fwd": (i32, [i32, i32, vp, vp, vp, i32, vp, vp, vp]),
+    "cgs_mix_bwd": (i32, [i32, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp]),
+    "cgs_phase2_losses": (i32, [i32, vp, vp, vp, f32, f32, f32, i32, i64, vp, vp, vp]),
+    "cgs_phase1_loss": (i32, [i32, vp, vp, i32, vp, vp, vp]),
+    "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]),
+    "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_dropout_mask": (i32, [Dropout, i64, vp, vp]),
+    "cgs_build_arch": (C.c_char_p, []),
+    "cgs_abi_version": (i32, []),
+}
+
+_lib = None
+
+
+class CgsError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the HIP library (once).  Fails loudly when it is absent -- there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CgsError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code == OK:
+        return
+    if code == ERR_UNSUPPORTED:
+        raise CgsError(f"{what}: shape/configuration not supported by the HIP kernels (CGS_ERR_UNSUPPORTED)")
+    if code == ERR_BADARG:
+        raise CgsError(f"{what}: bad argument (CGS_ERR_BADARG)")
+    raise CgsError(f"{what}: hipError {code}")
+
+
+def call(name, *args):
+    lib = load()
+    check(getattr(lib, name)(*args), name)

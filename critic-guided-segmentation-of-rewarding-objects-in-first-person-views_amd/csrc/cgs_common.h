@@ -1,0 +1,96 @@
+// Shared device-side helpers for the gfx950 kernels of libcgs_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "cgs_hip.h"
+
+#define CGS_WAVE 64
+
+// Weights are read through the constant address space: uniform addresses there always lower to
+// s_load_dword* (scalar cache -> SGPRs), so an FMA takes its weight as an SGPR operand and the
+// vector memory path stays free for activations.
+#define CGS_CONSTANT __attribute__((address_space(4)))
+typedef const float CGS_CONSTANT* cgs_cptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+__device__ __forceinline__ cgs_cptr cgs_to_const(const float* p) { return (cgs_cptr)p; }
+#pragma clang diagnostic pop
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float f4get(const float4& v, int c) {
+    return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11), counter = (idx, site, step_lo, step_hi), key = seed.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+
+struct DropCtx {
+    float p, scale;
+    uint32_t site;
+    uint2 key;
+    uint32_t step_lo, step_hi;
+    bool on;
+};
+
+__device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d) {
+    DropCtx c;
+    c.on = d.p > 0.f;
+    c.p = d.p;
+    c.scale = c.on ? 1.f / (1.f - d.p) : 1.f;
+    c.site = d.site;
+    c.key = make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+    uint64_t s = (c.on && d.step) ? *d.step : 0ull;
+    c.step_lo = (uint32_t)s;
+    c.step_hi = (uint32_t)(s >> 32);
+    return c;
+}
+
+// Multipliers (0 or 1/(1-p)) for the four consecutive floats whose float4 index is idx4.
+__device__ __forceinline__ float4 drop_mult4(const DropCtx& c, uint32_t idx4) {
+    uint4 r = philox4x32_10(make_uint4(idx4, c.site, c.step_lo, c.step_hi), c.key);
+    const float u = 1.f / 16777216.f;
+    float4 m;
+    m.x = ((r.x >> 8) * u >= c.p) ? c.scale : 0.f;
+    m.y = ((r.y >> 8) * u >= c.p) ? c.scale : 0.f;
+    m.z = ((r.z >> 8) * u >= c.p) ? c.scale : 0.f;
+    m.w = ((r.w >> 8) * u >= c.p) ? c.scale : 0.f;
+    return m;
+}
+
+__device__ __forceinline__ float4 operator*(const float4& a, const float4& b) {
+    return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
+// Wave-level sum over 64 lanes (result in every lane).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v) {
+    if constexpr (ACT == CGS_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == CGS_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+    else if constexpr (ACT == CGS_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    else return v;
+}
+
+#define CGS_HIP_CHECK_LAUNCH()                         \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)

@@ -1,0 +1,301 @@
+// LDS-tiled, im2col-free direct 3x3 convolution machinery shared by the forward, data-gradient and
+// weight-gradient kernels.
+//
+// Mapping (all sizes compile-time):
+//   * one thread = one 2x2 quad of conv outputs, all output channels of the current chunk in registers
+//     (the quad is the pooling window of the encoder and the nearest-upsample cell of the decoder, so
+//     max-pool, argmax and upsample-backward sums never leave the thread);
+//   * one workgroup = THREADS quads = a full-width strip of TH rows of one image, or IMGS whole images
+//     when the image is small.  Full-width strips make the horizontal halo pure zero padding and the
+//     global range a strip reads one contiguous NHWC block (coalesced 16-byte loads);
+//   * source A (direct / skip input) is staged in LDS as float4 "planes" (4 channels per plane):
+//       ldsA[plane][img][row 0..TH+1][col 0..W+1 (+1 pad slot per 16 columns)]
+//     so a wave reads 64 x 16 B from distinct 16-byte slots;
+//   * source B (the nearest-upsampled low-resolution input of a decoder conv) is staged at ITS OWN
+//     resolution: a quad's 4x4 receptive field covers just 3x3 source pixels, the concat and the
+//     upsampled tensor are never materialised;
+//   * weights come from the constant address space (s_load -> SGPR operands of v_fmac_f32).
+#pragma once
+#include "cgs_common.h"
+
+enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4 };
+
+template <int H_, int W_, int THREADS_>
+struct Geo {
+    static constexpr int H = H_, W = W_, THREADS = THREADS_;
+    static constexpr int QW = W / 2, QH = H / 2, Q = QW * QH;
+    static constexpr int IMGS = (Q >= THREADS) ? 1 : THREADS / Q;
+    static constexpr int RQ = (Q >= THREADS) ? THREADS / QW : QH;  // quad rows per workgroup
+    static constexpr int TH = 2 * RQ;                               // conv rows per workgroup
+    static constexpr int STRIPS = QH / RQ;
+    static constexpr int TRA = TH + 2;                              // rows of the source-A tile
+    static constexpr int PWA = (W + 1) + ((W + 1) >> 4) + 1;        // padded row length (slots)
+    static constexpr int TRB = RQ + 2, PWB = QW + 2;                // source-B tile (half resolution)
+    static_assert(THREADS % 64 == 0 && (Q >= THREADS ? (THREADS % QW == 0) : (THREADS % Q == 0)), "geometry");
+    __device__ static __forceinline__ int pc(int c) { return c + (c >> 4); }
+};
+
+struct QuadPos {
+    int img_l, qy_l, qx;  // image within workgroup, quad row within strip, quad column
+    int n, row0;          // global image index, first conv row of the strip
+};
+
+template <class G>
+__device__ __forceinline__ QuadPos quad_pos(int tid, int bid) {
+    QuadPos q;
+    constexpr int PER_IMG = G::RQ * G::QW;
+    q.img_l = tid / PER_IMG;
+    int r = tid % PER_IMG;
+    q.qy_l = r / G::QW;
+    q.qx = r % G::QW;
+    if constexpr (G::IMGS == 1) {
+        q.n = bid / G::STRIPS;
+        q.row0 = (bid % G::STRIPS) * G::TH;
+    } else {
+        q.n = bid * G::IMGS + q.img_l;
+        q.row0 = 0;
+    }
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loaders.  n0 = first image of the workgroup, row0 = first conv row.  All write float4 planes.
+// ------------------------------------------------------------------------------------------------
+template <class G, int PA>
+__device__ __forceinline__ int ldsA_idx(int p, int img, int r, int c) {
+    return ((p * G::IMGS + img) * G::TRA + r) * G::PWA + G::pc(c);
+}
+
+template <class G, int PA>
+__device__ __forceinline__ void zero_halo_cols(float4* ldsA, int tid) {
+    constexpr int E = PA * G::IMGS * G::TRA * 2;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int side = e & 1, rest = e >> 1;
+        int r = rest % G::TRA, pi = rest / G::TRA;  // pi = p*IMGS + img
+        ldsA[(pi * G::TRA + r) * G::PWA + G::pc(side ? G::W + 1 : 0)] = f4zero();
+    }
+}
+
+// NHWC fp32 source with CA = 4*PA channels (optionally with dropout fused).
+template <class G, int PA>
+__device__ __forceinline__ void load_a_f32(float4* ldsA, const float4* __restrict__ src, int n0, int row0,
+                                           int N, int tid, const DropCtx& dc) {
+    constexpr int E = G::IMGS * G::TRA * G::W * PA;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int p = e % PA, x = (e / PA) % G::W, r = (e / (PA * G::W)) % G::TRA, img = e / (PA * G::W * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        float4 v = f4zero();
+        if (n < N && y >= 0 && y < G::H) {
+            int gi = ((n * G::H + y) * G::W + x) * PA + p;
+            v = src[gi];
+            if (dc.on) v = v * drop_mult4(dc, (uint32_t)gi);
+        }
+        ldsA[ldsA_idx<G, PA>(p, img, r, x + 1)] = v;
+    }
+    zero_halo_cols<G, PA>(ldsA, tid);
+}
+
+// NHWC uint8 RGB source, /255 fused.  One thread converts 4 pixels (12 bytes = 3 dwords).
+template <class G>
+__device__ __forceinline__ void load_a_u8c3(float4* ldsA, const uint32_t* __restrict__ src, int n0, int row0,
+                                            int N, int tid) {
+    constexpr int GW = G::W / 4;
+    constexpr int E = G::IMGS * G::TRA * GW;
+    const float s = 1.f / 255.f;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        uint32_t d0 = 0, d1 = 0, d2 = 0;
+        if (n < N && y >= 0 && y < G::H) {
+            int gi = ((n * G::H + y) * G::W + g * 4) * 3 / 4;  // dword index (12 B per 4 pixels)
+            d0 = src[gi]; d1 = src[gi + 1]; d2 = src[gi + 2];
+        }
+        float4 p0 = make_float4((d0 & 255) * s, ((d0 >> 8) & 255) * s, ((d0 >> 16) & 255) * s, 0.f);
+        float4 p1 = make_float4((d0 >> 24) * s, (d1 & 255) * s, ((d1 >> 8) & 255) * s, 0.f);
+        float4 p2 = make_float4(((d1 >> 16) & 255) * s, (d1 >> 24) * s, (d2 & 255) * s, 0.f);
+        float4 p3 = make_float4(((d2 >> 8) & 255) * s, ((d2 >> 16) & 255) * s, (d2 >> 24) * s, 0.f);
+        int base = (img * G::TRA + r) * G::PWA;
+        ldsA[base + G::pc(g * 4 + 1)] = p0;
+        ldsA[base + G::pc(g * 4 + 2)] = p1;
+        ldsA[base + G::pc(g * 4 + 3)] = p2;
+        ldsA[base + G::pc(g * 4 + 4)] = p3;
+    }
+    zero_halo_cols<G, 1>(ldsA, tid);
+}
+
+// NHWC fp32 3-channel source (the replaced / injected mixes).  4 pixels = 3 float4.
+template <class G>
+__device__ __forceinline__ void load_a_f32c3(float4* ldsA, const float4* __restrict__ src, int n0, int row0,
+                                             int N, int tid) {
+    constexpr int GW = G::W / 4;
+    constexpr int E = G::IMGS * G::TRA * GW;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        float4 a = f4zero(), b = f4zero(), c = f4zero();
+        if (n < N && y >= 0 && y < G::H) {
+            int gi = ((n * G::H + y) * G::W + g * 4) * 3 / 4;
+            a = src[gi]; b = src[gi + 1]; c = src[gi + 2];
+        }
+        int base = (img * G::TRA + r) * G::PWA;
+        ldsA[base + G::pc(g * 4 + 1)] = make_float4(a.x, a.y, a.z, 0.f);
+        ldsA[base + G::pc(g * 4 + 2)] = make_float4(a.w, b.x, b.y, 0.f);
+        ldsA[base + G::pc(g * 4 + 3)] = make_float4(b.z, b.w, c.x, 0.f);
+        ldsA[base + G::pc(g * 4 + 4)] = make_float4(c.y, c.z, c.w, 0.f);
+    }
+    zero_halo_cols<G, 1>(ldsA, tid);
+}
+
+__device__ __forceinline__ float4 nib_select(const float4& v, uint32_t nib16, uint32_t pos) {
+    float4 o;
+    o.x = ((nib16 & 15u) == pos) ? v.x : 0.f;
+    o.y = (((nib16 >> 4) & 15u) == pos) ? v.y : 0.f;
+    o.z = (((nib16 >> 8) & 15u) == pos) ? v.z : 0.f;
+    o.w = (((nib16 >> 12) & 15u) == pos) ? v.w : 0.f;
+    return o;
+}
+
+// Gradient of a conv+ReLU+maxpool stage, re-expanded to pre-pool resolution on the fly:
+// tile(y,x,c) = dpooled(y/2,x/2,c) if amask nibble == 2*(y&1)+(x&1) else 0   (0xF nibble = ReLU dead).
+// HALO = 1: rows row0-1 .. row0+TH (data-gradient tile); HALO = 0: rows row0 .. row0+TH-1 into a tile with
+// TR rows and row length PW (caller-specified geometry through the index functor).
+template <class G, int PA, int HALO, class IdxF>
+__device__ __forceinline__ void load_poolexp(float4* lds, const float4* __restrict__ dp,
+                                             const uint32_t* __restrict__ am, int n0, int row0, int N,
+                                             int tid, IdxF idx) {
+    constexpr int HP = G::H / 2, WP = G::W / 2;
+    constexpr int JR = G::RQ + 2 * HALO;  // pooled rows touched
+    constexpr int E = G::IMGS * JR * WP * PA;
+    constexpr int AMW = (PA + 1) / 2;     // amask words per pooled pixel
+    const int pr0 = row0 / 2 - HALO;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int p = e % PA, px = (e / PA) % WP, j = (e / (PA * WP)) % JR, img = e / (PA * WP * JR);
+        int n = n0 + img, pr = pr0 + j;
+        float4 v = f4zero();
+        uint32_t nib = 0xFFFFu;
+        if (n < N && pr >= 0 && pr < HP) {
+            int pi = (n * HP + pr) * WP + px;
+            v = dp[pi * PA + p];
+            nib = (am[pi * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu;
+        }
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            int r = 2 * j + (pos >> 1) - HALO;  // row inside the tile
+            if (r >= 0 && r < G::TH + 2 * HALO) lds[idx(p, img, r, 2 * px + (pos & 1))] = nib_select(v, nib, pos);
+        }
+    }
+}
+
+// Source B at its own (half) resolution with a 1-pixel zero halo: rows sy0-1 .. sy0+RQ, cols -1 .. QW.
+template <class G, int PB>
+__device__ __forceinline__ void load_b_half(float4* ldsB, const float4* __restrict__ src, int n0, int row0,
+                                            int N, int tid) {
+    constexpr int E = G::IMGS * G::TRB * G::PWB * PB;
+    const int sy0 = row0 / 2;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int p = e % PB, c = (e / PB) % G::PWB, r = (e / (PB * G::PWB)) % G::TRB, img = e / (PB * G::PWB * G::TRB);
+        int n = n0 + img, sy = sy0 + r - 1, sx = c - 1;
+        float4 v = f4zero();
+        if (n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW) v = src[((n * G::QH + sy) * G::QW + sx) * PB + p];
+        ldsB[((p * G::IMGS + img) * G::TRB + r) * G::PWB + c] = v;
+    }
+}
+
+// Source B that is a single pixel per image (the bottleneck, upsampled x4 to the 4x4 map).
+template <class G, int PB>
+__device__ __forceinline__ void load_b_pix(float4* ldsB, const float4* __restrict__ src, int n0, int N, int tid) {
+    constexpr int E = G::IMGS * PB;
+    for (int e = tid; e < E; e += G::THREADS) {
+        int p = e % PB, img = e / PB;
+        int n = n0 + img;
+        ldsB[p * G::IMGS + img] = (n < N) ? src[n * PB + p] : f4zero();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Compute core: accumulate one float4 plane (4 input channels) of a 4x4 receptive field into the
+// 2x2 x OCB accumulator block.  WF(tap, ci, oc) returns the (wave-uniform) weight.
+// ------------------------------------------------------------------------------------------------
+template <int OCB, int NCH, class WF>
+__device__ __forceinline__ void fma_plane(float (&acc)[4][OCB], const float4 (&pt)[4][4], WF wf, int ci0, int oc0) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float wv[OCB];
+#pragma unroll
+                for (int o = 0; o < OCB; ++o) wv[o] = wf(ky * 3 + kx, ci0 + c, oc0 + o);
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        float x = f4get(pt[oy + ky][ox + kx], c);
+#pragma unroll
+                        for (int o = 0; o < OCB; ++o) acc[oy * 2 + ox][o] = fmaf(x, wv[o], acc[oy * 2 + ox][o]);
+                    }
+                // keep the scheduler from hoisting every tap's s_loads to the top (SGPR spills)
+                if (c == NCH - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+}
+
+template <int OCB, class WF>
+__device__ __forceinline__ void fma_scalar(float (&acc)[4][OCB], const float (&pt)[4][4], WF wf, int oc0) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float wv[OCB];
+#pragma unroll
+            for (int o = 0; o < OCB; ++o) wv[o] = wf(ky * 3 + kx, 0, oc0 + o);
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                for (int ox = 0; ox < 2; ++ox) {
+                    float x = pt[oy + ky][ox + kx];
+#pragma unroll
+                    for (int o = 0; o < OCB; ++o) acc[oy * 2 + ox][o] = fmaf(x, wv[o], acc[oy * 2 + ox][o]);
+                }
+        }
+}
+
+// Read the 4x4 receptive field of a quad from a source-A plane.
+template <class G>
+__device__ __forceinline__ void read_patch_a(float4 (&pt)[4][4], const float4* ldsA, int plane, const QuadPos& q,
+                                             const int (&pcx)[4]) {
+    int base = ((plane * G::IMGS + q.img_l) * G::TRA + 2 * q.qy_l) * G::PWA;
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) pt[dy][dx] = ldsA[base + dy * G::PWA + pcx[dx]];
+}
+
+// Receptive field of a quad in a nearest-upsampled source: 3x3 source pixels, patch rows/cols {0,1,1,2}.
+template <class G>
+__device__ __forceinline__ void read_patch_b2(float4 (&pt)[4][4], const float4* ldsB, int plane, const QuadPos& q) {
+    float4 s[3][3];
+    int base = ((plane * G::IMGS + q.img_l) * G::TRB + q.qy_l) * G::PWB + q.qx;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s[j][i] = ldsB[base + j * G::PWB + i];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) pt[dy][dx] = s[(dy + 1) >> 1][(dx + 1) >> 1];
+}
+
+// x4 upsampling of a 1x1 source to the 4x4 map: every in-image position sees the same pixel.
+template <class G>
+__device__ __forceinline__ void read_patch_b4(float4 (&pt)[4][4], const float4* ldsB, int plane, const QuadPos& q) {
+    float4 s = ldsB[plane * G::IMGS + q.img_l];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            int y = 2 * q.qy_l + dy - 1, x = 2 * q.qx + dx - 1;
+            bool in = (y >= 0) && (y < G::H) && (x >= 0) && (x < G::W);
+            pt[dy][dx] = in ? s : f4zero();
+        }
+}

@@ -1,0 +1,285 @@
+// Weight/bias gradients of the 3x3 convolutions as an implicit GEMM on the matrix cores.
+//
+//   dW[r][co] = sum_pixels  Xcol[pixel][r] * dY[pixel][co],   r = tap*CI + ci  (+ one all-ones row = dbias)
+//
+// is a true GEMM whose reduction dimension is the pixel index (millions), so it runs on
+// v_mfma_f32_16x16x4_f32 (exact fp32, k-ordered fma chain): 16 rows of r x 16 output channels per
+// instruction, 4 pixels per k-step, accumulators stay in 4 VGPRs per 16x16 block for the whole launch --
+// no cross-lane reduction, no float atomics.  Each wave walks a disjoint set of pixels and finally writes
+// its own partial slab; cgs_reduce_slabs() adds the slabs in a fixed order (bitwise reproducible).
+//
+// LDS tiles keep the NHWC order of global memory: X tile [img][TH+2][W+2][CI] with the concat of the
+// skip input and the nearest-upsampled low-res input materialised (zero halo), dY tile [img][TH][W][CO].
+// Lanes (r = lane&15, pixel = lane>>4) then read consecutive floats: bank-conflict free.
+#include "conv_tile.h"
+
+typedef float frag4 __attribute__((ext_vector_type(4)));
+
+struct WgradParams {
+    const void* src_a;
+    const float* src_b;
+    const float* dy;
+    const uint32_t* amask;
+    float* slab;
+    int n, ntiles;
+    cgs_dropout drop;
+};
+
+template <int H_, int W_, int TH_, int IMGS_, int THREADS_>
+struct WGeo {
+    static constexpr int H = H_, W = W_, TH = TH_, IMGS = IMGS_, THREADS = THREADS_;
+    static constexpr int RQ = TH / 2, QW = W / 2, QH = H / 2;  // for load_poolexp
+    static constexpr int TRA = TH + 2, PWA = W + 2, STRIPS = H / TH;
+    static constexpr int NSTEP = IMGS * TH * W / 4, NW = THREADS / 64;
+    static_assert(IMGS == 1 || TH == H, "multi-image tiles hold whole images");
+    static_assert((TH * W) % 4 == 0 && H % TH == 0, "tile shape");
+};
+
+enum { WSRC_F32 = 0, WSRC_U8 = 1, WDY_F32 = 0, WDY_POOLEXP = 1 };
+
+// C: G (WGeo), SRC (WSRC_*), CA, CB, UPS, CO, DY (WDY_*)
+template <class C>
+__global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
+    using G = typename C::G;
+    constexpr int CI = C::CA + C::CB, CO = C::CO;
+    constexpr int ROWS = 9 * CI + 1, NRB = (ROWS + 15) / 16;
+    constexpr int XT = G::IMGS * G::TRA * G::PWA * CI;  // floats
+    constexpr int YT = G::IMGS * G::TH * G::W * CO;
+    static_assert(CO <= 16 && CO % 4 == 0, "one 16-wide column block");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float* xt = (float*)smem;
+    float* yt = xt + ((XT + 3) / 4) * 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int N = P.n;
+    const DropCtx dc = drop_ctx(P.drop);
+
+    int rbase[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) {
+        int r = rb * 16 + l15;
+        if (r < 9 * CI) {
+            int tap = r / CI, ci = r % CI;
+            rbase[rb] = ((tap / 3) * G::PWA + (tap % 3)) * CI + ci;
+        } else {
+            rbase[rb] = (r == 9 * CI) ? -1 : -2;
+        }
+    }
+    frag4 acc[NRB];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) acc[rb] = frag4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n0 = (G::IMGS == 1) ? tile / G::STRIPS : tile * G::IMGS;
+        const int row0 = (G::IMGS == 1) ? (tile % G::STRIPS) * G::TH : 0;
+        // ---- X tile: concat(source A, upsampled source B) with zero halo ----
+        for (int e = tid; e < XT; e += G::THREADS) {
+            int ci = e % CI, c = (e / CI) % G::PWA, r = (e / (CI * G::PWA)) % G::TRA, img = e / (CI * G::PWA * G::TRA);
+            int n = n0 + img, y = row0 + r - 1, x = c - 1;
+            float v = 0.f;
+            if (n < N && y >= 0 && y < G::H && x >= 0 && x < G::W) {
+                if (ci < C::CA) {
+                    int gi = ((n * G::H + y) * G::W + x) * C::CA + ci;
+                    if constexpr (C::SRC == WSRC_U8) {
+                        v = ((const uint8_t*)P.src_a)[gi] * (1.f / 255.f);
+                    } else {
+                        v = ((const float*)P.src_a)[gi];
+                        if (dc.on) v *= f4get(drop_mult4(dc, (uint32_t)(gi >> 2)), gi & 3);
+                    }
+                } else if constexpr (C::CB > 0) {
+                    int cb = ci - C::CA;
+                    if constexpr (C::UPS == 2) v = P.src_b[((n * G::QH + (y >> 1)) * G::QW + (x >> 1)) * C::CB + cb];
+                    else v = P.src_b[n * C::CB + cb];
+                }
+            }
+            xt[e] = v;
+        }
+        // ---- dY tile ----
+        if constexpr (C::DY == WDY_F32) {
+            constexpr int E4 = YT / 4;
+            const float4* src = (const float4*)P.dy;
+            for (int e = tid; e < E4; e += G::THREADS) {
+                int img = e / (G::TH * G::W * CO / 4), rest = e % (G::TH * G::W * CO / 4);
+                int n = n0 + img;
+                float4 v = f4zero();
+                if (n < N) v = src[((size_t)(n * G::H + row0) * G::W * CO) / 4 + rest];
+                ((float4*)yt)[e] = v;
+            }
+        } else {
+            load_poolexp<G, CO / 4, 0>((float4*)yt, (const float4*)P.dy, P.amask, n0, row0, N, tid,
+                                       [](int p, int img, int r, int x) { return ((img * G::TH + r) * G::W + x) * (CO / 4) + p; });
+        }
+        __syncthreads();
+
+        for (int step = wave; step < G::NSTEP; step += G::NW) {
+            int p = step * 4 + kq;
+            int x = p % G::W, yl = (p / G::W) % G::TH, img = p / (G::W * G::TH);
+            int pixoff = ((img * G::TRA + yl) * G::PWA + x) * CI;
+            float b = (l15 < CO) ? yt[((img * G::TH + yl) * G::W + x) * CO + l15] : 0.f;
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) {
+                float a = (rbase[rb] >= 0) ? xt[rbase[rb] + pixoff] : (rbase[rb] == -1 ? 1.f : 0.f);
+                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // D layout: col = lane & 15 (= co), row = (lane >> 4) * 4 + reg (= r within the row block)
+    float* slab = P.slab + (size_t)(blockIdx.x * G::NW + wave) * (ROWS * CO);
+    if (l15 < CO) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int r = rb * 16 + kq * 4 + j;
+                if (r < ROWS) slab[r * CO + l15] = acc[rb][j];
+            }
+    }
+}
+
+// masker.2 (16 -> 1): a single output channel would waste 15/16 of the MFMA columns, so the product is
+// re-associated:  dW[tap][ci] = sum_{p'} X[p'][ci] * dY[p' - tapoffset]   (rows = ci, columns = tap).
+template <class G>
+__global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
+    constexpr int CI = 16;
+    constexpr int XT = G::TRA * G::PWA * CI, YT = G::TH * G::W;
+    constexpr int NSTEP = G::TRA * G::PWA / 4;
+    static_assert(G::IMGS == 1 && (G::TRA * G::PWA) % 4 == 0, "co1 tile");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float* xt = (float*)smem;
+    float* yt = xt + XT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int ky = l15 / 3, kx = l15 % 3;
+    frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n = tile / G::STRIPS, row0 = (tile % G::STRIPS) * G::TH;
+        for (int e = tid; e < XT / 4; e += G::THREADS) {
+            int q4 = e % (CI / 4), c = (e / (CI / 4)) % G::PWA, r = e / ((CI / 4) * G::PWA);
+            int y = row0 + r - 1, x = c - 1;
+            float4 v = f4zero();
+            if (y >= 0 && y < G::H && x >= 0 && x < G::W) v = ((const float4*)P.src_a)[((n * G::H + y) * G::W + x) * (CI / 4) + q4];
+            ((float4*)xt)[e] = v;
+        }
+        for (int e = tid; e < YT / 4; e += G::THREADS)
+            ((float4*)yt)[e] = ((const float4*)P.dy)[((size_t)(n * G::H + row0) * G::W) / 4 + e];
+        __syncthreads();
+        for (int step = wave; step < NSTEP; step += G::NW) {
+            int p = step * 4 + kq;  // position in the haloed tile
+            int c = p % G::PWA, r = p / G::PWA;
+            float a = xt[p * CI + l15];
+            int yl = r - ky, x = c - kx;
+            float b = (l15 < 9 && yl >= 0 && yl < G::TH && x >= 0 && x < G::W) ? yt[yl * G::W + x] : 0.f;
+            if (l15 == 4) bsum += b;  // centre tap sees every dY of the tile exactly once
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* slab = P.slab + (size_t)(blockIdx.x * G::NW + wave) * (9 * CI + 1);
+    if (l15 < 9) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slab[l15 * CI + kq * 4 + j] = acc[j];  // row = ci, col = tap
+    }
+    bsum = (l15 == 4) ? bsum : 0.f;
+    bsum = wave_sum(bsum);
+    if (lane == 0) slab[9 * CI] = bsum;
+}
+
+#define CGS_WG_CFG(NAME, HW, TH_, IMGS_, SRC_, CA_, CB_, UPS_, CO_, DY_)      \
+    struct NAME {                                                             \
+        using G = WGeo<HW, HW, TH_, IMGS_, 256>;                              \
+        static constexpr int SRC = SRC_, CA = CA_, CB = CB_, UPS = UPS_, CO = CO_, DY = DY_; \
+    };
+
+CGS_WG_CFG(WEnc0U8, 64, 16, 1, WSRC_U8, 3, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc0F32, 64, 16, 1, WSRC_F32, 3, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc1, 32, 16, 1, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc2, 16, 16, 2, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc3, 8, 8, 8, WSRC_F32, 8, 0, 2, 16, WDY_POOLEXP)
+CGS_WG_CFG(WDec3, 4, 4, 4, WSRC_F32, 16, 32, 4, 16, WDY_F32)
+CGS_WG_CFG(WDec2, 8, 8, 4, WSRC_F32, 8, 16, 2, 8, WDY_F32)
+CGS_WG_CFG(WDec1, 16, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
+CGS_WG_CFG(WDec0, 32, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
+CGS_WG_CFG(WMask0U8, 64, 8, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
+CGS_WG_CFG(WMask0F32, 64, 8, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
+using WMask2G = WGeo<64, 64, 8, 1, 256>;
+
+static constexpr int kMaxWgradBlocks = 256;
+
+template <class G>
+static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMGS - 1) / G::IMGS; }
+template <class G>
+static int wg_blocks(int n) { int t = wg_tiles<G>(n); return t < kMaxWgradBlocks ? t : kMaxWgradBlocks; }
+
+template <class C>
+static int launch_wgrad(WgradParams P, hipStream_t st) {
+    using G = typename C::G;
+    constexpr int CI = C::CA + C::CB;
+    size_t lds = ((size_t)((G::IMGS * G::TRA * G::PWA * CI + 3) / 4) * 4 + (size_t)G::IMGS * G::TH * G::W * C::CO) * sizeof(float);
+    P.ntiles = wg_tiles<G>(P.n);
+    if (P.ntiles == 0) return CGS_OK;
+    hipLaunchKernelGGL(wgrad_kernel<C>, dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+static bool wdesc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int src, int ups, int pool) {
+    return d->h == hw && d->w == hw && d->ca == ca && d->cb == cb && d->co == co && d->src_a == src &&
+           (cb == 0 || d->ups == ups) && d->pool == pool;
+}
+
+// returns slabs for the descriptor, or an error code
+extern "C" int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d) {
+    if (!d || d->n < 0) return CGS_ERR_BADARG;
+    const int n = d->n;
+#define SLABS(CFG) return wg_blocks<typename CFG::G>(n) * CFG::G::NW
+    if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, 1)) SLABS(WEnc0U8);
+    if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc0F32);
+    if (wdesc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc1);
+    if (wdesc_is(d, 16, 8, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc2);
+    if (wdesc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, 1)) SLABS(WEnc3);
+    if (wdesc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, 0)) SLABS(WDec3);
+    if (wdesc_is(d, 8, 8, 16, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec2);
+    if (wdesc_is(d, 16, 8, 8, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec1);
+    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec0);
+    if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, 0)) SLABS(WMask0U8);
+    if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) SLABS(WMask0F32);
+    if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) return wg_blocks<WMask2G>(n) * WMask2G::NW;
+#undef SLABS
+    return CGS_ERR_UNSUPPORTED;
+}
+
+extern "C" int cgs_conv3x3_bwd_weight(const cgs_conv_desc* d, const void* src_a, const float* src_b, const float* dy,
+                                      const uint32_t* amask, float* slab, cgs_stream_t stream) {
+    if (!d || !src_a || !dy || !slab || d->n < 0) return CGS_ERR_BADARG;
+    if (d->cb > 0 && !src_b) return CGS_ERR_BADARG;
+    if (d->pool && !amask) return CGS_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    WgradParams P{};
+    P.src_a = src_a; P.src_b = src_b; P.dy = dy; P.amask = amask; P.slab = slab; P.n = d->n; P.drop = d->drop_a;
+    if (d->drop_a.p > 0.f && !wdesc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, 1)) return CGS_ERR_UNSUPPORTED;
+    if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, 1)) return launch_wgrad<WEnc0U8>(P, st);
+    if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_F32, 2, 1)) return launch_wgrad<WEnc0F32>(P, st);
+    if (wdesc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, 1)) return launch_wgrad<WEnc1>(P, st);
+    if (wdesc_is(d, 16, 8, 0, 8, CGS_SRC_F32, 2, 1)) return launch_wgrad<WEnc2>(P, st);
+    if (wdesc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, 1)) return launch_wgrad<WEnc3>(P, st);
+    if (wdesc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, 0)) return launch_wgrad<WDec3>(P, st);
+    if (wdesc_is(d, 8, 8, 16, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec2>(P, st);
+    if (wdesc_is(d, 16, 8, 8, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec1>(P, st);
+    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec0>(P, st);
+    if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, 0)) return launch_wgrad<WMask0U8>(P, st);
+    if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) return launch_wgrad<WMask0F32>(P, st);
+    if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) {
+        using G = WMask2G;
+        size_t lds = ((size_t)G::TRA * G::PWA * 16 + (size_t)G::TH * G::W) * sizeof(float);
+        P.ntiles = wg_tiles<G>(P.n);
+        if (P.ntiles == 0) return CGS_OK;
+        hipLaunchKernelGGL(wgrad_co1_kernel<G>, dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
+    return CGS_ERR_UNSUPPORTED;
+}

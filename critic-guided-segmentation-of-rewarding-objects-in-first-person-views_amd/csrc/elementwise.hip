@@ -1,0 +1,312 @@
+// Memory-bound glue of the training step: mask replace/inject mix (main.py:395,406) and its backward
+// with the mask regularisers fused, the four losses, slab reduction (+ per-iteration tick), flat Adam,
+// NCHW<->NHWC boundary conversion and the dropout-mask test hook.
+#include "cgs_common.h"
+
+__device__ __forceinline__ void unpack12(uint32_t d0, uint32_t d1, uint32_t d2, float (&v)[12]) {
+    const float s = 1.f / 255.f;
+    v[0] = (d0 & 255) * s; v[1] = ((d0 >> 8) & 255) * s; v[2] = ((d0 >> 16) & 255) * s; v[3] = (d0 >> 24) * s;
+    v[4] = (d1 & 255) * s; v[5] = ((d1 >> 8) & 255) * s; v[6] = ((d1 >> 16) & 255) * s; v[7] = (d1 >> 24) * s;
+    v[8] = (d2 & 255) * s; v[9] = ((d2 >> 8) & 255) * s; v[10] = ((d2 >> 16) & 255) * s; v[11] = (d2 >> 24) * s;
+}
+
+// one thread = 4 pixels (12 bytes of A and of B, one float4 of Z, 3 float4 of each mix)
+__global__ void __launch_bounds__(256) mix_fwd_kernel(int groups, int rep_groups, const uint32_t* __restrict__ a,
+                                                      const uint32_t* __restrict__ b, const float4* __restrict__ z,
+                                                      int inject, float4* __restrict__ mixed, float* __restrict__ zsum) {
+    int g = blockIdx.x * 256 + threadIdx.x;
+    float s1 = 0.f, s2 = 0.f;
+    if (g < groups) {
+        float av[12], bv[12];
+        unpack12(a[3 * g], a[3 * g + 1], a[3 * g + 2], av);
+        unpack12(b[3 * g], b[3 * g + 1], b[3 * g + 2], bv);
+        float4 zz = z[g];
+        float zv[4] = {zz.x, zz.y, zz.z, zz.w};
+        float r[12], q[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            float zi = zv[i / 3];
+            r[i] = av[i] * (1.f - zi) + zi * bv[i];
+            q[i] = bv[i] * (1.f - zi) + zi * av[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mixed[3 * g + j] = make_float4(r[4 * j], r[4 * j + 1], r[4 * j + 2], r[4 * j + 3]);
+        if (inject) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                mixed[3 * (rep_groups + g) + j] = make_float4(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1 += fabsf(zv[i]); s2 += zv[i] * zv[i]; }
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&zsum[0], s1);
+        atomicAdd(&zsum[1], s2);
+    }
+}
+
+__global__ void __launch_bounds__(256) mix_bwd_kernel(int groups, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                      const float4* __restrict__ z, const float4* __restrict__ dmixed,
+                                                      int inject, float l1s, float l2s, float4* __restrict__ dzpre) {
+    int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    float av[12], bv[12];
+    unpack12(a[3 * g], a[3 * g + 1], a[3 * g + 2], av);
+    unpack12(b[3 * g], b[3 * g + 1], b[3 * g + 2], bv);
+    float dr[12], di[12];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float4 v = dmixed[3 * g + j];
+        dr[4 * j] = v.x; dr[4 * j + 1] = v.y; dr[4 * j + 2] = v.z; dr[4 * j + 3] = v.w;
+    }
+    if (inject) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float4 v = dmixed[3 * (groups + g) + j];
+            di[4 * j] = v.x; di[4 * j + 1] = v.y; di[4 * j + 2] = v.z; di[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) di[i] = 0.f;
+    }
+    float4 zz = z[g];
+    float zv[4] = {zz.x, zz.y, zz.z, zz.w}, o[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d = fmaf(bv[3 * p + c] - av[3 * p + c], dr[3 * p + c] - di[3 * p + c], d);
+        float zi = zv[p];
+        float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
+        d += l1s * sg + 2.f * l2s * zi;
+        o[p] = d * zi * (1.f - zi);
+    }
+    dzpre[g] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// single workgroup; pred slots [B | A | replaced | injected]
+__global__ void __launch_bounds__(256) phase2_losses_kernel(int n, const float* __restrict__ pred, const float* __restrict__ y,
+                                                            const float* __restrict__ zsum, float lfak, float l1, float l2,
+                                                            int flags, float inv_nz, float* __restrict__ losses,
+                                                            float* __restrict__ dpred) {
+    __shared__ float red[3][4];
+    const bool live = flags & 1, inject = flags & 2, bce = flags & 4;
+    const float inv_n = 1.f / (float)n;
+    float sc = 0.f, sr = 0.f, si = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float pb = pred[i], pa = pred[n + i], pr = pred[2 * n + i], pi = inject ? pred[3 * n + i] : 0.f;
+        float yi = y[i];
+        float da = 0.f;
+        if (live) {
+            if (bce) {
+                float lp = fmaxf(logf(pa), -100.f), lq = fmaxf(logf(1.f - pa), -100.f);
+                sc += -(yi * lp + (1.f - yi) * lq);
+                da = lfak * (pa - yi) / fmaxf((1.f - pa) * pa, 1e-12f) * inv_n;
+            } else {
+                float d = pa - yi;
+                sc += d * d;
+                da = lfak * 2.f * d * inv_n;
+            }
+        }
+        float drp = pr - pb;
+        sr += drp * drp;
+        dpred[i] = 0.f;
+        dpred[n + i] = da;
+        dpred[2 * n + i] = 2.f * drp * inv_n;
+        if (inject) {
+            float dip = pi - pa;
+            si += dip * dip;
+            dpred[3 * n + i] = 2.f * dip * inv_n;
+        }
+    }
+    sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sc; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = si; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float c = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_n;
+        float r = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_n;
+        float i = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) * inv_n;
+        float n1 = l1 * zsum[0] * inv_nz, n2 = l2 * zsum[1] * inv_nz;
+        losses[0] = c; losses[1] = r; losses[2] = i; losses[3] = n1; losses[4] = n2;
+        losses[5] = (live ? lfak * c : 0.f) + r + i + n1 + n2;
+        losses[6] = 0.f; losses[7] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) phase1_loss_kernel(int n, const float* __restrict__ pred, const float* __restrict__ y,
+                                                          int bce, float* __restrict__ losses, float* __restrict__ dpred) {
+    __shared__ float red[4];
+    const float inv_n = 1.f / (float)n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float p = pred[i], yi = y[i];
+        if (bce) {
+            float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.f - p), -100.f);
+            s += -(yi * lp + (1.f - yi) * lq);
+            dpred[i] = (p - yi) / fmaxf((1.f - p) * p, 1e-12f) * inv_n;
+        } else {
+            float d = p - yi;
+            s += d * d;
+            dpred[i] = 2.f * d * inv_n;
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) losses[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n;
+}
+
+// grid = (ceil(max_count/256), njobs)
+__global__ void __launch_bounds__(256) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
+    const cgs_reduce_job j = jobs[blockIdx.y];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < j.count) {
+        const float* p = j.slab + i;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 4 <= j.nslab; b += 4) {
+            s0 += p[(size_t)b * j.stride];
+            s1 += p[(size_t)(b + 1) * j.stride];
+            s2 += p[(size_t)(b + 2) * j.stride];
+            s3 += p[(size_t)(b + 3) * j.stride];
+        }
+        for (; b < j.nslab; ++b) s0 += p[(size_t)b * j.stride];
+        float s = (s0 + s1) + (s2 + s3);
+        j.dst[i] = j.accumulate ? j.dst[i] + s : s;
+    }
+    if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(long count, float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const uint64_t* __restrict__ step, float lr, float b1, float b2, float eps) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const double t = (double)(*step);
+    const float c1 = (float)(1.0 - pow((double)b1, t));
+    const float c2s = (float)sqrt(1.0 - pow((double)b2, t));
+    float gi = g[i];
+    float mi = b1 * m[i] + (1.f - b1) * gi;
+    float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float denom = sqrtf(vi) / c2s + eps;
+    p[i] -= (lr / c1) * (mi / denom);
+}
+
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(long total, int c, int hw, const float* __restrict__ src, float* __restrict__ dst) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;  // index into dst (NHWC)
+    if (i >= total) return;
+    int ch = i % c;
+    long pix = i / c;
+    long n = pix / hw, s = pix % hw;
+    dst[i] = src[(n * c + ch) * hw + s];
+}
+
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(long total, int c, int hw, const float* __restrict__ src, float* __restrict__ dst) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;  // index into dst (NCHW)
+    if (i >= total) return;
+    long s = i % hw;
+    long nc = i / hw;
+    long n = nc / c;
+    int ch = nc % c;
+    dst[i] = src[(n * hw + s) * c + ch];
+}
+
+__global__ void __launch_bounds__(256) dropout_mask_kernel(long count4, cgs_dropout d, float4* __restrict__ out) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    DropCtx dc = drop_ctx(d);
+    out[i] = dc.on ? drop_mult4(dc, (uint32_t)i) : make_float4(1.f, 1.f, 1.f, 1.f);
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, int32_t inject,
+                           float* mixed, float* zsum, cgs_stream_t stream) {
+    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !mixed || !zsum) return CGS_ERR_BADARG;
+    int groups = n * (hw / 4);
+    if (groups == 0) return CGS_OK;
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, groups, groups,
+                       (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, inject, (float4*)mixed, zsum);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, const float* dmixed,
+                           int32_t inject, float l1_scale, float l2_scale, float* dzpre, cgs_stream_t stream) {
+    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !dmixed || !dzpre) return CGS_ERR_BADARG;
+    int groups = n * (hw / 4);
+    if (groups == 0) return CGS_OK;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, groups,
+                       (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, (const float4*)dmixed, inject, l1_scale,
+                       l2_scale, (float4*)dzpre);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zsum, float lfak, float l1,
+                                 float l2, int32_t flags, int64_t nz, float* losses, float* dpred, cgs_stream_t stream) {
+    if (n <= 0 || nz <= 0 || !pred || !y || !zsum || !losses || !dpred) return CGS_ERR_BADARG;
+    hipLaunchKernelGGL(phase2_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, pred, y, zsum, lfak, l1, l2,
+                       flags, 1.f / (float)nz, losses, dpred);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int32_t bce, float* losses, float* dpred,
+                               cgs_stream_t stream) {
+    if (n <= 0 || !pred || !y || !losses || !dpred) return CGS_ERR_BADARG;
+    hipLaunchKernelGGL(phase1_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, pred, y, bce, losses, dpred);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step,
+                                cgs_stream_t stream) {
+    if (!jobs || njobs <= 0 || max_count <= 0) return CGS_ERR_BADARG;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_adam_flat(int64_t count, float* param, const float* grad, float* m, float* v, const uint64_t* step,
+                             float lr, float beta1, float beta2, float eps, cgs_stream_t stream) {
+    if (count < 0 || !param || !grad || !m || !v || !step) return CGS_ERR_BADARG;
+    if (count == 0) return CGS_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)count,
+                       param, grad, m, v, step, lr, beta1, beta2, eps);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_nchw_to_nhwc(int32_t n, int32_t c, int32_t hw, const float* src, float* dst, cgs_stream_t stream) {
+    if (n < 0 || c <= 0 || hw <= 0 || !src || !dst) return CGS_ERR_BADARG;
+    long total = (long)n * c * hw;
+    if (total == 0) return CGS_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total, c, hw, src, dst);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_nhwc_to_nchw(int32_t n, int32_t c, int32_t hw, const float* src, float* dst, cgs_stream_t stream) {
+    if (n < 0 || c <= 0 || hw <= 0 || !src || !dst) return CGS_ERR_BADARG;
+    long total = (long)n * c * hw;
+    if (total == 0) return CGS_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total, c, hw, src, dst);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stream) {
+    if (count < 0 || (count & 3) || !out) return CGS_ERR_BADARG;
+    if (count == 0) return CGS_OK;
+    long c4 = count / 4;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, c4, d, (float4*)out);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" const char* cgs_build_arch(void) { return "gfx950"; }
+extern "C" int cgs_abi_version(void) { return 1; }

@@ -1,0 +1,267 @@
+"""Kernel orchestration of the Hourglass on one MI355X: which libcgs_hip.so entry point runs for which
+reference op, in NHWC, over a flat kernel-layout parameter buffer.  PyTorch is used for device memory
+and the current stream only; every arithmetic step is a HIP kernel (no torch math on this path).
+
+Reference map:
+  critic_forward   NewCritic.forward            nets.py:197-212
+  masker_forward   UnetDecoder.forward          nets.py:494-523
+  *_backward       what loss.backward() does for those modules (main.py:198,462)
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .spec import (DEC_LAYERS, DROP_SITE_E2, DROP_SITE_E3, DROP_SITE_H1, ENC_LAYERS, Layout)
+
+_ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
+HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
+PW_SLAB = 32 * 32 + 32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t: torch.Tensor, dtype, what: str):
+    if not t.is_cuda:
+        raise _lib.CgsError(f"{what}: HIP kernels need a device tensor (got {t.device}); there is no CPU fallback")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise _lib.CgsError(f"{what}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+class DropState:
+    """Dropout configuration of a pass: probability, Philox seed and the device step counter."""
+
+    def __init__(self, p: float, seed: int, step: Optional[torch.Tensor]):
+        self.p, self.seed, self.step = float(p), int(seed), step
+
+    def desc(self, site: int, active: bool = True) -> _lib.Dropout:
+        if not active or self.p <= 0.0:
+            return _lib.Dropout(0.0, 0, 0, None)
+        return _lib.Dropout(self.p, site, self.seed, self.step.data_ptr())
+
+
+NO_DROP = DropState(0.0, 0, None)
+
+
+def conv_desc(n, hw, ca, cb, co, src_u8, ups, act, pool, drop: _lib.Dropout) -> _lib.ConvDesc:
+    return _lib.ConvDesc(n, hw, hw, ca, cb, co, _lib.SRC_U8 if src_u8 else _lib.SRC_F32, ups, _ACT[act], pool, drop)
+
+
+class SlabPlan:
+    """Collects (slab, destination) pairs of one backward pass; run() sums every slab into the flat
+    gradient buffer with ONE cgs_reduce_slabs launch (fixed order => bitwise reproducible)."""
+
+    def __init__(self):
+        self.jobs = []   # (slab tensor, nslab, count, dst offset)
+        self._table = None
+        self._keep = None
+
+    def add(self, slab: torch.Tensor, nslab: int, count: int, dst_off: int):
+        self.jobs.append((slab, nslab, count, dst_off))
+
+    def build(self, grad_flat: torch.Tensor, accumulate: bool = False):
+        arr = (_lib.ReduceJob * len(self.jobs))()
+        for i, (slab, nslab, count, off) in enumerate(self.jobs):
+            arr[i] = _lib.ReduceJob(slab.data_ptr(), grad_flat.data_ptr() + 4 * off, nslab, count, count, int(accumulate))
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        self._table = host.to(grad_flat.device)
+        self._keep = grad_flat
+        self._max = max(j[2] for j in self.jobs)
+        return self
+
+    def run(self, step: Optional[torch.Tensor] = None):
+        _lib.call("cgs_reduce_slabs", _p(self._table), len(self.jobs), self._max, _p(step), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# critic
+# ------------------------------------------------------------------------------------------------
+def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, drop: DropState = NO_DROP,
+                   out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """x: NHWC uint8 or NHWC fp32 [n,64,64,3].  Returns pooled embeds e0..e3 (pre-dropout), their argmax
+    masks am0..am3, e4 [n,32], h1 [n,32], pred [n].  ``out`` may hold preallocated views to fill."""
+    u8 = x.dtype == torch.uint8
+    _chk(x, torch.uint8 if u8 else torch.float32, "critic input")
+    dev = x.device
+    o = out if out is not None else {}
+    src = x
+    for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
+        e = o.get(f"e{i}")
+        if e is None:
+            e = o[f"e{i}"] = torch.empty((n, hw // 2, hw // 2, co), device=dev, dtype=torch.float32)
+        am = o.get(f"am{i}")
+        if am is None:
+            am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
+        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None))
+        _lib.call("cgs_conv3x3_fwd", C.byref(d), _p(src), None, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")),
+                  C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".bias")), _p(e), _p(am), _stream())
+        src = e
+    for k, shape in (("e4", (n, 32)), ("h1", (n, 32)), ("pred", (n,))):
+        if o.get(k) is None:
+            o[k] = torch.empty(shape, device=dev, dtype=torch.float32)
+    fp = flat.data_ptr()
+    _lib.call("cgs_head_fwd", n, _p(o["e3"]), C.c_void_p(fp + 4 * lay.off("features.14.weight")),
+              C.c_void_p(fp + 4 * lay.off("features.14.bias")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
+              C.c_void_p(fp + 4 * lay.off("crit.1.bias")), C.c_void_p(fp + 4 * lay.off("crit.4.weight")),
+              C.c_void_p(fp + 4 * lay.off("crit.4.bias")), drop.desc(DROP_SITE_E3), drop.desc(DROP_SITE_H1),
+              _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _stream())
+    return o
+
+
+def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, saved: Dict[str, torch.Tensor],
+                    dpred: torch.Tensor, plan: SlabPlan, drop: DropState = NO_DROP,
+                    d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
+                    dx: Optional[torch.Tensor] = None, dx_from: int = 0,
+                    ws: Optional[Dict[str, torch.Tensor]] = None) -> Optional[torch.Tensor]:
+    """Backward of critic_forward for images [0,n).  d_embeds = [dE0..dE4] gradients arriving at the embeds
+    from the decoder (valid for images < n_add; their buffers are reused as the running totals).
+    dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
+    Weight-gradient slabs are registered in ``plan`` (dst offsets = this module's flat layout)."""
+    u8 = x.dtype == torch.uint8
+    dev = x.device
+    fp = flat.data_ptr()
+    ws = ws if ws is not None else {}
+
+    def buf(name, shape, dtype=torch.float32):
+        t = ws.get(name)
+        if t is None:
+            t = ws[name] = torch.empty(shape, device=dev, dtype=dtype)
+        return t
+
+    has_add = d_embeds is not None and n_add > 0
+    lib = _lib.load()
+    # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
+    nsl = lib.cgs_head_bwd_slabs(n)
+    slab = buf("slab_head", (nsl, HEAD_SLAB))
+    d_cur = buf("de3", (n, 4, 4, 16))
+    _lib.call("cgs_head_bwd", n, _p(saved["e3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
+              _p(d_embeds[4]) if has_add else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
+              C.c_void_p(fp + 4 * lay.off("features.14.weight")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
+              C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3), drop.desc(DROP_SITE_H1),
+              _p(d_cur), _p(slab), _stream())
+    plan.add(slab, nsl, HEAD_SLAB, lay.off("features.14.weight"))
+    for i in (3, 2, 1, 0):
+        key, hw, ca, cb, co, ups, act, pool, site = ENC_LAYERS[i]
+        src = x if i == 0 else saved[f"e{i - 1}"]
+        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None))
+        nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+        if nsl < 0:
+            _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
+        cnt = 9 * ca * co + co
+        slab = buf(f"slab_enc{i}", (nsl, cnt))
+        _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
+        plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
+        if i > 0:   # d e{i-1} = conv_bwd * dropout mask + decoder skip gradient (fused epilogue)
+            nxt = buf(f"de{i - 1}", (n, hw, hw, ca))
+            _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(d_cur), _p(saved[f"am{i}"]), wptr, None, _lib.ACT_NONE,
+                      _p(d_embeds[i - 1]) if has_add else None, n_add if has_add else 0, _p(nxt), None, _stream())
+            d_cur = nxt
+        elif dx is not None and n - dx_from > 0:
+            m = n - dx_from
+            dd = conv_desc(m, hw, ca, cb, co, False, ups, act, pool, _lib.Dropout(0.0, 0, 0, None))
+            _lib.call("cgs_conv3x3_bwd_data", C.byref(dd), _p(d_cur[dx_from:]), _p(saved["am0"][dx_from:]), wptr, None,
+                      _lib.ACT_NONE, None, 0, _p(dx), None, _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# masker (decoder + mask head)
+# ------------------------------------------------------------------------------------------------
+def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
+                   out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    """x: NHWC uint8/fp32 image [n,64,64,3]; embeds = [e0,e1,e2,e3 (NHWC), e4 [n,32]].
+    Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64]."""
+    u8 = x.dtype == torch.uint8
+    dev = x.device
+    fp = flat.data_ptr()
+    o = out if out is not None else {}
+    if o.get("o4") is None:
+        o["o4"] = torch.empty((n, 32), device=dev, dtype=torch.float32)
+    _lib.call("cgs_pointwise_fwd", n, 32, 32, _p(embeds[4]), C.c_void_p(fp + 4 * lay.off("dec_model.4.weight")),
+              C.c_void_p(fp + 4 * lay.off("dec_model.4.bias")), _p(o["o4"]), _stream())
+    names = ("o3", "o2", "o1", "o0", "hm", "Z")
+    srcs_a = (embeds[3], embeds[2], embeds[1], embeds[0], x, None)
+    prev = o["o4"]
+    for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
+        shape = (n, hw, hw) if co == 1 else (n, hw, hw, co)
+        if o.get(name) is None:
+            o[name] = torch.empty(shape, device=dev, dtype=torch.float32)
+        a = sa if sa is not None else prev
+        b = prev if cb > 0 else None
+        d = conv_desc(n, hw, ca, cb, co, u8 and name == "hm", ups, act, pool, _lib.Dropout(0.0, 0, 0, None))
+        _lib.call("cgs_conv3x3_fwd", C.byref(d), _p(a), _p(b), C.c_void_p(fp + 4 * lay.off(key + ".weight")),
+                  C.c_void_p(fp + 4 * lay.off(key + ".bias")), _p(o[name]), None, _stream())
+        prev = o[name]
+    return o
+
+
+def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
+                    saved: Dict[str, torch.Tensor], dzpre: torch.Tensor, plan: SlabPlan,
+                    ws: Optional[Dict[str, torch.Tensor]] = None) -> List[torch.Tensor]:
+    """dzpre: gradient w.r.t. the mask head's PRE-sigmoid output [n,64,64].
+    Returns [dE0, dE1, dE2, dE3, dE4]: gradients w.r.t. the encoder embeds (skip connections)."""
+    u8 = x.dtype == torch.uint8
+    dev = x.device
+    fp = flat.data_ptr()
+    ws = ws if ws is not None else {}
+    lib = _lib.load()
+
+    def buf(name, shape):
+        t = ws.get(name)
+        if t is None:
+            t = ws[name] = torch.empty(shape, device=dev, dtype=torch.float32)
+        return t
+
+    nd = _lib.Dropout(0.0, 0, 0, None)
+    names = ("o3", "o2", "o1", "o0", "hm", "Z")
+    srcs_a = [embeds[3], embeds[2], embeds[1], embeds[0], x, saved["hm"]]
+    srcs_b = [saved["o4"], saved["o3"], saved["o2"], saved["o1"], saved["o0"], None]
+    d_embeds: List[Optional[torch.Tensor]] = [None] * 5
+    dy = dzpre
+    for li in (5, 4, 3, 2, 1, 0):
+        key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]
+        is_img = li == 4
+        d = conv_desc(n, hw, ca, cb, co, u8 and is_img, ups, act, pool, nd)
+        nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+        if nsl < 0:
+            _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
+        cnt = 9 * (ca + cb) * co + co
+        slab = buf(f"slab_dec{li}", (nsl, cnt))
+        _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
+        plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
+        if li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)
+            dhm = buf("dhm", (n, 64, 64, 16))
+            _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, _p(saved["hm"]), _lib.ACT_LRELU, None, 0,
+                      _p(dhm), None, _stream())
+            dy = dhm
+        elif li == 4:  # masker.0: only the upsampled decoder channels need a gradient
+            do0 = buf("do0", (n, 32, 32, 8))
+            _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, None, _lib.ACT_NONE, None, 0, None, _p(do0), _stream())
+            dy = do0
+        else:          # dec_model.{0,1,2,3}: skip gradient at full res + upsample-backward sum
+            ei = 3 - li
+            de = buf(f"dE{ei}", (n, hw, hw, ca))
+            shape_b = (n, 32) if ups == 4 else (n, hw // 2, hw // 2, cb)
+            db = buf(f"do{ei + 1}", shape_b)
+            _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, None, _lib.ACT_NONE, None, 0, _p(de), _p(db), _stream())
+            d_embeds[ei] = de
+            dy = db
+    # bottleneck 1x1 conv: dy = d o4 [n,32]
+    nsl = lib.cgs_pointwise_bwd_slabs(n)
+    slab = buf("slab_pw", (nsl, PW_SLAB))
+    de4 = buf("dE4", (n, 32))
+    _lib.call("cgs_pointwise_bwd", n, 32, 32, _p(embeds[4]), _p(dy), C.c_void_p(fp + 4 * lay.off("dec_model.4.weight")),
+              _p(de4), _p(slab), _stream())
+    plan.add(slab, nsl, PW_SLAB, lay.off("dec_model.4.weight"))
+    d_embeds[4] = de4
+    return d_embeds

@@ -1,0 +1,179 @@
+/*
+ * cgs_hip.h -- C ABI of libcgs_hip.so: the MI355X (gfx950) kernels behind the Hourglass
+ * (encoder + critic head + decoder/mask head) training and inference path.
+ *
+ * The reference (ndrwmlnk/critic-guided-segmentation-...) has no FFI/plugin boundary: its hot
+ * path is ordinary PyTorch module calls.  Each entry point below therefore names the reference
+ * lines whose ATen dispatches it replaces.  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked "host";
+ *   - the caller owns every buffer (inputs, outputs, saved-for-backward side buffers, slabs);
+ *     the library never allocates, frees or retains pointers across calls;
+ *   - every call enqueues on the given hipStream_t and never synchronises it (graph-capturable);
+ *   - return value: 0 = CGS_OK, CGS_ERR_* (< 0) for argument errors, a positive hipError_t otherwise.
+ *   - activations are NHWC fp32; images are NHWC uint8 or NHWC fp32 (3 channels);
+ *   - conv weights are HWIO fp32  w[ky][kx][ci][co]  (checkpoints stay OIHW; the host permutes);
+ *     input-channel order of a two-source conv is (source A channels, then source B channels),
+ *     i.e. the reference's torch.cat((skip, upsampled), 1) / torch.cat((X, upsampled), 1).
+ */
+#ifndef CGS_HIP_H
+#define CGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cgs_stream_t; /* hipStream_t */
+
+enum { CGS_OK = 0, CGS_ERR_UNSUPPORTED = -1, CGS_ERR_BADARG = -2 };
+enum { CGS_SRC_F32 = 0, CGS_SRC_U8 = 1 };
+enum { CGS_ACT_NONE = 0, CGS_ACT_RELU = 1, CGS_ACT_LRELU = 2, CGS_ACT_SIGMOID = 3 };
+
+/* Dropout on a tensor = Philox4x32-10 keep-mask keyed by (seed; element/4, site, *step).
+ * p == 0 disables it.  `step` points to a device-resident counter so that a captured graph
+ * draws fresh masks on every replay; forward and backward of one step read the same value. */
+typedef struct {
+    float p;
+    uint32_t site;
+    uint64_t seed;
+    const uint64_t* step; /* device; may be NULL when p == 0 */
+} cgs_dropout;
+
+/* One 3x3, stride-1, pad-1 convolution of the Hourglass (nets.py:170-183, 480-490). */
+typedef struct {
+    int32_t n;      /* images */
+    int32_t h, w;   /* conv output size before pooling (= size of source A) */
+    int32_t ca;     /* channels of source A (direct / skip input) */
+    int32_t cb;     /* channels of source B (nearest-upsampled low-res input); 0 = none */
+    int32_t co;     /* output channels */
+    int32_t src_a;  /* CGS_SRC_F32 | CGS_SRC_U8 (uint8 image, /255 fused into the loader) */
+    int32_t ups;    /* source B scale: 2 (source is h/2 x w/2) or 4 (source is 1x1, h = w = 4) */
+    int32_t act;    /* CGS_ACT_* applied after bias */
+    int32_t pool;   /* 1: fused 2x2/2 max-pool after the activation */
+    cgs_dropout drop_a; /* dropout applied to source A while loading (nets.py:179,183) */
+} cgs_conv_desc;
+
+/* ---- convolution forward ------------------------------------------------------------
+ * Replaces Conv2d + ReLU/LeakyReLU/Sigmoid + MaxPool2d + Upsample + cat + Dropout of
+ * NewCritic.forward (nets.py:197-205) and UnetDecoder.forward (nets.py:500-521).
+ *   out   : [n, h, w, co]  (pool=0)  or [n, h/2, w/2, co] (pool=1)
+ *   amask : pool=1 only, may be NULL.  uint32 [n, h/2, w/2, co/8]: one nibble per channel =
+ *           index (0..3, row-major in the 2x2 window, first maximum wins) of the pooled
+ *           element, or 0xF when the pooled value is <= 0 (ReLU gradient is zero there).   */
+int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const float* src_b,
+                    const float* w_hwio, const float* bias, float* out, uint32_t* amask,
+                    cgs_stream_t stream);
+
+/* ---- convolution backward, data -----------------------------------------------------
+ * Replaces the convolution_backward(input) + max_pool2d/threshold/upsample/cat/dropout backward
+ * nodes autograd builds for the layer (loss.backward(), main.py:198,462).
+ *   dy      : gradient w.r.t. the layer output: [n,h,w,co], or [n,h/2,w/2,co] + amask when pool=1
+ *             (the pre-pool gradient is re-expanded on the fly, ReLU mask included).
+ *   d_a     : [n,h,w,ca] gradient w.r.t. source A, or NULL to skip.  Fused epilogue:
+ *             d_a = conv_bwd * dropout_mask(drop_a) * act'(src_a_post) + addend
+ *               src_a_post/src_a_act: optional (may be NULL/NONE) post-activation values of source A
+ *               and the activation that produced them (LeakyReLU for masker.0 -> masker.2);
+ *               addend: optional [n_addend,h,w,ca] gradient already accumulated for source A (skip
+ *               connection), added for images < n_addend; may alias d_a.
+ *   d_b     : gradient w.r.t. source B at ITS resolution ([n,h/2,w/2,cb] or [n,cb] for ups=4), i.e. the
+ *             nearest-upsample backward (2x2 / 4x4 sum) is fused; NULL to skip.            */
+int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, const uint32_t* amask,
+                         const float* w_hwio, const float* src_a_post, int32_t src_a_act,
+                         const float* addend, int32_t n_addend, float* d_a, float* d_b,
+                         cgs_stream_t stream);
+
+/* ---- convolution backward, weights --------------------------------------------------
+ * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
+ *   slab[b][0 .. 9*(ca+cb)*co)  = partial dW (HWIO),  slab[b][9*(ca+cb)*co ..][co] = partial dbias
+ * and cgs_reduce_slabs() sums the slabs (deterministic, no float atomics).
+ * cgs_conv3x3_bwd_weight_slabs() returns the number of slabs the launch will write (>0) or an error. */
+int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d);
+int cgs_conv3x3_bwd_weight(const cgs_conv_desc* d, const void* src_a, const float* src_b,
+                           const float* dy, const uint32_t* amask, float* slab,
+                           cgs_stream_t stream);
+
+/* One reduction job: dst[i] (+)= sum_{b<nslab} slab[b*stride + i], i < count. */
+typedef struct {
+    const float* slab;
+    float* dst;
+    int32_t nslab, stride, count;
+    int32_t accumulate; /* 0: overwrite dst, 1: add to dst */
+} cgs_reduce_job;
+/* jobs: DEVICE array of njobs entries.  If step != NULL, *step is incremented by one (by one thread)
+ * -- this is the per-iteration tick that Adam and the dropout masks read. */
+int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count,
+                     uint64_t* step, cgs_stream_t stream);
+
+/* ---- critic head: 4x4 valid conv + Linear + Linear (nets.py:184-194) -----------------
+ *   e3     : [n,4,4,16] pooled embed (dropout `drop_in` fused into the load)
+ *   w4     : [256][32]  (k = (y*4+x)*16 + c, HWIO of features.14), b4 [32]
+ *   w1     : [32][32]   (k-major: crit.1.weight transposed), b1 [32];  w2 [32], b2 [1]
+ *   e4     : [n,32] post-ReLU bottleneck (embeds[4]);  h1 : [n,32] post-ReLU hidden (pre-dropout)
+ *   pred   : [n] sigmoid output.                                                            */
+int cgs_head_fwd(int32_t n, const float* e3, const float* w4, const float* b4, const float* w1,
+                 const float* b1, const float* w2, const float* b2, cgs_dropout drop_in,
+                 cgs_dropout drop_h, float* e4, float* h1, float* pred, cgs_stream_t stream);
+/* Backward of the head.  dpred [n]; d_e4_extra / d_e3_extra: optional [n_extra,32] / [n_extra,4,4,16]
+ * gradients arriving at e4 / e3 from the decoder (images < n_extra; d_e3_extra may alias d_e3).
+ * Writes d_e3 [n,4,4,16] = head gradient (dropout mask applied) + d_e3_extra, and one slab per
+ * workgroup: [w4 8192 | b4 32 | w1 1024 | b1 32 | w2 32 | b2 1] = 9313 floats.               */
+int cgs_head_bwd_slabs(int32_t n);
+int cgs_head_bwd(int32_t n, const float* e3, const float* e4, const float* h1, const float* pred,
+                 const float* dpred, const float* d_e4_extra, const float* d_e3_extra, int32_t n_extra,
+                 const float* w4,
+                 const float* w1, const float* w2, cgs_dropout drop_in, cgs_dropout drop_h,
+                 float* d_e3, float* slab, cgs_stream_t stream);
+
+/* ---- decoder 1x1 conv on the bottleneck (nets.py:484,501) --------------------------
+ *   y[n][o] = sum_k x[n][k] * w[k][o] + b[o],  32 -> 32 (MFMA v_mfma_f32_32x32x2_f32).      */
+int cgs_pointwise_fwd(int32_t n, int32_t ci, int32_t co, const float* x, const float* w,
+                      const float* b, float* y, cgs_stream_t stream);
+int cgs_pointwise_bwd_slabs(int32_t n);
+/* dx[n][k] = sum_o dy[n][o] w[k][o];  slab[b] = [dW ci*co | db co] partials. */
+int cgs_pointwise_bwd(int32_t n, int32_t ci, int32_t co, const float* x, const float* dy,
+                      const float* w, float* dx, float* slab, cgs_stream_t stream);
+
+/* ---- mask replace / inject mix (main.py:395,406) --------------------------------------
+ *   rep = A(1-Z) + Z B,  inj = B(1-Z) + Z A  with A,B uint8 NHWC (/255 fused), Z [n,64,64].
+ *   mixed : [2n,h,w,3] fp32 (rep images then inj images; inj skipped when inject == 0)
+ *   zsum  : device float[2], (sum |Z|, sum Z^2) ACCUMULATED (caller zeroes).                */
+int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z,
+                int32_t inject, float* mixed, float* zsum, cgs_stream_t stream);
+/* dzpre = (sum_c (B-A)_c (dRep_c - dInj_c) + l1*sign(Z) + 2*l2*Z) * Z(1-Z): the gradient w.r.t. the
+ * mask head's pre-sigmoid output, regularisers (main.py:421-429) included. */
+int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z,
+                const float* dmixed, int32_t inject, float l1_scale, float l2_scale,
+                float* dzpre, cgs_stream_t stream);
+
+/* ---- losses (main.py:380-384,400,411,421-429 and main.py:192-195) --------------------
+ * pred layout [4n]: slots [B | A | replaced | injected].  y [n].  zsum from cgs_mix_fwd.
+ * losses[8] = {critic, replace, inject, l1, l2, total, 0, 0};  dpred [4n] = d total / d pred.
+ * flags: bit0 live, bit1 inject, bit2 bce (--threshrew).  nz = n*h*w (mask elements).        */
+int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zsum,
+                      float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses,
+                      float* dpred, cgs_stream_t stream);
+/* phase 1: loss = mse(pred, y) or bce; losses[0] = loss; dpred [n]. */
+int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int32_t bce, float* losses,
+                    float* dpred, cgs_stream_t stream);
+
+/* ---- Adam, flat (torch.optim.Adam defaults semantics; main.py:178,330-334,463) -------- */
+int cgs_adam_flat(int64_t count, float* param, const float* grad, float* m, float* v,
+                  const uint64_t* step, float lr, float beta1, float beta2, float eps,
+                  cgs_stream_t stream);
+
+/* ---- layout helpers (module API boundary: the reference hands NCHW fp32 tensors) ------ */
+int cgs_nchw_to_nhwc(int32_t n, int32_t c, int32_t hw, const float* src, float* dst, cgs_stream_t stream);
+int cgs_nhwc_to_nchw(int32_t n, int32_t c, int32_t hw, const float* src, float* dst, cgs_stream_t stream);
+/* Writes the keep-mask multipliers (0 or 1/(1-p)) a dropout descriptor generates for `count` floats
+ * (count % 4 == 0): test hook used to feed the SAME masks to the CPU oracle. */
+int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stream);
+
+/* Library / device info: returns the gfx arch string the library was built for. */
+const char* cgs_build_arch(void);
+int cgs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGS_HIP_H */

@@ -1,0 +1,233 @@
+"""GPU parity of the HIP kernels (through the C ABI) against the CPU oracle, layer family by layer family.
+Tolerance: fp32, 1e-3 relative (BASELINE.json north_star) -- checked as |got-ref| <= 1e-3*|ref| + atol with a
+small atol scaled to each tensor's magnitude."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hourglass_ref as orc
+
+
+def rel_close(got, ref, what, rtol=1e-3, atol_scale=2e-5):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
+    atol = atol_scale * max(1e-12, float(np.abs(ref).max()))
+    err = np.abs(got - ref)
+    bad = err > (rtol * np.abs(ref) + atol)
+    assert not bad.any(), (f"{what}: {bad.sum()}/{bad.size} outside tol; max err {err.max():.3e} "
+                           f"(ref max {np.abs(ref).max():.3e}) at {np.unravel_index(err.argmax(), err.shape)}")
+
+
+def nhwc(t):  # device NHWC tensor -> numpy NCHW
+    return t.detach().float().cpu().permute(0, 3, 1, 2).numpy()
+
+
+@pytest.fixture(scope="module")
+def ctx(g1):
+    import cgs_amd
+    from cgs_amd import hourglass as hg, spec
+    dev = torch.device("cuda:0")
+    pc, pm = g1
+    lc, lm = spec.critic_layout(), spec.masker_layout()
+    fc = torch.empty(lc.total, device=dev)
+    fm = torch.empty(lm.total, device=dev)
+    lc.flatten({k: v.to(dev) for k, v in pc.items()}, fc)
+    lm.flatten({k: v.to(dev) for k, v in pm.items()}, fm)
+    return dict(hg=hg, spec=spec, dev=dev, pc=pc, pm=pm, lc=lc, lm=lm, fc=fc, fm=fm)
+
+
+def test_layout_roundtrip(ctx):
+    back = ctx["lc"].unflatten(ctx["fc"])
+    for k, v in ctx["pc"].items():
+        np.testing.assert_array_equal(back[k].cpu().numpy(), v.numpy())
+    back = ctx["lm"].unflatten(ctx["fm"])
+    for k, v in ctx["pm"].items():
+        np.testing.assert_array_equal(back[k].cpu().numpy(), v.numpy())
+
+
+@pytest.mark.parametrize("n", [8, 5, 37])
+def test_forward_matches_oracle(ctx, golden, n):
+    hg, dev = ctx["hg"], ctx["dev"]
+    x_u8 = np.random.RandomState(10 + n).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    X = orc.u8_to_nchw(x_u8)
+    with torch.no_grad():
+        pred, embeds = orc.critic_apply(ctx["pc"], X, collect=True)
+        Z, inter = orc.masker_apply(ctx["pm"], X, embeds, return_all=True)
+    xd = torch.from_numpy(x_u8).to(dev)
+    c = hg.critic_forward(ctx["fc"], ctx["lc"], xd, n)
+    m = hg.masker_forward(ctx["fm"], ctx["lm"], xd, [c["e0"], c["e1"], c["e2"], c["e3"], c["e4"]], n)
+    torch.cuda.synchronize()
+    for i in range(4):
+        rel_close(nhwc(c[f"e{i}"]), embeds[i].numpy(), f"e{i}")
+    rel_close(c["e4"].cpu().numpy(), embeds[4].flatten(1).numpy(), "e4")
+    rel_close(c["pred"].cpu().numpy(), pred[:, 0].numpy(), "pred")
+    rel_close(m["o4"].cpu().numpy(), inter["o4"].flatten(1).numpy(), "o4")
+    for k in ("o3", "o2", "o1", "o0", "hm"):
+        rel_close(nhwc(m[k]), inter[k].numpy(), k)
+    rel_close(m["Z"].cpu().numpy(), Z[:, 0].numpy(), "Z")
+    # same through the fp32 image path (the replaced / injected passes use it)
+    xf = (xd.float() / 255.0).contiguous()
+    c2 = hg.critic_forward(ctx["fc"], ctx["lc"], xf, n)
+    rel_close(c2["pred"].cpu().numpy(), pred[:, 0].numpy(), "pred(f32 input)")
+    rel_close(nhwc(c2["e0"]), embeds[0].numpy(), "e0(f32 input)")
+
+
+def test_golden_eval_fixture(ctx, golden):
+    """The committed reference capture itself (not just the oracle) on the GPU path."""
+    hg, dev = ctx["hg"], ctx["dev"]
+    g = golden("g2_eval.npz")
+    xd = torch.from_numpy(g["X"]).to(dev)
+    c = hg.critic_forward(ctx["fc"], ctx["lc"], xd, 8)
+    m = hg.masker_forward(ctx["fm"], ctx["lm"], xd, [c[f"e{i}"] for i in range(5)], 8)
+    rel_close(c["pred"].cpu().numpy(), g["pred"][:, 0], "pred")
+    rel_close(m["Z"].cpu().numpy(), g["Z"][:, 0], "Z")
+    for i in range(4):
+        rel_close(nhwc(c[f"e{i}"]), g[f"e{i}"], f"e{i}")
+
+
+def test_pool_argmax_mask(ctx):
+    """amask nibble = first maximum of the 2x2 window, 0xF where the pooled value is <= 0."""
+    hg, dev = ctx["hg"], ctx["dev"]
+    x_u8 = np.random.RandomState(3).randint(0, 256, (3, 64, 64, 3)).astype(np.uint8)
+    with torch.no_grad():
+        X = orc.u8_to_nchw(x_u8)
+        pre = torch.relu(torch.nn.functional.conv2d(X, ctx["pc"]["features.0.weight"], ctx["pc"]["features.0.bias"], padding=1))
+        pooled, idx = torch.nn.functional.max_pool2d(pre, 2, return_indices=True)
+    c = hg.critic_forward(ctx["fc"], ctx["lc"], torch.from_numpy(x_u8).to(dev), 3)
+    am = c["am0"].cpu().numpy().astype(np.uint32)[..., 0]  # [n,32,32]
+    yy, xx = np.meshgrid(np.arange(32), np.arange(32), indexing="ij")
+    for ch in range(8):
+        nib = (am >> (4 * ch)) & 15
+        ref_pos = ((idx[:, ch].numpy() // 64) - 2 * yy) * 2 + ((idx[:, ch].numpy() % 64) - 2 * xx)
+        dead = pooled[:, ch].numpy() <= 0
+        assert (nib[dead] == 15).all()
+        # ties between equal positive values are measure-zero for random inputs
+        assert (nib[~dead] == ref_pos[~dead]).mean() > 0.9999
+
+
+def _oracle_grads(ctx, x_u8, cot_pred, cot_embeds, cot_Z, f32_input=False):
+    pc = orc.leafify(ctx["pc"])
+    pm = orc.leafify(ctx["pm"])
+    X = orc.u8_to_nchw(x_u8).requires_grad_(f32_input)
+    pred, embeds = orc.critic_apply(pc, X, collect=True)
+    Z, inter = orc.masker_apply(pm, X.detach(), embeds, return_all=True)
+    loss = (pred[:, 0] * cot_pred).sum() + (Z[:, 0] * cot_Z).sum()
+    for e, c in zip(embeds, cot_embeds):
+        loss = loss + (e * c).sum()
+    loss.backward()
+    return pc, pm, X, Z
+
+
+@pytest.mark.parametrize("n", [8, 21])
+def test_backward_matches_oracle_autograd(ctx, n):
+    """critic + masker backward with random cotangents on every output, vs torch autograd on the oracle."""
+    hg, dev, lc, lm = ctx["hg"], ctx["dev"], ctx["lc"], ctx["lm"]
+    rs = np.random.RandomState(n)
+    x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    cot_pred = torch.from_numpy(rs.randn(n).astype(np.float32))
+    cot_Z = torch.from_numpy(rs.randn(n, 64, 64).astype(np.float32) * 0.1)
+    shapes = [(n, 8, 32, 32), (n, 8, 16, 16), (n, 8, 8, 8), (n, 16, 4, 4), (n, 32, 1, 1)]
+    cot_e = [torch.from_numpy(rs.randn(*s).astype(np.float32) * 0.05) for s in shapes]
+    pc, pm, X, Z = _oracle_grads(ctx, x_u8, cot_pred, cot_e, cot_Z, f32_input=True)
+
+    xd = torch.from_numpy(x_u8).to(dev)
+    xf = (xd.float() / 255.0).contiguous()   # fp32 image path so that the image gradient can be checked too
+    c = hg.critic_forward(ctx["fc"], lc, xf, n)
+    embeds = [c[f"e{i}"] for i in range(5)]
+    m = hg.masker_forward(ctx["fm"], lm, xf, embeds, n)
+    Zd = m["Z"]
+    dzpre = (cot_Z.to(dev) * Zd * (1 - Zd)).contiguous()
+    plan_m = hg.SlabPlan()
+    d_emb = hg.masker_backward(ctx["fm"], lm, xf, embeds, n, m, dzpre, plan_m)
+    gm = torch.zeros(lm.total, device=dev)
+    plan_m.build(gm).run()
+    # the cotangents on the embeds join the decoder's skip gradients
+    for i in range(4):
+        d_emb[i] += cot_e[i].to(dev).permute(0, 2, 3, 1).contiguous()
+    d_emb[4] += cot_e[4].to(dev).flatten(1)
+    plan_c = hg.SlabPlan()
+    dx = torch.empty((n, 64, 64, 3), device=dev)
+    hg.critic_backward(ctx["fc"], lc, xf, n, c, cot_pred.to(dev), plan_c, d_embeds=d_emb, n_add=n, dx=dx, dx_from=0)
+    gc = torch.zeros(lc.total, device=dev)
+    plan_c.build(gc).run()
+    torch.cuda.synchronize()
+    for k, v in lm.unflatten(gm).items():
+        rel_close(v.cpu().numpy(), pm[k].grad.numpy(), f"masker grad {k}")
+    for k, v in lc.unflatten(gc).items():
+        rel_close(v.cpu().numpy(), pc[k].grad.numpy(), f"critic grad {k}")
+    rel_close(nhwc(dx), X.grad.numpy(), "image gradient")
+
+
+def test_u8_and_f32_wgrad_agree(ctx):
+    """The uint8 loader (A images) and the fp32 loader (mixes) feed the same arithmetic."""
+    hg, dev, lc = ctx["hg"], ctx["dev"], ctx["lc"]
+    n = 6
+    rs = np.random.RandomState(5)
+    xd = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    xf = (xd.float() / 255.0).contiguous()
+    dp = torch.from_numpy(rs.randn(n).astype(np.float32)).to(dev)
+    outs = []
+    for x in (xd, xf):
+        c = hg.critic_forward(ctx["fc"], lc, x, n)
+        plan = hg.SlabPlan()
+        hg.critic_backward(ctx["fc"], lc, x, n, c, dp, plan)
+        g = torch.zeros(lc.total, device=dev)
+        plan.build(g).run()
+        outs.append(g.cpu().numpy())
+    rel_close(outs[0], outs[1], "u8 vs f32 critic grads", rtol=1e-4)
+
+
+def test_dropout_masks_statistics_and_step(ctx):
+    from cgs_amd import _lib
+    import ctypes as C
+    dev = ctx["dev"]
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    out = torch.empty(1 << 20, device=dev)
+    masks = []
+    for s in (0, 1):
+        step.fill_(s)
+        d = _lib.Dropout(0.3, 1, 1234, step.data_ptr())
+        _lib.call("cgs_dropout_mask", d, out.numel(), C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        masks.append(out.cpu().numpy().copy())
+    keep = masks[0] != 0
+    assert abs(keep.mean() - 0.7) < 3e-3
+    np.testing.assert_allclose(masks[0][keep], 1 / 0.7, rtol=1e-6)
+    assert (masks[0] != masks[1]).mean() > 0.3          # a new step draws a new mask
+    # lag-1 independence
+    assert abs(np.corrcoef(keep[:-1], keep[1:])[0, 1]) < 5e-3
+
+
+def test_forward_backward_with_dropout_vs_oracle_masks(ctx):
+    """Train-mode dropout (p=0.3): export the Philox keep-masks the kernels used and feed the SAME masks to
+    the oracle; forward values and every gradient must agree."""
+    from cgs_amd import _lib
+    import ctypes as C
+    hg, dev, lc = ctx["hg"], ctx["dev"], ctx["lc"]
+    n, p = 9, 0.3
+    rs = np.random.RandomState(77)
+    x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    step = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    drop = hg.DropState(p, 99, step)
+    xd = torch.from_numpy(x_u8).to(dev)
+    c = hg.critic_forward(ctx["fc"], lc, xd, n, drop)
+    dp = torch.from_numpy(rs.randn(n).astype(np.float32))
+    plan = hg.SlabPlan()
+    hg.critic_backward(ctx["fc"], lc, xd, n, c, dp.to(dev), plan, drop)
+    g = torch.zeros(lc.total, device=dev)
+    plan.build(g).run()
+    masks = []
+    for site, shape in ((0, (n, 8, 8, 8)), (1, (n, 4, 4, 16)), (2, (n, 32))):
+        out = torch.empty(int(np.prod(shape)), device=dev)
+        _lib.call("cgs_dropout_mask", drop.desc(site), out.numel(), C.c_void_p(out.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        mk = (out.cpu().reshape(shape) != 0).float()
+        masks.append(mk.permute(0, 3, 1, 2).contiguous() if len(shape) == 4 else mk)
+    pc = orc.leafify(ctx["pc"])
+    pred = orc.critic_apply(pc, orc.u8_to_nchw(x_u8), p=p, training=True, masks=masks)
+    (pred[:, 0] * dp).sum().backward()
+    rel_close(c["pred"].cpu().numpy(), pred[:, 0].detach().numpy(), "pred with dropout")
+    for k, v in lc.unflatten(g).items():
+        rel_close(v.cpu().numpy(), pc[k].grad.numpy(), f"critic grad {k} (dropout)")
