@@ -19,7 +19,8 @@ f32 = C.c_float
 
 
 class Dropout(C.Structure):
-    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("step", C.c_void_p)]
+    _fields_ = [("p", C.c_float), ("site", C.c_uint32), ("seed", C.c_uint64), ("step", C.c_void_p),
+                ("base", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ConvDesc(C.Structure):
@@ -49,7 +50,7 @@ SIGNATURES = {
     "cgs_mix_bwd": (i32, [i32, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp]),
     "cgs_phase2_losses": (i32, [i32, vp, vp, vp, f32, f32, f32, i32, i64, vp, vp, vp]),
     "cgs_phase1_loss": (i32, [i32, vp, vp, i32, vp, vp, vp]),
-    "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp]),
+    "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_dropout_mask": (i32, [Dropout, i64, vp, vp]),

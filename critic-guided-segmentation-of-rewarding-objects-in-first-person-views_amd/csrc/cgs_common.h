@@ -41,7 +41,7 @@ struct DropCtx {
     float p, scale;
     uint32_t site;
     uint2 key;
-    uint32_t step_lo, step_hi;
+    uint32_t step_lo, step_hi, base;
     bool on;
 };
 
@@ -51,6 +51,7 @@ __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d) {
     c.p = d.p;
     c.scale = c.on ? 1.f / (1.f - d.p) : 1.f;
     c.site = d.site;
+    c.base = d.base;
     c.key = make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32));
     uint64_t s = (c.on && d.step) ? *d.step : 0ull;
     c.step_lo = (uint32_t)s;
@@ -60,7 +61,7 @@ __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d) {
 
 // Multipliers (0 or 1/(1-p)) for the four consecutive floats whose float4 index is idx4.
 __device__ __forceinline__ float4 drop_mult4(const DropCtx& c, uint32_t idx4) {
-    uint4 r = philox4x32_10(make_uint4(idx4, c.site, c.step_lo, c.step_hi), c.key);
+    uint4 r = philox4x32_10(make_uint4(idx4 + c.base, c.site, c.step_lo, c.step_hi), c.key);
     const float u = 1.f / 16777216.f;
     float4 m;
     m.x = ((r.x >> 8) * u >= c.p) ? c.scale : 0.f;

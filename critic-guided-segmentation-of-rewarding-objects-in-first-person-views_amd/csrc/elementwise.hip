@@ -181,13 +181,13 @@ __global__ void __launch_bounds__(256) reduce_slabs_kernel(const cgs_reduce_job*
 
 __global__ void __launch_bounds__(256) adam_kernel(long count, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   const uint64_t* __restrict__ step, float lr, float b1, float b2, float eps) {
+                                                   const uint64_t* __restrict__ step, float lr, float b1, float b2, float eps, float gscale) {
     long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
     const double t = (double)(*step);
     const float c1 = (float)(1.0 - pow((double)b1, t));
     const float c2s = (float)sqrt(1.0 - pow((double)b2, t));
-    float gi = g[i];
+    float gi = g[i] * gscale;
     float mi = b1 * m[i] + (1.f - b1) * gi;
     float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -272,11 +272,11 @@ extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32
 }
 
 extern "C" int cgs_adam_flat(int64_t count, float* param, const float* grad, float* m, float* v, const uint64_t* step,
-                             float lr, float beta1, float beta2, float eps, cgs_stream_t stream) {
+                             float lr, float beta1, float beta2, float eps, float grad_scale, cgs_stream_t stream) {
     if (count < 0 || !param || !grad || !m || !v || !step) return CGS_ERR_BADARG;
     if (count == 0) return CGS_OK;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (long)count,
-                       param, grad, m, v, step, lr, beta1, beta2, eps);
+                       param, grad, m, v, step, lr, beta1, beta2, eps, grad_scale);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

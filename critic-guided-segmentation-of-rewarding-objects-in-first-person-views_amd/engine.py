@@ -1,0 +1,271 @@
+"""Fused training / inference engine: the loop bodies of Handler.critic_pipe (main.py:183-200) and
+Handler.segmentation_training (main.py:344-463) as one static sequence of HIP kernels over preallocated
+device buffers, captured into a HIP graph and replayed once per step.
+
+Per phase-2 step (N = images in A = images in B):
+  critic fwd on [B|A] (2N, uint8 loader)  ->  masker fwd on A  ->  mix  ->  critic fwd on [rep|inj] (2N)
+  -> losses  ->  critic bwd on [rep|inj] (image gradient)  ->  mix bwd (+L1/L2)  ->  masker bwd
+  -> critic bwd on A (skip gradients fused)  ->  slab reduction (+tick)  [-> RCCL all-reduce]  ->  flat Adam.
+Data parallelism: one process per GPU, each with its own N images; the only exchange is one all-reduce
+of the flat gradient buffer (25 661 floats) between the slab reduction and Adam.
+"""
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from . import hourglass as hg
+from .spec import ENC_LAYERS, critic_layout, masker_layout
+
+_P = hg._p
+_S = hg._stream
+
+
+def _align4(x):
+    return (x + 3) // 4 * 4
+
+
+class HourglassEngine:
+    """Owns the parameters (critic | masker in one flat kernel-layout buffer), Adam state and every
+    activation / gradient / slab buffer for a fixed batch size ``n``."""
+
+    def __init__(self, n: int, device="cuda:0", dropout: float = 0.3, lfak: float = 5, L1: float = 0.5, L2: float = 0.0,
+                 inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
+                 lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
+                 process_group=None):
+        if not torch.cuda.is_available():
+            raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
+        _lib.load()
+        self.n, self.dev = int(n), torch.device(device)
+        self.p, self.lfak, self.L1, self.L2 = float(dropout), float(lfak), float(L1), float(L2)
+        self.inject, self.live, self.bce = bool(inject), bool(live), bool(threshrew)
+        self.lr, self.b1, self.b2, self.eps = lr, betas[0], betas[1], eps
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.lc, self.lm = critic_layout(), masker_layout()
+        self.off_c, self.off_m = 0, _align4(self.lc.total)
+        self.total = self.off_m + self.lm.total
+        z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
+        self.flat, self.grad, self.m, self.v = z(self.total), z(self.total), z(self.total), z(self.total)
+        self.fc, self.fm = self.flat[:self.lc.total], self.flat[self.off_m:]
+        self.gc, self.gm = self.grad[:self.lc.total], self.grad[self.off_m:]
+        self.step_t = z(1, dt=torch.int64)
+        self.drop = hg.DropState(self.p, seed, self.step_t)
+        n4 = 4 * n
+        self.ab = z(2 * n, 64, 64, 3, dt=torch.uint8)       # [B | A]
+        self.y = z(n)
+        self.mixed = z(2 * n, 64, 64, 3)                     # [replaced | injected]
+        self.cbuf: Dict[str, torch.Tensor] = {}              # critic activations for the 4N slots
+        for i, (key, hw, ca, cb, co, *_r) in enumerate(ENC_LAYERS):
+            self.cbuf[f"e{i}"] = z(n4, hw // 2, hw // 2, co)
+            self.cbuf[f"am{i}"] = z(n4, hw // 2, hw // 2, co // 8, dt=torch.int32)
+        self.cbuf["e4"], self.cbuf["h1"], self.cbuf["pred"] = z(n4, 32), z(n4, 32), z(n4)
+        self.mbuf: Dict[str, torch.Tensor] = {}
+        self.zsum, self.losses, self.dpred = z(2), z(8), z(n4)
+        self.dmixed = z(2 * n, 64, 64, 3)
+        self.dzpre = z(n, 64, 64)
+        self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "p1": {}}
+        self._graphs: Dict[str, object] = {}
+        self._plans: Dict[str, hg.SlabPlan] = {}
+
+    # ---- parameters --------------------------------------------------------------------------
+    def load_state(self, critic_sd=None, masker_sd=None):
+        if critic_sd is not None:
+            self.lc.flatten({k: v.to(self.dev) for k, v in critic_sd.items()}, self.fc)
+        if masker_sd is not None:
+            self.lm.flatten({k: v.to(self.dev) for k, v in masker_sd.items()}, self.fm)
+
+    def critic_state(self):
+        return self.lc.unflatten(self.fc)
+
+    def masker_state(self):
+        return self.lm.unflatten(self.fm)
+
+    def adopt(self, critic_module, masker_module):
+        """Re-homes the flat parameters of nets.NewCritic / nets.UnetDecoder into this engine's buffer, so the
+        modules and the engine always see the same weights (no copies at save time)."""
+        with torch.no_grad():
+            self.fc.copy_(critic_module.flat.detach().to(self.dev))
+            self.fm.copy_(masker_module.flat.detach().to(self.dev))
+        critic_module.flat.data = self.fc
+        masker_module.flat.data = self.fm
+
+    def reset_optimizer(self):
+        self.m.zero_(); self.v.zero_(); self.step_t.zero_()
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _cview(self, a: int, b: int) -> Dict[str, torch.Tensor]:
+        return {k: t[a:b] for k, t in self.cbuf.items()}
+
+    def _slab_views(self, tag: str, n_first: int, n_second: int):
+        """Per-layer slab buffers shared by two backward passes (adjacent => one reduction job each)."""
+        lib = _lib.load()
+        out1, out2 = {}, {}
+        nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
+        specs = [("slab_head", lambda n: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
+        for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
+            def f(n, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
+                d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
+                return lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+            specs.append((f"slab_enc{i}", f, 9 * ca * co + co))
+        for name, fn, cnt in specs:
+            a, b = (fn(n_first) if n_first else 0), (fn(n_second) if n_second else 0)
+            big = torch.zeros((a + b, cnt), device=self.dev)
+            self._ws.setdefault("slabs_" + tag, []).append(big)
+            out1[name], out2[name] = big[:a], big[a:]
+        return out1, out2
+
+    def _adam(self):
+        lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
+        _lib.call("cgs_adam_flat", cnt, C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
+                  C.c_void_p(self.m.data_ptr() + 4 * lo), C.c_void_p(self.v.data_ptr() + 4 * lo), _P(self.step_t),
+                  self.lr, self.b1, self.b2, self.eps, 1.0 / self.world, _S())
+
+    def _allreduce(self):
+        if self.pg is not None and self.world > 1:
+            lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
+            torch.distributed.all_reduce(self.grad[lo:lo + cnt], group=self.pg)
+
+    # ---- phase 2 -----------------------------------------------------------------------------
+    def _phase2_fwd_bwd(self):
+        n = self.n
+        nmix = 2 * n if self.inject else n
+        drop = self.drop
+        self.zsum.zero_()
+        A = self.ab[n:]
+        B = self.ab[:n]
+        # critic on [B | A]
+        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n))
+        sa = self._cview(n, 2 * n)
+        embeds = [sa[f"e{i}"] for i in range(5)]
+        hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf)
+        _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
+        hg.critic_forward(self.fc, self.lc, self.mixed[:nmix], nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
+        flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
+        _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.lfak, self.L1, self.L2,
+                  flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
+        plan = self._plans.get("p2")
+        first = plan is None
+        if first:
+            plan = hg.SlabPlan()
+            self._sl_mix, self._sl_a = self._slab_views("p2", nmix, n if self.live else 0)
+            self._ws["cb_mix"].update(self._sl_mix)
+            self._ws["cb_a"].update(self._sl_a)
+        pc = plan if first else hg.SlabPlan()   # job registration only matters the first time
+        # critic backward on the mixes: image gradient for the mask path (+ weight gradients when live)
+        hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
+                           self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
+                           ws=self._ws["cb_mix"])
+        nz = float(n * 4096)
+        _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), _P(self.dmixed), int(self.inject),
+                  self.L1 / nz, self.L2 / nz, _P(self.dzpre), _S())
+        pm = hg.SlabPlan()
+        d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"])
+        if self.live:
+            hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
+                               n_add=n, ws=self._ws["cb_a"])
+        if first:
+            full = hg.SlabPlan()
+            if self.live:
+                for slab, nsl, cnt, off in pc.jobs:
+                    full.jobs.append((slab, nsl, cnt, self.off_c + off))
+            for slab, nsl, cnt, off in pm.jobs:
+                full.jobs.append((slab, nsl, cnt, self.off_m + off))
+            self._plans["p2"] = full.build(self.grad)
+        self._plans["p2"].run(self.step_t)
+
+    def phase2_step(self, A_u8: Optional[torch.Tensor] = None, B_u8: Optional[torch.Tensor] = None,
+                    Y: Optional[torch.Tensor] = None):
+        """One optimiser step of main.py:344-463.  Inputs (optional: omitted => reuse the resident batch) are
+        NHWC uint8 [n,64,64,3] and fp32 [n].  Returns the device tensor losses[8] =
+        (critic, replace, inject, l1, l2, total, 0, 0) -- no host sync here."""
+        n = self.n
+        if A_u8 is not None:
+            self.ab[n:].copy_(A_u8, non_blocking=True)
+        if B_u8 is not None:
+            self.ab[:n].copy_(B_u8, non_blocking=True)
+        if Y is not None:
+            self.y.copy_(Y.to(torch.float32), non_blocking=True)
+        self._run("p2", self._phase2_fwd_bwd)
+        return self.losses
+
+    # ---- phase 1 -----------------------------------------------------------------------------
+    def _phase1_fwd_bwd(self):
+        n = self.n
+        X = self.ab[:n]
+        hg.critic_forward(self.fc, self.lc, X, n, self.drop.shifted(0), out=self._cview(0, n))
+        _lib.call("cgs_phase1_loss", n, _P(self.cbuf["pred"]), _P(self.y), int(self.bce), _P(self.losses), _P(self.dpred), _S())
+        first = "p1" not in self._plans
+        pc = hg.SlabPlan()
+        hg.critic_backward(self.fc, self.lc, X, n, self._cview(0, n), self.dpred[:n], pc, self.drop.shifted(0), ws=self._ws["p1"])
+        if first:
+            full = hg.SlabPlan()
+            for slab, nsl, cnt, off in pc.jobs:
+                full.jobs.append((slab, nsl, cnt, self.off_c + off))
+            self._plans["p1"] = full.build(self.grad)
+        self._plans["p1"].run(self.step_t)
+
+    def _adam_p1(self):
+        _lib.call("cgs_adam_flat", self.lc.total, _P(self.flat), _P(self.grad), _P(self.m), _P(self.v), _P(self.step_t),
+                  self.lr, self.b1, self.b2, self.eps, 1.0 / self.world, _S())
+
+    def phase1_step(self, X_u8: Optional[torch.Tensor] = None, Y: Optional[torch.Tensor] = None):
+        """One optimiser step of main.py:183-200 (critic regression) on n images; returns losses (device)."""
+        n = self.n
+        if X_u8 is not None:
+            self.ab[:n].copy_(X_u8, non_blocking=True)
+        if Y is not None:
+            self.y.copy_(Y.to(torch.float32), non_blocking=True)
+        self._run("p1", self._phase1_fwd_bwd)
+        return self.losses
+
+    # ---- execution: eager first call (allocates workspaces, builds job tables), then HIP-graph replay ----
+    def _run(self, tag: str, body):
+        adam = self._adam if tag == "p2" else self._adam_p1
+        if tag == "p1" and self.pg is not None and self.world > 1:
+            def allred():
+                torch.distributed.all_reduce(self.grad[:self.lc.total], group=self.pg)
+        else:
+            allred = self._allreduce
+        g = self._graphs.get(tag)
+        if g is None:
+            body(); allred(); adam()                       # eager warm-up: allocations + tables
+            if not self.use_graph:
+                self._graphs[tag] = "eager"
+                return
+            # the warm-up was a real step; capture the static sequence for all later steps
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                body()
+                if self.world == 1:
+                    adam()
+            g2 = None
+            if self.world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    adam()
+            self._graphs[tag] = (g1, g2)
+            return
+        if g == "eager":
+            body(); allred(); adam()
+            return
+        g1, g2 = g
+        g1.replay()
+        if g2 is not None:
+            allred()
+            g2.replay()
+
+    # ---- inference (main.py:1130-1151) -----------------------------------------------------------
+    @torch.no_grad()
+    def infer(self, X: torch.Tensor, want_mask: bool = True):
+        """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
+        Returns (pred [b], Z [b,64,64] or None)."""
+        b = X.shape[0]
+        c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b)
+        if not want_mask:
+            return c["pred"], None
+        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b)
+        return c["pred"], m["Z"]

@@ -37,15 +37,19 @@ def _chk(t: torch.Tensor, dtype, what: str):
 
 
 class DropState:
-    """Dropout configuration of a pass: probability, Philox seed and the device step counter."""
+    """Dropout configuration of a pass: probability, Philox seed, the device step counter and the index of
+    the pass's first image inside the batch buffer (so differently sliced launches draw the same masks)."""
 
-    def __init__(self, p: float, seed: int, step: Optional[torch.Tensor]):
-        self.p, self.seed, self.step = float(p), int(seed), step
+    def __init__(self, p: float, seed: int, step: Optional[torch.Tensor], img_off: int = 0):
+        self.p, self.seed, self.step, self.img_off = float(p), int(seed), step, int(img_off)
 
-    def desc(self, site: int, active: bool = True) -> _lib.Dropout:
+    def shifted(self, img_off: int) -> "DropState":
+        return DropState(self.p, self.seed, self.step, img_off)
+
+    def desc(self, site: int, active: bool = True, per_img4: int = 0) -> _lib.Dropout:
         if not active or self.p <= 0.0:
-            return _lib.Dropout(0.0, 0, 0, None)
-        return _lib.Dropout(self.p, site, self.seed, self.step.data_ptr())
+            return _lib.Dropout(0.0, 0, 0, None, 0, 0)
+        return _lib.Dropout(self.p, site, self.seed, self.step.data_ptr(), self.img_off * per_img4, 0)
 
 
 NO_DROP = DropState(0.0, 0, None)
@@ -63,8 +67,17 @@ class SlabPlan:
         self.jobs = []   # (slab tensor, nslab, count, dst offset)
         self._table = None
         self._keep = None
+        self._extra = []
 
     def add(self, slab: torch.Tensor, nslab: int, count: int, dst_off: int):
+        # two passes that write adjacent slabs for the same destination become ONE job (no write race)
+        for i, (s0, n0, c0, o0) in enumerate(self.jobs):
+            if o0 == dst_off and c0 == count:
+                if slab.data_ptr() != s0.data_ptr() + 4 * n0 * c0:
+                    raise _lib.CgsError("slabs of passes that share a destination must be adjacent in memory")
+                self.jobs[i] = (s0, n0 + nslab, c0, o0)
+                self._extra.append(slab)
+                return
         self.jobs.append((slab, nslab, count, dst_off))
 
     def build(self, grad_flat: torch.Tensor, accumulate: bool = False):
@@ -100,7 +113,7 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
         am = o.get(f"am{i}")
         if am is None:
             am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
-        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None))
+        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         _lib.call("cgs_conv3x3_fwd", C.byref(d), _p(src), None, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")),
                   C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".bias")), _p(e), _p(am), _stream())
         src = e
@@ -111,7 +124,7 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     _lib.call("cgs_head_fwd", n, _p(o["e3"]), C.c_void_p(fp + 4 * lay.off("features.14.weight")),
               C.c_void_p(fp + 4 * lay.off("features.14.bias")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
               C.c_void_p(fp + 4 * lay.off("crit.1.bias")), C.c_void_p(fp + 4 * lay.off("crit.4.weight")),
-              C.c_void_p(fp + 4 * lay.off("crit.4.bias")), drop.desc(DROP_SITE_E3), drop.desc(DROP_SITE_H1),
+              C.c_void_p(fp + 4 * lay.off("crit.4.bias")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
               _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _stream())
     return o
 
@@ -145,13 +158,13 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     _lib.call("cgs_head_bwd", n, _p(saved["e3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
               _p(d_embeds[4]) if has_add else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
               C.c_void_p(fp + 4 * lay.off("features.14.weight")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
-              C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3), drop.desc(DROP_SITE_H1),
+              C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
               _p(d_cur), _p(slab), _stream())
     plan.add(slab, nsl, HEAD_SLAB, lay.off("features.14.weight"))
     for i in (3, 2, 1, 0):
         key, hw, ca, cb, co, ups, act, pool, site = ENC_LAYERS[i]
         src = x if i == 0 else saved[f"e{i - 1}"]
-        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None))
+        d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")

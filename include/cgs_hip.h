@@ -30,14 +30,19 @@ enum { CGS_OK = 0, CGS_ERR_UNSUPPORTED = -1, CGS_ERR_BADARG = -2 };
 enum { CGS_SRC_F32 = 0, CGS_SRC_U8 = 1 };
 enum { CGS_ACT_NONE = 0, CGS_ACT_RELU = 1, CGS_ACT_LRELU = 2, CGS_ACT_SIGMOID = 3 };
 
-/* Dropout on a tensor = Philox4x32-10 keep-mask keyed by (seed; element/4, site, *step).
+/* Dropout on a tensor = Philox4x32-10 keep-mask keyed by (seed; base + element/4, site, *step).
  * p == 0 disables it.  `step` points to a device-resident counter so that a captured graph
- * draws fresh masks on every replay; forward and backward of one step read the same value. */
+ * draws fresh masks on every replay; forward and backward of one step read the same value.
+ * `base` (in units of 4 floats) is added to the element index: a call that works on a slice of a
+ * larger batch buffer passes the slice's offset so that forward and backward launches that slice
+ * the batch differently still draw identical masks for identical images. */
 typedef struct {
     float p;
     uint32_t site;
     uint64_t seed;
     const uint64_t* step; /* device; may be NULL when p == 0 */
+    uint32_t base;
+    uint32_t reserved;
 } cgs_dropout;
 
 /* One 3x3, stride-1, pad-1 convolution of the Hourglass (nets.py:170-183, 480-490). */
@@ -157,10 +162,12 @@ int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float*
 int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int32_t bce, float* losses,
                     float* dpred, cgs_stream_t stream);
 
-/* ---- Adam, flat (torch.optim.Adam defaults semantics; main.py:178,330-334,463) -------- */
+/* ---- Adam, flat (torch.optim.Adam defaults semantics; main.py:178,330-334,463) --------
+ * t = *step (already ticked by cgs_reduce_slabs).  grad_scale multiplies the gradient as it is read
+ * (1/world_size after a sum all-reduce; 1 otherwise). */
 int cgs_adam_flat(int64_t count, float* param, const float* grad, float* m, float* v,
                   const uint64_t* step, float lr, float beta1, float beta2, float eps,
-                  cgs_stream_t stream);
+                  float grad_scale, cgs_stream_t stream);
 
 /* ---- layout helpers (module API boundary: the reference hands NCHW fp32 tensors) ------ */
 int cgs_nchw_to_nhwc(int32_t n, int32_t c, int32_t hw, const float* src, float* dst, cgs_stream_t stream);

@@ -1,0 +1,160 @@
+"""GPU parity of the fused training engine (HIP graph of kernels) against the committed reference captures
+(tests/golden/g3_*, g4_*) and against the CPU oracle with the kernels' own dropout masks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hourglass_ref as orc
+from test_gpu_kernels import rel_close
+
+
+def split(raw, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in raw.items() if k.startswith(prefix + "/")}
+
+
+def make_engine(g1, n, **kw):
+    from cgs_amd import engine
+    pc, pm = g1
+    e = engine.HourglassEngine(n, **kw)
+    e.load_state(pc, pm)
+    return e
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("g3_train_default", dict()),
+    ("g3_train_noinject", dict(inject=False)),
+    ("g3_train_frozen", dict(live=False)),
+    ("g3_train_l2", dict(L2=0.1)),
+])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_phase2_matches_reference_capture(golden, g1, tag, kw, use_graph):
+    g = golden(tag + ".npz")
+    dev = torch.device("cuda:0")
+    e = make_engine(g1, 8, dropout=0.0, use_graph=use_graph, **kw)
+    A, B, Y = (torch.from_numpy(g[k]).to(dev) for k in ("A", "B", "Y"))
+    for s in range(3):
+        losses = e.phase2_step(A, B, Y).cpu().numpy().astype(np.float64)
+        ref = g[f"parts{s}"]  # critic, replace, inject, L1, L2
+        got = losses[:5].copy()
+        if not kw.get("live", True):
+            got[0] = 0.0   # the reference does not evaluate the critic loss when frozen
+        np.testing.assert_allclose(got, ref, rtol=1e-3, atol=1e-7, err_msg=f"losses step {s}")
+        assert losses[5] == pytest.approx(float(g[f"total{s}"]), rel=1e-3)
+        if s == 0:
+            gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+            for k, v in split(g, "grad/masker").items():
+                rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
+            if kw.get("live", True):
+                for k, v in split(g, "grad/critic").items():
+                    rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
+            rel_close(e.mbuf["Z"].cpu().numpy(), g["Z0"][:, 0], "Z")
+            rel_close(e.cbuf["pred"][8:16].cpu().numpy(), g["pred0"], "pred")
+        if s in (0, 2):
+            for k, v in split(g, f"step{s + 1}/critic").items():
+                rel_close(e.critic_state()[k].cpu().numpy(), v, f"critic {k} after step {s + 1}", rtol=1e-3, atol_scale=1e-4)
+            for k, v in split(g, f"step{s + 1}/masker").items():
+                rel_close(e.masker_state()[k].cpu().numpy(), v, f"masker {k} after step {s + 1}", rtol=1e-3, atol_scale=1e-4)
+
+
+@pytest.mark.parametrize("tag,thr", [("g4_phase1_mse", 0.0), ("g4_phase1_bce", 0.5)])
+def test_phase1_matches_reference_capture(golden, g1, tag, thr):
+    g = golden(tag + ".npz")
+    dev = torch.device("cuda:0")
+    e = make_engine(g1, 8, dropout=0.0, threshrew=thr)
+    loss = e.phase1_step(torch.from_numpy(g["X"]).to(dev), torch.from_numpy(g["Y"]).to(dev)).cpu().numpy()
+    assert float(loss[0]) == pytest.approx(float(g["loss"]), rel=1e-3)
+    rel_close(e.cbuf["pred"][:8].cpu().numpy(), g["pred"], "pred")
+    gc = e.lc.unflatten(e.gc)
+    for k, v in split(g, "grad").items():
+        rel_close(gc[k].cpu().numpy(), v, f"grad {k}")
+    for k, v in split(g, "step1").items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v, f"{k} after step 1", atol_scale=1e-4)
+
+
+def _export_masks(e, n_imgs_total, step_value):
+    """Keep-masks of the three dropout sites for all image slots of the engine's batch buffer."""
+    from cgs_amd import _lib
+    out = []
+    for site, per_img in ((0, (8, 8, 8)), (1, (4, 4, 16)), (2, (32,))):
+        cnt = n_imgs_total * int(np.prod(per_img))
+        buf = torch.empty(cnt, device=e.dev)
+        _lib.call("cgs_dropout_mask", e.drop.desc(site), cnt, C.c_void_p(buf.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        mk = (buf.cpu().reshape((n_imgs_total,) + per_img) != 0).float()
+        out.append(mk.permute(0, 3, 1, 2).contiguous() if len(per_img) == 3 else mk)
+    return out
+
+
+def test_phase2_with_dropout_vs_oracle_masks(g1):
+    """dropout 0.3, train mode: the oracle is fed the keep-masks the kernels drew (slot order B, A, rep, inj)."""
+    n = 12
+    rs = np.random.RandomState(42)
+    dev = torch.device("cuda:0")
+    A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    e = make_engine(g1, n, dropout=0.3, use_graph=True)
+    e.step_t.fill_(7)   # masks depend on the step counter; export them for step 7 before the step ticks it
+    masks = _export_masks(e, 4 * n, 7)
+    losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    assert int(e.step_t.item()) == 8
+    sl = {"B": slice(0, n), "A": slice(n, 2 * n), "rep": slice(2 * n, 3 * n), "inj": slice(3 * n, 4 * n)}
+    omasks = [[m[sl[k]] for m in masks] for k in ("A", "B", "rep", "inj")]  # oracle order: A, B, replaced, injected
+    pc, pm = g1
+    rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1,
+                           p=0.3, training=True, masks=omasks)[0]
+    parts = rec["parts"]
+    np.testing.assert_allclose(losses[:4], [parts["critic"], parts["replace"], parts["inject"], parts["norm"]], rtol=1e-3)
+    gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+    for k, v in rec["grads_c"].items():
+        rel_close(gc[k].cpu().numpy(), v.numpy(), f"critic grad {k}")
+    for k, v in rec["grads_m"].items():
+        rel_close(gm[k].cpu().numpy(), v.numpy(), f"masker grad {k}")
+
+
+def test_graph_replay_equals_eager_and_is_reproducible(g1):
+    n = 16
+    rs = np.random.RandomState(1)
+    dev = torch.device("cuda:0")
+    A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    Y = torch.from_numpy(rs.rand(n).astype(np.float32)).to(dev)
+    finals = []
+    for use_graph in (False, True, True):
+        e = make_engine(g1, n, dropout=0.3, use_graph=use_graph)
+        for _ in range(4):
+            e.phase2_step(A, B, Y)
+        finals.append(e.flat.cpu().numpy().copy())
+    np.testing.assert_array_equal(finals[1], finals[2])   # slab reduction: no float atomics on the parameter path
+    np.testing.assert_array_equal(finals[0], finals[1])
+
+
+def test_large_batch_properties(g1):
+    """Full bench size (N=512): size-independent properties instead of an oracle run."""
+    n = 512
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(0)
+    A = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen).to(dev)
+    B = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen).to(dev)
+    Y = torch.rand(n, generator=gen).to(dev)
+    e = make_engine(g1, n, dropout=0.0)
+    p0 = e.flat.clone()
+    l0 = e.phase2_step(A, B, Y).cpu().numpy().copy()
+    g_full = e.grad.cpu().numpy().copy()
+    assert np.isfinite(l0).all() and np.isfinite(g_full).all()
+    Z = e.mbuf["Z"]
+    assert float(Z.min()) > 0 and float(Z.max()) < 1
+    # the batch-mean gradient equals the mean of the two half-batch gradients (linearity; what DP relies on)
+    halves = []
+    for sl in (slice(0, n // 2), slice(n // 2, n)):
+        h = make_engine(g1, n // 2, dropout=0.0, use_graph=False)
+        h.phase2_step(A[sl], B[sl], Y[sl])
+        halves.append(h.grad.cpu().numpy().copy())
+    rel_close(g_full, 0.5 * (halves[0] + halves[1]), "full-batch grad vs mean of half-batch grads", rtol=2e-3, atol_scale=1e-4)
+    # a step moved every parameter by at most ~lr (Adam's first step is +-lr)
+    delta = (e.flat - p0).abs().max().item()
+    assert 0 < delta <= 1.01e-3
