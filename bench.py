@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path named by BASELINE.json: Hourglass + critic phase-2 TRAIN step
+(4 critic fwd, 3 critic bwd, decoder fwd+bwd, mix, losses, Adam), synthetic 64x64x3 frames, batch 512/GPU, fp32.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see the contract in the task description):
+  value     = whole-job A-images/s (N images of A per GPU per step; weak scaling, inputs resident in HBM)
+  roofline  = algorithmic HBM bytes of one step (4.841 MB per A-image, fp32, chfak 1)
+              / average duration of one step's HIP-graph launch, timed with HIP events on the launch stream
+  cpu_baseline = the CPU oracle (a port of the reference step, oracle/hourglass_ref.py) timed on this box's
+              host cores on a bounded sample of the same workload (rank 0, --gpus 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+ALGO_BYTES_PER_IMAGE = 4.841e6      # SURVEY.md section 8(d), fp32, chfak 1 (1 210 343 elements x 4 B)
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=512, help="A-images (= B-images) per GPU per step")
+    ap.add_argument("--dropout", type=float, default=0.3)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    return ap.parse_args()
+
+
+def synthetic(n, rank, dev):
+    """uint8 frames + targets, seeds rank*3 + {0,1,2}."""
+    def gen(s):
+        return torch.Generator().manual_seed(rank * 3 + s)
+    A = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen(0)).to(dev)
+    B = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen(1)).to(dev)
+    Y = torch.rand(n, generator=gen(2)).to(dev)
+    return A, B, Y
+
+
+def g1_weights():
+    import numpy as np
+    raw = dict(np.load(os.path.join(REPO, "tests", "golden", "g1_weights_chfak1.npz")))
+    pc = {k.split("/", 1)[1]: torch.from_numpy(v) for k, v in raw.items() if k.startswith("critic/")}
+    pm = {k.split("/", 1)[1]: torch.from_numpy(v) for k, v in raw.items() if k.startswith("masker/")}
+    return pc, pm
+
+
+def cpu_baseline(n, steps, dropout):
+    """Times the CPU oracle (test infrastructure, used here ONLY as the reported baseline) on the host cores."""
+    from oracle import hourglass_ref as orc
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, int(os.environ.get("CGS_CPU_THREADS", "16"))))   # the GPU box's CPU share is 16
+    torch.set_num_threads(threads)
+    print(f"[bench] cpu baseline: {threads} threads (affinity {avail}, cpu_count {os.cpu_count()})", file=sys.stderr, flush=True)
+    pc, pm = g1_weights()
+    gen = torch.Generator().manual_seed(0)
+    A = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen)
+    B = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=gen)
+    Y = torch.rand(n, generator=gen)
+    Pc, Pm = orc.leafify(pc), orc.leafify(pm)
+    tensors = list(Pc.values()) + list(Pm.values())
+    opt = orc.AdamRef(tensors)
+
+    def one():
+        for t in tensors:
+            t.grad = None
+        total, *_ = orc.phase2_loss(Pc, Pm, orc.u8_to_nchw(A), orc.u8_to_nchw(B), Y, p=dropout, training=True)
+        total.backward()
+        opt.step([t.grad for t in tensors])
+
+    tw = time.perf_counter()
+    one()
+    print(f"[bench] cpu baseline warm-up step {time.perf_counter() - tw:.2f}s", file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(steps):
+        one()
+        done += 1
+        if time.perf_counter() - t0 > 30.0:      # bounded sample
+            break
+    dt = (time.perf_counter() - t0) / done
+    steps = done
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as fp:
+            for line in fp:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} phase-2 train steps of the same N={n} workload (1 warm-up), PyTorch CPU fp32, dropout {dropout}",
+            "ms_per_step": dt * 1e3, "cpu_model": model}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from cgs_amd import engine
+    n = args.batch
+    eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg)
+    eng.load_state(*g1_weights())
+    A, B, Y = synthetic(n, rank, dev)
+    eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.phase2_step()
+    barrier()
+    stream = torch.cuda.current_stream()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        eng.phase2_step()
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (graph launches go to this stream)
+    losses = eng.losses.cpu().tolist()
+    print(f"[bench] rank {rank}: {args.steps} steps in {wall:.3f}s", file=sys.stderr, flush=True)
+    if world > 1:
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        wall = float(t.item())
+    if rank == 0:
+        ms_step = wall * 1e3 / args.steps
+        launch_ms = dev_ms / args.steps
+        achieved = ALGO_BYTES_PER_IMAGE * n / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Hourglass+critic train images/sec, 64x64x3 batch=512",
+            "value": n * world * args.steps / wall,
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "phase-2 train step (4 critic fwd, 3 critic bwd, decoder fwd+bwd, mix, losses, Adam), "
+                                   "synthetic 64x64x3 uint8 frames resident in HBM, chfak=1, neck=32",
+                       "contrastive_batchsize": n // 2, "N_A": n, "N_B": n, "global_batch": n * world,
+                       "dropout": args.dropout, "lfak": 5, "L1": 0.5, "inject": True, "live": True,
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "one phase-2 step = one HIP-graph launch",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n,
+                         "launch_ms": launch_ms},
+            "final_losses": dict(zip(("critic", "replace", "inject", "l1", "l2", "total"), losses[:6])),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps, args.dropout)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
