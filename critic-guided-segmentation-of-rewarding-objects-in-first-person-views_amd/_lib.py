@@ -48,7 +48,8 @@ SIGNATURES = {
     "cgs_pointwise_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_mix_fwd": (i32, [i32, i32, vp, vp, vp, i32, vp, vp, vp]),
     "cgs_mix_bwd": (i32, [i32, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp]),
-    "cgs_phase2_losses": (i32, [i32, vp, vp, vp, f32, f32, f32, i32, i64, vp, vp, vp]),
+    "cgs_mix_fwd_partials": (i32, [i32, i32]),
+    "cgs_phase2_losses": (i32, [i32, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp, vp, vp]),
     "cgs_phase1_loss": (i32, [i32, vp, vp, i32, vp, vp, vp]),
     "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),

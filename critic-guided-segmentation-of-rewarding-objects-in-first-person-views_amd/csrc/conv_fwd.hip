@@ -33,7 +33,8 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
     constexpr int A_ELEMS = PA * G::IMGS * G::TRA * G::PWA;  // float4 slots (floats for SRC_SCALAR)
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float4* ldsA = smem;
-    float4* ldsB = smem + ((C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS);
+    constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
+    float4* ldsB = smem + DUMP + 1;
 
     const int tid = threadIdx.x;
     const QuadPos q = quad_pos<G>(tid, blockIdx.x);
@@ -52,19 +53,19 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
         load_a_f32c3<G>(ldsA, (const float4*)P.src_a, n0, q.row0, N, tid);
     } else if constexpr (C::SRC == SRC_POOLEXP) {
         load_poolexp<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, q.row0, N, tid,
-                               [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); });
+                               [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
         zero_halo_cols<G, PA>(ldsA, tid);
     } else {  // SRC_SCALAR: one fp32 channel, tile of floats [img][TRA][W+2]
         float* t = (float*)ldsA;
         const float* s = (const float*)P.src_a;
         constexpr int E = G::IMGS * G::TRA * (G::W + 2);
-        for (int e = tid; e < E; e += G::THREADS) {
+        for_elems<E, G::THREADS>(tid, [&](int e) {
             int c = e % (G::W + 2), r = (e / (G::W + 2)) % G::TRA, img = e / ((G::W + 2) * G::TRA);
             int n = n0 + img, y = q.row0 + r - 1, x = c - 1;
-            float v = 0.f;
-            if (n < N && y >= 0 && y < G::H && x >= 0 && x < G::W) v = s[(n * G::H + y) * G::W + x];
-            t[e] = v;
-        }
+            bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+            float v = s[in ? (n * G::H + y) * G::W + x : 0];
+            t[e] = in ? v : 0.f;
+        });
     }
     if constexpr (PB > 0) {
         if constexpr (C::UPS == 2) load_b_half<G, PB>(ldsB, (const float4*)P.src_b, n0, q.row0, N, tid);
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
             for (int i = 0; i < (C::OCB + 7) / 8; ++i) nib[i] = 0;
 #pragma unroll
             for (int o = 0; o < C::OCB; ++o) {
-                float b = wc == nullptr ? 0.f : cgs_to_const(P.bias)[oc0 + o];
+                float b = cgs_to_const(P.bias)[oc0 + o];
                 float m = act_fwd<C::ACT>(acc[0][o] + b);
                 uint32_t idx = 0;
 #pragma unroll
@@ -265,7 +266,7 @@ static size_t conv_lds_bytes() {
     constexpr int PB = C::CB / 4;
     size_t a = (C::SRC == SRC_SCALAR) ? (size_t)((G::IMGS * G::TRA * (G::W + 2) + 3) / 4) : (size_t)PA * G::IMGS * G::TRA * G::PWA;
     size_t b = PB == 0 ? 0 : (C::UPS == 2 ? (size_t)PB * G::IMGS * G::TRB * G::PWB : (size_t)PB * G::IMGS);
-    return (a + b) * sizeof(float4);
+    return (a + b + 1) * sizeof(float4);
 }
 
 template <class C>

@@ -60,7 +60,20 @@ __device__ __forceinline__ QuadPos quad_pos(int tid, int bid) {
 
 // ------------------------------------------------------------------------------------------------
 // Loaders.  n0 = first image of the workgroup, row0 = first conv row.  All write float4 planes.
+// Every loader is a fully unrolled, BRANCH-FREE loop (indices clamped, values zeroed by select, the
+// tail iteration redoes the last element): the global loads of all iterations are independent, so the
+// scheduler issues them back to back instead of paying one memory latency per iteration.
 // ------------------------------------------------------------------------------------------------
+template <int E, int THREADS, class F>
+__device__ __forceinline__ void for_elems(int tid, F f) {
+    constexpr int IT = (E + THREADS - 1) / THREADS;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        int e = tid + it * THREADS;
+        f(e < E ? e : E - 1);
+    }
+}
+
 template <class G, int PA>
 __device__ __forceinline__ int ldsA_idx(int p, int img, int r, int c) {
     return ((p * G::IMGS + img) * G::TRA + r) * G::PWA + G::pc(c);
@@ -69,11 +82,11 @@ __device__ __forceinline__ int ldsA_idx(int p, int img, int r, int c) {
 template <class G, int PA>
 __device__ __forceinline__ void zero_halo_cols(float4* ldsA, int tid) {
     constexpr int E = PA * G::IMGS * G::TRA * 2;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int side = e & 1, rest = e >> 1;
         int r = rest % G::TRA, pi = rest / G::TRA;  // pi = p*IMGS + img
         ldsA[(pi * G::TRA + r) * G::PWA + G::pc(side ? G::W + 1 : 0)] = f4zero();
-    }
+    });
 }
 
 // NHWC fp32 source with CA = 4*PA channels (optionally with dropout fused).
@@ -81,17 +94,15 @@ template <class G, int PA>
 __device__ __forceinline__ void load_a_f32(float4* ldsA, const float4* __restrict__ src, int n0, int row0,
                                            int N, int tid, const DropCtx& dc) {
     constexpr int E = G::IMGS * G::TRA * G::W * PA;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int p = e % PA, x = (e / PA) % G::W, r = (e / (PA * G::W)) % G::TRA, img = e / (PA * G::W * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
-        float4 v = f4zero();
-        if (n < N && y >= 0 && y < G::H) {
-            int gi = ((n * G::H + y) * G::W + x) * PA + p;
-            v = src[gi];
-            if (dc.on) v = v * drop_mult4(dc, (uint32_t)gi);
-        }
-        ldsA[ldsA_idx<G, PA>(p, img, r, x + 1)] = v;
-    }
+        bool in = n < N && y >= 0 && y < G::H;
+        int gi = in ? ((n * G::H + y) * G::W + x) * PA + p : 0;
+        float4 v = src[gi];
+        if (dc.on) v = v * drop_mult4(dc, (uint32_t)gi);
+        ldsA[ldsA_idx<G, PA>(p, img, r, x + 1)] = in ? v : f4zero();
+    });
     zero_halo_cols<G, PA>(ldsA, tid);
 }
 
@@ -102,14 +113,13 @@ __device__ __forceinline__ void load_a_u8c3(float4* ldsA, const uint32_t* __rest
     constexpr int GW = G::W / 4;
     constexpr int E = G::IMGS * G::TRA * GW;
     const float s = 1.f / 255.f;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
-        uint32_t d0 = 0, d1 = 0, d2 = 0;
-        if (n < N && y >= 0 && y < G::H) {
-            int gi = ((n * G::H + y) * G::W + g * 4) * 3 / 4;  // dword index (12 B per 4 pixels)
-            d0 = src[gi]; d1 = src[gi + 1]; d2 = src[gi + 2];
-        }
+        bool in = n < N && y >= 0 && y < G::H;
+        int gi = in ? ((n * G::H + y) * G::W + g * 4) * 3 / 4 : 0;  // dword index (12 B per 4 pixels)
+        uint32_t d0 = src[gi], d1 = src[gi + 1], d2 = src[gi + 2];
+        d0 = in ? d0 : 0u; d1 = in ? d1 : 0u; d2 = in ? d2 : 0u;
         float4 p0 = make_float4((d0 & 255) * s, ((d0 >> 8) & 255) * s, ((d0 >> 16) & 255) * s, 0.f);
         float4 p1 = make_float4((d0 >> 24) * s, (d1 & 255) * s, ((d1 >> 8) & 255) * s, 0.f);
         float4 p2 = make_float4(((d1 >> 16) & 255) * s, (d1 >> 24) * s, (d2 & 255) * s, 0.f);
@@ -119,7 +129,7 @@ __device__ __forceinline__ void load_a_u8c3(float4* ldsA, const uint32_t* __rest
         ldsA[base + G::pc(g * 4 + 2)] = p1;
         ldsA[base + G::pc(g * 4 + 3)] = p2;
         ldsA[base + G::pc(g * 4 + 4)] = p3;
-    }
+    });
     zero_halo_cols<G, 1>(ldsA, tid);
 }
 
@@ -129,20 +139,19 @@ __device__ __forceinline__ void load_a_f32c3(float4* ldsA, const float4* __restr
                                              int N, int tid) {
     constexpr int GW = G::W / 4;
     constexpr int E = G::IMGS * G::TRA * GW;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
-        float4 a = f4zero(), b = f4zero(), c = f4zero();
-        if (n < N && y >= 0 && y < G::H) {
-            int gi = ((n * G::H + y) * G::W + g * 4) * 3 / 4;
-            a = src[gi]; b = src[gi + 1]; c = src[gi + 2];
-        }
+        bool in = n < N && y >= 0 && y < G::H;
+        int gi = in ? ((n * G::H + y) * G::W + g * 4) * 3 / 4 : 0;
+        float4 a = src[gi], b = src[gi + 1], c = src[gi + 2];
+        if (!in) { a = f4zero(); b = f4zero(); c = f4zero(); }
         int base = (img * G::TRA + r) * G::PWA;
         ldsA[base + G::pc(g * 4 + 1)] = make_float4(a.x, a.y, a.z, 0.f);
         ldsA[base + G::pc(g * 4 + 2)] = make_float4(a.w, b.x, b.y, 0.f);
         ldsA[base + G::pc(g * 4 + 3)] = make_float4(b.z, b.w, c.x, 0.f);
         ldsA[base + G::pc(g * 4 + 4)] = make_float4(c.y, c.z, c.w, 0.f);
-    }
+    });
     zero_halo_cols<G, 1>(ldsA, tid);
 }
 
@@ -157,33 +166,32 @@ __device__ __forceinline__ float4 nib_select(const float4& v, uint32_t nib16, ui
 
 // Gradient of a conv+ReLU+maxpool stage, re-expanded to pre-pool resolution on the fly:
 // tile(y,x,c) = dpooled(y/2,x/2,c) if amask nibble == 2*(y&1)+(x&1) else 0   (0xF nibble = ReLU dead).
-// HALO = 1: rows row0-1 .. row0+TH (data-gradient tile); HALO = 0: rows row0 .. row0+TH-1 into a tile with
-// TR rows and row length PW (caller-specified geometry through the index functor).
+// HALO = 1: rows row0-1 .. row0+TH (data-gradient tile); HALO = 0: rows row0 .. row0+TH-1.  idx(p,img,r,x)
+// gives the destination slot; out-of-tile rows are redirected to the caller's dump slot idx(...) = `dump`.
 template <class G, int PA, int HALO, class IdxF>
 __device__ __forceinline__ void load_poolexp(float4* lds, const float4* __restrict__ dp,
                                              const uint32_t* __restrict__ am, int n0, int row0, int N,
-                                             int tid, IdxF idx) {
+                                             int tid, IdxF idx, int dump) {
     constexpr int HP = G::H / 2, WP = G::W / 2;
     constexpr int JR = G::RQ + 2 * HALO;  // pooled rows touched
     constexpr int E = G::IMGS * JR * WP * PA;
     constexpr int AMW = (PA + 1) / 2;     // amask words per pooled pixel
     const int pr0 = row0 / 2 - HALO;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int p = e % PA, px = (e / PA) % WP, j = (e / (PA * WP)) % JR, img = e / (PA * WP * JR);
         int n = n0 + img, pr = pr0 + j;
-        float4 v = f4zero();
-        uint32_t nib = 0xFFFFu;
-        if (n < N && pr >= 0 && pr < HP) {
-            int pi = (n * HP + pr) * WP + px;
-            v = dp[pi * PA + p];
-            nib = (am[pi * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu;
-        }
+        bool in = n < N && pr >= 0 && pr < HP;
+        int pi = in ? (n * HP + pr) * WP + px : 0;
+        float4 v = dp[pi * PA + p];
+        uint32_t nib = (am[pi * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu;
+        nib = in ? nib : 0xFFFFu;
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {
             int r = 2 * j + (pos >> 1) - HALO;  // row inside the tile
-            if (r >= 0 && r < G::TH + 2 * HALO) lds[idx(p, img, r, 2 * px + (pos & 1))] = nib_select(v, nib, pos);
+            bool ok = r >= 0 && r < G::TH + 2 * HALO;
+            lds[ok ? idx(p, img, r, 2 * px + (pos & 1)) : dump] = nib_select(v, nib, pos);
         }
-    }
+    });
 }
 
 // Source B at its own (half) resolution with a 1-pixel zero halo: rows sy0-1 .. sy0+RQ, cols -1 .. QW.
@@ -192,24 +200,25 @@ __device__ __forceinline__ void load_b_half(float4* ldsB, const float4* __restri
                                             int N, int tid) {
     constexpr int E = G::IMGS * G::TRB * G::PWB * PB;
     const int sy0 = row0 / 2;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int p = e % PB, c = (e / PB) % G::PWB, r = (e / (PB * G::PWB)) % G::TRB, img = e / (PB * G::PWB * G::TRB);
         int n = n0 + img, sy = sy0 + r - 1, sx = c - 1;
-        float4 v = f4zero();
-        if (n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW) v = src[((n * G::QH + sy) * G::QW + sx) * PB + p];
-        ldsB[((p * G::IMGS + img) * G::TRB + r) * G::PWB + c] = v;
-    }
+        bool in = n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW;
+        float4 v = src[in ? ((n * G::QH + sy) * G::QW + sx) * PB + p : 0];
+        ldsB[((p * G::IMGS + img) * G::TRB + r) * G::PWB + c] = in ? v : f4zero();
+    });
 }
 
 // Source B that is a single pixel per image (the bottleneck, upsampled x4 to the 4x4 map).
 template <class G, int PB>
 __device__ __forceinline__ void load_b_pix(float4* ldsB, const float4* __restrict__ src, int n0, int N, int tid) {
     constexpr int E = G::IMGS * PB;
-    for (int e = tid; e < E; e += G::THREADS) {
+    for_elems<E, G::THREADS>(tid, [&](int e) {
         int p = e % PB, img = e / PB;
         int n = n0 + img;
-        ldsB[p * G::IMGS + img] = (n < N) ? src[n * PB + p] : f4zero();
-    }
+        float4 v = src[n < N ? n * PB + p : 0];
+        ldsB[p * G::IMGS + img] = (n < N) ? v : f4zero();
+    });
 }
 
 // ------------------------------------------------------------------------------------------------

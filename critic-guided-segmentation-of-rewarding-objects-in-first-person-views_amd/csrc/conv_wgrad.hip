@@ -38,17 +38,22 @@ struct WGeo {
 enum { WSRC_F32 = 0, WSRC_U8 = 1, WDY_F32 = 0, WDY_POOLEXP = 1 };
 
 // C: G (WGeo), SRC (WSRC_*), CA, CB, UPS, CO, DY (WDY_*)
+// X tile: [img][TRA][PWA][PCI] floats, PCI = 4*(SA+SB): source A occupies SA float4 slots per pixel
+// (3-channel images are padded to one slot), source B the following SB slots.
 template <class C>
 __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
     using G = typename C::G;
     constexpr int CI = C::CA + C::CB, CO = C::CO;
+    constexpr int SA = (C::CA + 3) / 4, SB = C::CB / 4, S = SA + SB, PCI = 4 * S;
     constexpr int ROWS = 9 * CI + 1, NRB = (ROWS + 15) / 16;
-    constexpr int XT = G::IMGS * G::TRA * G::PWA * CI;  // floats
+    constexpr int NPIX = G::IMGS * G::TRA * G::PWA;      // tile pixels incl. halo
+    constexpr int XT4 = NPIX * S;                          // float4 slots
     constexpr int YT = G::IMGS * G::TH * G::W * CO;
     static_assert(CO <= 16 && CO % 4 == 0, "one 16-wide column block");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float* xt = (float*)smem;
-    float* yt = xt + ((XT + 3) / 4) * 4;
+    float* yt = xt + XT4 * 4;
+    constexpr int DUMP4 = XT4 + YT / 4;                    // spare float4 slot for redirected stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -61,7 +66,8 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
         int r = rb * 16 + l15;
         if (r < 9 * CI) {
             int tap = r / CI, ci = r % CI;
-            rbase[rb] = ((tap / 3) * G::PWA + (tap % 3)) * CI + ci;
+            int lch = ci < C::CA ? ci : 4 * SA + (ci - C::CA);
+            rbase[rb] = ((tap / 3) * G::PWA + (tap % 3)) * PCI + lch;
         } else {
             rbase[rb] = (r == 9 * CI) ? -1 : -2;
         }
@@ -73,49 +79,73 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n0 = (G::IMGS == 1) ? tile / G::STRIPS : tile * G::IMGS;
         const int row0 = (G::IMGS == 1) ? (tile % G::STRIPS) * G::TH : 0;
-        // ---- X tile: concat(source A, upsampled source B) with zero halo ----
-        for (int e = tid; e < XT; e += G::THREADS) {
-            int ci = e % CI, c = (e / CI) % G::PWA, r = (e / (CI * G::PWA)) % G::TRA, img = e / (CI * G::PWA * G::TRA);
-            int n = n0 + img, y = row0 + r - 1, x = c - 1;
-            float v = 0.f;
-            if (n < N && y >= 0 && y < G::H && x >= 0 && x < G::W) {
-                if (ci < C::CA) {
-                    int gi = ((n * G::H + y) * G::W + x) * C::CA + ci;
-                    if constexpr (C::SRC == WSRC_U8) {
-                        v = ((const uint8_t*)P.src_a)[gi] * (1.f / 255.f);
-                    } else {
-                        v = ((const float*)P.src_a)[gi];
-                        if (dc.on) v *= f4get(drop_mult4(dc, (uint32_t)(gi >> 2)), gi & 3);
-                    }
-                } else if constexpr (C::CB > 0) {
-                    int cb = ci - C::CA;
-                    if constexpr (C::UPS == 2) v = P.src_b[((n * G::QH + (y >> 1)) * G::QW + (x >> 1)) * C::CB + cb];
-                    else v = P.src_b[n * C::CB + cb];
+        // ---- X tile, source A ----
+        if constexpr (C::CA % 4 == 0) {
+            for_elems<NPIX * SA, G::THREADS>(tid, [&](int e) {
+                int s = e % SA, c = (e / SA) % G::PWA, r = (e / (SA * G::PWA)) % G::TRA, img = e / (SA * G::PWA * G::TRA);
+                int n = n0 + img, y = row0 + r - 1, x = c - 1;
+                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+                int gi = in ? ((n * G::H + y) * G::W + x) * SA + s : 0;
+                float4 v = ((const float4*)P.src_a)[gi];
+                if (dc.on) v = v * drop_mult4(dc, (uint32_t)gi);
+                ((float4*)xt)[(e / SA) * S + s] = in ? v : f4zero();
+            });
+        } else {  // 3-channel image: one padded slot per pixel
+            for_elems<NPIX, G::THREADS>(tid, [&](int e) {
+                int c = e % G::PWA, r = (e / G::PWA) % G::TRA, img = e / (G::PWA * G::TRA);
+                int n = n0 + img, y = row0 + r - 1, x = c - 1;
+                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+                int pix = in ? (n * G::H + y) * G::W + x : 0;
+                float4 v;
+                if constexpr (C::SRC == WSRC_U8) {
+                    const uint32_t* s32 = (const uint32_t*)P.src_a;
+                    int off = pix * 3, last = N * G::H * G::W * 3 / 4 - 1;
+                    int d = off >> 2;
+                    uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
+                    uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
+                    const float sc = 1.f / 255.f;
+                    v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+                } else {
+                    const float* sf = (const float*)P.src_a;
+                    v = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
                 }
-            }
-            xt[e] = v;
+                ((float4*)xt)[e * S] = in ? v : f4zero();
+            });
+        }
+        // ---- X tile, source B (nearest-upsampled, materialised at full resolution) ----
+        if constexpr (SB > 0) {
+            for_elems<NPIX * SB, G::THREADS>(tid, [&](int e) {
+                int s = e % SB, c = (e / SB) % G::PWA, r = (e / (SB * G::PWA)) % G::TRA, img = e / (SB * G::PWA * G::TRA);
+                int n = n0 + img, y = row0 + r - 1, x = c - 1;
+                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+                int gi;
+                if constexpr (C::UPS == 2) gi = in ? ((n * G::QH + (y >> 1)) * G::QW + (x >> 1)) * SB + s : 0;
+                else gi = in ? n * SB + s : 0;
+                float4 v = ((const float4*)P.src_b)[gi];
+                ((float4*)xt)[(e / SB) * S + SA + s] = in ? v : f4zero();
+            });
         }
         // ---- dY tile ----
         if constexpr (C::DY == WDY_F32) {
-            constexpr int E4 = YT / 4;
-            const float4* src = (const float4*)P.dy;
-            for (int e = tid; e < E4; e += G::THREADS) {
-                int img = e / (G::TH * G::W * CO / 4), rest = e % (G::TH * G::W * CO / 4);
+            constexpr int PER = G::TH * G::W * CO / 4;
+            for_elems<YT / 4, G::THREADS>(tid, [&](int e) {
+                int img = e / PER, rest = e % PER;
                 int n = n0 + img;
-                float4 v = f4zero();
-                if (n < N) v = src[((size_t)(n * G::H + row0) * G::W * CO) / 4 + rest];
-                ((float4*)yt)[e] = v;
-            }
+                bool in = n < N;
+                float4 v = ((const float4*)P.dy)[in ? ((n * G::H + row0) * G::W * CO) / 4 + rest : 0];
+                ((float4*)yt)[e] = in ? v : f4zero();
+            });
         } else {
             load_poolexp<G, CO / 4, 0>((float4*)yt, (const float4*)P.dy, P.amask, n0, row0, N, tid,
-                                       [](int p, int img, int r, int x) { return ((img * G::TH + r) * G::W + x) * (CO / 4) + p; });
+                                       [](int p, int img, int r, int x) { return ((img * G::TH + r) * G::W + x) * (CO / 4) + p; },
+                                       DUMP4 - XT4);
         }
         __syncthreads();
 
         for (int step = wave; step < G::NSTEP; step += G::NW) {
             int p = step * 4 + kq;
             int x = p % G::W, yl = (p / G::W) % G::TH, img = p / (G::W * G::TH);
-            int pixoff = ((img * G::TRA + yl) * G::PWA + x) * CI;
+            int pixoff = ((img * G::TRA + yl) * G::PWA + x) * PCI;
             float b = (l15 < CO) ? yt[((img * G::TH + yl) * G::W + x) * CO + l15] : 0.f;
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb) {
@@ -126,17 +156,25 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
         __syncthreads();
     }
 
+    // ---- sum the waves' accumulators through LDS (wave by wave), then one coalesced slab per workgroup ----
     // D layout: col = lane & 15 (= co), row = (lane >> 4) * 4 + reg (= r within the row block)
-    float* slab = P.slab + (size_t)(blockIdx.x * G::NW + wave) * (ROWS * CO);
-    if (l15 < CO) {
+    float* red = (float*)smem;
+    static_assert(ROWS * CO <= XT4 * 4 + YT, "reduction buffer fits in the tile storage");
+#pragma unroll 1
+    for (int w = 0; w < G::NW; ++w) {
+        if (wave == w && l15 < CO) {
 #pragma unroll
-        for (int rb = 0; rb < NRB; ++rb)
+            for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int r = rb * 16 + kq * 4 + j;
-                if (r < ROWS) slab[r * CO + l15] = acc[rb][j];
-            }
+                for (int j = 0; j < 4; ++j) {
+                    int r = rb * 16 + kq * 4 + j;
+                    if (r < ROWS) red[r * CO + l15] = (w == 0 ? 0.f : red[r * CO + l15]) + acc[rb][j];
+                }
+        }
+        __syncthreads();
     }
+    float* slab = P.slab + (size_t)blockIdx.x * (ROWS * CO);
+    for (int i = tid; i < ROWS * CO; i += G::THREADS) slab[i] = red[i];
 }
 
 // masker.2 (16 -> 1): a single output channel would waste 15/16 of the MFMA columns, so the product is
@@ -157,15 +195,16 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     float bsum = 0.f;
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n = tile / G::STRIPS, row0 = (tile % G::STRIPS) * G::TH;
-        for (int e = tid; e < XT / 4; e += G::THREADS) {
+        for_elems<XT / 4, G::THREADS>(tid, [&](int e) {
             int q4 = e % (CI / 4), c = (e / (CI / 4)) % G::PWA, r = e / ((CI / 4) * G::PWA);
             int y = row0 + r - 1, x = c - 1;
-            float4 v = f4zero();
-            if (y >= 0 && y < G::H && x >= 0 && x < G::W) v = ((const float4*)P.src_a)[((n * G::H + y) * G::W + x) * (CI / 4) + q4];
-            ((float4*)xt)[e] = v;
-        }
-        for (int e = tid; e < YT / 4; e += G::THREADS)
-            ((float4*)yt)[e] = ((const float4*)P.dy)[((size_t)(n * G::H + row0) * G::W) / 4 + e];
+            bool in = y >= 0 && y < G::H && x >= 0 && x < G::W;
+            float4 v = ((const float4*)P.src_a)[in ? ((n * G::H + y) * G::W + x) * (CI / 4) + q4 : 0];
+            ((float4*)xt)[e] = in ? v : f4zero();
+        });
+        for_elems<YT / 4, G::THREADS>(tid, [&](int e) {
+            ((float4*)yt)[e] = ((const float4*)P.dy)[((n * G::H + row0) * G::W) / 4 + e];
+        });
         __syncthreads();
         for (int step = wave; step < NSTEP; step += G::NW) {
             int p = step * 4 + kq;  // position in the haloed tile
@@ -178,14 +217,26 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
         }
         __syncthreads();
     }
-    float* slab = P.slab + (size_t)(blockIdx.x * G::NW + wave) * (9 * CI + 1);
-    if (l15 < 9) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) slab[l15 * CI + kq * 4 + j] = acc[j];  // row = ci, col = tap
-    }
+    // cross-wave sum through LDS, one slab per workgroup: [tap][ci] (row = ci, col = tap) then dbias
+    float* red = (float*)smem;
     bsum = (l15 == 4) ? bsum : 0.f;
     bsum = wave_sum(bsum);
-    if (lane == 0) slab[9 * CI] = bsum;
+#pragma unroll 1
+    for (int w = 0; w < G::NW; ++w) {
+        if (wave == w) {
+            if (l15 < 9) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int i = l15 * CI + kq * 4 + j;
+                    red[i] = (w == 0 ? 0.f : red[i]) + acc[j];
+                }
+            }
+            if (lane == 0) red[9 * CI] = (w == 0 ? 0.f : red[9 * CI]) + bsum;
+        }
+        __syncthreads();
+    }
+    float* slab = P.slab + (size_t)blockIdx.x * (9 * CI + 1);
+    for (int i = tid; i < 9 * CI + 1; i += G::THREADS) slab[i] = red[i];
 }
 
 #define CGS_WG_CFG(NAME, HW, TH_, IMGS_, SRC_, CA_, CB_, UPS_, CO_, DY_)      \
@@ -207,7 +258,7 @@ CGS_WG_CFG(WMask0U8, 64, 8, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
 CGS_WG_CFG(WMask0F32, 64, 8, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
 using WMask2G = WGeo<64, 64, 8, 1, 256>;
 
-static constexpr int kMaxWgradBlocks = 256;
+static constexpr int kMaxWgradBlocks = 512;
 
 template <class G>
 static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMGS - 1) / G::IMGS; }
@@ -218,7 +269,8 @@ template <class C>
 static int launch_wgrad(WgradParams P, hipStream_t st) {
     using G = typename C::G;
     constexpr int CI = C::CA + C::CB;
-    size_t lds = ((size_t)((G::IMGS * G::TRA * G::PWA * CI + 3) / 4) * 4 + (size_t)G::IMGS * G::TH * G::W * C::CO) * sizeof(float);
+    constexpr int S = (C::CA + 3) / 4 + C::CB / 4;
+    size_t lds = ((size_t)G::IMGS * G::TRA * G::PWA * S * 4 + (size_t)G::IMGS * G::TH * G::W * C::CO + 4) * sizeof(float);
     P.ntiles = wg_tiles<G>(P.n);
     if (P.ntiles == 0) return CGS_OK;
     hipLaunchKernelGGL(wgrad_kernel<C>, dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
@@ -235,7 +287,7 @@ static bool wdesc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int
 extern "C" int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d) {
     if (!d || d->n < 0) return CGS_ERR_BADARG;
     const int n = d->n;
-#define SLABS(CFG) return wg_blocks<typename CFG::G>(n) * CFG::G::NW
+#define SLABS(CFG) return wg_blocks<typename CFG::G>(n)
     if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, 1)) SLABS(WEnc0U8);
     if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc0F32);
     if (wdesc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc1);
@@ -247,7 +299,7 @@ extern "C" int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d) {
     if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec0);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, 0)) SLABS(WMask0U8);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) SLABS(WMask0F32);
-    if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) return wg_blocks<WMask2G>(n) * WMask2G::NW;
+    if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) return wg_blocks<WMask2G>(n);
 #undef SLABS
     return CGS_ERR_UNSUPPORTED;
 }

@@ -10,13 +10,14 @@ __device__ __forceinline__ void unpack12(uint32_t d0, uint32_t d1, uint32_t d2, 
     v[8] = (d2 & 255) * s; v[9] = ((d2 >> 8) & 255) * s; v[10] = ((d2 >> 16) & 255) * s; v[11] = (d2 >> 24) * s;
 }
 
-// one thread = 4 pixels (12 bytes of A and of B, one float4 of Z, 3 float4 of each mix)
+// one thread = 4 pixels (12 bytes of A and of B, one float4 of Z, 3 float4 of each mix); grid-stride.
+// Each workgroup writes its partial (sum |Z|, sum Z^2) to zpart[2*block .. 2*block+1]: no float atomics.
 __global__ void __launch_bounds__(256) mix_fwd_kernel(int groups, int rep_groups, const uint32_t* __restrict__ a,
                                                       const uint32_t* __restrict__ b, const float4* __restrict__ z,
-                                                      int inject, float4* __restrict__ mixed, float* __restrict__ zsum) {
-    int g = blockIdx.x * 256 + threadIdx.x;
+                                                      int inject, float4* __restrict__ mixed, float* __restrict__ zpart) {
+    __shared__ float red[2][4];
     float s1 = 0.f, s2 = 0.f;
-    if (g < groups) {
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
         float av[12], bv[12];
         unpack12(a[3 * g], a[3 * g + 1], a[3 * g + 2], av);
         unpack12(b[3 * g], b[3 * g + 1], b[3 * g + 2], bv);
@@ -41,9 +42,11 @@ __global__ void __launch_bounds__(256) mix_fwd_kernel(int groups, int rep_groups
     }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&zsum[0], s1);
-        atomicAdd(&zsum[1], s2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        zpart[2 * blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        zpart[2 * blockIdx.x + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
 }
 
@@ -88,10 +91,10 @@ __global__ void __launch_bounds__(256) mix_bwd_kernel(int groups, const uint32_t
 
 // single workgroup; pred slots [B | A | replaced | injected]
 __global__ void __launch_bounds__(256) phase2_losses_kernel(int n, const float* __restrict__ pred, const float* __restrict__ y,
-                                                            const float* __restrict__ zsum, float lfak, float l1, float l2,
-                                                            int flags, float inv_nz, float* __restrict__ losses,
-                                                            float* __restrict__ dpred) {
-    __shared__ float red[3][4];
+                                                            const float* __restrict__ zpart, int nzpart, float lfak,
+                                                            float l1, float l2, int flags, float inv_nz,
+                                                            float* __restrict__ losses, float* __restrict__ dpred) {
+    __shared__ float red[5][4];
     const bool live = flags & 1, inject = flags & 2, bce = flags & 4;
     const float inv_n = 1.f / (float)n;
     float sc = 0.f, sr = 0.f, si = 0.f;
@@ -121,14 +124,20 @@ __global__ void __launch_bounds__(256) phase2_losses_kernel(int n, const float* 
             dpred[3 * n + i] = 2.f * dip * inv_n;
         }
     }
-    sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sc; red[1][threadIdx.x >> 6] = sr; red[2][threadIdx.x >> 6] = si; }
+    float z1 = 0.f, z2 = 0.f;
+    for (int i = threadIdx.x; i < nzpart; i += 256) { z1 += zpart[2 * i]; z2 += zpart[2 * i + 1]; }
+    sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si); z1 = wave_sum(z1); z2 = wave_sum(z2);
+    if ((threadIdx.x & 63) == 0) {
+        int w = threadIdx.x >> 6;
+        red[0][w] = sc; red[1][w] = sr; red[2][w] = si; red[3][w] = z1; red[4][w] = z2;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         float c = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * inv_n;
         float r = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) * inv_n;
         float i = (red[2][0] + red[2][1] + red[2][2] + red[2][3]) * inv_n;
-        float n1 = l1 * zsum[0] * inv_nz, n2 = l2 * zsum[1] * inv_nz;
+        float zs1 = (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]), zs2 = (red[4][0] + red[4][1]) + (red[4][2] + red[4][3]);
+        float n1 = l1 * zs1 * inv_nz, n2 = l2 * zs2 * inv_nz;
         losses[0] = c; losses[1] = r; losses[2] = i; losses[3] = n1; losses[4] = n2;
         losses[5] = (live ? lfak * c : 0.f) + r + i + n1 + n2;
         losses[6] = 0.f; losses[7] = 0.f;
@@ -158,25 +167,32 @@ __global__ void __launch_bounds__(256) phase1_loss_kernel(int n, const float* __
     if (threadIdx.x == 0) losses[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n;
 }
 
-// grid = (ceil(max_count/256), njobs)
+// grid = (ceil(max_count/32), njobs); block = 32 columns x 8 slab lanes (coalesced 128-B rows)
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
+    __shared__ float red[8][33];
     const cgs_reduce_job j = jobs[blockIdx.y];
-    int i = blockIdx.x * 256 + threadIdx.x;
+    if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
+    if (blockIdx.x * 32 >= j.count) return;
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (i < j.count) {
         const float* p = j.slab + i;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int b = 0;
-        for (; b + 4 <= j.nslab; b += 4) {
+        int b = sl;
+        for (; b + 24 < j.nslab; b += 32) {
             s0 += p[(size_t)b * j.stride];
-            s1 += p[(size_t)(b + 1) * j.stride];
-            s2 += p[(size_t)(b + 2) * j.stride];
-            s3 += p[(size_t)(b + 3) * j.stride];
+            s1 += p[(size_t)(b + 8) * j.stride];
+            s2 += p[(size_t)(b + 16) * j.stride];
+            s3 += p[(size_t)(b + 24) * j.stride];
         }
-        for (; b < j.nslab; ++b) s0 += p[(size_t)b * j.stride];
-        float s = (s0 + s1) + (s2 + s3);
+        for (; b < j.nslab; b += 8) s0 += p[(size_t)b * j.stride];
+    }
+    red[sl][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < j.count) {
+        float s = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
         j.dst[i] = j.accumulate ? j.dst[i] + s : s;
     }
-    if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(long count, float* __restrict__ p, const float* __restrict__ g,
@@ -223,13 +239,20 @@ __global__ void __launch_bounds__(256) dropout_mask_kernel(long count4, cgs_drop
 }
 
 // ------------------------------------------------------------------------------------------------
+static int mix_blocks(int groups) { int b = (groups + 255) / 256; return b < 1024 ? b : 1024; }
+
+extern "C" int cgs_mix_fwd_partials(int32_t n, int32_t hw) {
+    if (n < 0 || hw <= 0 || (hw & 3)) return CGS_ERR_BADARG;
+    return mix_blocks(n * (hw / 4));
+}
+
 extern "C" int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, int32_t inject,
-                           float* mixed, float* zsum, cgs_stream_t stream) {
-    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !mixed || !zsum) return CGS_ERR_BADARG;
+                           float* mixed, float* zpart, cgs_stream_t stream) {
+    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !mixed || !zpart) return CGS_ERR_BADARG;
     int groups = n * (hw / 4);
     if (groups == 0) return CGS_OK;
-    hipLaunchKernelGGL(mix_fwd_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, groups, groups,
-                       (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, inject, (float4*)mixed, zsum);
+    hipLaunchKernelGGL(mix_fwd_kernel, dim3(mix_blocks(groups)), dim3(256), 0, (hipStream_t)stream, groups, groups,
+                       (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, inject, (float4*)mixed, zpart);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -246,11 +269,12 @@ extern "C" int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_
     return CGS_OK;
 }
 
-extern "C" int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zsum, float lfak, float l1,
-                                 float l2, int32_t flags, int64_t nz, float* losses, float* dpred, cgs_stream_t stream) {
-    if (n <= 0 || nz <= 0 || !pred || !y || !zsum || !losses || !dpred) return CGS_ERR_BADARG;
-    hipLaunchKernelGGL(phase2_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, pred, y, zsum, lfak, l1, l2,
-                       flags, 1.f / (float)nz, losses, dpred);
+extern "C" int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zpart, int32_t nzpart,
+                                 float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses, float* dpred,
+                                 cgs_stream_t stream) {
+    if (n <= 0 || nz <= 0 || nzpart < 0 || !pred || !y || !zpart || !losses || !dpred) return CGS_ERR_BADARG;
+    hipLaunchKernelGGL(phase2_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, pred, y, zpart, nzpart, lfak, l1,
+                       l2, flags, 1.f / (float)nz, losses, dpred);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -266,7 +290,7 @@ extern "C" int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int
 extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step,
                                 cgs_stream_t stream) {
     if (!jobs || njobs <= 0 || max_count <= 0) return CGS_ERR_BADARG;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 255) / 256, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 31) / 32, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -63,7 +63,8 @@ class HourglassEngine:
             self.cbuf[f"am{i}"] = z(n4, hw // 2, hw // 2, co // 8, dt=torch.int32)
         self.cbuf["e4"], self.cbuf["h1"], self.cbuf["pred"] = z(n4, 32), z(n4, 32), z(n4)
         self.mbuf: Dict[str, torch.Tensor] = {}
-        self.zsum, self.losses, self.dpred = z(2), z(8), z(n4)
+        self.nzpart = _lib.load().cgs_mix_fwd_partials(n, 4096)
+        self.zsum, self.losses, self.dpred = z(2 * self.nzpart), z(8), z(n4)
         self.dmixed = z(2 * n, 64, 64, 3)
         self.dzpre = z(n, 64, 64)
         self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "p1": {}}
@@ -133,7 +134,6 @@ class HourglassEngine:
         n = self.n
         nmix = 2 * n if self.inject else n
         drop = self.drop
-        self.zsum.zero_()
         A = self.ab[n:]
         B = self.ab[:n]
         # critic on [B | A]
@@ -144,7 +144,7 @@ class HourglassEngine:
         _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
         hg.critic_forward(self.fc, self.lc, self.mixed[:nmix], nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
-        _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.lfak, self.L1, self.L2,
+        _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
                   flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
         plan = self._plans.get("p2")
         first = plan is None

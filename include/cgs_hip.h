@@ -142,9 +142,11 @@ int cgs_pointwise_bwd(int32_t n, int32_t ci, int32_t co, const float* x, const f
 /* ---- mask replace / inject mix (main.py:395,406) --------------------------------------
  *   rep = A(1-Z) + Z B,  inj = B(1-Z) + Z A  with A,B uint8 NHWC (/255 fused), Z [n,64,64].
  *   mixed : [2n,h,w,3] fp32 (rep images then inj images; inj skipped when inject == 0)
- *   zsum  : device float[2], (sum |Z|, sum Z^2) ACCUMULATED (caller zeroes).                */
+ *   zpart : device float[2 * cgs_mix_fwd_partials(n,hw)]: per-workgroup partial (sum |Z|, sum Z^2),
+ *           summed by cgs_phase2_losses (fixed order: no float atomics).                    */
+int cgs_mix_fwd_partials(int32_t n, int32_t hw);
 int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z,
-                int32_t inject, float* mixed, float* zsum, cgs_stream_t stream);
+                int32_t inject, float* mixed, float* zpart, cgs_stream_t stream);
 /* dzpre = (sum_c (B-A)_c (dRep_c - dInj_c) + l1*sign(Z) + 2*l2*Z) * Z(1-Z): the gradient w.r.t. the
  * mask head's pre-sigmoid output, regularisers (main.py:421-429) included. */
 int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z,
@@ -152,12 +154,12 @@ int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const
                 float* dzpre, cgs_stream_t stream);
 
 /* ---- losses (main.py:380-384,400,411,421-429 and main.py:192-195) --------------------
- * pred layout [4n]: slots [B | A | replaced | injected].  y [n].  zsum from cgs_mix_fwd.
+ * pred layout [4n]: slots [B | A | replaced | injected].  y [n].  zpart/nzpart from cgs_mix_fwd.
  * losses[8] = {critic, replace, inject, l1, l2, total, 0, 0};  dpred [4n] = d total / d pred.
  * flags: bit0 live, bit1 inject, bit2 bce (--threshrew).  nz = n*h*w (mask elements).        */
-int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zsum,
-                      float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses,
-                      float* dpred, cgs_stream_t stream);
+int cgs_phase2_losses(int32_t n, const float* pred, const float* y, const float* zpart,
+                      int32_t nzpart, float lfak, float l1, float l2, int32_t flags, int64_t nz,
+                      float* losses, float* dpred, cgs_stream_t stream);
 /* phase 1: loss = mse(pred, y) or bce; losses[0] = loss; dpred [n]. */
 int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int32_t bce, float* losses,
                     float* dpred, cgs_stream_t stream);
