@@ -26,8 +26,8 @@ enum { EPI_POOL = 0, EPI_PLAIN = 1, EPI_DGRAD = 2 };
 // OC0, OC (logical output channel window), OCB (register block), EPI, ACT, OUT_A (dgrad: channels that
 // belong to source A), POST_ACT (dgrad: activation whose derivative multiplies d_a).
 template <class C>
-__global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
-    using G = Geo<C::H, C::W, C::THREADS>;
+__global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams P) {
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
     constexpr int PB = C::CB / 4;
     constexpr int A_ELEMS = PA * G::IMGS * G::TRA * G::PWA;  // float4 slots (floats for SRC_SCALAR)
@@ -36,8 +36,10 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
     constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
     float4* ldsB = smem + DUMP + 1;
 
-    const int tid = threadIdx.x;
-    const QuadPos q = quad_pos<G>(tid, blockIdx.x);
+    const int tid = threadIdx.x;                 // all threads take part in the loads
+    const int qtid = tid % C::THREADS;           // quad handled by this thread
+    const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
+    const QuadPos q = quad_pos<G>(qtid, blockIdx.x);
     const int n0 = (G::IMGS == 1) ? q.n : blockIdx.x * G::IMGS;
     const int N = P.n;
     const DropCtx dc = drop_ctx(P.drop);
@@ -59,7 +61,7 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
         float* t = (float*)ldsA;
         const float* s = (const float*)P.src_a;
         constexpr int E = G::IMGS * G::TRA * (G::W + 2);
-        for_elems<E, G::THREADS>(tid, [&](int e) {
+        for_elems<E, G::LT>(tid, [&](int e) {
             int c = e % (G::W + 2), r = (e / (G::W + 2)) % G::TRA, img = e / ((G::W + 2) * G::TRA);
             int n = n0 + img, y = q.row0 + r - 1, x = c - 1;
             bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
@@ -87,8 +89,9 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
     constexpr int NCHUNK = C::OC / C::OCB;
     static_assert(C::OC % C::OCB == 0, "chunking");
 
+    static_assert(NCHUNK % C::CW == 0, "chunks split evenly over the chunk waves");
 #pragma unroll 1
-    for (int ch = 0; ch < NCHUNK; ++ch) {
+    for (int ch = cw; ch < NCHUNK; ch += C::CW) {
         const int oc0 = C::OC0 + ch * C::OCB;
         if constexpr (C::EPI == EPI_DGRAD) {  // skip gradients nobody asked for (uniform branch)
             const bool is_a = oc0 < C::OUT_A;
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
                         s[o] += __shfl_xor(s[o], 1, 64);
                         s[o] += __shfl_xor(s[o], 2, 64);
                     }
-                    if (live && (tid & 3) == 0) {
+                    if (live && (qtid & 3) == 0) {
                         float* dst = P.out2 + (size_t)q.n * CBO + (oc0 - C::OUT_A);
 #pragma unroll
                         for (int o = 0; o < C::OCB; ++o) dst[o] = s[o];
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(C::THREADS) conv3x3_kernel(ConvParams P) {
 
 template <class C>
 static size_t conv_lds_bytes() {
-    using G = Geo<C::H, C::W, C::THREADS>;
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
     constexpr int PB = C::CB / 4;
     size_t a = (C::SRC == SRC_SCALAR) ? (size_t)((G::IMGS * G::TRA * (G::W + 2) + 3) / 4) : (size_t)PA * G::IMGS * G::TRA * G::PWA;
@@ -271,10 +274,10 @@ static size_t conv_lds_bytes() {
 
 template <class C>
 static int launch_conv(const ConvParams& P, hipStream_t st) {
-    using G = Geo<C::H, C::W, C::THREADS>;
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     if (P.n <= 0) return CGS_OK;
     int blocks = (G::IMGS == 1) ? P.n * G::STRIPS : (P.n + G::IMGS - 1) / G::IMGS;
-    hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(blocks), dim3(C::THREADS), conv_lds_bytes<C>(), st, P);
+    hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(blocks), dim3(C::THREADS * C::CW), conv_lds_bytes<C>(), st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -282,44 +285,44 @@ static int launch_conv(const ConvParams& P, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // Instance table (chfak = 1 Hourglass).  FWD(name, H, THREADS, SRC, CA, CB, UPS, CO, EPI, ACT)
 // ------------------------------------------------------------------------------------------------
-#define CGS_FWD_CFG(NAME, HW, THR, SRC_, CA_, CB_, UPS_, CO_, EPI_, ACT_)                              \
+#define CGS_FWD_CFG(NAME, HW, THR, SRC_, CA_, CB_, UPS_, CO_, EPI_, ACT_, OCB_, CW_)                   \
     struct NAME {                                                                                      \
         static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = CA_, CB = CB_, UPS = UPS_; \
-        static constexpr int WT = 0, WCI = CA_ + CB_, WCO = CO_, OC0 = 0, OC = CO_, OCB = CO_;          \
+        static constexpr int WT = 0, WCI = CA_ + CB_, WCO = CO_, OC0 = 0, OC = CO_, OCB = OCB_, CW = CW_; \
         static constexpr int EPI = EPI_, ACT = ACT_, OUT_A = 0, POST_ACT = CGS_ACT_NONE;                \
     };
 // data gradient: dY has DYC channels; weights are the layer's HWIO [.,.,LCI,LCO]
-#define CGS_DG_CFG(NAME, HW, THR, SRC_, DYC, LCI, LCO, UPS_, OC0_, OC_, OCB_, OUTA, PACT)              \
+#define CGS_DG_CFG(NAME, HW, THR, SRC_, DYC, LCI, LCO, UPS_, OC0_, OC_, OCB_, OUTA, PACT, CW_)         \
     struct NAME {                                                                                      \
         static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = DYC, CB = 0, UPS = UPS_;   \
-        static constexpr int WT = 1, WCI = LCI, WCO = LCO, OC0 = OC0_, OC = OC_, OCB = OCB_;            \
+        static constexpr int WT = 1, WCI = LCI, WCO = LCO, OC0 = OC0_, OC = OC_, OCB = OCB_, CW = CW_;  \
         static constexpr int EPI = EPI_DGRAD, ACT = CGS_ACT_NONE, OUT_A = OUTA, POST_ACT = PACT;        \
     };
 
-CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU)
-CGS_FWD_CFG(FEnc0F32, 64, 256, SRC_F32C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU)
-CGS_FWD_CFG(FEnc1, 32, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU)
-CGS_FWD_CFG(FEnc2, 16, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU)
-CGS_FWD_CFG(FEnc3, 8, 128, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU)
-CGS_FWD_CFG(FDec3, 4, 64, SRC_F32, 16, 32, 4, 16, EPI_PLAIN, CGS_ACT_NONE)
-CGS_FWD_CFG(FDec2, 8, 128, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE)
-CGS_FWD_CFG(FDec1, 16, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE)
-CGS_FWD_CFG(FDec0, 32, 256, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE)
-CGS_FWD_CFG(FMask0U8, 64, 256, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU)
-CGS_FWD_CFG(FMask0F32, 64, 256, SRC_F32C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU)
-CGS_FWD_CFG(FMask2, 64, 128, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID)
+CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
+CGS_FWD_CFG(FEnc0F32, 64, 256, SRC_F32C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
+CGS_FWD_CFG(FEnc1, 32, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
+CGS_FWD_CFG(FEnc2, 16, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
+CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 8, 2)
+CGS_FWD_CFG(FDec3, 4, 64, SRC_F32, 16, 32, 4, 16, EPI_PLAIN, CGS_ACT_NONE, 4, 4)
+CGS_FWD_CFG(FDec2, 8, 64, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
+CGS_FWD_CFG(FDec1, 16, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
+CGS_FWD_CFG(FDec0, 32, 256, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
+CGS_FWD_CFG(FMask0U8, 64, 256, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 16, 1)
+CGS_FWD_CFG(FMask0F32, 64, 256, SRC_F32C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 16, 1)
+CGS_FWD_CFG(FMask2, 64, 128, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID, 1, 1)
 
-//          name     HW  THR  SRC          DYC LCI LCO UPS OC0 OC OCB OUT_A post-act
-CGS_DG_CFG(DEnc0, 64, 256, SRC_POOLEXP, 8, 3, 8, 2, 0, 3, 3, 3, CGS_ACT_NONE)
-CGS_DG_CFG(DEnc1, 32, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DEnc2, 16, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DEnc3, 8, 128, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DDec3, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE)
-CGS_DG_CFG(DDec2, 8, 128, SRC_F32, 8, 24, 8, 2, 0, 24, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DDec1, 16, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DDec0, 32, 256, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE)
-CGS_DG_CFG(DMask0, 64, 128, SRC_F32, 16, 11, 16, 2, 3, 8, 8, 3, CGS_ACT_NONE)
-CGS_DG_CFG(DMask2, 64, 256, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 16, 16, CGS_ACT_LRELU)
+//          name     HW  THR  SRC          DYC LCI LCO UPS OC0 OC OCB OUT_A post-act       CW
+CGS_DG_CFG(DEnc0, 64, 256, SRC_POOLEXP, 8, 3, 8, 2, 0, 3, 3, 3, CGS_ACT_NONE, 1)
+CGS_DG_CFG(DEnc1, 32, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE, 1)
+CGS_DG_CFG(DEnc2, 16, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE, 1)
+CGS_DG_CFG(DEnc3, 8, 64, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)
+CGS_DG_CFG(DDec3, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 6)
+CGS_DG_CFG(DDec2, 8, 64, SRC_F32, 8, 24, 8, 2, 0, 24, 8, 8, CGS_ACT_NONE, 3)
+CGS_DG_CFG(DDec1, 16, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
+CGS_DG_CFG(DDec0, 32, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
+CGS_DG_CFG(DMask0, 64, 128, SRC_F32, 16, 11, 16, 2, 3, 8, 8, 3, CGS_ACT_NONE, 1)
+CGS_DG_CFG(DMask2, 64, 128, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 8, 16, CGS_ACT_LRELU, 2)
 
 static bool desc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int src, int ups, int act, int pool) {
     return d->h == hw && d->w == hw && d->ca == ca && d->cb == cb && d->co == co && d->src_a == src &&

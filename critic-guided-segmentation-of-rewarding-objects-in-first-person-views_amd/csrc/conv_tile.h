@@ -20,9 +20,11 @@
 
 enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4 };
 
-template <int H_, int W_, int THREADS_>
+// THREADS = quads per workgroup; CW = waves-groups that split the output-channel chunks of those quads
+// between them (small images: more waves per image); LT = threads that take part in the tile loads.
+template <int H_, int W_, int THREADS_, int CW_ = 1>
 struct Geo {
-    static constexpr int H = H_, W = W_, THREADS = THREADS_;
+    static constexpr int H = H_, W = W_, THREADS = THREADS_, CW = CW_, LT = THREADS_ * CW_;
     static constexpr int QW = W / 2, QH = H / 2, Q = QW * QH;
     static constexpr int IMGS = (Q >= THREADS) ? 1 : THREADS / Q;
     static constexpr int RQ = (Q >= THREADS) ? THREADS / QW : QH;  // quad rows per workgroup
@@ -82,7 +84,7 @@ __device__ __forceinline__ int ldsA_idx(int p, int img, int r, int c) {
 template <class G, int PA>
 __device__ __forceinline__ void zero_halo_cols(float4* ldsA, int tid) {
     constexpr int E = PA * G::IMGS * G::TRA * 2;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int side = e & 1, rest = e >> 1;
         int r = rest % G::TRA, pi = rest / G::TRA;  // pi = p*IMGS + img
         ldsA[(pi * G::TRA + r) * G::PWA + G::pc(side ? G::W + 1 : 0)] = f4zero();
@@ -94,7 +96,7 @@ template <class G, int PA>
 __device__ __forceinline__ void load_a_f32(float4* ldsA, const float4* __restrict__ src, int n0, int row0,
                                            int N, int tid, const DropCtx& dc) {
     constexpr int E = G::IMGS * G::TRA * G::W * PA;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int p = e % PA, x = (e / PA) % G::W, r = (e / (PA * G::W)) % G::TRA, img = e / (PA * G::W * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
         bool in = n < N && y >= 0 && y < G::H;
@@ -113,7 +115,7 @@ __device__ __forceinline__ void load_a_u8c3(float4* ldsA, const uint32_t* __rest
     constexpr int GW = G::W / 4;
     constexpr int E = G::IMGS * G::TRA * GW;
     const float s = 1.f / 255.f;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
         bool in = n < N && y >= 0 && y < G::H;
@@ -139,7 +141,7 @@ __device__ __forceinline__ void load_a_f32c3(float4* ldsA, const float4* __restr
                                              int N, int tid) {
     constexpr int GW = G::W / 4;
     constexpr int E = G::IMGS * G::TRA * GW;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
         int n = n0 + img, y = row0 + r - 1;
         bool in = n < N && y >= 0 && y < G::H;
@@ -177,7 +179,7 @@ __device__ __forceinline__ void load_poolexp(float4* lds, const float4* __restri
     constexpr int E = G::IMGS * JR * WP * PA;
     constexpr int AMW = (PA + 1) / 2;     // amask words per pooled pixel
     const int pr0 = row0 / 2 - HALO;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int p = e % PA, px = (e / PA) % WP, j = (e / (PA * WP)) % JR, img = e / (PA * WP * JR);
         int n = n0 + img, pr = pr0 + j;
         bool in = n < N && pr >= 0 && pr < HP;
@@ -200,7 +202,7 @@ __device__ __forceinline__ void load_b_half(float4* ldsB, const float4* __restri
                                             int N, int tid) {
     constexpr int E = G::IMGS * G::TRB * G::PWB * PB;
     const int sy0 = row0 / 2;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int p = e % PB, c = (e / PB) % G::PWB, r = (e / (PB * G::PWB)) % G::TRB, img = e / (PB * G::PWB * G::TRB);
         int n = n0 + img, sy = sy0 + r - 1, sx = c - 1;
         bool in = n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void load_b_half(float4* ldsB, const float4* __restri
 template <class G, int PB>
 __device__ __forceinline__ void load_b_pix(float4* ldsB, const float4* __restrict__ src, int n0, int N, int tid) {
     constexpr int E = G::IMGS * PB;
-    for_elems<E, G::THREADS>(tid, [&](int e) {
+    for_elems<E, G::LT>(tid, [&](int e) {
         int p = e % PB, img = e / PB;
         int n = n0 + img;
         float4 v = src[n < N ? n * PB + p : 0];

@@ -27,7 +27,7 @@ struct WgradParams {
 
 template <int H_, int W_, int TH_, int IMGS_, int THREADS_>
 struct WGeo {
-    static constexpr int H = H_, W = W_, TH = TH_, IMGS = IMGS_, THREADS = THREADS_;
+    static constexpr int H = H_, W = W_, TH = TH_, IMGS = IMGS_, THREADS = THREADS_, LT = THREADS_;
     static constexpr int RQ = TH / 2, QW = W / 2, QH = H / 2;  // for load_poolexp
     static constexpr int TRA = TH + 2, PWA = W + 2, STRIPS = H / TH;
     static constexpr int NSTEP = IMGS * TH * W / 4, NW = THREADS / 64;
@@ -142,16 +142,27 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
         }
         __syncthreads();
 
-        for (int step = wave; step < G::NSTEP; step += G::NW) {
-            int p = step * 4 + kq;
-            int x = p % G::W, yl = (p / G::W) % G::TH, img = p / (G::W * G::TH);
-            int pixoff = ((img * G::TRA + yl) * G::PWA + x) * PCI;
-            float b = (l15 < CO) ? yt[((img * G::TH + yl) * G::W + x) * CO + l15] : 0.f;
+        // 4 k-steps per iteration: all LDS reads of the four steps are issued before the MFMAs that consume them
+        constexpr int U = 4;
+        for (int step = wave; step < G::NSTEP; step += G::NW * U) {
+            float a[U][NRB], b[U];
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) {
-                float a = (rbase[rb] >= 0) ? xt[rbase[rb] + pixoff] : (rbase[rb] == -1 ? 1.f : 0.f);
-                acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[rb], 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                int st = step + u * G::NW;
+                bool ok = st < G::NSTEP;
+                int p = (ok ? st : 0) * 4 + kq;
+                int x = p % G::W, yl = (p / G::W) % G::TH, img = p / (G::W * G::TH);
+                int pixoff = ((img * G::TRA + yl) * G::PWA + x) * PCI;
+                b[u] = (ok && l15 < CO) ? yt[((img * G::TH + yl) * G::W + x) * CO + l15] : 0.f;
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    a[u][rb] = (rbase[rb] >= 0) ? xt[rbase[rb] + pixoff] : (rbase[rb] == -1 ? 1.f : 0.f);
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rb], b[u], acc[rb], 0, 0, 0);
         }
         __syncthreads();
     }
@@ -206,14 +217,23 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
             ((float4*)yt)[e] = ((const float4*)P.dy)[((n * G::H + row0) * G::W) / 4 + e];
         });
         __syncthreads();
-        for (int step = wave; step < NSTEP; step += G::NW) {
-            int p = step * 4 + kq;  // position in the haloed tile
-            int c = p % G::PWA, r = p / G::PWA;
-            float a = xt[p * CI + l15];
-            int yl = r - ky, x = c - kx;
-            float b = (l15 < 9 && yl >= 0 && yl < G::TH && x >= 0 && x < G::W) ? yt[yl * G::W + x] : 0.f;
-            if (l15 == 4) bsum += b;  // centre tap sees every dY of the tile exactly once
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        constexpr int U = 4;
+        for (int step = wave; step < NSTEP; step += G::NW * U) {
+            float a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                int st = step + u * G::NW;
+                bool ok = st < NSTEP;
+                int p = (ok ? st : 0) * 4 + kq;  // position in the haloed tile
+                int c = p % G::PWA, r = p / G::PWA;
+                a[u] = xt[p * CI + l15];
+                int yl = r - ky, x = c - kx;
+                bool in = ok && l15 < 9 && yl >= 0 && yl < G::TH && x >= 0 && x < G::W;
+                b[u] = in ? yt[(in ? yl : 0) * G::W + (in ? x : 0)] : 0.f;
+                if (l15 == 4) bsum += b[u];  // centre tap sees every dY of the tile exactly once
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -245,20 +265,20 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
         static constexpr int SRC = SRC_, CA = CA_, CB = CB_, UPS = UPS_, CO = CO_, DY = DY_; \
     };
 
-CGS_WG_CFG(WEnc0U8, 64, 16, 1, WSRC_U8, 3, 0, 2, 8, WDY_POOLEXP)
-CGS_WG_CFG(WEnc0F32, 64, 16, 1, WSRC_F32, 3, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc0U8, 64, 8, 1, WSRC_U8, 3, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc0F32, 64, 8, 1, WSRC_F32, 3, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc1, 32, 16, 1, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc2, 16, 16, 2, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc3, 8, 8, 8, WSRC_F32, 8, 0, 2, 16, WDY_POOLEXP)
 CGS_WG_CFG(WDec3, 4, 4, 4, WSRC_F32, 16, 32, 4, 16, WDY_F32)
 CGS_WG_CFG(WDec2, 8, 8, 4, WSRC_F32, 8, 16, 2, 8, WDY_F32)
 CGS_WG_CFG(WDec1, 16, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
-CGS_WG_CFG(WDec0, 32, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
-CGS_WG_CFG(WMask0U8, 64, 8, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
-CGS_WG_CFG(WMask0F32, 64, 8, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
-using WMask2G = WGeo<64, 64, 8, 1, 256>;
+CGS_WG_CFG(WDec0, 32, 8, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
+CGS_WG_CFG(WMask0U8, 64, 4, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
+CGS_WG_CFG(WMask0F32, 64, 4, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
+using WMask2G = WGeo<64, 64, 4, 1, 256>;
 
-static constexpr int kMaxWgradBlocks = 512;
+static constexpr int kMaxWgradBlocks = 1024;
 
 template <class G>
 static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMGS - 1) / G::IMGS; }

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int n, const float* __res
 // head backward: each workgroup walks HB_IPB images in chunks of 8 and keeps its weight-gradient
 // partials in registers; one slab per workgroup: [w4 8192 | b4 32 | w1 1024 | b1 32 | w2 32 | b2 1].
 // ------------------------------------------------------------------------------------------------
-static constexpr int HB_IPB = 32;
+static constexpr int HB_IPB = 8;
 static constexpr int HB_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1;
 
 __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* __restrict__ e3, const float* __restrict__ e4,
