@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from . import hourglass as hg
+from . import parallel
 from .spec import ENC_LAYERS, critic_layout, masker_layout
 
 _P = hg._p
@@ -33,7 +34,7 @@ class HourglassEngine:
     def __init__(self, n: int, device="cuda:0", dropout: float = 0.3, lfak: float = 5, L1: float = 0.5, L2: float = 0.0,
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
-                 process_group=None):
+                 process_group=None, share_with: "HourglassEngine" = None):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -48,10 +49,14 @@ class HourglassEngine:
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         self.total = self.off_m + self.lm.total
         z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
-        self.flat, self.grad, self.m, self.v = z(self.total), z(self.total), z(self.total), z(self.total)
+        if share_with is not None:   # another batch size over the SAME parameters / optimiser state
+            self.flat, self.grad, self.m, self.v, self.step_t = (share_with.flat, share_with.grad, share_with.m,
+                                                                 share_with.v, share_with.step_t)
+        else:
+            self.flat, self.grad, self.m, self.v = z(self.total), z(self.total), z(self.total), z(self.total)
+            self.step_t = z(1, dt=torch.int64)
         self.fc, self.fm = self.flat[:self.lc.total], self.flat[self.off_m:]
         self.gc, self.gm = self.grad[:self.lc.total], self.grad[self.off_m:]
-        self.step_t = z(1, dt=torch.int64)
         self.drop = hg.DropState(self.p, seed, self.step_t)
         n4 = 4 * n
         self.ab = z(2 * n, 64, 64, 3, dt=torch.uint8)       # [B | A]
@@ -77,6 +82,7 @@ class HourglassEngine:
             self.lc.flatten({k: v.to(self.dev) for k, v in critic_sd.items()}, self.fc)
         if masker_sd is not None:
             self.lm.flatten({k: v.to(self.dev) for k, v in masker_sd.items()}, self.fm)
+        parallel.broadcast_params_(self.flat, self.pg)    # replicas start identical
 
     def critic_state(self):
         return self.lc.unflatten(self.fc)
@@ -127,7 +133,7 @@ class HourglassEngine:
     def _allreduce(self):
         if self.pg is not None and self.world > 1:
             lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
-            torch.distributed.all_reduce(self.grad[lo:lo + cnt], group=self.pg)
+            parallel.allreduce_sum_(self.grad[lo:lo + cnt], self.pg)
 
     # ---- phase 2 -----------------------------------------------------------------------------
     def _phase2_fwd_bwd(self):
@@ -226,7 +232,7 @@ class HourglassEngine:
         adam = self._adam if tag == "p2" else self._adam_p1
         if tag == "p1" and self.pg is not None and self.world > 1:
             def allred():
-                torch.distributed.all_reduce(self.grad[:self.lc.total], group=self.pg)
+                parallel.allreduce_sum_(self.grad[:self.lc.total], self.pg)
         else:
             allred = self._allreduce
         g = self._graphs.get(tag)

@@ -1,0 +1,198 @@
+"""Drop-in module API of the reference's ``nets.py`` for the two networks ``main.py`` instantiates:
+
+    NewCritic(width, dims, bottleneck, colorchs, chfak, activation, pool, dropout).forward(X, collect=False)
+    UnetDecoder(width, edims, ddims, bottleneck, masker_channels, colorchs, chfak, ...).forward(X, embeds)
+
+(reference: nets.py:160-212 and nets.py:452-523).  Same constructor signatures, same call signatures and
+return shapes, same ``state_dict`` keys / OIHW tensors (checkpoints interchange with the reference), and
+they behave as ``nn.Module`` for ``.to() / .train() / .eval() / .parameters()`` and ``torch.optim``.
+
+What differs underneath: each module owns ONE flat fp32 parameter (``.flat``) in the kernels' layout (HWIO
+conv weights, k-major linears) and its forward / backward are HIP kernels through ``libcgs_hip.so``
+(``torch.autograd.Function`` shims).  Activations are NHWC on the device; tensors handed back to the caller
+are NCHW-shaped views with channels-last strides, so any torch op on them sees the reference's values.
+There is no CPU fallback: calling a module whose parameters are not on a HIP device raises.
+"""
+import math
+import os
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import hourglass as hg
+from .spec import critic_layout, masker_layout
+
+
+def _init_like_reference(layout, flat):
+    """PyTorch default init of Conv2d/Linear (kaiming_uniform(a=sqrt 5) weights, U(+-1/sqrt(fan_in)) biases)
+    drawn in the reference's parameter creation order, so ``torch.manual_seed(s)`` before construction gives
+    the same weights as constructing the reference module (same torch version)."""
+    sd = OrderedDict()
+    bound = 0.0
+    for key, seg in layout.segs.items():
+        t = torch.empty(seg.ref_shape)
+        if key.endswith(".weight"):
+            nn.init.kaiming_uniform_(t, a=math.sqrt(5))
+            fan_in = t[0].numel()
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+        else:
+            nn.init.uniform_(t, -bound, bound)
+        sd[key] = t
+    layout.flatten(sd, flat)
+
+
+def _to_nhwc(X: torch.Tensor) -> torch.Tensor:
+    """NCHW (any strides / float dtype) -> NHWC fp32 contiguous.  Layout plumbing only."""
+    if X.dim() != 4 or X.shape[1] != 3 or X.shape[2] != 64 or X.shape[3] != 64:
+        raise _lib.CgsError(f"expected an [N,3,64,64] image batch, got {tuple(X.shape)}")
+    return X.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+
+
+class _HipModule(nn.Module):
+    _layout_fn = None
+
+    def _setup(self, layout, dropout=0.0):
+        self.layout = layout
+        flat = torch.empty(layout.total)
+        _init_like_reference(layout, flat)
+        self.flat = nn.Parameter(flat)
+        self.dropout_p = float(dropout)
+        self.register_buffer("_step", torch.zeros(1, dtype=torch.int64), persistent=False)
+        self._seed = int.from_bytes(os.urandom(4), "little")   # Philox key; does not touch torch's RNG stream
+
+    # ---- checkpoint contract: reference keys, reference (OIHW) tensors ----
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        out = destination if destination is not None else OrderedDict()
+        for k, v in self.layout.unflatten(self.flat).items():
+            out[prefix + k] = v
+        return out
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        sd = {k: v for k, v in state_dict.items()}
+        with torch.no_grad():
+            self.layout.flatten({k: v.to(self.flat.device) for k, v in sd.items()}, self.flat.data)
+        return torch.nn.modules.module._IncompatibleKeys([], [])
+
+    def _need_device(self):
+        if not self.flat.is_cuda:
+            raise _lib.CgsError(f"{type(self).__name__}: parameters are on {self.flat.device}; the HIP kernels need "
+                                "a GPU (call .to('cuda')).  There is no CPU fallback on this path.")
+
+    def _drop_state(self):
+        if self.training and self.dropout_p > 0.0:
+            step = self._step.clone()
+            self._step += 1
+            return hg.DropState(self.dropout_p, self._seed, step)
+        return hg.NO_DROP
+
+
+def _unsupported(what):
+    raise NotImplementedError(f"{what} is not implemented by the HIP kernels of this build (chfak=1, width=64, "
+                              "dims=[8,8,8,16], neck=32, ReLU, max-pool, nearest upsampling are)")
+
+
+class _CriticFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, flat, mod, collect):
+        x = _to_nhwc(X)
+        n = x.shape[0]
+        drop = mod._drop_state()
+        out = hg.critic_forward(flat.detach(), mod.layout, x, n, drop)
+        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out = mod, drop, n, collect, x, out
+        ctx.save_for_backward(flat)
+        pred = out["pred"].view(n, 1)
+        if not collect:
+            return pred
+        return (pred,) + tuple(out[f"e{i}"].permute(0, 3, 1, 2) for i in range(4)) + (out["e4"].view(n, 32, 1, 1),)
+
+    @staticmethod
+    def backward(ctx, dpred, *de):
+        (flat,) = ctx.saved_tensors
+        n, dev = ctx.n, flat.device
+        lay = ctx.mod.layout
+        dp = torch.zeros(n, device=dev) if dpred is None else dpred.reshape(n).to(torch.float32).contiguous()
+        d_embeds = None
+        if ctx.collect and any(d is not None for d in de):
+            shapes = [(n, 32, 32, 8), (n, 16, 16, 8), (n, 8, 8, 8), (n, 4, 4, 16)]
+            d_embeds = []
+            for d, shp in zip(de[:4], shapes):
+                d_embeds.append(torch.zeros(shp, device=dev) if d is None else d.to(torch.float32).permute(0, 2, 3, 1).contiguous())
+            d_embeds.append(torch.zeros((n, 32), device=dev) if de[4] is None else de[4].to(torch.float32).reshape(n, 32).contiguous())
+        dx = torch.empty((n, 64, 64, 3), device=dev) if ctx.needs_input_grad[0] else None
+        plan = hg.SlabPlan()
+        hg.critic_backward(flat.detach(), lay, ctx.x, n, ctx.out, dp, plan, ctx.drop, d_embeds=d_embeds,
+                           n_add=n if d_embeds is not None else 0, dx=dx, dx_from=0)
+        g = torch.empty(lay.total, device=dev)
+        plan.build(g).run()
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), g, None, None
+
+
+class NewCritic(_HipModule):
+    """Encoder + critic head (nets.py:160-212)."""
+
+    def __init__(self, width=64, dims=[8, 8, 8, 16], bottleneck=32, colorchs=3, chfak=1, activation=nn.ReLU, pool="max",
+                 dropout=0.5):
+        super().__init__()
+        if width != 64 or list(dims) != [8, 8, 8, 16] or bottleneck != 32 or colorchs != 3 or chfak != 1:
+            _unsupported(f"NewCritic(width={width}, dims={dims}, bottleneck={bottleneck}, colorchs={colorchs}, chfak={chfak})")
+        if activation is not nn.ReLU or pool != "max":
+            _unsupported(f"NewCritic(activation={activation}, pool={pool})")
+        self.width = width
+        self._setup(critic_layout(chfak, bottleneck, colorchs), dropout)
+
+    def forward(self, X, collect=False):
+        self._need_device()
+        out = _CriticFn.apply(X.to(self.flat.device), self.flat, self, bool(collect))
+        if collect:
+            return out[0], list(out[1:])
+        return out
+
+
+class _MaskerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, e0, e1, e2, e3, e4, flat, mod):
+        x = _to_nhwc(X)
+        n = x.shape[0]
+        embeds = [e.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous() for e in (e0, e1, e2, e3)]
+        embeds.append(e4.detach().to(torch.float32).reshape(n, 32).contiguous())
+        m = hg.masker_forward(flat.detach(), mod.layout, x, embeds, n)
+        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m = mod, n, x, embeds, m
+        ctx.save_for_backward(flat)
+        return m["Z"].view(n, 1, 64, 64)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        (flat,) = ctx.saved_tensors
+        n, lay = ctx.n, ctx.mod.layout
+        Z = ctx.m["Z"]
+        dzpre = (dZ.reshape(n, 64, 64).to(torch.float32) * Z * (1.0 - Z)).contiguous()   # sigmoid'
+        plan = hg.SlabPlan()
+        d_emb = hg.masker_backward(flat.detach(), lay, ctx.x, ctx.embeds, n, ctx.m, dzpre, plan)
+        g = torch.empty(lay.total, device=flat.device)
+        plan.build(g).run()
+        de = [d.permute(0, 3, 1, 2) for d in d_emb[:4]] + [d_emb[4].view(n, 32, 1, 1)]
+        return (None,) + tuple(de) + (g, None)
+
+
+class UnetDecoder(_HipModule):
+    """Decoder + mask head (nets.py:452-523): nearest upsampling, linear trunk, LeakyReLU(0.01) + sigmoid head.
+    The image ``X`` is treated as a constant (the reference never differentiates the mask w.r.t. it)."""
+
+    def __init__(self, width=64, edims=[8, 8, 8, 16], ddims=[8, 8, 8, 16], bottleneck=32, masker_channels=16,
+                 colorchs=3, chfak=1, activation=nn.ReLU, pool="max", upsample=True, pure=False):
+        super().__init__()
+        if (width != 64 or list(edims) != [8, 8, 8, 16] or list(ddims) != [8, 8, 8, 16] or bottleneck != 32 or
+                masker_channels != 16 or colorchs != 3 or chfak != 1 or pool != "max" or not upsample or pure):
+            _unsupported(f"UnetDecoder(width={width}, edims={edims}, ddims={ddims}, bottleneck={bottleneck}, "
+                         f"masker_channels={masker_channels}, chfak={chfak}, pool={pool}, upsample={upsample}, pure={pure})")
+        self.width = width
+        self.masker_channels = masker_channels
+        self._setup(masker_layout(chfak, bottleneck, colorchs, masker_channels))
+
+    def forward(self, X, embeds):
+        self._need_device()
+        dev = self.flat.device
+        e = [t.to(dev) for t in embeds]
+        return _MaskerFn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)

@@ -1,0 +1,236 @@
+"""GPU tests of the drop-in boundary: the nn.Module API driven exactly the way the reference's main.py drives
+it (torch.optim.Adam + F.mse_loss around NewCritic / UnetDecoder), the -train / -process command line on a
+synthetic data set, and the world_size-2 data-parallel engine."""
+import gzip
+import os
+import pickle
+import subprocess
+import sys
+from itertools import chain
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hourglass_ref as orc
+from test_gpu_kernels import rel_close
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def split(raw, prefix):
+    return {k[len(prefix) + 1:]: v for k, v in raw.items() if k.startswith(prefix + "/")}
+
+
+def modules(g1, dropout=0.0):
+    from cgs_amd import nets
+    pc, pm = g1
+    c = nets.NewCritic(bottleneck=32, chfak=1, dropout=dropout).to("cuda")
+    m = nets.UnetDecoder(bottleneck=32, chfak=1).to("cuda")
+    c.load_state_dict(pc)
+    m.load_state_dict(pm)
+    return c, m
+
+
+def test_module_forward_shapes_and_values(golden, g1):
+    g = golden("g2_eval.npz")
+    c, m = modules(g1)
+    c.eval(); m.eval()
+    X = orc.u8_to_nchw(g["X"]).to("cuda")
+    pred, embeds = c(X, collect=True)
+    Z = m(X, embeds)
+    assert pred.shape == (8, 1) and Z.shape == (8, 1, 64, 64)
+    assert [tuple(e.shape) for e in embeds] == [(8, 8, 32, 32), (8, 8, 16, 16), (8, 8, 8, 8), (8, 16, 4, 4), (8, 32, 1, 1)]
+    rel_close(pred.detach().cpu().numpy(), g["pred"], "pred")
+    for i in range(5):
+        rel_close(embeds[i].detach().cpu().numpy(), g[f"e{i}"], f"e{i}")
+    rel_close(Z.detach().cpu().numpy(), g["Z"], "Z")
+    assert c(X).shape == (8, 1)     # collect=False returns the prediction only
+
+
+@pytest.mark.parametrize("tag,kw", [("g3_train_default", dict()), ("g3_train_noinject", dict(inject=False)),
+                                    ("g3_train_frozen", dict(live=False))])
+def test_reference_style_training_loop_through_modules(golden, g1, tag, kw):
+    """main.py:360-463 written against the module API (torch ops for the mix and the losses, torch.optim.Adam
+    for the update): 3 steps reproduce the reference's losses, gradients and parameters."""
+    g = golden(tag + ".npz")
+    inject, live = kw.get("inject", True), kw.get("live", True)
+    critic, masker = modules(g1)
+    critic.train(); masker.train()
+    opti = torch.optim.Adam(chain(critic.parameters(), masker.parameters())) if live else torch.optim.Adam(masker.parameters())
+    A = orc.u8_to_nchw(g["A"]).to("cuda")
+    B = orc.u8_to_nchw(g["B"]).to("cuda")
+    Y = torch.from_numpy(g["Y"]).to("cuda")
+    for s in range(3):
+        pred, embeds = critic(A, collect=True)
+        negpred = critic(B)
+        pred = pred.squeeze(); negpred = negpred.squeeze().detach()
+        loss = 0
+        parts = np.zeros(5)
+        if live:
+            cl = F.mse_loss(pred, Y); loss = loss + 5 * cl; parts[0] = cl.item()
+        Z = masker(A, embeds)
+        replaced = A * (1 - Z) + Z * B
+        rl = F.mse_loss(critic(replaced).squeeze(), negpred.detach()); loss = loss + rl; parts[1] = rl.item()
+        if inject:
+            injected = B * (1 - Z) + Z * A
+            il = F.mse_loss(critic(injected).squeeze(), pred.detach()); loss = loss + il; parts[2] = il.item()
+        nl = 0.5 * F.l1_loss(Z, torch.zeros_like(Z)); loss = loss + nl; parts[3] = nl.item()
+        opti.zero_grad()
+        loss.backward()
+        if s == 0:
+            gm = masker.layout.unflatten(masker.flat.grad)
+            for k, v in split(g, "grad/masker").items():
+                rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
+            if live:
+                gc = critic.layout.unflatten(critic.flat.grad)
+                for k, v in split(g, "grad/critic").items():
+                    rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
+        opti.step()
+        np.testing.assert_allclose(parts, g[f"parts{s}"], rtol=1e-3, atol=1e-7)
+        assert loss.item() == pytest.approx(float(g[f"total{s}"]), rel=1e-3)
+    for k, v in split(g, "step3/masker").items():
+        rel_close(masker.state_dict()[k].cpu().numpy(), v, f"masker {k} after 3 steps", atol_scale=1e-4)
+    for k, v in split(g, "step3/critic").items():
+        rel_close(critic.state_dict()[k].cpu().numpy(), v, f"critic {k} after 3 steps", atol_scale=1e-4)
+
+
+def test_layout_conversion_kernels():
+    from cgs_amd import _lib
+    import ctypes as C
+    x = torch.randn(5, 3, 64, 64, device="cuda")
+    y = torch.empty(5, 64, 64, 3, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.call("cgs_nchw_to_nhwc", 5, 3, 4096, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), st)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    z = torch.empty_like(x)
+    _lib.call("cgs_nhwc_to_nchw", 5, 3, 4096, C.c_void_p(y.data_ptr()), C.c_void_p(z.data_ptr()), st)
+    assert torch.equal(z, x)
+
+
+def _write_dataset(root, n_train=1536, n_test=512):
+    """Synthetic stand-in for the MineRL gz-pickle: bright frames carry high targets so
+    that the critic can separate them and the >=500 hi/lo asserts of extract_contrastive_data hold."""
+    rs = np.random.RandomState(0)
+    n = n_train + n_test
+    hi = rs.rand(n) > 0.5
+    X = rs.randint(0, 96, (n, 64, 64, 3)).astype(np.uint8)
+    X[hi] += 150
+    Y = np.zeros((7, n))
+    Y[:] = np.where(hi, 0.95, 0.05)[None] + rs.randn(7, n) * 0.01
+    I = (np.arange(n) % 2 ** 16).astype(np.uint16)
+    d = os.path.join(root, "runs", "data", "straight")
+    os.makedirs(d, exist_ok=True)
+    with gzip.GzipFile(os.path.join(d, f"Treechop-trunk-{n_train}-[0.98-0.97-0.96-0.95].pickle"), "wb") as fp:
+        pickle.dump((X, Y, I), fp)
+    return X, Y
+
+
+def test_cli_train_then_process(tmp_path):
+    """`main.py -train` on a synthetic gz-pickle, then `main.py -process` on a folder of PNGs: checkpoint names,
+    reference-format checkpoints (loadable by the oracle), output file names / dtypes, and mask values equal
+    to the oracle's run on the trained weights."""
+    from PIL import Image
+    root = str(tmp_path)
+    X, Y = _write_dataset(root)
+    common = ["--model", "m", "--datasize", "1536", "--testsize", "512", "--cepochs", "10", "--mepochs", "1"]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-train"] + common, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    cpath = os.path.join(root, "m", "saves", "critic-rewidx=1-cepochs=10-datamode=trunk-datasize=1536-shift=12-chfak=1-dropout=0.3.pt")
+    mpath = os.path.join(root, "m", "saves", "masker-mepochs=1-L1=0.5-inject=True.pt")
+    assert os.path.exists(cpath) and os.path.exists(mpath), os.listdir(os.path.join(root, "m", "saves"))
+    pc = torch.load(cpath, map_location="cpu")
+    pm = torch.load(mpath, map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in pc.items()] == [(k, s) for k, s in orc.critic_shapes(1)]
+    assert [(k, tuple(v.shape)) for k, v in pm.items()] == [(k, s) for k, s in orc.masker_shapes(1)]
+    # the critic learnt the bright/dark split
+    with torch.no_grad():
+        p = orc.critic_apply(pc, orc.u8_to_nchw(X[:256])).squeeze(1).numpy()
+    assert np.corrcoef(p, Y[1, :256])[0, 1] > 0.9
+    # -process
+    src = os.path.join(root, "in")
+    os.makedirs(src)
+    for i in range(5):
+        Image.fromarray(X[i]).save(os.path.join(src, f"frame.{i}.png"))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-process", "--source-imgs", "in",
+                        "--mask-output-imgs", "out"] + common, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    names = sorted(os.listdir(os.path.join(root, "out")))
+    assert names == sorted(f"frame.{i}-{c}.png" for i in range(5) for c in ("raw-mask", "thresholded-mask"))
+    _, M = orc.infer_masks(pc, pm, X[:5] / 255.0)
+    hard, stack = orc.postprocess_masks(X[:5] / 255.0, M, 0.5)
+    for i in range(5):
+        raw = np.array(Image.open(os.path.join(root, "out", f"frame.{i}-raw-mask.png")))
+        thr = np.array(Image.open(os.path.join(root, "out", f"frame.{i}-thresholded-mask.png")))
+        assert raw.shape == (64, 64, 3) and raw.dtype == np.uint8
+        assert np.abs(raw.astype(int) - stack[i, 1].astype(int)).max() <= 1       # uint8 quantisation of a 1e-3 match
+        assert (thr != stack[i, 2]).mean() < 2e-3 and set(np.unique(thr)) <= {0, 255}
+    # -concatenated writes one side-by-side image per input
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-process", "-concatenated", "--source-imgs", "in",
+                        "--mask-output-imgs", "out2"] + common, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    img = np.array(Image.open(os.path.join(root, "out2", "frame.0_with_mask.png")))
+    assert img.shape == (64, 192, 3)
+    np.testing.assert_array_equal(img[:, :64], X[0])
+
+
+DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch
+import torch.distributed as dist
+import cgs_amd
+from cgs_amd import parallel, engine
+pg = parallel.init_from_env("gloo")          # 2 ranks share the one GPU of the box; the collective path is the same
+rank, _, world = parallel.env_world()
+raw = dict(np.load(os.path.join({repo!r}, "tests", "golden", "g1_weights_chfak1.npz")))
+pc = {{k.split("/", 1)[1]: torch.from_numpy(v) for k, v in raw.items() if k.startswith("critic/")}}
+pm = {{k.split("/", 1)[1]: torch.from_numpy(v) for k, v in raw.items() if k.startswith("masker/")}}
+rs = np.random.RandomState(3)
+n = 32
+A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
+sl = parallel.shard_slice(n, rank, world)
+e = engine.HourglassEngine(n // world, dropout=0.0, process_group=pg)
+e.load_state(pc, pm)
+for _ in range(3):
+    e.phase2_step(A[sl], B[sl], Y[sl])
+torch.cuda.synchronize()
+flat = e.flat.cpu()
+others = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(others, flat)
+assert all(torch.equal(o, others[0]) for o in others), "replicas diverged"
+if rank == 0:
+    np.save({out!r}, flat.numpy())
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_data_parallel_engine_world2(tmp_path, g1):
+    """Two ranks (gloo rendezvous, both on this box's GPU), half the batch each, 3 steps: replicas stay
+    bit-identical and match the single-process full-batch run."""
+    out = str(tmp_path / "dp_flat.npy")
+    script = tmp_path / "dp_worker.py"
+    script.write_text(DP_WORKER.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    from cgs_amd import engine
+    pc, pm = g1
+    rs = np.random.RandomState(3)
+    n = 32
+    A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+    B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+    Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
+    e = engine.HourglassEngine(n, dropout=0.0)
+    e.load_state(pc, pm)
+    for _ in range(3):
+        e.phase2_step(A, B, Y)
+    rel_close(np.load(out), e.flat.cpu().numpy(), "DP(2) parameters vs single process", rtol=1e-3, atol_scale=1e-4)
