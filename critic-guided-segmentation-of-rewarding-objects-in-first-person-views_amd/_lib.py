@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcgs_hip.so")
+LIB_PATH = os.environ.get("CGS_LIB_PATH") or os.path.join(HERE, "libcgs_hip.so")   # override: A/B builds
 
 OK, ERR_UNSUPPORTED, ERR_BADARG = 0, -1, -2
 SRC_F32, SRC_U8 = 0, 1

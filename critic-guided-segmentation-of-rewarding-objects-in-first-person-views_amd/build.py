@@ -12,6 +12,8 @@ LIB = os.path.join(HERE, "libcgs_hip.so")
 SOURCES = ["conv_fwd.hip", "conv_wgrad.hip", "head.hip", "elementwise.hip"]
 HEADERS = ["cgs_common.h", "conv_tile.h", os.path.join(REPO, "include", "cgs_hip.h")]
 ARCH = "gfx950"
+# conv_fwd: keep the FMAs scalar (v_fma_f32 with VGPR operands runs at ~2x the v_pk_fma_f32 rate on gfx950)
+EXTRA_FLAGS = {"conv_fwd.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -40,7 +42,8 @@ def build_library(force=False, verbose=True):
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [cc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = EXTRA_FLAGS.get(src, [])
+        cmd = [cc] + flags + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")

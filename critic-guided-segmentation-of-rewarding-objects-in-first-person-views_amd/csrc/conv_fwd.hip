@@ -35,6 +35,12 @@ __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams 
     float4* ldsA = smem;
     constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
     float4* ldsB = smem + DUMP + 1;
+    constexpr int B_ELEMS = PB == 0 ? 0 : (C::UPS == 2 ? PB * G::IMGS * G::TRB * G::PWB : PB * G::IMGS);
+    // weights staged in LDS (HWIO order as in global memory): wave-uniform ds_reads broadcast them into VGPRs,
+    // so the FMAs are plain v_fma_f32 with vector operands (103 TF/s measured) instead of SGPR-operand or
+    // packed forms (52-60 TF/s measured on gfx950, tools/valu_peak.hip).
+    constexpr int W_FLOATS = 9 * C::WCI * C::WCO;
+    float* ldsW = (float*)(ldsB + B_ELEMS);
 
     const int tid = threadIdx.x;                 // all threads take part in the loads
     const int qtid = tid % C::THREADS;           // quad handled by this thread
@@ -47,7 +53,7 @@ __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams 
     // ---- stage inputs ----
     if constexpr (C::SRC == SRC_F32) {
         DropCtx dl = dc;
-        if constexpr (C::EPI == EPI_DGRAD) dl.on = false;  // dgrad applies the mask in the epilogue
+        if constexpr (C::EPI == EPI_DGRAD || !C::DROP) dl.on = false;  // dgrad applies the mask in the epilogue
         load_a_f32<G, PA>(ldsA, (const float4*)P.src_a, n0, q.row0, N, tid, dl);
     } else if constexpr (C::SRC == SRC_U8C3) {
         load_a_u8c3<G>(ldsA, (const uint32_t*)P.src_a, n0, q.row0, N, tid);
@@ -73,12 +79,18 @@ __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams 
         if constexpr (C::UPS == 2) load_b_half<G, PB>(ldsB, (const float4*)P.src_b, n0, q.row0, N, tid);
         else load_b_pix<G, PB>(ldsB, (const float4*)P.src_b, n0, N, tid);
     }
+    for_elems<(W_FLOATS + 3) / 4, G::LT>(tid, [&](int e) {
+        int i = 4 * e;
+        float4 v;
+        v.x = P.w[i < W_FLOATS ? i : 0]; v.y = P.w[i + 1 < W_FLOATS ? i + 1 : 0];
+        v.z = P.w[i + 2 < W_FLOATS ? i + 2 : 0]; v.w = P.w[i + 3 < W_FLOATS ? i + 3 : 0];
+        ((float4*)ldsW)[e] = v;
+    });
     __syncthreads();
 
-    const cgs_cptr wc = cgs_to_const(P.w);
     auto wf = [&](int tap, int ci, int oc) -> float {
-        if constexpr (C::WT == 0) return wc[(tap * C::WCI + ci) * C::WCO + oc];
-        else return wc[((8 - tap) * C::WCI + oc) * C::WCO + ci];
+        if constexpr (C::WT == 0) return ldsW[(tap * C::WCI + ci) * C::WCO + oc];
+        else return ldsW[((8 - tap) * C::WCI + oc) * C::WCO + ci];
     };
     int pcx[4];
 #pragma unroll
@@ -86,6 +98,12 @@ __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams 
 
     const int y0 = q.row0 + 2 * q.qy_l, x0 = 2 * q.qx;  // top-left conv output of the quad
     const bool live = q.n < N;
+    // Retire padding threads now (no barrier follows).  Besides saving work this keeps the compiler from
+    // sinking the whole FMA block into the `if (live)` store region, which would leave every weight read
+    // of the kernel live at once.  (The x4-upsample gradient sums across lanes, so it keeps all lanes.)
+    if constexpr (!(C::EPI == EPI_DGRAD && C::UPS == 4)) {
+        if (!live) return;
+    }
     constexpr int NCHUNK = C::OC / C::OCB;
     static_assert(C::OC % C::OCB == 0, "chunking");
 
@@ -199,7 +217,7 @@ __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams 
                         float v[C::OCB];
 #pragma unroll
                         for (int o = 0; o < C::OCB; ++o) v[o] = acc[i][o];
-                        if constexpr (C::OCB % 4 == 0) {
+                        if constexpr (C::OCB % 4 == 0 && C::DROP) {
                             if (dc.on) {
 #pragma unroll
                                 for (int j = 0; j < C::OCB / 4; ++j) {
@@ -269,7 +287,8 @@ static size_t conv_lds_bytes() {
     constexpr int PB = C::CB / 4;
     size_t a = (C::SRC == SRC_SCALAR) ? (size_t)((G::IMGS * G::TRA * (G::W + 2) + 3) / 4) : (size_t)PA * G::IMGS * G::TRA * G::PWA;
     size_t b = PB == 0 ? 0 : (C::UPS == 2 ? (size_t)PB * G::IMGS * G::TRB * G::PWB : (size_t)PB * G::IMGS);
-    return (a + b + 1) * sizeof(float4);
+    size_t w = (size_t)(9 * C::WCI * C::WCO + 3) / 4;
+    return (a + b + 1 + w) * sizeof(float4);
 }
 
 template <class C>
@@ -290,6 +309,7 @@ static int launch_conv(const ConvParams& P, hipStream_t st) {
         static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = CA_, CB = CB_, UPS = UPS_; \
         static constexpr int WT = 0, WCI = CA_ + CB_, WCO = CO_, OC0 = 0, OC = CO_, OCB = OCB_, CW = CW_; \
         static constexpr int EPI = EPI_, ACT = ACT_, OUT_A = 0, POST_ACT = CGS_ACT_NONE;                \
+        static constexpr bool DROP = (HW == 8 && CB_ == 0);  /* only features.10 reads a dropped-out input */ \
     };
 // data gradient: dY has DYC channels; weights are the layer's HWIO [.,.,LCI,LCO]
 #define CGS_DG_CFG(NAME, HW, THR, SRC_, DYC, LCI, LCO, UPS_, OC0_, OC_, OCB_, OUTA, PACT, CW_)         \
@@ -297,6 +317,7 @@ static int launch_conv(const ConvParams& P, hipStream_t st) {
         static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = DYC, CB = 0, UPS = UPS_;   \
         static constexpr int WT = 1, WCI = LCI, WCO = LCO, OC0 = OC0_, OC = OC_, OCB = OCB_, CW = CW_;  \
         static constexpr int EPI = EPI_DGRAD, ACT = CGS_ACT_NONE, OUT_A = OUTA, POST_ACT = PACT;        \
+        static constexpr bool DROP = (HW == 8 && SRC_ == SRC_POOLEXP);                                   \
     };
 
 CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)

@@ -246,8 +246,11 @@ __device__ __forceinline__ void fma_plane(float (&acc)[4][OCB], const float4 (&p
 #pragma unroll
                         for (int o = 0; o < OCB; ++o) acc[oy * 2 + ox][o] = fmaf(x, wv[o], acc[oy * 2 + ox][o]);
                     }
-                // keep the scheduler from hoisting every tap's s_loads to the top (SGPR spills)
-                if (c == NCH - 1) __builtin_amdgcn_sched_barrier(0);
+                // keep the weight reads of later taps from being hoisted above this tap's FMAs (register blow-up)
+                if (c == NCH - 1) {
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 }
 

@@ -34,7 +34,7 @@ class HourglassEngine:
     def __init__(self, n: int, device="cuda:0", dropout: float = 0.3, lfak: float = 5, L1: float = 0.5, L2: float = 0.0,
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
-                 process_group=None, share_with: "HourglassEngine" = None):
+                 process_group=None, share_with: "HourglassEngine" = None, overlap_wgrad: bool = False):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -74,6 +74,9 @@ class HourglassEngine:
         self.dzpre = z(n, 64, 64)
         self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "p1": {}}
         self._graphs: Dict[str, object] = {}
+        # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
+        # the cross-queue joins cost what the overlap gains)
+        self.side = hg.SideStream(torch.cuda.Stream(device=self.dev) if overlap_wgrad else None)
         self._plans: Dict[str, hg.SlabPlan] = {}
 
     # ---- parameters --------------------------------------------------------------------------
@@ -163,15 +166,16 @@ class HourglassEngine:
         # critic backward on the mixes: image gradient for the mask path (+ weight gradients when live)
         hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
                            self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
-                           ws=self._ws["cb_mix"])
+                           ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live)
         nz = float(n * 4096)
         _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), _P(self.dmixed), int(self.inject),
                   self.L1 / nz, self.L2 / nz, _P(self.dzpre), _S())
         pm = hg.SlabPlan()
-        d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"])
+        d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side)
         if self.live:
             hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
-                               n_add=n, ws=self._ws["cb_a"])
+                               n_add=n, ws=self._ws["cb_a"], side=self.side)
+        self.side.join()
         if first:
             full = hg.SlabPlan()
             if self.live:
@@ -205,7 +209,9 @@ class HourglassEngine:
         _lib.call("cgs_phase1_loss", n, _P(self.cbuf["pred"]), _P(self.y), int(self.bce), _P(self.losses), _P(self.dpred), _S())
         first = "p1" not in self._plans
         pc = hg.SlabPlan()
-        hg.critic_backward(self.fc, self.lc, X, n, self._cview(0, n), self.dpred[:n], pc, self.drop.shifted(0), ws=self._ws["p1"])
+        hg.critic_backward(self.fc, self.lc, X, n, self._cview(0, n), self.dpred[:n], pc, self.drop.shifted(0), ws=self._ws["p1"],
+                           side=self.side)
+        self.side.join()
         if first:
             full = hg.SlabPlan()
             for slab, nsl, cnt, off in pc.jobs:

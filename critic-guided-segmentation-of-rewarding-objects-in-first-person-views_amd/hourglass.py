@@ -59,6 +59,30 @@ def conv_desc(n, hw, ca, cb, co, src_u8, ups, act, pool, drop: _lib.Dropout) -> 
     return _lib.ConvDesc(n, hw, hw, ca, cb, co, _lib.SRC_U8 if src_u8 else _lib.SRC_F32, ups, _ACT[act], pool, drop)
 
 
+class SideStream:
+    """Weight-gradient kernels only feed the slab reduction at the end of the step, so they are launched on a
+    second HIP stream (captured into the same graph as a parallel branch): the MFMA wgrad kernels then overlap
+    the VALU data-gradient chain instead of serialising with it."""
+
+    def __init__(self, stream: Optional["torch.cuda.Stream"]):
+        self.stream = stream
+
+    def fork(self):
+        """Context manager: work launched inside runs on the side stream after everything enqueued so far."""
+        if self.stream is None:
+            import contextlib
+            return contextlib.nullcontext()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+NO_SIDE = SideStream(None)
+
+
 class SlabPlan:
     """Collects (slab, destination) pairs of one backward pass; run() sums every slab into the flat
     gradient buffer with ONE cgs_reduce_slabs launch (fixed order => bitwise reproducible)."""
@@ -133,7 +157,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     dpred: torch.Tensor, plan: SlabPlan, drop: DropState = NO_DROP,
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
-                    ws: Optional[Dict[str, torch.Tensor]] = None) -> Optional[torch.Tensor]:
+                    ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
+                    need_wgrad: bool = True) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  d_embeds = [dE0..dE4] gradients arriving at the embeds
     from the decoder (valid for images < n_add; their buffers are reused as the running totals).
     dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
@@ -150,6 +175,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         return t
 
     has_add = d_embeds is not None and n_add > 0
+    side = side if side is not None else NO_SIDE
     lib = _lib.load()
     # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
     nsl = lib.cgs_head_bwd_slabs(n)
@@ -169,9 +195,11 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         cnt = 9 * ca * co + co
-        slab = buf(f"slab_enc{i}", (nsl, cnt))
-        _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
-        plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+        if need_wgrad:
+            slab = buf(f"slab_enc{i}", (nsl, cnt))
+            with side.fork():
+                _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
+            plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
         wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
         if i > 0:   # d e{i-1} = conv_bwd * dropout mask + decoder skip gradient (fused epilogue)
             nxt = buf(f"de{i - 1}", (n, hw, hw, ca))
@@ -219,13 +247,14 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
 
 def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
                     saved: Dict[str, torch.Tensor], dzpre: torch.Tensor, plan: SlabPlan,
-                    ws: Optional[Dict[str, torch.Tensor]] = None) -> List[torch.Tensor]:
+                    ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None) -> List[torch.Tensor]:
     """dzpre: gradient w.r.t. the mask head's PRE-sigmoid output [n,64,64].
     Returns [dE0, dE1, dE2, dE3, dE4]: gradients w.r.t. the encoder embeds (skip connections)."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
     ws = ws if ws is not None else {}
+    side = side if side is not None else NO_SIDE
     lib = _lib.load()
 
     def buf(name, shape):
@@ -249,7 +278,8 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         cnt = 9 * (ca + cb) * co + co
         slab = buf(f"slab_dec{li}", (nsl, cnt))
-        _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
+        with side.fork():
+            _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
         wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
         if li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)
