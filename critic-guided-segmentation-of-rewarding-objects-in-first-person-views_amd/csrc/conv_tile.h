@@ -229,29 +229,31 @@ __device__ __forceinline__ void load_b_pix(float4* ldsB, const float4* __restric
 // ------------------------------------------------------------------------------------------------
 template <int OCB, int NCH, class WF>
 __device__ __forceinline__ void fma_plane(float (&acc)[4][OCB], const float4 (&pt)[4][4], WF wf, int ci0, int oc0) {
+    // 9*NCH steps of (one tap, one input channel): OCB weights -> 4*OCB FMAs.  The weights of step s+1 are
+    // read (LDS broadcast) before the FMAs of step s are issued; the compiler barrier after each step keeps
+    // the reads of step s+2 from being hoisted further (bounded registers, one step of latency cover).
+    constexpr int NS = 9 * NCH;
+    float w[2][OCB];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int o = 0; o < OCB; ++o) w[0][o] = wf(0, ci0, oc0 + o);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
+    for (int s = 0; s < NS; ++s) {
+        const int tap = s / NCH, c = s % NCH, ky = tap / 3, kx = tap % 3;
+        if (s + 1 < NS) {
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                float wv[OCB];
+            for (int o = 0; o < OCB; ++o) w[(s + 1) & 1][o] = wf((s + 1) / NCH, ci0 + (s + 1) % NCH, oc0 + o);
+        }
 #pragma unroll
-                for (int o = 0; o < OCB; ++o) wv[o] = wf(ky * 3 + kx, ci0 + c, oc0 + o);
+        for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
-                for (int oy = 0; oy < 2; ++oy)
+            for (int ox = 0; ox < 2; ++ox) {
+                float x = f4get(pt[oy + ky][ox + kx], c);
 #pragma unroll
-                    for (int ox = 0; ox < 2; ++ox) {
-                        float x = f4get(pt[oy + ky][ox + kx], c);
-#pragma unroll
-                        for (int o = 0; o < OCB; ++o) acc[oy * 2 + ox][o] = fmaf(x, wv[o], acc[oy * 2 + ox][o]);
-                    }
-                // keep the weight reads of later taps from being hoisted above this tap's FMAs (register blow-up)
-                if (c == NCH - 1) {
-                    asm volatile("" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int o = 0; o < OCB; ++o) acc[oy * 2 + ox][o] = fmaf(x, w[s & 1][o], acc[oy * 2 + ox][o]);
             }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <int OCB, class WF>

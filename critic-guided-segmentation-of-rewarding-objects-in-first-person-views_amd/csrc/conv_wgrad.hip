@@ -53,7 +53,6 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float* xt = (float*)smem;
     float* yt = xt + XT4 * 4;
-    constexpr int DUMP4 = XT4 + YT / 4;                    // spare float4 slot for redirected stores
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
@@ -76,27 +75,44 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) acc[rb] = frag4{0.f, 0.f, 0.f, 0.f};
 
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
-        const int n0 = (G::IMGS == 1) ? tile / G::STRIPS : tile * G::IMGS;
-        const int row0 = (G::IMGS == 1) ? (tile % G::STRIPS) * G::TH : 0;
-        // ---- X tile, source A ----
-        if constexpr (C::CA % 4 == 0) {
-            for_elems<NPIX * SA, G::THREADS>(tid, [&](int e) {
-                int s = e % SA, c = (e / SA) % G::PWA, r = (e / (SA * G::PWA)) % G::TRA, img = e / (SA * G::PWA * G::TRA);
-                int n = n0 + img, y = row0 + r - 1, x = c - 1;
-                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
-                int gi = in ? ((n * G::H + y) * G::W + x) * SA + s : 0;
-                float4 v = ((const float4*)P.src_a)[gi];
-                if (dc.on) v = v * drop_mult4(dc, (uint32_t)gi);
-                ((float4*)xt)[(e / SA) * S + s] = in ? v : f4zero();
-            });
-        } else {  // 3-channel image: one padded slot per pixel
-            for_elems<NPIX, G::THREADS>(tid, [&](int e) {
-                int c = e % G::PWA, r = (e / G::PWA) % G::TRA, img = e / (G::PWA * G::TRA);
-                int n = n0 + img, y = row0 + r - 1, x = c - 1;
-                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+    // ------------------------------------------------------------------------------------------
+    // Software pipeline over this workgroup's tiles: the global loads of tile t+1 are issued into
+    // registers (fetch) right after tile t has been committed to LDS, so they are in flight during
+    // tile t's MFMA phase; commit() writes them to LDS after the phase ends.
+    // ------------------------------------------------------------------------------------------
+    constexpr int NA = (C::CA % 4 == 0) ? NPIX * SA : NPIX;
+    constexpr int NB = NPIX * SB;
+    constexpr int PO = CO / 4;
+    constexpr int NY = (C::DY == WDY_F32) ? YT / 4 : G::IMGS * G::RQ * (G::W / 2) * PO;
+    constexpr int ITA = (NA + G::THREADS - 1) / G::THREADS, ITB = (NB + G::THREADS - 1) / G::THREADS;
+    constexpr int ITY = (NY + G::THREADS - 1) / G::THREADS;
+    float4 ra[ITA], rb[ITB > 0 ? ITB : 1], ry[ITY];
+    uint32_t rn[ITY];
+
+    auto tile_origin = [&](int tile, int& n0, int& row0) {
+        n0 = (G::IMGS == 1) ? tile / G::STRIPS : tile * G::IMGS;
+        row0 = (G::IMGS == 1) ? (tile % G::STRIPS) * G::TH : 0;
+    };
+    auto pix_decode = [&](int e, int n0, int row0, int& n, int& y, int& x) -> bool {
+        int c = e % G::PWA, r = (e / G::PWA) % G::TRA, img = e / (G::PWA * G::TRA);
+        n = n0 + img; y = row0 + r - 1; x = c - 1;
+        return n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+    };
+
+    auto fetch = [&](int tile) {
+        int n0, row0;
+        tile_origin(tile, n0, row0);
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = tid + it * G::THREADS; e = e < NA ? e : NA - 1;
+            int n, y, x;
+            if constexpr (C::CA % 4 == 0) {
+                bool in = pix_decode(e / SA, n0, row0, n, y, x);
+                int gi = in ? ((n * G::H + y) * G::W + x) * SA + (e % SA) : 0;
+                ra[it] = ((const float4*)P.src_a)[gi];
+            } else {
+                bool in = pix_decode(e, n0, row0, n, y, x);
                 int pix = in ? (n * G::H + y) * G::W + x : 0;
-                float4 v;
                 if constexpr (C::SRC == WSRC_U8) {
                     const uint32_t* s32 = (const uint32_t*)P.src_a;
                     int off = pix * 3, last = N * G::H * G::W * 3 / 4 - 1;
@@ -104,65 +120,126 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
                     uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
                     uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
                     const float sc = 1.f / 255.f;
-                    v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+                    ra[it] = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
                 } else {
                     const float* sf = (const float*)P.src_a;
-                    v = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
+                    ra[it] = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
                 }
-                ((float4*)xt)[e * S] = in ? v : f4zero();
-            });
-        }
-        // ---- X tile, source B (nearest-upsampled, materialised at full resolution) ----
-        if constexpr (SB > 0) {
-            for_elems<NPIX * SB, G::THREADS>(tid, [&](int e) {
-                int s = e % SB, c = (e / SB) % G::PWA, r = (e / (SB * G::PWA)) % G::TRA, img = e / (SB * G::PWA * G::TRA);
-                int n = n0 + img, y = row0 + r - 1, x = c - 1;
-                bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
-                int gi;
-                if constexpr (C::UPS == 2) gi = in ? ((n * G::QH + (y >> 1)) * G::QW + (x >> 1)) * SB + s : 0;
-                else gi = in ? n * SB + s : 0;
-                float4 v = ((const float4*)P.src_b)[gi];
-                ((float4*)xt)[(e / SB) * S + SA + s] = in ? v : f4zero();
-            });
-        }
-        // ---- dY tile ----
-        if constexpr (C::DY == WDY_F32) {
-            constexpr int PER = G::TH * G::W * CO / 4;
-            for_elems<YT / 4, G::THREADS>(tid, [&](int e) {
-                int img = e / PER, rest = e % PER;
-                int n = n0 + img;
-                bool in = n < N;
-                float4 v = ((const float4*)P.dy)[in ? ((n * G::H + row0) * G::W * CO) / 4 + rest : 0];
-                ((float4*)yt)[e] = in ? v : f4zero();
-            });
-        } else {
-            load_poolexp<G, CO / 4, 0>((float4*)yt, (const float4*)P.dy, P.amask, n0, row0, N, tid,
-                                       [](int p, int img, int r, int x) { return ((img * G::TH + r) * G::W + x) * (CO / 4) + p; },
-                                       DUMP4 - XT4);
-        }
-        __syncthreads();
-
-        // 4 k-steps per iteration: all LDS reads of the four steps are issued before the MFMAs that consume them
-        constexpr int U = 4;
-        for (int step = wave; step < G::NSTEP; step += G::NW * U) {
-            float a[U][NRB], b[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int st = step + u * G::NW;
-                bool ok = st < G::NSTEP;
-                int p = (ok ? st : 0) * 4 + kq;
-                int x = p % G::W, yl = (p / G::W) % G::TH, img = p / (G::W * G::TH);
-                int pixoff = ((img * G::TRA + yl) * G::PWA + x) * PCI;
-                b[u] = (ok && l15 < CO) ? yt[((img * G::TH + yl) * G::W + x) * CO + l15] : 0.f;
-#pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    a[u][rb] = (rbase[rb] >= 0) ? xt[rbase[rb] + pixoff] : (rbase[rb] == -1 ? 1.f : 0.f);
             }
+        }
+        if constexpr (SB > 0) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int it = 0; it < ITB; ++it) {
+                int e = tid + it * G::THREADS; e = e < NB ? e : NB - 1;
+                int n, y, x;
+                bool in = pix_decode(e / SB, n0, row0, n, y, x);
+                int gi;
+                if constexpr (C::UPS == 2) gi = in ? ((n * G::QH + (y >> 1)) * G::QW + (x >> 1)) * SB + (e % SB) : 0;
+                else gi = in ? n * SB + (e % SB) : 0;
+                rb[it] = ((const float4*)P.src_b)[gi];
+            }
+        }
 #pragma unroll
-                for (int rb = 0; rb < NRB; ++rb)
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rb], b[u], acc[rb], 0, 0, 0);
+        for (int it = 0; it < ITY; ++it) {
+            int e = tid + it * G::THREADS; e = e < NY ? e : NY - 1;
+            if constexpr (C::DY == WDY_F32) {
+                constexpr int PER = G::TH * G::W * CO / 4;
+                int n = n0 + e / PER;
+                ry[it] = ((const float4*)P.dy)[n < N ? ((n * G::H + row0) * G::W * CO) / 4 + e % PER : 0];
+            } else {
+                constexpr int HP = G::H / 2, WP = G::W / 2, AMW = (PO + 1) / 2;
+                int p = e % PO, px = (e / PO) % WP, j = (e / (PO * WP)) % G::RQ, img = e / (PO * WP * G::RQ);
+                int n = n0 + img, pr = row0 / 2 + j;
+                bool in = n < N;
+                int pi = in ? (n * HP + pr) * WP + px : 0;
+                ry[it] = ((const float4*)P.dy)[pi * PO + p];
+                rn[it] = in ? ((P.amask[pi * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu) : 0xFFFFu;
+            }
+        }
+    };
+
+    auto commit = [&](int tile) {
+        int n0, row0;
+        tile_origin(tile, n0, row0);
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = tid + it * G::THREADS; e = e < NA ? e : NA - 1;
+            int n, y, x;
+            if constexpr (C::CA % 4 == 0) {
+                bool in = pix_decode(e / SA, n0, row0, n, y, x);
+                float4 v = ra[it];
+                if (dc.on) v = v * drop_mult4(dc, (uint32_t)(in ? ((n * G::H + y) * G::W + x) * SA + (e % SA) : 0));
+                ((float4*)xt)[(e / SA) * S + (e % SA)] = in ? v : f4zero();
+            } else {
+                bool in = pix_decode(e, n0, row0, n, y, x);
+                ((float4*)xt)[e * S] = in ? ra[it] : f4zero();
+            }
+        }
+        if constexpr (SB > 0) {
+#pragma unroll
+            for (int it = 0; it < ITB; ++it) {
+                int e = tid + it * G::THREADS; e = e < NB ? e : NB - 1;
+                int n, y, x;
+                bool in = pix_decode(e / SB, n0, row0, n, y, x);
+                ((float4*)xt)[(e / SB) * S + SA + (e % SB)] = in ? rb[it] : f4zero();
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITY; ++it) {
+            int e = tid + it * G::THREADS; e = e < NY ? e : NY - 1;
+            if constexpr (C::DY == WDY_F32) {
+                constexpr int PER = G::TH * G::W * CO / 4;
+                ((float4*)yt)[e] = (n0 + e / PER < N) ? ry[it] : f4zero();
+            } else {
+                constexpr int WP = G::W / 2;
+                int p = e % PO, px = (e / PO) % WP, j = (e / (PO * WP)) % G::RQ, img = e / (PO * WP * G::RQ);
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    int r = 2 * j + (pos >> 1), x = 2 * px + (pos & 1);
+                    ((float4*)yt)[((img * G::TH + r) * G::W + x) * PO + p] = nib_select(ry[it], rn[it], pos);
+                }
+            }
+        }
+    };
+
+    constexpr int U = NRB >= 16 ? 1 : (NRB >= 8 ? 2 : 4);
+    int tile = blockIdx.x;
+    if (tile < P.ntiles) fetch(tile);
+    for (; tile < P.ntiles; tile += gridDim.x) {
+        commit(tile);
+        __syncthreads();
+        if (tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);   // in flight during the MFMA phase
+        // Each wave owns whole tile rows; inside a row the k-steps advance by constant strides, so every LDS
+        // address is (per-row base) + immediate offset: no per-step index arithmetic next to the MFMAs.
+        constexpr int NROWS = G::IMGS * G::TH, SPR = G::W / 4;
+        constexpr int UU = SPR < U ? SPR : U;
+        for (int R = wave; R < NROWS; R += G::NW) {
+            const int img = R / G::TH, yl = R % G::TH;
+            const int xrow = ((img * G::TRA + yl) * G::PWA + kq) * PCI;
+            const int yrow = ((img * G::TH + yl) * G::W + kq) * CO + (l15 < CO ? l15 : 0);
+            int xa[NRB];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb) xa[rb] = xrow + (rbase[rb] >= 0 ? rbase[rb] : 0);
+#pragma unroll
+            for (int c = 0; c < SPR; c += UU) {
+                float a[UU][NRB], b[UU];
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    float bv = yt[yrow + (c + u) * 4 * CO];
+                    b[u] = (l15 < CO) ? bv : 0.f;
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb) {
+                        float av = xt[xa[rb] + (c + u) * 4 * PCI];
+                        a[u][rb] = (rbase[rb] >= 0) ? av : (rbase[rb] == -1 ? 1.f : 0.f);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UU; ++u)
+#pragma unroll
+                    for (int rb = 0; rb < NRB; ++rb)
+                        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rb], b[u], acc[rb], 0, 0, 0);
+                asm volatile("" ::: "memory");   // keep the next chunk's LDS reads behind this chunk's (bounded registers)
+            }
         }
         __syncthreads();
     }
@@ -193,9 +270,10 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_kernel(WgradParams P) {
 template <class G>
 __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     constexpr int CI = 16;
-    constexpr int XT = G::TRA * G::PWA * CI, YT = G::TH * G::W;
-    constexpr int NSTEP = G::TRA * G::PWA / 4;
-    static_assert(G::IMGS == 1 && (G::TRA * G::PWA) % 4 == 0, "co1 tile");
+    constexpr int PW = 68;                       // haloed row (66) padded to a multiple of 4 positions
+    constexpr int XT = G::TRA * PW * CI, YT = G::TH * G::W;
+    constexpr int SPR = PW / 4;                  // k-steps per haloed row
+    static_assert(G::IMGS == 1 && G::W == 64 && G::TRA % G::NW == 0, "co1 tile");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float* xt = (float*)smem;
     float* yt = xt + XT;
@@ -207,7 +285,7 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n = tile / G::STRIPS, row0 = (tile % G::STRIPS) * G::TH;
         for_elems<XT / 4, G::THREADS>(tid, [&](int e) {
-            int q4 = e % (CI / 4), c = (e / (CI / 4)) % G::PWA, r = e / ((CI / 4) * G::PWA);
+            int q4 = e % (CI / 4), c = (e / (CI / 4)) % PW, r = e / ((CI / 4) * PW);
             int y = row0 + r - 1, x = c - 1;
             bool in = y >= 0 && y < G::H && x >= 0 && x < G::W;
             float4 v = ((const float4*)P.src_a)[in ? ((n * G::H + y) * G::W + x) * (CI / 4) + q4 : 0];
@@ -217,23 +295,29 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
             ((float4*)yt)[e] = ((const float4*)P.dy)[((n * G::H + row0) * G::W) / 4 + e];
         });
         __syncthreads();
-        constexpr int U = 4;
-        for (int step = wave; step < NSTEP; step += G::NW * U) {
-            float a[U], b[U];
+        for (int r = wave; r < G::TRA; r += G::NW) {      // each wave owns whole haloed rows
+            const int xrow = (r * PW + kq) * CI + l15;
+            const int yl = r - ky;
+            const bool rowok = l15 < 9 && yl >= 0 && yl < G::TH;
+            const int yrow = (rowok ? yl : 0) * G::W + kq - kx;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                int st = step + u * G::NW;
-                bool ok = st < NSTEP;
-                int p = (ok ? st : 0) * 4 + kq;  // position in the haloed tile
-                int c = p % G::PWA, r = p / G::PWA;
-                a[u] = xt[p * CI + l15];
-                int yl = r - ky, x = c - kx;
-                bool in = ok && l15 < 9 && yl >= 0 && yl < G::TH && x >= 0 && x < G::W;
-                b[u] = in ? yt[(in ? yl : 0) * G::W + (in ? x : 0)] : 0.f;
-                if (l15 == 4) bsum += b[u];  // centre tap sees every dY of the tile exactly once
+            for (int c = 0; c < SPR; c += 4) {
+                float a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (c + u < SPR) {
+                        a[u] = xt[xrow + (c + u) * 4 * CI];
+                        int x = 4 * (c + u) + kq - kx;
+                        bool in = rowok && x >= 0 && x < G::W;
+                        float bv = yt[in ? yrow + 4 * (c + u) : 0];
+                        b[u] = in ? bv : 0.f;
+                        if (l15 == 4) bsum += b[u];   // centre tap sees every dY of the tile exactly once
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (c + u < SPR) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
             }
-#pragma unroll
-            for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
         }
         __syncthreads();
     }
@@ -276,7 +360,7 @@ CGS_WG_CFG(WDec1, 16, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
 CGS_WG_CFG(WDec0, 32, 8, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
 CGS_WG_CFG(WMask0U8, 64, 4, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
 CGS_WG_CFG(WMask0F32, 64, 4, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
-using WMask2G = WGeo<64, 64, 4, 1, 256>;
+using WMask2G = WGeo<64, 64, 2, 1, 256>;
 
 static constexpr int kMaxWgradBlocks = 1024;
 
@@ -346,7 +430,7 @@ extern "C" int cgs_conv3x3_bwd_weight(const cgs_conv_desc* d, const void* src_a,
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) return launch_wgrad<WMask0F32>(P, st);
     if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) {
         using G = WMask2G;
-        size_t lds = ((size_t)G::TRA * G::PWA * 16 + (size_t)G::TH * G::W) * sizeof(float);
+        size_t lds = ((size_t)G::TRA * 68 * 16 + (size_t)G::TH * G::W) * sizeof(float);
         P.ntiles = wg_tiles<G>(P.n);
         if (P.ntiles == 0) return CGS_OK;
         hipLaunchKernelGGL(wgrad_co1_kernel<G>, dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);

@@ -18,11 +18,16 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int n, const float* __res
                                                        cgs_dropout drop_h, float* __restrict__ e4,
                                                        float* __restrict__ h1, float* __restrict__ pred) {
     __shared__ __attribute__((aligned(16))) float xs[8][256];
+    __shared__ __attribute__((aligned(16))) float w4s[256 * 32];   // 32 KB: the 4x4-conv weights, read 8x per block
+    __shared__ __attribute__((aligned(16))) float w1s[32 * 32];
     __shared__ float es[8][32];
     __shared__ float hs[8][33];
     const int tid = threadIdx.x, il = tid >> 5, o = tid & 31;
     const int img0 = blockIdx.x * 8, nn = img0 + il;
     const DropCtx di = drop_ctx(drop_in), dh = drop_ctx(drop_h);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ((float4*)w4s)[tid + i * 256] = ((const float4*)w4)[tid + i * 256];
+    ((float4*)w1s)[tid] = ((const float4*)w1)[tid];
     for (int e = tid; e < 8 * 64; e += 256) {
         int img = e >> 6, q = e & 63, m = img0 + img;
         float4 v = f4zero();
@@ -34,16 +39,23 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int n, const float* __res
         ((float4*)&xs[img][0])[q] = v;
     }
     __syncthreads();
-    float acc = b4[o];
+    float acc0 = b4[o], acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < 256; ++k) acc = fmaf(xs[il][k], w4[k * 32 + o], acc);
+    for (int k = 0; k < 256; k += 4) {
+        float4 xv = *(const float4*)&xs[il][k];
+        acc0 = fmaf(xv.x, w4s[k * 32 + o], acc0);
+        acc1 = fmaf(xv.y, w4s[(k + 1) * 32 + o], acc1);
+        acc2 = fmaf(xv.z, w4s[(k + 2) * 32 + o], acc2);
+        acc3 = fmaf(xv.w, w4s[(k + 3) * 32 + o], acc3);
+    }
+    float acc = (acc0 + acc1) + (acc2 + acc3);
     float e = acc > 0.f ? acc : 0.f;
     es[il][o] = e;
     if (nn < n) e4[nn * 32 + o] = e;
     __syncthreads();
     acc = b1[o];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc = fmaf(es[il][k], w1[k * 32 + o], acc);
+    for (int k = 0; k < 32; ++k) acc = fmaf(es[il][k], w1s[k * 32 + o], acc);
     float h = acc > 0.f ? acc : 0.f;
     if (nn < n) h1[nn * 32 + o] = h;
     float hd = h * drop_mult1(dh, (uint32_t)(nn * 32 + o));
@@ -76,8 +88,12 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* __res
     __shared__ float dh1s[8][32];
     __shared__ float dz4s[8][32];
     __shared__ float red[4][8][32];
+    __shared__ __attribute__((aligned(16))) float w4s[256 * 33];   // rows padded to 33 floats: row-per-lane reads
+    __shared__ float w1s[32 * 33];
     const int tid = threadIdx.x, il = tid >> 5, o = tid & 31, kg = il;
     const DropCtx di = drop_ctx(drop_in), dh = drop_ctx(drop_h);
+    for (int i = tid; i < 256 * 32; i += 256) w4s[(i >> 5) * 33 + (i & 31)] = w4[i];
+    for (int i = tid; i < 32 * 32; i += 256) w1s[(i >> 5) * 33 + (i & 31)] = w1[i];
     float acc4[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
@@ -122,7 +138,7 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* __res
         // d e4[il][k = o] = sum_o' w1[k][o'] dh1[il][o'] (+ decoder gradient), through ReLU
         float de = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) de = fmaf(w1[o * 32 + q], dh1s[il][q], de);
+        for (int q = 0; q < 32; ++q) de = fmaf(w1s[o * 33 + q], dh1s[il][q], de);
         if (d_e4_extra && nn < n_extra) de += d_e4_extra[nn * 32 + o];
         float dz4 = (ev > 0.f) ? de : 0.f;
         dz4s[il][o] = dz4;
@@ -141,14 +157,10 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* __res
 #pragma unroll 2
             for (int m = 0; m < 8; ++m) {
                 int k = o + 32 * m;
-                const float4* wr = (const float4*)(w4 + k * 32);
+                const float* wr = w4s + k * 33;
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float4 wv = wr[q];
-                    s = fmaf(wv.x, dz4s[il][4 * q], s); s = fmaf(wv.y, dz4s[il][4 * q + 1], s);
-                    s = fmaf(wv.z, dz4s[il][4 * q + 2], s); s = fmaf(wv.w, dz4s[il][4 * q + 3], s);
-                }
+                for (int q = 0; q < 32; ++q) s = fmaf(wr[q], dz4s[il][q], s);
                 int gi = nn * 256 + k;
                 float r = s * drop_mult1(di, (uint32_t)gi);
                 if (d_e3_extra && nn < n_extra) r += d_e3_extra[gi];
