@@ -3,293 +3,7 @@
 //             UnetDecoder.dec / masker convs with fused Upsample + cat + activation     nets.py:480-521
 //   backward: the same core with transposed/flipped weights; pool/ReLU gradient re-expansion in the
 //             loader; dropout, LeakyReLU', skip-gradient add and upsample-backward sums in the epilogue.
-#include "conv_tile.h"
-
-struct ConvParams {
-    const void* src_a;
-    const float* src_b;
-    const uint32_t* amask_in;
-    const float* w;
-    const float* bias;
-    float* out;        // fwd: output;  dgrad: d_a
-    float* out2;       // dgrad: d_b
-    uint32_t* amask_out;
-    const float* addend;
-    const float* a_post;
-    int n, n_addend;
-    cgs_dropout drop;
-};
-
-enum { EPI_POOL = 0, EPI_PLAIN = 1, EPI_DGRAD = 2 };
-
-// Cfg members: H,W,THREADS, SRC, CA, CB, UPS, WT (0 normal / 1 transposed), WCI, WCO (HWIO dims),
-// OC0, OC (logical output channel window), OCB (register block), EPI, ACT, OUT_A (dgrad: channels that
-// belong to source A), POST_ACT (dgrad: activation whose derivative multiplies d_a).
-template <class C>
-__global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams P) {
-    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
-    constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
-    constexpr int PB = C::CB / 4;
-    constexpr int A_ELEMS = PA * G::IMGS * G::TRA * G::PWA;  // float4 slots (floats for SRC_SCALAR)
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float4* ldsA = smem;
-    constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
-    float4* ldsB = smem + DUMP + 1;
-    constexpr int B_ELEMS = PB == 0 ? 0 : (C::UPS == 2 ? PB * G::IMGS * G::TRB * G::PWB : PB * G::IMGS);
-    // weights staged in LDS (HWIO order as in global memory): wave-uniform ds_reads broadcast them into VGPRs,
-    // so the FMAs are plain v_fma_f32 with vector operands (103 TF/s measured) instead of SGPR-operand or
-    // packed forms (52-60 TF/s measured on gfx950, tools/valu_peak.hip).
-    constexpr int W_FLOATS = 9 * C::WCI * C::WCO;
-    float* ldsW = (float*)(ldsB + B_ELEMS);
-
-    const int tid = threadIdx.x;                 // all threads take part in the loads
-    const int qtid = tid % C::THREADS;           // quad handled by this thread
-    const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
-    const QuadPos q = quad_pos<G>(qtid, blockIdx.x);
-    const int n0 = (G::IMGS == 1) ? q.n : blockIdx.x * G::IMGS;
-    const int N = P.n;
-    const DropCtx dc = drop_ctx(P.drop);
-
-    // ---- stage inputs ----
-    if constexpr (C::SRC == SRC_F32) {
-        DropCtx dl = dc;
-        if constexpr (C::EPI == EPI_DGRAD || !C::DROP) dl.on = false;  // dgrad applies the mask in the epilogue
-        load_a_f32<G, PA>(ldsA, (const float4*)P.src_a, n0, q.row0, N, tid, dl);
-    } else if constexpr (C::SRC == SRC_U8C3) {
-        load_a_u8c3<G>(ldsA, (const uint32_t*)P.src_a, n0, q.row0, N, tid);
-    } else if constexpr (C::SRC == SRC_F32C3) {
-        load_a_f32c3<G>(ldsA, (const float4*)P.src_a, n0, q.row0, N, tid);
-    } else if constexpr (C::SRC == SRC_POOLEXP) {
-        load_poolexp<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, q.row0, N, tid,
-                               [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
-        zero_halo_cols<G, PA>(ldsA, tid);
-    } else {  // SRC_SCALAR: one fp32 channel, tile of floats [img][TRA][W+2]
-        float* t = (float*)ldsA;
-        const float* s = (const float*)P.src_a;
-        constexpr int E = G::IMGS * G::TRA * (G::W + 2);
-        for_elems<E, G::LT>(tid, [&](int e) {
-            int c = e % (G::W + 2), r = (e / (G::W + 2)) % G::TRA, img = e / ((G::W + 2) * G::TRA);
-            int n = n0 + img, y = q.row0 + r - 1, x = c - 1;
-            bool in = n < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
-            float v = s[in ? (n * G::H + y) * G::W + x : 0];
-            t[e] = in ? v : 0.f;
-        });
-    }
-    if constexpr (PB > 0) {
-        if constexpr (C::UPS == 2) load_b_half<G, PB>(ldsB, (const float4*)P.src_b, n0, q.row0, N, tid);
-        else load_b_pix<G, PB>(ldsB, (const float4*)P.src_b, n0, N, tid);
-    }
-    for_elems<(W_FLOATS + 3) / 4, G::LT>(tid, [&](int e) {
-        int i = 4 * e;
-        float4 v;
-        v.x = P.w[i < W_FLOATS ? i : 0]; v.y = P.w[i + 1 < W_FLOATS ? i + 1 : 0];
-        v.z = P.w[i + 2 < W_FLOATS ? i + 2 : 0]; v.w = P.w[i + 3 < W_FLOATS ? i + 3 : 0];
-        ((float4*)ldsW)[e] = v;
-    });
-    __syncthreads();
-
-    auto wf = [&](int tap, int ci, int oc) -> float {
-        if constexpr (C::WT == 0) return ldsW[(tap * C::WCI + ci) * C::WCO + oc];
-        else return ldsW[((8 - tap) * C::WCI + oc) * C::WCO + ci];
-    };
-    int pcx[4];
-#pragma unroll
-    for (int dx = 0; dx < 4; ++dx) pcx[dx] = G::pc(2 * q.qx + dx);
-
-    const int y0 = q.row0 + 2 * q.qy_l, x0 = 2 * q.qx;  // top-left conv output of the quad
-    const bool live = q.n < N;
-    // Retire padding threads now (no barrier follows).  Besides saving work this keeps the compiler from
-    // sinking the whole FMA block into the `if (live)` store region, which would leave every weight read
-    // of the kernel live at once.  (The x4-upsample gradient sums across lanes, so it keeps all lanes.)
-    if constexpr (!(C::EPI == EPI_DGRAD && C::UPS == 4)) {
-        if (!live) return;
-    }
-    constexpr int NCHUNK = C::OC / C::OCB;
-    static_assert(C::OC % C::OCB == 0, "chunking");
-
-    static_assert(NCHUNK % C::CW == 0, "chunks split evenly over the chunk waves");
-#pragma unroll 1
-    for (int ch = cw; ch < NCHUNK; ch += C::CW) {
-        const int oc0 = C::OC0 + ch * C::OCB;
-        if constexpr (C::EPI == EPI_DGRAD) {  // skip gradients nobody asked for (uniform branch)
-            const bool is_a = oc0 < C::OUT_A;
-            if (is_a ? (P.out == nullptr) : (P.out2 == nullptr)) continue;
-        }
-        float acc[4][C::OCB];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int o = 0; o < C::OCB; ++o) acc[i][o] = 0.f;
-
-        if constexpr (C::SRC == SRC_SCALAR) {
-            const float* t = (const float*)ldsA;
-            float pt[4][4];
-            int base = (q.img_l * G::TRA + 2 * q.qy_l) * (G::W + 2) + 2 * q.qx;
-#pragma unroll
-            for (int dy = 0; dy < 4; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 4; ++dx) pt[dy][dx] = t[base + dy * (G::W + 2) + dx];
-            fma_scalar<C::OCB>(acc, pt, wf, oc0);
-        } else {
-            constexpr int PA_FULL = C::CA / 4, REM = C::CA % 4;
-#pragma unroll 1
-            for (int pa = 0; pa < PA_FULL; ++pa) {
-                float4 pt[4][4];
-                read_patch_a<G>(pt, ldsA, pa, q, pcx);
-                fma_plane<C::OCB, 4>(acc, pt, wf, 4 * pa, oc0);
-            }
-            if constexpr (REM > 0) {
-                float4 pt[4][4];
-                read_patch_a<G>(pt, ldsA, PA_FULL, q, pcx);
-                fma_plane<C::OCB, REM>(acc, pt, wf, 4 * PA_FULL, oc0);
-            }
-        }
-        if constexpr (PB > 0) {
-#pragma unroll 1
-            for (int pb = 0; pb < PB; ++pb) {
-                float4 pt[4][4];
-                if constexpr (C::UPS == 2) read_patch_b2<G>(pt, ldsB, pb, q);
-                else read_patch_b4<G>(pt, ldsB, pb, q);
-                fma_plane<C::OCB, 4>(acc, pt, wf, C::CA + 4 * pb, oc0);
-            }
-        }
-
-        // ---------------- epilogues ----------------
-        if constexpr (C::EPI == EPI_POOL) {
-            constexpr int HP = G::H / 2, WP = G::W / 2;
-            float pooled[C::OCB];
-            uint32_t nib[(C::OCB + 7) / 8];
-#pragma unroll
-            for (int i = 0; i < (C::OCB + 7) / 8; ++i) nib[i] = 0;
-#pragma unroll
-            for (int o = 0; o < C::OCB; ++o) {
-                float b = cgs_to_const(P.bias)[oc0 + o];
-                float m = act_fwd<C::ACT>(acc[0][o] + b);
-                uint32_t idx = 0;
-#pragma unroll
-                for (int i = 1; i < 4; ++i) {
-                    float v = act_fwd<C::ACT>(acc[i][o] + b);
-                    if (v > m) { m = v; idx = i; }
-                }
-                if (!(m > 0.f)) idx = 15u;
-                pooled[o] = m;
-                nib[o / 8] |= idx << (4 * (o % 8));
-            }
-            if (live) {
-                int pi = (q.n * HP + (y0 >> 1)) * WP + q.qx;
-                float4* o4 = (float4*)(P.out + (size_t)pi * C::WCO + oc0);
-#pragma unroll
-                for (int i = 0; i < C::OCB / 4; ++i)
-                    o4[i] = make_float4(pooled[4 * i], pooled[4 * i + 1], pooled[4 * i + 2], pooled[4 * i + 3]);
-                if (P.amask_out) {
-#pragma unroll
-                    for (int i = 0; i < (C::OCB + 7) / 8; ++i) P.amask_out[pi * (C::WCO / 8) + oc0 / 8 + i] = nib[i];
-                }
-            }
-        } else if constexpr (C::EPI == EPI_PLAIN) {
-            if (live) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int y = y0 + (i >> 1), x = x0 + (i & 1);
-                    float v[C::OCB];
-#pragma unroll
-                    for (int o = 0; o < C::OCB; ++o) v[o] = act_fwd<C::ACT>(acc[i][o] + cgs_to_const(P.bias)[oc0 + o]);
-                    float* dst = P.out + ((size_t)(q.n * G::H + y) * G::W + x) * C::WCO + oc0;
-                    if constexpr (C::OCB % 4 == 0) {
-#pragma unroll
-                        for (int j = 0; j < C::OCB / 4; ++j)
-                            ((float4*)dst)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-                    } else {
-#pragma unroll
-                        for (int o = 0; o < C::OCB; ++o) dst[o] = v[o];
-                    }
-                }
-            }
-        } else {  // EPI_DGRAD: logical output channel = input channel of the layer
-            const bool is_a = oc0 < C::OUT_A;
-            if (is_a) {
-                constexpr int CAO = C::OUT_A;  // channels per pixel of d_a
-                if (live) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int y = y0 + (i >> 1), x = x0 + (i & 1);
-                        size_t pix = (size_t)(q.n * G::H + y) * G::W + x;
-                        float v[C::OCB];
-#pragma unroll
-                        for (int o = 0; o < C::OCB; ++o) v[o] = acc[i][o];
-                        if constexpr (C::OCB % 4 == 0 && C::DROP) {
-                            if (dc.on) {
-#pragma unroll
-                                for (int j = 0; j < C::OCB / 4; ++j) {
-                                    float4 m = drop_mult4(dc, (uint32_t)((pix * CAO + oc0) / 4 + j));
-                                    v[4 * j] *= m.x; v[4 * j + 1] *= m.y; v[4 * j + 2] *= m.z; v[4 * j + 3] *= m.w;
-                                }
-                            }
-                        }
-                        if constexpr (C::POST_ACT == CGS_ACT_LRELU) {
-                            const float* ap = P.a_post + pix * CAO + oc0;
-#pragma unroll
-                            for (int o = 0; o < C::OCB; ++o) v[o] *= (ap[o] > 0.f) ? 1.f : 0.01f;
-                        }
-                        if (P.addend && q.n < P.n_addend) {
-                            const float* ad = P.addend + pix * CAO + oc0;
-#pragma unroll
-                            for (int o = 0; o < C::OCB; ++o) v[o] += ad[o];
-                        }
-                        float* dst = P.out + pix * CAO + oc0;
-                        if constexpr (C::OCB % 4 == 0) {
-#pragma unroll
-                            for (int j = 0; j < C::OCB / 4; ++j)
-                                ((float4*)dst)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-                        } else {
-#pragma unroll
-                            for (int o = 0; o < C::OCB; ++o) dst[o] = v[o];
-                        }
-                    }
-                }
-            } else {  // source-B gradient: nearest-upsample backward = sum over the cell
-                constexpr int CBO = C::WCI - C::OUT_A;
-                float s[C::OCB];
-#pragma unroll
-                for (int o = 0; o < C::OCB; ++o) s[o] = (acc[0][o] + acc[1][o]) + (acc[2][o] + acc[3][o]);
-                if constexpr (C::UPS == 4) {  // 4 quads (consecutive lanes) of an image sum to one pixel
-#pragma unroll
-                    for (int o = 0; o < C::OCB; ++o) {
-                        s[o] += __shfl_xor(s[o], 1, 64);
-                        s[o] += __shfl_xor(s[o], 2, 64);
-                    }
-                    if (live && (qtid & 3) == 0) {
-                        float* dst = P.out2 + (size_t)q.n * CBO + (oc0 - C::OUT_A);
-#pragma unroll
-                        for (int o = 0; o < C::OCB; ++o) dst[o] = s[o];
-                    }
-                } else if (live) {
-                    size_t pi = (size_t)(q.n * G::QH + (y0 >> 1)) * G::QW + q.qx;
-                    float* dst = P.out2 + pi * CBO + (oc0 - C::OUT_A);
-                    if constexpr (C::OCB % 4 == 0) {
-#pragma unroll
-                        for (int j = 0; j < C::OCB / 4; ++j)
-                            ((float4*)dst)[j] = make_float4(s[4 * j], s[4 * j + 1], s[4 * j + 2], s[4 * j + 3]);
-                    } else {
-#pragma unroll
-                        for (int o = 0; o < C::OCB; ++o) dst[o] = s[o];
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <class C>
-static size_t conv_lds_bytes() {
-    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
-    constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
-    constexpr int PB = C::CB / 4;
-    size_t a = (C::SRC == SRC_SCALAR) ? (size_t)((G::IMGS * G::TRA * (G::W + 2) + 3) / 4) : (size_t)PA * G::IMGS * G::TRA * G::PWA;
-    size_t b = PB == 0 ? 0 : (C::UPS == 2 ? (size_t)PB * G::IMGS * G::TRB * G::PWB : (size_t)PB * G::IMGS);
-    size_t w = (size_t)(9 * C::WCI * C::WCO + 3) / 4;
-    return (a + b + 1 + w) * sizeof(float4);
-}
+#include "conv_body.h"
 
 template <class C>
 static int launch_conv(const ConvParams& P, hipStream_t st) {
@@ -300,50 +14,6 @@ static int launch_conv(const ConvParams& P, hipStream_t st) {
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Instance table (chfak = 1 Hourglass).  FWD(name, H, THREADS, SRC, CA, CB, UPS, CO, EPI, ACT)
-// ------------------------------------------------------------------------------------------------
-#define CGS_FWD_CFG(NAME, HW, THR, SRC_, CA_, CB_, UPS_, CO_, EPI_, ACT_, OCB_, CW_)                   \
-    struct NAME {                                                                                      \
-        static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = CA_, CB = CB_, UPS = UPS_; \
-        static constexpr int WT = 0, WCI = CA_ + CB_, WCO = CO_, OC0 = 0, OC = CO_, OCB = OCB_, CW = CW_; \
-        static constexpr int EPI = EPI_, ACT = ACT_, OUT_A = 0, POST_ACT = CGS_ACT_NONE;                \
-        static constexpr bool DROP = (HW == 8 && CB_ == 0);  /* only features.10 reads a dropped-out input */ \
-    };
-// data gradient: dY has DYC channels; weights are the layer's HWIO [.,.,LCI,LCO]
-#define CGS_DG_CFG(NAME, HW, THR, SRC_, DYC, LCI, LCO, UPS_, OC0_, OC_, OCB_, OUTA, PACT, CW_)         \
-    struct NAME {                                                                                      \
-        static constexpr int H = HW, W = HW, THREADS = THR, SRC = SRC_, CA = DYC, CB = 0, UPS = UPS_;   \
-        static constexpr int WT = 1, WCI = LCI, WCO = LCO, OC0 = OC0_, OC = OC_, OCB = OCB_, CW = CW_;  \
-        static constexpr int EPI = EPI_DGRAD, ACT = CGS_ACT_NONE, OUT_A = OUTA, POST_ACT = PACT;        \
-        static constexpr bool DROP = (HW == 8 && SRC_ == SRC_POOLEXP);                                   \
-    };
-
-CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
-CGS_FWD_CFG(FEnc0F32, 64, 256, SRC_F32C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
-CGS_FWD_CFG(FEnc1, 32, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
-CGS_FWD_CFG(FEnc2, 16, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
-CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 8, 2)
-CGS_FWD_CFG(FDec3, 4, 64, SRC_F32, 16, 32, 4, 16, EPI_PLAIN, CGS_ACT_NONE, 4, 4)
-CGS_FWD_CFG(FDec2, 8, 64, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
-CGS_FWD_CFG(FDec1, 16, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
-CGS_FWD_CFG(FDec0, 32, 256, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
-CGS_FWD_CFG(FMask0U8, 64, 256, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 16, 1)
-CGS_FWD_CFG(FMask0F32, 64, 256, SRC_F32C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 16, 1)
-CGS_FWD_CFG(FMask2, 64, 128, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID, 1, 1)
-
-//          name     HW  THR  SRC          DYC LCI LCO UPS OC0 OC OCB OUT_A post-act       CW
-CGS_DG_CFG(DEnc0, 64, 256, SRC_POOLEXP, 8, 3, 8, 2, 0, 3, 3, 3, CGS_ACT_NONE, 1)
-CGS_DG_CFG(DEnc1, 32, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE, 1)
-CGS_DG_CFG(DEnc2, 16, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE, 1)
-CGS_DG_CFG(DEnc3, 8, 64, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)
-CGS_DG_CFG(DDec3, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 6)
-CGS_DG_CFG(DDec2, 8, 64, SRC_F32, 8, 24, 8, 2, 0, 24, 8, 8, CGS_ACT_NONE, 3)
-CGS_DG_CFG(DDec1, 16, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
-CGS_DG_CFG(DDec0, 32, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
-CGS_DG_CFG(DMask0, 64, 128, SRC_F32, 16, 11, 16, 2, 3, 8, 8, 3, CGS_ACT_NONE, 1)
-CGS_DG_CFG(DMask2, 64, 128, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 8, 16, CGS_ACT_LRELU, 2)
 
 static bool desc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int src, int ups, int act, int pool) {
     return d->h == hw && d->w == hw && d->ca == ca && d->cb == cb && d->co == co && d->src_a == src &&
