@@ -29,6 +29,19 @@ ALGO_BYTES_PER_IMAGE = 4.841e6      # SURVEY.md section 8(d), fp32, chfak 1 (1 2
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(n):
+    """HBM bytes per step from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
+    FETCH_SIZE doubled per the gfx950 rule; tools/pmc_traffic.py).  None when no summary exists for this batch size:
+    counters cannot be collected from inside the timed run."""
+    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as fp:
+            t = json.load(fp)
+        return t["traffic_bytes_per_step"] if t.get("n_images") == n else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,7 +193,7 @@ def main():
                        "dropout": args.dropout, "lfak": 5, "L1": 0.5, "inject": True, "live": True,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "kernel": "one phase-2 step = one HIP-graph launch",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n,
                          "launch_ms": launch_ms},
