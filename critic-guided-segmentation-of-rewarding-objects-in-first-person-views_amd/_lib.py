@@ -39,6 +39,8 @@ SIGNATURES = {
     "cgs_conv3x3_bwd_data": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]),
     "cgs_conv3x3_bwd_weight_slabs": (i32, [C.POINTER(ConvDesc)]),
     "cgs_conv3x3_bwd_weight": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
+    "cgs_conv3x3_bwd_both_slabs": (i32, [C.POINTER(ConvDesc)]),
+    "cgs_conv3x3_bwd_both": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp]),
     "cgs_reduce_slabs": (i32, [vp, i32, i32, vp, vp]),
     "cgs_head_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, Dropout, Dropout, vp, vp, vp, vp]),
     "cgs_head_bwd_slabs": (i32, [i32]),

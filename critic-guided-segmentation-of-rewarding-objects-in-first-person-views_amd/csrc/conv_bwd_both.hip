@@ -1,0 +1,115 @@
+// Weight gradient and data gradient of one small layer in ONE launch ("horizontal" fusion).
+//
+// Both consume the same dY and are independent of each other; for the 16x16-and-smaller layers each is a
+// latency-bound launch that leaves most CUs idle.  Here the first `nbw` workgroups run the MFMA wgrad body and
+// the rest run the VALU data-gradient body, so the two overlap on the chip without a second stream (cross-queue
+// joins inside a HIP graph cost 6-10 us each on ROCm 7.2, more than they gain).
+#include "conv_body.h"
+#include "wgrad_body.h"
+
+template <class CWG, class CDG>
+__global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradParams pw, ConvParams pd, int nbw) {
+    static_assert(CWG::G::THREADS == CDG::THREADS * CDG::CW, "both halves use the same workgroup size");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    if ((int)blockIdx.x < nbw) {
+        constexpr int SLAB = (9 * (CWG::CA + CWG::CB) + 1) * CWG::CO;
+        wgrad_body<CWG>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+    } else {
+        conv3x3_body<CDG, false>(pd, blockIdx.x - nbw, smem);
+    }
+}
+
+// instances with matching workgroup sizes
+CGS_DG_CFG(DEnc3x, 8, 128, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)       // 256 threads
+struct WDec2x { using G = WGeo<8, 8, 8, 4, 192>; static constexpr int SRC = WSRC_F32, CA = 8, CB = 16, UPS = 2, CO = 8, DY = WDY_F32; };
+struct WDec3x { using G = WGeo<4, 4, 4, 4, 192>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, CO = 16, DY = WDY_F32; };
+CGS_DG_CFG(DDec3y, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 3)          // 192 threads
+struct WMask0U8x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_U8, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
+struct WMask0F32x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_F32, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
+
+static constexpr int kMaxBothWgradBlocks = 256;
+static constexpr int kMaxBothWgradBlocksBig = 1024;
+
+template <class CWG>
+static int both_slabs(int n) {
+    using GW = typename CWG::G;
+    int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
+    int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
+    return tiles < cap ? tiles : cap;
+}
+
+template <class CWG, class CDG>
+static int launch_both(WgradParams pw, const ConvParams& pd, hipStream_t st) {
+    using GW = typename CWG::G;
+    using GD = Geo<CDG::H, CDG::W, CDG::THREADS, CDG::CW>;
+    if (pd.n <= 0) return CGS_OK;
+    int tiles = (GW::IMGS == 1) ? pw.n * GW::STRIPS : (pw.n + GW::IMGS - 1) / GW::IMGS;
+    int nbw = both_slabs<CWG>(pw.n);
+    int nbd = (GD::IMGS == 1) ? pd.n * GD::STRIPS : (pd.n + GD::IMGS - 1) / GD::IMGS;
+    pw.ntiles = tiles;
+    size_t lw = wgrad_lds_bytes<CWG>(), ld = conv_lds_bytes<CDG>();
+    hipLaunchKernelGGL((conv_bwd_both_kernel<CWG, CDG>), dim3(nbw + nbd), dim3(GW::THREADS), lw > ld ? lw : ld, st, pw, pd, nbw);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+static int which(const cgs_conv_desc* d) {
+    auto is = [&](int hw, int ca, int cb, int co, int pool) {
+        return d->h == hw && d->w == hw && d->ca == ca && d->cb == cb && d->co == co && d->src_a == CGS_SRC_F32 &&
+               (cb == 0 || d->ups == 2) && d->pool == pool;
+    };
+    if (is(8, 8, 0, 16, 1) && d->act == CGS_ACT_RELU) return 1;    // features.10
+    if (is(16, 8, 0, 8, 1) && d->act == CGS_ACT_RELU) return 2;    // features.6
+    if (is(16, 8, 8, 8, 0) && d->act == CGS_ACT_NONE) return 3;    // dec_model.1
+    if (is(8, 8, 16, 8, 0) && d->act == CGS_ACT_NONE) return 4;    // dec_model.2
+    if (is(32, 8, 0, 8, 1) && d->act == CGS_ACT_RELU) return 5;    // features.3
+    if (is(32, 8, 8, 8, 0) && d->act == CGS_ACT_NONE) return 6;    // dec_model.0
+    if (d->h == 4 && d->w == 4 && d->ca == 16 && d->cb == 32 && d->co == 16 && d->ups == 4 && !d->pool) return 7;  // dec_model.3
+    if (is(64, 3, 0, 8, 1) && d->act == CGS_ACT_RELU) return 8;    // features.0 on the fp32 mixes
+    if (d->h == 64 && d->ca == 3 && d->cb == 8 && d->co == 16 && !d->pool) return d->src_a == CGS_SRC_U8 ? 9 : 10;  // masker.0
+    return 0;
+}
+
+extern "C" int cgs_conv3x3_bwd_both_slabs(const cgs_conv_desc* d) {
+    if (!d || d->n < 0) return CGS_ERR_BADARG;
+    switch (which(d)) {
+        case 1: return both_slabs<WEnc3>(d->n);
+        case 2: return both_slabs<WEnc2>(d->n);
+        case 3: return both_slabs<WDec1>(d->n);
+        case 4: return both_slabs<WDec2x>(d->n);
+        case 5: return both_slabs<WEnc1>(d->n);
+        case 6: return both_slabs<WDec0>(d->n);
+        case 7: return both_slabs<WDec3x>(d->n);
+        case 8: return both_slabs<WEnc0F32>(d->n);
+        case 9: return both_slabs<WMask0U8x>(d->n);
+        case 10: return both_slabs<WMask0F32x>(d->n);
+    }
+    return CGS_ERR_UNSUPPORTED;
+}
+
+extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, const float* src_b, const float* dy,
+                                    const uint32_t* amask, const float* w, const float* addend, int32_t n_addend,
+                                    float* d_a, float* d_b, float* slab, cgs_stream_t stream) {
+    if (!d || !src_a || !dy || !w || !slab || (!d_a && !d_b) || d->n < 0) return CGS_ERR_BADARG;
+    if (d->pool && !amask) return CGS_ERR_BADARG;
+    if (d->cb > 0 && !src_b) return CGS_ERR_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    WgradParams pw{};
+    pw.src_a = src_a; pw.src_b = src_b; pw.dy = dy; pw.amask = amask; pw.slab = slab; pw.n = d->n; pw.drop = d->drop_a;
+    ConvParams pd{};
+    pd.src_a = dy; pd.amask_in = amask; pd.w = w; pd.out = d_a; pd.out2 = d_b; pd.addend = addend; pd.n_addend = n_addend;
+    pd.n = d->n; pd.drop = d->drop_a;
+    switch (which(d)) {
+        case 1: return launch_both<WEnc3, DEnc3x>(pw, pd, st);
+        case 2: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc2, DEnc2>(pw, pd, st);
+        case 3: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec1, DDec1>(pw, pd, st);
+        case 4: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec2x, DDec2>(pw, pd, st);
+        case 5: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc1, DEnc1>(pw, pd, st);
+        case 6: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec0, DDec0>(pw, pd, st);
+        case 7: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec3x, DDec3y>(pw, pd, st);
+        case 8: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc0F32, DEnc0>(pw, pd, st);
+        case 9: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0U8x, DMask0>(pw, pd, st);
+        case 10: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0F32x, DMask0>(pw, pd, st);
+    }
+    return CGS_ERR_UNSUPPORTED;
+}

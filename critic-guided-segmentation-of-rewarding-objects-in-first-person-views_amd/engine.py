@@ -116,8 +116,10 @@ class HourglassEngine:
         nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
         specs = [("slab_head", lambda n: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
         for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
-            def f(n, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
+            def f(n, i=i, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
                 d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
+                if i in hg.BOTH_ENC and i > 0:
+                    return lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
                 return lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
             specs.append((f"slab_enc{i}", f, 9 * ca * co + co))
         for name, fn, cnt in specs:

@@ -8,6 +8,7 @@ Reference map:
   *_backward       what loss.backward() does for those modules (main.py:198,462)
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -17,6 +18,12 @@ from .spec import (DEC_LAYERS, DROP_SITE_E2, DROP_SITE_E3, DROP_SITE_H1, ENC_LAY
 
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
+# small layers: weight- and data-gradient halves share one launch (csrc/conv_bwd_both.hip)
+BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
+_both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
+BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
+BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
+_DEC_TAG = {0: "d3", 1: "d2", 2: "d1", 3: "d0", 4: "m0", 5: "m2"}
 PW_SLAB = 32 * 32 + 32
 
 
@@ -191,16 +198,29 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         key, hw, ca, cb, co, ups, act, pool, site = ENC_LAYERS[i]
         src = x if i == 0 else saved[f"e{i - 1}"]
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
+        cnt = 9 * ca * co + co
+        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
+        if need_wgrad and i in BOTH_ENC and (i > 0 or (dx is not None and dx_from == 0 and not u8)):
+            # both halves in one launch: slab + d e{i-1} (dropout mask and decoder skip gradient fused)
+            nsl = lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
+            if nsl < 0:
+                _lib.check(nsl, "cgs_conv3x3_bwd_both_slabs")
+            slab = buf(f"slab_enc{i}", (nsl, cnt))
+            nxt = buf(f"de{i - 1}", (n, hw, hw, ca)) if i > 0 else dx
+            _lib.call("cgs_conv3x3_bwd_both", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), wptr,
+                      _p(d_embeds[i - 1]) if (has_add and i > 0) else None, n_add if (has_add and i > 0) else 0, _p(nxt), None,
+                      _p(slab), _stream())
+            plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+            d_cur = nxt
+            continue
         nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
-        cnt = 9 * ca * co + co
         if need_wgrad:
             slab = buf(f"slab_enc{i}", (nsl, cnt))
             with side.fork():
                 _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
             plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
         if i > 0:   # d e{i-1} = conv_bwd * dropout mask + decoder skip gradient (fused epilogue)
             nxt = buf(f"de{i - 1}", (n, hw, hw, ca))
             _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(d_cur), _p(saved[f"am{i}"]), wptr, None, _lib.ACT_NONE,
@@ -273,15 +293,32 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
         key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]
         is_img = li == 4
         d = conv_desc(n, hw, ca, cb, co, u8 and is_img, ups, act, pool, nd)
+        cnt = 9 * (ca + cb) * co + co
+        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
+        if _DEC_TAG[li] in BOTH_DEC and li != 5:
+            nsl = lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
+            if nsl < 0:
+                _lib.check(nsl, "cgs_conv3x3_bwd_both_slabs")
+            slab = buf(f"slab_dec{li}", (nsl, cnt))
+            if li == 4:   # masker.0: only the upsampled decoder channels need a gradient
+                de, db = None, buf("do0", (n, 32, 32, 8))
+            else:
+                ei = 3 - li
+                de = buf(f"dE{ei}", (n, hw, hw, ca))
+                db = buf(f"do{ei + 1}", (n, 32) if ups == 4 else (n, hw // 2, hw // 2, cb))
+                d_embeds[ei] = de
+            _lib.call("cgs_conv3x3_bwd_both", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, wptr, None, 0,
+                      _p(de), _p(db), _p(slab), _stream())
+            plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+            dy = db
+            continue
         nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
-        cnt = 9 * (ca + cb) * co + co
         slab = buf(f"slab_dec{li}", (nsl, cnt))
         with side.fork():
             _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-        wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
         if li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)
             dhm = buf("dhm", (n, 64, 64, 16))
             _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, _p(saved["hm"]), _lib.ACT_LRELU, None, 0,

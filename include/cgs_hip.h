@@ -98,6 +98,16 @@ int cgs_conv3x3_bwd_weight(const cgs_conv_desc* d, const void* src_a, const floa
                            const float* dy, const uint32_t* amask, float* slab,
                            cgs_stream_t stream);
 
+/* ---- both backward halves of a SMALL layer in one launch ------------------------------
+ * Same results as cgs_conv3x3_bwd_weight + cgs_conv3x3_bwd_data (identical device code), but the wgrad
+ * workgroups and the data-gradient workgroups share one grid, so the two latency-bound halves overlap.
+ * Supported: features.3/6/10, features.0 on fp32 input, dec_model.0-3, masker.0 (CGS_ERR_UNSUPPORTED otherwise).
+ * d_a / d_b as for cgs_conv3x3_bwd_data (either may be NULL); slab as for cgs_conv3x3_bwd_weight with _both_slabs() slabs. */
+int cgs_conv3x3_bwd_both_slabs(const cgs_conv_desc* d);
+int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, const float* src_b, const float* dy,
+                         const uint32_t* amask, const float* w_hwio, const float* addend, int32_t n_addend,
+                         float* d_a, float* d_b, float* slab, cgs_stream_t stream);
+
 /* One reduction job: dst[i] (+)= sum_{b<nslab} slab[b*stride + i], i < count. */
 typedef struct {
     const float* slab;
