@@ -81,8 +81,8 @@ extern "C" int cgs_conv3x3_bwd_both_slabs(const cgs_conv_desc* d) {
         case 6: return both_slabs<WDec0>(d->n);
         case 7: return both_slabs<WDec3x>(d->n);
         case 8: return both_slabs<WEnc0F32>(d->n);
-        case 9: return both_slabs<WMask0U8x>(d->n);
-        case 10: return both_slabs<WMask0F32x>(d->n);
+        case 9: return both_slabs<WMask0U8>(d->n);
+        case 10: return both_slabs<WMask0F32>(d->n);
     }
     return CGS_ERR_UNSUPPORTED;
 }
@@ -108,8 +108,8 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
         case 6: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec0, DDec0>(pw, pd, st);
         case 7: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec3x, DDec3y>(pw, pd, st);
         case 8: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc0F32, DEnc0>(pw, pd, st);
-        case 9: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0U8x, DMask0>(pw, pd, st);
-        case 10: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0F32x, DMask0>(pw, pd, st);
+        case 9: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0U8, DMask0>(pw, pd, st);
+        case 10: if (d->drop_a.p > 0.f || d_a) return CGS_ERR_UNSUPPORTED; return launch_both<WMask0F32, DMask0>(pw, pd, st);
     }
     return CGS_ERR_UNSUPPORTED;
 }
