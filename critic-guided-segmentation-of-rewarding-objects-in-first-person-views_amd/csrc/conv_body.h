@@ -334,7 +334,7 @@ CGS_FWD_CFG(FDec1, 16, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
 CGS_FWD_CFG(FDec0, 32, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
 CGS_FWD_CFG(FMask0U8, 64, 128, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 8, 2)
 CGS_FWD_CFG(FMask0F32, 64, 128, SRC_F32C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 8, 2)
-CGS_FWD_CFG(FMask2, 64, 128, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID, 1, 1)
+CGS_FWD_CFG(FMask2, 64, 256, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID, 1, 1)
 
 //          name     HW  THR  SRC          DYC LCI LCO UPS OC0 OC OCB OUT_A post-act       CW
 CGS_DG_CFG(DEnc0, 64, 256, SRC_POOLEXP, 8, 3, 8, 2, 0, 3, 3, 3, CGS_ACT_NONE, 1)

@@ -10,7 +10,13 @@ static int launch_conv(const ConvParams& P, hipStream_t st) {
     using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     if (P.n <= 0) return CGS_OK;
     int blocks = (G::IMGS == 1) ? P.n * G::STRIPS : (P.n + G::IMGS - 1) / G::IMGS;
-    hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(blocks), dim3(C::THREADS * C::CW), conv_lds_bytes<C>(), st, P);
+    const size_t lds = conv_lds_bytes<C>();
+    if (lds > 64 * 1024) {   // more than the default dynamic-LDS limit: raise it once for this instance
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<C>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return (int)attr;
+    }
+    hipLaunchKernelGGL(conv3x3_kernel<C>, dim3(blocks), dim3(C::THREADS * C::CW), lds, st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     constexpr int PW = 68;                       // haloed row (66) padded to a multiple of 4 positions
     constexpr int XT = G::TRA * PW * CI, YT = G::TH * G::W;
     constexpr int SPR = PW / 4;                  // k-steps per haloed row
-    static_assert(G::IMGS == 1 && G::W == 64 && G::TRA % G::NW == 0, "co1 tile");
+    static_assert(G::IMGS == 1 && G::W == 64, "co1 tile");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     float* xt = (float*)smem;
     float* yt = xt + XT;
@@ -287,19 +287,48 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     const int ky = l15 / 3, kx = l15 % 3;
     frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    // register prefetch of the next tile (same pipeline as wgrad_body)
+    constexpr int NX = XT / 4, NYY = YT / 4;
+    constexpr int ITX = (NX + G::THREADS - 1) / G::THREADS, ITYY = (NYY + G::THREADS - 1) / G::THREADS;
+    float4 rx[ITX], ryy[ITYY];
+    auto fetch = [&](int tile) {
         const int n = tile / G::STRIPS, row0 = (tile % G::STRIPS) * G::TH;
-        for_elems<XT / 4, G::THREADS>(tid, [&](int e) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            int e = tid + it * G::THREADS; e = e < NX ? e : NX - 1;
             int q4 = e % (CI / 4), c = (e / (CI / 4)) % PW, r = e / ((CI / 4) * PW);
             int y = row0 + r - 1, x = c - 1;
             bool in = y >= 0 && y < G::H && x >= 0 && x < G::W;
-            float4 v = ((const float4*)P.src_a)[in ? ((n * G::H + y) * G::W + x) * (CI / 4) + q4 : 0];
-            ((float4*)xt)[e] = in ? v : f4zero();
-        });
-        for_elems<YT / 4, G::THREADS>(tid, [&](int e) {
-            ((float4*)yt)[e] = ((const float4*)P.dy)[((n * G::H + row0) * G::W) / 4 + e];
-        });
+            rx[it] = ((const float4*)P.src_a)[in ? ((n * G::H + y) * G::W + x) * (CI / 4) + q4 : 0];
+        }
+#pragma unroll
+        for (int it = 0; it < ITYY; ++it) {
+            int e = tid + it * G::THREADS; e = e < NYY ? e : NYY - 1;
+            ryy[it] = ((const float4*)P.dy)[((n * G::H + row0) * G::W) / 4 + e];
+        }
+    };
+    auto commit = [&](int tile) {
+        const int row0 = (tile % G::STRIPS) * G::TH;
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            int e = tid + it * G::THREADS; e = e < NX ? e : NX - 1;
+            int c = (e / (CI / 4)) % PW, r = e / ((CI / 4) * PW);
+            int y = row0 + r - 1, x = c - 1;
+            bool in = y >= 0 && y < G::H && x >= 0 && x < G::W;
+            ((float4*)xt)[e] = in ? rx[it] : f4zero();
+        }
+#pragma unroll
+        for (int it = 0; it < ITYY; ++it) {
+            int e = tid + it * G::THREADS; e = e < NYY ? e : NYY - 1;
+            ((float4*)yt)[e] = ryy[it];
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < P.ntiles) fetch(tile);
+    for (; tile < P.ntiles; tile += gridDim.x) {
+        commit(tile);
         __syncthreads();
+        if (tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);
         for (int r = wave; r < G::TRA; r += G::NW) {      // each wave owns whole haloed rows
             const int xrow = (r * PW + kq) * CI + l15;
             const int yl = r - ky;
@@ -312,11 +341,15 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
                 for (int u = 0; u < 4; ++u) {
                     if (c + u < SPR) {
                         a[u] = xt[xrow + (c + u) * 4 * CI];
+                        // only the first and the last k-step of a row can fall outside the image columns
+                        constexpr bool edge_possible = true;
+                        const bool interior = (c + u >= 1) && (c + u <= 15);
                         int x = 4 * (c + u) + kq - kx;
-                        bool in = rowok && x >= 0 && x < G::W;
+                        bool in = rowok && (interior || (x >= 0 && x < G::W));
                         float bv = yt[in ? yrow + 4 * (c + u) : 0];
                         b[u] = in ? bv : 0.f;
-                        if (l15 == 4) bsum += b[u];   // centre tap sees every dY of the tile exactly once
+                        bsum += b[u];                 // only the centre-tap lanes' sums are used (dbias)
+                        (void)edge_possible;
                     }
                 }
 #pragma unroll
@@ -365,5 +398,5 @@ CGS_WG_CFG(WDec1, 16, 16, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
 CGS_WG_CFG(WDec0, 32, 8, 1, WSRC_F32, 8, 8, 2, 8, WDY_F32)
 CGS_WG_CFG(WMask0U8, 64, 4, 1, WSRC_U8, 3, 8, 2, 16, WDY_F32)
 CGS_WG_CFG(WMask0F32, 64, 4, 1, WSRC_F32, 3, 8, 2, 16, WDY_F32)
-using WMask2G = WGeo<64, 64, 2, 1, 256>;
+using WMask2G = WGeo<64, 64, 4, 1, 384>;   // 6 haloed rows, one per wave
 
