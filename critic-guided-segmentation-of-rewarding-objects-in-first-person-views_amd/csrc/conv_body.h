@@ -326,11 +326,11 @@ static size_t conv_lds_bytes() {
 CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
 CGS_FWD_CFG(FEnc0F32, 64, 256, SRC_F32C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
 CGS_FWD_CFG(FEnc1, 32, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
-CGS_FWD_CFG(FEnc2, 16, 256, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
-CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 8, 2)
+CGS_FWD_CFG(FEnc2, 16, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
+CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 4, 4)
 CGS_FWD_CFG(FDec3, 4, 64, SRC_F32, 16, 32, 4, 16, EPI_PLAIN, CGS_ACT_NONE, 4, 4)
 CGS_FWD_CFG(FDec2, 8, 64, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
-CGS_FWD_CFG(FDec1, 16, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 8, 1)
+CGS_FWD_CFG(FDec1, 16, 64, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
 CGS_FWD_CFG(FDec0, 32, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
 CGS_FWD_CFG(FMask0U8, 64, 128, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 8, 2)
 CGS_FWD_CFG(FMask0F32, 64, 128, SRC_F32C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 8, 2)
@@ -339,11 +339,11 @@ CGS_FWD_CFG(FMask2, 64, 256, SRC_F32, 16, 0, 2, 1, EPI_PLAIN, CGS_ACT_SIGMOID, 1
 //          name     HW  THR  SRC          DYC LCI LCO UPS OC0 OC OCB OUT_A post-act       CW
 CGS_DG_CFG(DEnc0, 64, 256, SRC_POOLEXP, 8, 3, 8, 2, 0, 3, 3, 3, CGS_ACT_NONE, 1)
 CGS_DG_CFG(DEnc1, 32, 128, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)
-CGS_DG_CFG(DEnc2, 16, 256, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 8, 8, CGS_ACT_NONE, 1)
+CGS_DG_CFG(DEnc2, 16, 128, SRC_POOLEXP, 8, 8, 8, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DEnc3, 8, 64, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DDec3, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 6)
 CGS_DG_CFG(DDec2, 8, 64, SRC_F32, 8, 24, 8, 2, 0, 24, 8, 8, CGS_ACT_NONE, 3)
-CGS_DG_CFG(DDec1, 16, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
+CGS_DG_CFG(DDec1, 16, 64, SRC_F32, 8, 16, 8, 2, 0, 16, 4, 8, CGS_ACT_NONE, 4)
 CGS_DG_CFG(DDec0, 32, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DMask0, 64, 128, SRC_F32, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DMask2, 64, 128, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 8, 16, CGS_ACT_LRELU, 2)
