@@ -167,31 +167,34 @@ __global__ void __launch_bounds__(256) phase1_loss_kernel(int n, const float* __
     if (threadIdx.x == 0) losses[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n;
 }
 
-// grid = (ceil(max_count/32), njobs); block = 32 columns x 8 slab lanes (coalesced 128-B rows)
+// grid = (ceil(max_count/16), njobs); block = 16 columns x 16 slab lanes, 8 independent partial sums per thread
+// (the slabs were just written, so they are L2-resident: the kernel is latency-bound and wants loads in flight).
 __global__ void __launch_bounds__(256) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
-    __shared__ float red[8][33];
+    __shared__ float red[16][17];
     const cgs_reduce_job j = jobs[blockIdx.y];
     if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
-    if (blockIdx.x * 32 >= j.count) return;
-    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (blockIdx.x * 16 >= j.count) return;
+    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
     if (i < j.count) {
         const float* p = j.slab + i;
         int b = sl;
-        for (; b + 24 < j.nslab; b += 32) {
-            s0 += p[(size_t)b * j.stride];
-            s1 += p[(size_t)(b + 8) * j.stride];
-            s2 += p[(size_t)(b + 16) * j.stride];
-            s3 += p[(size_t)(b + 24) * j.stride];
+        for (; b + 7 * 16 < j.nslab; b += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(b + u * 16) * j.stride];
         }
-        for (; b < j.nslab; b += 8) s0 += p[(size_t)b * j.stride];
+        for (; b < j.nslab; b += 16) s[0] += p[(size_t)b * j.stride];
     }
-    red[sl][col] = (s0 + s1) + (s2 + s3);
+    red[sl][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (sl == 0 && i < j.count) {
-        float s = ((red[0][col] + red[1][col]) + (red[2][col] + red[3][col])) + ((red[4][col] + red[5][col]) + (red[6][col] + red[7][col]));
-        j.dst[i] = j.accumulate ? j.dst[i] + s : s;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][col];
+        j.dst[i] = j.accumulate ? j.dst[i] + t : t;
     }
 }
 
@@ -290,7 +293,7 @@ extern "C" int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int
 extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step,
                                 cgs_stream_t stream) {
     if (!jobs || njobs <= 0 || max_count <= 0) return CGS_ERR_BADARG;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 31) / 32, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 15) / 16, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
