@@ -216,20 +216,31 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* e3, c
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int d32_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
 
+// stage a [32][32] fp32 tile (rows of 32 contiguous floats, `rows_valid` of them real) into LDS with coalesced 16-B loads
+__device__ __forceinline__ void pw_stage(float (*dst)[33], const float* __restrict__ src, int rows_valid, int lane) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int idx = lane + 64 * it, row = idx >> 3, c4 = idx & 7;
+        float4 v = row < rows_valid ? ((const float4*)src)[row * 8 + c4] : f4zero();
+        dst[row][c4 * 4] = v.x; dst[row][c4 * 4 + 1] = v.y; dst[row][c4 * 4 + 2] = v.z; dst[row][c4 * 4 + 3] = v.w;
+    }
+}
+
 __global__ void __launch_bounds__(64) pointwise32_fwd_kernel(int n, const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y) {
+    __shared__ float xs[32][33], ws[32][33];
     const int lane = threadIdx.x, i = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    const int mi = n0 + i;
+    pw_stage(xs, x + (size_t)n0 * 32, n - n0 < 32 ? n - n0 : 32, lane);
+    pw_stage(ws, w, 32, lane);
+    __syncthreads();
     frag16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         int k = 2 * s + half;
-        float a = (mi < n) ? x[mi * 32 + k] : 0.f;
-        float bb = w[k * 32 + i];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[i][k], ws[k][i], acc, 0, 0, 0);
     }
     float bias = b[i];
 #pragma unroll
@@ -244,9 +255,14 @@ static constexpr int PW_SLAB = 32 * 32 + 32;
 __global__ void __launch_bounds__(64) pointwise32_bwd_kernel(int n, const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ w, float* __restrict__ dx,
                                                             float* __restrict__ slab) {
+    __shared__ float xs[32][33], ds[32][33], ws[32][33];
     const int lane = threadIdx.x, i = lane & 31, half = lane >> 5;
     const int n0 = blockIdx.x * 32;
-    const int mi = n0 + i;
+    const int rows = n - n0 < 32 ? n - n0 : 32;
+    pw_stage(xs, x + (size_t)n0 * 32, rows, lane);
+    pw_stage(ds, dy + (size_t)n0 * 32, rows, lane);
+    pw_stage(ws, w, 32, lane);
+    __syncthreads();
     // dx[img][k] = sum_o dy[img][o] w[k][o]
     frag16 acc;
 #pragma unroll
@@ -254,9 +270,7 @@ __global__ void __launch_bounds__(64) pointwise32_bwd_kernel(int n, const float*
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
         int oo = 2 * s + half;
-        float a = (mi < n) ? dy[mi * 32 + oo] : 0.f;
-        float bb = w[i * 32 + oo];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ds[i][oo], ws[i][oo], acc, 0, 0, 0);
     }
     if (dx) {
 #pragma unroll
@@ -271,11 +285,10 @@ __global__ void __launch_bounds__(64) pointwise32_bwd_kernel(int n, const float*
     float bsum = 0.f;
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        int m = n0 + 2 * s + half;
-        float a = (m < n) ? x[m * 32 + i] : 0.f;
-        float bb = (m < n) ? dy[m * 32 + i] : 0.f;
+        int m = 2 * s + half;
+        float bb = ds[m][i];
         bsum += bb;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[m][i], bb, acc, 0, 0, 0);
     }
     float* sl = slab + (size_t)blockIdx.x * PW_SLAB;
 #pragma unroll
