@@ -231,3 +231,81 @@ def test_forward_backward_with_dropout_vs_oracle_masks(ctx):
     rel_close(c["pred"].cpu().numpy(), pred[:, 0].detach().numpy(), "pred with dropout")
     for k, v in lc.unflatten(g).items():
         rel_close(v.cpu().numpy(), pc[k].grad.numpy(), f"critic grad {k} (dropout)")
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9])
+def test_ragged_batches_forward_backward(ctx, n):
+    """Batch sizes that do not fill a workgroup's image group (padding lanes, partial tiles)."""
+    hg, dev, lc, lm = ctx["hg"], ctx["dev"], ctx["lc"], ctx["lm"]
+    rs = np.random.RandomState(100 + n)
+    x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    cot_pred = torch.from_numpy(rs.randn(n).astype(np.float32))
+    cot_Z = torch.from_numpy(rs.randn(n, 64, 64).astype(np.float32) * 0.1)
+    zeros = [torch.zeros(s) for s in [(n, 8, 32, 32), (n, 8, 16, 16), (n, 8, 8, 8), (n, 16, 4, 4), (n, 32, 1, 1)]]
+    pc, pm, X, Z = _oracle_grads(ctx, x_u8, cot_pred, zeros, cot_Z)
+    xd = torch.from_numpy(x_u8).to(dev)
+    c = hg.critic_forward(ctx["fc"], lc, xd, n)
+    embeds = [c[f"e{i}"] for i in range(5)]
+    m = hg.masker_forward(ctx["fm"], lm, xd, embeds, n)
+    rel_close(m["Z"].cpu().numpy(), Z[:, 0].detach().numpy(), "Z")
+    dzpre = (cot_Z.to(dev) * m["Z"] * (1 - m["Z"])).contiguous()
+    plan_m, plan_c = hg.SlabPlan(), hg.SlabPlan()
+    d_emb = hg.masker_backward(ctx["fm"], lm, xd, embeds, n, m, dzpre, plan_m)
+    hg.critic_backward(ctx["fc"], lc, xd, n, c, cot_pred.to(dev), plan_c, d_embeds=d_emb, n_add=n)
+    gm, gc = torch.zeros(lm.total, device=dev), torch.zeros(lc.total, device=dev)
+    plan_m.build(gm).run()
+    plan_c.build(gc).run()
+    for k, v in lm.unflatten(gm).items():
+        rel_close(v.cpu().numpy(), pm[k].grad.numpy(), f"masker grad {k} (n={n})")
+    for k, v in lc.unflatten(gc).items():
+        rel_close(v.cpu().numpy(), pc[k].grad.numpy(), f"critic grad {k} (n={n})")
+
+
+def test_empty_batch_and_bad_arguments(ctx):
+    """n = 0 is a no-op; unsupported shapes and null pointers are reported through the return code."""
+    from cgs_amd import _lib
+    import ctypes as C
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    buf = torch.zeros(64, device=ctx["dev"])
+    p = C.c_void_p(buf.data_ptr())
+    d0 = _lib.ConvDesc(0, 64, 64, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
+    assert lib.cgs_conv3x3_fwd(C.byref(d0), p, None, p, p, p, None, st) == _lib.OK
+    assert lib.cgs_head_fwd(0, p, p, p, p, p, p, p, _lib.Dropout(), _lib.Dropout(), p, p, p, st) == _lib.OK
+    bad = _lib.ConvDesc(4, 48, 48, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
+    assert lib.cgs_conv3x3_fwd(C.byref(bad), p, None, p, p, p, None, st) == _lib.ERR_UNSUPPORTED
+    ok = _lib.ConvDesc(4, 64, 64, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
+    assert lib.cgs_conv3x3_fwd(C.byref(ok), None, None, p, p, p, None, st) == _lib.ERR_BADARG
+    assert lib.cgs_conv3x3_bwd_data(C.byref(ok), p, None, p, None, 0, None, 0, p, None, st) == _lib.ERR_BADARG  # pool needs amask
+    assert lib.cgs_pointwise_fwd(4, 16, 32, p, p, p, p, st) == _lib.ERR_UNSUPPORTED
+    assert lib.cgs_mix_fwd(1, 4095, p, p, p, 1, p, p, st) == _lib.ERR_BADARG
+    with pytest.raises(_lib.CgsError, match="CGS_ERR_UNSUPPORTED"):
+        _lib.call("cgs_conv3x3_fwd", C.byref(bad), p, None, p, p, p, None, st)
+    torch.cuda.synchronize()
+
+
+def test_shared_launch_backward_equals_separate_launches(ctx):
+    """cgs_conv3x3_bwd_both runs the same device code as bwd_weight + bwd_data: identical bits."""
+    from cgs_amd import _lib
+    import ctypes as C
+    hg, dev, lc = ctx["hg"], ctx["dev"], ctx["lc"]
+    lib = _lib.load()
+    n = 24
+    rs = np.random.RandomState(8)
+    e0 = torch.from_numpy(rs.rand(n, 32, 32, 8).astype(np.float32)).to(dev)
+    de1 = torch.from_numpy(rs.randn(n, 16, 16, 8).astype(np.float32)).to(dev)
+    am = torch.from_numpy(rs.randint(0, 2 ** 31, (n, 16, 16, 1)).astype(np.int32)).to(dev)   # arbitrary nibbles (incl. invalid ones)
+    w = C.c_void_p(ctx["fc"].data_ptr() + 4 * lc.off("features.3.weight"))
+    d = hg.conv_desc(n, 32, 8, 0, 8, False, 2, "relu", 1, _lib.Dropout())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ns1 = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+    s1 = torch.zeros(ns1, 584, device=dev); dx1 = torch.empty(n, 32, 32, 8, device=dev)
+    _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), P(e0), None, P(de1), P(am), P(s1), st)
+    _lib.call("cgs_conv3x3_bwd_data", C.byref(d), P(de1), P(am), w, None, _lib.ACT_NONE, None, 0, P(dx1), None, st)
+    ns2 = lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
+    s2 = torch.zeros(ns2, 584, device=dev); dx2 = torch.empty_like(dx1)
+    _lib.call("cgs_conv3x3_bwd_both", C.byref(d), P(e0), None, P(de1), P(am), w, None, 0, P(dx2), None, P(s2), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx2)
+    np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s2.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5)
