@@ -14,6 +14,8 @@ struct ConvParams {
     uint32_t* amask_out;
     const float* addend;
     const float* a_post;
+    const float* w2;       // SRC_DH: masker.2 weights [9][16]
+    float* dh_out;         // SRC_DH: gradient w.r.t. the masker.0 output, written for the weight-gradient kernel
     int n, n_addend;
     cgs_dropout drop;
 };
@@ -40,6 +42,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
     // packed forms (52-60 TF/s measured on gfx950, tools/valu_peak.hip).
     constexpr int W_FLOATS = 9 * C::WCI * C::WCO;
     float* ldsW = (float*)(ldsB + B_ELEMS);
+    constexpr int DZW = G::W + 4, DZ_FLOATS = (C::SRC == SRC_DH) ? (G::TRA + 2) * DZW : 0;
+    float* ldsDz = ldsW + ((W_FLOATS + 3) / 4) * 4;     // SRC_DH: dzpre tile with a 2-pixel halo
 
     const int tid = threadIdx.x;                 // all threads take part in the loads
     const int qtid = tid % C::THREADS;           // quad handled by this thread
@@ -61,6 +65,49 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
     } else if constexpr (C::SRC == SRC_POOLEXP) {
         load_poolexp<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, q.row0, N, tid,
                                [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
+        zero_halo_cols<G, PA>(ldsA, tid);
+    } else if constexpr (C::SRC == SRC_DH) {
+        // d(masker.0 output) is never read from memory here: it is rebuilt from dzpre (1 channel) and the LeakyReLU
+        // mask of the saved activation, dH = LeakyReLU'(h) * conv_bwd(dzpre; masker.2), used as this kernel's input
+        // tile AND written out once (interior rows) for the masker.0 weight-gradient kernel.
+        static_assert(G::IMGS == 1 && C::CA == 16, "mask-head tile");
+        const float* dzp = (const float*)P.src_a;
+        for_elems<DZ_FLOATS, G::LT>(tid, [&](int e) {
+            int c2 = e % DZW, r2 = e / DZW;
+            int y = q.row0 + r2 - 2, x = c2 - 2;
+            bool in = n0 < N && y >= 0 && y < G::H && x >= 0 && x < G::W;
+            float v = dzp[in ? (n0 * G::H + y) * G::W + x : 0];
+            ldsDz[e] = in ? v : 0.f;
+        });
+        const int pl = tid & 3;                       // the 4-channel plane this thread builds (LT % 4 == 0)
+        float w2r[9][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w2r[t][c] = P.w2[t * 16 + 4 * pl + c];
+        __syncthreads();
+        constexpr int E = G::TRA * G::W * 4;
+        for_elems<E, G::LT>(tid, [&](int e) {
+            int x = (e / 4) % G::W, r = e / (4 * G::W);
+            int y = q.row0 + r - 1;
+            bool in = n0 < N && y >= 0 && y < G::H;
+            int gi = in ? ((n0 * G::H + y) * G::W + x) * 4 + pl : 0;
+            float4 hv = ((const float4*)P.a_post)[gi];
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float d = ldsDz[(r + 2 - ky) * DZW + x + 3 - kx];
+                    a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
+                    a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
+                }
+            float4 v = make_float4(a0 * (hv.x > 0.f ? 1.f : 0.01f), a1 * (hv.y > 0.f ? 1.f : 0.01f),
+                                   a2 * (hv.z > 0.f ? 1.f : 0.01f), a3 * (hv.w > 0.f ? 1.f : 0.01f));
+            v = in ? v : f4zero();
+            ldsA[ldsA_idx<G, PA>(pl, 0, r, x + 1)] = v;
+            if (in && r >= 1 && r <= G::TH) ((float4*)P.dh_out)[gi] = v;
+        });
         zero_halo_cols<G, PA>(ldsA, tid);
     } else {  // SRC_SCALAR: one fp32 channel, tile of floats [img][TRA][W+2]
         float* t = (float*)ldsA;
@@ -301,7 +348,8 @@ static size_t conv_lds_bytes() {
     size_t a = (C::SRC == SRC_SCALAR) ? (size_t)((G::IMGS * G::TRA * (G::W + 2) + 3) / 4) : (size_t)PA * G::IMGS * G::TRA * G::PWA;
     size_t b = PB == 0 ? 0 : (C::UPS == 2 ? (size_t)PB * G::IMGS * G::TRB * G::PWB : (size_t)PB * G::IMGS);
     size_t w = (size_t)(9 * C::WCI * C::WCO + 3) / 4;
-    return (a + b + 1 + w) * sizeof(float4);
+    size_t dz = (C::SRC == SRC_DH) ? (size_t)((G::TRA + 2) * (G::W + 4) + 3) / 4 : 0;
+    return (a + b + 1 + w + dz) * sizeof(float4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -347,4 +395,6 @@ CGS_DG_CFG(DDec1, 16, 64, SRC_F32, 8, 16, 8, 2, 0, 16, 4, 8, CGS_ACT_NONE, 4)
 CGS_DG_CFG(DDec0, 32, 128, SRC_F32, 8, 16, 8, 2, 0, 16, 8, 8, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DMask0, 64, 128, SRC_F32, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 2)
 CGS_DG_CFG(DMask2, 64, 128, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 8, 16, CGS_ACT_LRELU, 2)
+// masker.2 + masker.0 data gradients in one pass (SRC_DH rebuilds d(masker.0 output) in the loader)
+CGS_DG_CFG(DMaskHead, 64, 128, SRC_DH, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 2)
 

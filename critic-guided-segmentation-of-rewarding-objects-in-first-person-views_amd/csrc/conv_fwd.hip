@@ -85,3 +85,11 @@ extern "C" int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, con
     }
     return CGS_ERR_UNSUPPORTED;
 }
+
+extern "C" int cgs_mask_head_bwd_data(int32_t n, const float* dzpre, const float* h, const float* w_m2, const float* w_m0,
+                                      float* d_h, float* d_o0, cgs_stream_t stream) {
+    if (n < 0 || !dzpre || !h || !w_m2 || !w_m0 || !d_h || !d_o0) return CGS_ERR_BADARG;
+    ConvParams P{};
+    P.src_a = dzpre; P.a_post = h; P.w2 = w_m2; P.w = w_m0; P.dh_out = d_h; P.out2 = d_o0; P.n = n;
+    return launch_conv<DMaskHead>(P, (hipStream_t)stream);
+}

@@ -18,7 +18,7 @@
 #pragma once
 #include "cgs_common.h"
 
-enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4 };
+enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5 };
 
 // THREADS = quads per workgroup; CW = waves-groups that split the output-channel chunks of those quads
 // between them (small images: more waves per image); LT = threads that take part in the tile loads.

@@ -20,6 +20,7 @@ _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "
 HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
 # small layers: weight- and data-gradient halves share one launch (csrc/conv_bwd_both.hip)
 BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
+MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
 _both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
@@ -289,6 +290,8 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
     srcs_b = [saved["o4"], saved["o3"], saved["o2"], saved["o1"], saved["o0"], None]
     d_embeds: List[Optional[torch.Tensor]] = [None] * 5
     dy = dzpre
+    fused_head_do0 = None
+    u8_or_f32_needs_da = False   # the image never needs a gradient on this path
     for li in (5, 4, 3, 2, 1, 0):
         key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]
         is_img = li == 4
@@ -319,11 +322,20 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
         with side.fork():
             _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-        if li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)
+        if li == 5 and MASK_HEAD_FUSED and not u8_or_f32_needs_da:
+            # masker.2 weight gradient is launched above; its data gradient is rebuilt inside the masker.0 kernel
+            dhm, do0 = buf("dhm", (n, 64, 64, 16)), buf("do0", (n, 32, 32, 8))
+            _lib.call("cgs_mask_head_bwd_data", n, _p(dzpre), _p(saved["hm"]), wptr,
+                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(dhm), _p(do0), _stream())
+            dy = dhm
+            fused_head_do0 = do0
+        elif li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)
             dhm = buf("dhm", (n, 64, 64, 16))
             _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, _p(saved["hm"]), _lib.ACT_LRELU, None, 0,
                       _p(dhm), None, _stream())
             dy = dhm
+        elif li == 4 and fused_head_do0 is not None:
+            dy = fused_head_do0      # already produced together with d hm
         elif li == 4:  # masker.0: only the upsampled decoder channels need a gradient
             do0 = buf("do0", (n, 32, 32, 8))
             _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, None, _lib.ACT_NONE, None, 0, None, _p(do0), _stream())

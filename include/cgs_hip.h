@@ -88,6 +88,14 @@ int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, const uint32_t
                          const float* addend, int32_t n_addend, float* d_a, float* d_b,
                          cgs_stream_t stream);
 
+/* ---- mask head, data gradients of masker.2 AND masker.0 in one pass (nets.py:488-491 backward) ----
+ * dzpre [n,64,64] (gradient w.r.t. the pre-sigmoid mask), h [n,64,64,16] (saved masker.0 output).
+ *   d_h  [n,64,64,16] = LeakyReLU'(h) * conv_bwd_data(dzpre; w_m2)   (written once, for the masker.0 wgrad)
+ *   d_o0 [n,32,32,8]  = upsample-backward of conv_bwd_data(d_h; w_m0) restricted to the 8 decoder channels.
+ * d_h is rebuilt inside the loader from the 1-channel dzpre instead of being read back from memory.      */
+int cgs_mask_head_bwd_data(int32_t n, const float* dzpre, const float* h, const float* w_m2_hwio,
+                           const float* w_m0_hwio, float* d_h, float* d_o0, cgs_stream_t stream);
+
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
  *   slab[b][0 .. 9*(ca+cb)*co)  = partial dW (HWIO),  slab[b][9*(ca+cb)*co ..][co] = partial dbias
