@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="A-images (= B-images) per GPU per step")
     ap.add_argument("--dropout", type=float, default=0.3)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--mode", choices=["train", "infer", "phase1"], default="train",
+                    help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
+                         "phase1 = critic regression step (main.py:183-200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -125,6 +128,36 @@ def cpu_baseline(n, steps, dropout):
             "ms_per_step": dt * 1e3, "cpu_model": model}
 
 
+def side_mode(args, dev, world, rank):
+    """Secondary measurements of the same path (not the headline metric): inference and the phase-1 step."""
+    from cgs_amd import engine
+    n = args.batch
+    eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph)
+    eng.load_state(*g1_weights())
+    A, B, Y = synthetic(n, rank, dev)
+    if args.mode == "infer":
+        run = lambda: eng.infer(A)
+        bytes_per_img, what = 1.126e6, "eval-mode critic(collect)+masker forward, fp32 (SURVEY 8d: 0.563 MB/img at fp16 -> 1.126 MB fp32)"
+    else:
+        eng.phase1_step(A, Y)
+        run = lambda: eng.phase1_step()
+        bytes_per_img, what = (67457 + 78529) * 4.0, "phase-1 critic regression step (critic fwd + bwd + Adam)"
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    ach = bytes_per_img * n / dt / 1e9
+    print(json.dumps({"metric": f"Hourglass {args.mode} images/sec, 64x64x3 batch={n}", "value": n / dt, "unit": "images/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                      "dtype": "f32", "data": "synthetic", "config": {"workload": what, "batch": n},
+                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                   "traffic": None}}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +176,8 @@ def main():
 
     from cgs_amd import engine
     n = args.batch
+    if args.mode != "train":
+        return side_mode(args, dev, world, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)

@@ -15,7 +15,7 @@ from itertools import chain
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, dataformat
 from .engine import HourglassEngine
 from .nets import NewCritic, UnetDecoder
 
@@ -91,15 +91,14 @@ class Handler:
     # ------------------------------------------------------------------ data
     def collect_data(self):
         args = self.args
-        filepath = self.data_path + f"{args.envname}-{args.datamode}-{args.datasize}-[{args.gammas}].pickle"
+        filepath = dataformat.dataset_path(args.envname, args.datamode, args.datasize, args.gammas, self.data_path)
         print("collecting dataset at", filepath)
         if not os.path.exists(filepath):
             raise FileNotFoundError(
                 f"{filepath} not found. This build reads the reference's gz-pickle (X uint8 [N,64,64,3], Y float [7,N], "
                 "I uint16 [N]) but does not collect it: MineRL download/decoding is out of scope (SURVEY.md 2.3).")
         print("loading existing dataset...")
-        with gzip.open(filepath, "rb") as fp:
-            X, Y, I = pickle.load(fp)
+        X, Y, I = dataformat.read_dataset(filepath)
         print("finished loading exisiting dataset")
         return X, Y, I
 
