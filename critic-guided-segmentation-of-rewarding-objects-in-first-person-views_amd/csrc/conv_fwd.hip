@@ -4,6 +4,15 @@
 //   backward: the same core with transposed/flipped weights; pool/ReLU gradient re-expansion in the
 //             loader; dropout, LeakyReLU', skip-gradient add and upsample-backward sums in the epilogue.
 #include "conv_body.h"
+#include <cstdlib>
+
+// layers routed to the MFMA implicit-GEMM kernels (mconv.hip); CGS_MCONV=0 keeps them on the VALU kernels (A/B)
+int mconv_fwd_dispatch(int which, int n, const void* src_a, const float* src_b, const float* w, const float* bias, float* out,
+                       hipStream_t st);
+static bool use_mconv() {
+    static const bool on = [] { const char* e = std::getenv("CGS_MCONV"); return !(e && e[0] == '0'); }();
+    return on;
+}
 
 template <class C>
 static int launch_conv(const ConvParams& P, hipStream_t st) {
@@ -41,12 +50,15 @@ extern "C" int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const 
     if (desc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc1>(P, st);
     if (desc_is(d, 16, 8, 0, 8, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc2>(P, st);
     if (desc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc3>(P, st);
-    if (desc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, NO, 0)) return launch_conv<FDec3>(P, st);
+    if (desc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, NO, 0))
+        return use_mconv() ? mconv_fwd_dispatch(2, d->n, src_a, src_b, w, bias, out, st) : launch_conv<FDec3>(P, st);
     if (desc_is(d, 8, 8, 16, 8, CGS_SRC_F32, 2, NO, 0)) return launch_conv<FDec2>(P, st);
     if (desc_is(d, 16, 8, 8, 8, CGS_SRC_F32, 2, NO, 0)) return launch_conv<FDec1>(P, st);
     if (desc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, NO, 0)) return launch_conv<FDec0>(P, st);
-    if (desc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, L, 0)) return launch_conv<FMask0U8>(P, st);
-    if (desc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, L, 0)) return launch_conv<FMask0F32>(P, st);
+    if (desc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, L, 0))
+        return use_mconv() ? mconv_fwd_dispatch(0, d->n, src_a, src_b, w, bias, out, st) : launch_conv<FMask0U8>(P, st);
+    if (desc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, L, 0))
+        return use_mconv() ? mconv_fwd_dispatch(1, d->n, src_a, src_b, w, bias, out, st) : launch_conv<FMask0F32>(P, st);
     if (desc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, S, 0)) return launch_conv<FMask2>(P, st);
     return CGS_ERR_UNSUPPORTED;
 }
