@@ -315,18 +315,24 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
             plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
             dy = db
             continue
-        nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+        head_fused = li == 5 and MASK_HEAD_FUSED and not u8_or_f32_needs_da
+        nsl = lib.cgs_mask_head_bwd_slabs(n) if head_fused else 0   # >0: masker.2 wgrad rides along with the mask head
+        wg_in_head = nsl > 0
+        if not wg_in_head:
+            nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         slab = buf(f"slab_dec{li}", (nsl, cnt))
-        with side.fork():
-            _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
+        if not wg_in_head:
+            with side.fork():
+                _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-        if li == 5 and MASK_HEAD_FUSED and not u8_or_f32_needs_da:
-            # masker.2 weight gradient is launched above; its data gradient is rebuilt inside the masker.0 kernel
+        if head_fused:
+            # masker.2 data gradient is rebuilt inside the masker.0 data-gradient kernel (never stored as a conv output)
             dhm, do0 = buf("dhm", (n, 64, 64, 16)), buf("do0", (n, 32, 32, 8))
             _lib.call("cgs_mask_head_bwd_data", n, _p(dzpre), _p(saved["hm"]), wptr,
-                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(dhm), _p(do0), _stream())
+                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(dhm), _p(do0),
+                      _p(slab) if wg_in_head else None, _stream())
             dy = dhm
             fused_head_do0 = do0
         elif li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)

@@ -92,9 +92,16 @@ int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, const uint32_t
  * dzpre [n,64,64] (gradient w.r.t. the pre-sigmoid mask), h [n,64,64,16] (saved masker.0 output).
  *   d_h  [n,64,64,16] = LeakyReLU'(h) * conv_bwd_data(dzpre; w_m2)   (written once, for the masker.0 wgrad)
  *   d_o0 [n,32,32,8]  = upsample-backward of conv_bwd_data(d_h; w_m0) restricted to the 8 decoder channels.
- * d_h is rebuilt inside the loader from the 1-channel dzpre instead of being read back from memory.      */
+ * d_h is rebuilt inside the loader from the 1-channel dzpre instead of being read back from memory; the
+ * nearest-upsample in front of masker.0 is folded into its weights (one stride-2 4x4 conv on the matrix cores).
+ *   slab_m2 : optional [cgs_mask_head_bwd_slabs(n)][145] partial masker.2 weight+bias gradients (same slab
+ *             layout as cgs_conv3x3_bwd_weight for that layer), produced from the h / dzpre values already in
+ *             registers.  cgs_mask_head_bwd_slabs() returns 0 when this build cannot produce them (the caller
+ *             then runs cgs_conv3x3_bwd_weight for masker.2 and passes NULL here).                          */
+int cgs_mask_head_bwd_slabs(int32_t n);
 int cgs_mask_head_bwd_data(int32_t n, const float* dzpre, const float* h, const float* w_m2_hwio,
-                           const float* w_m0_hwio, float* d_h, float* d_o0, cgs_stream_t stream);
+                           const float* w_m0_hwio, float* d_h, float* d_o0, float* slab_m2,
+                           cgs_stream_t stream);
 
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"

@@ -1,5 +1,5 @@
 import csv, sys, glob
-f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv"))[-1]
+f = sorted(glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv") + glob.glob(sys.argv[1] + "/*_kernel_stats.csv"))[-1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 36
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
