@@ -9,9 +9,9 @@
 // layers routed to the MFMA implicit-GEMM kernels (mconv.hip); CGS_MCONV=0 keeps them on the VALU kernels (A/B)
 int mconv_fwd_dispatch(int which, int n, const void* src_a, const float* src_b, const float* w, const float* bias, float* out,
                        hipStream_t st);
-int mconv_mask_head(int n, const float* dzpre, const float* h, const float* w2, const float* w0, float* dh, float* d_o0,
-                    float* slab, hipStream_t st);
-int mconv_mask_head_slabs(int n);
+int mask_head_launch(int n, int img_kind, const void* img, const float* o0, const float* dzpre, const float* h,
+                     const float* w2, const float* w0, float* dh, float* d_o0, float* slab2, float* slab0, hipStream_t st);
+int mask_head_slabs(int n);
 static bool use_mconv() {
     static const bool on = [] { const char* e = std::getenv("CGS_MCONV"); return !(e && e[0] == '0'); }();
     return on;
@@ -103,14 +103,19 @@ extern "C" int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, con
 
 extern "C" int cgs_mask_head_bwd_slabs(int32_t n) {
     if (n < 0) return CGS_ERR_BADARG;
-    return use_mconv() ? mconv_mask_head_slabs(n) : 0;
+    return use_mconv() ? mask_head_slabs(n) : 0;
 }
 
-extern "C" int cgs_mask_head_bwd_data(int32_t n, const float* dzpre, const float* h, const float* w_m2, const float* w_m0,
-                                      float* d_h, float* d_o0, float* slab_m2, cgs_stream_t stream) {
-    if (n < 0 || !dzpre || !h || !w_m2 || !w_m0 || !d_h || !d_o0) return CGS_ERR_BADARG;
-    if (use_mconv()) return mconv_mask_head(n, dzpre, h, w_m2, w_m0, d_h, d_o0, slab_m2, (hipStream_t)stream);
-    if (slab_m2) return CGS_ERR_UNSUPPORTED;   // cgs_mask_head_bwd_slabs() said 0: the caller runs the separate wgrad
+extern "C" int cgs_mask_head_bwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* dzpre, const float* h,
+                                 const float* w_m2, const float* w_m0, float* d_h, float* d_o0, float* slab_m2,
+                                 float* slab_m0, cgs_stream_t stream) {
+    if (n < 0 || !dzpre || !h || !w_m2 || !w_m0 || !d_o0) return CGS_ERR_BADARG;
+    if (slab_m0 && (!slab_m2 || !x || !o0 || (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32))) return CGS_ERR_BADARG;
+    if (use_mconv())
+        return mask_head_launch(n, src_a, x, o0, dzpre, h, w_m2, w_m0, d_h, d_o0, slab_m2, slab_m0, (hipStream_t)stream);
+    // VALU build (CGS_MCONV=0): data gradients only; cgs_mask_head_bwd_slabs() said 0, the caller runs the separate wgrads
+    if (slab_m2 || slab_m0) return CGS_ERR_UNSUPPORTED;
+    if (!d_h) return CGS_ERR_BADARG;
     ConvParams P{};
     P.src_a = dzpre; P.a_post = h; P.w2 = w_m2; P.w = w_m0; P.dh_out = d_h; P.out2 = d_o0; P.n = n;
     return launch_conv<DMaskHead>(P, (hipStream_t)stream);

@@ -1,0 +1,464 @@
+// Mask head backward (nets.py:488-491 backward) in ONE kernel:
+//   * dH = d(masker.0 output) is rebuilt from the 1-channel dzpre and the LeakyReLU mask of the saved activation h
+//     (never read from memory, and written out only if the caller asks for it),
+//   * masker.2 weight gradient: dW2[ky][kx][ch] = sum_p h[p][ch] * dzpre[p + (1-ky, 1-kx)] uses exactly the (h pixel,
+//     dzpre neighbour) pairs the dH rebuild has in registers,
+//   * masker.0 data gradient w.r.t. its low-resolution input o0, with the nearest-upsample FOLDED into the weights:
+//       d_o0[q][c] = sum over the 2x2 cell of q of the 3x3 data gradient
+//                  = sum_{u,v in 0..3} sum_oc dH[2q + (u-1, v-1)][oc] * W4[u][v][oc][c],
+//       W4[u][v][oc][c] = sum_{a in {0,1}, ky = a+2-u in 0..2} sum_{b in {0,1}, kx = b+2-v in 0..2} W[ky][kx][3+c][oc]
+//     i.e. one stride-2 4x4 convolution (16 taps per output) instead of four 3x3 ones (36 taps): 2.25x fewer MACs;
+//     GEMM M = 16 low-res pixels of a row, K = 16 window positions x 16 channels, N = 8 (half a tile is padding),
+//   * masker.0 weight gradient (optional): implicit GEMM rows (tap, ci) x 16 output channels over the pixels, dH read
+//     straight from the LDS tile it was rebuilt into.
+// Workgroup = 8 waves with two roles, one tile (TH rows of one image) apart:
+//   waves 0-3 ("builders", VALU + memory): rebuild dH of tile i into xt[i&1] (+ masker.2 weight-gradient partials),
+//   waves 4-7 ("matrix" waves): the two GEMMs of tile i-1 out of xt[(i-1)&1] on the matrix cores.
+// Each SIMD hosts one wave of each role, so the VALU and MFMA pipes and the memory system work at the same time.
+// The role split is a SCALAR branch at the top level with one loop per role (the same number of workgroup barriers on
+// both sides): the register allocator then sees each role's state only inside its own loop.  With both roles in one
+// loop body every array of either role is live everywhere, the kernel spills, and each scratch reload carries an
+// s_waitcnt vmcnt(0) that also drains the prefetched global loads.
+// The dH tile is NHWC in LDS with a pixel stride of 17 floats so the stride-2 pixel reads of a wave hit 32 banks.
+#include "wgrad_body.h"   // frag4, for_elems
+
+struct MHeadParams {
+    const float* dzpre; const float* h; const float* w2; const float* w0;
+    const void* img;       // W0: masker.0 direct input (NHWC u8 or f32, 3 channels)
+    const float* o0;       // W0: masker.0 low-resolution input [n,32,32,8]
+    float* dh;             // optional
+    float* d_o0;
+    float* slab2;          // WG: masker.2 weight-gradient partials, one [145] slab per workgroup
+    float* slab0;          // W0: masker.0 weight-gradient partials, one [1600] slab per workgroup
+    int n, ntiles;
+};
+
+template <int TH, bool W0>
+struct MHeadGeo {
+    static constexpr int H = 64, W = 64, TRA = TH + 2, PW = W + 2, PS = 17, DZW = W + 4, DZR = TH + 4, STRIPS = H / TH;
+    static constexpr int XT = TRA * PW * PS, W4 = 16 * 16 * 8, DZ = DZR * DZW;
+    static constexpr int PCI = 12, XIN = W0 ? TRA * PW * PCI : 0;     // masker.0 input tile [TRA][PW][3+pad | 8]
+    static constexpr int FLOATS = 2 * XT + XIN + W4 + DZ;             // the dH tile is double buffered
+    static constexpr size_t LDS = (size_t)((FLOATS + 3) / 4) * 16;
+    static constexpr int CI = 11, ROWS = 9 * CI + 1, NRB = (ROWS + 15) / 16;   // masker.0 weight-gradient GEMM rows
+    static constexpr int RED2 = 0, RED0 = 1024;                        // reduction buffers (floats into the dH tiles)
+    static_assert(RED0 + 4 * ROWS * 16 <= 2 * XT, "reduction buffers fit in the tile storage");
+};
+
+struct MHeadLds { float *xt0, *xin, *w4, *dz; };
+
+// ---------------------------------------------------------------------------------------------------------------
+// Builder waves (threads 0..255).  Per tile: [phase 1] dzpre tile -> LDS | barrier | [phase 2] rebuild dH | barrier
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH, bool WG, bool W0>
+__device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MHeadLds& L, const int btid, const int T,
+                                                  const int bid, const int grid) {
+    using G = MHeadGeo<TH, W0>;
+    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, DZW = G::DZW;
+    constexpr int IT = TRA * W * 4 / 256, DIT = (G::DZ + 255) / 256;
+    static_assert((TRA * W * 4) % 256 == 0, "whole iterations: no element is visited twice");
+    const int lane = btid & 63, wave = btid >> 6;
+    const int pl = btid & 3;           // the 4-channel plane of dH this thread builds
+    auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };   // clamped: prefetches past the end re-read
+
+    float w2r[9][4];
+    float wacc[9][4], bacc = 0.f;      // masker.2 weight-gradient partials of this thread (plane pl)
+    float4 hvs[IT];
+    float dzr[DIT];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { w2r[t][c] = P.w2[t * 16 + 4 * pl + c]; wacc[t][c] = 0.f; }
+
+    // loads = address arithmetic + the load only; masking happens where the value is consumed (a select here would
+    // wait for the load)
+    auto load_h = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            int e = btid + it * 256;
+            int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
+            bool in = y >= 0 && y < H;
+            hvs[it] = ((const float4*)P.h)[in ? ((n0 * H + y) * W + x) * 4 + pl : 0];
+        }
+    };
+    auto load_dz = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            int e = btid + it * 256;
+            e = e < G::DZ ? e : G::DZ - 1;
+            int y = row0 + e / DZW - 2, x = e % DZW - 2;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            dzr[it] = P.dzpre[in ? (n0 * H + y) * W + x : 0];
+        }
+    };
+    auto store_dz = [&](int tile) {
+        const int row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < DIT; ++it) {
+            int e = btid + it * 256;
+            e = e < G::DZ ? e : G::DZ - 1;
+            int y = row0 + e / DZW - 2, x = e % DZW - 2;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            L.dz[e] = in ? dzr[it] : 0.f;
+        }
+    };
+    load_dz(tile_of(0));
+    load_h(tile_of(0));
+
+    for (int i = 0; i <= T; ++i) {
+        store_dz(tile_of(i));
+        __syncthreads();                                   // barrier 1 of tile i
+        if (i < T) {
+            const int tile = tile_of(i);
+            const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+            float* xt = L.xt0 + (i & 1) * G::XT;
+            const float* dz = L.dz;
+            load_dz(tile_of(i + 1));      // in flight during the rebuild
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int e = btid + it * 256;
+                const int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
+                const bool in = y >= 0 && y < H;
+                const int gi = in ? ((n0 * H + y) * W + x) * 4 + pl : 0;
+                const float4 hv = hvs[it];
+                const bool own = in && r >= 1 && r <= TH;   // rows owned by this strip (halo rows: the neighbours')
+                const float4 hw_ = own ? hv : f4zero();
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float d = dz[(r + 2 - ky) * DZW + x + 3 - kx];
+                        a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
+                        a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
+                        if (WG) {
+                            wacc[ky * 3 + kx][0] = fmaf(d, hw_.x, wacc[ky * 3 + kx][0]);
+                            wacc[ky * 3 + kx][1] = fmaf(d, hw_.y, wacc[ky * 3 + kx][1]);
+                            wacc[ky * 3 + kx][2] = fmaf(d, hw_.z, wacc[ky * 3 + kx][2]);
+                            wacc[ky * 3 + kx][3] = fmaf(d, hw_.w, wacc[ky * 3 + kx][3]);
+                        }
+                    }
+                if (WG) {
+                    bacc += (own && pl == 0) ? dz[(r + 1) * DZW + x + 2] : 0.f;
+                    // pin the accumulators here: otherwise their FMAs are sunk past the whole item loop and every dz / h
+                    // value of all items stays live (hundreds of registers)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(wacc[t][c]));
+                }
+                float4 v = make_float4(a0 * (hv.x > 0.f ? 1.f : 0.01f), a1 * (hv.y > 0.f ? 1.f : 0.01f),
+                                       a2 * (hv.z > 0.f ? 1.f : 0.01f), a3 * (hv.w > 0.f ? 1.f : 0.01f));
+                v = in ? v : f4zero();
+                float* d = xt + (r * PW + x + 1) * PS + 4 * pl;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                if (own && P.dh) ((float4*)P.dh)[gi] = v;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            load_h(tile_of(i + 1));       // in flight until the next rebuild
+        }
+        __syncthreads();                                   // barrier 2 of tile i
+    }
+
+    if constexpr (WG) {
+        // lanes with equal (lane & 3) hold the same channel plane: butterfly over the other 16 lanes; the 4 waves' partials
+        // go to LDS [wave][plane][37] (all tiles are done: the tile storage is free)
+        float* red2 = L.xt0 + G::RED2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float v = wacc[t][c];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (lane < 4) red2[(wave * 4 + lane) * 37 + t * 4 + c] = v;
+            }
+        float v = bacc;
+        v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (lane < 4) red2[(wave * 4 + lane) * 37 + 36] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Matrix waves (threads 256..511; mtid = 0..255).  Per tile i: [phase 1] masker.0 input of tile i-1 -> LDS | barrier |
+// [phase 2] prefetch the input of tile i, data-gradient and weight-gradient GEMMs of tile i-1 | barrier
+// ---------------------------------------------------------------------------------------------------------------
+template <int TH, bool W0, int SRC>
+__device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHeadLds& L, const int mtid, const int T,
+                                                 const int bid, const int grid) {
+    using G = MHeadGeo<TH, W0>;
+    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, PCI = G::PCI;
+    constexpr int CI = G::CI, ROWS = G::ROWS, NRB = W0 ? G::NRB : 1;
+    constexpr int NPIX = TRA * PW, ITA = (NPIX + 255) / 256, ITB = (NPIX * 2 + 255) / 256;
+    const int lane = mtid & 63, mwave = mtid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };
+    // data gradient, B operand of k-step s = (window position, channel plane): w4[(4s + kq)*8 + l15] for the 8 real
+    // columns.  The 8 padding columns just repeat them (their results are never stored).  base + constant per step.
+    const float* wb = L.w4 + kq * 8 + (l15 & 7);
+    // weight gradient: GEMM rows r = tap*11 + ci (99) + the bias row; A operand = masker.0 input at (pixel + tap)
+    int rbase[NRB];
+    frag4 wg0[NRB];
+    float4 ra[W0 ? ITA : 1], rb[W0 ? ITB : 1];
+#pragma unroll
+    for (int q = 0; q < NRB; ++q) {
+        int r = q * 16 + l15;
+        if (r < 9 * CI) {
+            int tap = r / CI, ci = r % CI;
+            int lch = ci < 3 ? ci : 4 + (ci - 3);
+            rbase[q] = ((tap / 3) * PW + (tap % 3)) * PCI + lch;
+        } else {
+            rbase[q] = (r == 9 * CI) ? -1 : -2;
+        }
+        wg0[q] = frag4{0.f, 0.f, 0.f, 0.f};
+    }
+    // fetch = address arithmetic + loads only (raw dwords); decoding and zero padding happen in commit, one phase
+    // later: anything that touches the loaded value here would stall the wave on global memory
+    auto fetch_x = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
+            int y = row0 + e / PW - 1, x = e % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            int pix = in ? (n0 * H + y) * W + x : 0;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                ra[it].x = __uint_as_float(s32[d]);
+                ra[it].y = __uint_as_float(s32[d + 1 <= last ? d + 1 : last]);
+            } else {
+                const float* sf = (const float*)P.img;
+                ra[it] = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            int e = mtid + it * 256; e = e < 2 * NPIX ? e : 2 * NPIX - 1;
+            int px = e >> 1;
+            int y = row0 + px / PW - 1, x = px % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            rb[it] = ((const float4*)P.o0)[in ? ((n0 * 32 + (y >> 1)) * 32 + (x >> 1)) * 2 + (e & 1) : 0];
+        }
+    };
+    auto commit_x = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
+            int y = row0 + e / PW - 1, x = e % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            float4 v = ra[it];
+            if constexpr (SRC == WSRC_U8) {
+                int pix = in ? (n0 * H + y) * W + x : 0;
+                uint64_t both = (((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x)) >> (((pix * 3) & 3) * 8);
+                const float sc = 1.f / 255.f;
+                v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+            }
+            ((float4*)L.xin)[e * 3] = in ? v : f4zero();
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            int e = mtid + it * 256; e = e < 2 * NPIX ? e : 2 * NPIX - 1;
+            int px = e >> 1;
+            int y = row0 + px / PW - 1, x = px % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            ((float4*)L.xin)[px * 3 + 1 + (e & 1)] = in ? rb[it] : f4zero();
+        }
+    };
+
+    for (int i = 0; i <= T; ++i) {
+        if constexpr (W0) {
+            if (i > 0) commit_x(tile_of(i - 1));
+        }
+        __syncthreads();                                   // barrier 1 of tile i
+        if constexpr (W0) {
+            if (i < T) fetch_x(tile_of(i));                // committed in the next phase 1
+        }
+        if (i > 0) {
+            const int tile = tile_of(i - 1);
+            const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+            const float* xt = L.xt0 + ((i - 1) & 1) * G::XT;
+            // Operands come from LDS one group AHEAD of the MFMAs that use them (register double buffer): a wave issues
+            // in order, so reads placed after a group's MFMAs would only start once the last of them has issued and the
+            // matrix pipe would idle for a full LDS round trip per group.  A group must stay below 16 LDS instructions:
+            // s_waitcnt lgkmcnt counts to 15, so "wait for the previous group only" is not expressible beyond that.
+            {
+                // data gradient: this wave's two 16-pixel tiles (low-res row qyl, both halves) share the B reads
+                static_assert(TH == 8, "two 16-pixel tiles per matrix wave");
+                const int qyl = mwave;
+                const int abase = ((2 * qyl) * PW + 2 * l15) * PS + kq;
+                frag4 d0 = frag4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
+                constexpr int GS = 8, NG = 64 / GS;   // 24 dwords = 12 ds_read2 per group
+                float a0[2][GS], a1[2][GS], bw[2][GS];
+                auto ld = [&](int g, int buf) {
+#pragma unroll
+                    for (int j = 0; j < GS; ++j) {
+                        const int s = g * GS + j, pos = s >> 2, u = pos >> 2, v = pos & 3;
+                        const int off = (u * PW + v) * PS + 4 * (s & 3);
+                        a0[buf][j] = xt[abase + off];
+                        a1[buf][j] = xt[abase + 32 * PS + off];
+                        bw[buf][j] = wb[s * 32];
+                    }
+                };
+                ld(0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) ld(g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < GS; ++j) {
+                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g & 1][j], bw[g & 1][j], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g & 1][j], bw[g & 1][j], d1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (l15 < 8) {
+                    const int qy = row0 / 2 + qyl;
+                    float* o = P.d_o0 + ((size_t)(n0 * 32 + qy) * 32 + 4 * kq) * 8 + l15;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { o[j * 8] = d0[j]; o[(16 + j) * 8] = d1[j]; }
+                }
+            }
+            if constexpr (W0) {
+                // weight gradient: each matrix wave owns whole tile rows; inside a row the k-steps advance by constant
+                // strides, so every LDS address is (per-row base) + immediate offset
+                constexpr int SPR = W / 4, UU = 2, NCH = (TH / 4) * (SPR / UU);   // 16 dwords = 8 ds_read2 per chunk
+                int xa[NRB];
+#pragma unroll
+                for (int q = 0; q < NRB; ++q) xa[q] = kq * PCI + (rbase[q] >= 0 ? rbase[q] : 0);
+                const int yb = (PW + 1 + kq) * PS + l15;
+                const float m1 = rbase[NRB - 1] >= 0 ? 1.f : 0.f, m0 = rbase[NRB - 1] == -1 ? 1.f : 0.f;
+                float a[2][UU][NRB], b[2][UU];
+                auto ld = [&](int ch, int buf) {      // chunk ch: row mwave + 4*(ch / (SPR/UU)), steps UU*(ch % (SPR/UU))..
+                    const int yl = mwave + 4 * (ch / (SPR / UU)), c = UU * (ch % (SPR / UU));
+                    // the two k-steps of one row block sit at a constant distance: adjacent loads -> one ds_read2_b32
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) b[buf][u] = xt[yb + yl * PW * PS + (c + u) * 4 * PS];
+#pragma unroll
+                    for (int q = 0; q < NRB; ++q)
+#pragma unroll
+                        for (int u = 0; u < UU; ++u) a[buf][u][q] = L.xin[xa[q] + yl * PW * PCI + (c + u) * 4 * PCI];
+                };
+                ld(0, 0);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    if (ch + 1 < NCH) ld(ch + 1, (ch + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < UU; ++u)
+#pragma unroll
+                        for (int q = 0; q < NRB; ++q) {
+                            // rows past the weights (bias row: constant 1, padding: 0) as arithmetic at the point of use,
+                            // not a select at the load: the load stays unconditional and pairs into ds_read2
+                            float av = a[ch & 1][u][q];
+                            if (q == NRB - 1) av = fmaf(av, m1, m0);
+                            wg0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[ch & 1][u], wg0[q], 0, 0, 0);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        __syncthreads();                                   // barrier 2 of tile i
+    }
+
+    if constexpr (W0) {
+        // D layout: col = lane & 15 (= co), row = (lane >> 4) * 4 + reg; one partial [ROWS][16] per matrix wave
+        float* red0 = L.xt0 + G::RED0 + mwave * (ROWS * 16);
+#pragma unroll
+        for (int q = 0; q < NRB; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int r = q * 16 + kq * 4 + j;
+                if (r < ROWS) red0[r * 16 + l15] = wg0[q][j];
+            }
+    }
+}
+
+// WG: produce slab2; W0: produce slab0 (needs img/o0); SRC: WSRC_U8 / WSRC_F32 image
+template <int TH, bool WG, bool W0, int SRC>
+__global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
+    using G = MHeadGeo<TH, W0>;
+    constexpr int TRA = G::TRA, PW = G::PW, PS = G::PS, ROWS = G::ROWS;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    MHeadLds L;
+    L.xt0 = (float*)smem;              // dH tiles [2][TRA][PW][PS]
+    L.xin = L.xt0 + 2 * G::XT;         // masker.0 input tile (W0)
+    L.w4 = L.xin + G::XIN;             // folded weights [u][v][oc][c]
+    L.dz = L.w4 + G::W4;               // dzpre tile with a 2-pixel halo
+    const int tid = threadIdx.x;
+
+    for (int e = tid; e < G::W4; e += 512) {
+        const int c = e & 7, oc = (e >> 3) & 15, v = (e >> 7) & 3, u = e >> 9;
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                int ky = a + 2 - u, kx = b + 2 - v;
+                if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) s += P.w0[((ky * 3 + kx) * 11 + 3 + c) * 16 + oc];
+            }
+        L.w4[e] = s;
+    }
+    for (int e = tid; e < 2 * TRA * 2 * 16; e += 512) {      // zero halo columns of both dH tiles (never written again)
+        int ch = e & 15, side = (e >> 4) & 1, r = (e >> 5) % TRA, bufi = e / (32 * TRA);
+        L.xt0[bufi * G::XT + (r * PW + (side ? PW - 1 : 0)) * PS + ch] = 0.f;
+    }
+    __syncthreads();
+
+    const int grid = gridDim.x, bid = blockIdx.x;
+    const int T = (P.ntiles - bid + grid - 1) / grid;      // tiles of this workgroup: bid, bid+grid, ...
+    // SCALAR role branch: whole waves take one side, both sides execute 2*(T+1) workgroup barriers
+    if (__builtin_amdgcn_readfirstlane(tid) < 256) mask_head_builder<TH, WG, W0>(P, L, tid, T, bid, grid);
+    else mask_head_matrix<TH, W0, SRC>(P, L, tid - 256, T, bid, grid);
+    __syncthreads();
+
+    // ---------------- weight-gradient partials: one slab per workgroup ----------------
+    if constexpr (W0) {
+        const float* red0 = L.xt0 + G::RED0;
+        for (int e = tid; e < ROWS * 16; e += 512)
+            P.slab0[(size_t)blockIdx.x * (ROWS * 16) + e] =
+                (red0[e] + red0[ROWS * 16 + e]) + (red0[2 * ROWS * 16 + e] + red0[3 * ROWS * 16 + e]);
+    }
+    if constexpr (WG) {
+        const float* red2 = L.xt0 + G::RED2;
+        if (tid < 145) {
+            // slab layout = HWIO [9][16][1] weights then the bias
+            int t = tid / 16, ch = tid % 16, p = ch >> 2, c = ch & 3;
+            int idx = (tid < 144) ? t * 4 + c : 36;
+            if (tid == 144) p = 0;
+            float v = (red2[(0 * 4 + p) * 37 + idx] + red2[(1 * 4 + p) * 37 + idx]) + (red2[(2 * 4 + p) * 37 + idx] + red2[(3 * 4 + p) * 37 + idx]);
+            P.slab2[(size_t)blockIdx.x * 145 + tid] = v;
+        }
+    }
+}
+
+// one workgroup per CU (LDS), persistent over its tiles
+static int mask_head_blocks(int n) { int t = n * (64 / 8); return t < 256 ? t : 256; }
+int mask_head_slabs(int n) { return n <= 0 ? 0 : mask_head_blocks(n); }
+
+template <bool WG, bool W0, int SRC>
+static int launch_mask_head(MHeadParams P, hipStream_t st) {
+    constexpr int TH = 8;
+    using G = MHeadGeo<TH, W0>;
+    P.ntiles = P.n * G::STRIPS;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_head_kernel<TH, WG, W0, SRC>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);   // > 64 KB
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((mask_head_kernel<TH, WG, W0, SRC>), dim3(mask_head_blocks(P.n)), dim3(512), G::LDS, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// img_kind: CGS_SRC_U8 / CGS_SRC_F32 (only read when slab0 is requested)
+int mask_head_launch(int n, int img_kind, const void* img, const float* o0, const float* dzpre, const float* h,
+                     const float* w2, const float* w0, float* dh, float* d_o0, float* slab2, float* slab0, hipStream_t st) {
+    if (n <= 0) return CGS_OK;
+    MHeadParams P{dzpre, h, w2, w0, img, o0, dh, d_o0, slab2, slab0, n, 0};
+    if (slab0) {
+        if (!slab2 || !img || !o0) return CGS_ERR_BADARG;
+        return img_kind == CGS_SRC_U8 ? launch_mask_head<true, true, WSRC_U8>(P, st) : launch_mask_head<true, true, WSRC_F32>(P, st);
+    }
+    return slab2 ? launch_mask_head<true, false, WSRC_F32>(P, st) : launch_mask_head<false, false, WSRC_F32>(P, st);
+}

@@ -169,257 +169,3 @@ int mconv_fwd_dispatch(int which, int n, const void* src_a, const float* src_b, 
     }
     return CGS_ERR_UNSUPPORTED;
 }
-
-// ------------------------------------------------------------------------------------------------
-// Mask head backward on the matrix cores: d(masker.0 output) rebuilt from dzpre (as SRC_DH in conv_body.h), then
-// the masker.0 data gradient w.r.t. its low-resolution input o0 with the nearest-upsample FOLDED into the weights:
-//   d_o0[q][c] = sum over the 2x2 cell of q of the 3x3 data gradient
-//              = sum_{u,v in 0..3} sum_oc dH[2q + (u-1, v-1)][oc] * W4[u][v][oc][c],
-//   W4[u][v][oc][c] = sum_{a in {0,1}, ky = a+2-u in 0..2} sum_{b in {0,1}, kx = b+2-v in 0..2} W[ky][kx][3+c][oc]
-// i.e. one stride-2 4x4 convolution (16 taps per output) instead of four 3x3 ones (36 taps): 2.25x fewer MACs.
-// GEMM: M = 16 low-res pixels of one row, K = 16 window positions x 16 channels, N = 8 (half of the tile is padding).
-// The dH tile is NHWC in LDS with a pixel stride of 17 floats so the stride-2 pixel reads of a wave hit 32 banks.
-// The masker.2 WEIGHT gradient rides along: dW2[ky][kx][ch] = sum_p h[p][ch] * dzpre[p + (1-ky, 1-kx)] uses exactly the
-// (h pixel, dzpre neighbour) pairs the dH rebuild already has in registers, so no second pass over h is needed.
-// ------------------------------------------------------------------------------------------------
-struct MHeadParams {
-    const float* dzpre; const float* h; const float* w2; const float* w0;
-    float* dh; float* d_o0;
-    float* slab;     // optional: masker.2 weight-gradient partials, one [145] slab per workgroup
-    int n, ntiles;
-};
-
-template <int TH>
-struct MHeadGeo {
-    static constexpr int H = 64, W = 64, TRA = TH + 2, PW = W + 2, PS = 17, DZW = W + 4, DZR = TH + 4, STRIPS = H / TH;
-    static constexpr int XT = TRA * PW * PS, W4 = 16 * 16 * 8, DZ = DZR * DZW;
-    static constexpr int FLOATS = 2 * XT + W4 + 2 * DZ;          // both tiles are double buffered
-    static constexpr size_t LDS = (size_t)((FLOATS + 3) / 4) * 16;
-};
-
-// Workgroup = 8 waves with two roles, one tile (TH rows of one image) apart:
-//   waves 0-3 ("builders", VALU + memory): rebuild dH of tile i into xt[i&1] (and the masker.2 weight-gradient partials),
-//   waves 4-7 ("matrix" waves): run the folded 4x4 convolution of tile i-1 out of xt[(i-1)&1] on the matrix cores,
-// with ONE workgroup barrier per tile.  Each SIMD hosts one wave of each role, so the VALU and MFMA pipes and the
-// memory system work at the same time instead of one phase after the other.
-template <int TH, bool WG>
-__global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
-    using G = MHeadGeo<TH>;
-    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, DZW = G::DZW;
-    extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    float* xt0 = (float*)smem;         // dH tiles [2][TRA][PW][PS]
-    float* w4 = xt0 + 2 * G::XT;       // folded weights [u][v][oc][c]
-    float* dz0 = w4 + G::W4;           // dzpre tiles [2] with a 2-pixel halo
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool builder = tid < 256;
-    const int btid = tid & 255;
-
-    for (int e = tid; e < G::W4; e += 512) {
-        const int c = e & 7, oc = (e >> 3) & 15, v = (e >> 7) & 3, u = e >> 9;
-        float s = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                int ky = a + 2 - u, kx = b + 2 - v;
-                if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) s += P.w0[((ky * 3 + kx) * 11 + 3 + c) * 16 + oc];
-            }
-        w4[e] = s;
-    }
-    for (int e = tid; e < 2 * TRA * 2 * 16; e += 512) {      // zero halo columns of both tiles (never written again)
-        int ch = e & 15, side = (e >> 4) & 1, r = (e >> 5) % TRA, bufi = e / (32 * TRA);
-        xt0[bufi * G::XT + (r * PW + (side ? PW - 1 : 0)) * PS + ch] = 0.f;
-    }
-
-    const int grid = gridDim.x, bid = blockIdx.x;
-    const int T = (P.ntiles - bid + grid - 1) / grid;      // tiles of this workgroup: bid, bid+grid, ...
-    auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };   // clamped: prefetches past the end re-read
-
-    // ---------------- builder state ----------------
-    const int pl = btid & 3;           // the 4-channel plane of dH this thread builds
-    constexpr int IT = TRA * W * 4 / 256, DIT = (G::DZ + 255) / 256;
-    static_assert((TRA * W * 4) % 256 == 0, "whole iterations: no element is visited twice");
-    float w2r[9][4];
-    float wacc[9][4], bacc = 0.f;      // masker.2 weight-gradient partials of this thread (plane pl)
-    float4 hvs[IT];
-    float dzr[DIT];
-    auto load_h = [&](int tile) {
-        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            int e = btid + it * 256;
-            int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
-            bool in = y >= 0 && y < H;
-            hvs[it] = ((const float4*)P.h)[in ? ((n0 * H + y) * W + x) * 4 + pl : 0];
-        }
-    };
-    auto load_dz = [&](int tile) {
-        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-#pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            int e = btid + it * 256;
-            e = e < G::DZ ? e : G::DZ - 1;
-            int c2 = e % DZW, r2 = e / DZW;
-            int y = row0 + r2 - 2, x = c2 - 2;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            float v = P.dzpre[in ? (n0 * H + y) * W + x : 0];
-            dzr[it] = in ? v : 0.f;
-        }
-    };
-    auto store_dz = [&](float* dz) {
-#pragma unroll
-        for (int it = 0; it < DIT; ++it) {
-            int e = btid + it * 256;
-            dz[e < G::DZ ? e : G::DZ - 1] = dzr[it];
-        }
-    };
-    if (builder) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { w2r[t][c] = P.w2[t * 16 + 4 * pl + c]; wacc[t][c] = 0.f; }
-        load_dz(tile_of(0));
-        store_dz(dz0);                 // dz tile of tile i lives in dz0 + (i&1)*DZ
-        load_dz(tile_of(1));
-        load_h(tile_of(0));
-    }
-    __syncthreads();
-
-    // ---------------- matrix-wave state ----------------
-    const int l15 = lane & 15, kq = lane >> 4, mwave = wave & 3;
-    // B operand of k-step s = (window position, channel plane): w4[(4s + kq)*8 + l15] for the 8 real columns.  The 8
-    // padding columns just repeat them (their results are never stored).  Read from LDS per tile, base + constant.
-    const float* wb = w4 + kq * 8 + (l15 & 7);
-
-    for (int i = 0; i <= T; ++i) {
-        if (builder) {
-            if (i < T) {
-                const int tile = tile_of(i);
-                const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-                float* xt = xt0 + (i & 1) * G::XT;
-                const float* dz = dz0 + (i & 1) * G::DZ;
-                store_dz(dz0 + ((i + 1) & 1) * G::DZ);           // dzpre of tile i+1 (read one barrier from now)
-#pragma unroll
-                for (int it = 0; it < IT; ++it) {
-                    const int e = btid + it * 256;
-                    const int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
-                    const bool in = y >= 0 && y < H;
-                    const int gi = in ? ((n0 * H + y) * W + x) * 4 + pl : 0;
-                    const float4 hv = hvs[it];
-                    const bool own = in && r >= 1 && r <= TH;   // rows owned by this strip (halo rows: the neighbours')
-                    const float4 hw_ = own ? hv : f4zero();
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            float d = dz[(r + 2 - ky) * DZW + x + 3 - kx];
-                            a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
-                            a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
-                            if (WG) {
-                                wacc[ky * 3 + kx][0] = fmaf(d, hw_.x, wacc[ky * 3 + kx][0]);
-                                wacc[ky * 3 + kx][1] = fmaf(d, hw_.y, wacc[ky * 3 + kx][1]);
-                                wacc[ky * 3 + kx][2] = fmaf(d, hw_.z, wacc[ky * 3 + kx][2]);
-                                wacc[ky * 3 + kx][3] = fmaf(d, hw_.w, wacc[ky * 3 + kx][3]);
-                            }
-                        }
-                    if (WG) {
-                        bacc += (own && pl == 0) ? dz[(r + 1) * DZW + x + 2] : 0.f;
-                        // pin the accumulators here: otherwise their FMAs are sunk past the whole item loop and every
-                        // dz / h value of all items stays live (hundreds of registers)
-#pragma unroll
-                        for (int t = 0; t < 9; ++t)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(wacc[t][c]));
-                    }
-                    float4 v = make_float4(a0 * (hv.x > 0.f ? 1.f : 0.01f), a1 * (hv.y > 0.f ? 1.f : 0.01f),
-                                           a2 * (hv.z > 0.f ? 1.f : 0.01f), a3 * (hv.w > 0.f ? 1.f : 0.01f));
-                    v = in ? v : f4zero();
-                    float* d = xt + (r * PW + x + 1) * PS + 4 * pl;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                    if (own) ((float4*)P.dh)[gi] = v;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                load_dz(tile_of(i + 2));     // in flight across the next tile's rebuild
-                load_h(tile_of(i + 1));
-            }
-        } else if (i > 0) {
-            const int tile = tile_of(i - 1);
-            const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-            const float* xt = xt0 + ((i - 1) & 1) * G::XT;
-            constexpr int NT = (TH / 2) * 2;           // 16-pixel tiles: 2 per low-res row
-            for (int t = mwave; t < NT; t += 4) {
-                const int qyl = t >> 1, qx0 = (t & 1) * 16;
-                const int abase = ((2 * qyl) * PW + 2 * (qx0 + l15)) * PS + kq;
-                frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < 64; ++s) {
-                    const int pos = s >> 2, u = pos >> 2, v = pos & 3;
-                    float a = xt[abase + (u * PW + v) * PS + 4 * (s & 3)];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb[s * 32], acc, 0, 0, 0);
-                    if ((s & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // at most 8 k-steps of operands in flight
-                }
-                if (l15 < 8) {
-                    const int qy = row0 / 2 + qyl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        P.d_o0[((size_t)(n0 * 32 + qy) * 32 + qx0 + 4 * kq + j) * 8 + l15] = acc[j];
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    if constexpr (WG) {
-        // builder lanes with equal (lane & 3) hold the same channel plane: butterfly over the other 16 lanes, then over
-        // the 4 builder waves through LDS
-        float* red = xt0;                // [4 waves][4 planes][37]
-        if (builder) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float v = wacc[t][c];
-                    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-                    if (lane < 4) red[(wave * 4 + lane) * 37 + t * 4 + c] = v;
-                }
-            float v = bacc;
-            v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-            if (lane < 4) red[(wave * 4 + lane) * 37 + 36] = v;
-        }
-        __syncthreads();
-        if (tid < 145) {
-            // slab layout = HWIO [9][16][1] weights then the bias
-            int t = tid / 16, ch = tid % 16, p = ch >> 2, c = ch & 3;
-            int idx = (tid < 144) ? t * 4 + c : 36;
-            if (tid == 144) p = 0;
-            float v = (red[(0 * 4 + p) * 37 + idx] + red[(1 * 4 + p) * 37 + idx]) + (red[(2 * 4 + p) * 37 + idx] + red[(3 * 4 + p) * 37 + idx]);
-            P.slab[(size_t)blockIdx.x * 145 + tid] = v;
-        }
-    }
-}
-
-// one workgroup per CU (LDS), persistent over its tiles
-static int mask_head_blocks(int n) { int t = n * MHeadGeo<8>::STRIPS; return t < 256 ? t : 256; }
-int mconv_mask_head_slabs(int n) { return n <= 0 ? 0 : mask_head_blocks(n); }
-
-int mconv_mask_head(int n, const float* dzpre, const float* h, const float* w2, const float* w0, float* dh, float* d_o0,
-                    float* slab, hipStream_t st) {
-    constexpr int TH = 8;
-    using G = MHeadGeo<TH>;
-    if (n <= 0) return CGS_OK;
-    MHeadParams P{dzpre, h, w2, w0, dh, d_o0, slab, n, n * G::STRIPS};
-    int blocks = mask_head_blocks(n);
-    static hipError_t attr = [] {   // 105 KB of dynamic LDS: above the default limit
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_head_kernel<TH, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_head_kernel<TH, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS);
-    }();
-    if (attr != hipSuccess) return (int)attr;
-    if (slab) hipLaunchKernelGGL((mask_head_kernel<TH, true>), dim3(blocks), dim3(512), G::LDS, st, P);
-    else hipLaunchKernelGGL((mask_head_kernel<TH, false>), dim3(blocks), dim3(512), G::LDS, st, P);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
-}

@@ -291,8 +291,11 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
     d_embeds: List[Optional[torch.Tensor]] = [None] * 5
     dy = dzpre
     fused_head_do0 = None
+    head_done = False    # masker.2 AND masker.0 fully handled by the mask-head kernel
     u8_or_f32_needs_da = False   # the image never needs a gradient on this path
     for li in (5, 4, 3, 2, 1, 0):
+        if li == 4 and head_done:
+            continue
         key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]
         is_img = li == 4
         d = conv_desc(n, hw, ca, cb, co, u8 and is_img, ups, act, pool, nd)
@@ -316,23 +319,32 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
             dy = db
             continue
         head_fused = li == 5 and MASK_HEAD_FUSED and not u8_or_f32_needs_da
-        nsl = lib.cgs_mask_head_bwd_slabs(n) if head_fused else 0   # >0: masker.2 wgrad rides along with the mask head
-        wg_in_head = nsl > 0
-        if not wg_in_head:
-            nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
+        nsl = lib.cgs_mask_head_bwd_slabs(n) if head_fused else 0
+        if nsl > 0:
+            # the whole mask head in one launch: d o0, masker.2 and masker.0 weight gradients; d hm is never stored
+            cnt0 = 9 * 11 * 16 + 16
+            slab2, slab0 = buf("slab_dec5", (nsl, cnt)), buf("slab_dec4", (nsl, cnt0))
+            do0 = buf("do0", (n, 32, 32, 8))
+            _lib.call("cgs_mask_head_bwd", n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(saved["o0"]), _p(dzpre),
+                      _p(saved["hm"]), wptr, C.c_void_p(fp + 4 * lay.off("masker.0.weight")), None, _p(do0),
+                      _p(slab2), _p(slab0), _stream())
+            plan.add(slab2, nsl, cnt, lay.off(key + ".weight"))
+            plan.add(slab0, nsl, cnt0, lay.off("masker.0.weight"))
+            dy = do0
+            head_done = True
+            continue
+        nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         slab = buf(f"slab_dec{li}", (nsl, cnt))
-        if not wg_in_head:
-            with side.fork():
-                _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
+        with side.fork():
+            _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
         if head_fused:
-            # masker.2 data gradient is rebuilt inside the masker.0 data-gradient kernel (never stored as a conv output)
+            # (VALU build) masker.2 data gradient rebuilt inside the masker.0 data-gradient kernel
             dhm, do0 = buf("dhm", (n, 64, 64, 16)), buf("do0", (n, 32, 32, 8))
-            _lib.call("cgs_mask_head_bwd_data", n, _p(dzpre), _p(saved["hm"]), wptr,
-                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(dhm), _p(do0),
-                      _p(slab) if wg_in_head else None, _stream())
+            _lib.call("cgs_mask_head_bwd", n, 0, None, None, _p(dzpre), _p(saved["hm"]), wptr,
+                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(dhm), _p(do0), None, None, _stream())
             dy = dhm
             fused_head_do0 = do0
         elif li == 5:    # masker.2: d hm = conv_bwd(dzpre) * LeakyReLU'(hm)

@@ -88,20 +88,23 @@ int cgs_conv3x3_bwd_data(const cgs_conv_desc* d, const float* dy, const uint32_t
                          const float* addend, int32_t n_addend, float* d_a, float* d_b,
                          cgs_stream_t stream);
 
-/* ---- mask head, data gradients of masker.2 AND masker.0 in one pass (nets.py:488-491 backward) ----
- * dzpre [n,64,64] (gradient w.r.t. the pre-sigmoid mask), h [n,64,64,16] (saved masker.0 output).
- *   d_h  [n,64,64,16] = LeakyReLU'(h) * conv_bwd_data(dzpre; w_m2)   (written once, for the masker.0 wgrad)
- *   d_o0 [n,32,32,8]  = upsample-backward of conv_bwd_data(d_h; w_m0) restricted to the 8 decoder channels.
- * d_h is rebuilt inside the loader from the 1-channel dzpre instead of being read back from memory; the
- * nearest-upsample in front of masker.0 is folded into its weights (one stride-2 4x4 conv on the matrix cores).
- *   slab_m2 : optional [cgs_mask_head_bwd_slabs(n)][145] partial masker.2 weight+bias gradients (same slab
- *             layout as cgs_conv3x3_bwd_weight for that layer), produced from the h / dzpre values already in
- *             registers.  cgs_mask_head_bwd_slabs() returns 0 when this build cannot produce them (the caller
- *             then runs cgs_conv3x3_bwd_weight for masker.2 and passes NULL here).                          */
+/* ---- mask head backward in one pass (nets.py:488-491 backward: masker.2 and masker.0) ----------------
+ * dzpre [n,64,64] (gradient w.r.t. the pre-sigmoid mask), h [n,64,64,16] (saved masker.0 output, post-LeakyReLU).
+ *   d_o0 [n,32,32,8]  = upsample-backward of conv_bwd_data(d_h; w_m0) restricted to the 8 decoder channels, where
+ *                       d_h = LeakyReLU'(h) * conv_bwd_data(dzpre; w_m2) is rebuilt on the fly from the 1-channel
+ *                       dzpre (never read from memory) and the nearest-upsample in front of masker.0 is folded into
+ *                       its weights (one stride-2 4x4 convolution on the matrix cores);
+ *   d_h  [n,64,64,16] : optional copy of that intermediate (NULL: never stored);
+ *   slab_m2 : optional [cgs_mask_head_bwd_slabs(n)][145]  partial masker.2 weight+bias gradients,
+ *   slab_m0 : optional [cgs_mask_head_bwd_slabs(n)][1600] partial masker.0 weight+bias gradients (needs slab_m2, x =
+ *             the masker.0 image input [n,64,64,3] of kind src_a, and o0 [n,32,32,8]); both in the slab layout of
+ *             cgs_conv3x3_bwd_weight for those layers, to be summed by cgs_reduce_slabs().
+ * cgs_mask_head_bwd_slabs() returns 0 when this build cannot produce the slabs (the caller then passes NULL, asks for
+ * d_h and runs cgs_conv3x3_bwd_weight for the two layers).                                                      */
 int cgs_mask_head_bwd_slabs(int32_t n);
-int cgs_mask_head_bwd_data(int32_t n, const float* dzpre, const float* h, const float* w_m2_hwio,
-                           const float* w_m0_hwio, float* d_h, float* d_o0, float* slab_m2,
-                           cgs_stream_t stream);
+int cgs_mask_head_bwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* dzpre, const float* h,
+                      const float* w_m2_hwio, const float* w_m0_hwio, float* d_h, float* d_o0, float* slab_m2,
+                      float* slab_m0, cgs_stream_t stream);
 
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"

@@ -311,52 +311,64 @@ def test_shared_launch_backward_equals_separate_launches(ctx):
     np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s2.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("n", [3, 16, 130])
-def test_mask_head_backward_vs_torch_fp32(ctx, n):
-    """cgs_mask_head_bwd_data (masker.2 dgrad rebuilt in the loader, upsample folded into the masker.0 weights, MFMA;
-    masker.2 wgrad riding along) against a plain fp32 torch autograd of nets.py:488-491 on the same tensors."""
+@pytest.mark.parametrize("n,u8", [(3, False), (16, True), (130, False)])
+def test_mask_head_backward_vs_torch_fp32(ctx, n, u8):
+    """cgs_mask_head_bwd (masker.2 dgrad rebuilt on the fly, upsample folded into the masker.0 weights, MFMA; masker.2 and
+    masker.0 weight gradients riding along) against a plain torch autograd (fp64) of nets.py:488-491 on the same tensors."""
     from cgs_amd import _lib
     import ctypes as C
     import torch.nn.functional as F
     dev, lm, pm = ctx["dev"], ctx["lm"], ctx["pm"]
     lib = _lib.load()
     rs = np.random.RandomState(40 + n)
-    img = rs.rand(n, 3, 64, 64).astype(np.float32)
+    img_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    img = img_u8.astype(np.float32) / np.float32(255.0) if u8 else rs.rand(n, 64, 64, 3).astype(np.float32)
     o0 = rs.randn(n, 8, 32, 32).astype(np.float32)
     dz = (rs.randn(n, 64, 64) * 1e-3).astype(np.float32)
-    w0, b0 = pm["masker.0.weight"].double(), pm["masker.0.bias"].double()
-    w2, b2 = pm["masker.2.weight"].double(), pm["masker.2.bias"].double()
+    w0t = pm["masker.0.weight"].double().requires_grad_(True); b0t = pm["masker.0.bias"].double().requires_grad_(True)
+    w2t = pm["masker.2.weight"].double().requires_grad_(True); b2t = pm["masker.2.bias"].double().requires_grad_(True)
     o0t = torch.from_numpy(o0).double().requires_grad_(True)
-    w2t = w2.clone().requires_grad_(True); b2t = b2.clone().requires_grad_(True)
-    cat = torch.cat([torch.from_numpy(img).double(), F.interpolate(o0t, scale_factor=2, mode="nearest")], 1)
-    hpre = F.conv2d(cat, w0, b0, padding=1)
+    cat = torch.cat([torch.from_numpy(img).double().permute(0, 3, 1, 2), F.interpolate(o0t, scale_factor=2, mode="nearest")], 1)
+    hpre = F.conv2d(cat, w0t, b0t, padding=1)
     hpre.retain_grad()                    # the kernel's d_h is the gradient w.r.t. the masker.0 conv output (pre-LeakyReLU)
     h = F.leaky_relu(hpre, 0.01)
     zpre = F.conv2d(h, w2t, b2t, padding=1)
     zpre.backward(torch.from_numpy(dz).double()[:, None])
 
     hd = h.detach().float().permute(0, 2, 3, 1).contiguous().to(dev)
+    xd = torch.from_numpy(img_u8 if u8 else img).to(dev)
+    o0d = torch.from_numpy(o0).permute(0, 2, 3, 1).contiguous().to(dev)
     dzd = torch.from_numpy(dz).to(dev)
-    dh = torch.full((n, 64, 64, 16), float("nan"), device=dev)
-    do0 = torch.full((n, 32, 32, 8), float("nan"), device=dev)
+    nan = float("nan")
+    dh = torch.full((n, 64, 64, 16), nan, device=dev)
+    do0 = torch.full((n, 32, 32, 8), nan, device=dev)
     nsl = lib.cgs_mask_head_bwd_slabs(n)
     assert nsl > 0
-    slab = torch.full((nsl, 145), float("nan"), device=dev)
+    slab2 = torch.full((nsl, 145), nan, device=dev)
+    slab0 = torch.full((nsl, 1600), nan, device=dev)
     P = lambda t: C.c_void_p(t.data_ptr())
     fm = ctx["fm"]
-    _lib.call("cgs_mask_head_bwd_data", n, P(dzd), P(hd), C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.2.weight")),
-              C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.0.weight")), P(dh), P(do0), P(slab),
-              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    w2p = C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.2.weight"))
+    w0p = C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.0.weight"))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    kind = _lib.SRC_U8 if u8 else _lib.SRC_F32
+    _lib.call("cgs_mask_head_bwd", n, kind, P(xd), P(o0d), P(dzd), P(hd), w2p, w0p, P(dh), P(do0), P(slab2), P(slab0), st)
     torch.cuda.synchronize()
     rel_close(nhwc(dh), hpre.grad.numpy(), "d h")
     rel_close(nhwc(do0), o0t.grad.numpy(), "d o0", atol_scale=5e-5)
-    g = slab.sum(0).cpu().numpy()
+    g = slab2.sum(0).cpu().numpy()
     rel_close(g[:144].reshape(3, 3, 16), w2t.grad[0].permute(1, 2, 0).numpy(), "d masker.2.weight", atol_scale=1e-4)
     rel_close(g[144:], b2t.grad.numpy(), "d masker.2.bias", atol_scale=1e-4)
-    # without the slab the data gradients are the same bits
-    dh2, do02 = torch.empty_like(dh), torch.empty_like(do0)
-    _lib.call("cgs_mask_head_bwd_data", n, P(dzd), P(hd), C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.2.weight")),
-              C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.0.weight")), P(dh2), P(do02), None,
-              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    g = slab0.sum(0).cpu().numpy()
+    rel_close(g[:1584].reshape(3, 3, 11, 16), w0t.grad.permute(2, 3, 1, 0).numpy(), "d masker.0.weight", atol_scale=1e-4)
+    rel_close(g[1584:], b0t.grad.numpy(), "d masker.0.bias", atol_scale=1e-4)
+    # every subset of the optional outputs gives the same bits for what it does produce
+    do0b = torch.empty_like(do0); s2b = torch.empty_like(slab2)
+    _lib.call("cgs_mask_head_bwd", n, kind, None, None, P(dzd), P(hd), w2p, w0p, None, P(do0b), P(s2b), None, st)
+    dhc, do0c = torch.empty_like(dh), torch.empty_like(do0)
+    _lib.call("cgs_mask_head_bwd", n, 0, None, None, P(dzd), P(hd), w2p, w0p, P(dhc), P(do0c), None, None, st)
     torch.cuda.synchronize()
-    assert torch.equal(dh, dh2) and torch.equal(do0, do02)
+    assert torch.equal(do0, do0b) and torch.equal(do0, do0c) and torch.equal(dh, dhc) and torch.equal(slab2, s2b)
+    # argument errors are return codes, not faults
+    assert lib.cgs_mask_head_bwd(n, kind, None, None, P(dzd), P(hd), w2p, w0p, None, P(do0), P(slab2), P(slab0), st) < 0
+    assert lib.cgs_mask_head_bwd(n, 7, P(xd), P(o0d), P(dzd), P(hd), w2p, w0p, None, P(do0), P(slab2), P(slab0), st) < 0
