@@ -1,6 +1,6 @@
 // 3x3 convolution (forward / data gradient) as an implicit GEMM on the matrix cores, for the layers where the
-// GEMM shape fills an MFMA tile: 16 output channels (masker.0 forward, dec_model.3 forward), also with many
-// input channels at tiny spatial size (dec_model.3 forward: 48 -> 16 channels at 4x4).  (A data-gradient variant for
+// GEMM shape fills an MFMA tile: 16 output channels with many input channels at tiny spatial size (dec_model.3
+// forward: 48 -> 16 channels at 4x4, generic kernel below) and masker.0 forward (its own kernel at the end of the file).  (A data-gradient variant for
 // dec_model.3 was measured slower than the shared-launch VALU kernel and is not kept.)
 //
 //   out[pixel][oc] = sum_k Xcol[pixel][k] * Wm[k][oc],  k = tap*PCI + channel   (v_mfma_f32_16x16x4_f32, exact fp32)
@@ -140,9 +140,159 @@ __global__ void __launch_bounds__(C::G::THREADS) mconv_kernel(MConvParams P) {
     }
 }
 
-struct MMask0U8 { using G = WGeo<64, 64, 8, 1, 256>; static constexpr int SRC = WSRC_U8, CA = 3, CB = 8, UPS = 2, WT = 0, WCI = 11, WCO = 16, NOUT = 16, ACT = CGS_ACT_LRELU, EPI = MEPI_PLAIN, OUT_A = 0; };
-struct MMask0F32 { using G = WGeo<64, 64, 8, 1, 256>; static constexpr int SRC = WSRC_F32, CA = 3, CB = 8, UPS = 2, WT = 0, WCI = 11, WCO = 16, NOUT = 16, ACT = CGS_ACT_LRELU, EPI = MEPI_PLAIN, OUT_A = 0; };
 struct MDec3F { using G = WGeo<4, 4, 4, 8, 256>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, WT = 0, WCI = 48, WCO = 16, NOUT = 16, ACT = CGS_ACT_NONE, EPI = MEPI_PLAIN, OUT_A = 0; };
+
+// ------------------------------------------------------------------------------------------------
+// masker.0 forward (nets.py:488-489: Upsample(o0) ++ image -> conv 11->16 -> LeakyReLU) with the nearest-upsample
+// FOLDED into the weights.  For an output pixel of parity (py, px) the 3x3 taps over the upsampled o0 collapse onto a
+// 2x2 neighbourhood of o0 itself:
+//   out[y][x][oc] = sum_{tap, c<3} img[(y,x)+tap-1][c] * W[tap][c][oc]
+//                 + sum_{a,b in {0,1}} sum_cb o0[(y>>1)+a-(1-py)][(x>>1)+b-(1-px)][cb] * W2[py][px][a][b][cb][oc],
+//   W2[py][px][a][b] = sum_{ky in K(py,a)} sum_{kx in K(px,b)} W[ky][kx][3+cb],  K(0,0)={0} K(0,1)={1,2} K(1,0)={0,1} K(1,1)={2}
+// (zero padding stays exact: a tap that leaves the image is the only member of its K set at that border).
+// K per pixel: 9 taps x 4 (3 image channels + a zero) + 4 x 8 = 68 instead of 9 x 12 = 108: 17 MFMAs per 16 pixels, not 27.
+// An MFMA tile = 16 same-parity pixels of one row (x = 2i + px), so its A addresses are (per-lane base) + constant.
+// LDS: image tile [10][66][5] floats and o0 tile [6][34][10] floats at its own resolution: the odd pixel strides make
+// the stride-2 pixel reads of a wave conflict-free.  Wave w owns the half hf = w&1 of rows 4*(w>>1) .. +3, both column
+// parities (so it can store whole 2 KB row segments); the weights (9 image taps + 4 parities x 8) stay in registers
+// for all tiles of the persistent workgroup.
+// ------------------------------------------------------------------------------------------------
+struct Mask0FwdParams {
+    const void* img; const float* o0; const float* w; const float* bias; float* out;
+    int n, ntiles;
+};
+
+template <int SRC>
+__global__ void __launch_bounds__(256) mask0_fwd_kernel(Mask0FwdParams P) {
+    constexpr int H = 64, W = 64, TH = 8, STRIPS = H / TH;
+    constexpr int IR = TH + 2, IC = W + 2, IPS = 5;          // image tile rows, cols, pixel stride (floats)
+    constexpr int LR = TH / 2 + 2, LC = W / 2 + 2, LPS = 10;  // o0 tile
+    constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
+    __shared__ float ximg[IR * IC * IPS];
+    __shared__ __attribute__((aligned(16))) float xo[LR * LC * LPS];
+    __shared__ __attribute__((aligned(16))) float stage[4][32 * 16];   // per wave: 32 output pixels x 16 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int hf = wave & 1, rg = wave >> 1;   // this wave: columns 32*hf .. +31 of rows 4*rg .. 4*rg+3, both parities
+
+    // ---- weights -> registers (B operand: k = kq, n = l15 = oc) ----
+    float wimg[9], wo[2][2][2][2][2];     // [py][px][a][b][s]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wimg[t] = (kq < 3) ? P.w[(t * 11 + kq) * 16 + l15] : 0.f;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int s4 = 0; s4 < 2; ++s4) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                                const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                                if (iny && inx) v += P.w[((ky * 3 + kx) * 11 + 3 + 4 * s4 + kq) * 16 + l15];
+                            }
+                        wo[py][px][a][b][s4] = v;
+                    }
+    const float bias = P.bias[l15];
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n0 = tile / STRIPS, row0 = (tile % STRIPS) * TH;
+        // ---- tiles -> LDS ----
+        for_elems<NIMG, 256>(tid, [&](int e) {
+            int r = e / IC, c = e % IC;
+            int y = row0 + r - 1, x = c - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            int pix = in ? (n0 * H + y) * W + x : 0;
+            float v0, v1, v2;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
+                uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
+                const float sc = 1.f / 255.f;
+                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+            } else {
+                const float* sf = (const float*)P.img;
+                v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
+            }
+            float* d = ximg + e * IPS;
+            d[0] = in ? v0 : 0.f; d[1] = in ? v1 : 0.f; d[2] = in ? v2 : 0.f; d[3] = 0.f;
+        });
+        for_elems<NLO, 256>(tid, [&](int e) {
+            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 1, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            float4 v = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+            v = in ? v : f4zero();
+            float2* d = (float2*)(xo + (pr * LC + pc) * LPS + 4 * half);
+            d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+        });
+        __syncthreads();
+
+        // ---- 4 rows x 2 column parities of this wave; operands of the next MFMA tile are read before the MFMAs of the
+        //      current one (in-order issue: see mask_head.hip) ----
+        const int ibase = ((4 * rg) * IC + 2 * (16 * hf + l15)) * IPS + kq;   // + ((r+ky)*IC + px + kx)*IPS
+        const int obase = ((2 * rg) * LC + 16 * hf + l15) * LPS + kq;         // + (((r>>1)+a+py)*LC + px + b)*LPS + 4*s
+        float ai[2][9], ao[2][8];
+        auto ld = [&](int t, int buf) {         // MFMA tile t: row r = t>>1 of this wave's 4, parity px = t&1
+            const int r = t >> 1, px = t & 1, py = r & 1;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ai[buf][k] = ximg[ibase + ((r + k / 3) * IC + px + k % 3) * IPS];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = q >> 2, b = (q >> 1) & 1, s4 = q & 1;
+                ao[buf][q] = xo[obase + (((r >> 1) + a + py) * LC + px + b) * LPS + 4 * s4];
+            }
+        };
+        ld(0, 0);
+        frag4 res[2];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t + 1 < 8) ld(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int r = t >> 1, px = t & 1, py = r & 1;
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[t & 1][k], wimg[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t & 1][q], wo[py][px][q >> 2][(q >> 1) & 1][q & 1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            res[px] = acc;
+            if (px == 1) {
+                // D[row = 4kq + j (pixel i)][col = l15 (oc)]: both parities of 16 i's = 32 consecutive pixels.  Through the
+                // wave's LDS stage so that every lane stores 16 contiguous bytes and the wave 2 KB contiguous.
+                float* st = stage[wave];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    st[(2 * (4 * kq + j)) * 16 + l15] = act_fwd<CGS_ACT_LRELU>(res[0][j] + bias);
+                    st[(2 * (4 * kq + j) + 1) * 16 + l15] = act_fwd<CGS_ACT_LRELU>(res[1][j] + bias);
+                }
+                float4 v0 = ((const float4*)st)[lane], v1 = ((const float4*)st)[64 + lane];
+                float4* o = (float4*)(P.out + ((size_t)(n0 * H + row0 + 4 * rg + r) * W + 32 * hf) * 16);
+                o[lane] = v0; o[64 + lane] = v1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int SRC>
+static int launch_mask0_fwd(Mask0FwdParams P, hipStream_t st) {
+    if (P.n <= 0) return CGS_OK;
+    P.ntiles = P.n * 8;
+    int blocks = P.ntiles < 2048 ? P.ntiles : 2048;
+    hipLaunchKernelGGL(mask0_fwd_kernel<SRC>, dim3(blocks), dim3(256), 0, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
 
 template <class C>
 static int launch_mconv(MConvParams P, hipStream_t st) {
@@ -163,8 +313,8 @@ int mconv_fwd_dispatch(int which, int n, const void* src_a, const float* src_b, 
     MConvParams P{};
     P.src_a = src_a; P.src_b = src_b; P.w = w; P.bias = bias; P.out = out; P.n = n;
     switch (which) {
-        case 0: return launch_mconv<MMask0U8>(P, st);
-        case 1: return launch_mconv<MMask0F32>(P, st);
+        case 0: return launch_mask0_fwd<WSRC_U8>(Mask0FwdParams{src_a, src_b, w, bias, out, n, 0}, st);
+        case 1: return launch_mask0_fwd<WSRC_F32>(Mask0FwdParams{src_a, src_b, w, bias, out, n, 0}, st);
         case 2: return launch_mconv<MDec3F>(P, st);
     }
     return CGS_ERR_UNSUPPORTED;
