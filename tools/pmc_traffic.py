@@ -5,7 +5,8 @@ Usage: python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write r01
 import collections, csv, glob, json, sys
 
 def load(d, name):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    import os
+    f = max(glob.glob(f"{d}/*/*_counter_collection.csv") + glob.glob(f"{d}/*counter_collection.csv"), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
     idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
@@ -24,7 +25,7 @@ tot_w = sum(write.values())
 out = {"n_images": n, "kernels_per_step": nk, "fetch_bytes_raw": sum(fetch.values()), "fetch_bytes_corrected_x2": tot_f,
        "write_bytes": tot_w, "traffic_bytes_per_step": tot_f + tot_w, "algorithmic_bytes_per_step": 4.841e6 * n,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --no-graph; values are KB; "
-                 "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B); summed over the 52 kernels of one step"}
+                 "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B); summed over the kernels of one step"}
 json.dump(out, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 with open(f"profiles/{tag}_traffic.txt", "w") as fp:
     fp.write(json.dumps({k: v for k, v in out.items() if k != "method"}) + "\n")
