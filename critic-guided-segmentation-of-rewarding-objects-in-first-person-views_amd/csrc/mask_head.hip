@@ -8,9 +8,14 @@
 //                  = sum_{u,v in 0..3} sum_oc dH[2q + (u-1, v-1)][oc] * W4[u][v][oc][c],
 //       W4[u][v][oc][c] = sum_{a in {0,1}, ky = a+2-u in 0..2} sum_{b in {0,1}, kx = b+2-v in 0..2} W[ky][kx][3+c][oc]
 //     i.e. one stride-2 4x4 convolution (16 taps per output) instead of four 3x3 ones (36 taps): 2.25x fewer MACs;
-//     GEMM M = 16 low-res pixels of a row, K = 16 window positions x 16 channels, N = 8 (half a tile is padding),
-//   * masker.0 weight gradient (optional): implicit GEMM rows (tap, ci) x 16 output channels over the pixels, dH read
-//     straight from the LDS tile it was rebuilt into.
+//     GEMM: M = 16 PAIRS of horizontally adjacent low-res pixels, N = 2 x 8 channels (one column block per pixel of the
+//     pair, no padding columns), K = 4 x 6 window positions (the union of the two 4x4 windows) x 16 channels,
+//   * masker.0 weight gradient (optional): implicit GEMM over the pixels with dH read straight from the LDS tile it was
+//     rebuilt into.  Rows: 27 image (tap, channel) rows + the bias row, and for the 8 upsampled channels the FOLDED rows:
+//     per pixel parity (py, px) the 9 taps over the upsampled o0 hit only a 2x2 neighbourhood (a, b) of o0 itself, so
+//     4 x 8 rows per parity class are accumulated (over that class's pixels only) and unfolded at the end:
+//       dW[ky][kx][3+cb] = sum_{py,px} dW4[py][px][a(py,ky)][b(px,kx)][cb],  a(0,.) = {0,1,1}, a(1,.) = {0,0,1}
+//     -> 4 instead of 7 MFMAs per 4 pixels.
 // Workgroup = 8 waves with two roles, one tile (TH rows of one image) apart:
 //   waves 0-3 ("builders", VALU + memory): rebuild dH of tile i into xt[i&1] (+ masker.2 weight-gradient partials),
 //   waves 4-7 ("matrix" waves): the two GEMMs of tile i-1 out of xt[(i-1)&1] on the matrix cores.
@@ -36,16 +41,18 @@ struct MHeadParams {
 template <int TH, bool W0>
 struct MHeadGeo {
     static constexpr int H = 64, W = 64, TRA = TH + 2, PW = W + 2, PS = 17, DZW = W + 4, DZR = TH + 4, STRIPS = H / TH;
-    static constexpr int XT = TRA * PW * PS, W4 = 16 * 16 * 8, DZ = DZR * DZW;
-    static constexpr int PCI = 12, XIN = W0 ? TRA * PW * PCI : 0;     // masker.0 input tile [TRA][PW][3+pad | 8]
-    static constexpr int FLOATS = 2 * XT + XIN + W4 + DZ;             // the dH tile is double buffered
+    static constexpr int XT = TRA * PW * PS, DZ = DZR * DZW;
+    static constexpr int W4P = 24 * 16 * 16;                           // pair-folded masker.0 weights [4x6 pos][oc][2x8]
+    static constexpr int LR = TH / 2 + 2, LC = W / 2 + 2;              // o0 tile at its own resolution
+    static constexpr int XIMG = W0 ? TRA * PW * 4 : 0, XO = W0 ? LR * LC * 8 : 0;   // masker.0 inputs (image [r,g,b,0])
+    static constexpr int FLOATS = 2 * XT + XIMG + XO + W4P + DZ;      // the dH tile is double buffered
     static constexpr size_t LDS = (size_t)((FLOATS + 3) / 4) * 16;
-    static constexpr int CI = 11, ROWS = 9 * CI + 1, NRB = (ROWS + 15) / 16;   // masker.0 weight-gradient GEMM rows
-    static constexpr int RED2 = 0, RED0 = 1024;                        // reduction buffers (floats into the dH tiles)
-    static_assert(RED0 + 4 * ROWS * 16 <= 2 * XT, "reduction buffers fit in the tile storage");
+    // reduction buffers (floats into the dH tiles, used after the last tile)
+    static constexpr int RED2 = 0, REDA = 1024, REDB = REDA + 4 * 32 * 16, RED_END = REDB + 4 * 4 * 32 * 16;
+    static_assert(RED_END <= 2 * XT, "reduction buffers fit in the tile storage");
 };
 
-struct MHeadLds { float *xt0, *xin, *w4, *dz; };
+struct MHeadLds { float *xt0, *ximg, *xo, *w4p, *dz; };
 
 // ---------------------------------------------------------------------------------------------------------------
 // Builder waves (threads 0..255).  Per tile: [phase 1] dzpre tile -> LDS | barrier | [phase 2] rebuild dH | barrier
@@ -188,31 +195,30 @@ template <int TH, bool W0, int SRC>
 __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHeadLds& L, const int mtid, const int T,
                                                  const int bid, const int grid) {
     using G = MHeadGeo<TH, W0>;
-    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, PCI = G::PCI;
-    constexpr int CI = G::CI, ROWS = G::ROWS, NRB = W0 ? G::NRB : 1;
-    constexpr int NPIX = TRA * PW, ITA = (NPIX + 255) / 256, ITB = (NPIX * 2 + 255) / 256;
+    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, LR = G::LR, LC = G::LC;
+    constexpr int NPIX = TRA * PW, NLO = LR * LC * 2, ITA = (NPIX + 255) / 256, ITB = (NLO + 255) / 256;
+    static_assert(TH == 8, "4 matrix waves: one low-res row (data gradient) and one even + one odd row (weight gradient) each");
     const int lane = mtid & 63, mwave = mtid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };
-    // data gradient, B operand of k-step s = (window position, channel plane): w4[(4s + kq)*8 + l15] for the 8 real
-    // columns.  The 8 padding columns just repeat them (their results are never stored).  base + constant per step.
-    const float* wb = L.w4 + kq * 8 + (l15 & 7);
-    // weight gradient: GEMM rows r = tap*11 + ci (99) + the bias row; A operand = masker.0 input at (pixel + tap)
-    int rbase[NRB];
-    frag4 wg0[NRB];
+    // weight gradient accumulators: image rows + bias (2 row blocks), folded o0 rows per parity (py, px) (2 row blocks each)
+    frag4 accA[2], accB[2][2][2];
     float4 ra[W0 ? ITA : 1], rb[W0 ? ITB : 1];
 #pragma unroll
-    for (int q = 0; q < NRB; ++q) {
-        int r = q * 16 + l15;
-        if (r < 9 * CI) {
-            int tap = r / CI, ci = r % CI;
-            int lch = ci < 3 ? ci : 4 + (ci - 3);
-            rbase[q] = ((tap / 3) * PW + (tap % 3)) * PCI + lch;
-        } else {
-            rbase[q] = (r == 9 * CI) ? -1 : -2;
-        }
-        wg0[q] = frag4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 2; ++q) {
+        accA[q] = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accB[c >> 1][c & 1][q] = frag4{0.f, 0.f, 0.f, 0.f};
     }
+    // image rows r = 16q + l15: (tap, channel) = (r / 3, r % 3) for r < 27, r = 27 the bias row (operand 1), else padding
+    int rimg[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        int r = 16 * q + l15, tap = r / 3, c = r % 3;
+        rimg[q] = r < 27 ? ((tap / 3) * PW + tap % 3) * 4 + c : 0;
+    }
+    const float m1 = (16 + l15 < 27) ? 1.f : 0.f, m0 = (16 + l15 == 27) ? 1.f : 0.f;   // second row block: valid / bias / pad
+
     // fetch = address arithmetic + loads only (raw dwords); decoding and zero padding happen in commit, one phase
     // later: anything that touches the loaded value here would stall the wave on global memory
     auto fetch_x = [&](int tile) {
@@ -235,11 +241,11 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
         }
 #pragma unroll
         for (int it = 0; it < ITB; ++it) {
-            int e = mtid + it * 256; e = e < 2 * NPIX ? e : 2 * NPIX - 1;
-            int px = e >> 1;
-            int y = row0 + px / PW - 1, x = px % PW - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            rb[it] = ((const float4*)P.o0)[in ? ((n0 * 32 + (y >> 1)) * 32 + (x >> 1)) * 2 + (e & 1) : 0];
+            int e = mtid + it * 256; e = e < NLO ? e : NLO - 1;
+            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 1, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            rb[it] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
         }
     };
     auto commit_x = [&](int tile) {
@@ -256,15 +262,16 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                 const float sc = 1.f / 255.f;
                 v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
             }
-            ((float4*)L.xin)[e * 3] = in ? v : f4zero();
+            v.w = 0.f;
+            ((float4*)L.ximg)[e] = in ? v : f4zero();
         }
 #pragma unroll
         for (int it = 0; it < ITB; ++it) {
-            int e = mtid + it * 256; e = e < 2 * NPIX ? e : 2 * NPIX - 1;
-            int px = e >> 1;
-            int y = row0 + px / PW - 1, x = px % PW - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            ((float4*)L.xin)[px * 3 + 1 + (e & 1)] = in ? rb[it] : f4zero();
+            int e = mtid + it * 256; e = e < NLO ? e : NLO - 1;
+            int pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 1, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            ((float4*)L.xo)[e] = in ? rb[it] : f4zero();       // [pr][pc][8]: e = (pr*LC + pc)*2 + half
         }
     };
 
@@ -285,21 +292,20 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
             // matrix pipe would idle for a full LDS round trip per group.  A group must stay below 16 LDS instructions:
             // s_waitcnt lgkmcnt counts to 15, so "wait for the previous group only" is not expressible beyond that.
             {
-                // data gradient: this wave's two 16-pixel tiles (low-res row qyl, both halves) share the B reads
-                static_assert(TH == 8, "two 16-pixel tiles per matrix wave");
+                // data gradient of low-res row qyl = mwave: lane pair i = l15 covers low-res pixels 2i (columns 0-7 of the
+                // tile) and 2i+1 (columns 8-15); window = rows 2qyl-1..2qyl+2, columns 4i-1..4i+4 of dH
                 const int qyl = mwave;
-                const int abase = ((2 * qyl) * PW + 2 * l15) * PS + kq;
-                frag4 d0 = frag4{0.f, 0.f, 0.f, 0.f}, d1 = d0;
-                constexpr int GS = 8, NG = 64 / GS;   // 24 dwords = 12 ds_read2 per group
-                float a0[2][GS], a1[2][GS], bw[2][GS];
+                const int abase = ((2 * qyl) * PW + 4 * l15) * PS + kq;
+                const float* wb = L.w4p + kq * 16 + l15;          // B: w4p[(pos*16 + 4*plane + kq)*16 + l15]
+                frag4 d = frag4{0.f, 0.f, 0.f, 0.f};
+                constexpr int GS = 12, NG = 96 / GS;              // 24 dwords = 12 ds_read2 per group
+                float av[2][GS], bw[2][GS];
                 auto ld = [&](int g, int buf) {
 #pragma unroll
                     for (int j = 0; j < GS; ++j) {
-                        const int s = g * GS + j, pos = s >> 2, u = pos >> 2, v = pos & 3;
-                        const int off = (u * PW + v) * PS + 4 * (s & 3);
-                        a0[buf][j] = xt[abase + off];
-                        a1[buf][j] = xt[abase + 32 * PS + off];
-                        bw[buf][j] = wb[s * 32];
+                        const int s = g * GS + j, pos = s >> 2, u = pos / 6, v6 = pos % 6;
+                        av[buf][j] = xt[abase + (u * PW + v6) * PS + 4 * (s & 3)];
+                        bw[buf][j] = wb[s * 64];
                     }
                 };
                 ld(0, 0);
@@ -308,54 +314,52 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                     if (g + 1 < NG) ld(g + 1, (g + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < GS; ++j) {
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[g & 1][j], bw[g & 1][j], d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[g & 1][j], bw[g & 1][j], d1, 0, 0, 0);
-                    }
+                    for (int j = 0; j < GS; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][j], bw[g & 1][j], d, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (l15 < 8) {
-                    const int qy = row0 / 2 + qyl;
-                    float* o = P.d_o0 + ((size_t)(n0 * 32 + qy) * 32 + 4 * kq) * 8 + l15;
+                // D[row = pair 4kq + j][col = l15 = 8*(pixel of the pair) + channel]: 16 contiguous floats per pair
+                float* o = P.d_o0 + ((size_t)(n0 * 32 + row0 / 2 + qyl) * 32 + 2 * (4 * kq)) * 8 + l15;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { o[j * 8] = d0[j]; o[(16 + j) * 8] = d1[j]; }
-                }
+                for (int j = 0; j < 4; ++j) o[j * 16] = d[j];
             }
             if constexpr (W0) {
-                // weight gradient: each matrix wave owns whole tile rows; inside a row the k-steps advance by constant
-                // strides, so every LDS address is (per-row base) + immediate offset
-                constexpr int SPR = W / 4, UU = 2, NCH = (TH / 4) * (SPR / UU);   // 16 dwords = 8 ds_read2 per chunk
-                int xa[NRB];
+                // weight gradient: this wave's rows 2*mwave (py = 0) and 2*mwave + 1 (py = 1); a k-step = 4 same-parity
+                // pixels x = 2*(4s + kq) + px of one row.  Chunk = (py, px, two k-steps): 5 ds_read2 + 8 MFMAs.
+                constexpr int UU = 2, CPP = 8 / UU, NCH = 4 * CPP;
+                const int bb = (PW + 1 + 2 * kq) * PS + l15;              // dH: ((yl+1)*PW + 1 + 2*(4s+kq) + px)*PS + l15
+                const int ib = (2 * kq) * 4;                               // image: ((yl+ky)*PW + 2*(4s+kq) + px + kx)*4 + c
+                const int ob = kq * 8 + l15;                               // o0: ((mwave+a+py)*LC + 4s + kq + b + px)*8 + cb
+                float ai[2][UU][2], ao[2][UU][2], b[2][UU];
+                auto ld = [&](int ch, int buf) {
+                    const int py = ch / (2 * CPP), px = (ch / CPP) & 1, s0 = UU * (ch % CPP);
+                    const int yl = 2 * mwave + py;
 #pragma unroll
-                for (int q = 0; q < NRB; ++q) xa[q] = kq * PCI + (rbase[q] >= 0 ? rbase[q] : 0);
-                const int yb = (PW + 1 + kq) * PS + l15;
-                const float m1 = rbase[NRB - 1] >= 0 ? 1.f : 0.f, m0 = rbase[NRB - 1] == -1 ? 1.f : 0.f;
-                float a[2][UU][NRB], b[2][UU];
-                auto ld = [&](int ch, int buf) {      // chunk ch: row mwave + 4*(ch / (SPR/UU)), steps UU*(ch % (SPR/UU))..
-                    const int yl = mwave + 4 * (ch / (SPR / UU)), c = UU * (ch % (SPR / UU));
-                    // the two k-steps of one row block sit at a constant distance: adjacent loads -> one ds_read2_b32
+                    for (int u = 0; u < UU; ++u) b[buf][u] = xt[bb + (yl * PW + px + 8 * (s0 + u)) * PS];
 #pragma unroll
-                    for (int u = 0; u < UU; ++u) b[buf][u] = xt[yb + yl * PW * PS + (c + u) * 4 * PS];
+                    for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int q = 0; q < NRB; ++q)
+                        for (int u = 0; u < UU; ++u) ai[buf][u][q] = L.ximg[ib + rimg[q] + (yl * PW + px + 8 * (s0 + u)) * 4];
 #pragma unroll
-                        for (int u = 0; u < UU; ++u) a[buf][u][q] = L.xin[xa[q] + yl * PW * PCI + (c + u) * 4 * PCI];
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int u = 0; u < UU; ++u) ao[buf][u][q] = L.xo[ob + ((mwave + q + py) * LC + px + 4 * (s0 + u)) * 8];
                 };
                 ld(0, 0);
 #pragma unroll
                 for (int ch = 0; ch < NCH; ++ch) {
                     if (ch + 1 < NCH) ld(ch + 1, (ch + 1) & 1);
                     __builtin_amdgcn_sched_barrier(0);
+                    const int py = ch / (2 * CPP), px = (ch / CPP) & 1;
 #pragma unroll
-                    for (int u = 0; u < UU; ++u)
-#pragma unroll
-                        for (int q = 0; q < NRB; ++q) {
-                            // rows past the weights (bias row: constant 1, padding: 0) as arithmetic at the point of use,
-                            // not a select at the load: the load stays unconditional and pairs into ds_read2
-                            float av = a[ch & 1][u][q];
-                            if (q == NRB - 1) av = fmaf(av, m1, m0);
-                            wg0[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[ch & 1][u], wg0[q], 0, 0, 0);
-                        }
+                    for (int u = 0; u < UU; ++u) {
+                        const float bv = b[ch & 1][u];
+                        // rows past the 27 image rows (bias row: constant 1, padding: 0) as arithmetic at the point of use:
+                        // the load stays unconditional and pairs into ds_read2
+                        accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[ch & 1][u][0], bv, accA[0], 0, 0, 0);
+                        accA[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(ai[ch & 1][u][1], m1, m0), bv, accA[1], 0, 0, 0);
+                        accB[py][px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][0], bv, accB[py][px][0], 0, 0, 0);
+                        accB[py][px][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][1], bv, accB[py][px][1], 0, 0, 0);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -364,14 +368,17 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     }
 
     if constexpr (W0) {
-        // D layout: col = lane & 15 (= co), row = (lane >> 4) * 4 + reg; one partial [ROWS][16] per matrix wave
-        float* red0 = L.xt0 + G::RED0 + mwave * (ROWS * 16);
+        // D layout: col = lane & 15 (= oc), row = 16q + (lane >> 4) * 4 + reg; one partial set per matrix wave
+        float* redA = L.xt0 + G::REDA + mwave * (32 * 16);
+        float* redB = L.xt0 + G::REDB + mwave * (4 * 32 * 16);
 #pragma unroll
-        for (int q = 0; q < NRB; ++q)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int r = q * 16 + kq * 4 + j;
-                if (r < ROWS) red0[r * 16 + l15] = wg0[q][j];
+                const int r = 16 * q + 4 * kq + j;
+                redA[r * 16 + l15] = accA[q][j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) redB[(c * 32 + r) * 16 + l15] = accB[c >> 1][c & 1][q][j];
             }
     }
 }
@@ -380,26 +387,30 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
 template <int TH, bool WG, bool W0, int SRC>
 __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     using G = MHeadGeo<TH, W0>;
-    constexpr int TRA = G::TRA, PW = G::PW, PS = G::PS, ROWS = G::ROWS;
+    constexpr int TRA = G::TRA, PW = G::PW, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     MHeadLds L;
     L.xt0 = (float*)smem;              // dH tiles [2][TRA][PW][PS]
-    L.xin = L.xt0 + 2 * G::XT;         // masker.0 input tile (W0)
-    L.w4 = L.xin + G::XIN;             // folded weights [u][v][oc][c]
-    L.dz = L.w4 + G::W4;               // dzpre tile with a 2-pixel halo
+    L.ximg = L.xt0 + 2 * G::XT;        // masker.0 image tile [TRA][PW][r,g,b,0] (W0)
+    L.xo = L.ximg + G::XIMG;           // masker.0 low-resolution input tile [LR][LC][8] (W0)
+    L.w4p = L.xo + G::XO;              // pair-folded weights [u 0..3][v6 0..5][oc][8*g + c]
+    L.dz = L.w4p + G::W4P;             // dzpre tile with a 2-pixel halo
     const int tid = threadIdx.x;
 
-    for (int e = tid; e < G::W4; e += 512) {
-        const int c = e & 7, oc = (e >> 3) & 15, v = (e >> 7) & 3, u = e >> 9;
+    for (int e = tid; e < G::W4P; e += 512) {
+        const int col = e & 15, oc = (e >> 4) & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
+        const int g = col >> 3, c = col & 7, v = v6 - 2 * g;      // pixel g of the pair sees window column v6 as v
         float s = 0.f;
+        if (v >= 0 && v <= 3) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                int ky = a + 2 - u, kx = b + 2 - v;
-                if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) s += P.w0[((ky * 3 + kx) * 11 + 3 + c) * 16 + oc];
-            }
-        L.w4[e] = s;
+                for (int b = 0; b < 2; ++b) {
+                    int ky = a + 2 - u, kx = b + 2 - v;
+                    if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) s += P.w0[((ky * 3 + kx) * 11 + 3 + c) * 16 + oc];
+                }
+        }
+        L.w4p[e] = s;
     }
     for (int e = tid; e < 2 * TRA * 2 * 16; e += 512) {      // zero halo columns of both dH tiles (never written again)
         int ch = e & 15, side = (e >> 4) & 1, r = (e >> 5) % TRA, bufi = e / (32 * TRA);
@@ -416,10 +427,31 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
 
     // ---------------- weight-gradient partials: one slab per workgroup ----------------
     if constexpr (W0) {
-        const float* red0 = L.xt0 + G::RED0;
-        for (int e = tid; e < ROWS * 16; e += 512)
-            P.slab0[(size_t)blockIdx.x * (ROWS * 16) + e] =
-                (red0[e] + red0[ROWS * 16 + e]) + (red0[2 * ROWS * 16 + e] + red0[3 * ROWS * 16 + e]);
+        // unfold: image rows and bias straight from the A partials; the 8 upsampled channels of tap (ky, kx) are the sum
+        // over the 4 parity classes of their folded row a(py,ky), b(px,kx)   (fixed order: deterministic)
+        const float* redA = L.xt0 + G::REDA;
+        const float* redB = L.xt0 + G::REDB;
+        auto sum4 = [&](const float* p, int stride) { return (p[0] + p[stride]) + (p[2 * stride] + p[3 * stride]); };
+        for (int e = tid; e < 1600; e += 512) {
+            float v;
+            if (e >= 1584) {
+                v = sum4(redA + 27 * 16 + (e - 1584), 32 * 16);
+            } else {
+                const int oc = e & 15, ci = (e >> 4) % 11, tap = (e >> 4) / 11, ky = tap / 3, kx = tap % 3;
+                if (ci < 3) {
+                    v = sum4(redA + (tap * 3 + ci) * 16 + oc, 32 * 16);
+                } else {
+                    v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int py = c >> 1, px = c & 1;
+                        const int a = py == 0 ? (ky >= 1) : (ky == 2), b = px == 0 ? (kx >= 1) : (kx == 2);
+                        v += sum4(redB + (c * 32 + (a * 2 + b) * 8 + (ci - 3)) * 16 + oc, 4 * 32 * 16);
+                    }
+                }
+            }
+            P.slab0[(size_t)blockIdx.x * 1600 + e] = v;
+        }
     }
     if constexpr (WG) {
         const float* red2 = L.xt0 + G::RED2;
