@@ -22,8 +22,8 @@ __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradPar
 // instances with matching workgroup sizes
 CGS_DG_CFG(DEnc3x, 8, 128, SRC_POOLEXP, 16, 8, 16, 2, 0, 8, 4, 8, CGS_ACT_NONE, 2)       // 256 threads
 struct WDec2x { using G = WGeo<8, 8, 8, 4, 192>; static constexpr int SRC = WSRC_F32, CA = 8, CB = 16, UPS = 2, CO = 8, DY = WDY_F32; };
-struct WDec3x { using G = WGeo<4, 4, 4, 4, 192>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, CO = 16, DY = WDY_F32; };
-CGS_DG_CFG(DDec3y, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 3)          // 192 threads
+struct WDec3x { using G = WGeo<4, 4, 4, 4, 384>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, CO = 16, DY = WDY_F32; };
+CGS_DG_CFG(DDec3y, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 6)          // 384 threads: one 8-channel chunk per wave
 struct WMask0U8x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_U8, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
 struct WMask0F32x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_F32, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
 
