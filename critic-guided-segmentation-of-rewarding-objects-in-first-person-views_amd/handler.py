@@ -304,9 +304,46 @@ class Handler:
                         f"{outpath}/{img_names[fidx]}-{columns[midx - 1]}.png")
         return M
 
-    def eval(self):
-        raise NotImplementedError("-eval / -test (IoU on the red-trees set) is not part of this build yet "
-                                  "(SURVEY.md section 8 f2; the data set is a missing blob)")
+    # ------------------------------------------------------------------ -eval: IoU on the labelled red-trees set
+    @staticmethod
+    def get_iou(A, B):
+        """main.py:1265-1270: |A & B| / |A | B| over the whole set, rounded to 3 digits."""
+        intersection = np.sum(A & B)
+        union = np.sum(A | B)
+        return round(float(intersection / union), 3)
+
+    def eval(self, folder="", vis=False):
+        """main.py:891-1020 without its optional branches: masks of `red-trees/X.npy[100:5000:2]` (batch 128, eval
+        mode), thresholded at --eval-thresh, IoU against `all(Y.npy, axis=-1)`.  Returns [iou] like the reference."""
+        args = self.args
+        if args.noevalmode:
+            raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
+        if args.salience or args.crf or args.resimages or folder or vis:
+            raise NotImplementedError("-salience / -crf / -resimages / folder / video evaluation are outside this build's scope")
+        evaldatapath = "red-trees/"
+        X = np.load(evaldatapath + "X.npy")                       # uint8 [n,64,64,3] (the reference divides by 255 here)
+        Y = np.expand_dims(np.all(np.load(evaldatapath + "Y.npy"), axis=-1), axis=-1)
+        X = X[100:5000:2]
+        Y = Y[100:5000:2]
+        self.critic.eval()
+        self.masker.eval()
+        eng = self._engine(2 * 32)
+        batchsize = 128
+        M = []
+        for bidx in range(0, len(X), batchsize):
+            print("eval at", bidx / len(X), end="\r")
+            xb = X[bidx:bidx + batchsize]
+            batch = torch.from_numpy(np.ascontiguousarray(xb)).to(self.device)
+            if batch.dtype != torch.uint8:
+                batch = (batch.double() / 255.0).float()            # float data sets: main.py:921,939
+            _pred, Z = eng.infer(batch)
+            M.append(Z.cpu().numpy()[:, None])
+        M = np.concatenate(M, axis=0)
+        hardM = M > args.eval_thresh
+        iou = self.get_iou(hardM.squeeze(), Y.transpose(0, 3, 1, 2).squeeze())
+        ious = [iou]
+        print(f"\nRESULTS", ious)
+        return ious
 
     # ------------------------------------------------------------------ helpers
     @staticmethod

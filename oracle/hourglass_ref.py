@@ -25,6 +25,7 @@ Reference lines restated (relative to /root/reference):
   adam_step         main.py:178,330-334,461-463 (torch.optim.Adam defaults)
   infer_masks       main.py:1130-1151
   postprocess_masks main.py:1163-1167,1212-1223
+  eval_iou          main.py:891-1020 (no salience / CRF), get_iou main.py:1265-1270
 """
 from __future__ import annotations
 
@@ -324,3 +325,21 @@ def postprocess_masks(X01: np.ndarray, M: np.ndarray, threshold: float = 0.5):
     cols = [X01] + [np.concatenate((m, m, m), axis=1).transpose(0, 2, 3, 1) for m in (M, hard)]
     stack = np.stack(cols, axis=1)
     return hard, (stack * 255).astype(np.uint8)
+
+
+def eval_iou(PC, PM, X_u8: np.ndarray, Y: np.ndarray, eval_thresh: float = 0.05, batchsize: int = 128) -> float:
+    """main.py:891-1020 (plain branch): X_u8 [n,64,64,3] and Y [n,64,64,k] are the FULL red-trees arrays; the reference
+    evaluates rows 100:5000:2, thresholds the eval-mode masks at `eval_thresh` (strictly greater) and returns
+    get_iou(hardM, all(Y, -1)) rounded to 3 digits (main.py:1265-1270)."""
+    Yb = np.expand_dims(np.all(Y, axis=-1), axis=-1)
+    Xs, Ys = X_u8[100:5000:2], Yb[100:5000:2]
+    M = []
+    with torch.no_grad():
+        for b in range(0, len(Xs), batchsize):
+            X = u8_to_nchw(Xs[b:b + batchsize])
+            _pred, embeds = critic_apply(PC, X, collect=True)
+            M.append(masker_apply(PM, X, embeds).numpy())
+    M = np.concatenate(M, axis=0)
+    hardM = M > eval_thresh
+    A, B = hardM.squeeze(), Ys.transpose(0, 3, 1, 2).squeeze()
+    return round(float(np.sum(A & B) / np.sum(A | B)), 3)

@@ -176,6 +176,24 @@ def test_cli_train_then_process(tmp_path):
     img = np.array(Image.open(os.path.join(root, "out2", "frame.0_with_mask.png")))
     assert img.shape == (64, 192, 3)
     np.testing.assert_array_equal(img[:, :64], X[0])
+    # -eval: IoU on a (synthetic) red-trees set in the working directory, against the oracle on the trained weights
+    os.makedirs(os.path.join(root, "red-trees"))
+    rs = np.random.RandomState(11)
+    Xe = rs.randint(0, 256, (420, 64, 64, 3)).astype(np.uint8)
+    Ye = np.zeros((420, 64, 64, 3), dtype=bool)
+    Ye[:, 16:48, 8:40] = True                       # "all channels set" = labelled object
+    Ye[:, 20:30, 10:20, 1] = False                  # ... except where one channel is not
+    np.save(os.path.join(root, "red-trees", "X.npy"), Xe)
+    np.save(os.path.join(root, "red-trees", "Y.npy"), Ye)
+    with torch.no_grad():                           # a threshold at the median mask value: a non-degenerate IoU
+        _, M0 = orc.infer_masks(pc, pm, Xe[100:164:2] / 255.0)
+    thr = float(np.median(M0))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-eval", "--eval-thresh", repr(thr)] + common, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    want = orc.eval_iou(pc, pm, Xe, Ye, eval_thresh=thr)
+    got = float(r.stdout.split("RESULTS [")[-1].split("]")[0])
+    assert 0.0 < want < 1.0 and abs(got - want) <= 2e-3, (got, want)
 
 
 DP_WORKER = r"""

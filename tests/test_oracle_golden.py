@@ -168,3 +168,18 @@ def test_postprocess_shapes(golden, g1):
     assert stack.dtype == np.uint8 and stack.shape == (3, 3, 64, 64, 3)
     np.testing.assert_array_equal(stack[:, 0], g["X"][:3])
     assert set(np.unique(stack[:, 2])) <= {0, 255}
+
+
+def test_eval_iou_restatement(g1):
+    """eval_iou = main.py:891-1020 (plain branch) + get_iou main.py:1265-1270: subset 100:5000:2, strict threshold,
+    |A&B| / |A|B| over the whole set, 3 digits."""
+    pc, pm = g1
+    rs = np.random.RandomState(5)
+    X = rs.randint(0, 256, (140, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(140, 64, 64, 3) > 0.2
+    _, M = orc.infer_masks(pc, pm, X[100:5000:2] / 255.0)
+    thr = float(np.median(M))
+    A = (M > thr).squeeze()
+    B = np.all(Y, axis=-1)[100:5000:2]
+    assert orc.eval_iou(pc, pm, X, Y, eval_thresh=thr) == round(float((A & B).sum() / (A | B).sum()), 3)
+    assert orc.eval_iou(pc, pm, X, Y, eval_thresh=2.0) == 0.0      # nothing above 2: empty prediction
