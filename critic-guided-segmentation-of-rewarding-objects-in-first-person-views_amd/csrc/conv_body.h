@@ -377,7 +377,7 @@ CGS_FWD_CFG(FEnc1, 32, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
 CGS_FWD_CFG(FEnc2, 16, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
 CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 4, 4)
 CGS_FWD_CFG(FDec3, 4, 64, SRC_F32, 16, 32, 4, 16, EPI_PLAIN, CGS_ACT_NONE, 4, 4)
-CGS_FWD_CFG(FDec2, 8, 64, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
+CGS_FWD_CFG(FDec2, 8, 64, SRC_F32, 8, 16, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 2, 4)
 CGS_FWD_CFG(FDec1, 16, 64, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
 CGS_FWD_CFG(FDec0, 32, 128, SRC_F32, 8, 8, 2, 8, EPI_PLAIN, CGS_ACT_NONE, 4, 2)
 CGS_FWD_CFG(FMask0U8, 64, 128, SRC_U8C3, 3, 8, 2, 16, EPI_PLAIN, CGS_ACT_LRELU, 8, 2)

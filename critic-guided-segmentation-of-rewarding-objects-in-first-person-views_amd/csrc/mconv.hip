@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(C::G::THREADS) mconv_kernel(MConvParams P) {
     }
 }
 
-struct MDec3F { using G = WGeo<4, 4, 4, 8, 256>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, WT = 0, WCI = 48, WCO = 16, NOUT = 16, ACT = CGS_ACT_NONE, EPI = MEPI_PLAIN, OUT_A = 0; };
+struct MDec3F { using G = WGeo<4, 4, 4, 2, 128>; static constexpr int SRC = WSRC_F32, CA = 16, CB = 32, UPS = 4, WT = 0, WCI = 48, WCO = 16, NOUT = 16, ACT = CGS_ACT_NONE, EPI = MEPI_PLAIN, OUT_A = 0; };
 
 // ------------------------------------------------------------------------------------------------
 // masker.0 forward (nets.py:488-489: Upsample(o0) ++ image -> conv 11->16 -> LeakyReLU) with the nearest-upsample
