@@ -105,8 +105,20 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
     float* w1s = w4s + 256 * 33;
     const int tid = threadIdx.x, il = tid >> 5, o = tid & 31, kg = il;
     const DropCtx di = drop_ctx(drop_in), dh = drop_ctx(drop_h);
-    for (int i = tid; i < 256 * 32; i += 256) w4s[(i >> 5) * 33 + (i & 31)] = w4[i];
-    for (int i = tid; i < 32 * 32; i += 256) w1s[(i >> 5) * 33 + (i & 31)] = w1[i];
+    // all weight loads of a thread are independent 16-byte loads issued back to back (one memory latency, not 36)
+    {
+        float4 v4[8], v1 = ((const float4*)w1)[tid];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v4[i] = ((const float4*)w4)[tid + i * 256];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + i * 256;
+            float* d = w4s + (idx >> 3) * 33 + (idx & 7) * 4;
+            d[0] = v4[i].x; d[1] = v4[i].y; d[2] = v4[i].z; d[3] = v4[i].w;
+        }
+        float* d = w1s + (tid >> 3) * 33 + (tid & 7) * 4;
+        d[0] = v1.x; d[1] = v1.y; d[2] = v1.z; d[3] = v1.w;
+    }
     float acc4[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
