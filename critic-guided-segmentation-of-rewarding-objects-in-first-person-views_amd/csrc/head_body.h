@@ -11,7 +11,7 @@ __device__ __forceinline__ float drop_mult1(const DropCtx& dc, uint32_t i) {
 // ------------------------------------------------------------------------------------------------
 // head forward: 8 images x 32 outputs per workgroup
 // ------------------------------------------------------------------------------------------------
-static constexpr int HEAD_FWD_LDS = (8 * 256 + 256 * 32 + 32 * 32 + 8 * 32 + 8 * 33) * 4;   // bytes
+static constexpr int HEAD_FWD_LDS = (8 * 256 + 256 * 32 + 32 * 32 + 8 * 32 + 8 * 33 + 32 * 32) * 4;   // bytes
 
 // 8 images (img0 .. img0+7) x 32 outputs by 256 threads; lds = HEAD_FWD_LDS bytes, 16-byte aligned
 __device__ __forceinline__ void head_fwd_body(int n, int img0, const float* __restrict__ e3, const float* __restrict__ w4,
@@ -19,18 +19,22 @@ __device__ __forceinline__ void head_fwd_body(int n, int img0, const float* __re
                                               const float* __restrict__ b1, const float* __restrict__ w2,
                                               const float* __restrict__ b2, const cgs_dropout& drop_in,
                                               const cgs_dropout& drop_h, float* __restrict__ e4,
-                                              float* __restrict__ h1, float* __restrict__ pred, float* lds) {
+                                              float* __restrict__ h1, float* __restrict__ pred,
+                                              const float* __restrict__ wpw, const float* __restrict__ bpw,
+                                              float* __restrict__ o4, float* lds) {
     float (*xs)[256] = (float (*)[256])lds;
     float* w4s = lds + 8 * 256;                 // 32 KB: the 4x4-conv weights, read 8x per block
     float* w1s = w4s + 256 * 32;
     float (*es)[32] = (float (*)[32])(w1s + 32 * 32);
     float (*hs)[33] = (float (*)[33])(w1s + 32 * 32 + 8 * 32);
+    float* wps = w1s + 32 * 32 + 8 * 32 + 8 * 33;   // optional: the decoder's 1x1 bottleneck conv (dec_model.4), k-major
     const int tid = threadIdx.x, il = tid >> 5, o = tid & 31;
     const int nn = img0 + il;
     const DropCtx di = drop_ctx(drop_in), dh = drop_ctx(drop_h);
 #pragma unroll
     for (int i = 0; i < 8; ++i) ((float4*)w4s)[tid + i * 256] = ((const float4*)w4)[tid + i * 256];
     ((float4*)w1s)[tid] = ((const float4*)w1)[tid];
+    if (o4) ((float4*)wps)[tid] = ((const float4*)wpw)[tid];
     for (int e = tid; e < 8 * 64; e += 256) {
         int img = e >> 6, q = e & 63, m = img0 + img;
         float4 v = f4zero();
@@ -56,6 +60,12 @@ __device__ __forceinline__ void head_fwd_body(int n, int img0, const float* __re
     es[il][o] = e;
     if (nn < n) e4[nn * 32 + o] = e;
     __syncthreads();
+    if (o4) {   // decoder bottleneck o4 = W_pw e4 + b_pw (nets.py:501) from the e4 row already in LDS
+        float a = bpw[o];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) a = fmaf(es[il][k], wps[k * 32 + o], a);
+        if (nn < n) o4[nn * 32 + o] = a;
+    }
     acc = b1[o];
 #pragma unroll
     for (int k = 0; k < 32; ++k) acc = fmaf(es[il][k], w1s[k * 32 + o], acc);
@@ -75,9 +85,9 @@ __device__ __forceinline__ void head_fwd_body(int n, int img0, const float* __re
 __global__ void __launch_bounds__(256) head_fwd_kernel(int n, const float* e3, const float* w4, const float* b4,
                                                        const float* w1, const float* b1, const float* w2, const float* b2,
                                                        cgs_dropout drop_in, cgs_dropout drop_h, float* e4, float* h1,
-                                                       float* pred) {
+                                                       float* pred, const float* wpw, const float* bpw, float* o4) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    head_fwd_body(n, blockIdx.x * 8, e3, w4, b4, w1, b1, w2, b2, drop_in, drop_h, e4, h1, pred, (float*)smem);
+    head_fwd_body(n, blockIdx.x * 8, e3, w4, b4, w1, b1, w2, b2, drop_in, drop_h, e4, h1, pred, wpw, bpw, o4, (float*)smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -86,7 +96,7 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int n, const float* e3, c
 // ------------------------------------------------------------------------------------------------
 static constexpr int HB_IPB = 8;
 static constexpr int HB_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1;
-static constexpr int HEAD_BWD_LDS = (8 * 256 + 3 * 8 * 32 + 4 * 8 * 32 + 256 * 33 + 32 * 33) * 4;   // bytes
+static constexpr int HEAD_BWD_LDS = (8 * 256 + 3 * 8 * 32 + 5 * 8 * 32 + 256 * 33 + 32 * 33 + 32 * 33 + 8 * 32) * 4;   // bytes
 
 // HB_IPB images starting at `base`; writes ONE slab at `sl`
 __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __restrict__ e3, const float* __restrict__ e4,
@@ -95,14 +105,17 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
                                               const float* d_e3_extra, int n_extra, const float* __restrict__ w4,
                                               const float* __restrict__ w1, const float* __restrict__ w2,
                                               const cgs_dropout& drop_in, const cgs_dropout& drop_h,
-                                              float* d_e3, float* __restrict__ sl, float* lds) {
+                                              float* d_e3, float* __restrict__ sl, const float* __restrict__ d_o4,
+                                              const float* __restrict__ wpw, float* __restrict__ slpw, float* lds) {
     float (*xs)[256] = (float (*)[256])lds;
     float (*es)[32] = (float (*)[32])(lds + 8 * 256);
     float (*dh1s)[32] = (float (*)[32])(lds + 8 * 256 + 8 * 32);
     float (*dz4s)[32] = (float (*)[32])(lds + 8 * 256 + 2 * 8 * 32);
     float (*red)[8][32] = (float (*)[8][32])(lds + 8 * 256 + 3 * 8 * 32);
-    float* w4s = lds + 8 * 256 + 3 * 8 * 32 + 4 * 8 * 32;        // rows padded to 33 floats: row-per-lane reads
+    float* w4s = lds + 8 * 256 + 3 * 8 * 32 + 5 * 8 * 32;        // rows padded to 33 floats: row-per-lane reads
     float* w1s = w4s + 256 * 33;
+    float* wps = w1s + 32 * 33;                                    // optional dec_model.4 weights, rows padded to 33
+    float (*do4s)[32] = (float (*)[32])(wps + 32 * 33);
     const int tid = threadIdx.x, il = tid >> 5, o = tid & 31, kg = il;
     const DropCtx di = drop_ctx(drop_in), dh = drop_ctx(drop_h);
     // all weight loads of a thread are independent 16-byte loads issued back to back (one memory latency, not 36)
@@ -118,7 +131,13 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
         }
         float* d = w1s + (tid >> 3) * 33 + (tid & 7) * 4;
         d[0] = v1.x; d[1] = v1.y; d[2] = v1.z; d[3] = v1.w;
+        if (d_o4) {
+            float4 vp = ((const float4*)wpw)[tid];
+            float* dp = wps + (tid >> 3) * 33 + (tid & 7) * 4;
+            dp[0] = vp.x; dp[1] = vp.y; dp[2] = vp.z; dp[3] = vp.w;
+        }
     }
+    float accpw[4] = {0.f, 0.f, 0.f, 0.f}, pbpw = 0.f;             // dec_model.4 weight / bias gradient partials
     float acc4[32];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
@@ -144,6 +163,11 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
             dz2 = dpred[nn] * p * (1.f - p);
         }
         es[il][o] = ev;
+        if (d_o4) {
+            float g = (nn < n_extra) ? d_o4[nn * 32 + o] : 0.f;   // the decoder saw the first n_extra images only
+            do4s[il][o] = g;
+            pbpw += g;
+        }
         float m2 = drop_mult1(dh, (uint32_t)(nn * 32 + o));
         pw2 = fmaf(dz2, hv * m2, pw2);
         if (o == 0) pb2 += dz2;
@@ -164,6 +188,17 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
 #pragma unroll
         for (int q = 0; q < 32; ++q) de = fmaf(w1s[o * 33 + q], dh1s[il][q], de);
         if (d_e4_extra && nn < n_extra) de += d_e4_extra[nn * 32 + o];
+        if (d_o4) {   // decoder bottleneck backward: d e4[k = o] += sum_j W_pw[k][j] d o4[j];  dW_pw[k][j] += e4[k] d o4[j]
+#pragma unroll
+            for (int q = 0; q < 32; ++q) de = fmaf(wps[o * 33 + q], do4s[il][q], de);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s = fmaf(es[i][kg * 4 + j], do4s[i][o], s);
+                accpw[j] += s;
+            }
+        }
         float dz4 = (ev > 0.f) ? de : 0.f;
         dz4s[il][o] = dz4;
         pb4 += dz4;
@@ -197,7 +232,11 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
     for (int j = 0; j < 32; ++j) sl[(kg * 32 + j) * 32 + o] = acc4[j];
 #pragma unroll
     for (int j = 0; j < 4; ++j) sl[8192 + 32 + (kg * 4 + j) * 32 + o] = accw1[j];
-    red[0][il][o] = pb4; red[1][il][o] = pb1; red[2][il][o] = pw2; red[3][il][o] = pb2;
+    if (d_o4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) slpw[(kg * 4 + j) * 32 + o] = accpw[j];
+    }
+    red[0][il][o] = pb4; red[1][il][o] = pb1; red[2][il][o] = pw2; red[3][il][o] = pb2; red[4][il][o] = pbpw;
     __syncthreads();
     if (il == 0) {
         float s4 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
@@ -207,6 +246,12 @@ __device__ __forceinline__ void head_bwd_body(int n, int base, const float* __re
         sl[8192 + 32 + 1024 + o] = s1;
         sl[8192 + 32 + 1024 + 32 + o] = s2;
         if (o == 0) sl[8192 + 32 + 1024 + 32 + 32] = sb;
+        if (d_o4) {   // bias gradient of dec_model.4
+            float sp = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sp += red[4][i][o];
+            slpw[1024 + o] = sp;
+        }
     }
     __syncthreads();
 }
@@ -215,10 +260,12 @@ __global__ void __launch_bounds__(256) head_bwd_kernel(int n, const float* e3, c
                                                        const float* pred, const float* dpred, const float* d_e4_extra,
                                                        const float* d_e3_extra, int n_extra, const float* w4,
                                                        const float* w1, const float* w2, cgs_dropout drop_in,
-                                                       cgs_dropout drop_h, float* d_e3, float* slab) {
+                                                       cgs_dropout drop_h, float* d_e3, float* slab, const float* d_o4,
+                                                       const float* wpw, float* slab_pw) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     head_bwd_body(n, blockIdx.x * HB_IPB, e3, e4, h1, pred, dpred, d_e4_extra, d_e3_extra, n_extra, w4, w1, w2, drop_in,
-                  drop_h, d_e3, slab + (size_t)blockIdx.x * HB_SLAB, (float*)smem);
+                  drop_h, d_e3, slab + (size_t)blockIdx.x * HB_SLAB, d_o4, wpw,
+                  slab_pw ? slab_pw + (size_t)blockIdx.x * (32 * 32 + 32) : nullptr, (float*)smem);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -148,10 +148,17 @@ class HourglassEngine:
         A = self.ab[n:]
         B = self.ab[:n]
         # critic on [B | A]
-        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n))
+        # (the decoder's bottleneck 1x1 conv rides along with the critic head kernel: o4 for all 2n images, A's half used)
+        if getattr(self, "_o4_full", None) is None:
+            self._o4_full = torch.empty((2 * n, 32), device=self.dev, dtype=torch.float32)
+            self.mbuf["o4"] = self._o4_full[n:]
+        fm_ptr = self.fm.data_ptr()
+        pw = (C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")), C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")),
+              self._o4_full)
+        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n), pw=pw)
         sa = self._cview(n, 2 * n)
         embeds = [sa[f"e{i}"] for i in range(5)]
-        hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf)
+        hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf, o4_done=True)
         _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
         hg.critic_forward(self.fc, self.lc, self.mixed[:nmix], nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
@@ -173,10 +180,15 @@ class HourglassEngine:
         _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), _P(self.dmixed), int(self.inject),
                   self.L1 / nz, self.L2 / nz, _P(self.dzpre), _S())
         pm = hg.SlabPlan()
-        d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side)
+        # live: the 1x1 bottleneck conv's backward runs inside the critic head kernel (frozen: no critic backward on A,
+        # the masker does it itself)
+        d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side,
+                                   pw_in_head=self.live)
         if self.live:
+            d_o4, d_emb[4] = d_emb[4], None
             hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
-                               n_add=n, ws=self._ws["cb_a"], side=self.side)
+                               n_add=n, ws=self._ws["cb_a"], side=self.side,
+                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
         self.side.join()
         if first:
             full = hg.SlabPlan()
@@ -278,8 +290,12 @@ class HourglassEngine:
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
         Returns (pred [b], Z [b,64,64] or None)."""
         b = X.shape[0]
-        c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b)
         if not want_mask:
-            return c["pred"], None
-        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b)
+            return hg.critic_forward(self.fc, self.lc, X.contiguous(), b)["pred"], None
+        o4 = torch.empty((b, 32), device=X.device, dtype=torch.float32)
+        fm_ptr = self.fm.data_ptr()
+        c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b,
+                              pw=(C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")),
+                                  C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")), o4))
+        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b, out={"o4": o4}, o4_done=True)
         return c["pred"], m["Z"]

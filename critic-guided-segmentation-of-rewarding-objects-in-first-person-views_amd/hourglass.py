@@ -130,9 +130,10 @@ class SlabPlan:
 # critic
 # ------------------------------------------------------------------------------------------------
 def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, drop: DropState = NO_DROP,
-                   out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                   out: Optional[Dict[str, torch.Tensor]] = None, pw=None) -> Dict[str, torch.Tensor]:
     """x: NHWC uint8 or NHWC fp32 [n,64,64,3].  Returns pooled embeds e0..e3 (pre-dropout), their argmax
-    masks am0..am3, e4 [n,32], h1 [n,32], pred [n].  ``out`` may hold preallocated views to fill."""
+    masks am0..am3, e4 [n,32], h1 [n,32], pred [n].  ``out`` may hold preallocated views to fill.
+    pw = (w_ptr, b_ptr, o4[n,32]): also emit the decoder's bottleneck 1x1 conv of e4 (dec_model.4) from the head kernel."""
     u8 = x.dtype == torch.uint8
     _chk(x, torch.uint8 if u8 else torch.float32, "critic input")
     dev = x.device
@@ -157,7 +158,8 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
               C.c_void_p(fp + 4 * lay.off("features.14.bias")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
               C.c_void_p(fp + 4 * lay.off("crit.1.bias")), C.c_void_p(fp + 4 * lay.off("crit.4.weight")),
               C.c_void_p(fp + 4 * lay.off("crit.4.bias")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
-              _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _stream())
+              _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), pw[0] if pw else None, pw[1] if pw else None,
+              _p(pw[2]) if pw else None, _stream())
     return o
 
 
@@ -166,8 +168,9 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True) -> Optional[torch.Tensor]:
-    """Backward of critic_forward for images [0,n).  d_embeds = [dE0..dE4] gradients arriving at the embeds
+                    need_wgrad: bool = True, pw_bwd=None) -> Optional[torch.Tensor]:
+    """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
+    bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.  d_embeds = [dE0..dE4] gradients arriving at the embeds
     from the decoder (valid for images < n_add; their buffers are reused as the running totals).
     dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
     Weight-gradient slabs are registered in ``plan`` (dst offsets = this module's flat layout)."""
@@ -189,12 +192,18 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     nsl = lib.cgs_head_bwd_slabs(n)
     slab = buf("slab_head", (nsl, HEAD_SLAB))
     d_cur = buf("de3", (n, 4, 4, 16))
+    use_pw = pw_bwd is not None and has_add
+    slab_pw = buf("slab_head_pw", (nsl, PW_SLAB)) if use_pw else None
+    de4 = d_embeds[4] if has_add else None
     _lib.call("cgs_head_bwd", n, _p(saved["e3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
-              _p(d_embeds[4]) if has_add else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
+              _p(de4) if (has_add and de4 is not None) else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
               C.c_void_p(fp + 4 * lay.off("features.14.weight")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
               C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
-              _p(d_cur), _p(slab), _stream())
+              _p(d_cur), _p(slab), _p(pw_bwd[0]) if use_pw else None, pw_bwd[1] if use_pw else None,
+              _p(slab_pw) if use_pw else None, _stream())
     plan.add(slab, nsl, HEAD_SLAB, lay.off("features.14.weight"))
+    if use_pw:
+        pw_bwd[2].add(slab_pw, nsl, PW_SLAB, pw_bwd[3])
     for i in (3, 2, 1, 0):
         key, hw, ca, cb, co, ups, act, pool, site = ENC_LAYERS[i]
         src = x if i == 0 else saved[f"e{i - 1}"]
@@ -239,17 +248,21 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
 # masker (decoder + mask head)
 # ------------------------------------------------------------------------------------------------
 def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
-                   out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                   out: Optional[Dict[str, torch.Tensor]] = None, o4_done: bool = False) -> Dict[str, torch.Tensor]:
     """x: NHWC uint8/fp32 image [n,64,64,3]; embeds = [e0,e1,e2,e3 (NHWC), e4 [n,32]].
-    Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64]."""
+    Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64].  o4_done: out['o4'] was already produced by the critic's
+    head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
     o = out if out is not None else {}
-    if o.get("o4") is None:
-        o["o4"] = torch.empty((n, 32), device=dev, dtype=torch.float32)
-    _lib.call("cgs_pointwise_fwd", n, 32, 32, _p(embeds[4]), C.c_void_p(fp + 4 * lay.off("dec_model.4.weight")),
-              C.c_void_p(fp + 4 * lay.off("dec_model.4.bias")), _p(o["o4"]), _stream())
+    if o4_done:
+        assert o.get("o4") is not None, "o4_done: the caller's head kernel already produced out['o4']"
+    else:
+        if o.get("o4") is None:
+            o["o4"] = torch.empty((n, 32), device=dev, dtype=torch.float32)
+        _lib.call("cgs_pointwise_fwd", n, 32, 32, _p(embeds[4]), C.c_void_p(fp + 4 * lay.off("dec_model.4.weight")),
+                  C.c_void_p(fp + 4 * lay.off("dec_model.4.bias")), _p(o["o4"]), _stream())
     names = ("o3", "o2", "o1", "o0", "hm", "Z")
     srcs_a = (embeds[3], embeds[2], embeds[1], embeds[0], x, None)
     prev = o["o4"]
@@ -268,9 +281,12 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
 
 def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
                     saved: Dict[str, torch.Tensor], dzpre: torch.Tensor, plan: SlabPlan,
-                    ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None) -> List[torch.Tensor]:
+                    ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
+                    pw_in_head: bool = False) -> List[torch.Tensor]:
     """dzpre: gradient w.r.t. the mask head's PRE-sigmoid output [n,64,64].
-    Returns [dE0, dE1, dE2, dE3, dE4]: gradients w.r.t. the encoder embeds (skip connections)."""
+    Returns [dE0, dE1, dE2, dE3, dE4]: gradients w.r.t. the encoder embeds (skip connections).
+    pw_in_head: stop at the bottleneck -- the 5th entry is then d o4 [n,32] (gradient w.r.t. the 1x1 conv's OUTPUT) and
+    the caller hands it to critic_backward(..., pw_bwd=...), whose head kernel runs the 1x1 conv's backward."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
@@ -367,6 +383,9 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
             d_embeds[ei] = de
             dy = db
     # bottleneck 1x1 conv: dy = d o4 [n,32]
+    if pw_in_head:
+        d_embeds[4] = dy
+        return d_embeds
     nsl = lib.cgs_pointwise_bwd_slabs(n)
     slab = buf("slab_pw", (nsl, PW_SLAB))
     de4 = buf("dE4", (n, 32))

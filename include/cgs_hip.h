@@ -143,20 +143,28 @@ int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_coun
  *   w4     : [256][32]  (k = (y*4+x)*16 + c, HWIO of features.14), b4 [32]
  *   w1     : [32][32]   (k-major: crit.1.weight transposed), b1 [32];  w2 [32], b2 [1]
  *   e4     : [n,32] post-ReLU bottleneck (embeds[4]);  h1 : [n,32] post-ReLU hidden (pre-dropout)
- *   pred   : [n] sigmoid output.                                                            */
+ *   pred   : [n] sigmoid output.
+ *   o4     : optional [n,32] = the DECODER's bottleneck 1x1 conv of e4 (nets.py:501, weights w_pw [32][32] k-major and
+ *            b_pw [32] of dec_model.4) computed from the e4 row while it is on chip; NULL: not computed
+ *            (cgs_pointwise_fwd is the stand-alone form).                                     */
 int cgs_head_fwd(int32_t n, const float* e3, const float* w4, const float* b4, const float* w1,
                  const float* b1, const float* w2, const float* b2, cgs_dropout drop_in,
-                 cgs_dropout drop_h, float* e4, float* h1, float* pred, cgs_stream_t stream);
+                 cgs_dropout drop_h, float* e4, float* h1, float* pred, const float* w_pw,
+                 const float* b_pw, float* o4, cgs_stream_t stream);
 /* Backward of the head.  dpred [n]; d_e4_extra / d_e3_extra: optional [n_extra,32] / [n_extra,4,4,16]
  * gradients arriving at e4 / e3 from the decoder (images < n_extra; d_e3_extra may alias d_e3).
  * Writes d_e3 [n,4,4,16] = head gradient (dropout mask applied) + d_e3_extra, and one slab per
- * workgroup: [w4 8192 | b4 32 | w1 1024 | b1 32 | w2 32 | b2 1] = 9313 floats.               */
+ * workgroup: [w4 8192 | b4 32 | w1 1024 | b1 32 | w2 32 | b2 1] = 9313 floats.
+ * d_o4 (optional, [n_extra,32]): gradient w.r.t. the decoder bottleneck output o4 instead of (or besides)
+ * d_e4_extra: the 1x1 conv's backward runs here too (d e4 += W_pw d_o4) and its weight/bias gradient goes to
+ * slab_pw [cgs_head_bwd_slabs(n)][1056] (layout of cgs_pointwise_bwd's slab).                 */
 int cgs_head_bwd_slabs(int32_t n);
 int cgs_head_bwd(int32_t n, const float* e3, const float* e4, const float* h1, const float* pred,
                  const float* dpred, const float* d_e4_extra, const float* d_e3_extra, int32_t n_extra,
                  const float* w4,
                  const float* w1, const float* w2, cgs_dropout drop_in, cgs_dropout drop_h,
-                 float* d_e3, float* slab, cgs_stream_t stream);
+                 float* d_e3, float* slab, const float* d_o4, const float* w_pw, float* slab_pw,
+                 cgs_stream_t stream);
 
 /* ---- decoder 1x1 conv on the bottleneck (nets.py:484,501) --------------------------
  *   y[n][o] = sum_k x[n][k] * w[k][o] + b[o],  32 -> 32 (MFMA v_mfma_f32_32x32x2_f32).      */

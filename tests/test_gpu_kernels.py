@@ -271,7 +271,7 @@ def test_empty_batch_and_bad_arguments(ctx):
     p = C.c_void_p(buf.data_ptr())
     d0 = _lib.ConvDesc(0, 64, 64, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
     assert lib.cgs_conv3x3_fwd(C.byref(d0), p, None, p, p, p, None, st) == _lib.OK
-    assert lib.cgs_head_fwd(0, p, p, p, p, p, p, p, _lib.Dropout(), _lib.Dropout(), p, p, p, st) == _lib.OK
+    assert lib.cgs_head_fwd(0, p, p, p, p, p, p, p, _lib.Dropout(), _lib.Dropout(), p, p, p, None, None, None, st) == _lib.OK
     bad = _lib.ConvDesc(4, 48, 48, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
     assert lib.cgs_conv3x3_fwd(C.byref(bad), p, None, p, p, p, None, st) == _lib.ERR_UNSUPPORTED
     ok = _lib.ConvDesc(4, 64, 64, 3, 0, 8, _lib.SRC_U8, 2, _lib.ACT_RELU, 1, _lib.Dropout())
