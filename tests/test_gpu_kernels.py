@@ -372,3 +372,55 @@ def test_mask_head_backward_vs_torch_fp32(ctx, n, u8):
     # argument errors are return codes, not faults
     assert lib.cgs_mask_head_bwd(n, kind, None, None, P(dzd), P(hd), w2p, w0p, None, P(do0), P(slab2), P(slab0), st) < 0
     assert lib.cgs_mask_head_bwd(n, 7, P(xd), P(o0d), P(dzd), P(hd), w2p, w0p, None, P(do0), P(slab2), P(slab0), st) < 0
+
+
+def test_bottleneck_conv_inside_head_kernels_equals_standalone(ctx):
+    """cgs_head_fwd(..., w_pw, b_pw, o4) == cgs_pointwise_fwd on its e4, and cgs_head_bwd(..., d_o4, w_pw, slab_pw) ==
+    cgs_pointwise_bwd followed by cgs_head_bwd(d_e4_extra = its dx): same d_e3, same head slab, same dec_model.4 gradient."""
+    from cgs_amd import _lib
+    from cgs_amd.hourglass import HEAD_SLAB, PW_SLAB
+    import ctypes as C
+    dev, lc, lm, fc, fm = ctx["dev"], ctx["lc"], ctx["lm"], ctx["fc"], ctx["fm"]
+    lib = _lib.load()
+    n, n_extra = 21, 13
+    rs = np.random.RandomState(77)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(dev)
+    e3 = T(np.maximum(rs.randn(n, 4, 4, 16), 0))
+    P = lambda t: C.c_void_p(t.data_ptr())
+    wc = lambda k: C.c_void_p(fc.data_ptr() + 4 * lc.off(k))
+    wm = lambda k: C.c_void_p(fm.data_ptr() + 4 * lm.off(k))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nd = _lib.Dropout()
+    mk = lambda *s: torch.full(s, float("nan"), device=dev)
+    e4, h1, pred, o4 = mk(n, 32), mk(n, 32), mk(n), mk(n, 32)
+    _lib.call("cgs_head_fwd", n, P(e3), wc("features.14.weight"), wc("features.14.bias"), wc("crit.1.weight"), wc("crit.1.bias"),
+              wc("crit.4.weight"), wc("crit.4.bias"), nd, nd, P(e4), P(h1), P(pred), wm("dec_model.4.weight"),
+              wm("dec_model.4.bias"), P(o4), st)
+    o4_ref = mk(n, 32)
+    _lib.call("cgs_pointwise_fwd", n, 32, 32, P(e4), wm("dec_model.4.weight"), wm("dec_model.4.bias"), P(o4_ref), st)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(o4.cpu().numpy(), o4_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # backward
+    dpred = T(rs.randn(n) * 0.1)
+    d_o4 = T(rs.randn(n_extra, 32) * 0.1)
+    d_e3x = T(rs.randn(n_extra, 4, 4, 16) * 0.1)
+    nsl = lib.cgs_head_bwd_slabs(n)
+    # (a) stand-alone 1x1 backward, then the head with d_e4_extra
+    nsp = lib.cgs_pointwise_bwd_slabs(n_extra)
+    dx, slab_pw_a = mk(n_extra, 32), mk(nsp, PW_SLAB)
+    _lib.call("cgs_pointwise_bwd", n_extra, 32, 32, P(e4), P(d_o4), wm("dec_model.4.weight"), P(dx), P(slab_pw_a), st)
+    de3_a, slab_a = mk(n, 4, 4, 16), mk(nsl, HEAD_SLAB)
+    _lib.call("cgs_head_bwd", n, P(e3), P(e4), P(h1), P(pred), P(dpred), P(dx), P(d_e3x), n_extra, wc("features.14.weight"),
+              wc("crit.1.weight"), wc("crit.4.weight"), nd, nd, P(de3_a), P(slab_a), None, None, None, st)
+    # (b) everything in the head kernel
+    de3_b, slab_b, slab_pw_b = mk(n, 4, 4, 16), mk(nsl, HEAD_SLAB), mk(nsl, PW_SLAB)
+    _lib.call("cgs_head_bwd", n, P(e3), P(e4), P(h1), P(pred), P(dpred), None, P(d_e3x), n_extra, wc("features.14.weight"),
+              wc("crit.1.weight"), wc("crit.4.weight"), nd, nd, P(de3_b), P(slab_b), P(d_o4), wm("dec_model.4.weight"),
+              P(slab_pw_b), st)
+    torch.cuda.synchronize()
+    rel_close(de3_b.cpu().numpy(), de3_a.cpu().numpy(), "d e3", rtol=1e-4)
+    rel_close(slab_b.sum(0).cpu().numpy(), slab_a.sum(0).cpu().numpy(), "head slab", rtol=1e-4)
+    rel_close(slab_pw_b.sum(0).cpu().numpy(), slab_pw_a.sum(0).cpu().numpy(), "dec_model.4 slab", rtol=1e-4)
+    # argument errors are return codes
+    assert lib.cgs_head_bwd(n, P(e3), P(e4), P(h1), P(pred), P(dpred), None, None, 0, wc("features.14.weight"), wc("crit.1.weight"),
+                            wc("crit.4.weight"), nd, nd, P(de3_b), P(slab_b), P(d_o4), None, None, st) < 0
