@@ -167,33 +167,40 @@ __global__ void __launch_bounds__(256) phase1_loss_kernel(int n, const float* __
     if (threadIdx.x == 0) losses[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n;
 }
 
-// grid = (ceil(max_count/16), njobs); block = 16 columns x 16 slab lanes, 8 independent partial sums per thread
-// (the slabs were just written, so they are L2-resident: the kernel is latency-bound and wants loads in flight).
-__global__ void __launch_bounds__(256) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
-    __shared__ float red[16][17];
+// grid = (ceil(max_count/32), njobs); block = 32 columns (one 128-byte line per slab row) x 32 slab lanes, up to 16
+// independent partial sums per thread in flight.  The longest job (2048 slabs) sets the kernel's duration: 64 rows per
+// thread = 4 rounds of loads.
+__global__ void __launch_bounds__(1024) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
+    constexpr int SL = 32;
+    __shared__ float red[SL][33];
     const cgs_reduce_job j = jobs[blockIdx.y];
     if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
-    if (blockIdx.x * 16 >= j.count) return;
-    const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + col;
-    float s[8];
+    if (blockIdx.x * 32 >= j.count) return;
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    float s[16];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int u = 0; u < 16; ++u) s[u] = 0.f;
     if (i < j.count) {
         const float* p = j.slab + i;
         int b = sl;
-        for (; b + 7 * 16 < j.nslab; b += 8 * 16) {
+        for (; b + 15 * SL < j.nslab; b += 16 * SL) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += p[(size_t)(b + u * 16) * j.stride];
+            for (int u = 0; u < 16; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
         }
-        for (; b < j.nslab; b += 16) s[0] += p[(size_t)b * j.stride];
+        for (; b + 3 * SL < j.nslab; b += 4 * SL) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
+        }
+        for (; b < j.nslab; b += SL) s[0] += p[(size_t)b * j.stride];
     }
-    red[sl][col] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[sl][col] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+                   (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
     __syncthreads();
     if (sl == 0 && i < j.count) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][col];
+        for (int k = 0; k < SL; ++k) t += red[k][col];
         j.dst[i] = j.accumulate ? j.dst[i] + t : t;
     }
 }
@@ -293,7 +300,7 @@ extern "C" int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int
 extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step,
                                 cgs_stream_t stream) {
     if (!jobs || njobs <= 0 || max_count <= 0) return CGS_ERR_BADARG;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 15) / 16, njobs), dim3(256), 0, (hipStream_t)stream, jobs, step);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 31) / 32, njobs), dim3(1024), 0, (hipStream_t)stream, jobs, step);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

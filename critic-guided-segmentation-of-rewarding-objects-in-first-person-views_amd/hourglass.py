@@ -113,17 +113,25 @@ class SlabPlan:
         self.jobs.append((slab, nslab, count, dst_off))
 
     def build(self, grad_flat: torch.Tensor, accumulate: bool = False):
-        arr = (_lib.ReduceJob * len(self.jobs))()
-        for i, (slab, nslab, count, off) in enumerate(self.jobs):
-            arr[i] = _lib.ReduceJob(slab.data_ptr(), grad_flat.data_ptr() + 4 * off, nslab, count, count, int(accumulate))
+        # The launch is a (max columns / 32) x (jobs) grid: wide slabs are cut into column chunks (same row stride) so that
+        # every job fills its share of the grid instead of most workgroups exiting at once.
+        CH = 1024
+        rows = []
+        for slab, nslab, count, off in self.jobs:
+            for c0 in range(0, count, CH):
+                rows.append((slab.data_ptr() + 4 * c0, grad_flat.data_ptr() + 4 * (off + c0), nslab, count, min(CH, count - c0)))
+        arr = (_lib.ReduceJob * len(rows))()
+        for i, (sp, dp, nslab, stride, cnt) in enumerate(rows):
+            arr[i] = _lib.ReduceJob(sp, dp, nslab, stride, cnt, int(accumulate))
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         self._table = host.to(grad_flat.device)
         self._keep = grad_flat
-        self._max = max(j[2] for j in self.jobs)
+        self._njobs = len(rows)
+        self._max = max(r[4] for r in rows)
         return self
 
     def run(self, step: Optional[torch.Tensor] = None):
-        _lib.call("cgs_reduce_slabs", _p(self._table), len(self.jobs), self._max, _p(step), _stream())
+        _lib.call("cgs_reduce_slabs", _p(self._table), self._njobs, self._max, _p(step), _stream())
 
 
 # ------------------------------------------------------------------------------------------------
