@@ -28,7 +28,7 @@ struct WMask0U8x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC =
 struct WMask0F32x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_F32, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
 
 static constexpr int kMaxBothWgradBlocks = 256;
-static constexpr int kMaxBothWgradBlocksBig = 1024;
+static constexpr int kMaxBothWgradBlocksBig = 512;
 
 template <class CWG>
 static int both_slabs(int n) {

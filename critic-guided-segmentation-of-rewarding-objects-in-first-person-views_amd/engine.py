@@ -114,16 +114,18 @@ class HourglassEngine:
         lib = _lib.load()
         out1, out2 = {}, {}
         nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
-        specs = [("slab_head", lambda n: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
+        specs = [("slab_head", lambda n, first: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
         for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
-            def f(n, i=i, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
+            def f(n, first, i=i, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
                 d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
-                if i in hg.BOTH_ENC and i > 0:
+                # mirrors critic_backward: features.0 shares a launch with its data gradient only in the first pass
+                # (fp32 mixes, image gradient wanted); the second pass reads uint8 frames and needs no image gradient
+                if i in hg.BOTH_ENC and (i > 0 or first):
                     return lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
                 return lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
             specs.append((f"slab_enc{i}", f, 9 * ca * co + co))
         for name, fn, cnt in specs:
-            a, b = (fn(n_first) if n_first else 0), (fn(n_second) if n_second else 0)
+            a, b = (fn(n_first, True) if n_first else 0), (fn(n_second, False) if n_second else 0)
             big = torch.zeros((a + b, cnt), device=self.dev)
             self._ws.setdefault("slabs_" + tag, []).append(big)
             out1[name], out2[name] = big[:a], big[a:]
