@@ -284,6 +284,193 @@ __global__ void __launch_bounds__(256) mask0_fwd_kernel(Mask0FwdParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Inference form of the whole mask head (nets.py:488-491, eval): masker.0 as above, but its output h (16 channels at
+// 64x64, the largest activation of the network) goes to an LDS tile instead of memory, and masker.2 (conv 16 -> 1 + sigmoid)
+// runs on that tile in the same workgroup.  h is needed only by the backward pass, so `-process` / `-eval` / infer() never
+// write or re-read its 134 MB per 512 images.  A strip of 8 mask rows needs 10 rows of h (one halo row each side,
+// recomputed by the neighbours): 25 % more MFMAs against two full passes over h saved.
+// ------------------------------------------------------------------------------------------------
+struct MaskInferParams {
+    const void* img; const float* o0; const float* w0; const float* b0; const float* w2; const float* b2; float* z;
+    int n, ntiles;
+};
+
+struct MaskInferGeo {
+    static constexpr int H = 64, W = 64, TH = 8, STRIPS = H / TH, HR = TH + 2;       // h rows per tile
+    static constexpr int IR = TH + 4, IC = W + 2, IPS = 5;                            // image tile
+    static constexpr int LR = TH / 2 + 4, LC = W / 2 + 2, LPS = 10;                   // o0 tile
+    static constexpr int HPS = 20;                                                    // h pixel stride: conflict-free float4 reads
+    static constexpr int XIMG = IR * IC * IPS, XO = LR * LC * LPS, HS = HR * IC * HPS, W2S = 144;
+    static constexpr size_t LDS = (size_t)((XIMG + 3) / 4 * 4 + XO + HS + W2S) * 4;
+};
+
+template <int SRC>
+__global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
+    using G = MaskInferGeo;
+    constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, IPS = G::IPS, LR = G::LR, LC = G::LC,
+                  LPS = G::LPS, HPS = G::HPS;
+    constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    float* ximg = (float*)smem;
+    float* xo = ximg + (G::XIMG + 3) / 4 * 4;
+    float* hs = xo + G::XO;            // [HR][IC][HPS]: h rows row0-1 .. row0+8, columns -1 .. 64
+    float* w2s = hs + G::HS;           // masker.2 weights [9][16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int hf = wave & 1, par = wave >> 1;   // this wave: columns 32*hf .. +31 of the h rows j = par, par+2, .. (5 rows)
+    const int py = (par + 1) & 1;               // row parity of those rows (row0 is even, h row j is image row row0-1+j)
+
+    // ---- masker.0 weights -> registers (B operand: k = kq, n = l15 = oc), for this wave's row parity ----
+    float wimg[9], wo[2][2][2][2];     // [px][a][b][s]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wimg[t] = (kq < 3) ? P.w0[(t * 11 + kq) * 16 + l15] : 0.f;
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int s4 = 0; s4 < 2; ++s4) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                            const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                            const float w = P.w0[((ky * 3 + kx) * 11 + 3 + 4 * s4 + kq) * 16 + l15];
+                            v += (iny && inx) ? w : 0.f;
+                        }
+                    wo[px][a][b][s4] = v;
+                }
+    const float bias0 = P.b0[l15], bias2 = P.b2[0];
+    if (tid < 144) w2s[tid] = P.w2[tid];
+    for (int e = tid; e < HR * 2 * 16; e += 256) {      // zero halo columns of the h tile (never written again)
+        int ch = e & 15, side = (e >> 4) & 1, r = e >> 5;
+        hs[(r * IC + (side ? IC - 1 : 0)) * HPS + ch] = 0.f;
+    }
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        // ---- input tiles -> LDS: image rows row0-2 .. row0+9, o0 rows row0/2-2 .. row0/2+5 ----
+        for_elems<NIMG, 256>(tid, [&](int e) {
+            int r = e / IC, c = e % IC;
+            int y = row0 + r - 2, x = c - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            int pix = in ? (n0 * H + y) * W + x : 0;
+            float v0, v1, v2;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
+                uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
+                const float sc = 1.f / 255.f;
+                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+            } else {
+                const float* sf = (const float*)P.img;
+                v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
+            }
+            float* d = ximg + e * IPS;
+            d[0] = in ? v0 : 0.f; d[1] = in ? v1 : 0.f; d[2] = in ? v2 : 0.f; d[3] = 0.f;
+        });
+        for_elems<NLO, 256>(tid, [&](int e) {
+            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 2, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            float4 v = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+            v = in ? v : f4zero();
+            float2* d = (float2*)(xo + (pr * LC + pc) * LPS + 4 * half);
+            d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+        });
+        __syncthreads();
+
+        // ---- masker.0 on the matrix cores into the h tile: 5 rows x 2 column parities per wave ----
+        // h row j = par + 2*jj: image tile row of tap ky = j + ky;  o0 tile row of fold a = jj + a + 1 (see derivation in
+        // the header: (y>>1) + a - (1-py) relative to the tile's first low-res row, identical for both row parities)
+        const int ibase = (par * IC + 2 * (16 * hf + l15)) * IPS + kq;     // + ((2*jj + ky)*IC + px + kx)*IPS
+        const int obase = (16 * hf + l15) * LPS + kq;                      // + ((jj + a + 1)*LC + px + b)*LPS + 4*s
+        float ai[2][9], ao[2][8];
+        auto ld = [&](int t, int buf) {         // MFMA tile t: row jj = t>>1, column parity px = t&1
+            const int jj = t >> 1, px = t & 1;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) ai[buf][k] = ximg[ibase + ((2 * jj + k / 3) * IC + px + k % 3) * IPS];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = q >> 2, b = (q >> 1) & 1, s4 = q & 1;
+                ao[buf][q] = xo[obase + ((jj + a + 1) * LC + px + b) * LPS + 4 * s4];
+            }
+        };
+        ld(0, 0);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            if (t + 1 < 10) ld(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int jj = t >> 1, px = t & 1;
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[t & 1][k], wimg[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[t & 1][q], wo[px][q >> 2][(q >> 1) & 1][q & 1], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // D[row = 4kq + i (pixel)][col = l15 (oc)] -> h tile; rows outside the image are masker.2's ZERO padding
+            const int j = par + 2 * jj, y = row0 - 1 + j;
+            const float keep = (y >= 0 && y < H) ? 1.f : 0.f;
+            float* hrow = hs + (j * IC + 1 + 2 * (16 * hf + 4 * kq) + px) * HPS + l15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hrow[2 * i * HPS] = keep * act_fwd<CGS_ACT_LRELU>(acc[i] + bias0);
+        }
+        __syncthreads();
+
+        // ---- masker.2 + sigmoid on the tile: thread = pixels (yl, x) and (yl+4, x) ----
+        {
+            const int x = tid & 63, yl0 = tid >> 6;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                const int yl = yl0 + 4 * rep;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4* hp = (const float4*)(hs + ((yl + t / 3) * IC + x + t % 3) * HPS);
+                    const auto* wp = cgs_to_const(P.w2) + t * 16;     // wave-uniform: scalar loads, SGPR operands
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float4 hv = hp[c4];
+                        a0 = fmaf(hv.x, wp[4 * c4], a0); a1 = fmaf(hv.y, wp[4 * c4 + 1], a1);
+                        a2 = fmaf(hv.z, wp[4 * c4 + 2], a2); a3 = fmaf(hv.w, wp[4 * c4 + 3], a3);
+                    }
+                    if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // at most one row of taps of operands in flight
+                }
+                const float zpre = ((a0 + a1) + (a2 + a3)) + bias2;
+                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = 1.f / (1.f + expf(-zpre));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
+                      const float* b2, float* z, hipStream_t st) {
+    if (n <= 0) return CGS_OK;
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS};
+    int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
+    if (img_kind == CGS_SRC_U8) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_infer_kernel<WSRC_U8>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)MaskInferGeo::LDS);
+        if (attr != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL(mask_infer_kernel<WSRC_U8>, dim3(blocks), dim3(256), MaskInferGeo::LDS, st, P);
+    } else {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_infer_kernel<WSRC_F32>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)MaskInferGeo::LDS);
+        if (attr != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL(mask_infer_kernel<WSRC_F32>, dim3(blocks), dim3(256), MaskInferGeo::LDS, st, P);
+    }
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 template <int SRC>
 static int launch_mask0_fwd(Mask0FwdParams P, hipStream_t st) {
     if (P.n <= 0) return CGS_OK;

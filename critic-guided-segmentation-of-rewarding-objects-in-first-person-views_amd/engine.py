@@ -299,5 +299,6 @@ class HourglassEngine:
         c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b,
                               pw=(C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")),
                                   C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")), o4))
-        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b, out={"o4": o4}, o4_done=True)
+        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b, out={"o4": o4}, o4_done=True,
+                              keep_hm=False)
         return c["pred"], m["Z"]

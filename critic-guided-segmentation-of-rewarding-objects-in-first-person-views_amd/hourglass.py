@@ -20,6 +20,7 @@ _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "
 HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
 # small layers: weight- and data-gradient halves share one launch (csrc/conv_bwd_both.hip)
 BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
+MASK_INFER_FUSED = os.environ.get("CGS_MASK_INFER_FUSED", "1") != "0"   # inference: masker.0 + masker.2 in one kernel
 MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
 _both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
@@ -256,10 +257,12 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
 # masker (decoder + mask head)
 # ------------------------------------------------------------------------------------------------
 def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
-                   out: Optional[Dict[str, torch.Tensor]] = None, o4_done: bool = False) -> Dict[str, torch.Tensor]:
+                   out: Optional[Dict[str, torch.Tensor]] = None, o4_done: bool = False,
+                   keep_hm: bool = True) -> Dict[str, torch.Tensor]:
     """x: NHWC uint8/fp32 image [n,64,64,3]; embeds = [e0,e1,e2,e3 (NHWC), e4 [n,32]].
     Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64].  o4_done: out['o4'] was already produced by the critic's
-    head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv."""
+    head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv.  keep_hm=False (inference): the 16-channel
+    masker.0 output is not needed afterwards -- masker.0 and masker.2 run as one kernel and 'hm' is never stored."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
@@ -275,6 +278,19 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     srcs_a = (embeds[3], embeds[2], embeds[1], embeds[0], x, None)
     prev = o["o4"]
     for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
+        if name == "hm" and not keep_hm and MASK_INFER_FUSED:
+            if o.get("Z") is None:
+                o["Z"] = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
+            rc = _lib.load().cgs_mask_infer_fwd(n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
+                                                C.c_void_p(fp + 4 * lay.off("masker.0.weight")),
+                                                C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
+                                                C.c_void_p(fp + 4 * lay.off("masker.2.weight")),
+                                                C.c_void_p(fp + 4 * lay.off("masker.2.bias")), _p(o["Z"]), _stream())
+            if rc == 0:
+                return o
+            if rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cgs_mask_infer_fwd")
+            # unsupported in this build: fall through to the two-kernel form
         shape = (n, hw, hw) if co == 1 else (n, hw, hw, co)
         if o.get(name) is None:
             o[name] = torch.empty(shape, device=dev, dtype=torch.float32)

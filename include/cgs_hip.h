@@ -106,6 +106,15 @@ int cgs_mask_head_bwd(int32_t n, int32_t src_a, const void* x, const float* o0, 
                       const float* w_m2_hwio, const float* w_m0_hwio, float* d_h, float* d_o0, float* slab_m2,
                       float* slab_m0, cgs_stream_t stream);
 
+/* ---- mask head forward for inference (nets.py:488-491 in eval mode) in one pass -----------------------
+ * z [n,64,64] = sigmoid(conv3x3(LeakyReLU(conv3x3(cat(x, up(o0)); w_m0, b_m0)); w_m2, b_m2)) without ever storing the
+ * 16-channel intermediate (it is needed only by the backward pass): masker.0 on the matrix cores into an LDS tile,
+ * masker.2 + sigmoid on that tile.  x [n,64,64,3] of kind src_a (CGS_SRC_U8 / CGS_SRC_F32), o0 [n,32,32,8].
+ * Returns CGS_ERR_UNSUPPORTED in the VALU fallback build (use two cgs_conv3x3_fwd calls).                       */
+int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
+                       const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
+                       cgs_stream_t stream);
+
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
  *   slab[b][0 .. 9*(ca+cb)*co)  = partial dW (HWIO),  slab[b][9*(ca+cb)*co ..][co] = partial dbias

@@ -424,3 +424,30 @@ def test_bottleneck_conv_inside_head_kernels_equals_standalone(ctx):
     # argument errors are return codes
     assert lib.cgs_head_bwd(n, P(e3), P(e4), P(h1), P(pred), P(dpred), None, None, 0, wc("features.14.weight"), wc("crit.1.weight"),
                             wc("crit.4.weight"), nd, nd, P(de3_b), P(slab_b), P(d_o4), None, None, st) < 0
+
+
+@pytest.mark.parametrize("n,u8", [(5, True), (37, False)])
+def test_fused_inference_mask_head_matches_oracle_and_two_kernel_form(ctx, n, u8):
+    """cgs_mask_infer_fwd (masker.0 into an LDS tile + masker.2 + sigmoid, the 16-channel intermediate never stored) vs the
+    oracle's masker and vs the two cgs_conv3x3_fwd launches of the training path."""
+    from cgs_amd import _lib
+    import ctypes as C
+    hg, dev, lm, fm = ctx["hg"], ctx["dev"], ctx["lm"], ctx["fm"]
+    lib = _lib.load()
+    x_u8 = np.random.RandomState(60 + n).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    X = orc.u8_to_nchw(x_u8)
+    with torch.no_grad():
+        _, embeds = orc.critic_apply(ctx["pc"], X, collect=True)
+        Z = orc.masker_apply(ctx["pm"], X, embeds)
+    xd = torch.from_numpy(x_u8).to(dev)
+    xin = xd if u8 else (xd.float() / 255.0).contiguous()
+    c = hg.critic_forward(ctx["fc"], ctx["lc"], xin, n)
+    emb = [c[f"e{i}"] for i in range(5)]
+    m2 = hg.masker_forward(fm, lm, xin, emb, n)                       # two-kernel form (keeps hm)
+    m1 = hg.masker_forward(fm, lm, xin, emb, n, keep_hm=False)        # one kernel
+    torch.cuda.synchronize()
+    assert "hm" not in m1 and "hm" in m2
+    rel_close(m1["Z"].cpu().numpy(), Z[:, 0].numpy(), "Z (fused inference)")
+    np.testing.assert_allclose(m1["Z"].cpu().numpy(), m2["Z"].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    p = C.c_void_p(xin.data_ptr())
+    assert lib.cgs_mask_infer_fwd(n, 7, p, p, p, p, p, p, p, C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
