@@ -286,6 +286,20 @@ class HourglassEngine:
             allred()
             g2.replay()
 
+    # ---- saliency baseline (main.py:941-953): |d mean(pred) / d X| summed over the colour channels ----------------
+    def saliency(self, X: torch.Tensor):
+        """Eval-mode critic forward + backward to the input.  X: NHWC fp32 [b,64,64,3] in [0,1] on the device.
+        Returns (pred [b], d mean(pred)/dX [b,64,64,3]); the caller takes abs().sum(channels) like the reference."""
+        b = X.shape[0]
+        X = X.contiguous()
+        if X.dtype != torch.float32:
+            raise _lib.CgsError("saliency needs the fp32 image batch (the gradient is taken w.r.t. it)")
+        c = hg.critic_forward(self.fc, self.lc, X, b)
+        dpred = torch.full((b,), 1.0 / b, device=X.device, dtype=torch.float32)      # pred.mean().backward()
+        dx = torch.empty((b, 64, 64, 3), device=X.device, dtype=torch.float32)
+        hg.critic_backward(self.fc, self.lc, X, b, c, dpred, hg.SlabPlan(), dx=dx, dx_from=0, need_wgrad=False)
+        return c["pred"], dx
+
     # ---- inference (main.py:1130-1151) -----------------------------------------------------------
     @torch.no_grad()
     def infer(self, X: torch.Tensor, want_mask: bool = True):

@@ -310,16 +310,19 @@ class Handler:
         """main.py:1265-1270: |A & B| / |A | B| over the whole set, rounded to 3 digits."""
         intersection = np.sum(A & B)
         union = np.sum(A | B)
-        return round(float(intersection / union), 3)
+        return round(float(intersection / union), 3) if union else float("nan")
 
     def eval(self, folder="", vis=False):
-        """main.py:891-1020 without its optional branches: masks of `red-trees/X.npy[100:5000:2]` (batch 128, eval
-        mode), thresholded at --eval-thresh, IoU against `all(Y.npy, axis=-1)`.  Returns [iou] like the reference."""
+        """main.py:891-1020 without CRF / videos: masks of `red-trees/X.npy[100:5000:2]` (batch 128, eval mode), thresholded
+        at --eval-thresh, IoU against `all(Y.npy, axis=-1)`; with -salience also the saliency baseline of main.py:941-953,
+        976-1003 (|d mean(pred)/dX| summed over channels, normalised, weighted by pred, thresholded) and its IoU.
+        Returns [iou] or [iou, saliou] like the reference."""
+        import sys as _sys
         args = self.args
         if args.noevalmode:
             raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
-        if args.salience or args.crf or args.resimages or folder or vis:
-            raise NotImplementedError("-salience / -crf / -resimages / folder / video evaluation are outside this build's scope")
+        if args.crf or args.resimages or folder or vis:
+            raise NotImplementedError("-crf / -resimages / folder / video evaluation are outside this build's scope")
         evaldatapath = "red-trees/"
         X = np.load(evaldatapath + "X.npy")                       # uint8 [n,64,64,3] (the reference divides by 255 here)
         Y = np.expand_dims(np.all(np.load(evaldatapath + "Y.npy"), axis=-1), axis=-1)
@@ -329,19 +332,37 @@ class Handler:
         self.masker.eval()
         eng = self._engine(2 * 32)
         batchsize = 128
-        M = []
+        M, salM, preds = [], [], []
         for bidx in range(0, len(X), batchsize):
             print("eval at", bidx / len(X), end="\r")
             xb = X[bidx:bidx + batchsize]
             batch = torch.from_numpy(np.ascontiguousarray(xb)).to(self.device)
-            if batch.dtype != torch.uint8:
-                batch = (batch.double() / 255.0).float()            # float data sets: main.py:921,939
-            _pred, Z = eng.infer(batch)
+            if batch.dtype != torch.uint8 or args.salience:
+                batch = (batch.double() / 255.0).float()            # main.py:921,939 (float64 / 255 -> float32)
+            if args.salience:
+                _p, dx = eng.saliency(batch)
+                salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
+            pred, Z = eng.infer(batch)
+            preds.append(pred.cpu().numpy())
             M.append(Z.cpu().numpy()[:, None])
         M = np.concatenate(M, axis=0)
+        preds = np.concatenate(preds, axis=0)
         hardM = M > args.eval_thresh
-        iou = self.get_iou(hardM.squeeze(), Y.transpose(0, 3, 1, 2).squeeze())
-        ious = [iou]
+        Yc = Y.transpose(0, 3, 1, 2)
+        ious = [self.get_iou(hardM.squeeze(), Yc.squeeze())]
+        if args.salience:
+            salM = np.concatenate(salM, axis=0)
+            thresh = args.salience_thresh
+            if args.salglobal:
+                norm = (salM * (salM >= 0)).mean() * thresh
+            else:
+                k = int(salM.shape[-1] * salM.shape[-2] * thresh)
+                norm = np.sort(salM.reshape(salM.shape[0], 1, -1), axis=-1)[:, :, k, None, None]
+            salM = salM / (norm + _sys.float_info.min)
+            salM = salM * preds[:, None, None, None]
+            salM[(salM >= 1)] = 1
+            salhardM = (salM > thresh).astype(np.uint8)
+            ious.append(self.get_iou(salhardM.squeeze(), Yc.squeeze()))
         print(f"\nRESULTS", ious)
         return ious
 

@@ -26,6 +26,7 @@ Reference lines restated (relative to /root/reference):
   infer_masks       main.py:1130-1151
   postprocess_masks main.py:1163-1167,1212-1223
   eval_iou          main.py:891-1020 (no salience / CRF), get_iou main.py:1265-1270
+  eval_saliency_iou main.py:941-953,976-1003,1010-1012 (the saliency baseline of -eval -salience)
 """
 from __future__ import annotations
 
@@ -343,3 +344,36 @@ def eval_iou(PC, PM, X_u8: np.ndarray, Y: np.ndarray, eval_thresh: float = 0.05,
     hardM = M > eval_thresh
     A, B = hardM.squeeze(), Ys.transpose(0, 3, 1, 2).squeeze()
     return round(float(np.sum(A & B) / np.sum(A | B)), 3)
+
+
+def eval_saliency_iou(PC, X_u8: np.ndarray, Y: np.ndarray, salience_thresh: float = 1.5, salglobal: bool = True,
+                      batchsize: int = 128):
+    """The saliency baseline of main.py:941-953, 976-1003, 1010-1012 (eval-mode critic, pred.mean().backward() per batch,
+    m = |grad|.sum(channels); normalise, weight by pred, clip at 1, threshold) on rows 100:5000:2.
+    Returns (saliou or nan, salM [n,1,64,64] after normalisation, raw |grad| maps)."""
+    import sys
+    Yb = np.expand_dims(np.all(Y, axis=-1), axis=-1)
+    Xs, Ys = X_u8[100:5000:2], Yb[100:5000:2]
+    sal, preds = [], []
+    for b in range(0, len(Xs), batchsize):
+        batch = u8_to_nchw(Xs[b:b + batchsize]).clone().requires_grad_(True)
+        pred = critic_apply(PC, batch)
+        pred.mean().backward()
+        sal.append(batch.grad.abs().sum(dim=1)[:, None].numpy())
+        preds.append(pred.detach().squeeze(1).numpy())
+    raw = np.concatenate(sal, axis=0)
+    preds = np.concatenate(preds, axis=0)
+    salM = raw.copy()
+    if salglobal:
+        norm = (salM * (salM >= 0)).mean() * salience_thresh
+    else:
+        k = int(salM.shape[-1] * salM.shape[-2] * salience_thresh)
+        norm = np.sort(salM.reshape(salM.shape[0], 1, -1), axis=-1)[:, :, k, None, None]
+    salM = salM / (norm + sys.float_info.min)
+    salM = salM * preds[:, None, None, None]
+    salM[(salM >= 1)] = 1
+    hard = (salM > salience_thresh).astype(np.uint8)
+    A, B = hard.squeeze(), Ys.transpose(0, 3, 1, 2).squeeze()
+    union = np.sum(A | B)
+    iou = round(float(np.sum(A & B) / union), 3) if union else float("nan")
+    return iou, salM, raw

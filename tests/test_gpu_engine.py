@@ -158,3 +158,28 @@ def test_large_batch_properties(g1):
     # a step moved every parameter by at most ~lr (Adam's first step is +-lr)
     delta = (e.flat - p0).abs().max().item()
     assert 0 < delta <= 1.01e-3
+
+
+def test_saliency_gradient_matches_oracle_autograd(g1):
+    """engine.saliency (eval-mode critic forward + backward to the input, main.py:941-953) vs torch autograd on the oracle."""
+    from cgs_amd import engine
+    pc, pm = g1
+    dev = torch.device("cuda:0")
+    n = 19
+    x_u8 = np.random.RandomState(91).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Xc = orc.u8_to_nchw(x_u8).clone().requires_grad_(True)
+    pred = orc.critic_apply(pc, Xc)
+    pred.mean().backward()
+    want = Xc.grad.permute(0, 2, 3, 1).numpy()
+    eng = engine.HourglassEngine(8, device=dev, dropout=0.3)
+    eng.load_state(pc, pm)
+    xd = (torch.from_numpy(x_u8).to(dev).double() / 255.0).float()
+    p, dx = eng.saliency(xd)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(p.cpu().numpy(), pred.detach()[:, 0].numpy(), rtol=1e-3, atol=1e-6)
+    got = dx.cpu().numpy()
+    scale = np.abs(want).max()
+    assert scale > 0
+    assert np.abs(got - want).max() <= 1e-3 * scale + 1e-9, (np.abs(got - want).max(), scale)
+    # the map the reference thresholds: |grad| summed over the colour channels
+    np.testing.assert_allclose(np.abs(got).sum(-1), np.abs(want).sum(-1), rtol=2e-3, atol=2e-3 * scale)

@@ -194,6 +194,14 @@ def test_cli_train_then_process(tmp_path):
     want = orc.eval_iou(pc, pm, Xe, Ye, eval_thresh=thr)
     got = float(r.stdout.split("RESULTS [")[-1].split("]")[0])
     assert 0.0 <= want <= 1.0 and abs(got - want) <= 2e-3, (got, want)
+    # -eval -salience: the saliency baseline's IoU next to the mask's
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-eval", "-salience", "--eval-thresh", repr(thr),
+                        "--salience-thresh", "0.5"] + common, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    got2 = [float(v) for v in r.stdout.split("RESULTS [")[-1].split("]")[0].split(",")]
+    want_sal, _, _ = orc.eval_saliency_iou(pc, Xe, Ye, salience_thresh=0.5)
+    assert len(got2) == 2 and abs(got2[0] - want) <= 2e-3
+    assert (np.isnan(got2[1]) and np.isnan(want_sal)) or abs(got2[1] - want_sal) <= 5e-3, (got2, want_sal)
 
 
 DP_WORKER = r"""

@@ -183,3 +183,17 @@ def test_eval_iou_restatement(g1):
     B = np.all(Y, axis=-1)[100:5000:2]
     assert orc.eval_iou(pc, pm, X, Y, eval_thresh=thr) == round(float((A & B).sum() / (A | B).sum()), 3)
     assert orc.eval_iou(pc, pm, X, Y, eval_thresh=2.0) == 0.0      # nothing above 2: empty prediction
+
+
+def test_saliency_restatement_shapes_and_clipping(g1):
+    """eval_saliency_iou: maps are clipped at 1 and weighted by pred; with the reference's default threshold 1.5 nothing
+    can exceed it (the reference's saliency IoU is then 0): restated literally."""
+    pc, _ = g1
+    rs = np.random.RandomState(6)
+    X = rs.randint(0, 256, (124, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(124, 64, 64, 3) > 0.1
+    iou, salM, raw = orc.eval_saliency_iou(pc, X, Y)
+    assert salM.shape == (12, 1, 64, 64) and raw.shape == salM.shape
+    assert salM.max() <= 1.0 and raw.min() >= 0.0 and iou == 0.0
+    iou2, _, _ = orc.eval_saliency_iou(pc, X, Y, salience_thresh=0.25)
+    assert 0.0 <= iou2 <= 1.0
