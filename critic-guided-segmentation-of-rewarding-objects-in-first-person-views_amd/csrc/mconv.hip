@@ -451,6 +451,168 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16-operand variant of the inference mask head (BASELINE config 4: "-process inference-only, fp16 conv kernels"):
+// the masker.0 GEMM runs on v_mfma_f32_16x16x16_f16 (fp16 image / o0 / weight operands, fp32 accumulate): K = 16 per
+// instruction, 5 instead of 17 MFMAs per 16 pixels, each 4x shorter than an fp32 MFMA.  masker.2 stays fp32 on the
+// fp32 h tile.  OPT-IN only (engine.infer(..., fp16_mask_head=True)); the result differs from the fp32 path by ~1e-3
+// absolute in Z (tests/test_gpu_kernels.py), so it is never used for training or for the parity-gated paths.
+// K layout of one instruction = 4 lanes-groups (kq) x 4 halves: image: kq = tap (4m + kq), halves = (r, g, b, 0);
+// o0: kq = (fold column b = kq>>1, channel group kq&1), instruction m = fold row a.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+template <int SRC>
+__global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams P) {
+    using G = MaskInferGeo;
+    constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, LR = G::LR, LC = G::LC, HPS = G::HPS;
+    constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    _Float16* ximg = (_Float16*)smem;                      // [IR][IC][4]  (r, g, b, 0)
+    _Float16* xo = ximg + IR * IC * 4;                     // [LR][LC][8]
+    float* hs = (float*)(xo + LR * LC * 8);                // [HR][IC][HPS] fp32
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int hf = wave & 1, par = wave >> 1;
+    const int py = (par + 1) & 1;
+
+    // ---- masker.0 weights -> fp16 registers (B operand: k = 4*kq + c, n = l15 = oc) ----
+    half4_t wimg[3], wo[2][2];         // image: instruction m covers taps 4m..4m+3;  o0: [px][a = m]
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        const int t = 4 * m + kq;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wimg[m][c] = (_Float16)((t < 9 && c < 3) ? P.w0[((t < 9 ? t : 0) * 11 + (c < 3 ? c : 0)) * 16 + l15] : 0.f);
+    }
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int b = kq >> 1, ch = 4 * (kq & 1) + c;
+                float v = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                        const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                        const float w = P.w0[((ky * 3 + kx) * 11 + 3 + ch) * 16 + l15];
+                        v += (iny && inx) ? w : 0.f;
+                    }
+                wo[px][a][c] = (_Float16)v;
+            }
+    const float bias0 = P.b0[l15], bias2 = P.b2[0];
+    for (int e = tid; e < HR * 2 * 16; e += 256) {
+        int ch = e & 15, side = (e >> 4) & 1, r = e >> 5;
+        hs[(r * IC + (side ? IC - 1 : 0)) * HPS + ch] = 0.f;
+    }
+    // per-lane tap offsets of the three image instructions (halves): tap t = 4m + kq (t > 8: any valid address, zero weight)
+    int toff[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) { int t = 4 * m + kq; t = t < 9 ? t : 8; toff[m] = ((t / 3) * IC + t % 3) * 4; }
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        for_elems<NIMG, 256>(tid, [&](int e) {
+            int r = e / IC, c = e % IC;
+            int y = row0 + r - 2, x = c - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            int pix = in ? (n0 * H + y) * W + x : 0;
+            float v0, v1, v2;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
+                uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
+                const float sc = 1.f / 255.f;
+                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+            } else {
+                const float* sf = (const float*)P.img;
+                v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
+            }
+            half4_t hv;
+            hv[0] = (_Float16)(in ? v0 : 0.f); hv[1] = (_Float16)(in ? v1 : 0.f); hv[2] = (_Float16)(in ? v2 : 0.f); hv[3] = (_Float16)0.f;
+            *(half4_t*)(ximg + e * 4) = hv;
+        });
+        for_elems<NLO, 256>(tid, [&](int e) {
+            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 2, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            float4 v = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+            v = in ? v : f4zero();
+            half4_t hv;
+            hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+            *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
+        });
+        __syncthreads();
+
+        const int ibase = (par * IC + 2 * (16 * hf + l15)) * 4;            // halves; + (2*jj*IC + px)*4 + toff[m]
+        const int obase = (16 * hf + l15) * 8 + 4 * kq;                    // halves; + ((jj + a + 1)*LC + px)*8
+#pragma unroll
+        for (int t = 0; t < 10; ++t) {
+            const int jj = t >> 1, px = t & 1;
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const half4_t a = *(const half4_t*)(ximg + ibase + (2 * jj * IC + px) * 4 + toff[m]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, wimg[m], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                const half4_t a = *(const half4_t*)(xo + obase + ((jj + a2 + 1) * LC + px) * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, wo[px][a2], acc, 0, 0, 0);
+            }
+            const int j = par + 2 * jj, y = row0 - 1 + j;
+            const float keep = (y >= 0 && y < H) ? 1.f : 0.f;
+            float* hrow = hs + (j * IC + 1 + 2 * (16 * hf + 4 * kq) + px) * HPS + l15;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hrow[2 * i * HPS] = keep * act_fwd<CGS_ACT_LRELU>(acc[i] + bias0);
+        }
+        __syncthreads();
+        {
+            const int x = tid & 63, yl0 = tid >> 6;
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                const int yl = yl0 + 4 * rep;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4* hp = (const float4*)(hs + ((yl + t / 3) * IC + x + t % 3) * HPS);
+                    const auto* wp = cgs_to_const(P.w2) + t * 16;
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float4 hv = hp[c4];
+                        a0 = fmaf(hv.x, wp[4 * c4], a0); a1 = fmaf(hv.y, wp[4 * c4 + 1], a1);
+                        a2 = fmaf(hv.z, wp[4 * c4 + 2], a2); a3 = fmaf(hv.w, wp[4 * c4 + 3], a3);
+                    }
+                    if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+                }
+                const float zpre = ((a0 + a1) + (a2 + a3)) + bias2;
+                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = 1.f / (1.f + expf(-zpre));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static constexpr size_t kMaskInferF16Lds =
+    (size_t)MaskInferGeo::IR * MaskInferGeo::IC * 4 * 2 + (size_t)MaskInferGeo::LR * MaskInferGeo::LC * 8 * 2 + (size_t)MaskInferGeo::HS * 4;
+
+int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
+                          const float* w2, const float* b2, float* z, hipStream_t st) {
+    if (n <= 0) return CGS_OK;
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS};
+    int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
+    if (img_kind == CGS_SRC_U8)
+        hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_U8>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    else
+        hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_F32>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
                       const float* b2, float* z, hipStream_t st) {
     if (n <= 0) return CGS_OK;

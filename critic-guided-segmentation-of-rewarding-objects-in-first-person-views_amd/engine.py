@@ -302,9 +302,9 @@ class HourglassEngine:
 
     # ---- inference (main.py:1130-1151) -----------------------------------------------------------
     @torch.no_grad()
-    def infer(self, X: torch.Tensor, want_mask: bool = True):
+    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
-        Returns (pred [b], Z [b,64,64] or None)."""
+        Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM."""
         b = X.shape[0]
         if not want_mask:
             return hg.critic_forward(self.fc, self.lc, X.contiguous(), b)["pred"], None
@@ -314,5 +314,5 @@ class HourglassEngine:
                               pw=(C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")),
                                   C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")), o4))
         m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b, out={"o4": o4}, o4_done=True,
-                              keep_hm=False)
+                              keep_hm=False, fp16_mask_head=fp16_mask_head)
         return c["pred"], m["Z"]

@@ -258,11 +258,12 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
 # ------------------------------------------------------------------------------------------------
 def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
                    out: Optional[Dict[str, torch.Tensor]] = None, o4_done: bool = False,
-                   keep_hm: bool = True) -> Dict[str, torch.Tensor]:
+                   keep_hm: bool = True, fp16_mask_head: bool = False) -> Dict[str, torch.Tensor]:
     """x: NHWC uint8/fp32 image [n,64,64,3]; embeds = [e0,e1,e2,e3 (NHWC), e4 [n,32]].
     Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64].  o4_done: out['o4'] was already produced by the critic's
     head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv.  keep_hm=False (inference): the 16-channel
-    masker.0 output is not needed afterwards -- masker.0 and masker.2 run as one kernel and 'hm' is never stored."""
+    masker.0 output is not needed afterwards -- masker.0 and masker.2 run as one kernel and 'hm' is never stored;
+    fp16_mask_head (with keep_hm=False only, opt-in): that kernel's masker.0 GEMM takes fp16 operands (~1e-3 abs in Z)."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
@@ -277,15 +278,16 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     names = ("o3", "o2", "o1", "o0", "hm", "Z")
     srcs_a = (embeds[3], embeds[2], embeds[1], embeds[0], x, None)
     prev = o["o4"]
+    if fp16_mask_head and (keep_hm or not MASK_INFER_FUSED):
+        raise _lib.CgsError("fp16_mask_head is an inference-only option of the one-kernel mask head (keep_hm=False)")
     for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
         if name == "hm" and not keep_hm and MASK_INFER_FUSED:
             if o.get("Z") is None:
                 o["Z"] = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
-            rc = _lib.load().cgs_mask_infer_fwd(n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
-                                                C.c_void_p(fp + 4 * lay.off("masker.0.weight")),
-                                                C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
-                                                C.c_void_p(fp + 4 * lay.off("masker.2.weight")),
-                                                C.c_void_p(fp + 4 * lay.off("masker.2.bias")), _p(o["Z"]), _stream())
+            fn = _lib.load().cgs_mask_infer_fwd_f16 if fp16_mask_head else _lib.load().cgs_mask_infer_fwd
+            rc = fn(n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
+                    C.c_void_p(fp + 4 * lay.off("masker.0.weight")), C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
+                    C.c_void_p(fp + 4 * lay.off("masker.2.weight")), C.c_void_p(fp + 4 * lay.off("masker.2.bias")), _p(o["Z"]), _stream())
             if rc == 0:
                 return o
             if rc != _lib.ERR_UNSUPPORTED:

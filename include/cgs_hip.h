@@ -115,6 +115,13 @@ int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const float* o0,
                        const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
                        cgs_stream_t stream);
 
+/* Same contract with fp16 OPERANDS for the masker.0 GEMM (v_mfma_f32_16x16x16_f16, fp32 accumulate; masker.2 stays
+ * fp32): BASELINE config 4 ("-process inference-only, fp16 conv kernels").  Opt-in: z differs from the fp32 result by
+ * about 1e-3 absolute; never used by training.                                                                  */
+int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
+                           const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
+                           cgs_stream_t stream);
+
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
  *   slab[b][0 .. 9*(ca+cb)*co)  = partial dW (HWIO),  slab[b][9*(ca+cb)*co ..][co] = partial dbias

@@ -451,3 +451,25 @@ def test_fused_inference_mask_head_matches_oracle_and_two_kernel_form(ctx, n, u8
     np.testing.assert_allclose(m1["Z"].cpu().numpy(), m2["Z"].cpu().numpy(), rtol=2e-5, atol=2e-6)
     p = C.c_void_p(xin.data_ptr())
     assert lib.cgs_mask_infer_fwd(n, 7, p, p, p, p, p, p, p, C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
+
+
+def test_fp16_operand_inference_mask_head_within_1e3_abs(ctx):
+    """BASELINE config 4: the opt-in fp16-operand masker.0 GEMM (fp32 accumulate, fp32 masker.2).  Tolerance is the one
+    SURVEY 8d states for fp16 inference: ~1e-3 ABSOLUTE in Z against the fp32 oracle (checked: max 2e-3, mean 3e-4)."""
+    hg, dev, lm, fm = ctx["hg"], ctx["dev"], ctx["lm"], ctx["fm"]
+    n = 33
+    x_u8 = np.random.RandomState(71).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    X = orc.u8_to_nchw(x_u8)
+    with torch.no_grad():
+        _, embeds = orc.critic_apply(ctx["pc"], X, collect=True)
+        Z = orc.masker_apply(ctx["pm"], X, embeds)[:, 0].numpy()
+    for u8 in (True, False):
+        xd = torch.from_numpy(x_u8).to(dev)
+        xin = xd if u8 else (xd.float() / 255.0).contiguous()
+        c = hg.critic_forward(ctx["fc"], ctx["lc"], xin, n)
+        m = hg.masker_forward(fm, lm, xin, [c[f"e{i}"] for i in range(5)], n, keep_hm=False, fp16_mask_head=True)
+        torch.cuda.synchronize()
+        err = np.abs(m["Z"].cpu().numpy() - Z)
+        assert err.max() <= 2e-3 and err.mean() <= 3e-4, (err.max(), err.mean())
+    with pytest.raises(Exception):
+        hg.masker_forward(fm, lm, xin, [c[f"e{i}"] for i in range(5)], n, keep_hm=True, fp16_mask_head=True)
