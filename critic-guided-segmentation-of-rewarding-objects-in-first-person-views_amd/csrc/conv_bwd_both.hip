@@ -113,3 +113,70 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
     }
     return CGS_ERR_UNSUPPORTED;
 }
+
+// ------------------------------------------------------------------------------------------------
+// features.0 backward of the replaced / injected passes TOGETHER with the mix backward (main.py:395,406 backward):
+// a data-gradient workgroup takes the same strip of replaced image i and of injected image i one after the other,
+// keeps the first image gradient on chip (LDS stash) and writes d(pre-sigmoid mask) from the second pass's epilogue:
+//   dzpre = [ sum_c (B - A) (d_rep - d_inj) + l1s sign(z) + 2 l2s z ] z (1 - z)
+// so the 2 x 25 MB image gradients are never stored and cgs_mix_bwd's pass over them disappears.  The weight-gradient
+// workgroups of features.0 (over all mixes) share the launch as in conv_bwd_both_kernel.  Bit-identical to the two-launch
+// form (same data-gradient code, same arithmetic order in the mix part).
+// ------------------------------------------------------------------------------------------------
+struct DEnc0S : DEnc0 { static constexpr bool STASH = true; };
+struct MixBwdArgs {
+    const uint8_t* a; const uint8_t* b; const float* z; float* dzpre;
+    int n_a, inject;
+    float l1s, l2s;
+};
+
+__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, int stash_off) {
+    using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
+    static_assert(WEnc0F32::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    if ((int)blockIdx.x < nbw) {
+        constexpr int SLAB = (9 * 3 + 1) * 8;
+        wgrad_body<WEnc0F32>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+        return;
+    }
+    const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
+    pd.stash = (float*)smem + stash_off;                 // [4 pixels x 3 channels][256 threads]
+    pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s;
+    pd.mix_inject = M.inject;
+    if (M.inject) {
+        pd.mix_phase = 1;                                // injected image: gradient to the stash
+        conv3x3_body<DEnc0S, true>(pd, (M.n_a + img) * G::STRIPS + strip, smem);
+        __syncthreads();                                 // everybody is done with the first pass's tiles
+    }
+    pd.mix_phase = 2;                                    // replaced image: combine, write dzpre of A-image `img`
+    conv3x3_body<DEnc0S, true>(pd, img * G::STRIPS + strip, smem);
+}
+
+extern "C" int cgs_enc0_bwd_mix_slabs(int32_t n_mix) { return n_mix < 0 ? CGS_ERR_BADARG : both_slabs<WEnc0F32>(n_mix); }
+
+extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
+                                const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
+                                float l2_scale, float* dzpre, float* slab, cgs_stream_t stream) {
+    if (n_a < 0 || !dy || !amask || !w || !a || !b || !z || !dzpre) return CGS_ERR_BADARG;
+    if ((mixed == nullptr) != (slab == nullptr)) return CGS_ERR_BADARG;     // weight gradient: both or neither
+    if (n_a == 0) return CGS_OK;
+    using GW = WEnc0F32::G;
+    using GD = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
+    const int n_mix = inject ? 2 * n_a : n_a;
+    WgradParams pw{};
+    pw.src_a = mixed; pw.dy = dy; pw.amask = amask; pw.slab = slab; pw.n = n_mix;
+    pw.ntiles = n_mix * GW::STRIPS;
+    ConvParams pd{};
+    pd.src_a = dy; pd.amask_in = amask; pd.w = w; pd.n = n_mix;
+    MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale};
+    const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
+    const int nbd = n_a * GD::STRIPS;
+    size_t lw = wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
+    size_t base = lw > ld ? lw : ld;
+    base = (base + 15) / 16 * 16;
+    const size_t lds = base + 12 * 256 * sizeof(float);      // 41 KB tiles + 12 KB stash: three workgroups per CU
+    hipLaunchKernelGGL(enc0_bwd_mix_kernel, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
+                       (int)(base / sizeof(float)));
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

@@ -175,12 +175,19 @@ class HourglassEngine:
             self._ws["cb_a"].update(self._sl_a)
         pc = plan if first else hg.SlabPlan()   # job registration only matters the first time
         # critic backward on the mixes: image gradient for the mask path (+ weight gradients when live)
-        hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
-                           self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
-                           ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live)
         nz = float(n * 4096)
-        _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), _P(self.dmixed), int(self.inject),
-                  self.L1 / nz, self.L2 / nz, _P(self.dzpre), _S())
+        if hg.ENC0_MIX_FUSED:
+            # features.0's backward carries the mix backward: the image gradients of the mixes never leave the chip
+            hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
+                               self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
+                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live,
+                               mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre))
+        else:
+            hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
+                               self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
+                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live)
+            _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), _P(self.dmixed), int(self.inject),
+                      self.L1 / nz, self.L2 / nz, _P(self.dzpre), _S())
         pm = hg.SlabPlan()
         # live: the 1x1 bottleneck conv's backward runs inside the critic head kernel (frozen: no critic backward on A,
         # the masker does it itself)

@@ -21,6 +21,7 @@ HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
 # small layers: weight- and data-gradient halves share one launch (csrc/conv_bwd_both.hip)
 BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
 MASK_INFER_FUSED = os.environ.get("CGS_MASK_INFER_FUSED", "1") != "0"   # inference: masker.0 + masker.2 in one kernel
+ENC0_MIX_FUSED = os.environ.get("CGS_ENC0_MIX_FUSED", "1") != "0"   # features.0 backward + mix backward in one launch
 MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
 _both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
@@ -177,9 +178,11 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True, pw_bwd=None) -> Optional[torch.Tensor]:
+                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
-    bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.  d_embeds = [dE0..dE4] gradients arriving at the embeds
+    bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.
+    mix_bwd = (A_u8, B_u8, Z, inject, l1_scale, l2_scale, dzpre): x are the replaced|injected mixes of n_a = len(A) images;
+    features.0's backward then also performs the mix backward (cgs_enc0_bwd_mix) and writes dzpre; no dx is produced.  d_embeds = [dE0..dE4] gradients arriving at the embeds
     from the decoder (valid for images < n_add; their buffers are reused as the running totals).
     dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
     Weight-gradient slabs are registered in ``plan`` (dst offsets = this module's flat layout)."""
@@ -219,6 +222,16 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         cnt = 9 * ca * co + co
         wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
+        if i == 0 and mix_bwd is not None:
+            A8, B8, Zm, inj, l1s, l2s, dzp = mix_bwd
+            slab = None
+            if need_wgrad:
+                nsl = lib.cgs_enc0_bwd_mix_slabs(n)
+                slab = buf("slab_enc0", (nsl, cnt))
+                plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
+            _lib.call("cgs_enc0_bwd_mix", A8.shape[0], int(bool(inj)), _p(src) if need_wgrad else None, _p(d_cur),
+                      _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(dzp), _p(slab), _stream())
+            return None
         if need_wgrad and i in BOTH_ENC and (i > 0 or (dx is not None and dx_from == 0 and not u8)):
             # both halves in one launch: slab + d e{i-1} (dropout mask and decoder skip gradient fused)
             nsl = lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))

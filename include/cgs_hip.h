@@ -154,6 +154,18 @@ typedef struct {
 int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count,
                      uint64_t* step, cgs_stream_t stream);
 
+/* ---- features.0 backward of the replaced / injected passes + mix backward in one launch ----------------------
+ * (main.py:395,406 backward chained onto convolution_backward of features.0).  n_a A-images; the mixes are images
+ * [0,n_a) = replaced, [n_a,2 n_a) = injected (inject != 0).  dy [n_mix,32,32,8] + amask: gradient at features.0's pooled
+ * output; mixed [n_mix,64,64,3] + slab [cgs_enc0_bwd_mix_slabs(n_mix)][224]: inputs/outputs of the weight gradient (both
+ * NULL: data path only, frozen critic).  a, b: uint8 frames [n_a,64,64,3]; z [n_a,64,64]; l1/l2_scale as cgs_mix_bwd.
+ * Writes dzpre [n_a,64,64] = what cgs_conv3x3_bwd_data -> cgs_mix_bwd would (bit-identical); the image gradients are
+ * never stored.                                                                                                  */
+int cgs_enc0_bwd_mix_slabs(int32_t n_mix);
+int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
+                     const float* w_hwio, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
+                     float l2_scale, float* dzpre, float* slab, cgs_stream_t stream);
+
 /* ---- critic head: 4x4 valid conv + Linear + Linear (nets.py:184-194) -----------------
  *   e3     : [n,4,4,16] pooled embed (dropout `drop_in` fused into the load)
  *   w4     : [256][32]  (k = (y*4+x)*16 + c, HWIO of features.14), b4 [32]

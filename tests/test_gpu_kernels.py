@@ -473,3 +473,50 @@ def test_fp16_operand_inference_mask_head_within_1e3_abs(ctx):
         assert err.max() <= 2e-3 and err.mean() <= 3e-4, (err.max(), err.mean())
     with pytest.raises(Exception):
         hg.masker_forward(fm, lm, xin, [c[f"e{i}"] for i in range(5)], n, keep_hm=True, fp16_mask_head=True)
+
+
+@pytest.mark.parametrize("inject,wgrad", [(True, True), (False, True), (True, False)])
+def test_enc0_backward_with_mix_backward_equals_two_launches(ctx, inject, wgrad):
+    """cgs_enc0_bwd_mix == cgs_conv3x3_bwd_both (features.0 on the fp32 mixes) followed by cgs_mix_bwd: identical dzpre bits
+    and identical weight-gradient slabs; the image gradients are never stored."""
+    from cgs_amd import _lib
+    import ctypes as C
+    hg, dev, lc, fc = ctx["hg"], ctx["dev"], ctx["lc"], ctx["fc"]
+    lib = _lib.load()
+    n_a = 11
+    n_mix = 2 * n_a if inject else n_a
+    rs = np.random.RandomState(5 + inject + 2 * wgrad)
+    A = torch.from_numpy(rs.randint(0, 256, (n_a, 64, 64, 3)).astype(np.uint8)).to(dev)
+    B = torch.from_numpy(rs.randint(0, 256, (n_a, 64, 64, 3)).astype(np.uint8)).to(dev)
+    Z = torch.from_numpy(rs.rand(n_a, 64, 64).astype(np.float32)).to(dev)
+    mixed = torch.from_numpy(rs.rand(n_mix, 64, 64, 3).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rs.randn(n_mix, 32, 32, 8).astype(np.float32)).to(dev)
+    am = torch.from_numpy(rs.randint(0, 2 ** 31, (n_mix, 32, 32, 1)).astype(np.int32)).to(dev)
+    w = C.c_void_p(fc.data_ptr() + 4 * lc.off("features.0.weight"))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    l1s, l2s = 0.5 / (n_a * 4096), 0.1 / (n_a * 4096)
+    d = hg.conv_desc(n_mix, 64, 3, 0, 8, False, 2, "relu", 1, _lib.Dropout())
+    # reference: two launches
+    dmix = torch.empty(n_mix, 64, 64, 3, device=dev)
+    if wgrad:
+        ns = lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
+        s_ref = torch.zeros(ns, 224, device=dev)
+        _lib.call("cgs_conv3x3_bwd_both", C.byref(d), P(mixed), None, P(dy), P(am), w, None, 0, P(dmix), None, P(s_ref), st)
+    else:
+        _lib.call("cgs_conv3x3_bwd_data", C.byref(d), P(dy), P(am), w, None, _lib.ACT_NONE, None, 0, P(dmix), None, st)
+    dz_ref = torch.empty(n_a, 64, 64, device=dev)
+    _lib.call("cgs_mix_bwd", n_a, 4096, P(A), P(B), P(Z), P(dmix), int(inject), l1s, l2s, P(dz_ref), st)
+    # one launch
+    dz = torch.full((n_a, 64, 64), float("nan"), device=dev)
+    slab = None
+    if wgrad:
+        assert lib.cgs_enc0_bwd_mix_slabs(n_mix) == ns
+        slab = torch.zeros(ns, 224, device=dev)
+    _lib.call("cgs_enc0_bwd_mix", n_a, int(inject), P(mixed) if wgrad else None, P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s,
+              P(dz), P(slab), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref)
+    if wgrad:
+        assert torch.equal(slab, s_ref)
+    assert lib.cgs_enc0_bwd_mix(n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, P(dz), None, st) < 0
