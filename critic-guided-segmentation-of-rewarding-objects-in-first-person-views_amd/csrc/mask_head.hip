@@ -140,14 +140,15 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
                         float d = dz[(r + 2 - ky) * DZW + x + 3 - kx];
                         a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
                         a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
-                        if (WG) {
+                        if (WG && it != 0 && it != IT - 1) {     // items 0 and IT-1 are the halo rows: never owned
                             wacc[ky * 3 + kx][0] = fmaf(d, hw_.x, wacc[ky * 3 + kx][0]);
                             wacc[ky * 3 + kx][1] = fmaf(d, hw_.y, wacc[ky * 3 + kx][1]);
                             wacc[ky * 3 + kx][2] = fmaf(d, hw_.z, wacc[ky * 3 + kx][2]);
                             wacc[ky * 3 + kx][3] = fmaf(d, hw_.w, wacc[ky * 3 + kx][3]);
                         }
                     }
-                if (WG) {
+                static_assert(IT == TH + 2, "one item per tile row: item index == row index");
+                if (WG && it != 0 && it != IT - 1) {
                     bacc += (own && pl == 0) ? dz[(r + 1) * DZW + x + 2] : 0.f;
                     // pin the accumulators here: otherwise their FMAs are sunk past the whole item loop and every dz / h
                     // value of all items stays live (hundreds of registers)
