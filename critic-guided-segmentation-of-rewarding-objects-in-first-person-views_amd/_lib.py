@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CGS_LIB_PATH") or os.path.join(HERE, "libcgs_hip.so")   # override: A/B builds
 
 OK, ERR_UNSUPPORTED, ERR_BADARG = 0, -1, -2
-SRC_F32, SRC_U8 = 0, 1
+SRC_F32, SRC_U8, SRC_MIX = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 
 vp = C.c_void_p
@@ -26,6 +26,10 @@ class Dropout(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [("n", i32), ("h", i32), ("w", i32), ("ca", i32), ("cb", i32), ("co", i32), ("src_a", i32),
                 ("ups", i32), ("act", i32), ("pool", i32), ("drop_a", Dropout)]
+
+
+class MixSrc(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("z", C.c_void_p), ("n_a", i32), ("reserved", i32)]
 
 
 class ReduceJob(C.Structure):

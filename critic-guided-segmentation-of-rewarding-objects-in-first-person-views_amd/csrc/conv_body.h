@@ -22,6 +22,8 @@ struct ConvParams {
     const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z; float* mix_dz;
     float mix_l1s, mix_l2s;
     int mix_phase, mix_inject;
+    int mix_n_a;           // SRC_MIXC3: number of A-images (mix image n >= mix_n_a is the injected one of n - mix_n_a)
+    float* zpart;          // masker.2 forward: optional per-workgroup partial sums (sum |z|, sum z^2) for the L1 / L2 mask losses
     int n, n_addend;
     cgs_dropout drop;
 };
@@ -73,6 +75,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
         load_a_u8c3<G>(ldsA, (const uint32_t*)P.src_a, n0, q.row0, N, tid);
     } else if constexpr (C::SRC == SRC_F32C3) {
         load_a_f32c3<G>(ldsA, (const float4*)P.src_a, n0, q.row0, N, tid);
+    } else if constexpr (C::SRC == SRC_MIXC3) {
+        load_a_mix<G>(ldsA, (const uint32_t*)P.mix_a, (const uint32_t*)P.mix_b, (const float4*)P.mix_z, P.mix_n_a, n0, q.row0, N, tid);
     } else if constexpr (C::SRC == SRC_POOLEXP) {
         load_poolexp<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, q.row0, N, tid,
                                [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
@@ -251,6 +255,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                 }
             }
         } else if constexpr (C::EPI == EPI_PLAIN) {
+            [[maybe_unused]] float zs1 = 0.f, zs2 = 0.f;
             if (live) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -258,6 +263,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                     float v[C::OCB];
 #pragma unroll
                     for (int o = 0; o < C::OCB; ++o) v[o] = act_fwd<C::ACT>(acc[i][o] + cgs_to_const(P.bias)[oc0 + o]);
+                    if constexpr (C::ACT == CGS_ACT_SIGMOID && C::WCO == 1) { zs1 += fabsf(v[0]); zs2 += v[0] * v[0]; }
                     float* dst = P.out + ((size_t)(q.n * G::H + y) * G::W + x) * C::WCO + oc0;
                     if constexpr (C::OCB % 4 == 0) {
 #pragma unroll
@@ -266,6 +272,23 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                     } else {
 #pragma unroll
                         for (int o = 0; o < C::OCB; ++o) dst[o] = v[o];
+                    }
+                }
+            }
+            if constexpr (C::ACT == CGS_ACT_SIGMOID && C::WCO == 1 && !FUSED) {
+                // the mask layer: per-workgroup (sum |z|, sum z^2) for the L1 / L2 mask losses (main.py:421-429), no atomics
+                static_assert(G::IMGS == 1 && C::CW == 1 && NCHUNK == 1, "every thread of the workgroup is live and passes here once");
+                if (P.zpart) {
+                    float* zred = (float*)smem;          // the tiles are consumed: reuse (after a barrier)
+                    zs1 = wave_sum(zs1); zs2 = wave_sum(zs2);
+                    __syncthreads();
+                    if ((tid & 63) == 0) { zred[2 * (tid >> 6)] = zs1; zred[2 * (tid >> 6) + 1] = zs2; }
+                    __syncthreads();
+                    if (tid == 0) {
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < G::LT / 64; ++wv) { t1 += zred[2 * wv]; t2 += zred[2 * wv + 1]; }
+                        P.zpart[2 * bid] = t1; P.zpart[2 * bid + 1] = t2;
                     }
                 }
             }
@@ -419,6 +442,7 @@ static size_t conv_lds_bytes() {
 
 CGS_FWD_CFG(FEnc0U8, 64, 256, SRC_U8C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
 CGS_FWD_CFG(FEnc0F32, 64, 256, SRC_F32C3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
+CGS_FWD_CFG(FEnc0Mix, 64, 256, SRC_MIXC3, 3, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 8, 1)
 CGS_FWD_CFG(FEnc1, 32, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
 CGS_FWD_CFG(FEnc2, 16, 128, SRC_F32, 8, 0, 2, 8, EPI_POOL, CGS_ACT_RELU, 4, 2)
 CGS_FWD_CFG(FEnc3, 8, 64, SRC_F32, 8, 0, 2, 16, EPI_POOL, CGS_ACT_RELU, 4, 4)

@@ -130,13 +130,14 @@ struct MixBwdArgs {
     float l1s, l2s;
 };
 
+template <class CWG>
 __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, int stash_off) {
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
-    static_assert(WEnc0F32::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
+    static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     if ((int)blockIdx.x < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;
-        wgrad_body<WEnc0F32>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+        wgrad_body<CWG>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
         return;
     }
     const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
@@ -158,7 +159,7 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
                                 const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
                                 float l2_scale, float* dzpre, float* slab, cgs_stream_t stream) {
     if (n_a < 0 || !dy || !amask || !w || !a || !b || !z || !dzpre) return CGS_ERR_BADARG;
-    if ((mixed == nullptr) != (slab == nullptr)) return CGS_ERR_BADARG;     // weight gradient: both or neither
+    if (mixed && !slab) return CGS_ERR_BADARG;           // `mixed` is only the weight gradient's input
     if (n_a == 0) return CGS_OK;
     using GW = WEnc0F32::G;
     using GD = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
@@ -166,6 +167,7 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     WgradParams pw{};
     pw.src_a = mixed; pw.dy = dy; pw.amask = amask; pw.slab = slab; pw.n = n_mix;
     pw.ntiles = n_mix * GW::STRIPS;
+    pw.mix_a = a; pw.mix_b = b; pw.mix_z = z; pw.mix_n_a = n_a;
     ConvParams pd{};
     pd.src_a = dy; pd.amask_in = amask; pd.w = w; pd.n = n_mix;
     MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale};
@@ -175,8 +177,12 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     size_t base = lw > ld ? lw : ld;
     base = (base + 15) / 16 * 16;
     const size_t lds = base + 12 * 256 * sizeof(float);      // 41 KB tiles + 12 KB stash: three workgroups per CU
-    hipLaunchKernelGGL(enc0_bwd_mix_kernel, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
-                       (int)(base / sizeof(float)));
+    if (mixed || !slab)        // materialised mixes (or no weight gradient at all)
+        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0F32>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
+                           (int)(base / sizeof(float)));
+    else                       // weight-gradient input = the mixes recomputed from a, b, z in the tile loader
+        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0Mix>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
+                           (int)(base / sizeof(float)));
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

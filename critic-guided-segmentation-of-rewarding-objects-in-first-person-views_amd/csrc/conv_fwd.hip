@@ -50,6 +50,15 @@ extern "C" int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const 
     ConvParams P{};
     P.src_a = src_a; P.src_b = src_b; P.w = w; P.bias = bias; P.out = out; P.amask_out = amask;
     P.n = d->n; P.drop = d->drop_a;
+    if (d->src_a == CGS_SRC_MIX) {     // features.0 on the replaced | injected mixes, computed in the loader
+        const cgs_mix_src* m = (const cgs_mix_src*)src_a;       // HOST struct
+        if (!m->a || !m->b || !m->z || m->n_a <= 0 || d->n > 2 * m->n_a) return CGS_ERR_BADARG;
+        if (!(d->h == 64 && d->w == 64 && d->ca == 3 && d->cb == 0 && d->co == 8 && d->act == CGS_ACT_RELU && d->pool == 1 &&
+              d->drop_a.p == 0.f))
+            return CGS_ERR_UNSUPPORTED;
+        P.src_a = nullptr; P.mix_a = m->a; P.mix_b = m->b; P.mix_z = m->z; P.mix_n_a = m->n_a;
+        return launch_conv<FEnc0Mix>(P, st);
+    }
     const int R = CGS_ACT_RELU, L = CGS_ACT_LRELU, S = CGS_ACT_SIGMOID, NO = CGS_ACT_NONE;
     if (d->drop_a.p > 0.f && !(desc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, R, 1))) return CGS_ERR_UNSUPPORTED;
     if (desc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, R, 1)) return launch_conv<FEnc0U8>(P, st);
@@ -66,7 +75,10 @@ extern "C" int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const 
         return use_mconv() ? mconv_fwd_dispatch(0, d->n, src_a, src_b, w, bias, out, st) : launch_conv<FMask0U8>(P, st);
     if (desc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, L, 0))
         return use_mconv() ? mconv_fwd_dispatch(1, d->n, src_a, src_b, w, bias, out, st) : launch_conv<FMask0F32>(P, st);
-    if (desc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, S, 0)) return launch_conv<FMask2>(P, st);
+    if (desc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, S, 0)) {
+        P.amask_out = nullptr; P.zpart = (float*)amask;      // the mask layer: `amask` carries the optional z partial sums
+        return launch_conv<FMask2>(P, st);
+    }
     return CGS_ERR_UNSUPPORTED;
 }
 

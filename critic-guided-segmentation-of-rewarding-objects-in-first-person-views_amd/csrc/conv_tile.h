@@ -18,7 +18,7 @@
 #pragma once
 #include "cgs_common.h"
 
-enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5 };
+enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5, SRC_MIXC3 = 6 };
 
 // THREADS = quads per workgroup; CW = waves-groups that split the output-channel chunks of those quads
 // between them (small images: more waves per image); LT = threads that take part in the tile loads.
@@ -153,6 +153,43 @@ __device__ __forceinline__ void load_a_f32c3(float4* ldsA, const float4* __restr
         ldsA[base + G::pc(g * 4 + 2)] = make_float4(a.w, b.x, b.y, 0.f);
         ldsA[base + G::pc(g * 4 + 3)] = make_float4(b.z, b.w, c.x, 0.f);
         ldsA[base + G::pc(g * 4 + 4)] = make_float4(c.y, c.z, c.w, 0.f);
+    });
+    zero_halo_cols<G, 1>(ldsA, tid);
+}
+
+// The replaced / injected mixes of main.py:395,406 computed on the fly from the uint8 frames and the mask (never stored):
+// image n < n_a: A(1-Z) + Z B of A-image n;  image n >= n_a: B(1-Z) + Z A of A-image n - n_a.  One thread = 4 pixels.
+template <class G>
+__device__ __forceinline__ void load_a_mix(float4* ldsA, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                           const float4* __restrict__ z, int n_a, int n0, int row0, int N, int tid) {
+    constexpr int GW = G::W / 4;
+    constexpr int E = G::IMGS * G::TRA * GW;
+    const float s = 1.f / 255.f;
+    for_elems<E, G::LT>(tid, [&](int e) {
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        const bool inj = n >= n_a;
+        int src_n = in ? (inj ? n - n_a : n) : 0;
+        int pg = in ? (src_n * G::H + y) * G::W / 4 + g : 0;          // 4-pixel group index
+        uint32_t a0 = a[3 * pg], a1 = a[3 * pg + 1], a2 = a[3 * pg + 2];
+        uint32_t b0 = b[3 * pg], b1 = b[3 * pg + 1], b2 = b[3 * pg + 2];
+        float4 zz = z[pg];
+        if (inj) { uint32_t t; t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; t = a2; a2 = b2; b2 = t; }
+        // byte k of the 12-byte group: channel k % 3 of pixel k / 3
+        auto mixv = [&](uint32_t da, uint32_t db, int sh, float zi) {
+            float av = ((da >> sh) & 255) * s, bv = ((db >> sh) & 255) * s;
+            return av * (1.f - zi) + zi * bv;
+        };
+        float4 p0 = make_float4(mixv(a0, b0, 0, zz.x), mixv(a0, b0, 8, zz.x), mixv(a0, b0, 16, zz.x), 0.f);
+        float4 p1 = make_float4(mixv(a0, b0, 24, zz.y), mixv(a1, b1, 0, zz.y), mixv(a1, b1, 8, zz.y), 0.f);
+        float4 p2 = make_float4(mixv(a1, b1, 16, zz.z), mixv(a1, b1, 24, zz.z), mixv(a2, b2, 0, zz.z), 0.f);
+        float4 p3 = make_float4(mixv(a2, b2, 8, zz.w), mixv(a2, b2, 16, zz.w), mixv(a2, b2, 24, zz.w), 0.f);
+        int base = (img * G::TRA + r) * G::PWA;
+        ldsA[base + G::pc(g * 4 + 1)] = in ? p0 : f4zero();
+        ldsA[base + G::pc(g * 4 + 2)] = in ? p1 : f4zero();
+        ldsA[base + G::pc(g * 4 + 3)] = in ? p2 : f4zero();
+        ldsA[base + G::pc(g * 4 + 4)] = in ? p3 : f4zero();
     });
     zero_halo_cols<G, 1>(ldsA, tid);
 }

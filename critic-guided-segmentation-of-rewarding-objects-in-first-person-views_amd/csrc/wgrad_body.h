@@ -13,6 +13,9 @@ struct WgradParams {
     float* slab;
     int n, ntiles;
     cgs_dropout drop;
+    // WSRC_MIX: source A = the replaced | injected mixes computed on the fly (see conv_tile.h load_a_mix)
+    const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z;
+    int mix_n_a;
 };
 
 template <int H_, int W_, int TH_, int IMGS_, int THREADS_>
@@ -25,7 +28,7 @@ struct WGeo {
     static_assert((TH * W) % 4 == 0 && H % TH == 0, "tile shape");
 };
 
-enum { WSRC_F32 = 0, WSRC_U8 = 1, WDY_F32 = 0, WDY_POOLEXP = 1 };
+enum { WSRC_F32 = 0, WSRC_U8 = 1, WSRC_MIX = 2, WDY_F32 = 0, WDY_POOLEXP = 1 };
 
 // C: G (WGeo), SRC (WSRC_*), CA, CB, UPS, CO, DY (WDY_*)
 // X tile: [img][TRA][PWA][PCI] floats, PCI = 4*(SA+SB): source A occupies SA float4 slots per pixel
@@ -79,6 +82,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
     constexpr int ITY = (NY + G::THREADS - 1) / G::THREADS;
     float4 ra[ITA], rb[ITB > 0 ? ITB : 1], ry[ITY];
     uint32_t rn[ITY];
+    [[maybe_unused]] float rz[ITA];     // WSRC_MIX: the mask value of the pixel
 
     auto tile_origin = [&](int tile, int& n0, int& row0) {
         n0 = (G::IMGS == 1) ? tile / G::STRIPS : tile * G::IMGS;
@@ -104,7 +108,16 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
             } else {
                 bool in = pix_decode(e, n0, row0, n, y, x);
                 int pix = in ? (n * G::H + y) * G::W + x : 0;
-                if constexpr (C::SRC == WSRC_U8) {
+                if constexpr (C::SRC == WSRC_MIX) {
+                    // raw dwords only (decoded in commit): A (lo, hi), B (lo, hi) around the pixel's 3 bytes, and z
+                    const bool inj = in && n >= P.mix_n_a;
+                    const int spix = in ? ((inj ? n - P.mix_n_a : n) * G::H + y) * G::W + x : 0;
+                    const uint32_t* a32 = (const uint32_t*)P.mix_a;
+                    const uint32_t* b32 = (const uint32_t*)P.mix_b;
+                    const int off = spix * 3, last = P.mix_n_a * G::H * G::W * 3 / 4 - 1, d = off >> 2, d1 = d + 1 <= last ? d + 1 : last;
+                    ra[it] = make_float4(__uint_as_float(a32[d]), __uint_as_float(a32[d1]), __uint_as_float(b32[d]), __uint_as_float(b32[d1]));
+                    rz[it] = P.mix_z[spix];
+                } else if constexpr (C::SRC == WSRC_U8) {
                     const uint32_t* s32 = (const uint32_t*)P.src_a;
                     int off = pix * 3, last = N * G::H * G::W * 3 / 4 - 1;
                     int d = off >> 2;
@@ -163,7 +176,24 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
                 ((float4*)xt)[(e / SA) * S + (e % SA)] = in ? v : f4zero();
             } else {
                 bool in = pix_decode(e, n0, row0, n, y, x);
-                ((float4*)xt)[e * S] = in ? ra[it] : f4zero();
+                float4 v = ra[it];
+                if constexpr (C::SRC == WSRC_MIX) {
+                    const bool inj = in && n >= P.mix_n_a;
+                    const int spix = in ? ((inj ? n - P.mix_n_a : n) * G::H + y) * G::W + x : 0;
+                    const int sh = ((spix * 3) & 3) * 8;
+                    uint64_t a6 = (((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x)) >> sh;
+                    uint64_t b6 = (((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z)) >> sh;
+                    if (inj) { uint64_t t = a6; a6 = b6; b6 = t; }
+                    const float sc = 1.f / 255.f, zi = rz[it];
+                    float m[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float av = ((a6 >> (8 * c)) & 255) * sc, bv = ((b6 >> (8 * c)) & 255) * sc;
+                        m[c] = av * (1.f - zi) + zi * bv;
+                    }
+                    v = make_float4(m[0], m[1], m[2], 0.f);
+                }
+                ((float4*)xt)[e * S] = in ? v : f4zero();
             }
         }
         if constexpr (SB > 0) {
@@ -388,6 +418,7 @@ __global__ void __launch_bounds__(G::THREADS) wgrad_co1_kernel(WgradParams P) {
     };
 
 CGS_WG_CFG(WEnc0U8, 64, 8, 1, WSRC_U8, 3, 0, 2, 8, WDY_POOLEXP)
+CGS_WG_CFG(WEnc0Mix, 64, 8, 1, WSRC_MIX, 3, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc0F32, 64, 8, 1, WSRC_F32, 3, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc1, 32, 16, 1, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)
 CGS_WG_CFG(WEnc2, 16, 16, 2, WSRC_F32, 8, 0, 2, 8, WDY_POOLEXP)

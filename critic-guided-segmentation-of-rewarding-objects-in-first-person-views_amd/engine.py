@@ -61,16 +61,17 @@ class HourglassEngine:
         n4 = 4 * n
         self.ab = z(2 * n, 64, 64, 3, dt=torch.uint8)       # [B | A]
         self.y = z(n)
-        self.mixed = z(2 * n, 64, 64, 3)                     # [replaced | injected]
+        self.mixed = None if hg.ENC0_MIX_FUSED else z(2 * n, 64, 64, 3)      # [replaced | injected] (virtual on the fused path)
         self.cbuf: Dict[str, torch.Tensor] = {}              # critic activations for the 4N slots
         for i, (key, hw, ca, cb, co, *_r) in enumerate(ENC_LAYERS):
             self.cbuf[f"e{i}"] = z(n4, hw // 2, hw // 2, co)
             self.cbuf[f"am{i}"] = z(n4, hw // 2, hw // 2, co // 8, dt=torch.int32)
         self.cbuf["e4"], self.cbuf["h1"], self.cbuf["pred"] = z(n4, 32), z(n4, 32), z(n4)
         self.mbuf: Dict[str, torch.Tensor] = {}
-        self.nzpart = _lib.load().cgs_mix_fwd_partials(n, 4096)
+        # partial sums of |Z| and Z^2: from the mask layer's workgroups (4 per image) or from cgs_mix_fwd's
+        self.nzpart = 4 * n if hg.ENC0_MIX_FUSED else _lib.load().cgs_mix_fwd_partials(n, 4096)
         self.zsum, self.losses, self.dpred = z(2 * self.nzpart), z(8), z(n4)
-        self.dmixed = z(2 * n, 64, 64, 3)
+        self.dmixed = None if hg.ENC0_MIX_FUSED else z(2 * n, 64, 64, 3)
         self.dzpre = z(n, 64, 64)
         self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "p1": {}}
         self._graphs: Dict[str, object] = {}
@@ -160,9 +161,17 @@ class HourglassEngine:
         hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n), pw=pw)
         sa = self._cview(n, 2 * n)
         embeds = [sa[f"e{i}"] for i in range(5)]
-        hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf, o4_done=True)
-        _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
-        hg.critic_forward(self.fc, self.lc, self.mixed[:nmix], nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
+        hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf, o4_done=True,
+                          zpart=self.zsum if hg.ENC0_MIX_FUSED else None)
+        if hg.ENC0_MIX_FUSED:
+            # the mixes are virtual: features.0 computes them in its tile loaders (forward here, weight gradient below); the
+            # mask layer left the (sum |z|, sum z^2) partials in self.zsum
+            mixsrc = hg.MixInput(A, B, self.mbuf["Z"])
+            hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
+        else:
+            mixsrc = self.mixed[:nmix]
+            _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
+            hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
         _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
                   flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
@@ -178,8 +187,8 @@ class HourglassEngine:
         nz = float(n * 4096)
         if hg.ENC0_MIX_FUSED:
             # features.0's backward carries the mix backward: the image gradients of the mixes never leave the chip
-            hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
-                               self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,
+            hg.critic_backward(self.fc, self.lc, mixsrc, nmix, self._cview(2 * n, 2 * n + nmix),
+                               self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=None, dx_from=0,
                                ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live,
                                mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre))
         else:

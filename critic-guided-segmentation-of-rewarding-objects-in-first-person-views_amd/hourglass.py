@@ -93,6 +93,22 @@ class SideStream:
 NO_SIDE = SideStream(None)
 
 
+class MixInput:
+    """The replaced | injected mixes of main.py:395,406 as a VIRTUAL critic input: features.0's kernels compute
+    A(1-Z)+ZB / B(1-Z)+ZA in their tile loaders from the uint8 frames and the mask, nothing is materialised."""
+
+    def __init__(self, A_u8: torch.Tensor, B_u8: torch.Tensor, Z: torch.Tensor):
+        _chk(A_u8, torch.uint8, "A"); _chk(B_u8, torch.uint8, "B"); _chk(Z, torch.float32, "Z")
+        self.A, self.B, self.Z = A_u8, B_u8, Z
+        self.n_a = A_u8.shape[0]
+        self.device = A_u8.device
+        self.dtype = torch.float32
+        self.src = _lib.MixSrc(A_u8.data_ptr(), B_u8.data_ptr(), Z.data_ptr(), self.n_a, 0)
+
+    def ptr(self):
+        return C.cast(C.pointer(self.src), C.c_void_p)
+
+
 class SlabPlan:
     """Collects (slab, destination) pairs of one backward pass; run() sums every slab into the flat
     gradient buffer with ONE cgs_reduce_slabs launch (fixed order => bitwise reproducible)."""
@@ -144,8 +160,10 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     """x: NHWC uint8 or NHWC fp32 [n,64,64,3].  Returns pooled embeds e0..e3 (pre-dropout), their argmax
     masks am0..am3, e4 [n,32], h1 [n,32], pred [n].  ``out`` may hold preallocated views to fill.
     pw = (w_ptr, b_ptr, o4[n,32]): also emit the decoder's bottleneck 1x1 conv of e4 (dec_model.4) from the head kernel."""
-    u8 = x.dtype == torch.uint8
-    _chk(x, torch.uint8 if u8 else torch.float32, "critic input")
+    mixin = isinstance(x, MixInput)
+    u8 = (not mixin) and x.dtype == torch.uint8
+    if not mixin:
+        _chk(x, torch.uint8 if u8 else torch.float32, "critic input")
     dev = x.device
     o = out if out is not None else {}
     src = x
@@ -157,7 +175,10 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
         if am is None:
             am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
-        _lib.call("cgs_conv3x3_fwd", C.byref(d), _p(src), None, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")),
+        if mixin and i == 0:
+            d.src_a = _lib.SRC_MIX
+        _lib.call("cgs_conv3x3_fwd", C.byref(d), src.ptr() if (mixin and i == 0) else _p(src), None,
+                  C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")),
                   C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".bias")), _p(e), _p(am), _stream())
         src = e
     for k, shape in (("e4", (n, 32)), ("h1", (n, 32)), ("pred", (n,))):
@@ -186,7 +207,10 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     from the decoder (valid for images < n_add; their buffers are reused as the running totals).
     dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
     Weight-gradient slabs are registered in ``plan`` (dst offsets = this module's flat layout)."""
-    u8 = x.dtype == torch.uint8
+    mixin = isinstance(x, MixInput)
+    if mixin and mix_bwd is None:
+        raise _lib.CgsError("a MixInput critic input needs mix_bwd (features.0's backward consumes the virtual mixes)")
+    u8 = (not mixin) and x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
     ws = ws if ws is not None else {}
@@ -229,7 +253,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                 nsl = lib.cgs_enc0_bwd_mix_slabs(n)
                 slab = buf("slab_enc0", (nsl, cnt))
                 plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-            _lib.call("cgs_enc0_bwd_mix", A8.shape[0], int(bool(inj)), _p(src) if need_wgrad else None, _p(d_cur),
+            _lib.call("cgs_enc0_bwd_mix", A8.shape[0], int(bool(inj)), _p(src) if (need_wgrad and not mixin) else None, _p(d_cur),
                       _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(dzp), _p(slab), _stream())
             return None
         if need_wgrad and i in BOTH_ENC and (i > 0 or (dx is not None and dx_from == 0 and not u8)):
@@ -271,12 +295,14 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
 # ------------------------------------------------------------------------------------------------
 def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
                    out: Optional[Dict[str, torch.Tensor]] = None, o4_done: bool = False,
-                   keep_hm: bool = True, fp16_mask_head: bool = False) -> Dict[str, torch.Tensor]:
+                   keep_hm: bool = True, fp16_mask_head: bool = False,
+                   zpart: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
     """x: NHWC uint8/fp32 image [n,64,64,3]; embeds = [e0,e1,e2,e3 (NHWC), e4 [n,32]].
     Returns o4 [n,32], o3..o0, hm [n,64,64,16], Z [n,64,64].  o4_done: out['o4'] was already produced by the critic's
     head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv.  keep_hm=False (inference): the 16-channel
     masker.0 output is not needed afterwards -- masker.0 and masker.2 run as one kernel and 'hm' is never stored;
-    fp16_mask_head (with keep_hm=False only, opt-in): that kernel's masker.0 GEMM takes fp16 operands (~1e-3 abs in Z)."""
+    fp16_mask_head (with keep_hm=False only, opt-in): that kernel's masker.0 GEMM takes fp16 operands (~1e-3 abs in Z).
+    zpart [4n, 2] (training): the mask layer also leaves its per-workgroup (sum |z|, sum z^2) there for the L1/L2 losses."""
     u8 = x.dtype == torch.uint8
     dev = x.device
     fp = flat.data_ptr()
@@ -313,7 +339,7 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
         b = prev if cb > 0 else None
         d = conv_desc(n, hw, ca, cb, co, u8 and name == "hm", ups, act, pool, _lib.Dropout(0.0, 0, 0, None))
         _lib.call("cgs_conv3x3_fwd", C.byref(d), _p(a), _p(b), C.c_void_p(fp + 4 * lay.off(key + ".weight")),
-                  C.c_void_p(fp + 4 * lay.off(key + ".bias")), _p(o[name]), None, _stream())
+                  C.c_void_p(fp + 4 * lay.off(key + ".bias")), _p(o[name]), _p(zpart) if name == "Z" else None, _stream())
         prev = o[name]
     return o
 

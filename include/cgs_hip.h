@@ -27,7 +27,18 @@ extern "C" {
 typedef void* cgs_stream_t; /* hipStream_t */
 
 enum { CGS_OK = 0, CGS_ERR_UNSUPPORTED = -1, CGS_ERR_BADARG = -2 };
-enum { CGS_SRC_F32 = 0, CGS_SRC_U8 = 1 };
+enum { CGS_SRC_F32 = 0, CGS_SRC_U8 = 1, CGS_SRC_MIX = 2 };
+
+/* CGS_SRC_MIX (features.0 only): `src_a` points to this HOST struct; the source image n of the launch is computed in the
+ * tile loader and never stored: n < n_a: A[n](1-Z[n]) + Z[n] B[n] (replaced), n >= n_a: B(1-Z) + Z A of A-image n - n_a
+ * (injected) -- main.py:395,406.  a, b: uint8 [n_a,64,64,3]; z: fp32 [n_a,64,64] (all device pointers).            */
+typedef struct {
+    const uint8_t* a;
+    const uint8_t* b;
+    const float* z;
+    int32_t n_a;
+    int32_t reserved;
+} cgs_mix_src;
 enum { CGS_ACT_NONE = 0, CGS_ACT_RELU = 1, CGS_ACT_LRELU = 2, CGS_ACT_SIGMOID = 3 };
 
 /* Dropout on a tensor = Philox4x32-10 keep-mask keyed by (seed; base + element/4, site, *step).
@@ -52,7 +63,7 @@ typedef struct {
     int32_t ca;     /* channels of source A (direct / skip input) */
     int32_t cb;     /* channels of source B (nearest-upsampled low-res input); 0 = none */
     int32_t co;     /* output channels */
-    int32_t src_a;  /* CGS_SRC_F32 | CGS_SRC_U8 (uint8 image, /255 fused into the loader) */
+    int32_t src_a;  /* CGS_SRC_F32 | CGS_SRC_U8 (uint8 image, /255 fused into the loader) | CGS_SRC_MIX (see cgs_mix_src) */
     int32_t ups;    /* source B scale: 2 (source is h/2 x w/2) or 4 (source is 1x1, h = w = 4) */
     int32_t act;    /* CGS_ACT_* applied after bias */
     int32_t pool;   /* 1: fused 2x2/2 max-pool after the activation */
@@ -65,7 +76,9 @@ typedef struct {
  *   out   : [n, h, w, co]  (pool=0)  or [n, h/2, w/2, co] (pool=1)
  *   amask : pool=1 only, may be NULL.  uint32 [n, h/2, w/2, co/8]: one nibble per channel =
  *           index (0..3, row-major in the 2x2 window, first maximum wins) of the pooled
- *           element, or 0xF when the pooled value is <= 0 (ReLU gradient is zero there).   */
+ *           element, or 0xF when the pooled value is <= 0 (ReLU gradient is zero there).
+ *           For the mask layer (h=w=64, ca=16, co=1, sigmoid, pool=0) the same slot optionally receives, as floats
+ *           [n*4][2], the per-workgroup partial sums (sum |z|, sum z^2) that cgs_phase2_losses consumes.         */
 int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const float* src_b,
                     const float* w_hwio, const float* bias, float* out, uint32_t* amask,
                     cgs_stream_t stream);
@@ -157,8 +170,9 @@ int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_coun
 /* ---- features.0 backward of the replaced / injected passes + mix backward in one launch ----------------------
  * (main.py:395,406 backward chained onto convolution_backward of features.0).  n_a A-images; the mixes are images
  * [0,n_a) = replaced, [n_a,2 n_a) = injected (inject != 0).  dy [n_mix,32,32,8] + amask: gradient at features.0's pooled
- * output; mixed [n_mix,64,64,3] + slab [cgs_enc0_bwd_mix_slabs(n_mix)][224]: inputs/outputs of the weight gradient (both
- * NULL: data path only, frozen critic).  a, b: uint8 frames [n_a,64,64,3]; z [n_a,64,64]; l1/l2_scale as cgs_mix_bwd.
+ * output; slab [cgs_enc0_bwd_mix_slabs(n_mix)][224]: weight-gradient partials (NULL: data path only, frozen critic);
+ * mixed [n_mix,64,64,3]: the weight gradient's input if the mixes were materialised, NULL: they are recomputed from a, b, z
+ * in the tile loader (as cgs_conv3x3_fwd with CGS_SRC_MIX does).  a, b: uint8 frames [n_a,64,64,3]; z [n_a,64,64]; l1/l2_scale as cgs_mix_bwd.
  * Writes dzpre [n_a,64,64] = what cgs_conv3x3_bwd_data -> cgs_mix_bwd would (bit-identical); the image gradients are
  * never stored.                                                                                                  */
 int cgs_enc0_bwd_mix_slabs(int32_t n_mix);
