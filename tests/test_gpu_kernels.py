@@ -520,3 +520,51 @@ def test_enc0_backward_with_mix_backward_equals_two_launches(ctx, inject, wgrad)
     if wgrad:
         assert torch.equal(slab, s_ref)
     assert lib.cgs_enc0_bwd_mix(n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, P(dz), None, st) < 0
+
+
+def test_virtual_mixes_equal_materialised_mixes(ctx):
+    """CGS_SRC_MIX: features.0 forward (and its weight gradient inside cgs_enc0_bwd_mix with mixed=NULL) on the mixes computed
+    in the tile loader == the same kernels on the output of cgs_mix_fwd; the mask layer's z partial sums == cgs_mix_fwd's."""
+    from cgs_amd import _lib
+    import ctypes as C
+    hg, dev, lc, fc = ctx["hg"], ctx["dev"], ctx["lc"], ctx["fc"]
+    lib = _lib.load()
+    n_a = 9
+    rs = np.random.RandomState(123)
+    A = torch.from_numpy(rs.randint(0, 256, (n_a, 64, 64, 3)).astype(np.uint8)).to(dev)
+    B = torch.from_numpy(rs.randint(0, 256, (n_a, 64, 64, 3)).astype(np.uint8)).to(dev)
+    Z = torch.from_numpy(rs.rand(n_a, 64, 64).astype(np.float32)).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    mixed = torch.empty(2 * n_a, 64, 64, 3, device=dev)
+    zp = torch.empty(2 * lib.cgs_mix_fwd_partials(n_a, 4096), device=dev)
+    _lib.call("cgs_mix_fwd", n_a, 4096, P(A), P(B), P(Z), 1, P(mixed), P(zp), st)
+    # forward
+    c_ref = hg.critic_forward(fc, lc, mixed, 2 * n_a)
+    c_vir = hg.critic_forward(fc, lc, hg.MixInput(A, B, Z), 2 * n_a)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c_vir["e0"].cpu().numpy(), c_ref["e0"].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c_vir["pred"].cpu().numpy(), c_ref["pred"].cpu().numpy(), rtol=1e-5, atol=1e-7)
+    # weight gradient inside the fused backward
+    dy = torch.from_numpy(rs.randn(2 * n_a, 32, 32, 8).astype(np.float32)).to(dev)
+    am = c_ref["am0"]
+    w = C.c_void_p(fc.data_ptr() + 4 * lc.off("features.0.weight"))
+    ns = lib.cgs_enc0_bwd_mix_slabs(2 * n_a)
+    s_ref, s_vir = torch.zeros(ns, 224, device=dev), torch.zeros(ns, 224, device=dev)
+    dz_ref, dz_vir = torch.empty(n_a, 64, 64, device=dev), torch.empty(n_a, 64, 64, device=dev)
+    _lib.call("cgs_enc0_bwd_mix", n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, P(dz_ref), P(s_ref), st)
+    _lib.call("cgs_enc0_bwd_mix", n_a, 1, None, P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, P(dz_vir), P(s_vir), st)
+    torch.cuda.synchronize()
+    assert torch.equal(dz_ref, dz_vir)
+    rel_close(s_vir.sum(0).cpu().numpy(), s_ref.sum(0).cpu().numpy(), "features.0 weight gradient on virtual mixes", rtol=1e-4)
+    # z partial sums out of the mask layer
+    h = torch.from_numpy(rs.randn(n_a, 64, 64, 16).astype(np.float32)).to(dev)
+    lm, fm = ctx["lm"], ctx["fm"]
+    d = hg.conv_desc(n_a, 64, 16, 0, 1, False, 2, "sigmoid", 0, _lib.Dropout())
+    zout, zpart = torch.empty(n_a, 64, 64, device=dev), torch.full((4 * n_a, 2), float("nan"), device=dev)
+    _lib.call("cgs_conv3x3_fwd", C.byref(d), P(h), None, C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.2.weight")),
+              C.c_void_p(fm.data_ptr() + 4 * lm.off("masker.2.bias")), P(zout), P(zpart), st)
+    torch.cuda.synchronize()
+    zz = zout.double()
+    np.testing.assert_allclose(zpart[:, 0].double().sum().item(), zz.abs().sum().item(), rtol=1e-5)
+    np.testing.assert_allclose(zpart[:, 1].double().sum().item(), (zz * zz).sum().item(), rtol=1e-5)
