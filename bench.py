@@ -217,7 +217,7 @@ def main():
         launch_ms = dev_ms / args.steps
         achieved = ALGO_BYTES_PER_IMAGE * n / (launch_ms * 1e-3) / 1e9
         out = {
-            "metric": "Hourglass+critic train images/sec, 64x64x3 batch=512",
+            "metric": f"Hourglass+critic train images/sec, 64x64x3 batch={n}",
             "value": n * world * args.steps / wall,
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
