@@ -53,21 +53,30 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
     const int N = P.n;
     const DropCtx dc = drop_ctx(P.drop);
 
-    int rbase[NRB];
+    // Work split over the workgroup's waves.  Default: every wave keeps all row blocks and the waves split the tile ROWS (k
+    // dimension) -> cross-wave sum at the end.  Small maps with many row blocks (dec_model.2/3: 14-28 blocks, 4x4 / 8x8
+    // pixels): the waves split the ROW BLOCKS and each walks all pixels -> no reduction (it cost more than the MFMAs
+    // there), each wave writes its rows of the slab itself.  (On the 16x16 / 32x32 decoder layers the uneven block split
+    // -- 10 blocks over 4 waves -- costs more than the reduction saves: measured 37 vs 30 us on dec_model.0.)
+    constexpr bool MSPLIT = NRB >= 2 * G::NW && G::H <= 8;
+    constexpr int NRBW = MSPLIT ? (NRB + G::NW - 1) / G::NW : NRB;     // row blocks held by one wave
+    int rbase[NRBW];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) {
+    for (int rbi = 0; rbi < NRBW; ++rbi) {
+        const int rb = MSPLIT ? wave + rbi * G::NW : rbi;
         int r = rb * 16 + l15;
+        if (MSPLIT && rb >= NRB) r = ROWS + 16;      // a wave's surplus slot: padding rows
         if (r < 9 * CI) {
             int tap = r / CI, ci = r % CI;
             int lch = ci < C::CA ? ci : 4 * SA + (ci - C::CA);
-            rbase[rb] = ((tap / 3) * G::PWA + (tap % 3)) * PCI + lch;
+            rbase[rbi] = ((tap / 3) * G::PWA + (tap % 3)) * PCI + lch;
         } else {
-            rbase[rb] = (r == 9 * CI) ? -1 : -2;
+            rbase[rbi] = (r == 9 * CI) ? -1 : -2;
         }
     }
-    frag4 acc[NRB];
+    frag4 acc[NRBW];
 #pragma unroll
-    for (int rb = 0; rb < NRB; ++rb) acc[rb] = frag4{0.f, 0.f, 0.f, 0.f};
+    for (int rb = 0; rb < NRBW; ++rb) acc[rb] = frag4{0.f, 0.f, 0.f, 0.f};
 
     // ------------------------------------------------------------------------------------------
     // Software pipeline over this workgroup's tiles: the global loads of tile t+1 are issued into
@@ -223,7 +232,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
         }
     };
 
-    constexpr int U = NRB >= 16 ? 1 : (NRB >= 8 ? 2 : 4);
+    constexpr int U = NRBW >= 16 ? 1 : (NRBW >= 8 ? 2 : 4);
     int tile = tile0;
     if (tile < tend) fetch(tile);
     for (; tile < tend; tile += tstride) {
@@ -234,22 +243,22 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
         // address is (per-row base) + immediate offset: no per-step index arithmetic next to the MFMAs.
         constexpr int NROWS = G::IMGS * G::TH, SPR = G::W / 4;
         constexpr int UU = SPR < U ? SPR : U;
-        for (int R = wave; R < NROWS; R += G::NW) {
+        for (int R = MSPLIT ? 0 : wave; R < NROWS; R += MSPLIT ? 1 : G::NW) {
             const int img = R / G::TH, yl = R % G::TH;
             const int xrow = ((img * G::TRA + yl) * G::PWA + kq) * PCI;
             const int yrow = ((img * G::TH + yl) * G::W + kq) * CO + (l15 < CO ? l15 : 0);
-            int xa[NRB];
+            int xa[NRBW];
 #pragma unroll
-            for (int rb = 0; rb < NRB; ++rb) xa[rb] = xrow + (rbase[rb] >= 0 ? rbase[rb] : 0);
+            for (int rb = 0; rb < NRBW; ++rb) xa[rb] = xrow + (rbase[rb] >= 0 ? rbase[rb] : 0);
 #pragma unroll
             for (int c = 0; c < SPR; c += UU) {
-                float a[UU][NRB], b[UU];
+                float a[UU][NRBW], b[UU];
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     float bv = yt[yrow + (c + u) * 4 * CO];
                     b[u] = (l15 < CO) ? bv : 0.f;
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb) {
+                    for (int rb = 0; rb < NRBW; ++rb) {
                         float av = xt[xa[rb] + (c + u) * 4 * PCI];
                         a[u][rb] = (rbase[rb] >= 0) ? av : (rbase[rb] == -1 ? 1.f : 0.f);
                     }
@@ -257,7 +266,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
 #pragma unroll
                 for (int u = 0; u < UU; ++u)
 #pragma unroll
-                    for (int rb = 0; rb < NRB; ++rb)
+                    for (int rb = 0; rb < NRBW; ++rb)
                         acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][rb], b[u], acc[rb], 0, 0, 0);
                 asm volatile("" ::: "memory");   // keep the next chunk's LDS reads behind this chunk's (bounded registers)
             }
@@ -267,6 +276,20 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
 
     // ---- sum the waves' accumulators through LDS (wave by wave), then one coalesced slab per workgroup ----
     // D layout: col = lane & 15 (= co), row = (lane >> 4) * 4 + reg (= r within the row block)
+    if constexpr (MSPLIT) {
+        // every wave owns its row blocks outright: straight to the slab (64-byte runs per row)
+        if (l15 < CO) {
+#pragma unroll
+            for (int rbi = 0; rbi < NRBW; ++rbi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = (wave + rbi * G::NW) * 16 + kq * 4 + j;
+                    if (r < ROWS) slab[r * CO + l15] = acc[rbi][j];
+                }
+        }
+        __syncthreads();   // the LDS region may be reused by a following stage
+        return;
+    }
     float* red = (float*)smem;
     static_assert(ROWS * CO <= XT4 * 4 + YT, "reduction buffer fits in the tile storage");
 #pragma unroll 1
