@@ -268,8 +268,10 @@ class Handler:
         os.makedirs(self.path, exist_ok=True)
         if args.noevalmode:
             raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
-        if args.salience or args.process_salience or args.crf:
-            raise NotImplementedError("-salience / -process_salience / -crf are outside this build's scope")
+        if args.crf:
+            raise NotImplementedError("-crf is outside this build's scope")
+        if args.process_salience and not args.salience:
+            raise ValueError("-process_salience needs -salience (the reference collects the maps only then, main.py:1136-1147)")
         self.critic.eval()
         self.masker.eval()
         eng = self._engine(2 * 32)
@@ -277,19 +279,25 @@ class Handler:
         img_names = os.listdir(folder)
         X = np.stack([np.array(Image.open(f"{folder}/{name}"))[..., :3] for name in img_names]) / 255.0
         img_names = [a[:-1 - a[::-1].index(".")] for a in img_names if "." in a]
-        M, preds = [], []
+        M, preds, salM = [], [], []
         for bidx in range(0, len(X), batchsize):
             print("segmentation in progress", round(bidx / len(X), 2), end="%\r")
             batch = torch.from_numpy(X[bidx:bidx + batchsize]).float().to(self.device)   # NHWC fp32 in [0,1]
+            if args.salience:           # main.py:1136-1147: |d mean(pred) / d batch| summed over the colour channels
+                _p, dx = eng.saliency(batch)
+                salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
             pred, Z = eng.infer(batch)
             preds.append(pred.cpu().numpy())
             M.append(Z.cpu().numpy()[:, None])
         print()
         print("postprocessing...")
         M = np.concatenate(M, axis=0)
+        preds = np.concatenate(preds, axis=0)
         allM = [M]
         if args.binarymaskthreshold:
             allM.append(M >= args.binarymaskthreshold)
+        if args.process_salience:       # main.py:1176-1197 (file names follow the reference's column list by POSITION)
+            allM.extend(self._saliency_post(np.concatenate(salM, axis=0), preds, args.salience_thresh, args.salglobal))
         outpath = args.mask_output_imgs
         os.makedirs(outpath, exist_ok=True)
         masks = np.stack([X] + [np.concatenate((m, m, m), axis=1).transpose(0, 2, 3, 1) for m in allM], axis=1)
@@ -304,6 +312,21 @@ class Handler:
                         f"{outpath}/{img_names[fidx]}-{columns[midx - 1]}.png")
         return M
 
+    @staticmethod
+    def _saliency_post(salM, preds, thresh, salglobal):
+        """main.py:976-1003 / 1176-1197: normalise the |gradient| maps (global mean x thresh, or each map's k-th sorted
+        value), weight by the critic's prediction, clip at 1, threshold.  Returns (salM, salhardM uint8)."""
+        import sys as _sys
+        if salglobal:
+            norm = (salM * (salM >= 0)).mean() * thresh
+        else:
+            k = int(salM.shape[-1] * salM.shape[-2] * thresh)
+            norm = np.sort(salM.reshape(salM.shape[0], 1, -1), axis=-1)[:, :, k, None, None]
+        salM = salM / (norm + _sys.float_info.min)
+        salM = salM * preds[:, None, None, None]
+        salM[(salM >= 1)] = 1
+        return salM, (salM > thresh).astype(np.uint8)
+
     # ------------------------------------------------------------------ -eval: IoU on the labelled red-trees set
     @staticmethod
     def get_iou(A, B):
@@ -317,7 +340,6 @@ class Handler:
         at --eval-thresh, IoU against `all(Y.npy, axis=-1)`; with -salience also the saliency baseline of main.py:941-953,
         976-1003 (|d mean(pred)/dX| summed over channels, normalised, weighted by pred, thresholded) and its IoU.
         Returns [iou] or [iou, saliou] like the reference."""
-        import sys as _sys
         args = self.args
         if args.noevalmode:
             raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
@@ -351,17 +373,7 @@ class Handler:
         Yc = Y.transpose(0, 3, 1, 2)
         ious = [self.get_iou(hardM.squeeze(), Yc.squeeze())]
         if args.salience:
-            salM = np.concatenate(salM, axis=0)
-            thresh = args.salience_thresh
-            if args.salglobal:
-                norm = (salM * (salM >= 0)).mean() * thresh
-            else:
-                k = int(salM.shape[-1] * salM.shape[-2] * thresh)
-                norm = np.sort(salM.reshape(salM.shape[0], 1, -1), axis=-1)[:, :, k, None, None]
-            salM = salM / (norm + _sys.float_info.min)
-            salM = salM * preds[:, None, None, None]
-            salM[(salM >= 1)] = 1
-            salhardM = (salM > thresh).astype(np.uint8)
+            salM, salhardM = self._saliency_post(np.concatenate(salM, axis=0), preds, args.salience_thresh, args.salglobal)
             ious.append(self.get_iou(salhardM.squeeze(), Yc.squeeze()))
         print(f"\nRESULTS", ious)
         return ious

@@ -176,6 +176,22 @@ def test_cli_train_then_process(tmp_path):
     img = np.array(Image.open(os.path.join(root, "out2", "frame.0_with_mask.png")))
     assert img.shape == (64, 192, 3)
     np.testing.assert_array_equal(img[:, :64], X[0])
+    # -salience -process_salience: two more images per frame, named by position in the reference's column list
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-process", "-salience", "-process_salience",
+                        "--salience-thresh", "0.5", "--source-imgs", "in", "--mask-output-imgs", "out3"] + common, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    names = sorted(os.listdir(os.path.join(root, "out3")))
+    assert names == sorted(f"frame.{i}-{c}.png" for i in range(5)
+                           for c in ("raw-mask", "thresholded-mask", "crf-mask", "saliency-map"))
+    Xc = orc.u8_to_nchw(X[:5]).clone().requires_grad_(True)
+    pr = orc.critic_apply(pc, Xc)
+    pr.mean().backward()
+    raw_sal = Xc.grad.abs().sum(dim=1)[:, None].numpy()
+    sal = raw_sal / ((raw_sal * (raw_sal >= 0)).mean() * 0.5 + sys.float_info.min) * pr.detach().numpy()[:, :, None, None]
+    sal[sal >= 1] = 1
+    got_sal = np.array(Image.open(os.path.join(root, "out3", "frame.2-crf-mask.png")))[..., 0].astype(int)
+    assert np.abs(got_sal - (sal[2, 0] * 255).astype(np.uint8).astype(int)).max() <= 2
     # -eval: IoU on a (synthetic) red-trees set in the working directory, against the oracle on the trained weights
     os.makedirs(os.path.join(root, "red-trees"))
     rs = np.random.RandomState(11)
