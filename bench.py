@@ -16,8 +16,12 @@ Prints ONE JSON line on rank 0 (see the contract in the task description):
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
+
+# dmabuf IPC only on this driver: must be in the environment BEFORE the HIP runtime initialises (RCCL / torch read it at init)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 
@@ -163,9 +167,32 @@ def side_mode(args, dev, world, rank):
                                    "traffic": None}}), flush=True)
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) as a CHILD torchrun job and
+    exit with its code.  Nothing in this parent has touched the GPU (torch.cuda.device_count() does not initialise HIP on
+    this image), and the parent does not exec: it waits for the child."""
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr, flush=True)
+        return 2
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -173,11 +200,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    ranks_seen, backend = 1, None
+    if world > 1 or os.environ.get("CGS_BENCH_FORCE_PG") == "1":     # (forced: a 1-rank RCCL group, to rehearse the N>1 code path)
         import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
         pg = dist.group.WORLD
+        ranks_seen, backend = dist.get_world_size(), dist.get_backend()
 
     from cgs_amd import engine
     n = args.batch
@@ -189,7 +219,7 @@ def main():
     eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +261,9 @@ def main():
                                    "synthetic 64x64x3 uint8 frames resident in HBM, chfak=1, neck=32",
                        "contrastive_batchsize": n // 2, "N_A": n, "N_B": n, "global_batch": n * world,
                        "dropout": args.dropout, "lfak": 5, "L1": 0.5, "inject": True, "live": True,
-                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
+                       "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                       "ranks_seen_by_collective_backend": ranks_seen, "collective_backend": backend,
+                       "gradient_allreduce": "one flat fp32 bucket (25 661 floats) per step between the two step graphs" if pg is not None else None},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "kernel": "one phase-2 step = one HIP-graph launch",
@@ -242,7 +274,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps, args.dropout)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

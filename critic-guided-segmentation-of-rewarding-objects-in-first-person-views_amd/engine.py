@@ -10,6 +10,7 @@ Data parallelism: one process per GPU, each with its own N images; the only exch
 of the flat gradient buffer (25 661 floats) between the slab reduction and Adam.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -45,6 +46,10 @@ class HourglassEngine:
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
+        # data parallel: the all-reduce sits between the step graph and the Adam graph.  CGS_FORCE_ALLREDUCE=1 keeps that
+        # three-launch form for a 1-rank group too (rehearsal of the RCCL path on a 1-GPU box).
+        self.dp = process_group is not None and (self.world > 1 or os.environ.get("CGS_FORCE_ALLREDUCE") == "1")
         self.lc, self.lm = critic_layout(), masker_layout()
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         self.total = self.off_m + self.lm.total
@@ -57,7 +62,8 @@ class HourglassEngine:
             self.step_t = z(1, dt=torch.int64)
         self.fc, self.fm = self.flat[:self.lc.total], self.flat[self.off_m:]
         self.gc, self.gm = self.grad[:self.lc.total], self.grad[self.off_m:]
-        self.drop = hg.DropState(self.p, seed, self.step_t)
+        # every rank draws its own dropout stream (the global batch then holds independent masks, as one process would)
+        self.drop = hg.DropState(self.p, (seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF, self.step_t)
         n4 = 4 * n
         self.ab = z(2 * n, 64, 64, 3, dt=torch.uint8)       # [B | A]
         self.y = z(n)
@@ -139,7 +145,7 @@ class HourglassEngine:
                   self.lr, self.b1, self.b2, self.eps, 1.0 / self.world, _S())
 
     def _allreduce(self):
-        if self.pg is not None and self.world > 1:
+        if self.dp:
             lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
             parallel.allreduce_sum_(self.grad[lo:lo + cnt], self.pg)
 
@@ -268,7 +274,7 @@ class HourglassEngine:
     # ---- execution: eager first call (allocates workspaces, builds job tables), then HIP-graph replay ----
     def _run(self, tag: str, body):
         adam = self._adam if tag == "p2" else self._adam_p1
-        if tag == "p1" and self.pg is not None and self.world > 1:
+        if tag == "p1" and self.dp:
             def allred():
                 parallel.allreduce_sum_(self.grad[:self.lc.total], self.pg)
         else:
@@ -284,10 +290,10 @@ class HourglassEngine:
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 body()
-                if self.world == 1:
+                if not self.dp:
                     adam()
             g2 = None
-            if self.world > 1:
+            if self.dp:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     adam()
@@ -306,6 +312,7 @@ class HourglassEngine:
     def saliency(self, X: torch.Tensor):
         """Eval-mode critic forward + backward to the input.  X: NHWC fp32 [b,64,64,3] in [0,1] on the device.
         Returns (pred [b], d mean(pred)/dX [b,64,64,3]); the caller takes abs().sum(channels) like the reference."""
+        hg._chk_img(X, 0, "saliency input")
         b = X.shape[0]
         X = X.contiguous()
         if X.dtype != torch.float32:
@@ -321,6 +328,7 @@ class HourglassEngine:
     def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
         Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM."""
+        hg._chk_img(X, 0, "infer input")
         b = X.shape[0]
         if not want_mask:
             return hg.critic_forward(self.fc, self.lc, X.contiguous(), b)["pred"], None

@@ -151,8 +151,16 @@ class Handler:
             break
 
     # ------------------------------------------------------------------ phase 1: critic regression
+    def _refuse_unbuilt_flags(self):
+        """Flags the reference reads on this path that this build does not implement: refuse instead of training something else."""
+        a = self.args
+        if not a.staticnorm:
+            raise NotImplementedError("-staticnorm '' (mask regulariser weighted by 1 - pred, main.py:415-418) is not implemented "
+                                      "by the HIP loss kernels; the engine uses valuefak = 1")
+
     def critic_pipe(self, mode="train", test=0):
         args = self.args
+        self._refuse_unbuilt_flags()
         if args.cload and self.load_models([self.criticname]):
             print("loaded critic, no new training")
             return
@@ -164,6 +172,9 @@ class Handler:
         self.critic.train()
         self._engine(self.batch_size)
         self._reset_adam()                       # a fresh torch.optim.Adam(critic.parameters()) (main.py:178)
+        if args.directeval:                      # main.py:179-180
+            self.eval()
+            self.critic.train()
         for epoch in range(int(mode == "test") or args.cepochs):
             for b_idx, (X, Y) in enumerate(self._batches()):
                 if args.shift:
@@ -218,6 +229,7 @@ class Handler:
     # ------------------------------------------------------------------ phase 2: mask training
     def segmentation_training(self):
         args = self.args
+        self._refuse_unbuilt_flags()
         self.extract_contrastive_data()
         train_path = self.path + "segment/"
         os.makedirs(train_path, exist_ok=True)
@@ -229,6 +241,10 @@ class Handler:
         n = 2 * self.contrastive_batchsize
         eng = self._engine(n, live=args.live)
         self._reset_adam()                       # a fresh Adam over critic+masker (live) or masker (frozen)
+        if args.directeval:                      # main.py:337-338
+            self.eval()
+            self.critic.train()
+            self.masker.train()
         for epoch in range(args.mepochs):
             for b_idx in range(math.ceil(self.Xpos.shape[0] / self.contrastive_batchsize)):
                 Hidx, Lidx, Cidx = self.get_contrastive_idxs()

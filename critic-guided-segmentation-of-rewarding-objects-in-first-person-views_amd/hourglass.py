@@ -46,6 +46,14 @@ def _chk(t: torch.Tensor, dtype, what: str):
     return t
 
 
+def _chk_img(x, n: int, what: str):
+    """The kernels hard-code 64x64x3 NHWC frames and read n*64*64*3 elements: anything else is refused before a launch
+    (the reference fails with a shape error from its first Linear in the same situation, nets.py:189-190)."""
+    shp = tuple(x.shape) if not isinstance(x, MixInput) else (x.n_a, 64, 64, 3)
+    if len(shp) != 4 or shp[1:] != (64, 64, 3) or (not isinstance(x, MixInput) and shp[0] < n):
+        raise _lib.CgsError(f"{what}: expected an NHWC image batch [>={n},64,64,3], got {shp}")
+
+
 class DropState:
     """Dropout configuration of a pass: probability, Philox seed, the device step counter and the index of
     the pass's first image inside the batch buffer (so differently sliced launches draw the same masks)."""
@@ -164,6 +172,7 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     u8 = (not mixin) and x.dtype == torch.uint8
     if not mixin:
         _chk(x, torch.uint8 if u8 else torch.float32, "critic input")
+    _chk_img(x, n, "critic input")
     dev = x.device
     o = out if out is not None else {}
     src = x
@@ -304,6 +313,8 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     fp16_mask_head (with keep_hm=False only, opt-in): that kernel's masker.0 GEMM takes fp16 operands (~1e-3 abs in Z).
     zpart [4n, 2] (training): the mask layer also leaves its per-workgroup (sum |z|, sum z^2) there for the L1/L2 losses."""
     u8 = x.dtype == torch.uint8
+    _chk(x, torch.uint8 if u8 else torch.float32, "masker image input")
+    _chk_img(x, n, "masker image input")
     dev = x.device
     fp = flat.data_ptr()
     o = out if out is not None else {}

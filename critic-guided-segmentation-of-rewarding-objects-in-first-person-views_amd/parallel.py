@@ -20,7 +20,9 @@ def init_from_env(backend: Optional[str] = None):
     rank, local, world = env_world()
     if world <= 1:
         return None
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
+    # dmabuf IPC only on this driver.  The HIP runtime reads this at initialisation: launchers should export it themselves
+    # (bench.py sets it before importing torch); setting it here only helps when nothing has touched the GPU yet.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
@@ -49,7 +51,7 @@ def _host_staged(flat: torch.Tensor, group) -> bool:
 
 def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
     """In-place sum all-reduce of one flat bucket (single collective: latency-bound at this size)."""
-    if group is not None and dist.get_world_size(group) > 1:
+    if group is not None:
         if _host_staged(flat, group):
             tmp = flat.cpu()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)

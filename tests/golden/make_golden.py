@@ -17,6 +17,7 @@ Fixtures (all float32 unless noted):
   g2_eval.npz            eval-mode forward: pred, 5 embeds, decoder intermediates, mask
   g2_eval_chfak5.npz     same for the paper-size model (weights = oracle.seeded_params seeds)
   g3_train_*.npz         phase-2 step, dropout=0: losses, grads, params after steps 1..3
+                         (default / -noinject / -frozen / --L2 0.1 / --threshrew 0.5 = BCE live-critic loss, main.py:380-381)
   g4_phase1_*.npz        phase-1 step: loss, grads, params after step 1 (mse and bce variants)
   g5_shift.npz           shift_batch under torch.manual_seed(k)
   g7_dropout.npz         phase-2 step with dropout 0.3 and the recorded keep-masks
@@ -124,7 +125,7 @@ np.savez(os.path.join(HERE, "g2_eval_chfak5.npz"), X=g25["X"], pred=g25["pred"],
 
 
 # ---------------------------------------------------------------- G3 / G7: phase-2 steps
-def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False):
+def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False, threshrew=0.0):
     from itertools import chain
     critic, masker = build(1, dropout=dropout)
     load_np(critic, "critic", g1); load_np(masker, "masker", g1)
@@ -133,6 +134,8 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
         else torch.optim.Adam(masker.parameters())
     a_u8, b_u8 = frames(0, 8), frames(1, 8)
     Y = torch.from_numpy(np.random.RandomState(2).rand(8)).float()
+    if threshrew:       # load_data binarises the targets (main.py:124-127), the step then uses BCE (main.py:380-381)
+        Y = (Y > threshrew).float()
     out = {"A": a_u8, "B": b_u8, "Y": Y.numpy()}
     masks = []
     orig_dropout = F.dropout
@@ -154,7 +157,7 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
             loss = 0
             parts = np.zeros(5, np.float64)  # critic, replace, inject, L1, L2
             if live:
-                cl = F.mse_loss(pred, Y)
+                cl = F.binary_cross_entropy(pred, Y) if threshrew else F.mse_loss(pred, Y)
                 loss = loss + lfak * cl; parts[0] = cl.item()
             Z = masker(A, embeds)
             replaced = A * (1 - Z) + Z * B
@@ -198,6 +201,7 @@ phase2("g3_train_default")
 phase2("g3_train_noinject", inject=False)
 phase2("g3_train_frozen", live=False)
 phase2("g3_train_l2", L2=0.1)
+phase2("g3_train_bce", threshrew=0.5)
 phase2("g7_dropout", steps=1, dropout=0.3, record_masks=True)
 
 

@@ -29,6 +29,7 @@ def make_engine(g1, n, **kw):
     ("g3_train_noinject", dict(inject=False)),
     ("g3_train_frozen", dict(live=False)),
     ("g3_train_l2", dict(L2=0.1)),
+    ("g3_train_bce", dict(threshrew=0.5)),      # --threshrew: BCE live-critic loss (main.py:380-381)
 ])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_phase2_matches_reference_capture(golden, g1, tag, kw, use_graph):
@@ -89,9 +90,10 @@ def _export_masks(e, n_imgs_total, step_value):
     return out
 
 
-def test_phase2_with_dropout_vs_oracle_masks(g1):
-    """dropout 0.3, train mode: the oracle is fed the keep-masks the kernels drew (slot order B, A, rep, inj)."""
-    n = 12
+@pytest.mark.parametrize("n", [12, 512])
+def test_phase2_with_dropout_vs_oracle_masks(g1, n):
+    """dropout 0.3, train mode: the oracle is fed the keep-masks the kernels drew (slot order B, A, rep, inj).
+    n = 512 is the benchmark configuration itself (BASELINE.json config 2): losses, all 28 gradients, updated parameters."""
     rs = np.random.RandomState(42)
     dev = torch.device("cuda:0")
     A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
@@ -114,6 +116,10 @@ def test_phase2_with_dropout_vs_oracle_masks(g1):
         rel_close(gc[k].cpu().numpy(), v.numpy(), f"critic grad {k}")
     for k, v in rec["grads_m"].items():
         rel_close(gm[k].cpu().numpy(), v.numpy(), f"masker grad {k}")
+    for k, v in rec["params_c"].items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"critic {k} after the step", rtol=1e-3, atol_scale=1e-4)
+    for k, v in rec["params_m"].items():
+        rel_close(e.masker_state()[k].cpu().numpy(), v.numpy(), f"masker {k} after the step", rtol=1e-3, atol_scale=1e-4)
 
 
 def test_graph_replay_equals_eager_and_is_reproducible(g1):

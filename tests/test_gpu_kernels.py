@@ -48,10 +48,22 @@ def test_layout_roundtrip(ctx):
         np.testing.assert_array_equal(back[k].cpu().numpy(), v.numpy())
 
 
-@pytest.mark.parametrize("n", [8, 5, 37])
-def test_forward_matches_oracle(ctx, golden, n):
+def tie_frames(n, seed):
+    """Frames like real first-person views have: flat patches.  Constant-colour 8x8 blocks (every 2x2 pool window inside a
+    block is a 4-way tie of equal conv outputs), images made of rows repeated four times (vertical ties), one flat image."""
+    rs = np.random.RandomState(seed)
+    blocks = rs.randint(0, 256, (n, 8, 8, 3)).astype(np.uint8)
+    x = np.repeat(np.repeat(blocks, 8, axis=1), 8, axis=2)
+    rows = rs.randint(0, 256, (n, 16, 64, 3)).astype(np.uint8)
+    x[2::3] = np.repeat(rows, 4, axis=1)[2::3]
+    x[-1] = 200
+    return np.ascontiguousarray(x)
+
+
+@pytest.mark.parametrize("n,kind", [(8, "noise"), (5, "noise"), (37, "noise"), (13, "ties")])
+def test_forward_matches_oracle(ctx, golden, n, kind):
     hg, dev = ctx["hg"], ctx["dev"]
-    x_u8 = np.random.RandomState(10 + n).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    x_u8 = np.random.RandomState(10 + n).randint(0, 256, (n, 64, 64, 3)).astype(np.uint8) if kind == "noise" else tie_frames(n, 7)
     X = orc.u8_to_nchw(x_u8)
     with torch.no_grad():
         pred, embeds = orc.critic_apply(ctx["pc"], X, collect=True)
@@ -108,6 +120,45 @@ def test_pool_argmax_mask(ctx):
         assert (nib[~dead] == ref_pos[~dead]).mean() > 0.9999
 
 
+def test_pool_argmax_first_index_on_ties(ctx):
+    """max_pool2d keeps the FIRST maximum of a window (row-major); on frames with flat patches equal positive conv outputs
+    tie constantly.  Every nibble of all four pooling stages must equal the reference index wherever the pooled value is
+    positive -- checked where the window's two largest values are exactly equal (a true tie) or clearly apart (positions a
+    last-bit rounding difference between the CPU and GPU convolutions cannot reorder)."""
+    hg, dev = ctx["hg"], ctx["dev"]
+    n = 13
+    x_u8 = tie_frames(n, 7)
+    F = torch.nn.functional
+    c = hg.critic_forward(ctx["fc"], ctx["lc"], torch.from_numpy(x_u8).to(dev), n)
+    torch.cuda.synchronize()
+    keys = ["features.0", "features.3", "features.6", "features.10"]
+    h = orc.u8_to_nchw(x_u8)
+    ties_total = 0
+    with torch.no_grad():
+        for i, key in enumerate(keys):
+            pre = torch.relu(F.conv2d(h, ctx["pc"][key + ".weight"], ctx["pc"][key + ".bias"], padding=1))
+            pooled, idx = F.max_pool2d(pre, 2, return_indices=True)
+            hw = pre.shape[-1]
+            win = pre.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, pre.shape[1], hw // 2, hw // 2, 4)
+            top2 = win.topk(2, dim=-1).values
+            gap = (top2[..., 0] - top2[..., 1]).numpy()
+            exact_tie = gap == 0
+            clear = gap > 1e-4 * max(float(pre.max()), 1e-6)
+            am = c[f"am{i}"].cpu().numpy().astype(np.uint32)            # [n, hp, wp, co/8]
+            yy, xx = np.meshgrid(np.arange(hw // 2), np.arange(hw // 2), indexing="ij")
+            for ch in range(pre.shape[1]):
+                nib = (am[..., ch // 8] >> (4 * (ch % 8))) & 15
+                ii = idx[:, ch].numpy()
+                ref_pos = ((ii // hw) - 2 * yy) * 2 + ((ii % hw) - 2 * xx)
+                pos = pooled[:, ch].numpy() > 0
+                assert (nib[~pos] == 15).all(), f"{key} ch{ch}: dead windows must carry 0xF"
+                chk = pos & (exact_tie[:, ch] | clear[:, ch])
+                assert (nib[chk] == ref_pos[chk]).all(), f"{key} ch{ch}: argmax differs from max_pool2d's first index"
+                ties_total += int((pos & exact_tie[:, ch]).sum())
+            h = pooled
+    assert ties_total > 5000, f"the tie set exercised only {ties_total} positive ties"
+
+
 def _oracle_grads(ctx, x_u8, cot_pred, cot_embeds, cot_Z, f32_input=False):
     pc = orc.leafify(ctx["pc"])
     pm = orc.leafify(ctx["pm"])
@@ -121,12 +172,13 @@ def _oracle_grads(ctx, x_u8, cot_pred, cot_embeds, cot_Z, f32_input=False):
     return pc, pm, X, Z
 
 
-@pytest.mark.parametrize("n", [8, 21])
-def test_backward_matches_oracle_autograd(ctx, n):
-    """critic + masker backward with random cotangents on every output, vs torch autograd on the oracle."""
+@pytest.mark.parametrize("n,kind", [(8, "noise"), (21, "noise"), (13, "ties")])
+def test_backward_matches_oracle_autograd(ctx, n, kind):
+    """critic + masker backward with random cotangents on every output, vs torch autograd on the oracle.
+    kind = ties: flat-patch frames, where the pooling gradient must follow max_pool2d's first-index rule."""
     hg, dev, lc, lm = ctx["hg"], ctx["dev"], ctx["lc"], ctx["lm"]
     rs = np.random.RandomState(n)
-    x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8) if kind == "noise" else tie_frames(n, 7)
     cot_pred = torch.from_numpy(rs.randn(n).astype(np.float32))
     cot_Z = torch.from_numpy(rs.randn(n, 64, 64).astype(np.float32) * 0.1)
     shapes = [(n, 8, 32, 32), (n, 8, 16, 16), (n, 8, 8, 8), (n, 16, 4, 4), (n, 32, 1, 1)]

@@ -114,6 +114,29 @@ def test_cli_surface_matches_reference():
     assert p.process and p.concatenated and p.source_imgs == "in" and p.mask_output_imgs == "out"
 
 
+def test_handler_shift_batch_matches_reference_capture(golden):
+    """The PRODUCT shift_batch (handler.Handler.shift_batch, main.py:584-591) against the reference capture G5: same two
+    draws from the global torch RNG, bit-exact rolled batch."""
+    import types
+    g = golden("g5_shift.npz")
+    X = torch.from_numpy(g["X"])
+    me = types.SimpleNamespace(args=types.SimpleNamespace(shift=12))
+    for k in range(4):
+        torch.manual_seed(k)
+        rolled = handler.Handler.shift_batch(me, X)
+        np.testing.assert_array_equal(rolled.numpy(), g[f"rolled{k}"])
+        assert rolled.dtype == torch.uint8 and rolled.is_contiguous()
+
+
+def test_flags_outside_the_build_are_refused_not_ignored():
+    import types
+    me = types.SimpleNamespace(args=cli.parse_args(["-staticnorm", ""]))
+    assert me.args.staticnorm is False
+    with pytest.raises(NotImplementedError):
+        handler.Handler._refuse_unbuilt_flags(me)
+    handler.Handler._refuse_unbuilt_flags(types.SimpleNamespace(args=cli.parse_args([])))   # defaults pass
+
+
 def test_checkpoint_names_follow_reference_mangling():
     c, m = handler.checkpoint_names(cli.parse_args([]))
     assert c == "rewidx=1-cepochs=15-datamode=trunk-datasize=100000-shift=12-chfak=1-dropout=0.3"
