@@ -14,6 +14,9 @@ int mask_head_launch(int n, int img_kind, const void* img, const float* o0, cons
 int mask_head_slabs(int n);
 int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
                       const float* b2, float* z, hipStream_t st);
+int mask_train_partials(int n);
+int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
+                      const float* b2, float* h, float* z, float* zpart, hipStream_t st);
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st);
 static bool use_mconv() {
@@ -143,6 +146,15 @@ extern "C" int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const
     if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
     if (!use_mconv()) return CGS_ERR_UNSUPPORTED;     // VALU build: the caller runs masker.0 and masker.2 as two convolutions
     return mask_infer_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream);
+}
+
+extern "C" int cgs_mask_train_fwd_partials(int32_t n) { return n < 0 ? CGS_ERR_BADARG : mask_train_partials(n); }
+
+extern "C" int cgs_mask_train_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                  const float* w_m2, const float* b_m2, float* h, float* z, float* zpart, cgs_stream_t stream) {
+    if (n < 0 || !x || !o0 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !h || !z || !zpart) return CGS_ERR_BADARG;
+    if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
+    return mask_train_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, h, z, zpart, (hipStream_t)stream);
 }
 
 extern "C" int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0,

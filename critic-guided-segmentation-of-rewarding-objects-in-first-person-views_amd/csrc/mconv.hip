@@ -294,6 +294,9 @@ __global__ void __launch_bounds__(256) mask0_fwd_kernel(Mask0FwdParams P) {
 struct MaskInferParams {
     const void* img; const float* o0; const float* w0; const float* b0; const float* w2; const float* b2; float* z;
     int n, ntiles;
+    // training form (TRAIN = true): h (the masker.0 output the backward pass needs) is stored once from the LDS tile, and every
+    // tile leaves (sum |z|, sum z^2) for the L1 / L2 mask losses (main.py:421-429) at zpart[2 * tile]
+    float* h_out; float* zpart;
 };
 
 struct MaskInferGeo {
@@ -305,9 +308,10 @@ struct MaskInferGeo {
     static constexpr size_t LDS = (size_t)((XIMG + 3) / 4 * 4 + XO + HS + W2S) * 4;
 };
 
-template <int SRC>
+template <int SRC, bool TRAIN>
 __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
     using G = MaskInferGeo;
+    __shared__ float zred[8];
     constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, IPS = G::IPS, LR = G::LR, LC = G::LC,
                   LPS = G::LPS, HPS = G::HPS;
     constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
@@ -424,6 +428,16 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
         }
         __syncthreads();
 
+        if constexpr (TRAIN) {
+            // h rows row0 .. row0+7 (tile rows 1 .. 8) -> memory, once: a row is 4 KB contiguous, 16 B per lane
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int e = tid + it * 256, c4 = e & 3, x = (e >> 2) & 63, yl = e >> 8;
+                const float4 v = *(const float4*)(hs + ((yl + 1) * IC + 1 + x) * HPS + 4 * c4);
+                ((float4*)P.h_out)[((size_t)(n0 * H + row0 + yl) * W + x) * 4 + c4] = v;
+            }
+        }
+        [[maybe_unused]] float zs1 = 0.f, zs2 = 0.f;
         // ---- masker.2 + sigmoid on the tile: thread = pixels (yl, x) and (yl+4, x) ----
         {
             const int x = tid & 63, yl0 = tid >> 6;
@@ -444,10 +458,22 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
                     if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);      // at most one row of taps of operands in flight
                 }
                 const float zpre = ((a0 + a1) + (a2 + a3)) + bias2;
-                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = 1.f / (1.f + expf(-zpre));
+                const float zv = 1.f / (1.f + expf(-zpre));
+                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = zv;
+                if constexpr (TRAIN) { zs1 += fabsf(zv); zs2 += zv * zv; }
             }
         }
+        if constexpr (TRAIN) {
+            zs1 = wave_sum(zs1); zs2 = wave_sum(zs2);
+            if (lane == 0) { zred[2 * wave] = zs1; zred[2 * wave + 1] = zs2; }
+        }
         __syncthreads();
+        if constexpr (TRAIN) {
+            if (tid == 0) {      // fixed order: reproducible
+                P.zpart[2 * tile] = (zred[0] + zred[2]) + (zred[4] + zred[6]);
+                P.zpart[2 * tile + 1] = (zred[1] + zred[3]) + (zred[5] + zred[7]);
+            }
+        }
     }
 }
 
@@ -603,7 +629,7 @@ static constexpr size_t kMaskInferF16Lds =
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st) {
     if (n <= 0) return CGS_OK;
-    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS};
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr};
     int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
     if (img_kind == CGS_SRC_U8)
         hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_U8>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
@@ -613,24 +639,31 @@ int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0,
     return CGS_OK;
 }
 
+template <int SRC, bool TRAIN>
+static int launch_mask_infer(const MaskInferParams& P, hipStream_t st) {
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_infer_kernel<SRC, TRAIN>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)MaskInferGeo::LDS);
+    if (attr != hipSuccess) return (int)attr;
+    int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
+    hipLaunchKernelGGL((mask_infer_kernel<SRC, TRAIN>), dim3(blocks), dim3(256), MaskInferGeo::LDS, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
                       const float* b2, float* z, hipStream_t st) {
     if (n <= 0) return CGS_OK;
-    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS};
-    int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
-    if (img_kind == CGS_SRC_U8) {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_infer_kernel<WSRC_U8>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)MaskInferGeo::LDS);
-        if (attr != hipSuccess) return (int)attr;
-        hipLaunchKernelGGL(mask_infer_kernel<WSRC_U8>, dim3(blocks), dim3(256), MaskInferGeo::LDS, st, P);
-    } else {
-        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_infer_kernel<WSRC_F32>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)MaskInferGeo::LDS);
-        if (attr != hipSuccess) return (int)attr;
-        hipLaunchKernelGGL(mask_infer_kernel<WSRC_F32>, dim3(blocks), dim3(256), MaskInferGeo::LDS, st, P);
-    }
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr};
+    return img_kind == CGS_SRC_U8 ? launch_mask_infer<WSRC_U8, false>(P, st) : launch_mask_infer<WSRC_F32, false>(P, st);
+}
+
+// training form: also stores h and the per-tile (sum |z|, sum z^2); zpart holds 2 * mask_train_partials(n) floats
+int mask_train_partials(int n) { return n * MaskInferGeo::STRIPS; }
+int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
+                      const float* b2, float* h, float* z, float* zpart, hipStream_t st) {
+    if (n <= 0) return CGS_OK;
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, h, zpart};
+    return img_kind == CGS_SRC_U8 ? launch_mask_infer<WSRC_U8, true>(P, st) : launch_mask_infer<WSRC_F32, true>(P, st);
 }
 
 template <int SRC>

@@ -75,7 +75,7 @@ class HourglassEngine:
         self.cbuf["e4"], self.cbuf["h1"], self.cbuf["pred"] = z(n4, 32), z(n4, 32), z(n4)
         self.mbuf: Dict[str, torch.Tensor] = {}
         # partial sums of |Z| and Z^2: from the mask layer's workgroups (4 per image) or from cgs_mix_fwd's
-        self.nzpart = 4 * n if hg.ENC0_MIX_FUSED else _lib.load().cgs_mix_fwd_partials(n, 4096)
+        self.nzpart = hg.zpart_count(n) if hg.ENC0_MIX_FUSED else _lib.load().cgs_mix_fwd_partials(n, 4096)
         self.zsum, self.losses, self.dpred = z(2 * self.nzpart), z(8), z(n4)
         self.dmixed = None if hg.ENC0_MIX_FUSED else z(2 * n, 64, 64, 3)
         self.dzpre = z(n, 64, 64)

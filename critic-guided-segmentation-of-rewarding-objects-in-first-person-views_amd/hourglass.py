@@ -23,6 +23,7 @@ BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
 MASK_INFER_FUSED = os.environ.get("CGS_MASK_INFER_FUSED", "1") != "0"   # inference: masker.0 + masker.2 in one kernel
 ENC0_MIX_FUSED = os.environ.get("CGS_ENC0_MIX_FUSED", "1") != "0"   # features.0 backward + mix backward in one launch
 MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
+MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "1") != "0"   # training forward: masker.0 + masker.2 in one kernel
 _both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
@@ -311,7 +312,7 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     head kernel (critic_forward(..., pw=...)), skip the stand-alone 1x1 conv.  keep_hm=False (inference): the 16-channel
     masker.0 output is not needed afterwards -- masker.0 and masker.2 run as one kernel and 'hm' is never stored;
     fp16_mask_head (with keep_hm=False only, opt-in): that kernel's masker.0 GEMM takes fp16 operands (~1e-3 abs in Z).
-    zpart [4n, 2] (training): the mask layer also leaves its per-workgroup (sum |z|, sum z^2) there for the L1/L2 losses."""
+    zpart [zpart_count(n), 2] (training): the mask layer also leaves its per-tile (sum |z|, sum z^2) there for the L1/L2 losses."""
     u8 = x.dtype == torch.uint8
     _chk(x, torch.uint8 if u8 else torch.float32, "masker image input")
     _chk_img(x, n, "masker image input")
@@ -343,6 +344,16 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             if rc != _lib.ERR_UNSUPPORTED:
                 _lib.check(rc, "cgs_mask_infer_fwd")
             # unsupported in this build: fall through to the two-kernel form
+        if name == "hm" and keep_hm and MASK_TRAIN_FUSED and zpart is not None:
+            # training: masker.0 and masker.2 in one kernel -- h is stored once and never re-read for Z
+            for k, shp in (("hm", (n, 64, 64, 16)), ("Z", (n, 64, 64))):
+                if o.get(k) is None:
+                    o[k] = torch.empty(shp, device=dev, dtype=torch.float32)
+            _lib.call("cgs_mask_train_fwd", n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
+                      C.c_void_p(fp + 4 * lay.off("masker.0.weight")), C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
+                      C.c_void_p(fp + 4 * lay.off("masker.2.weight")), C.c_void_p(fp + 4 * lay.off("masker.2.bias")),
+                      _p(o["hm"]), _p(o["Z"]), _p(zpart), _stream())
+            return o
         shape = (n, hw, hw) if co == 1 else (n, hw, hw, co)
         if o.get(name) is None:
             o[name] = torch.empty(shape, device=dev, dtype=torch.float32)
@@ -353,6 +364,11 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
                   C.c_void_p(fp + 4 * lay.off(key + ".bias")), _p(o[name]), _p(zpart) if name == "Z" else None, _stream())
         prev = o[name]
     return o
+
+
+def zpart_count(n: int) -> int:
+    """Number of (sum |z|, sum z^2) partial pairs the training mask layer writes for n images."""
+    return _lib.load().cgs_mask_train_fwd_partials(n) if MASK_TRAIN_FUSED else 4 * n
 
 
 def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,

@@ -128,6 +128,15 @@ int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const float* o0,
                        const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
                        cgs_stream_t stream);
 
+/* Training form of the same pass (nets.py:488-491 in train mode; replaces masker.0's and masker.2's separate forwards): also
+ * stores h [n,64,64,16] = LeakyReLU(masker.0) ONCE from the on-chip tile (the backward pass needs it) and leaves, per tile,
+ * (sum |z|, sum z^2) for the L1 / L2 mask losses of main.py:421-429 in zpart [2 * cgs_mask_train_fwd_partials(n)].
+ * h is never re-read to compute z (the stand-alone masker.2 forward read all 134 MB of it at n = 512).              */
+int cgs_mask_train_fwd_partials(int32_t n);
+int cgs_mask_train_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
+                       const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* h, float* z,
+                       float* zpart, cgs_stream_t stream);
+
 /* Same contract with fp16 OPERANDS for the masker.0 GEMM (v_mfma_f32_16x16x16_f16, fp32 accumulate; masker.2 stays
  * fp32): BASELINE config 4 ("-process inference-only, fp16 conv kernels").  Opt-in: z differs from the fp32 result by
  * about 1e-3 absolute; never used by training.                                                                  */

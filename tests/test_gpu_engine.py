@@ -100,15 +100,23 @@ def test_phase2_with_dropout_vs_oracle_masks(g1, n):
     B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
     Y = rs.rand(n).astype(np.float32)
     e = make_engine(g1, n, dropout=0.3, use_graph=True)
-    e.step_t.fill_(7)   # masks depend on the step counter; export them for step 7 before the step ticks it
-    masks = _export_masks(e, 4 * n, 7)
+    start = 7 if n == 12 else 0   # masks depend on the step counter; export them for that step before the step ticks it
+    e.step_t.fill_(start)
+    masks = _export_masks(e, 4 * n, start)
     losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
-    assert int(e.step_t.item()) == 8
+    assert int(e.step_t.item()) == start + 1
     sl = {"B": slice(0, n), "A": slice(n, 2 * n), "rep": slice(2 * n, 3 * n), "inj": slice(3 * n, 4 * n)}
     omasks = [[m[sl[k]] for m in masks] for k in ("A", "B", "rep", "inj")]  # oracle order: A, B, replaced, injected
     pc, pm = g1
-    rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1,
-                           p=0.3, training=True, masks=omasks)[0]
+    if n == 512:
+        # At 2 M pixels per weight the CPU's own fp32 summation is off by 1-3e-3 of a tensor's maximum on the mask-head
+        # gradients (measured against float64), more than the tolerance: the checker runs in float64 here.
+        dd = lambda P: {k: v.double() for k, v in P.items()}
+        rec = orc.train_phase2(dd(pc), dd(pm), [(orc.u8_to_nchw(A).double(), orc.u8_to_nchw(B).double(), torch.from_numpy(Y).double())],
+                               steps=1, p=0.3, training=True, masks=[[m.double() for m in mm] for mm in omasks])[0]
+    else:
+        rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1,
+                               p=0.3, training=True, masks=omasks)[0]
     parts = rec["parts"]
     np.testing.assert_allclose(losses[:4], [parts["critic"], parts["replace"], parts["inject"], parts["norm"]], rtol=1e-3)
     gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
@@ -116,10 +124,11 @@ def test_phase2_with_dropout_vs_oracle_masks(g1, n):
         rel_close(gc[k].cpu().numpy(), v.numpy(), f"critic grad {k}")
     for k, v in rec["grads_m"].items():
         rel_close(gm[k].cpu().numpy(), v.numpy(), f"masker grad {k}")
-    for k, v in rec["params_c"].items():
-        rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"critic {k} after the step", rtol=1e-3, atol_scale=1e-4)
-    for k, v in rec["params_m"].items():
-        rel_close(e.masker_state()[k].cpu().numpy(), v.numpy(), f"masker {k} after the step", rtol=1e-3, atol_scale=1e-4)
+    if start == 0:     # Adam's bias correction follows the same counter: only a run from step 0 is the oracle's first step
+        for k, v in rec["params_c"].items():
+            rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"critic {k} after the step", rtol=1e-3, atol_scale=1e-4)
+        for k, v in rec["params_m"].items():
+            rel_close(e.masker_state()[k].cpu().numpy(), v.numpy(), f"masker {k} after the step", rtol=1e-3, atol_scale=1e-4)
 
 
 def test_graph_replay_equals_eager_and_is_reproducible(g1):
