@@ -32,6 +32,14 @@ class MixSrc(C.Structure):
     _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("z", C.c_void_p), ("n_a", i32), ("reserved", i32)]
 
 
+class TailEncWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w6", "b6", "w10", "b10", "w14", "b14", "wl1", "bl1", "wl2", "bl2", "wpw", "bpw")]
+
+
+class TailDecWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("w3", "b3", "w2", "b2", "w1", "b1")]
+
+
 class ReduceJob(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("dst", C.c_void_p), ("nslab", i32), ("stride", i32), ("count", i32),
                 ("accumulate", i32)]
@@ -47,6 +55,12 @@ SIGNATURES = {
     "cgs_mask_train_fwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_head_bwd_slabs": (i32, [i32]),
     "cgs_mask_head_bwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_tail_enc_fwd": (i32, [i32, C.POINTER(TailEncWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, Dropout, Dropout, Dropout, vp]),
+    "cgs_tail_dec_fwd": (i32, [i32, C.POINTER(TailDecWeights), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_tail_enc_bwd_slabs": (i32, [i32]),
+    "cgs_tail_enc_bwd": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 13 + [i32] + [vp] * 5 + [Dropout, Dropout, Dropout, vp]),
+    "cgs_tail_dec_bwd_slabs": (i32, [i32]),
+    "cgs_tail_dec_bwd": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 14 + [vp]),
     "cgs_conv3x3_bwd_weight_slabs": (i32, [C.POINTER(ConvDesc)]),
     "cgs_conv3x3_bwd_weight": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "cgs_conv3x3_bwd_both_slabs": (i32, [C.POINTER(ConvDesc)]),

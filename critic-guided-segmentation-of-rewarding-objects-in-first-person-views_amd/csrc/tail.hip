@@ -1,0 +1,793 @@
+// "Tail" kernels: every 16x16-and-smaller layer of the Hourglass, image by image inside one workgroup.
+//
+//   tail_enc_fwd : features.6 (+ReLU+pool) -> Dropout -> features.10 (+ReLU+pool) -> Dropout -> features.14 (4x4 valid conv)
+//                  -> ReLU -> crit.1 -> ReLU -> Dropout -> crit.4 -> Sigmoid           nets.py:176-194
+//                  (+ the decoder's 1x1 bottleneck conv dec_model.4 of e4, nets.py:501, riding along)
+//   tail_dec_fwd : dec_model.3 / .2 / .1 with their Upsample + cat inputs                  nets.py:503-513
+//   tail_enc_bwd, tail_dec_bwd : what loss.backward() does for those layers (main.py:462)
+//
+// Before: one launch per layer over the whole batch (6 + 3 launches forward, 7 + 3 backward per critic pass), each bound by
+// its own launch + load + store latency chain (7-17 us for < 1 us of arithmetic at N = 512).  Here a workgroup of 4 waves
+// owns an image: the layer inputs / outputs live in LDS tiles, the convolutions run on the matrix cores (tail_common.h), the
+// head runs on the vector ALU, only what the backward pass or another kernel needs is written to memory.  The grid is
+// persistent (image = blockIdx.x, += gridDim.x) so the weight-gradient accumulators of the backward kernels stay in
+// registers across a workgroup's images and every workgroup writes ONE slab per layer.
+//
+// Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
+// masks these kernels draw.
+#include "tail_common.h"
+#include <cstdlib>
+
+namespace {
+
+using T16x8 = Tile<16, 16, 8>;      // e1 / d(features.6 pre-pool)
+using T8x8 = Tile<8, 8, 8>;         // dropout(e2) / do2
+using T8x16 = Tile<8, 8, 16>;       // d(features.10 pre-pool)
+using T16x16 = Tile<16, 16, 16>;    // cat(e1, up(o2))
+using T8x24 = Tile<8, 8, 24>;       // cat(e2, up(o3))
+using T4x48 = Tile<4, 4, 48>;       // cat(e3, up4(o4))
+using T4x16 = Tile<4, 4, 16>;       // do3
+
+// gradient of conv+ReLU+pool re-expanded to one position of the 2x2 window: nibble == pos ? v : 0 (0xF = ReLU dead)
+__device__ __forceinline__ float4 nib_select4(const float4& v, uint32_t nib16, uint32_t pos) {
+    float4 r;
+    r.x = ((nib16 & 15u) == pos) ? v.x : 0.f;
+    r.y = (((nib16 >> 4) & 15u) == pos) ? v.y : 0.f;
+    r.z = (((nib16 >> 8) & 15u) == pos) ? v.z : 0.f;
+    r.w = (((nib16 >> 12) & 15u) == pos) ? v.w : 0.f;
+    return r;
+}
+
+__device__ __forceinline__ float drop1(const DropCtx& dc, uint32_t i) {
+    return dc.on ? f4get(drop_mult4(dc, i >> 2), i & 3) : 1.f;
+}
+
+int tail_blocks(int n, int cap) { return n < cap ? n : cap; }
+int env_cap(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return v > 0 ? v : dflt;
+}
+int tail_fwd_cap() { static const int cap = env_cap("CGS_TAIL_FWD_BLOCKS", 1024); return cap; }
+int tail_bwd_cap() { static const int cap = env_cap("CGS_TAIL_BWD_BLOCKS", 512); return cap; }
+
+unsigned long long* g_tail_stamps = nullptr;     // debug: per-workgroup stage time stamps (tools/tail_stamps.py)
+
+}  // namespace
+
+// Debug hook (not part of the product path): when set, thread 0 of every tail workgroup records s_memtime at its stage
+// boundaries of its FIRST image into stamps[(kernel * 2048 + block) * 16 + stage].
+extern "C" int cgs_tail_debug_stamps(unsigned long long* stamps) { g_tail_stamps = stamps; return CGS_OK; }
+#define TAIL_STAMP(k)                                                                                     \
+    do {                                                                                                  \
+        if (P.dbg && tid == 0 && img == (int)blockIdx.x) P.dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// encoder tail + critic head, forward
+// ------------------------------------------------------------------------------------------------
+struct TailEncFwdParams {
+    cgs_tail_enc_weights w;
+    const float* e1;
+    float* e2; uint32_t* am2; float* e3; uint32_t* am3; float* e4; float* h1; float* pred; float* o4;
+    cgs_dropout drop_e2, drop_e3, drop_h1;
+    int n;
+    unsigned long long* dbg;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_fwd_kernel(TailEncFwdParams P) {
+    __shared__ __attribute__((aligned(16))) float x1[T16x8::FLOATS];     // e1 tile
+    __shared__ __attribute__((aligned(16))) float x2[T8x8::FLOATS];      // dropout(e2) tile
+    __shared__ __attribute__((aligned(16))) float w6s[72 * 8], w10s[72 * 16];
+    __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
+    __shared__ float red[8][32], es[32], hs[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    const int l15 = lane & 15;
+    const int o = tid & 31, kg = tid >> 5;
+    const DropCtx d2 = drop_ctx(P.drop_e2), d3 = drop_ctx(P.drop_e3), dh = drop_ctx(P.drop_h1);
+
+    // ---- once per workgroup: conv weights -> LDS (natural HWIO), halos -> 0, head weights -> registers ----
+    tile_zero<T16x8>(x1, tid);
+    tile_zero<T8x8>(x2, tid);
+    for (int e = tid; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
+    for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
+    float w4r[32], w1r[4], wpr[4];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w1r[j] = P.w.wl1[(kg * 4 + j) * 32 + o];
+        wpr[j] = P.o4 ? P.w.wpw[(kg * 4 + j) * 32 + o] : 0.f;
+    }
+    const float b6 = P.w.b6[l15 & 7], b10 = P.w.b10[l15];
+    const float b14 = P.w.b14[o], bl1 = P.w.bl1[o], wl2 = P.w.wl2[o], bl2 = P.w.bl2[0], bpw = P.o4 ? P.w.bpw[o] : 0.f;
+    __syncthreads();
+
+    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+        TAIL_STAMP(1);
+        // ---- e1 -> tile interior (512 float4) ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
+            *(float4*)(x1 + T16x8::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+        }
+        __syncthreads();
+        TAIL_STAMP(2);
+        // ---- features.6 + ReLU + pool: 16 tiles ----
+        conv_tiles<T16x8, 0, 8, 1>(
+            x1, [&](int tap, int c, int) { return w6s[(tap * 8 + c) * 8 + (l15 & 7)]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                uint32_t idx;
+                const float m = pool_quad(acc[0], b6, idx);
+                const uint32_t word = pack_nibbles(l15 < 8 ? idx : 0u, l15);
+                if (l15 < 8) {
+                    P.e2[((size_t)img * 64 + q) * 8 + l15] = m;
+                    x2[T8x8::at(q >> 3, q & 7) + l15] = m;
+                    if (l15 == 0) P.am2[(size_t)img * 64 + q] = word;
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(3);
+        if (d2.on && tid < 128) {       // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
+            const int q = tid >> 1, p = tid & 1;
+            float4* v = (float4*)(x2 + T8x8::at(q >> 3, q & 7) + 4 * p);
+            *v = *v * drop_mult4(d2, (uint32_t)(img * 128 + tid));
+        }
+        __syncthreads();
+        TAIL_STAMP(4);
+        // ---- features.10 + ReLU + pool: 4 tiles, one per wave ----
+        conv_tiles<T8x8, 0, 8, 1>(
+            x2, [&](int tap, int c, int) { return w10s[(tap * 8 + c) * 16 + l15]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                uint32_t idx;
+                const float m = pool_quad(acc[0], b10, idx);
+                const uint32_t word = pack_nibbles(idx, l15);
+                P.e3[((size_t)img * 16 + q) * 16 + l15] = m;
+                xs[q * 16 + l15] = m * drop1(d3, (uint32_t)((img * 16 + q) * 16 + l15));
+                if ((l15 & 7) == 0) P.am3[((size_t)img * 16 + q) * 2 + (l15 >> 3)] = word;
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(5);
+        // ---- features.14 (256 -> 32) + ReLU: thread (o, kg) sums k = 32*kg .. +31 ----
+        {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                const float4 xv = *(const float4*)(xs + kg * 32 + j);
+                a0 = fmaf(xv.x, w4r[j], a0); a1 = fmaf(xv.y, w4r[j + 1], a1);
+                a2 = fmaf(xv.z, w4r[j + 2], a2); a3 = fmaf(xv.w, w4r[j + 3], a3);
+            }
+            red[kg][o] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        TAIL_STAMP(6);
+        if (tid < 32) {
+            float s = b14;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) s += red[g][o];
+            s = fmaxf(s, 0.f);
+            es[o] = s;
+            P.e4[(size_t)img * 32 + o] = s;
+        }
+        __syncthreads();
+        TAIL_STAMP(7);
+        // ---- crit.1 (32 -> 32) and the decoder's 1x1 conv of e4: thread (o, kg) sums k = 4*kg .. +3 ----
+        {
+            float s1 = 0.f, sp = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ev = es[kg * 4 + j];
+                s1 = fmaf(ev, w1r[j], s1);
+                sp = fmaf(ev, wpr[j], sp);
+            }
+            red[kg][o] = s1;
+            __syncthreads();
+            TAIL_STAMP(8);
+            float h = 0.f;
+            if (tid < 32) {
+                float s = bl1;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) s += red[g][o];
+                h = fmaxf(s, 0.f);
+                P.h1[(size_t)img * 32 + o] = h;
+            }
+            __syncthreads();
+            TAIL_STAMP(9);
+            red[kg][o] = sp;
+            __syncthreads();
+            TAIL_STAMP(10);
+            if (tid < 32) {
+                if (P.o4) {
+                    float s = bpw;
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) s += red[g][o];
+                    P.o4[(size_t)img * 32 + o] = s;
+                }
+                // ---- Dropout -> crit.4 (32 -> 1) -> Sigmoid ----
+                float t = h * drop1(dh, (uint32_t)(img * 32 + o)) * wl2;
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
+                if (o == 0) P.pred[img] = 1.f / (1.f + expf(-(t + bl2)));
+            }
+        }
+        __syncthreads();
+        TAIL_STAMP(11);
+    }
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+}
+
+extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
+                                uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_dropout drop_e2,
+                                cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->b6 || !w->w10 || !w->b10 || !w->w14 || !w->b14 || !w->wl1 || !w->bl1 || !w->wl2 || !w->bl2) return CGS_ERR_BADARG;
+    if (o4 && (!w->wpw || !w->bpw)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
+    const int blocks = tail_blocks(n, tail_fwd_cap());
+    hipLaunchKernelGGL(tail_enc_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder tail, forward: dec_model.3 (cat(e3, up4(o4)) @4x4) -> dec_model.2 (cat(e2, up(o3)) @8x8) -> dec_model.1
+// (cat(e1, up(o2)) @16x16); the decoder trunk is linear (no activation, nets.py:503-513).
+// ------------------------------------------------------------------------------------------------
+struct TailDecFwdParams {
+    cgs_tail_dec_weights w;
+    const float* e1; const float* e2; const float* e3; const float* o4;
+    float* o3; float* o2; float* o1;
+    int n;
+    unsigned long long* dbg;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P) {
+    __shared__ __attribute__((aligned(16))) float t1[T16x16::FLOATS];
+    __shared__ __attribute__((aligned(16))) float t2[T8x24::FLOATS];
+    __shared__ __attribute__((aligned(16))) float t3[T4x48::FLOATS];
+    __shared__ __attribute__((aligned(16))) float w2s[216 * 8], w1s[144 * 8];
+    __shared__ float part[4][16][16];       // dec_model.3: the waves split K, partial [pixel][co]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    tile_zero<T16x16>(t1, tid);
+    tile_zero<T8x24>(t2, tid);
+    tile_zero<T4x48>(t3, tid);
+    for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
+    for (int e = tid; e < 144 * 8 / 4; e += 256) ((float4*)w1s)[e] = ((const float4*)P.w.w1)[e];
+    const float b2 = P.w.b2[l15 & 7], b1 = P.w.b1[l15 & 7];
+    __syncthreads();
+
+    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+        TAIL_STAMP(1);
+        // ---- skip inputs and the bottleneck -> tiles ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
+            *(float4*)(t1 + T16x16::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+        }
+        if (tid < 128) {
+            const int p = tid & 1, x = (tid >> 1) & 7, y = tid >> 4;
+            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = ((const float4*)P.e2)[(size_t)img * 128 + tid];
+        } else if (tid < 192) {
+            const int e = tid - 128, p = e & 3, x = (e >> 2) & 3, y = e >> 4;
+            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = ((const float4*)P.e3)[(size_t)img * 64 + e];
+        }
+        if (tid < 128) {         // up4(o4): every pixel of the 4x4 map sees the bottleneck vector
+            const int p = tid & 7, pix = tid >> 3;
+            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p) = ((const float4*)P.o4)[(size_t)img * 8 + p];
+        }
+        __syncthreads();
+        TAIL_STAMP(2);
+        // ---- dec_model.3: one 16-pixel tile, K = 9 x 48; wave w takes channels 12w .. 12w+11 of every tap ----
+        {
+            const int q = l15 >> 2, y = 2 * (q >> 1) + ((l15 >> 1) & 1), x = 2 * (q & 1) + (l15 & 1);
+            const int abase = (y * T4x48::PW + x) * 48 + 12 * wave + kq;
+            const float* wg = P.w.w3 + (12 * wave + kq) * 16 + l15;
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = ((tap / 3) * T4x48::PW + tap % 3) * 48;
+#pragma unroll
+                for (int c0 = 0; c0 < 12; c0 += 4)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(t3[abase + toff + c0], wg[(tap * 48 + c0) * 16], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[wave][4 * kq + j][l15] = acc[j];
+        }
+        __syncthreads();
+        TAIL_STAMP(3);
+        {
+            const int i = tid >> 4, co = tid & 15;                       // tile pixel i = 4*quad + 2*dy + dx
+            const int q = i >> 2, y = 2 * (q >> 1) + ((i >> 1) & 1), x = 2 * (q & 1) + (i & 1);
+            const float v = ((part[0][i][co] + part[1][i][co]) + (part[2][i][co] + part[3][i][co])) + P.w.b3[co];
+            P.o3[((size_t)img * 16 + y * 4 + x) * 16 + co] = v;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) t2[T8x24::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + co] = v;
+        }
+        __syncthreads();
+        TAIL_STAMP(4);
+        // ---- dec_model.2: 4 tiles ----
+        conv_tiles<T8x24, 0, 24, 1>(
+            t2, [&](int tap, int c, int) { return w2s[(tap * 24 + c) * 8 + (l15 & 7)]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                if (l15 < 8) {
+                    const int qy = q >> 2, qx = q & 3;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int y = 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
+                        const float v = acc[0][j] + b2;
+                        P.o2[((size_t)img * 64 + y * 8 + x) * 8 + l15] = v;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) t1[T16x16::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + l15] = v;
+                    }
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(5);
+        // ---- dec_model.1: 16 tiles ----
+        conv_tiles<T16x16, 0, 16, 1>(
+            t1, [&](int tap, int c, int) { return w1s[(tap * 16 + c) * 8 + (l15 & 7)]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                if (l15 < 8) {
+                    const int qy = q >> 3, qx = q & 7;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        P.o1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j] + b1;
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(6);
+    }
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+}
+
+extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                                const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1) return CGS_ERR_BADARG;
+    if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr};
+    const int blocks = tail_blocks(n, tail_fwd_cap());
+    hipLaunchKernelGGL(tail_dec_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder tail + critic head, backward (one critic pass).  Per image:
+//   head backward (crit.4, crit.1, features.14, and the decoder's 1x1 conv when d_o4 is given) -> d e3
+//   -> re-expansion through the pool/ReLU nibbles -> features.10 weight + data gradient -> Dropout mask, + skip gradient
+//   -> re-expansion -> features.6 weight + data gradient (+ skip gradient) -> d e1 (memory, for features.3's backward).
+// Weight-gradient partials stay in registers across the workgroup's images; one slab per layer per workgroup:
+//   slab_head [w14 8192 | b14 32 | wl1 1024 | bl1 32 | wl2 32 | bl2 1], slab_pw [1024 | 32], slab10 [1152 | 16], slab6 [576 | 8].
+// ------------------------------------------------------------------------------------------------
+static constexpr int kTailHeadSlab = 8192 + 32 + 1024 + 32 + 32 + 1, kTailPwSlab = 1024 + 32, kTailSlab10 = 1168, kTailSlab6 = 584;
+
+struct TailEncBwdParams {
+    cgs_tail_enc_weights w;
+    const float* e1; const float* e2; const uint32_t* am2; const float* e3; const uint32_t* am3;
+    const float* e4; const float* h1; const float* pred; const float* dpred;
+    const float* dE1; const float* dE2; const float* dE3; const float* d_o4; int n_add;
+    float* de1;
+    float* slab_head; float* slab_pw; float* slab10; float* slab6;
+    cgs_dropout drop_e2, drop_e3, drop_h1;
+    int n;
+    unsigned long long* dbg;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_enc_bwd_kernel(TailEncBwdParams P) {
+    // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
+    // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
+    // four barriers per image.
+    constexpr int OX1 = 0, OX2 = OX1 + T16x8::FLOATS, ODY2 = OX2 + T8x8::FLOATS, ODY3 = ODY2 + T16x8::FLOATS, OEND = ODY3 + T8x16::FLOATS;
+    __shared__ __attribute__((aligned(16))) float tiles[OEND];           // after the loop: scratch of the weight-gradient reduction
+    float* x1 = tiles + OX1;       // e1: X of features.6
+    float* x2 = tiles + OX2;       // dropout(e2): X of features.10
+    float* dy2 = tiles + ODY2;     // gradient at features.6's pre-pool output
+    float* dy3 = tiles + ODY3;     // gradient at features.10's pre-pool output
+    __shared__ __attribute__((aligned(16))) float w6s[72 * 8], w10s[72 * 16];
+    __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat
+    __shared__ __attribute__((aligned(16))) float m2s[512], d2s[512];    // Dropout multipliers of e2; skip gradient dE2
+    __shared__ __attribute__((aligned(16))) float o1s[2048];             // d e1 before the coalesced store
+    __shared__ uint32_t am2s[64];
+    __shared__ float dz4s[32];
+    static_assert(OEND >= 4 * 5 * 256, "reduction scratch fits the tile area");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    const int l15 = lane & 15;
+    const int o = tid & 31, kg = tid >> 5, half = lane & 32;
+    const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
+    const DropCtx d2 = drop_ctx(P.drop_e2), d3 = drop_ctx(P.drop_e3), dh = drop_ctx(P.drop_h1);
+    const bool has_pw = P.d_o4 != nullptr;
+
+    tile_zero<T16x8>(x1, tid);
+    tile_zero<T8x8>(x2, tid);
+    tile_zero<T16x8>(dy2, tid);
+    tile_zero<T8x16>(dy3, tid);
+    for (int e = tid; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
+    for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
+    // head weights in registers for all images: features.14 row k = tid, crit.1 / dec_model.4 row hk columns 4*part..+3
+    const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
+    const float4 wpv = has_pw ? *(const float4*)(P.w.wpw + hk * 32 + 4 * part) : f4zero();
+    const float wl2 = P.w.wl2[o];
+    float acc4[32], accw1[4], accpw[4];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { accw1[j] = 0.f; accpw[j] = 0.f; }
+    float pb4 = 0.f, pb1 = 0.f, pw2 = 0.f, pb2 = 0.f, pbpw = 0.f;
+    WgradAccK<T8x8, T8x16, 16> wg10;
+    WgradAccK<T16x8, T16x8, 8> wg6;
+    wg10.init(lane);
+    wg6.init(lane);
+
+    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+        TAIL_STAMP(1);
+        const bool add = img < P.n_add;
+        // ---- every global load of this image, back to back ----
+        float4 le1[2], lde1[2] = {f4zero(), f4zero()}, le23 = f4zero(), ldE2 = f4zero();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            le1[it] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256 * it];
+            if (P.dE1 && add) lde1[it] = ((const float4*)P.dE1)[(size_t)img * 512 + tid + 256 * it];     // parked in o1s below
+        }
+        uint32_t lam2 = 0;
+        if (tid < 128) {
+            le23 = ((const float4*)P.e2)[(size_t)img * 128 + tid];
+            if (P.dE2 && add) ldE2 = ((const float4*)P.dE2)[(size_t)img * 128 + tid];
+            if (tid < 64) lam2 = P.am2[(size_t)img * 64 + tid];
+        } else if (tid < 192) {
+            le23 = ((const float4*)P.e3)[(size_t)img * 64 + tid - 128];
+        }
+        const uint32_t lam3 = P.am3[(size_t)img * 32 + (tid >> 3)];           // word of pooled pixel tid >> 4, channel half (tid >> 3) & 1
+        const float ldE3 = (P.dE3 && add) ? P.dE3[(size_t)img * 256 + tid] : 0.f;
+        const float ev = P.e4[(size_t)img * 32 + o], hv = P.h1[(size_t)img * 32 + o];
+        const float pr = P.pred[img], dpr = P.dpred[img];
+        const float go4 = (has_pw && add) ? P.d_o4[(size_t)img * 32 + o] : 0.f;
+        // Dropout multipliers while the loads are in flight
+        __builtin_amdgcn_sched_barrier(0);        // (one Philox at a time: interleaved they spill)
+        float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (tid < 128) { if (d2.on) mk = drop_mult4(d2, (uint32_t)(img * 128 + tid)); }
+        else if (tid < 192) { if (d3.on) mk = drop_mult4(d3, (uint32_t)(img * 64 + tid - 128)); }
+        __builtin_amdgcn_sched_barrier(0);
+        const float m2 = drop1(dh, (uint32_t)(img * 32 + o));
+        __builtin_amdgcn_sched_barrier(0);
+        const float m3 = drop1(d3, (uint32_t)(img * 256 + tid));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- commit to LDS ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
+            *(float4*)(x1 + T16x8::at(y, x) + 4 * p) = le1[it];
+            ((float4*)o1s)[e] = lde1[it];          // features.6's data gradient is added on top of the skip gradient
+        }
+        if (tid < 128) {
+            const int q = tid >> 1, p = tid & 1;
+            *(float4*)(x2 + T8x8::at(q >> 3, q & 7) + 4 * p) = le23 * mk;
+            ((float4*)m2s)[tid] = mk;
+            ((float4*)d2s)[tid] = ldE2;
+            if (tid < 64) am2s[tid] = lam2;
+        } else if (tid < 192) {
+            ((float4*)xs)[tid - 128] = le23 * mk;
+        }
+        // ---- head on shuffles, redundantly in every wave (a half-wave holds all 32 values of o) ----
+        const float dz2 = dpr * pr * (1.f - pr);
+        const float dh1 = hv > 0.f ? dz2 * wl2 * m2 : 0.f;
+        if (kg == 0) {
+            pw2 = fmaf(dz2, hv * m2, pw2);
+            pb1 += dh1;
+            pbpw += go4;
+            if (o == 0) pb2 += dz2;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ek = __shfl(ev, half + kg * 4 + j, 64);
+            accw1[j] = fmaf(ek, dh1, accw1[j]);
+            accpw[j] = fmaf(ek, go4, accpw[j]);
+        }
+        {   // d e4[hk] = sum_o' wl1[hk][o'] dh1[o'] + sum_j wpw[hk][j] d o4[j]: 8 lanes x 4 columns, then ReLU of features.14
+            const float w1a[4] = {w1v.x, w1v.y, w1v.z, w1v.w}, wpa[4] = {wpv.x, wpv.y, wpv.z, wpv.w};
+            float part_sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part_sum = fmaf(w1a[j], __shfl(dh1, half + 4 * part + j, 64), part_sum);
+                part_sum = fmaf(wpa[j], __shfl(go4, half + 4 * part + j, 64), part_sum);
+            }
+            part_sum += __shfl_xor(part_sum, 1, 64);
+            part_sum += __shfl_xor(part_sum, 2, 64);
+            part_sum += __shfl_xor(part_sum, 4, 64);
+            const float ek = __shfl(ev, half + hk, 64);
+            if (part == 0) dz4s[hk] = ek > 0.f ? part_sum : 0.f;
+        }
+        __syncthreads();
+        TAIL_STAMP(2);
+        // ---- d e3[k = tid] -> straight into features.10's pre-pool gradient tile; d features.14 weights ----
+        {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) {
+                const float4 dv = *(const float4*)(dz4s + 4 * q4);
+                s0 = fmaf(w14r[q4].x, dv.x, s0); s1 = fmaf(w14r[q4].y, dv.y, s1);
+                s2 = fmaf(w14r[q4].z, dv.z, s2); s3 = fmaf(w14r[q4].w, dv.w, s3);
+            }
+            const float r = ((s0 + s1) + (s2 + s3)) * m3 + ldE3;
+            const int q = tid >> 4, c = tid & 15, qy = q >> 2, qx = q & 3;
+            const uint32_t nib = (lam3 >> (4 * (c & 7))) & 15u;
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos)
+                dy3[T8x16::at(2 * qy + (pos >> 1), 2 * qx + (pos & 1)) + c] = (nib == (uint32_t)pos) ? r : 0.f;
+            __builtin_amdgcn_sched_barrier(0);      // w14r is dead from here on: keep the next loads behind this point
+            const float dzo = dz4s[o];
+            if (kg == 0) pb4 += dzo;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                const float4 xv = *(const float4*)(xs + kg * 32 + j);
+                acc4[j] = fmaf(xv.x, dzo, acc4[j]); acc4[j + 1] = fmaf(xv.y, dzo, acc4[j + 1]);
+                acc4[j + 2] = fmaf(xv.z, dzo, acc4[j + 2]); acc4[j + 3] = fmaf(xv.w, dzo, acc4[j + 3]);
+                if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        TAIL_STAMP(3);
+        // ---- features.10: weight gradient; data gradient -> Dropout mask, + skip gradient, re-expansion for features.6 ----
+        wg10.accumulate(x2, dy3, wave, lane);
+        conv_tiles<T8x16, 0, 16, 1>(
+            dy3, [&](int tap, int c, int) { return w10s[((8 - tap) * 8 + (l15 & 7)) * 16 + c]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                if (l15 < 8) {
+                    const int qy = q >> 2, qx = q & 3;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int py = 2 * qy + (j >> 1), px = 2 * qx + (j & 1), pp = py * 8 + px;   // pixel of the 8x8 map = pooled pixel of features.6
+                        const float r = acc[0][j] * m2s[pp * 8 + l15] + d2s[pp * 8 + l15];
+                        const uint32_t nib = (am2s[pp] >> (4 * l15)) & 15u;
+#pragma unroll
+                        for (int pos = 0; pos < 4; ++pos)
+                            dy2[T16x8::at(2 * py + (pos >> 1), 2 * px + (pos & 1)) + l15] = (nib == (uint32_t)pos) ? r : 0.f;
+                    }
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(4);
+        // ---- features.6: weight gradient; data gradient -> d e1 ----
+        wg6.accumulate(x1, dy2, wave, lane);
+        conv_tiles<T16x8, 0, 8, 1>(
+            dy2, [&](int tap, int c, int) { return w6s[((8 - tap) * 8 + (l15 & 7)) * 8 + c]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                if (l15 < 8) {
+                    const int qy = q >> 3, qx = q & 7;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o1s[((2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] += acc[0][j];
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(5);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            ((float4*)P.de1)[(size_t)img * 512 + tid + 256 * it] = ((const float4*)o1s)[tid + 256 * it];
+        }
+    }
+
+    // ---- one slab per layer for this workgroup ----
+    __syncthreads();
+    const size_t b = blockIdx.x;
+    if (P.slab_head) {
+        float* sl = P.slab_head + b * kTailHeadSlab;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) sl[(kg * 32 + j) * 32 + o] = acc4[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[8192 + 32 + (kg * 4 + j) * 32 + o] = accw1[j];
+        if (tid < 32) {
+            sl[8192 + o] = pb4;
+            sl[8192 + 32 + 1024 + o] = pb1;
+            sl[8192 + 32 + 1024 + 32 + o] = pw2;
+            if (o == 0) sl[8192 + 32 + 1024 + 32 + 32] = pb2;
+        }
+    }
+    if (P.slab_pw) {
+        float* sl = P.slab_pw + b * kTailPwSlab;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[(kg * 4 + j) * 32 + o] = accpw[j];
+        if (tid < 32) sl[1024 + o] = pbpw;
+    }
+    wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
+    wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+}
+
+extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }
+
+extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                                const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                                const float* dpred, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
+                                int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
+                                cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !dpred || !de1) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
+    if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, dE1, dE2, dE3, d_o4, n_add, de1,
+                       slab_head, slab_pw, slab10, slab6, drop_e2, drop_e3, drop_h1, n, g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
+    hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder tail, backward.  Per image, from d o1 (gradient w.r.t. dec_model.1's output, produced by dec_model.0's backward):
+//   dec_model.1: weight gradient; data gradient -> dE1 (skip, memory) and, summed over the 2x2 upsample cell, d o2 (LDS)
+//   dec_model.2: likewise -> dE2, d o3;   dec_model.3: likewise -> dE3, d o4 (sum over the 4x4 map, memory)
+// Slabs: slab1 [9*16*8 | 8], slab2 [9*24*8 | 8], slab3 [9*48*16 | 16], one per workgroup.
+// ------------------------------------------------------------------------------------------------
+static constexpr int kTailSlabD1 = 9 * 16 * 8 + 8, kTailSlabD2 = 9 * 24 * 8 + 8, kTailSlabD3 = 9 * 48 * 16 + 16;
+
+struct TailDecBwdParams {
+    cgs_tail_dec_weights w;
+    const float* e1; const float* e2; const float* e3; const float* o4; const float* o3; const float* o2;
+    const float* do1;
+    float* dE1; float* dE2; float* dE3; float* d_o4;
+    float* slab3; float* slab2; float* slab1;
+    int n;
+    unsigned long long* dbg;
+};
+
+struct TailDecBwdLds {
+    static constexpr int T1 = 0, T2 = T1 + T16x16::FLOATS, T3 = T2 + T8x24::FLOATS, D1 = T3 + T4x48::FLOATS,
+                         D2 = D1 + T16x8::FLOATS, D3 = D2 + T8x8::FLOATS, W1 = D3 + T4x16::FLOATS, W2 = W1 + 144 * 8,
+                         RED = W2 + 216 * 8, FLOATS = RED + 4 * 32;
+    static constexpr size_t BYTES = (size_t)FLOATS * 4;
+};
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_dec_bwd_kernel(TailDecBwdParams P) {
+    using L = TailDecBwdLds;
+    extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    float* sm = (float*)smem4;
+    float* t1 = sm + L::T1; float* t2 = sm + L::T2; float* t3 = sm + L::T3;
+    float* dy1 = sm + L::D1; float* dy2 = sm + L::D2; float* dy3 = sm + L::D3;
+    float* w1s = sm + L::W1; float* w2s = sm + L::W2; float* red = sm + L::RED;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    const int l15 = lane & 15;
+
+    tile_zero<T16x16>(t1, tid); tile_zero<T8x24>(t2, tid); tile_zero<T4x48>(t3, tid);
+    tile_zero<T16x8>(dy1, tid); tile_zero<T8x8>(dy2, tid); tile_zero<T4x16>(dy3, tid);
+    for (int e = tid; e < 144 * 8 / 4; e += 256) ((float4*)w1s)[e] = ((const float4*)P.w.w1)[e];
+    for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
+    WgradAcc<T16x16, T16x8, 8, 3> wg1;
+    WgradAcc<T8x24, T8x8, 8, 4> wg2;
+    WgradAcc<T4x48, T4x16, 16, 7> wg3;
+    wg1.init(wave, lane); wg2.init(wave, lane); wg3.init(wave, lane);
+    __syncthreads();
+
+    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+        TAIL_STAMP(1);
+        // ---- layer inputs (skip ++ upsampled) and d o1 -> tiles ----
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
+            *(float4*)(t1 + T16x16::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+            *(float4*)(dy1 + T16x8::at(y, x) + 4 * p) = ((const float4*)P.do1)[(size_t)img * 512 + e];
+        }
+        if (tid < 128) {
+            const int p = tid & 1, x = (tid >> 1) & 7, y = tid >> 4;
+            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = ((const float4*)P.e2)[(size_t)img * 128 + tid];
+            const float4 v = ((const float4*)P.o2)[(size_t)img * 128 + tid];            // up(o2) -> channels 8..15 of t1
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *(float4*)(t1 + T16x16::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
+        } else if (tid < 192) {
+            const int e = tid - 128, p = e & 3, x = (e >> 2) & 3, y = e >> 4;
+            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = ((const float4*)P.e3)[(size_t)img * 64 + e];
+            const float4 v = ((const float4*)P.o3)[(size_t)img * 64 + e];               // up(o3) -> channels 8..23 of t2
+#pragma unroll
+            for (int d = 0; d < 4; ++d) *(float4*)(t2 + T8x24::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
+        }
+        if (tid < 128) {
+            const int p = tid & 7, pix = tid >> 3;
+            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p) = ((const float4*)P.o4)[(size_t)img * 8 + p];
+        }
+        __syncthreads();
+        TAIL_STAMP(2);
+        // ---- dec_model.1 ----
+        wg1.accumulate(t1, dy1, lane);
+        conv_tiles<T16x8, 0, 8, 1>(
+            dy1, [&](int tap, int c, int) { return w1s[((8 - tap) * 16 + l15) * 8 + c]; },
+            [&](int q, const frag4 (&acc)[1]) {
+                const int qy = q >> 3, qx = q & 7;
+                if (l15 < 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        P.dE1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j];
+                } else {
+                    dy2[T8x8::at(qy, qx) + l15 - 8] = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]);
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(3);
+        // ---- dec_model.2 ----
+        wg2.accumulate(t2, dy2, lane);
+        conv_tiles<T8x8, 0, 8, 2>(
+            dy2, [&](int tap, int c, int cb) { const int ci = 16 * cb + l15; return w2s[((8 - tap) * 24 + (ci < 24 ? ci : 23)) * 8 + c]; },
+            [&](int q, const frag4 (&acc)[2]) {
+                const int qy = q >> 2, qx = q & 3;
+                if (l15 < 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        P.dE2[((size_t)img * 64 + (2 * qy + (j >> 1)) * 8 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j];
+                    dy3[T4x16::at(qy, qx) + 8 + l15] = (acc[1][0] + acc[1][1]) + (acc[1][2] + acc[1][3]);
+                } else {
+                    dy3[T4x16::at(qy, qx) + l15 - 8] = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]);
+                }
+            },
+            wave, lane);
+        __syncthreads();
+        TAIL_STAMP(4);
+        // ---- dec_model.3: weight gradient on the matrix cores; data gradient on the vector ALU (48 input channels x 4 quads:
+        //      thread = (ci, quad), weights read in their natural [tap][ci][co] order, 16 contiguous floats per (tap, ci)) ----
+        wg3.accumulate(t3, dy3, lane);
+        if (tid < 192) {
+            const int ci = tid % 48, q = tid / 48, qy = q >> 1, qx = q & 1;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const float4* wr = (const float4*)(P.w.w3 + ((size_t)(8 - tap) * 48 + ci) * 16);
+                const float4 wv[4] = {wr[0], wr[1], wr[2], wr[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 2 * qy + (j >> 1) + tap / 3 - 1, x = 2 * qx + (j & 1) + tap % 3 - 1;   // -1 .. 4: inside the halo tile
+                    const float4* dp = (const float4*)(dy3 + T4x16::at(y, x));
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const float4 dv = dp[c4];
+                        a[j] = fmaf(dv.x, wv[c4].x, a[j]); a[j] = fmaf(dv.y, wv[c4].y, a[j]);
+                        a[j] = fmaf(dv.z, wv[c4].z, a[j]); a[j] = fmaf(dv.w, wv[c4].w, a[j]);
+                    }
+                }
+            }
+            if (ci < 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    P.dE3[((size_t)img * 16 + (2 * qy + (j >> 1)) * 4 + 2 * qx + (j & 1)) * 16 + ci] = a[j];
+            } else {
+                red[q * 32 + ci - 16] = (a[0] + a[1]) + (a[2] + a[3]);
+            }
+        }
+        __syncthreads();
+        TAIL_STAMP(5);
+        if (tid < 32) P.d_o4[(size_t)img * 32 + tid] = (red[tid] + red[32 + tid]) + (red[64 + tid] + red[96 + tid]);
+        __syncthreads();
+        TAIL_STAMP(6);
+    }
+    const size_t b = blockIdx.x;
+    if (P.slab1) wg1.store(P.slab1 + b * kTailSlabD1, wave, lane);
+    if (P.slab2) wg2.store(P.slab2 + b * kTailSlabD2, wave, lane);
+    if (P.slab3) wg3.store(P.slab3 + b * kTailSlabD3, wave, lane);
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+}
+
+extern "C" int cgs_tail_dec_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }
+
+extern "C" int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                                const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
+                                float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !do1 || !dE1 || !dE2 || !dE3 || !d_o4) return CGS_ERR_BADARG;
+    if (!w->w3 || !w->w2 || !w->w1) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
+    hipLaunchKernelGGL(tail_dec_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

@@ -121,12 +121,16 @@ class HourglassEngine:
         lib = _lib.load()
         out1, out2 = {}, {}
         nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
-        specs = [("slab_head", lambda n, first: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
+        tail = hg.TAIL_BWD       # head / features.10 / features.6 slabs then come from the tail kernel's workgroups
+        specs = [("slab_head", (lambda n, first: lib.cgs_tail_enc_bwd_slabs(n)) if tail else (lambda n, first: lib.cgs_head_bwd_slabs(n)),
+                  hg.HEAD_SLAB)]
         for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
             def f(n, first, i=i, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
                 d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
                 # mirrors critic_backward: features.0 shares a launch with its data gradient only in the first pass
                 # (fp32 mixes, image gradient wanted); the second pass reads uint8 frames and needs no image gradient
+                if tail and i >= 2:
+                    return lib.cgs_tail_enc_bwd_slabs(n)
                 if i in hg.BOTH_ENC and (i > 0 or first):
                     return lib.cgs_conv3x3_bwd_both_slabs(C.byref(d))
                 return lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))

@@ -23,7 +23,12 @@ BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
 MASK_INFER_FUSED = os.environ.get("CGS_MASK_INFER_FUSED", "1") != "0"   # inference: masker.0 + masker.2 in one kernel
 ENC0_MIX_FUSED = os.environ.get("CGS_ENC0_MIX_FUSED", "1") != "0"   # features.0 backward + mix backward in one launch
 MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
-MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "1") != "0"   # training forward: masker.0 + masker.2 in one kernel
+# training forward: masker.0 + masker.2 in one kernel (h stored once).  Measured equal to the two-kernel form at N = 512 (103 us vs
+# 60 + 40 us: the one-kernel form holds 80 KB of LDS, 2 workgroups per CU, and its phases serialise), so it is opt-in for now.
+MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "0") != "0"
+# the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
+TAIL_FWD = os.environ.get("CGS_TAIL_FWD", "1") != "0"
+TAIL_BWD = os.environ.get("CGS_TAIL_BWD", "1") != "0"
 _both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
@@ -72,6 +77,24 @@ class DropState:
 
 
 NO_DROP = DropState(0.0, 0, None)
+
+
+def _wp(flat: torch.Tensor, lay: Layout, key: str):
+    return flat.data_ptr() + 4 * lay.off(key)
+
+
+def tail_enc_weights(fc: torch.Tensor, lc: Layout, pw=None) -> _lib.TailEncWeights:
+    """Pointers into the flat critic buffer for the tail kernels (pw = (w_ptr, b_ptr, ...) of the decoder's 1x1 conv)."""
+    g = lambda k: _wp(fc, lc, k)
+    return _lib.TailEncWeights(g("features.6.weight"), g("features.6.bias"), g("features.10.weight"), g("features.10.bias"),
+                               g("features.14.weight"), g("features.14.bias"), g("crit.1.weight"), g("crit.1.bias"),
+                               g("crit.4.weight"), g("crit.4.bias"), pw[0] if pw else None, pw[1] if pw else None)
+
+
+def tail_dec_weights(fm: torch.Tensor, lm: Layout) -> _lib.TailDecWeights:
+    g = lambda k: _wp(fm, lm, k)
+    return _lib.TailDecWeights(g("dec_model.3.weight"), g("dec_model.3.bias"), g("dec_model.2.weight"), g("dec_model.2.bias"),
+                               g("dec_model.1.weight"), g("dec_model.1.bias"))
 
 
 def conv_desc(n, hw, ca, cb, co, src_u8, ups, act, pool, drop: _lib.Dropout) -> _lib.ConvDesc:
@@ -184,6 +207,8 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
         am = o.get(f"am{i}")
         if am is None:
             am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
+        if TAIL_FWD and i >= 2:
+            continue        # features.6 / features.10 / head: one tail kernel below
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         if mixin and i == 0:
             d.src_a = _lib.SRC_MIX
@@ -194,6 +219,13 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     for k, shape in (("e4", (n, 32)), ("h1", (n, 32)), ("pred", (n,))):
         if o.get(k) is None:
             o[k] = torch.empty(shape, device=dev, dtype=torch.float32)
+    if TAIL_FWD:
+        pwp = (pw[0], pw[1]) if pw else None
+        tw = tail_enc_weights(flat, lay, (pwp[0].value, pwp[1].value) if pwp else None)
+        _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(o["e1"]), _p(o["e2"]), _p(o["am2"]), _p(o["e3"]), _p(o["am3"]),
+                  _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _p(pw[2]) if pw else None, drop.desc(DROP_SITE_E2, True, 128),
+                  drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
+        return o
     fp = flat.data_ptr()
     _lib.call("cgs_head_fwd", n, _p(o["e3"]), C.c_void_p(fp + 4 * lay.off("features.14.weight")),
               C.c_void_p(fp + 4 * lay.off("features.14.bias")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
@@ -234,23 +266,49 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     has_add = d_embeds is not None and n_add > 0
     side = side if side is not None else NO_SIDE
     lib = _lib.load()
+    first_layer = 3
+    if TAIL_BWD and not (has_add and d_embeds[4] is not None and pw_bwd is None):
+        # head + features.10 + features.6 backward in one tail kernel: d e1 (skip gradients included)
+        use_pw = pw_bwd is not None and has_add
+        nsl = lib.cgs_tail_enc_bwd_slabs(n)
+        sl_head = buf("slab_head", (nsl, HEAD_SLAB)) if need_wgrad else None
+        sl10 = buf("slab_enc3", (nsl, 9 * 8 * 16 + 16)) if need_wgrad else None
+        sl6 = buf("slab_enc2", (nsl, 9 * 8 * 8 + 8)) if need_wgrad else None
+        sl_pw = buf("slab_head_pw", (nsl, PW_SLAB)) if use_pw else None
+        d_cur = buf("de1", (n, 16, 16, 8))
+        tw = tail_enc_weights(flat, lay, (pw_bwd[1].value, None) if use_pw else None)
+        _lib.call("cgs_tail_enc_bwd", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
+                  _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
+                  _p(d_embeds[1]) if has_add else None, _p(d_embeds[2]) if has_add else None,
+                  _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None, n_add if has_add else 0,
+                  _p(d_cur), _p(sl_head), _p(sl_pw), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
+                  drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
+        if need_wgrad:
+            plan.add(sl_head, nsl, HEAD_SLAB, lay.off("features.14.weight"))
+            plan.add(sl10, nsl, 9 * 8 * 16 + 16, lay.off("features.10.weight"))
+            plan.add(sl6, nsl, 9 * 8 * 8 + 8, lay.off("features.6.weight"))
+        if use_pw:
+            pw_bwd[2].add(sl_pw, nsl, PW_SLAB, pw_bwd[3])
+        first_layer = 1
     # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
-    nsl = lib.cgs_head_bwd_slabs(n)
-    slab = buf("slab_head", (nsl, HEAD_SLAB))
-    d_cur = buf("de3", (n, 4, 4, 16))
-    use_pw = pw_bwd is not None and has_add
-    slab_pw = buf("slab_head_pw", (nsl, PW_SLAB)) if use_pw else None
-    de4 = d_embeds[4] if has_add else None
-    _lib.call("cgs_head_bwd", n, _p(saved["e3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
-              _p(de4) if (has_add and de4 is not None) else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
-              C.c_void_p(fp + 4 * lay.off("features.14.weight")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
-              C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
-              _p(d_cur), _p(slab), _p(pw_bwd[0]) if use_pw else None, pw_bwd[1] if use_pw else None,
-              _p(slab_pw) if use_pw else None, _stream())
-    plan.add(slab, nsl, HEAD_SLAB, lay.off("features.14.weight"))
-    if use_pw:
-        pw_bwd[2].add(slab_pw, nsl, PW_SLAB, pw_bwd[3])
-    for i in (3, 2, 1, 0):
+    if first_layer == 3:
+      if True:
+        nsl = lib.cgs_head_bwd_slabs(n)
+        slab = buf("slab_head", (nsl, HEAD_SLAB))
+        d_cur = buf("de3", (n, 4, 4, 16))
+        use_pw = pw_bwd is not None and has_add
+        slab_pw = buf("slab_head_pw", (nsl, PW_SLAB)) if use_pw else None
+        de4 = d_embeds[4] if has_add else None
+        _lib.call("cgs_head_bwd", n, _p(saved["e3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
+                  _p(de4) if (has_add and de4 is not None) else None, _p(d_embeds[3]) if has_add else None, n_add if has_add else 0,
+                  C.c_void_p(fp + 4 * lay.off("features.14.weight")), C.c_void_p(fp + 4 * lay.off("crit.1.weight")),
+                  C.c_void_p(fp + 4 * lay.off("crit.4.weight")), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
+                  _p(d_cur), _p(slab), _p(pw_bwd[0]) if use_pw else None, pw_bwd[1] if use_pw else None,
+                  _p(slab_pw) if use_pw else None, _stream())
+        plan.add(slab, nsl, HEAD_SLAB, lay.off("features.14.weight"))
+        if use_pw:
+            pw_bwd[2].add(slab_pw, nsl, PW_SLAB, pw_bwd[3])
+    for i in range(first_layer, -1, -1):
         key, hw, ca, cb, co, ups, act, pool, site = ENC_LAYERS[i]
         src = x if i == 0 else saved[f"e{i - 1}"]
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
@@ -331,7 +389,17 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     prev = o["o4"]
     if fp16_mask_head and (keep_hm or not MASK_INFER_FUSED):
         raise _lib.CgsError("fp16_mask_head is an inference-only option of the one-kernel mask head (keep_hm=False)")
+    if TAIL_FWD:      # dec_model.3 / .2 / .1 in one tail kernel
+        for nm, shp in (("o3", (n, 4, 4, 16)), ("o2", (n, 8, 8, 8)), ("o1", (n, 16, 16, 8))):
+            if o.get(nm) is None:
+                o[nm] = torch.empty(shp, device=dev, dtype=torch.float32)
+        tw = tail_dec_weights(flat, lay)
+        _lib.call("cgs_tail_dec_fwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
+                  _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), _stream())
+        prev = o["o1"]
     for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
+        if TAIL_FWD and name in ("o3", "o2", "o1"):
+            continue
         if name == "hm" and not keep_hm and MASK_INFER_FUSED:
             if o.get("Z") is None:
                 o["Z"] = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
@@ -404,6 +472,22 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
     for li in (5, 4, 3, 2, 1, 0):
         if li == 4 and head_done:
             continue
+        if TAIL_BWD and li == 2:
+            # dec_model.1 / .2 / .3 backward in one tail kernel: dy = d o1 -> skip gradients dE1..dE3 and d o4
+            nsl = lib.cgs_tail_dec_bwd_slabs(n)
+            cnts = {1: 9 * 16 * 8 + 8, 2: 9 * 24 * 8 + 8, 3: 9 * 48 * 16 + 16}
+            sl = {k: buf(f"slab_dec{3 - k}", (nsl, c)) for k, c in cnts.items()}     # names as the per-layer path: li = 3 - k
+            for ei, shp in ((1, (n, 16, 16, 8)), (2, (n, 8, 8, 8)), (3, (n, 4, 4, 16))):
+                d_embeds[ei] = buf(f"dE{ei}", shp)
+            do4 = buf("do4", (n, 32))
+            tw = tail_dec_weights(flat, lay)
+            _lib.call("cgs_tail_dec_bwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(saved["o4"]),
+                      _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
+                      _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
+            for k, c in cnts.items():
+                plan.add(sl[k], nsl, c, lay.off(f"dec_model.{k}.weight"))
+            dy = do4
+            break
         key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]
         is_img = li == 4
         d = conv_desc(n, hw, ca, cb, co, u8 and is_img, ups, act, pool, nd)

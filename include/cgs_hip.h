@@ -144,6 +144,54 @@ int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, const float*
                            const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
                            cgs_stream_t stream);
 
+/* ---- the 16x16-and-smaller layers, image by image inside one workgroup ("tail" kernels, csrc/tail.hip) ------------
+ * Replace, for one critic pass / the decoder, the per-layer launches of features.6, features.10 (nets.py:176-183), the
+ * critic head features.14 + crit.1 + crit.4 (nets.py:184-194) and dec_model.4/.3/.2/.1 (nets.py:501-513): every
+ * intermediate stays in LDS, the convolutions run on the matrix cores, the same tensors as the per-layer entry points are
+ * written (so either form feeds the other's backward).  Weight pointers are the kernel-layout (HWIO / k-major) tensors of
+ * the flat parameter buffer.  Shapes (NHWC): e1 [n,16,16,8], e2 [n,8,8,8], am2 [n,8,8,1], e3 [n,4,4,16], am3 [n,4,4,2],
+ * e4/h1/o4 [n,32], pred [n], o3 [n,4,4,16], o2 [n,8,8,8], o1 [n,16,16,8].                                            */
+typedef struct {
+    const float *w6, *b6;     /* features.6   [3][3][8][8],  [8]  */
+    const float *w10, *b10;   /* features.10  [3][3][8][16], [16] */
+    const float *w14, *b14;   /* features.14  [256][32] (k = (y*4+x)*16+c), [32] */
+    const float *wl1, *bl1;   /* crit.1       [32][32] k-major, [32] */
+    const float *wl2, *bl2;   /* crit.4       [32], [1] */
+    const float *wpw, *bpw;   /* dec_model.4  [32][32] k-major, [32]; only read when o4 / d_o4 is given */
+} cgs_tail_enc_weights;
+typedef struct {
+    const float *w3, *b3;     /* dec_model.3  [3][3][48][16], [16] */
+    const float *w2, *b2;     /* dec_model.2  [3][3][24][8],  [8]  */
+    const float *w1, *b1;     /* dec_model.1  [3][3][16][8],  [8]  */
+} cgs_tail_dec_weights;
+/* drop_e2 / drop_e3 / drop_h1: Dropout in front of features.10, features.14 and crit.4 (base = first image * 128 / 64 / 8).
+ * o4 may be NULL (no decoder follows this pass).                                                                      */
+int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
+                     uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_dropout drop_e2,
+                     cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                     const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
+
+/* Backward of the same layers.  cgs_tail_enc_bwd: one critic pass, from dpred [n] to de1 [n,16,16,8] (gradient w.r.t. e1,
+ * input of features.3's backward).  dE1 / dE2 / dE3 (skip gradients from the decoder, shapes of e1 / e2 / e3) and d_o4 [n,32]
+ * (gradient w.r.t. dec_model.4's output: its backward then runs here too) may be NULL; they are read for images < n_add.
+ * Every workgroup writes one slab per layer: cgs_tail_enc_bwd_slabs(n) slabs of
+ *   slab_head [8192 + 32 + 1024 + 32 + 32 + 1]  (features.14 w,b | crit.1 w,b | crit.4 w,b -- contiguous in the flat buffer)
+ *   slab_pw [1024 + 32] (dec_model.4, only with d_o4),  slab10 [1152 + 16] (features.10),  slab6 [576 + 8] (features.6);
+ * a NULL slab pointer skips that store (data gradient only).
+ * cgs_tail_dec_bwd: dec_model.1/.2/.3 from do1 [n,16,16,8]: skip gradients dE1/dE2/dE3, d_o4 [n,32], and
+ * cgs_tail_dec_bwd_slabs(n) slabs of slab1 [1152 + 8], slab2 [1728 + 8], slab3 [6912 + 16].                          */
+int cgs_tail_enc_bwd_slabs(int32_t n);
+int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                     const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                     const float* dpred, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
+                     int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
+                     cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+int cgs_tail_dec_bwd_slabs(int32_t n);
+int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                     const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
+                     float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, cgs_stream_t stream);
+
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
  *   slab[b][0 .. 9*(ca+cb)*co)  = partial dW (HWIO),  slab[b][9*(ca+cb)*co ..][co] = partial dbias

@@ -1,0 +1,41 @@
+"""Stage timing of the tail kernels (debug hook cgs_tail_debug_stamps): mean s_memtime deltas between the stage boundaries of
+every workgroup's first image, per kernel.  Usage (GPU box): python tools/tail_stamps.py [batch]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+from cgs_amd import _lib, engine  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+dev = torch.device("cuda:0")
+eng = engine.HourglassEngine(n, device=dev, dropout=0.3, use_graph=False)
+eng.load_state(*bench.g1_weights())
+A, B, Y = bench.synthetic(n, 0, dev)
+for _ in range(3):
+    eng.phase2_step(A, B, Y)
+torch.cuda.synchronize()
+buf = torch.zeros(4 * 2048 * 16, dtype=torch.int64, device=dev)
+lib = _lib.load()
+lib.cgs_tail_debug_stamps.argtypes = [C.c_void_p]
+lib.cgs_tail_debug_stamps(C.c_void_p(buf.data_ptr()))
+eng.phase2_step()
+torch.cuda.synchronize()
+lib.cgs_tail_debug_stamps(C.c_void_p(0))
+st = buf.cpu().numpy().reshape(4, 2048, 16)
+for k, name in enumerate(("enc_fwd (last call: mixes)", "dec_fwd", "enc_bwd (last call: A pass)", "dec_bwd")):
+    s = st[k]
+    live = s[:, 0] != 0
+    s = s[live].astype(np.float64)
+    if not len(s):
+        continue
+    cols = [c for c in range(16) if (s[:, c] != 0).all()]
+    d = np.diff(s[:, cols], axis=1)
+    print(f"{name}: {live.sum()} workgroups, stamps {cols}")
+    print("   mean ticks per stage:", np.round(d.mean(0), 0).tolist(), " total", round(float((s[:, cols[-1]] - s[:, cols[0]]).mean())))
+    print("   kernel span (first start .. last end):", float(s[:, cols[-1]].max() - s[:, cols[0]].min()))
