@@ -106,6 +106,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
         TAIL_STAMP(1);
+        int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
+        asm volatile("" : "+v"(lz));
+        const int lane_i = lane + lz;
         // ---- e1 -> tile interior (512 float4) ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -127,7 +130,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                     if (l15 == 0) P.am2[(size_t)img * 64 + q] = word;
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(3);
         if (d2.on && tid < 128) {       // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 xs[q * 16 + l15] = m * drop1(d3, (uint32_t)((img * 16 + q) * 16 + l15));
                 if ((l15 & 7) == 0) P.am3[((size_t)img * 16 + q) * 2 + (l15 >> 3)] = word;
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
         // ---- features.14 (256 -> 32) + ReLU: thread (o, kg) sums k = 32*kg .. +31 ----
@@ -265,6 +268,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
         TAIL_STAMP(1);
+        int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
+        asm volatile("" : "+v"(lz));
+        const int lane_i = lane + lz;
         // ---- skip inputs and the bottleneck -> tiles ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                     }
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
         // ---- dec_model.1: 16 tiles ----
@@ -342,7 +348,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                         P.o1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j] + b1;
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(6);
     }
@@ -432,6 +438,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
         TAIL_STAMP(1);
         const bool add = img < P.n_add;
+        // Opaque zero: the LDS addresses of the MFMA stages depend only on the lane, so the compiler hoists ALL of them out of
+        // the image loop and keeps them in registers (-> 256 VGPRs + scratch spills).  Deriving them from lane + lz keeps them
+        // per-iteration temporaries.
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        const int lane_i = lane + lz;
         // ---- every global load of this image, back to back ----
         float4 le1[2], lde1[2] = {f4zero(), f4zero()}, le23 = f4zero(), ldE2 = f4zero();
 #pragma unroll
@@ -509,8 +521,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
         __syncthreads();
         TAIL_STAMP(2);
-        // ---- d e3[k = tid] -> straight into features.10's pre-pool gradient tile; d features.14 weights ----
+        // ---- d features.14 weights; d e3[k = tid] -> straight into features.10's pre-pool gradient tile ----
         {
+            float4 w14r[8];                       // features.14 row k = tid (L2-resident), in flight during the weight-gradient update
+#pragma unroll
+            for (int q4 = 0; q4 < 8; ++q4) w14r[q4] = ((const float4*)(P.w.w14 + (size_t)tid * 32))[q4];
+            const float dzo = dz4s[o];
+            if (kg == 0) pb4 += dzo;
+#pragma unroll
+            for (int j = 0; j < 32; j += 4) {
+                const float4 xv = *(const float4*)(xs + kg * 32 + j);
+                acc4[j] = fmaf(xv.x, dzo, acc4[j]); acc4[j + 1] = fmaf(xv.y, dzo, acc4[j + 1]);
+                acc4[j + 2] = fmaf(xv.z, dzo, acc4[j + 2]); acc4[j + 3] = fmaf(xv.w, dzo, acc4[j + 3]);
+                if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);
+            }
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
@@ -524,21 +548,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos)
                 dy3[T8x16::at(2 * qy + (pos >> 1), 2 * qx + (pos & 1)) + c] = (nib == (uint32_t)pos) ? r : 0.f;
-            __builtin_amdgcn_sched_barrier(0);      // w14r is dead from here on: keep the next loads behind this point
-            const float dzo = dz4s[o];
-            if (kg == 0) pb4 += dzo;
-#pragma unroll
-            for (int j = 0; j < 32; j += 4) {
-                const float4 xv = *(const float4*)(xs + kg * 32 + j);
-                acc4[j] = fmaf(xv.x, dzo, acc4[j]); acc4[j + 1] = fmaf(xv.y, dzo, acc4[j + 1]);
-                acc4[j + 2] = fmaf(xv.z, dzo, acc4[j + 2]); acc4[j + 3] = fmaf(xv.w, dzo, acc4[j + 3]);
-                if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);
-            }
         }
         __syncthreads();
         TAIL_STAMP(3);
         // ---- features.10: weight gradient; data gradient -> Dropout mask, + skip gradient, re-expansion for features.6 ----
-        wg10.accumulate(x2, dy3, wave, lane);
+        wg10.accumulate(x2, dy3, wave, lane_i);
         conv_tiles<T8x16, 0, 16, 1>(
             dy3, [&](int tap, int c, int) { return w10s[((8 - tap) * 8 + (l15 & 7)) * 16 + c]; },
             [&](int q, const frag4 (&acc)[1]) {
@@ -555,11 +569,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(4);
         // ---- features.6: weight gradient; data gradient -> d e1 ----
-        wg6.accumulate(x1, dy2, wave, lane);
+        wg6.accumulate(x1, dy2, wave, lane_i);
         conv_tiles<T16x8, 0, 8, 1>(
             dy2, [&](int tap, int c, int) { return w6s[((8 - tap) * 8 + (l15 & 7)) * 8 + c]; },
             [&](int q, const frag4 (&acc)[1]) {
@@ -569,7 +583,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     for (int j = 0; j < 4; ++j) o1s[((2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] += acc[0][j];
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
 #pragma unroll
@@ -671,6 +685,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 
     for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
         TAIL_STAMP(1);
+        int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
+        asm volatile("" : "+v"(lz));
+        const int lane_i = lane + lz;
         // ---- layer inputs (skip ++ upsampled) and d o1 -> tiles ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -698,7 +715,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         TAIL_STAMP(2);
         // ---- dec_model.1 ----
-        wg1.accumulate(t1, dy1, lane);
+        wg1.accumulate(t1, dy1, lane_i);
         conv_tiles<T16x8, 0, 8, 1>(
             dy1, [&](int tap, int c, int) { return w1s[((8 - tap) * 16 + l15) * 8 + c]; },
             [&](int q, const frag4 (&acc)[1]) {
@@ -711,11 +728,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     dy2[T8x8::at(qy, qx) + l15 - 8] = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]);
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(3);
         // ---- dec_model.2 ----
-        wg2.accumulate(t2, dy2, lane);
+        wg2.accumulate(t2, dy2, lane_i);
         conv_tiles<T8x8, 0, 8, 2>(
             dy2, [&](int tap, int c, int cb) { const int ci = 16 * cb + l15; return w2s[((8 - tap) * 24 + (ci < 24 ? ci : 23)) * 8 + c]; },
             [&](int q, const frag4 (&acc)[2]) {
@@ -729,12 +746,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     dy3[T4x16::at(qy, qx) + l15 - 8] = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]);
                 }
             },
-            wave, lane);
+            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(4);
         // ---- dec_model.3: weight gradient on the matrix cores; data gradient on the vector ALU (48 input channels x 4 quads:
         //      thread = (ci, quad), weights read in their natural [tap][ci][co] order, 16 contiguous floats per (tap, ci)) ----
-        wg3.accumulate(t3, dy3, lane);
+        wg3.accumulate(t3, dy3, lane_i);
         if (tid < 192) {
             const int ci = tid % 48, q = tid / 48, qy = q >> 1, qx = q & 1;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
