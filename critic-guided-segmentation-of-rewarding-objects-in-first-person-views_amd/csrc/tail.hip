@@ -10,7 +10,8 @@
 // its own launch + load + store latency chain (7-17 us for < 1 us of arithmetic at N = 512).  Here a workgroup of 4 waves
 // owns an image: the layer inputs / outputs live in LDS tiles, the convolutions run on the matrix cores (tail_common.h), the
 // head runs on the vector ALU, only what the backward pass or another kernel needs is written to memory.  The grid is
-// persistent (image = blockIdx.x, += gridDim.x) so the weight-gradient accumulators of the backward kernels stay in
+// persistent (image = blockIdx.x, += number of workgroups; the count is a kernel ARGUMENT: reading gridDim.x loads the dispatch packet
+// from host-visible memory, measured ~10 us at the top of these latency-bound kernels) so the weight-gradient accumulators of the backward kernels stay in
 // registers across a workgroup's images and every workgroup writes ONE slab per layer.
 //
 // Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
@@ -72,10 +73,11 @@ struct TailEncFwdParams {
     float* e2; uint32_t* am2; float* e3; uint32_t* am3; float* e4; float* h1; float* pred; float* o4;
     cgs_dropout drop_e2, drop_e3, drop_h1;
     int n;
+    int nblocks;
     unsigned long long* dbg;
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_fwd_kernel(TailEncFwdParams P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P) {
     __shared__ __attribute__((aligned(16))) float x1[T16x8::FLOATS];     // e1 tile
     __shared__ __attribute__((aligned(16))) float x2[T8x8::FLOATS];      // dropout(e2) tile
     __shared__ __attribute__((aligned(16))) float w6s[72 * 8], w10s[72 * 16];
@@ -104,7 +106,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const float b14 = P.w.b14[o], bl1 = P.w.bl1[o], wl2 = P.w.wl2[o], bl2 = P.w.bl2[0], bpw = P.o4 ? P.w.bpw[o] : 0.f;
     __syncthreads();
 
-    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
@@ -229,8 +231,8 @@ extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const 
     if (!w->w6 || !w->b6 || !w->w10 || !w->b10 || !w->w14 || !w->b14 || !w->wl1 || !w->bl1 || !w->wl2 || !w->bl2) return CGS_ERR_BADARG;
     if (o4 && (!w->wpw || !w->bpw)) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
-    const int blocks = tail_blocks(n, tail_fwd_cap());
+    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
+    const int blocks = P.nblocks;
     hipLaunchKernelGGL(tail_enc_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
@@ -245,6 +247,7 @@ struct TailDecFwdParams {
     const float* e1; const float* e2; const float* e3; const float* o4;
     float* o3; float* o2; float* o1;
     int n;
+    int nblocks;
     unsigned long long* dbg;
 };
 
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const float b2 = P.w.b2[l15 & 7], b1 = P.w.b1[l15 & 7];
     __syncthreads();
 
-    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
@@ -360,7 +363,7 @@ extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const 
     if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1) return CGS_ERR_BADARG;
     if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr};
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr};
     const int blocks = tail_blocks(n, tail_fwd_cap());
     hipLaunchKernelGGL(tail_dec_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
@@ -386,6 +389,7 @@ struct TailEncBwdParams {
     float* slab_head; float* slab_pw; float* slab10; float* slab6;
     cgs_dropout drop_e2, drop_e3, drop_h1;
     int n;
+    int nblocks;
     unsigned long long* dbg;
 };
 
@@ -411,19 +415,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5, half = lane & 32;
     const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
-    const DropCtx d2 = drop_ctx(P.drop_e2), d3 = drop_ctx(P.drop_e3), dh = drop_ctx(P.drop_h1);
+    const DropCtx d2_ = drop_ctx(P.drop_e2), d3_ = drop_ctx(P.drop_e3), dh_ = drop_ctx(P.drop_h1);
     const bool has_pw = P.d_o4 != nullptr;
 
     tile_zero<T16x8>(x1, tid);
     tile_zero<T8x8>(x2, tid);
     tile_zero<T16x8>(dy2, tid);
     tile_zero<T8x16>(dy3, tid);
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
     for (int e = tid; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
     for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
     // head weights in registers for all images: features.14 row k = tid, crit.1 / dec_model.4 row hk columns 4*part..+3
-    const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
-    const float4 wpv = has_pw ? *(const float4*)(P.w.wpw + hk * 32 + 4 * part) : f4zero();
-    const float wl2 = P.w.wl2[o];
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
     float acc4[32], accw1[4], accpw[4];
 #pragma unroll
     for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
@@ -431,11 +434,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int j = 0; j < 4; ++j) { accw1[j] = 0.f; accpw[j] = 0.f; }
     float pb4 = 0.f, pb1 = 0.f, pw2 = 0.f, pb2 = 0.f, pbpw = 0.f;
     WgradAccK<T8x8, T8x16, 16> wg10;
-    WgradAccK<T16x8, T16x8, 8> wg6;
+    WgradAcc<T16x8, T16x8, 8, 2> wg6;
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     wg10.init(lane);
-    wg6.init(lane);
+    wg6.init(wave, lane);
 
-    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         const bool add = img < P.n_add;
         // Opaque zero: the LDS addresses of the MFMA stages depend only on the lane, so the compiler hoists ALL of them out of
@@ -444,12 +448,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         int lz = 0;
         asm volatile("" : "+v"(lz));
         const int lane_i = lane + lz;
+        // (same for the Philox round keys: 3 contexts x 20 loop-invariant scalars otherwise live across the loop -> SGPR spills)
+        DropCtx d2 = d2_, d3 = d3_, dh = dh_;
+        asm volatile("" : "+s"(d2.key.x), "+s"(d2.key.y), "+s"(d3.key.x), "+s"(d3.key.y), "+s"(dh.key.x), "+s"(dh.key.y));
         // ---- every global load of this image, back to back ----
-        float4 le1[2], lde1[2] = {f4zero(), f4zero()}, le23 = f4zero(), ldE2 = f4zero();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            le1[it] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256 * it];
-            if (P.dE1 && add) lde1[it] = ((const float4*)P.dE1)[(size_t)img * 512 + tid + 256 * it];     // parked in o1s below
+        // (scalars, not arrays: an array the optimiser fails to fully unroll becomes a per-thread LDS array indexed by the flat
+        //  work-item id, which needs the workgroup size from the dispatch packet -- a ~10 us load from host-visible memory)
+        float4 le23 = f4zero(), ldE2 = f4zero(), lde1a = f4zero(), lde1b = f4zero();
+        const float4 le1a = ((const float4*)P.e1)[(size_t)img * 512 + tid], le1b = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256];
+        if (P.dE1 && add) {       // parked in o1s below
+            lde1a = ((const float4*)P.dE1)[(size_t)img * 512 + tid];
+            lde1b = ((const float4*)P.dE1)[(size_t)img * 512 + tid + 256];
         }
         uint32_t lam2 = 0;
         if (tid < 128) {
@@ -464,6 +473,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float ev = P.e4[(size_t)img * 32 + o], hv = P.h1[(size_t)img * 32 + o];
         const float pr = P.pred[img], dpr = P.dpred[img];
         const float go4 = (has_pw && add) ? P.d_o4[(size_t)img * 32 + o] : 0.f;
+        // head weights of this thread (L2-resident; reloaded per image rather than held in registers across the loop)
+        const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
+        const float4 wpv = has_pw ? *(const float4*)(P.w.wpw + hk * 32 + 4 * part) : f4zero();
+        const float wl2 = P.w.wl2[o];
         // Dropout multipliers while the loads are in flight
         __builtin_amdgcn_sched_barrier(0);        // (one Philox at a time: interleaved they spill)
         float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -475,11 +488,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const float m3 = drop1(d3, (uint32_t)(img * 256 + tid));
         __builtin_amdgcn_sched_barrier(0);
         // ---- commit to LDS ----
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(x1 + T16x8::at(y, x) + 4 * p) = le1[it];
-            ((float4*)o1s)[e] = lde1[it];          // features.6's data gradient is added on top of the skip gradient
+        {
+            const int p = tid & 1, x = (tid >> 1) & 15, y = tid >> 5;          // float4 index e = tid and tid + 256 (8 rows further)
+            *(float4*)(x1 + T16x8::at(y, x) + 4 * p) = le1a;
+            *(float4*)(x1 + T16x8::at(y + 8, x) + 4 * p) = le1b;
+            ((float4*)o1s)[tid] = lde1a;               // features.6's data gradient is added on top of the skip gradient
+            ((float4*)o1s)[tid + 256] = lde1b;
         }
         if (tid < 128) {
             const int q = tid >> 1, p = tid & 1;
@@ -573,7 +587,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         TAIL_STAMP(4);
         // ---- features.6: weight gradient; data gradient -> d e1 ----
-        wg6.accumulate(x1, dy2, wave, lane_i);
+        wg6.accumulate(x1, dy2, lane_i);
         conv_tiles<T16x8, 0, 8, 1>(
             dy2, [&](int tap, int c, int) { return w6s[((8 - tap) * 8 + (l15 & 7)) * 8 + c]; },
             [&](int q, const frag4 (&acc)[1]) {
@@ -586,10 +600,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            ((float4*)P.de1)[(size_t)img * 512 + tid + 256 * it] = ((const float4*)o1s)[tid + 256 * it];
-        }
+        ((float4*)P.de1)[(size_t)img * 512 + tid] = ((const float4*)o1s)[tid];
+        ((float4*)P.de1)[(size_t)img * 512 + tid + 256] = ((const float4*)o1s)[tid + 256];
     }
 
     // ---- one slab per layer for this workgroup ----
@@ -615,7 +627,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (tid < 32) sl[1024 + o] = pbpw;
     }
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
-    wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
+    if (P.slab6) wg6.store(P.slab6 + b * kTailSlab6, wave, lane);
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
@@ -631,7 +643,7 @@ extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const 
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, dE1, dE2, dE3, d_o4, n_add, de1,
-                       slab_head, slab_pw, slab10, slab6, drop_e2, drop_e3, drop_h1, n, g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
+                       slab_head, slab_pw, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
     hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
@@ -652,6 +664,7 @@ struct TailDecBwdParams {
     float* dE1; float* dE2; float* dE3; float* d_o4;
     float* slab3; float* slab2; float* slab1;
     int n;
+    int nblocks;
     unsigned long long* dbg;
 };
 
@@ -683,7 +696,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     wg1.init(wave, lane); wg2.init(wave, lane); wg3.init(wave, lane);
     __syncthreads();
 
-    for (int img = blockIdx.x; img < P.n; img += gridDim.x) {
+    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
@@ -803,7 +816,7 @@ extern "C" int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const 
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
     if (attr != hipSuccess) return (int)attr;
-    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
+    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
     hipLaunchKernelGGL(tail_dec_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;

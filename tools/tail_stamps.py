@@ -35,6 +35,7 @@ for k, name in enumerate(("enc_fwd (last call: mixes)", "dec_fwd", "enc_bwd (las
     if not len(s):
         continue
     cols = [c for c in range(16) if (s[:, c] != 0).all()]
+    cols.sort(key=lambda c: s[:, c].mean())
     d = np.diff(s[:, cols], axis=1)
     print(f"{name}: {live.sum()} workgroups, stamps {cols}")
     print("   mean ticks per stage:", np.round(d.mean(0), 0).tolist(), " total", round(float((s[:, cols[-1]] - s[:, cols[0]]).mean())))
