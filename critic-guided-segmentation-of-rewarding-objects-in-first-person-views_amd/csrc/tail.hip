@@ -434,10 +434,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int j = 0; j < 4; ++j) { accw1[j] = 0.f; accpw[j] = 0.f; }
     float pb4 = 0.f, pb1 = 0.f, pw2 = 0.f, pb2 = 0.f, pbpw = 0.f;
     WgradAccK<T8x8, T8x16, 16> wg10;
-    WgradAcc<T16x8, T16x8, 8, 2> wg6;
+    WgradAccK<T16x8, T16x8, 8> wg6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     wg10.init(lane);
-    wg6.init(wave, lane);
+    wg6.init(lane);
 
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
@@ -587,7 +587,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         TAIL_STAMP(4);
         // ---- features.6: weight gradient; data gradient -> d e1 ----
-        wg6.accumulate(x1, dy2, lane_i);
+        wg6.accumulate(x1, dy2, wave, lane_i);
         conv_tiles<T16x8, 0, 8, 1>(
             dy2, [&](int tap, int c, int) { return w6s[((8 - tap) * 8 + (l15 & 7)) * 8 + c]; },
             [&](int q, const frag4 (&acc)[1]) {
@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (tid < 32) sl[1024 + o] = pbpw;
     }
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
-    if (P.slab6) wg6.store(P.slab6 + b * kTailSlab6, wave, lane);
+    wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 

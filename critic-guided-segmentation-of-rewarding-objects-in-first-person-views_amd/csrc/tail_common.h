@@ -99,18 +99,31 @@ struct WgradAcc {
         static_assert(TX::H == TY::H && TX::W == TY::W, "same map");
         const int l15 = lane & 15, kq = lane >> 4;
         const int co = l15 % CO;
-#pragma unroll 2
-        for (int s = 0; s < TX::H * TX::W / 4; ++s) {
-            const int p = 4 * s + kq, y = p / TX::W, x = p % TX::W;
-            const int pa = (y * TX::PW + x) * TX::PCI;
-            const float b = dyt[TY::at(y, x) + co];
+        // BATCH pixel steps per trip: all their LDS reads are issued before the first MFMA (a wave issues in order: a read placed
+        // behind an MFMA that waits for its operands is not in flight), the barriers keep the compiler from serialising them again
+        constexpr int NSTEP = TX::H * TX::W / 4, BATCH = NSTEP % 4 == 0 ? 4 : 1;
+#pragma unroll 1
+        for (int s0 = 0; s0 < NSTEP; s0 += BATCH) {
+            float a[BATCH][NRBW], b[BATCH];
 #pragma unroll
-            for (int i = 0; i < NRBW; ++i) {
-                if (i < nblk) {
-                    const float a = roff[i] >= 0 ? xt[pa + roff[i]] : (roff[i] == -1 ? 1.f : 0.f);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
-                }
+            for (int u = 0; u < BATCH; ++u) {
+                const int p = 4 * (s0 + u) + kq, y = p / TX::W, x = p % TX::W;
+                const int pa = (y * TX::PW + x) * TX::PCI;
+                b[u] = dyt[TY::at(y, x) + co];
+#pragma unroll
+                for (int i = 0; i < NRBW; ++i) a[u][i] = xt[pa + (roff[i] >= 0 ? roff[i] : 0)];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+                for (int i = 0; i < NRBW; ++i) {
+                    if (i < nblk) {
+                        const float av = roff[i] >= 0 ? a[u][i] : (roff[i] == -1 ? 1.f : 0.f);
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u], acc[i], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -178,17 +191,27 @@ struct WgradAccK {
     __device__ __forceinline__ void accumulate(const float* xt, const float* dyt, int wave, int lane) {
         const int l15 = lane & 15, kq = lane >> 4;
         const int co = l15 % CO;
-#pragma unroll 4
-        for (int s = wave; s < NSTEP; s += 4) {
-            const int p = 4 * s + kq, y = p / TX::W, x = p % TX::W;
-            const int pa = (y * TX::PW + x) * TX::PCI;
-            const float b = dyt[TY::at(y, x) + co];
+        constexpr int PERW = NSTEP / 4, BATCH = PERW % 4 == 0 ? 4 : (PERW % 2 == 0 ? 2 : 1);     // see WgradAcc::accumulate
+#pragma unroll 1
+        for (int k0 = 0; k0 < PERW; k0 += BATCH) {
+            float a[BATCH][NRB], b[BATCH];
 #pragma unroll
-            for (int i = 0; i < NRB; ++i) {
-                float a = xt[pa + (roff[i] >= 0 ? roff[i] : 0)];
-                a = roff[i] >= 0 ? a : (roff[i] == -1 ? 1.f : 0.f);
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+            for (int u = 0; u < BATCH; ++u) {
+                const int p = 4 * (wave + 4 * (k0 + u)) + kq, y = p / TX::W, x = p % TX::W;
+                const int pa = (y * TX::PW + x) * TX::PCI;
+                b[u] = dyt[TY::at(y, x) + co];
+#pragma unroll
+                for (int i = 0; i < NRB; ++i) a[u][i] = xt[pa + (roff[i] >= 0 ? roff[i] : 0)];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u)
+#pragma unroll
+                for (int i = 0; i < NRB; ++i) {
+                    const float av = roff[i] >= 0 ? a[u][i] : (roff[i] == -1 ? 1.f : 0.f);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u], acc[i], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
