@@ -82,6 +82,8 @@ SIGNATURES = {
     "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_gather_roll_u8": (i32, [vp, vp, i32, i32, vp, vp]),
+    "cgs_gather_f32": (i32, [vp, vp, i32, vp, vp]),
     "cgs_dropout_mask": (i32, [Dropout, i64, vp, vp]),
     "cgs_build_arch": (C.c_char_p, []),
     "cgs_abi_version": (i32, []),

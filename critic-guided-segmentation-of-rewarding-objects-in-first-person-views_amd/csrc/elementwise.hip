@@ -342,5 +342,53 @@ extern "C" int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_st
     return CGS_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Contrastive batch assembly on the device (main.py:344-356): dst[i] = frame src[idx[i]] rolled along the width by `shift`
+// pixels (dst[y][x] = src[y][(x + shift) mod 64]; shift_batch's left roll by s is shift = s, its right roll shift = 64 - s),
+// and the matching gather of the fp32 targets.  One workgroup per frame, one thread per 4 output dwords of a 192-byte row.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gather_roll_u8_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ idx,
+                                                             int shift, uint32_t* __restrict__ dst) {
+    const uint8_t* s = src + (size_t)idx[blockIdx.x] * 12288;
+    uint32_t* d = dst + (size_t)blockIdx.x * 3072;
+    const int sb = 3 * shift;
+    for (int w = threadIdx.x; w < 3072; w += 256) {
+        const int y = w / 48, b0 = (w % 48) * 4;
+        const uint8_t* row = s + y * 192;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int b = b0 + k + sb;
+            b = b >= 192 ? b - 192 : b;
+            v |= (uint32_t)row[b] << (8 * k);
+        }
+        d[w] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) gather_f32_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int n,
+                                                         float* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+extern "C" int cgs_gather_roll_u8(const uint8_t* src, const int64_t* idx, int32_t n, int32_t shift_px, uint8_t* dst,
+                                  cgs_stream_t stream) {
+    if (!src || !idx || !dst || n < 0 || shift_px < 0 || shift_px >= 64) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(gather_roll_u8_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, src, idx, shift_px, (uint32_t*)dst);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gather_f32(const float* src, const int64_t* idx, int32_t n, float* dst, cgs_stream_t stream) {
+    if (!src || !idx || !dst || n < 0) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(gather_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, idx, n, dst);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 extern "C" const char* cgs_build_arch(void) { return "gfx950"; }
 extern "C" int cgs_abi_version(void) { return 1; }

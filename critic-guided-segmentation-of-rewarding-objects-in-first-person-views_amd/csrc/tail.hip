@@ -58,7 +58,7 @@ unsigned long long* g_tail_stamps = nullptr;     // debug: per-workgroup stage t
 
 // Debug hook (not part of the product path): when set, thread 0 of every tail workgroup records s_memtime at its stage
 // boundaries of its FIRST image into stamps[(kernel * 2048 + block) * 16 + stage].
-extern "C" int cgs_tail_debug_stamps(unsigned long long* stamps) { g_tail_stamps = stamps; return CGS_OK; }
+extern "C" int dbg_tail_stamps(unsigned long long* stamps) { g_tail_stamps = stamps; return CGS_OK; }
 #define TAIL_STAMP(k)                                                                                     \
     do {                                                                                                  \
         if (P.dbg && tid == 0 && img == (int)blockIdx.x) P.dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \

@@ -35,7 +35,8 @@ class HourglassEngine:
     def __init__(self, n: int, device="cuda:0", dropout: float = 0.3, lfak: float = 5, L1: float = 0.5, L2: float = 0.0,
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
-                 process_group=None, share_with: "HourglassEngine" = None, overlap_wgrad: bool = False):
+                 process_group=None, share_with: "HourglassEngine" = None, overlap_wgrad: bool = False,
+                 separate: bool = False):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -52,7 +53,11 @@ class HourglassEngine:
         self.dp = process_group is not None and (self.world > 1 or os.environ.get("CGS_FORCE_ALLREDUCE") == "1")
         self.lc, self.lm = critic_layout(), masker_layout()
         self.off_c, self.off_m = 0, _align4(self.lc.total)
-        self.total = self.off_m + self.lm.total
+        # -separate (main.py:110-111, 390): a second critic supplies the masker's skip inputs; its parameters sit behind the
+        # masker's, so "masker + sepcrit" (the frozen optimiser group, main.py:334) is one contiguous range too
+        self.separate = bool(separate)
+        self.off_s = _align4(self.off_m + self.lm.total)
+        self.total = self.off_s + self.lc.total if self.separate else self.off_m + self.lm.total
         z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
         if share_with is not None:   # another batch size over the SAME parameters / optimiser state
             self.flat, self.grad, self.m, self.v, self.step_t = (share_with.flat, share_with.grad, share_with.m,
@@ -60,8 +65,10 @@ class HourglassEngine:
         else:
             self.flat, self.grad, self.m, self.v = z(self.total), z(self.total), z(self.total), z(self.total)
             self.step_t = z(1, dt=torch.int64)
-        self.fc, self.fm = self.flat[:self.lc.total], self.flat[self.off_m:]
-        self.gc, self.gm = self.grad[:self.lc.total], self.grad[self.off_m:]
+        self.fc, self.fm = self.flat[:self.lc.total], self.flat[self.off_m:self.off_m + self.lm.total]
+        self.gc, self.gm = self.grad[:self.lc.total], self.grad[self.off_m:self.off_m + self.lm.total]
+        if self.separate:
+            self.fs, self.gs = self.flat[self.off_s:], self.grad[self.off_s:]
         # every rank draws its own dropout stream (the global batch then holds independent masks, as one process would)
         self.drop = hg.DropState(self.p, (seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF, self.step_t)
         n4 = 4 * n
@@ -73,13 +80,21 @@ class HourglassEngine:
             self.cbuf[f"e{i}"] = z(n4, hw // 2, hw // 2, co)
             self.cbuf[f"am{i}"] = z(n4, hw // 2, hw // 2, co // 8, dt=torch.int32)
         self.cbuf["e4"], self.cbuf["h1"], self.cbuf["pred"] = z(n4, 32), z(n4, 32), z(n4)
+        self.sbuf: Dict[str, torch.Tensor] = {}              # -separate: the second critic's activations on A
+        if self.separate:
+            for i, (key, hw, ca, cb, co, *_r) in enumerate(ENC_LAYERS):
+                self.sbuf[f"e{i}"] = z(n, hw // 2, hw // 2, co)
+                self.sbuf[f"am{i}"] = z(n, hw // 2, hw // 2, co // 8, dt=torch.int32)
+            self.sbuf["e4"], self.sbuf["h1"], self.sbuf["pred"] = z(n, 32), z(n, 32), z(n)
+            self._zero_dpred = z(n)
         self.mbuf: Dict[str, torch.Tensor] = {}
         # partial sums of |Z| and Z^2: from the mask layer's workgroups (4 per image) or from cgs_mix_fwd's
         self.nzpart = hg.zpart_count(n) if hg.ENC0_MIX_FUSED else _lib.load().cgs_mix_fwd_partials(n, 4096)
         self.zsum, self.losses, self.dpred = z(2 * self.nzpart), z(8), z(n4)
         self.dmixed = None if hg.ENC0_MIX_FUSED else z(2 * n, 64, 64, 3)
         self.dzpre = z(n, 64, 64)
-        self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "p1": {}}
+        self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "cb_sep": {}, "p1": {}}
+        self._infer_step = z(1, dt=torch.int64)              # -noevalmode: Dropout stream of inference batches
         self._graphs: Dict[str, object] = {}
         # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
         # the cross-queue joins cost what the overlap gains)
@@ -87,11 +102,13 @@ class HourglassEngine:
         self._plans: Dict[str, hg.SlabPlan] = {}
 
     # ---- parameters --------------------------------------------------------------------------
-    def load_state(self, critic_sd=None, masker_sd=None):
+    def load_state(self, critic_sd=None, masker_sd=None, sepcrit_sd=None):
         if critic_sd is not None:
             self.lc.flatten({k: v.to(self.dev) for k, v in critic_sd.items()}, self.fc)
         if masker_sd is not None:
             self.lm.flatten({k: v.to(self.dev) for k, v in masker_sd.items()}, self.fm)
+        if sepcrit_sd is not None:
+            self.lc.flatten({k: v.to(self.dev) for k, v in sepcrit_sd.items()}, self.fs)
         parallel.broadcast_params_(self.flat, self.pg)    # replicas start identical
 
     def critic_state(self):
@@ -100,14 +117,21 @@ class HourglassEngine:
     def masker_state(self):
         return self.lm.unflatten(self.fm)
 
-    def adopt(self, critic_module, masker_module):
+    def sepcrit_state(self):
+        return self.lc.unflatten(self.fs)
+
+    def adopt(self, critic_module, masker_module, sepcrit_module=None):
         """Re-homes the flat parameters of nets.NewCritic / nets.UnetDecoder into this engine's buffer, so the
         modules and the engine always see the same weights (no copies at save time)."""
         with torch.no_grad():
             self.fc.copy_(critic_module.flat.detach().to(self.dev))
             self.fm.copy_(masker_module.flat.detach().to(self.dev))
+            if sepcrit_module is not None:
+                self.fs.copy_(sepcrit_module.flat.detach().to(self.dev))
         critic_module.flat.data = self.fc
         masker_module.flat.data = self.fm
+        if sepcrit_module is not None:
+            sepcrit_module.flat.data = self.fs
 
     def reset_optimizer(self):
         self.m.zero_(); self.v.zero_(); self.step_t.zero_()
@@ -142,15 +166,19 @@ class HourglassEngine:
             out1[name], out2[name] = big[:a], big[a:]
         return out1, out2
 
+    def _opt_range(self):
+        """(first float, count) of the optimiser group: everything when live, else masker (+ sepcrit) (main.py:330-334)."""
+        return (0, self.total) if self.live else (self.off_m, self.total - self.off_m)
+
     def _adam(self):
-        lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
+        lo, cnt = self._opt_range()
         _lib.call("cgs_adam_flat", cnt, C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
                   C.c_void_p(self.m.data_ptr() + 4 * lo), C.c_void_p(self.v.data_ptr() + 4 * lo), _P(self.step_t),
                   self.lr, self.b1, self.b2, self.eps, 1.0 / self.world, _S())
 
     def _allreduce(self):
         if self.dp:
-            lo, cnt = (0, self.total) if self.live else (self.off_m, self.lm.total)
+            lo, cnt = self._opt_range()
             parallel.allreduce_sum_(self.grad[lo:lo + cnt], self.pg)
 
     # ---- phase 2 -----------------------------------------------------------------------------
@@ -168,9 +196,15 @@ class HourglassEngine:
         fm_ptr = self.fm.data_ptr()
         pw = (C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")), C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")),
               self._o4_full)
-        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n), pw=pw)
+        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n),
+                          pw=None if self.separate else pw)
         sa = self._cview(n, 2 * n)
-        embeds = [sa[f"e{i}"] for i in range(5)]
+        if self.separate:     # main.py:389-390: the masker's inputs come from the second critic's pass over A
+            pws = (pw[0], pw[1], self.mbuf["o4"])
+            hg.critic_forward(self.fs, self.lc, A, n, drop.shifted(4 * n), out=self.sbuf, pw=pws)
+            embeds = [self.sbuf[f"e{i}"] for i in range(5)]
+        else:
+            embeds = [sa[f"e{i}"] for i in range(5)]
         hg.masker_forward(self.fm, self.lm, A, embeds, n, out=self.mbuf, o4_done=True,
                           zpart=self.zsum if hg.ENC0_MIX_FUSED else None)
         if hg.ENC0_MIX_FUSED:
@@ -211,8 +245,18 @@ class HourglassEngine:
         # live: the 1x1 bottleneck conv's backward runs inside the critic head kernel (frozen: no critic backward on A,
         # the masker does it itself)
         d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side,
-                                   pw_in_head=self.live)
-        if self.live:
+                                   pw_in_head=self.live or self.separate)
+        ps = hg.SlabPlan()
+        if self.separate:
+            # the skip gradients (and the bottleneck's) go into the SECOND critic; its own head sees no loss (dpred = 0)
+            d_o4, d_emb[4] = d_emb[4], None
+            hg.critic_backward(self.fs, self.lc, A, n, self.sbuf, self._zero_dpred, ps, drop.shifted(4 * n), d_embeds=d_emb,
+                               n_add=n, ws=self._ws["cb_sep"], side=self.side,
+                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
+            if self.live:
+                hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), ws=self._ws["cb_a"],
+                                   side=self.side)
+        elif self.live:
             d_o4, d_emb[4] = d_emb[4], None
             hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
                                n_add=n, ws=self._ws["cb_a"], side=self.side,
@@ -225,6 +269,8 @@ class HourglassEngine:
                     full.jobs.append((slab, nsl, cnt, self.off_c + off))
             for slab, nsl, cnt, off in pm.jobs:
                 full.jobs.append((slab, nsl, cnt, self.off_m + off))
+            for slab, nsl, cnt, off in ps.jobs:
+                full.jobs.append((slab, nsl, cnt, self.off_s + off))
             self._plans["p2"] = full.build(self.grad)
         self._plans["p2"].run(self.step_t)
 
@@ -242,6 +288,22 @@ class HourglassEngine:
             self.y.copy_(Y.to(torch.float32), non_blocking=True)
         self._run("p2", self._phase2_fwd_bwd)
         return self.losses
+
+    def gather_contrastive(self, Xpos: torch.Tensor, Xneg: torch.Tensor, ypos: torch.Tensor, yneg: torch.Tensor,
+                           idx: torch.Tensor, shift_px: int = 0):
+        """Assembles the resident batch of a phase-2 step on the device (main.py:344-356): A = [Xpos[idx[:h]] | Xneg[idx[h:n]]]
+        rolled along the width by shift_px pixels, B = Xneg[idx[n:2n]] (not rolled), y = the targets of A.  Xpos / Xneg: uint8
+        [*,64,64,3] frame sets resident on the device, ypos / yneg fp32 [*], idx int64 [2n] on the device (h = n / 2)."""
+        n, h = self.n, self.n // 2
+        A, B = self.ab[n:], self.ab[:n]
+        ip = idx.data_ptr()
+        g = lambda src, off, cnt, sh, dst: _lib.call("cgs_gather_roll_u8", _P(src), C.c_void_p(ip + 8 * off), cnt, int(sh) % 64,
+                                                     C.c_void_p(dst), _S())
+        g(Xpos, 0, h, shift_px, A.data_ptr())
+        g(Xneg, h, n - h, shift_px, A.data_ptr() + h * 12288)
+        g(Xneg, n, n, 0, B.data_ptr())
+        _lib.call("cgs_gather_f32", _P(ypos), C.c_void_p(ip), h, _P(self.y), _S())
+        _lib.call("cgs_gather_f32", _P(yneg), C.c_void_p(ip + 8 * h), n - h, C.c_void_p(self.y.data_ptr() + 4 * h), _S())
 
     # ---- phase 1 -----------------------------------------------------------------------------
     def _phase1_fwd_bwd(self):
@@ -329,18 +391,27 @@ class HourglassEngine:
 
     # ---- inference (main.py:1130-1151) -----------------------------------------------------------
     @torch.no_grad()
-    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False):
+    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
-        Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM."""
+        Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM.
+        train_mode (-noevalmode, main.py:1109-1118): Dropout stays active, a fresh mask per call.
+        With a second critic (-separate, main.py:1140-1142) the masker's inputs come from it."""
         hg._chk_img(X, 0, "infer input")
         b = X.shape[0]
+        drop = hg.NO_DROP
+        if train_mode and self.p > 0.0:
+            drop = hg.DropState(self.p, self.drop.seed ^ 0xD1CE, self._infer_step)
         if not want_mask:
-            return hg.critic_forward(self.fc, self.lc, X.contiguous(), b)["pred"], None
-        o4 = torch.empty((b, 32), device=X.device, dtype=torch.float32)
-        fm_ptr = self.fm.data_ptr()
-        c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b,
-                              pw=(C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")),
-                                  C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")), o4))
-        m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [c[f"e{i}"] for i in range(5)], b, out={"o4": o4}, o4_done=True,
-                              keep_hm=False, fp16_mask_head=fp16_mask_head)
-        return c["pred"], m["Z"]
+            out = hg.critic_forward(self.fc, self.lc, X.contiguous(), b, drop)["pred"], None
+        else:
+            o4 = torch.empty((b, 32), device=X.device, dtype=torch.float32)
+            fm_ptr = self.fm.data_ptr()
+            pw = (C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")), C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")), o4)
+            c = hg.critic_forward(self.fc, self.lc, X.contiguous(), b, drop, pw=None if self.separate else pw)
+            src = hg.critic_forward(self.fs, self.lc, X.contiguous(), b, drop.shifted(b), pw=pw) if self.separate else c
+            m = hg.masker_forward(self.fm, self.lm, X.contiguous(), [src[f"e{i}"] for i in range(5)], b, out={"o4": o4},
+                                  o4_done=True, keep_hm=False, fp16_mask_head=fp16_mask_head)
+            out = c["pred"], m["Z"]
+        if drop is not hg.NO_DROP:
+            self._infer_step += 1
+        return out

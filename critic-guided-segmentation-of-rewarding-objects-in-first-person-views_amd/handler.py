@@ -15,7 +15,7 @@ from itertools import chain
 import numpy as np
 import torch
 
-from . import _lib, dataformat
+from . import _lib, dataformat, parallel
 from .engine import HourglassEngine
 from .nets import NewCritic, UnetDecoder
 
@@ -36,7 +36,11 @@ class Handler:
         if not torch.cuda.is_available():
             raise _lib.CgsError("this build runs the Hourglass on an MI355X through HIP kernels; no GPU is visible "
                                 "and there is no CPU fallback")
-        self.device = "cuda"
+        # one process per GPU under torchrun (RANK / LOCAL_RANK / WORLD_SIZE): the training steps then all-reduce their gradients
+        # and the contrastive sweep is sharded by frame; a plain `python main.py` is world size 1
+        self.pg = parallel.init_from_env()
+        self.rank, local, self.world = parallel.env_world()
+        self.device = f"cuda:{local}" if self.world > 1 else "cuda"
         print("device:", self.device)
         self.models = dict()
         self.criticname = "critic"
@@ -61,10 +65,10 @@ class Handler:
     # ------------------------------------------------------------------ models / checkpoints
     def reset_models(self):
         args = self.args
-        if args.separate:
-            raise NotImplementedError("-separate (second critic) is not implemented on the HIP path")
         self.critic = NewCritic(bottleneck=args.neck, chfak=args.chfak, dropout=args.dropout).to(self.device)
         self.masker = UnetDecoder(bottleneck=args.neck, chfak=args.chfak).to(self.device)
+        if args.separate:       # main.py:110-111: a second critic feeds the masker; like the reference it is never checkpointed
+            self.sepcrit = NewCritic(bottleneck=args.neck, chfak=args.chfak, dropout=args.dropout).to(self.device)
 
     def load_models(self, modelnames=[]):
         if not modelnames:
@@ -80,6 +84,8 @@ class Handler:
         return True
 
     def save_models(self, modelnames=[]):
+        if self.rank != 0:          # replicas are identical: one writer
+            return
         os.makedirs(self.save_path, exist_ok=True)
         if not modelnames:
             modelnames = self.models.keys()
@@ -123,14 +129,15 @@ class Handler:
             idx = np.sort(perm[b:b + self.batch_size])
             yield torch.from_numpy(self.X[idx]), torch.from_numpy(self.Y[self.args.rewidx, idx]).float()
 
+    def _shift_draw(self):
+        """The two draws main.py:585-586 takes from the global torch RNG, as a signed roll along the width (positive = the
+        reference's "right" branch, negative = its "left" branch)."""
+        amount = int(self.args.shift * torch.rand(1))
+        return -amount if bool(torch.rand(1) > 0.5) else amount
+
     def shift_batch(self, X):
-        """Whole-batch circular roll along width, two draws from the torch RNG (main.py:584-591)."""
-        xshift = int(self.args.shift * torch.rand(1))
-        if torch.rand(1) > 0.5:
-            X = torch.cat((X[:, :, xshift:], X[:, :, :xshift]), dim=2)
-        else:
-            X = torch.cat((X[:, :, -xshift:], X[:, :, :-xshift]), dim=2)
-        return X
+        """Whole-batch circular roll along the width (main.py:584-591): one torch.roll instead of the reference's cat of slices."""
+        return torch.roll(X, shifts=Handler._shift_draw(self), dims=2)
 
     # ------------------------------------------------------------------ engines
     def _engine(self, n, live=True):
@@ -139,9 +146,12 @@ class Handler:
             a = self.args
             first = next(iter(self._engines.values()), None)
             e = HourglassEngine(n, device=self.device, dropout=a.dropout, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject,
-                                live=live, threshrew=a.threshrew, share_with=first)
+                                live=live, threshrew=a.threshrew, share_with=first, process_group=self.pg,
+                                separate=bool(a.separate))
             if first is None:
-                e.adopt(self.critic, self.masker)   # modules and engine share one parameter buffer from now on
+                # modules and engine share one parameter buffer from now on
+                e.adopt(self.critic, self.masker, self.sepcrit if a.separate else None)
+                parallel.broadcast_params_(e.flat, self.pg)
             self._engines[key] = e
         return self._engines[key]
 
@@ -191,50 +201,75 @@ class Handler:
         print()
 
     # ------------------------------------------------------------------ contrastive split
+    def _sweep_preds(self, eng, X, batchsize=4096):
+        """Eval-mode critic value of every frame (main.py:245-253), on the device in large batches; under data parallelism each
+        rank sweeps a contiguous shard of the frames and the shards are all-gathered."""
+        n = len(X)
+        lo, hi = 0, n
+        per = n
+        if self.world > 1:
+            per = -(-n // self.world)
+            lo, hi = min(n, self.rank * per), min(n, (self.rank + 1) * per)
+        out = torch.zeros(per, device=self.device)
+        for b in range(lo, hi, batchsize):
+            e = min(hi, b + batchsize)
+            pred, _ = eng.infer(torch.from_numpy(X[b:e]).to(self.device), want_mask=False)
+            out[b - lo:e - lo] = pred
+        if self.world > 1:
+            parts = [torch.zeros_like(out) for _ in range(self.world)]
+            torch.distributed.all_gather(parts, out, group=self.pg)
+            out = torch.cat(parts)[:n]
+        return out.cpu()
+
     def extract_contrastive_data(self):
+        """Splits the training frames by the critic's value into the high set (> --high-rew-thresh) and the low set
+        (< --low-rew-thresh) (main.py:238-312), keeps both resident on the device as uint8 and sets up the reference's index
+        sampler (32 high + 32 low frames for A, 64 low frames for B, drawn with replacement from the global numpy RNG)."""
         args = self.args
         self.critic.eval()
         eng = self._engine(2 * 32)
-        batchsize = 4096
         if args.critic or args.cload:
-            preds = []
-            for b in range(0, len(self.X), batchsize):
-                xb = torch.from_numpy(self.X[b:b + batchsize]).to(self.device)
-                pred, _ = eng.infer(xb, want_mask=False)
-                preds.append(pred.cpu())
-            preds = torch.cat(preds, dim=0)
-            positives = preds > args.high_rew_thresh
-            negatives = preds < args.low_rew_thresh
+            preds = self._sweep_preds(eng, self.X)
+            positives, negatives = preds > args.high_rew_thresh, preds < args.low_rew_thresh
         else:
             print("no critic provided -> using random pos and neg frames")
             positives = torch.rand(len(self.X)) > 0.5
-            negatives = positives == False  # noqa: E712
+            negatives = ~positives
             preds = torch.cat((positives, negatives), dim=0)
+        npos, nneg = int(positives.sum()), int(negatives.sum())
         os.makedirs(self.path, exist_ok=True)
-        with open(self.path + f"{positives.sum()}>{args.high_rew_thresh}__{negatives.sum()}<{args.low_rew_thresh}.txt", "w") as fp:
-            fp.write("")
-        assert (sum(positives) >= 500 and sum(negatives) >= 500)
-        positives, negatives = positives.numpy(), negatives.numpy()
-        self.Xpos, self.Ypos = self.X[positives], self.Y[:, positives]
-        self.Xneg, self.Yneg = self.X[negatives], self.Y[:, negatives]
-        assert (preds[torch.from_numpy(positives)].float().mean()) > args.high_rew_thresh
-        self.XposIdxs = np.arange(len(self.Xpos))
-        self.XnegIdxs = np.arange(len(self.Xneg))
-        self.ContrastIdxs = np.arange(len(self.Xneg))
+        if self.rank == 0:      # the reference leaves the two counts behind as an (empty) file name
+            open(self.path + f"{npos}>{args.high_rew_thresh}__{nneg}<{args.low_rew_thresh}.txt", "w").close()
+        assert npos >= 500 and nneg >= 500
+        assert preds[positives].float().mean() > args.high_rew_thresh
+        pos, neg = positives.numpy(), negatives.numpy()
+        self.Xpos, self.Ypos = self.X[pos], self.Y[:, pos]
+        self.Xneg, self.Yneg = self.X[neg], self.Y[:, neg]
+        # device-resident copies: a training step then gathers its frames with one index upload, no host frames involved
+        dev = self.device
+        self._Xpos_d, self._Xneg_d = torch.from_numpy(self.Xpos).to(dev), torch.from_numpy(self.Xneg).to(dev)
+        self._ypos_d = torch.from_numpy(np.ascontiguousarray(self.Ypos[args.rewidx])).float().to(dev)
+        self._yneg_d = torch.from_numpy(np.ascontiguousarray(self.Yneg[args.rewidx])).float().to(dev)
+        self.XposIdxs, self.XnegIdxs, self.ContrastIdxs = np.arange(npos), np.arange(nneg), np.arange(nneg)
         self.contrastive_batchsize = 32
-        self.get_contrastive_idxs = lambda: (np.random.choice(self.XposIdxs, self.contrastive_batchsize),
-                                             np.random.choice(self.XnegIdxs, self.contrastive_batchsize),
-                                             np.random.choice(self.ContrastIdxs, 2 * self.contrastive_batchsize))
+        cb = self.contrastive_batchsize
+        self.get_contrastive_idxs = lambda: (np.random.choice(self.XposIdxs, cb), np.random.choice(self.XnegIdxs, cb),
+                                             np.random.choice(self.ContrastIdxs, 2 * cb))
 
     # ------------------------------------------------------------------ phase 2: mask training
     def segmentation_training(self):
+        """main.py:314-575 without the debug image grids: per step three index draws (numpy RNG, as the reference), the two
+        shift draws (torch RNG), ONE 128-entry index upload; the frames are gathered, rolled and trained on without leaving
+        the device."""
+        import time
         args = self.args
         self._refuse_unbuilt_flags()
         self.extract_contrastive_data()
         train_path = self.path + "segment/"
         os.makedirs(train_path, exist_ok=True)
-        with open(train_path + "log.txt", "w") as log_file:
-            log_file.write(f"{self.args}\n\n")
+        if self.rank == 0:
+            with open(train_path + "log.txt", "w") as log_file:
+                log_file.write(f"{self.args}\n\n")
         log = []
         self.critic.train()
         self.masker.train()
@@ -245,35 +280,35 @@ class Handler:
             self.eval()
             self.critic.train()
             self.masker.train()
+        idx_host = torch.empty(2 * n, dtype=torch.int64).pin_memory()
+        idx_dev = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+        names = ["replace", "inject", "norm", "live-critic"]
+        steps, t0 = 0, time.perf_counter()
         for epoch in range(args.mepochs):
             for b_idx in range(math.ceil(self.Xpos.shape[0] / self.contrastive_batchsize)):
                 Hidx, Lidx, Cidx = self.get_contrastive_idxs()
-                X = torch.cat((torch.from_numpy(self.Xpos[Hidx]), torch.from_numpy(self.Xneg[Lidx])), dim=0)
-                Y = torch.cat((torch.from_numpy(self.Ypos[args.rewidx, Hidx]), torch.from_numpy(self.Yneg[args.rewidx, Lidx])), dim=0)
-                CX = torch.from_numpy(self.Xneg[Cidx])
-                if args.shift:
-                    X = self.shift_batch(X)
-                losses = eng.phase2_step(X.contiguous().to(self.device, non_blocking=True),
-                                         CX.to(self.device, non_blocking=True), Y.float().to(self.device, non_blocking=True))
-                if not b_idx % 10:
+                idx_host.copy_(torch.from_numpy(np.concatenate((Hidx, Lidx, Cidx))))
+                idx_dev.copy_(idx_host, non_blocking=True)
+                roll = self._shift_draw() if args.shift else 0      # torch.roll(X, roll, dims=2): dst[x] = src[x - roll]
+                eng.gather_contrastive(self._Xpos_d, self._Xneg_d, self._ypos_d, self._yneg_d, idx_dev, shift_px=(-roll) % 64)
+                losses = eng.phase2_step()
+                steps += 1
+                if not b_idx % 10:                                   # the only host sync
                     c, r, i, l1, l2, total = losses[:6].tolist()
                     log.append((r, i if args.inject else 0, l1 + l2, c if args.live else 0))
-                    s = f"e{epoch} b{b_idx}"
-                    if args.live:
-                        s += f"    live-critic {c}"
-                    s += f"   replace: {r}"
-                    if args.inject:
-                        s += f"   inject: {i}"
-                    if args.L1:
-                        s += f"   L1: {l1}"
-                    if args.L2:
-                        s += f"   L2: {l2}"
-                    print(s, end="\r")
-            llog = np.array(log)
-            self._plot(train_path + "_loss.png", {nm: llog[:, k] for k, nm in enumerate(["replace", "inject", "norm", "live-critic"])})
+                    msg = f"e{epoch} b{b_idx}" + (f"    live-critic {c}" if args.live else "") + f"   replace: {r}"
+                    msg += (f"   inject: {i}" if args.inject else "") + (f"   L1: {l1}" if args.L1 else "") + (f"   L2: {l2}" if args.L2 else "")
+                    print(msg, end="\r")
+            if self.rank == 0:
+                llog = np.array(log)
+                self._plot(train_path + "_loss.png", {nm: llog[:, k] for k, nm in enumerate(names)})
             if not (epoch + 1) % args.saveevery:
                 self.save_models(modelnames=[self.maskername])
-        print()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        self.train_images_per_s = steps * n * self.world / dt if dt > 0 else 0.0
+        print(f"\nmask training: {steps} steps of {n} A-images in {dt:.2f} s = {self.train_images_per_s:.0f} images/s"
+              + (f" over {self.world} ranks" if self.world > 1 else ""))
         self.save_models(modelnames=[self.maskername])
 
     # ------------------------------------------------------------------ -process: masks for a folder of images
@@ -282,10 +317,10 @@ class Handler:
         print("STARTING SEGMENTATION...")
         args = self.args
         os.makedirs(self.path, exist_ok=True)
-        if args.noevalmode:
-            raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
         if args.crf:
             raise NotImplementedError("-crf is outside this build's scope")
+        if args.noevalmode and args.salience:
+            raise NotImplementedError("-noevalmode together with -salience (Dropout inside the saliency backward) is not implemented")
         if args.process_salience and not args.salience:
             raise ValueError("-process_salience needs -salience (the reference collects the maps only then, main.py:1136-1147)")
         self.critic.eval()
@@ -302,7 +337,7 @@ class Handler:
             if args.salience:           # main.py:1136-1147: |d mean(pred) / d batch| summed over the colour channels
                 _p, dx = eng.saliency(batch)
                 salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
-            pred, Z = eng.infer(batch)
+            pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # -noevalmode: Dropout stays on (main.py:1109-1118)
             preds.append(pred.cpu().numpy())
             M.append(Z.cpu().numpy()[:, None])
         print()
@@ -357,8 +392,8 @@ class Handler:
         976-1003 (|d mean(pred)/dX| summed over channels, normalised, weighted by pred, thresholded) and its IoU.
         Returns [iou] or [iou, saliou] like the reference."""
         args = self.args
-        if args.noevalmode:
-            raise NotImplementedError("-noevalmode (dropout at inference) is not implemented on the HIP path")
+        if args.noevalmode and args.salience:
+            raise NotImplementedError("-noevalmode together with -salience (Dropout inside the saliency backward) is not implemented")
         if args.crf or args.resimages or folder or vis:
             raise NotImplementedError("-crf / -resimages / folder / video evaluation are outside this build's scope")
         evaldatapath = "red-trees/"
@@ -380,7 +415,7 @@ class Handler:
             if args.salience:
                 _p, dx = eng.saliency(batch)
                 salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
-            pred, Z = eng.infer(batch)
+            pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # main.py:900-909
             preds.append(pred.cpu().numpy())
             M.append(Z.cpu().numpy()[:, None])
         M = np.concatenate(M, axis=0)

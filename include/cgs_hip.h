@@ -314,6 +314,14 @@ int cgs_nhwc_to_nchw(int32_t n, int32_t c, int32_t hw, const float* src, float* 
 int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stream);
 
 /* Library / device info: returns the gfx arch string the library was built for. */
+/* ---- contrastive batch assembly on the device (main.py:344-356, 584-591) ------------------------------------------
+ * dst [n,64,64,3] uint8: frame src[idx[i]] of a device-resident uint8 frame set, rolled circularly along the width:
+ * dst[i][y][x] = src[idx[i]][y][(x + shift_px) mod 64].  Handler.shift_batch's "left" roll by s pixels is shift_px = s, its
+ * "right" roll shift_px = (64 - s) mod 64.  idx: device int64 [n].  cgs_gather_f32: dst[i] = src[idx[i]] (the targets). */
+int cgs_gather_roll_u8(const uint8_t* src, const int64_t* idx, int32_t n, int32_t shift_px, uint8_t* dst,
+                       cgs_stream_t stream);
+int cgs_gather_f32(const float* src, const int64_t* idx, int32_t n, float* dst, cgs_stream_t stream);
+
 const char* cgs_build_arch(void);
 int cgs_abi_version(void);
 

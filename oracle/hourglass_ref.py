@@ -188,12 +188,13 @@ def phase1_loss(Pc: Params, XP: torch.Tensor, Y: torch.Tensor, threshrew: float 
 
 def phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: torch.Tensor,
                 lfak: float = 5, L1: float = 0.5, L2: float = 0.0, inject: bool = True, live: bool = True,
-                threshrew: float = 0.0, p: float = 0.0, training: bool = True, masks=None):
+                threshrew: float = 0.0, p: float = 0.0, training: bool = True, masks=None, Ps: Optional[Params] = None):
     """Joint mask/critic objective of one phase-2 step (main.py:364-429, staticnorm => valuefak=1).
 
     ``masks`` (optional) = 4 lists of 3 dropout keep-masks for the passes [A, B, replaced, injected]
-    in the order the reference draws them.  Returns (total, parts dict, Z, pred)."""
-    mk = masks if masks is not None else [None, None, None, None]
+    in the order the reference draws them (a 5th list: the second critic's pass over A).  ``Ps``: parameters of the second
+    critic of -separate (main.py:389-390): the masker then takes ITS embeds of A.  Returns (total, parts dict, Z, pred)."""
+    mk = masks if masks is not None else [None, None, None, None, None]
     pred, embeds = critic_apply(Pc, A, collect=True, p=p, training=training, masks=mk[0])
     negpred = critic_apply(Pc, B, p=p, training=training, masks=mk[1])
     pred = pred.squeeze()
@@ -204,6 +205,8 @@ def phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: tor
         cl = F.binary_cross_entropy(pred, Y) if threshrew else F.mse_loss(pred, Y)
         total = total + lfak * cl
         parts["critic"] = cl
+    if Ps is not None:
+        _, embeds = critic_apply(Ps, A, collect=True, p=p, training=training, masks=mk[4] if len(mk) > 4 else None)
     Z = masker_apply(Pm, A, embeds)
     replaced = A * (1 - Z) + Z * B
     rv = critic_apply(Pc, replaced, p=p, training=training, masks=mk[2]).squeeze()
@@ -259,27 +262,33 @@ def leafify(P: Params) -> Params:
     return {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
 
 
-def train_phase2(Pc: Params, Pm: Params, batches, steps: int, live=True, **loss_kw):
+def train_phase2(Pc: Params, Pm: Params, batches, steps: int, live=True, Ps: Optional[Params] = None, **loss_kw):
     """Runs ``steps`` optimiser steps of phase 2 on (A,B,Y) batches; returns per-step records.
-    Optimiser membership follows main.py:330-334 (critic+masker when live, masker only when frozen)."""
+    Optimiser membership follows main.py:330-334 (critic+masker when live, masker only when frozen; + the second critic
+    of -separate in both cases)."""
     Pc, Pm = leafify(Pc), leafify(Pm)
-    keys = ([("c", k) for k in Pc] if live else []) + [("m", k) for k in Pm]
-    tensors = [(Pc if w == "c" else Pm)[k] for w, k in keys]
+    Ps = leafify(Ps) if Ps is not None else None
+    keys = ([("c", k) for k in Pc] if live else []) + [("m", k) for k in Pm] + ([("s", k) for k in Ps] if Ps is not None else [])
+    tensors = [{"c": Pc, "m": Pm, "s": Ps}[w][k] for w, k in keys]
     opt = AdamRef(tensors)
     records = []
     for s in range(steps):
         A, B, Y = batches[s % len(batches)]
-        for t in list(Pc.values()) + list(Pm.values()):
+        for t in list(Pc.values()) + list(Pm.values()) + (list(Ps.values()) if Ps is not None else []):
             t.grad = None
-        total, parts, Z, pred = phase2_loss(Pc, Pm, A, B, Y, live=live, **loss_kw)
+        total, parts, Z, pred = phase2_loss(Pc, Pm, A, B, Y, live=live, Ps=Ps, **loss_kw)
         total.backward()
         rec = dict(total=float(total.detach()), parts={k: float(v.detach()) for k, v in parts.items()},
                    grads_c={k: (v.grad.clone() if v.grad is not None else None) for k, v in Pc.items()},
                    grads_m={k: (v.grad.clone() if v.grad is not None else None) for k, v in Pm.items()},
                    Z=Z.detach().clone(), pred=pred.detach().clone())
+        if Ps is not None:
+            rec["grads_s"] = {k: (v.grad.clone() if v.grad is not None else None) for k, v in Ps.items()}
         opt.step([t.grad for t in tensors])
         rec["params_c"] = {k: v.detach().clone() for k, v in Pc.items()}
         rec["params_m"] = {k: v.detach().clone() for k, v in Pm.items()}
+        if Ps is not None:
+            rec["params_s"] = {k: v.detach().clone() for k, v in Ps.items()}
         records.append(rec)
     return records
 

@@ -17,7 +17,8 @@ Fixtures (all float32 unless noted):
   g2_eval.npz            eval-mode forward: pred, 5 embeds, decoder intermediates, mask
   g2_eval_chfak5.npz     same for the paper-size model (weights = oracle.seeded_params seeds)
   g3_train_*.npz         phase-2 step, dropout=0: losses, grads, params after steps 1..3
-                         (default / -noinject / -frozen / --L2 0.1 / --threshrew 0.5 = BCE live-critic loss, main.py:380-381)
+                         (default / -noinject / -frozen / --L2 0.1 / --threshrew 0.5 = BCE live-critic loss, main.py:380-381 /
+                         -separate = a second critic feeds the masker, main.py:110-111,389-390, live and frozen)
   g4_phase1_*.npz        phase-1 step: loss, grads, params after step 1 (mse and bce variants)
   g5_shift.npz           shift_batch under torch.manual_seed(k)
   g7_dropout.npz         phase-2 step with dropout 0.3 and the recorded keep-masks
@@ -125,18 +126,27 @@ np.savez(os.path.join(HERE, "g2_eval_chfak5.npz"), X=g25["X"], pred=g25["pred"],
 
 
 # ---------------------------------------------------------------- G3 / G7: phase-2 steps
-def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False, threshrew=0.0):
+def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False, threshrew=0.0,
+           separate=False):
     from itertools import chain
     critic, masker = build(1, dropout=dropout)
     load_np(critic, "critic", g1); load_np(masker, "masker", g1)
     critic.train(); masker.train()
-    opti = torch.optim.Adam(chain(critic.parameters(), masker.parameters())) if live \
-        else torch.optim.Adam(masker.parameters())
+    sepcrit = None
+    if separate:        # main.py:110-111: a second NewCritic; its embeds of A feed the masker (main.py:389-390)
+        torch.manual_seed(77)
+        sepcrit = refnets.NewCritic(bottleneck=32, chfak=1, dropout=dropout)
+        sepcrit.train()
+    sp = sepcrit.parameters() if separate else []
+    opti = torch.optim.Adam(chain(critic.parameters(), masker.parameters(), sp)) if live \
+        else torch.optim.Adam(chain(masker.parameters(), sp))
     a_u8, b_u8 = frames(0, 8), frames(1, 8)
     Y = torch.from_numpy(np.random.RandomState(2).rand(8)).float()
     if threshrew:       # load_data binarises the targets (main.py:124-127), the step then uses BCE (main.py:380-381)
         Y = (Y > threshrew).float()
     out = {"A": a_u8, "B": b_u8, "Y": Y.numpy()}
+    if separate:
+        out.update(sd_np("sepcrit0", sepcrit.state_dict()))
     masks = []
     orig_dropout = F.dropout
     if record_masks:
@@ -159,6 +169,8 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
             if live:
                 cl = F.binary_cross_entropy(pred, Y) if threshrew else F.mse_loss(pred, Y)
                 loss = loss + lfak * cl; parts[0] = cl.item()
+            if separate:
+                _, embeds = sepcrit(A, collect=True)
             Z = masker(A, embeds)
             replaced = A * (1 - Z) + Z * B
             rl = F.mse_loss(critic(replaced).squeeze(), negpred.detach())
@@ -184,12 +196,18 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
                 for k, v in masker.named_parameters():
                     if v.grad is not None:
                         out[f"grad/masker/{k}"] = v.grad.numpy().copy()
+                if separate:
+                    for k, v in sepcrit.named_parameters():
+                        if v.grad is not None:
+                            out[f"grad/sepcrit/{k}"] = v.grad.numpy().copy()
             opti.step()
             out[f"total{s}"] = np.float64(loss.item())
             out[f"parts{s}"] = parts
             if s in (0, steps - 1):
                 out.update(sd_np(f"step{s + 1}/critic", critic.state_dict()))
                 out.update(sd_np(f"step{s + 1}/masker", masker.state_dict()))
+                if separate:
+                    out.update(sd_np(f"step{s + 1}/sepcrit", sepcrit.state_dict()))
     finally:
         F.dropout = orig_dropout
     for i, mk in enumerate(masks):
@@ -202,6 +220,8 @@ phase2("g3_train_noinject", inject=False)
 phase2("g3_train_frozen", live=False)
 phase2("g3_train_l2", L2=0.1)
 phase2("g3_train_bce", threshrew=0.5)
+phase2("g3_train_separate", separate=True)
+phase2("g3_train_separate_frozen", separate=True, live=False)
 phase2("g7_dropout", steps=1, dropout=0.3, record_masks=True)
 
 

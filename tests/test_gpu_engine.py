@@ -61,6 +61,76 @@ def test_phase2_matches_reference_capture(golden, g1, tag, kw, use_graph):
                 rel_close(e.masker_state()[k].cpu().numpy(), v, f"masker {k} after step {s + 1}", rtol=1e-3, atol_scale=1e-4)
 
 
+@pytest.mark.parametrize("tag,live", [("g3_train_separate", True), ("g3_train_separate_frozen", False)])
+def test_phase2_separate_critic_matches_reference_capture(golden, g1, tag, live):
+    """-separate (main.py:110-111, 328-334, 389-390): the masker is fed by a second critic that trains along."""
+    from cgs_amd import engine
+    g = golden(tag + ".npz")
+    dev = torch.device("cuda:0")
+    pc, pm = g1
+    e = engine.HourglassEngine(8, dropout=0.0, live=live, separate=True)
+    e.load_state(pc, pm, {k: torch.from_numpy(v) for k, v in split(g, "sepcrit0").items()})
+    A, B, Y = (torch.from_numpy(g[k]).to(dev) for k in ("A", "B", "Y"))
+    for s in range(3):
+        losses = e.phase2_step(A, B, Y).cpu().numpy().astype(np.float64)
+        got = losses[:5].copy()
+        if not live:
+            got[0] = 0.0
+        np.testing.assert_allclose(got, g[f"parts{s}"], rtol=1e-3, atol=1e-7, err_msg=f"losses step {s}")
+        if s == 0:
+            gm, gs = e.lm.unflatten(e.gm), e.lc.unflatten(e.gs)
+            for k, v in split(g, "grad/masker").items():
+                rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
+            for k, v in split(g, "grad/sepcrit").items():
+                rel_close(gs[k].cpu().numpy(), v, f"second-critic grad {k}")
+            if live:
+                gc = e.lc.unflatten(e.gc)
+                for k, v in split(g, "grad/critic").items():
+                    rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
+    for k, v in split(g, "step3/sepcrit").items():
+        rel_close(e.sepcrit_state()[k].cpu().numpy(), v, f"second critic {k} after step 3", rtol=1e-3, atol_scale=1e-4)
+    for k, v in split(g, "step3/masker").items():
+        rel_close(e.masker_state()[k].cpu().numpy(), v, f"masker {k} after step 3", rtol=1e-3, atol_scale=1e-4)
+    for k, v in split(g, "step3/critic").items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v, f"critic {k} after step 3", rtol=1e-3, atol_scale=1e-4)
+
+
+def test_device_batch_assembly_matches_host_gather_and_roll():
+    """cgs_gather_roll_u8 / cgs_gather_f32 (main.py:344-356 + shift_batch 584-591 on the device) vs numpy fancy indexing + torch.roll."""
+    from cgs_amd import engine
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    Xpos = rs.randint(0, 256, (50, 64, 64, 3)).astype(np.uint8)
+    Xneg = rs.randint(0, 256, (70, 64, 64, 3)).astype(np.uint8)
+    ypos, yneg = rs.rand(50).astype(np.float32), rs.rand(70).astype(np.float32)
+    n = 16
+    e = engine.HourglassEngine(n, dropout=0.0)
+    for roll in (0, 5, -7, 11, -12):
+        H, L, Cc = rs.choice(50, n // 2), rs.choice(70, n // 2), rs.choice(70, n)
+        idx = torch.from_numpy(np.concatenate((H, L, Cc))).to(dev)
+        e.gather_contrastive(torch.from_numpy(Xpos).to(dev), torch.from_numpy(Xneg).to(dev), torch.from_numpy(ypos).to(dev),
+                             torch.from_numpy(yneg).to(dev), idx, shift_px=(-roll) % 64)
+        torch.cuda.synchronize()
+        want_a = torch.roll(torch.from_numpy(np.concatenate((Xpos[H], Xneg[L]))), shifts=roll, dims=2).numpy()
+        np.testing.assert_array_equal(e.ab[n:].cpu().numpy(), want_a)
+        np.testing.assert_array_equal(e.ab[:n].cpu().numpy(), Xneg[Cc])
+        np.testing.assert_array_equal(e.y.cpu().numpy(), np.concatenate((ypos[H], yneg[L])))
+
+
+def test_infer_with_dropout_noevalmode(g1):
+    """-noevalmode (main.py:1109-1118): Dropout stays active at inference -- a fresh mask per call, eval-mode results otherwise."""
+    e = make_engine(g1, 8, dropout=0.3)
+    dev = torch.device("cuda:0")
+    X = torch.from_numpy(np.random.RandomState(8).randint(0, 256, (40, 64, 64, 3)).astype(np.uint8)).to(dev)
+    p0, z0 = e.infer(X)
+    p1, z1 = e.infer(X, train_mode=True)
+    p2, z2 = e.infer(X, train_mode=True)
+    p3, z3 = e.infer(X)
+    assert torch.equal(p0, p3) and torch.equal(z0, z3)                 # eval mode is deterministic
+    assert not torch.equal(p1, p2) and not torch.equal(p0, p1)         # train mode draws new masks every call
+    assert float((z1 - z0).abs().max()) > 0 and torch.isfinite(z1).all() and float(z1.min()) > 0 and float(z1.max()) < 1
+
+
 @pytest.mark.parametrize("tag,thr", [("g4_phase1_mse", 0.0), ("g4_phase1_bce", 0.5)])
 def test_phase1_matches_reference_capture(golden, g1, tag, thr):
     g = golden(tag + ".npz")

@@ -94,6 +94,25 @@ def test_phase2_steps_match_reference(golden, g1, tag, kw):
                 np.testing.assert_allclose(recs[s - 1][which][k].numpy(), v.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"{s}:{k}")
 
 
+@pytest.mark.parametrize("tag,live", [("g3_train_separate", True), ("g3_train_separate_frozen", False)])
+def test_phase2_separate_critic_matches_reference(golden, g1, tag, live):
+    """-separate (main.py:110-111, 389-390): a second critic's embeds feed the masker; it joins the optimiser group."""
+    pc, pm = g1
+    g = golden(tag + ".npz")
+    ps = {k: v for k, v in split(g, "sepcrit0").items()}
+    A, B, Y = orc.u8_to_nchw(g["A"]), orc.u8_to_nchw(g["B"]), t(g["Y"])
+    recs = orc.train_phase2(pc, pm, [(A, B, Y)], steps=3, live=live, Ps=ps)
+    for s in range(3):
+        assert recs[s]["total"] == pytest.approx(float(g[f"total{s}"]), rel=2e-5)
+    for which, gk in (("grads_m", "grad/masker"), ("grads_s", "grad/sepcrit")) + ((("grads_c", "grad/critic"),) if live else ()):
+        for k, v in split(g, gk).items():
+            np.testing.assert_allclose(recs[0][which][k].numpy(), v.numpy(), rtol=2e-4, atol=2e-6, err_msg=f"{gk}/{k}")
+    for k, v in split(g, "step3/sepcrit").items():
+        np.testing.assert_allclose(recs[2]["params_s"][k].numpy(), v.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    for k, v in split(g, "step3/masker").items():
+        np.testing.assert_allclose(recs[2]["params_m"][k].numpy(), v.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
 def test_frozen_leaves_critic_untouched(golden, g1):
     pc, pm = g1
     g = golden("g3_train_frozen.npz")

@@ -1,4 +1,4 @@
-"""Stage timing of the tail kernels (debug hook cgs_tail_debug_stamps): mean s_memtime deltas between the stage boundaries of
+"""Stage timing of the tail kernels (debug hook dbg_tail_stamps): mean s_memtime deltas between the stage boundaries of
 every workgroup's first image, per kernel.  Usage (GPU box): python tools/tail_stamps.py [batch]"""
 import ctypes as C
 import os
@@ -22,11 +22,11 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = torch.zeros(4 * 2048 * 16, dtype=torch.int64, device=dev)
 lib = _lib.load()
-lib.cgs_tail_debug_stamps.argtypes = [C.c_void_p]
-lib.cgs_tail_debug_stamps(C.c_void_p(buf.data_ptr()))
+lib.dbg_tail_stamps.argtypes = [C.c_void_p]
+lib.dbg_tail_stamps(C.c_void_p(buf.data_ptr()))
 eng.phase2_step()
 torch.cuda.synchronize()
-lib.cgs_tail_debug_stamps(C.c_void_p(0))
+lib.dbg_tail_stamps(C.c_void_p(0))
 st = buf.cpu().numpy().reshape(4, 2048, 16)
 for k, name in enumerate(("enc_fwd (last call: mixes)", "dec_fwd", "enc_bwd (last call: A pass)", "dec_bwd")):
     s = st[k]
