@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fp16-mask-head", action="store_true",
                     help="--mode infer only: fp16 operands for the masker.0 GEMM (BASELINE config 4); ~1e-3 abs in the masks")
-    ap.add_argument("--mode", choices=["train", "infer", "phase1"], default="train",
+    ap.add_argument("--mode", choices=["train", "infer", "phase1", "cli-train"], default="train",
                     help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
                          "phase1 = critic regression step (main.py:183-200)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -134,9 +134,45 @@ def cpu_baseline(n, steps, dropout):
             "ms_per_step": dt * 1e3, "cpu_model": model}
 
 
+def cli_train_mode(args):
+    """End-to-end throughput of the reference's mask-training loop as `main.py -train` runs it (Handler.segmentation_training,
+    main.py:340-463): batch 32 + 32 | 64 (N = 64), per step three numpy index draws, two torch shift draws, one 128-entry index
+    upload, on-device gather + roll, the fused step.  Synthetic frames; the critic is the G1 fixture, thresholds at its 40 / 60 %
+    quantiles so the >= 500 asserts hold."""
+    import tempfile
+    import numpy as np
+    from cgs_amd import cli, handler
+    pc, pm = g1_weights()
+    rs = np.random.RandomState(0)
+    nfr = 16384
+    X = rs.randint(0, 256, (nfr, 64, 64, 3)).astype(np.uint8)
+    X[: nfr // 2] = (X[: nfr // 2] * 0.3).astype(np.uint8)
+    Y = rs.rand(7, nfr)
+    tmp = tempfile.mkdtemp(prefix="cgs_bench_")
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        a = cli.parse_args(["--model", "m", "--dropout", str(args.dropout)])
+        H = handler.Handler(a)
+        H.critic.load_state_dict(pc); H.masker.load_state_dict(pm)
+        H.X, H.Y = X, Y
+        eng = H._engine(64)
+        preds = H._sweep_preds(eng, X).numpy()
+        a.high_rew_thresh, a.low_rew_thresh = float(np.quantile(preds, 0.6)), float(np.quantile(preds, 0.4))
+        H.segmentation_training()
+    finally:
+        os.chdir(cwd)
+    print(json.dumps({"metric": "main.py -train mask-training loop images/sec, 64x64x3, N=64 (reference batch)",
+                      "value": H.train_images_per_s, "unit": "images/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
+                      "data": "synthetic", "config": {"workload": "Handler.segmentation_training: index draws + upload + device gather/roll + "
+                                                       "fused phase-2 step, N_A = N_B = 64, one epoch over the high-value set"}}), flush=True)
+
+
 def side_mode(args, dev, world, rank):
     """Secondary measurements of the same path (not the headline metric): inference and the phase-1 step."""
     from cgs_amd import engine
+    if args.mode == "cli-train":
+        return cli_train_mode(args)
     n = args.batch
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph)
     eng.load_state(*g1_weights())

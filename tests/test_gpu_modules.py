@@ -2,6 +2,7 @@
 it (torch.optim.Adam + F.mse_loss around NewCritic / UnetDecoder), the -train / -process command line on a
 synthetic data set, and the world_size-2 data-parallel engine."""
 import gzip
+import json
 import os
 import pickle
 import subprocess
@@ -227,7 +228,7 @@ import numpy as np, torch
 import torch.distributed as dist
 import cgs_amd
 from cgs_amd import parallel, engine
-pg = parallel.init_from_env("gloo")          # 2 ranks share the one GPU of the box; the collective path is the same
+pg = parallel.init_from_env({backend!r})     # gloo: 2 ranks share the one GPU of the box; nccl (= RCCL): one GPU per rank
 rank, _, world = parallel.env_world()
 raw = dict(np.load(os.path.join({repo!r}, "tests", "golden", "g1_weights_chfak1.npz")))
 pc = {{k.split("/", 1)[1]: torch.from_numpy(v) for k, v in raw.items() if k.startswith("critic/")}}
@@ -247,6 +248,10 @@ flat = e.flat.cpu()
 others = [torch.empty_like(flat) for _ in range(world)]
 dist.all_gather(others, flat)
 assert all(torch.equal(o, others[0]) for o in others), "replicas diverged"
+# every rank draws its own dropout stream (the global batch then holds independent masks)
+seeds = [None] * world
+dist.all_gather_object(seeds, engine.HourglassEngine(2, dropout=0.3, process_group=pg).drop.seed)
+assert len(set(seeds)) == world, seeds
 if rank == 0:
     np.save({out!r}, flat.numpy())
 dist.barrier(); dist.destroy_process_group()
@@ -257,13 +262,21 @@ def test_data_parallel_engine_world2(tmp_path, g1):
     """Two ranks (gloo rendezvous, both on this box's GPU), half the batch each, 3 steps: replicas stay
     bit-identical and match the single-process full-batch run."""
     out = str(tmp_path / "dp_flat.npy")
-    script = tmp_path / "dp_worker.py"
-    script.write_text(DP_WORKER.format(repo=REPO, out=out))
+    _run_dp_workers(tmp_path, out, "gloo")
+    _check_dp_result(out, g1)
+
+
+def _run_dp_workers(tmp_path, out, backend):
+    script = tmp_path / f"dp_worker_{backend}.py"
+    script.write_text(DP_WORKER.format(repo=REPO, out=out, backend=backend))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29531", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", "29531" if backend == "gloo" else "29532", str(script)],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def _check_dp_result(out, g1):
     from cgs_amd import engine
     pc, pm = g1
     rs = np.random.RandomState(3)
@@ -276,3 +289,79 @@ def test_data_parallel_engine_world2(tmp_path, g1):
     for _ in range(3):
         e.phase2_step(A, B, Y)
     rel_close(np.load(out), e.flat.cpu().numpy(), "DP(2) parameters vs single process", rtol=1e-3, atol_scale=1e-4)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_data_parallel_engine_world2_rccl(tmp_path, g1):
+    """The same two-rank run over backend "nccl" (= RCCL over xGMI), one GPU per rank: the production collective path."""
+    out = str(tmp_path / "dp_flat_rccl.npy")
+    _run_dp_workers(tmp_path, out, "nccl")
+    _check_dp_result(out, g1)
+
+
+def test_rccl_path_one_rank_rehearsal():
+    """bench.py with a ONE-rank RCCL group and the data-parallel launch form forced (step graph -> in-place device all-reduce
+    -> Adam graph): init_process_group("nccl", device_id=...), the collective on the device buffer between the two HIP graphs,
+    the barrier and the max-over-ranks timing all execute on this 1-GPU box; its cost shows as the step-time difference."""
+    env = dict(os.environ, CGS_BENCH_FORCE_PG="1", CGS_FORCE_ALLREDUCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_seen_by_collective_backend"] == 1
+    assert np.isfinite(line["final_losses"]["total"]) and line["n_gpus"] == 1
+    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r0 = subprocess.run(cmd, capture_output=True, text=True, env=plain, timeout=900)
+    assert r0.returncode == 0, r0.stderr[-3000:]
+    base = json.loads([ln for ln in r0.stdout.splitlines() if ln.startswith("{")][-1])
+    extra_ms = line["ms_per_step"] - base["ms_per_step"]
+    print(f"three-launch form with a 1-rank RCCL all-reduce: {line['ms_per_step']:.3f} ms vs {base['ms_per_step']:.3f} ms single graph "
+          f"(+{extra_ms * 1e3:.0f} us per step)")
+    assert extra_ms < 0.25, "the all-reduce between the two graphs must stay well below the 6x-at-8-GPUs budget"
+
+
+def test_bench_gpus_flag_starts_ranks_or_refuses():
+    """`python bench.py --gpus N` without a torchrun environment starts N ranks itself (child torchrun, the parent makes no GPU
+    call) or exits non-zero when fewer than N GPUs are visible -- it must never silently run on one GPU."""
+    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(want), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=plain, timeout=300)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+
+
+def test_extract_contrastive_split_matches_oracle(tmp_path, g1, monkeypatch):
+    """Handler.extract_contrastive_data (main.py:238-312): the high / low split of the frames equals thresholding the CPU
+    oracle's eval-mode critic values; the device-resident copies hold exactly those frames; the sampler draws in range."""
+    from cgs_amd import cli, handler
+    monkeypatch.chdir(tmp_path)
+    pc, pm = g1
+    rs = np.random.RandomState(5)
+    n = 2000
+    X = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    X[: n // 2] = (X[: n // 2] * 0.3).astype(np.uint8)            # two brightness populations: a spread of critic values
+    Y = rs.rand(7, n)
+    with torch.no_grad():
+        want = torch.cat([orc.critic_apply(pc, orc.u8_to_nchw(X[b:b + 250])).squeeze(1) for b in range(0, n, 250)]).numpy()
+    hi, lo = float(np.quantile(want, 0.6)), float(np.quantile(want, 0.4))
+    args = cli.parse_args(["--model", "m", "--high-rew-thresh", repr(hi), "--low-rew-thresh", repr(lo)])
+    H = handler.Handler(args)
+    H.critic.load_state_dict(pc)
+    H.X, H.Y = X, Y
+    H.extract_contrastive_data()
+    border = (np.abs(want - hi) < 1e-5) | (np.abs(want - lo) < 1e-5)       # frames whose value sits on a threshold
+    pos, neg = want > hi, want < lo
+    got_pos = np.zeros(n, bool); got_neg = np.zeros(n, bool)
+    # recover the split from the stored frames' targets (Y columns are unique)
+    col = {tuple(np.round(Y[:, i], 12)): i for i in range(n)}
+    for j in range(H.Ypos.shape[1]):
+        got_pos[col[tuple(np.round(H.Ypos[:, j], 12))]] = True
+    for j in range(H.Yneg.shape[1]):
+        got_neg[col[tuple(np.round(H.Yneg[:, j], 12))]] = True
+    assert (got_pos == pos)[~border].all() and (got_neg == neg)[~border].all()
+    np.testing.assert_array_equal(H._Xpos_d.cpu().numpy(), H.Xpos)
+    np.testing.assert_array_equal(H._Xneg_d.cpu().numpy(), H.Xneg)
+    np.testing.assert_allclose(H._ypos_d.cpu().numpy(), H.Ypos[args.rewidx].astype(np.float32))
+    Hi, Li, Ci = H.get_contrastive_idxs()
+    assert len(Hi) == 32 and len(Li) == 32 and len(Ci) == 64 and Hi.max() < len(H.Xpos) and max(Li.max(), Ci.max()) < len(H.Xneg)
