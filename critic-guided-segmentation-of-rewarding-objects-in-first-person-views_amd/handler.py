@@ -283,7 +283,7 @@ class Handler:
         idx_host = torch.empty(2 * n, dtype=torch.int64).pin_memory()
         idx_dev = torch.empty(2 * n, dtype=torch.int64, device=self.device)
         names = ["replace", "inject", "norm", "live-critic"]
-        steps, t0 = 0, time.perf_counter()
+        steps, steps_t0, t0, dt = 0, 0, time.perf_counter(), 0.0
         for epoch in range(args.mepochs):
             for b_idx in range(math.ceil(self.Xpos.shape[0] / self.contrastive_batchsize)):
                 Hidx, Lidx, Cidx = self.get_contrastive_idxs()
@@ -293,21 +293,25 @@ class Handler:
                 eng.gather_contrastive(self._Xpos_d, self._Xneg_d, self._ypos_d, self._yneg_d, idx_dev, shift_px=(-roll) % 64)
                 losses = eng.phase2_step()
                 steps += 1
+                if steps == 20:                                      # throughput is reported for the steady state (after the
+                    torch.cuda.synchronize()                         # eager first step and the graph capture)
+                    t0, steps_t0, dt = time.perf_counter(), steps, 0.0
                 if not b_idx % 10:                                   # the only host sync
                     c, r, i, l1, l2, total = losses[:6].tolist()
                     log.append((r, i if args.inject else 0, l1 + l2, c if args.live else 0))
                     msg = f"e{epoch} b{b_idx}" + (f"    live-critic {c}" if args.live else "") + f"   replace: {r}"
                     msg += (f"   inject: {i}" if args.inject else "") + (f"   L1: {l1}" if args.L1 else "") + (f"   L2: {l2}" if args.L2 else "")
                     print(msg, end="\r")
+            torch.cuda.synchronize()
+            dt += time.perf_counter() - t0            # (plots and checkpoints are not part of the step throughput)
             if self.rank == 0:
                 llog = np.array(log)
                 self._plot(train_path + "_loss.png", {nm: llog[:, k] for k, nm in enumerate(names)})
             if not (epoch + 1) % args.saveevery:
                 self.save_models(modelnames=[self.maskername])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        self.train_images_per_s = steps * n * self.world / dt if dt > 0 else 0.0
-        print(f"\nmask training: {steps} steps of {n} A-images in {dt:.2f} s = {self.train_images_per_s:.0f} images/s"
+            t0 = time.perf_counter()
+        self.train_images_per_s = (steps - steps_t0) * n * self.world / dt if dt > 0 else 0.0
+        print(f"\nmask training: {steps} steps of {n} A-images, {steps - steps_t0} of them in {dt:.3f} s = {self.train_images_per_s:.0f} images/s"
               + (f" over {self.world} ranks" if self.world > 1 else ""))
         self.save_models(modelnames=[self.maskername])
 
