@@ -82,6 +82,11 @@ SIGNATURES = {
     "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_gen_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "cgs_gen_convt4s2_fwd": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen_convt4s2_bwd_data": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_gather_roll_u8": (i32, [vp, vp, i32, i32, vp, vp]),
     "cgs_gather_f32": (i32, [vp, vp, i32, vp, vp]),
     "cgs_dropout_mask": (i32, [Dropout, i64, vp, vp]),

@@ -1,0 +1,334 @@
+// Shape-generic kernels (runtime channel counts and map sizes) for the model sizes the hand-specialised kernels do not
+// cover: NewCritic / UnetDecoder with chfak != 1 (the paper's model is chfak = 5: 40/40/40/80/160 channels, docs/index.html:151,
+// nets.py:166,184,190) and the legacy single-module hourglass `Unet` with its ConvTranspose2d(4,2,1) decoder and
+// LeakyReLU(0.2) (nets.py:356-449).  Forward passes only for the two big families (inference: `-process`, `-eval`, the module
+// API in eval mode); the transposed convolution also has its data- and weight-gradient kernels.
+//
+//   gen_conv3x3_fwd : Conv2d(3x3, s1, p1) over cat(A, nearest-up(B)) + bias + {none, ReLU, LeakyReLU(slope), sigmoid}
+//                     (+ MaxPool2d(2) with a 2-bit argmax) as an implicit GEMM on v_mfma_f32_16x16x4_f32: NHWC LDS tile of 16
+//                     input channels at a time, weights from memory (HWIO), accumulators persistent over the channel chunks.
+//   gen_gemm        : out[n][N] = act(X[n][K] W[K][N] + b): the 4x4 valid convolution at the bottleneck, the Linear layers,
+//                     the 1x1 convolution, ConvTranspose2d(4,1,0) on a 1x1 map.
+//   gen_convt4s2_*  : ConvTranspose2d(4, 2, 1) over cat(A, B): forward, data gradient, weight gradient (direct form).
+#include "tail_common.h"
+
+namespace {
+
+struct GenConvParams {
+    const void* src_a; const float* src_b; const float* w; const float* bias;
+    float* out; uint8_t* argmax;
+    int n, hw, ca, cb, co, a_u8, ups, act, pool, th;
+    float slope;
+};
+
+__device__ __forceinline__ float gen_act(float v, int act, float slope) {
+    if (act == CGS_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == CGS_ACT_LRELU) return v > 0.f ? v : slope * v;
+    if (act == CGS_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+constexpr int GEN_KC = 16;            // input channels staged per chunk
+constexpr int GEN_MAX_TPW = 4;        // pixel tiles (16 pixels) per wave: strips hold <= 256 pixels
+
+// grid: ((image * strips + strip) * column blocks + column block); 256 threads
+__global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    float* tile = (float*)gsm;                      // [(th + 2)][(hw + 2)][GEN_KC]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
+    const int strips = H / TH, ncb = (P.co + 15) / 16;
+    const int cbi = blockIdx.x % ncb, strip = (blockIdx.x / ncb) % strips, img = blockIdx.x / (ncb * strips);
+    const int row0 = strip * TH;
+    const int pa4 = (P.ca + 3) & ~3, cp = pa4 + P.cb, ci_total = P.ca + P.cb;
+    const int nchunk = (cp + GEN_KC - 1) / GEN_KC;
+    const int col = cbi * 16 + l15;
+    const int ntiles = TH * W / 16, QW = W / 2;
+
+    frag4 acc[GEN_MAX_TPW];
+    int abase[GEN_MAX_TPW];
+#pragma unroll
+    for (int i = 0; i < GEN_MAX_TPW; ++i) {
+        acc[i] = frag4{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + 4 * i;
+        const int q = 4 * t + (l15 >> 2), qy = q / QW, qx = q % QW;
+        const int y = 2 * qy + ((l15 >> 1) & 1), x = 2 * qx + (l15 & 1);     // strip-local
+        abase[i] = (y * PW + x) * GEN_KC + kq;
+    }
+    const int su = P.ups, HB = H / su, WB = W / su;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // ---- stage 16 channels of the strip (with halo) ----
+        const int ngrp = (TH + 2) * PW * (GEN_KC / 4);
+        for (int e = tid; e < ngrp; e += 256) {
+            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
+            const int y = row0 + r - 1, x = c - 1, k0 = ch * GEN_KC + 4 * g;
+            float4 v = f4zero();
+            if (y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
+                if (k0 < pa4) {
+                    const size_t pix = ((size_t)img * H + y) * W + x;
+                    if (P.a_u8) {
+                        const uint8_t* s = (const uint8_t*)P.src_a + pix * P.ca + k0;
+                        const float sc = 1.f / 255.f;
+                        v.x = s[0] * sc;
+                        if (k0 + 1 < P.ca) v.y = s[1] * sc;
+                        if (k0 + 2 < P.ca) v.z = s[2] * sc;
+                        if (k0 + 3 < P.ca) v.w = s[3] * sc;
+                    } else if ((P.ca & 3) == 0) {
+                        v = *(const float4*)((const float*)P.src_a + pix * P.ca + k0);
+                    } else {
+                        const float* s = (const float*)P.src_a + pix * P.ca + k0;
+                        v.x = s[0];
+                        if (k0 + 1 < P.ca) v.y = s[1];
+                        if (k0 + 2 < P.ca) v.z = s[2];
+                        if (k0 + 3 < P.ca) v.w = s[3];
+                    }
+                } else {
+                    const size_t pixb = ((size_t)img * HB + y / su) * WB + x / su;
+                    v = *(const float4*)(P.src_b + pixb * P.cb + (k0 - pa4));
+                }
+            }
+            *(float4*)(tile + (size_t)px * GEN_KC + 4 * g) = v;
+        }
+        __syncthreads();
+        // ---- 9 taps x 4 k-steps; the weight operand of a k-step is shared by the wave's pixel tiles ----
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = ((tap / 3) * PW + tap % 3) * GEN_KC;
+            float b[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int k = ch * GEN_KC + 4 * s + kq;                 // padded channel index
+                const int ci = k < pa4 ? (k < P.ca ? k : -1) : (k < cp ? P.ca + (k - pa4) : -1);
+                b[s] = (ci >= 0 && col < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < GEN_MAX_TPW; ++i) {
+                if (wave + 4 * i < ntiles) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile[abase[i] + toff + 4 * s], b[s], acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue ----
+    if (col < P.co) {
+        const float bias = P.bias[col];
+#pragma unroll
+        for (int i = 0; i < GEN_MAX_TPW; ++i) {
+            const int t = wave + 4 * i;
+            if (t >= ntiles) continue;
+            const int q = 4 * t + kq, qy = q / QW, qx = q % QW;
+            if (P.pool) {
+                float m = gen_act(acc[i][0] + bias, P.act, P.slope);
+                int idx = 0;
+#pragma unroll
+                for (int j = 1; j < 4; ++j) {
+                    const float v = gen_act(acc[i][j] + bias, P.act, P.slope);
+                    if (v > m) { m = v; idx = j; }
+                }
+                const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
+                P.out[pp] = m;
+                if (P.argmax) P.argmax[pp] = (uint8_t)idx;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
+                    P.out[(((size_t)img * H + y) * W + x) * P.co + col] = gen_act(acc[i][j] + bias, P.act, P.slope);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[m][n] = act(sum_k X[m][k] W[k][n] + bias[n]);  one wave per 16 x 16 output tile (v_mfma_f32_16x16x4_f32)
+// ------------------------------------------------------------------------------------------------
+struct GenGemmParams {
+    const float* x; const float* w; const float* bias; float* out;
+    int m, k, n, act;
+    float slope;
+};
+
+__global__ void __launch_bounds__(64) gen_gemm_kernel(GenGemmParams P) {
+    const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
+    const int ntn = (P.n + 15) / 16;
+    const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
+    const int row = m0 + l15, col = n0 + l15;
+    const float* xr = P.x + (size_t)(row < P.m ? row : 0) * P.k;
+    frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < P.k; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (row < P.m && k < P.k) ? xr[k] : 0.f;
+        const float b = (col < P.n && k < P.k) ? P.w[(size_t)k * P.n + col] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    if (col < P.n) {
+        const float bias = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m0 + 4 * kq + j;
+            if (r < P.m) P.out[(size_t)r * P.n + col] = gen_act(acc[j] + bias, P.act, P.slope);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(kernel 4, stride 2, padding 1) over cat(A [ca], B [cb]) (both [n,h,w,*] NHWC fp32): out [n,2h,2w,co]
+//   out[oy][ox][co] = b[co] + sum_{ky,kx,ci : oy = 2 iy - 1 + ky, ox = 2 ix - 1 + kx} x[iy][ix][ci] W[ky][kx][ci][co]
+// (kernel layout of the weight: [ky][kx][ci][co]; PyTorch stores [ci][co][ky][kx]).  Direct form, one thread per output element;
+// the legacy model is small (<= 32 channels), this family is about exact semantics, not speed.
+// ------------------------------------------------------------------------------------------------
+struct GenConvTParams {
+    const float* a; const float* b; const float* w; const float* bias; const float* dy;
+    float* out; float* da; float* db; float* dw; float* dbias;
+    int n, h, ca, cb, co, act;
+    float slope;
+};
+
+__device__ __forceinline__ float convt_in(const GenConvTParams& P, int img, int iy, int ix, int ci) {
+    const size_t pix = ((size_t)img * P.h + iy) * P.h + ix;
+    return ci < P.ca ? P.a[pix * P.ca + ci] : P.b[pix * P.cb + (ci - P.ca)];
+}
+
+__global__ void __launch_bounds__(256) gen_convt_fwd_kernel(GenConvTParams P) {
+    const int OH = 2 * P.h, ci_total = P.ca + P.cb;
+    const size_t total = (size_t)P.n * OH * OH * P.co;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int co = e % P.co, ox = (e / P.co) % OH, oy = (e / ((size_t)P.co * OH)) % OH, img = e / ((size_t)P.co * OH * OH);
+        float s = P.bias[co];
+        for (int ky = (oy + 1) & 1; ky < 4; ky += 2) {
+            const int iy = (oy + 1 - ky) >> 1;
+            if (iy < 0 || iy >= P.h) continue;
+            for (int kx = (ox + 1) & 1; kx < 4; kx += 2) {
+                const int ix = (ox + 1 - kx) >> 1;
+                if (ix < 0 || ix >= P.h) continue;
+                const float* wp = P.w + ((size_t)(ky * 4 + kx) * ci_total) * P.co + co;
+                for (int ci = 0; ci < ci_total; ++ci) s = fmaf(convt_in(P, img, iy, ix, ci), wp[(size_t)ci * P.co], s);
+            }
+        }
+        P.out[e] = gen_act(s, P.act, P.slope);
+    }
+}
+
+// dy: gradient w.r.t. the PRE-activation output [n,2h,2w,co].  da / db: gradients w.r.t. A and B.
+__global__ void __launch_bounds__(256) gen_convt_bwd_data_kernel(GenConvTParams P) {
+    const int OH = 2 * P.h, ci_total = P.ca + P.cb;
+    const size_t total = (size_t)P.n * P.h * P.h * ci_total;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int ci = e % ci_total, ix = (e / ci_total) % P.h, iy = (e / ((size_t)ci_total * P.h)) % P.h,
+                  img = e / ((size_t)ci_total * P.h * P.h);
+        float s = 0.f;
+        for (int ky = 0; ky < 4; ++ky) {
+            const int oy = 2 * iy - 1 + ky;
+            if (oy < 0 || oy >= OH) continue;
+            for (int kx = 0; kx < 4; ++kx) {
+                const int ox = 2 * ix - 1 + kx;
+                if (ox < 0 || ox >= OH) continue;
+                const float* dp = P.dy + (((size_t)img * OH + oy) * OH + ox) * P.co;
+                const float* wp = P.w + ((size_t)(ky * 4 + kx) * ci_total + ci) * P.co;
+                for (int co = 0; co < P.co; ++co) s = fmaf(dp[co], wp[co], s);
+            }
+        }
+        const size_t pix = ((size_t)img * P.h + iy) * P.h + ix;
+        if (ci < P.ca) { if (P.da) P.da[pix * P.ca + ci] = s; }
+        else if (P.db) P.db[pix * P.cb + (ci - P.ca)] = s;
+    }
+}
+
+// one workgroup per weight element (ky, kx, ci, co) (+ one per bias element): fixed-order tree sum over all pixels
+__global__ void __launch_bounds__(256) gen_convt_bwd_weight_kernel(GenConvTParams P) {
+    __shared__ float red[256];
+    const int OH = 2 * P.h, ci_total = P.ca + P.cb, nw = 16 * ci_total * P.co;
+    const int e = blockIdx.x;
+    float s = 0.f;
+    if (e < nw) {
+        const int co = e % P.co, ci = (e / P.co) % ci_total, kx = (e / (P.co * ci_total)) % 4, ky = e / (P.co * ci_total * 4);
+        const int npix = P.n * P.h * P.h;
+        for (int p = threadIdx.x; p < npix; p += 256) {
+            const int ix = p % P.h, iy = (p / P.h) % P.h, img = p / (P.h * P.h);
+            const int oy = 2 * iy - 1 + ky, ox = 2 * ix - 1 + kx;
+            if (oy < 0 || oy >= OH || ox < 0 || ox >= OH) continue;
+            s = fmaf(convt_in(P, img, iy, ix, ci), P.dy[(((size_t)img * OH + oy) * OH + ox) * P.co + co], s);
+        }
+    } else {
+        const int co = e - nw, npix = P.n * OH * OH;
+        for (int p = threadIdx.x; p < npix; p += 256) s += P.dy[(size_t)p * P.co + co];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { if (e < nw) P.dw[e] = red[0]; else P.dbias[e - nw] = red[0]; }
+}
+
+}  // namespace
+
+extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                   int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* w,
+                                   const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
+    if (n < 0 || !src_a || !w || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
+    if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
+    if (hw != 4 && hw != 8 && hw != 16 && hw != 32 && hw != 64) return CGS_ERR_UNSUPPORTED;
+    if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    int th = 256 / hw;                       // strips of <= 256 pixels
+    if (th > hw) th = hw;
+    if (th < 2) th = 2;
+    GenConvParams P{src_a, src_b, w, bias, out, argmax, n, hw, ca, cb, co, a_is_u8, cb > 0 ? ups : 1, act, pool, th, slope};
+    const int ncb = (co + 15) / 16, strips = hw / th;
+    const size_t lds = (size_t)(th + 2) * (hw + 2) * GEN_KC * sizeof(float);
+    hipLaunchKernelGGL(gen_conv3x3_fwd_kernel, dim3(n * strips * ncb), dim3(256), lds, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
+                            const float* bias, float* out, cgs_stream_t stream) {
+    if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out) return CGS_ERR_BADARG;
+    if (m == 0) return CGS_OK;
+    GenGemmParams P{x, w, bias, out, m, k, n, act, slope};
+    hipLaunchKernelGGL(gen_gemm_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+static bool convt_ok(int n, int h, int ca, int cb, int co) { return n >= 0 && h > 0 && h <= 64 && ca > 0 && cb >= 0 && co > 0; }
+
+extern "C" int cgs_gen_convt4s2_fwd(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, int32_t act, float slope,
+                                    const float* a, const float* b, const float* w, const float* bias, float* out,
+                                    cgs_stream_t stream) {
+    if (!convt_ok(n, h, ca, cb, co) || !a || (cb > 0 && !b) || !w || !bias || !out) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    GenConvTParams P{a, b, w, bias, nullptr, out, nullptr, nullptr, nullptr, nullptr, n, h, ca, cb, co, act, slope};
+    const size_t total = (size_t)n * 4 * h * h * co;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gen_convt_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_convt4s2_bwd_data(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, const float* dy,
+                                         const float* w, float* da, float* db, cgs_stream_t stream) {
+    if (!convt_ok(n, h, ca, cb, co) || !dy || !w || (!da && !db)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    GenConvTParams P{nullptr, nullptr, w, nullptr, dy, nullptr, da, db, nullptr, nullptr, n, h, ca, cb, co, 0, 0.f};
+    const size_t total = (size_t)n * h * h * (ca + cb);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gen_convt_bwd_data_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_convt4s2_bwd_weight(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, const float* a,
+                                           const float* b, const float* dy, float* dw, float* dbias, cgs_stream_t stream) {
+    if (!convt_ok(n, h, ca, cb, co) || !a || (cb > 0 && !b) || !dy || !dw || !dbias) return CGS_ERR_BADARG;
+    GenConvTParams P{a, b, nullptr, nullptr, dy, nullptr, nullptr, nullptr, dw, dbias, n, h, ca, cb, co, 0, 0.f};
+    hipLaunchKernelGGL(gen_convt_bwd_weight_kernel, dim3(16 * (ca + cb) * co + co), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

@@ -140,7 +140,41 @@ class Handler:
         return torch.roll(X, shifts=Handler._shift_draw(self), dims=2)
 
     # ------------------------------------------------------------------ engines
-    def _engine(self, n, live=True):
+    class _GenericInference:
+        """Model sizes outside the specialised kernels (chfak != 1 / neck != 32): eval-mode critic (+ masker) on the shape-generic
+        forward kernels, same infer() contract as HourglassEngine."""
+
+        def __init__(self, h):
+            self.h = h
+
+        @torch.no_grad()
+        def infer(self, X, want_mask=True, train_mode=False, **_kw):
+            from . import generic as gen
+            h = self.h
+            if train_mode:
+                raise NotImplementedError("-noevalmode is implemented for chfak=1, neck=32 only")
+            c = gen.critic_forward(h.critic.flat.detach(), h.critic.layout, X.contiguous(), h.args.chfak, h.args.neck)
+            if not want_mask:
+                return c["pred"], None
+            src = c
+            if h.args.separate:
+                src = gen.critic_forward(h.sepcrit.flat.detach(), h.sepcrit.layout, X.contiguous(), h.args.chfak, h.args.neck)
+            m = gen.masker_forward(h.masker.flat.detach(), h.masker.layout, X.contiguous(), [src[f"e{i}"] for i in range(5)],
+                                   h.args.chfak, h.args.neck)
+            return c["pred"], m["Z"]
+
+        def saliency(self, X):
+            raise NotImplementedError("-salience is implemented for chfak=1, neck=32 only")
+
+    def _generic_size(self):
+        return self.args.chfak != 1 or self.args.neck != 32
+
+    def _engine(self, n, live=True, training=False):
+        if self._generic_size():
+            if training:
+                raise NotImplementedError(f"training with --chfak {self.args.chfak} --neck {self.args.neck}: the fused training step is "
+                                          "built for chfak=1, neck=32; other sizes run inference (-process, -eval) on the generic kernels")
+            return Handler._GenericInference(self)
         key = (n, live)
         if key not in self._engines:
             a = self.args
@@ -180,7 +214,7 @@ class Handler:
             log_file.write(f"{self.args}\n\n")
         llog = []
         self.critic.train()
-        self._engine(self.batch_size)
+        self._engine(self.batch_size, training=True)
         self._reset_adam()                       # a fresh torch.optim.Adam(critic.parameters()) (main.py:178)
         if args.directeval:                      # main.py:179-180
             self.eval()
@@ -274,7 +308,7 @@ class Handler:
         self.critic.train()
         self.masker.train()
         n = 2 * self.contrastive_batchsize
-        eng = self._engine(n, live=args.live)
+        eng = self._engine(n, live=args.live, training=True)
         self._reset_adam()                       # a fresh Adam over critic+masker (live) or masker (frozen)
         if args.directeval:                      # main.py:337-338
             self.eval()

@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from . import generic as gen
 from . import hourglass as hg
 from .spec import critic_layout, masker_layout
 
@@ -89,8 +90,17 @@ class _HipModule(nn.Module):
 
 
 def _unsupported(what):
-    raise NotImplementedError(f"{what} is not implemented by the HIP kernels of this build (chfak=1, width=64, "
-                              "dims=[8,8,8,16], neck=32, ReLU, max-pool, nearest upsampling are)")
+    raise NotImplementedError(f"{what} is not implemented by the HIP kernels of this build (width=64, dims=[8,8,8,16] x chfak, "
+                              "ReLU, max-pool, nearest upsampling are; training needs chfak=1, neck=32)")
+
+
+def _generic_only_inference(mod, X):
+    """chfak != 1 / neck != 32 run on the shape-generic forward kernels (csrc/gen.hip): eval-mode inference only."""
+    if mod.training and getattr(mod, "dropout_p", 0.0) > 0.0:
+        raise NotImplementedError(f"{type(mod).__name__}(chfak={mod.chfak}): train-mode Dropout / backward are implemented for "
+                                  "chfak=1, neck=32 only; call .eval() (inference: -process, -eval) for other sizes")
+    if torch.is_grad_enabled() and (X.requires_grad or (mod.training and mod.flat.requires_grad)):
+        raise NotImplementedError(f"{type(mod).__name__}(chfak={mod.chfak}): no backward pass for this model size in this build")
 
 
 class _CriticFn(torch.autograd.Function):
@@ -135,15 +145,26 @@ class NewCritic(_HipModule):
     def __init__(self, width=64, dims=[8, 8, 8, 16], bottleneck=32, colorchs=3, chfak=1, activation=nn.ReLU, pool="max",
                  dropout=0.5):
         super().__init__()
-        if width != 64 or list(dims) != [8, 8, 8, 16] or bottleneck != 32 or colorchs != 3 or chfak != 1:
+        if width != 64 or list(dims) != [8, 8, 8, 16] or colorchs != 3 or int(chfak) < 1 or int(bottleneck) % 4:
             _unsupported(f"NewCritic(width={width}, dims={dims}, bottleneck={bottleneck}, colorchs={colorchs}, chfak={chfak})")
         if activation is not nn.ReLU or pool != "max":
             _unsupported(f"NewCritic(activation={activation}, pool={pool})")
         self.width = width
+        self.chfak, self.neck = int(chfak), int(bottleneck)
+        self._generic = self.chfak != 1 or self.neck != 32
         self._setup(critic_layout(chfak, bottleneck, colorchs), dropout)
 
     def forward(self, X, collect=False):
         self._need_device()
+        if self._generic:
+            _generic_only_inference(self, X)
+            with torch.no_grad():
+                o = gen.critic_forward(self.flat.detach(), self.layout, _to_nhwc(X.to(self.flat.device)), self.chfak, self.neck)
+            n = X.shape[0]
+            pred = o["pred"].view(n, 1)
+            if not collect:
+                return pred
+            return pred, [o[f"e{i}"].permute(0, 3, 1, 2) for i in range(4)] + [o["e4"].view(n, -1, 1, 1)]
         out = _CriticFn.apply(X.to(self.flat.device), self.flat, self, bool(collect))
         if collect:
             return out[0], list(out[1:])
@@ -183,16 +204,100 @@ class UnetDecoder(_HipModule):
     def __init__(self, width=64, edims=[8, 8, 8, 16], ddims=[8, 8, 8, 16], bottleneck=32, masker_channels=16,
                  colorchs=3, chfak=1, activation=nn.ReLU, pool="max", upsample=True, pure=False):
         super().__init__()
-        if (width != 64 or list(edims) != [8, 8, 8, 16] or list(ddims) != [8, 8, 8, 16] or bottleneck != 32 or
-                masker_channels != 16 or colorchs != 3 or chfak != 1 or pool != "max" or not upsample or pure):
+        if (width != 64 or list(edims) != [8, 8, 8, 16] or list(ddims) != [8, 8, 8, 16] or int(bottleneck) % 4 or
+                masker_channels != 16 or colorchs != 3 or int(chfak) < 1 or pool != "max" or not upsample or pure):
             _unsupported(f"UnetDecoder(width={width}, edims={edims}, ddims={ddims}, bottleneck={bottleneck}, "
                          f"masker_channels={masker_channels}, chfak={chfak}, pool={pool}, upsample={upsample}, pure={pure})")
         self.width = width
         self.masker_channels = masker_channels
+        self.chfak, self.neck = int(chfak), int(bottleneck)
+        self._generic = self.chfak != 1 or self.neck != 32
         self._setup(masker_layout(chfak, bottleneck, colorchs, masker_channels))
 
     def forward(self, X, embeds):
         self._need_device()
         dev = self.flat.device
+        if self._generic:
+            _generic_only_inference(self, X)
+            if torch.is_grad_enabled() and any(t.requires_grad for t in embeds):
+                raise NotImplementedError(f"UnetDecoder(chfak={self.chfak}): no backward pass for this model size in this build")
+            with torch.no_grad():
+                n = X.shape[0]
+                emb = [t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for t in embeds[:4]]
+                emb.append(embeds[4].detach().to(dev, torch.float32).reshape(n, -1).contiguous())
+                m = gen.masker_forward(self.flat.detach(), self.layout, _to_nhwc(X.to(dev)), emb, self.chfak, self.neck,
+                                       self.masker_channels)
+            return m["Z"].view(n, 1, 64, 64)
         e = [t.to(dev) for t in embeds]
         return _MaskerFn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)
+
+
+class Unet(nn.Module):
+    """The legacy single-module hourglass (nets.py:356-449; `main.py` never builds it, TrainHandler.__init__old did): Conv2d +
+    LeakyReLU(0.2) + MaxPool2d encoder, bottleneck 4x4 convolution, and -- with ``upsample=False``, the form implemented
+    here -- a ConvTranspose2d decoder: ConvTranspose2d(bottleneck, 16, 4, 1, 0) on the 1x1 map, then three
+    ConvTranspose2d(., ., 4, 2, 1) over cat(decoder, pooled encoder) with LeakyReLU(0.2), a last one into the sigmoid mask.
+    Same constructor, parameter names (``enc_model.N`` / ``dec_model.N`` / ``critic.N``) and default initialisation order as the
+    reference, so checkpoints and seeds interchange; the modules below only HOLD the parameters, the arithmetic runs on the
+    shape-generic HIP kernels (forward pass; cgs_gen_convt4s2_bwd_* carry the transposed convolution's gradients)."""
+
+    def __init__(self, width=64, edims=[8, 8, 8, 16], ddims=[8, 8, 8, 16], bottleneck=32, colorchs=3, chfak=1,
+                 activation=nn.ReLU, pool="max", upsample=True, pure=False):
+        super().__init__()
+        if upsample or pure or pool != "max" or width != 64:
+            _unsupported(f"Unet(upsample={upsample}, pure={pure}, pool={pool}, width={width}) -- the ConvTranspose2d form "
+                         "(upsample=False, pure=False, max-pool) is the one built here")
+        e = [int(v) * chfak for v in edims]
+        d = [int(v) * chfak for v in ddims]
+        self.width, self.upsample, self.pure = width, upsample, pure
+        self.e, self.d, self.bottleneck = e, d, int(bottleneck)
+        enc = [nn.Conv2d(colorchs, e[0], 3, 1, 1), nn.Conv2d(e[0], e[1], 3, 1, 1), nn.Conv2d(e[1], e[2], 3, 1, 1),
+               nn.Conv2d(e[2], e[3], 3, 1, 1), nn.Conv2d(e[3], bottleneck, 4)]
+        dec = [nn.ConvTranspose2d(e[0] + d[0], 1, 4, 2, 1), nn.ConvTranspose2d(e[1] + d[1], d[0], 4, 2, 1),
+               nn.ConvTranspose2d(e[2] + d[2], d[1], 4, 2, 1), nn.ConvTranspose2d(e[3] + d[3], d[2], 4, 2, 1),
+               nn.ConvTranspose2d(bottleneck, d[3], 4, 1, 0)]
+        self.dec_model = nn.Sequential(*dec)
+        self.enc_model = nn.Sequential(*enc)
+        self.critic = nn.Sequential(nn.Flatten(), nn.Linear(bottleneck, 32), nn.ReLU(), nn.Linear(32, 1))
+
+    @staticmethod
+    def _k(t):       # conv weight OIHW -> HWIO flat / bias as is
+        return t.detach().permute(2, 3, 1, 0).contiguous().reshape(-1)
+
+    def forward(self, X, critic=False, embeds=False):
+        w0 = self.enc_model[0].weight
+        if not w0.is_cuda:
+            raise _lib.CgsError("Unet: parameters are on the CPU; the HIP kernels need a GPU (call .to('cuda')), there is no CPU fallback")
+        if torch.is_grad_enabled() and (X.requires_grad or self.training):
+            raise NotImplementedError("Unet: forward pass only in this build (call .eval() / torch.no_grad()); the transposed "
+                                      "convolution's gradient kernels are exposed as cgs_gen_convt4s2_bwd_data / _bwd_weight")
+        with torch.no_grad():
+            x = _to_nhwc(X.to(w0.device))
+            n = x.shape[0]
+            p, src = [], x
+            for i in range(4):       # x_i = LeakyReLU(0.2)(conv); p_i = MaxPool2d(2)(x_i)   (nets.py:405-419)
+                m = self.enc_model[i]
+                wk, b = self._k(m.weight), m.bias.detach().contiguous()
+                src = gen.conv3x3(src, None, wk.data_ptr(), b.data_ptr(), m.out_channels, act="lrelu", slope=0.2, pool=True)
+                p.append(src)
+            m = self.enc_model[4]
+            wk, b = self._k(m.weight), m.bias.detach().contiguous()
+            x4 = gen.gemm(p[3].reshape(n, -1), wk.data_ptr(), b.data_ptr(), 16 * self.e[3], self.bottleneck, act="lrelu", slope=0.2)
+            if critic:
+                l1, l2 = self.critic[1], self.critic[3]
+                w1, w2 = l1.weight.detach().t().contiguous(), l2.weight.detach().t().contiguous()
+                h = gen.gemm(x4, w1.data_ptr(), l1.bias.detach().data_ptr(), self.bottleneck, 32, act="relu")
+                return gen.gemm(h, w2.data_ptr(), l2.bias.detach().data_ptr(), 32, 1)
+            # dec[4]: ConvTranspose2d(bottleneck, d3, 4, 1, 0) on a 1x1 map = a GEMM into the 4x4 x d3 map (NHWC)
+            m = self.dec_model[4]
+            wk = m.weight.detach().permute(0, 2, 3, 1).contiguous().reshape(self.bottleneck, 16 * self.d[3])    # [ci][ky][kx][co]
+            b = m.bias.detach().repeat(16).contiguous()
+            u = gen.gemm(x4, wk.data_ptr(), b.data_ptr(), self.bottleneck, 16 * self.d[3], act="lrelu", slope=0.2).reshape(n, 4, 4, self.d[3])
+            for i in (3, 2, 1):      # u_{i-1} = LeakyReLU(0.2)(dec[i](cat(u_i, p_i)))   (nets.py:437-443)
+                m = self.dec_model[i]
+                u = gen.convt_fwd(u, p[i], gen.convt_weight_to_kernel(m.weight.detach()), m.bias.detach().contiguous(), act="lrelu", slope=0.2)
+            m = self.dec_model[0]
+            y = gen.convt_fwd(u, p[0], gen.convt_weight_to_kernel(m.weight.detach()), m.bias.detach().contiguous(), act="sigmoid")
+            torch.cuda.current_stream().synchronize()      # temporaries of this call (re-laid-out weights) die with it
+            y = y.permute(0, 3, 1, 2)
+            return (y, u.permute(0, 3, 1, 2)) if embeds else y

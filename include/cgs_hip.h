@@ -314,6 +314,28 @@ int cgs_nhwc_to_nchw(int32_t n, int32_t c, int32_t hw, const float* src, float* 
 int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stream);
 
 /* Library / device info: returns the gfx arch string the library was built for. */
+/* ---- shape-generic kernels (csrc/gen.hip): model sizes outside the specialised set ---------------------------------
+ * NewCritic / UnetDecoder with chfak != 1 (nets.py:166,184,190; the paper's model is chfak = 5) and the legacy `Unet` with its
+ * ConvTranspose2d(4,2,1) decoder and LeakyReLU(0.2) (nets.py:356-449).  NHWC fp32 (source A optionally uint8, /255 fused),
+ * runtime channel counts, weights in kernel layout (HWIO; [k][n] for GEMMs; [ky][kx][ci][co] for the transposed conv).
+ * cgs_gen_conv3x3_fwd: out = act(conv3x3(cat(A [ca], nearest-up_ups(B [cb])), w) + bias), hw in {4,8,16,32,64}; pool = 1:
+ *   MaxPool2d(2) of it, out [n,hw/2,hw/2,co] and argmax [same] = position 0..3 of the first maximum (may be NULL).
+ * cgs_gen_gemm: out [m,n] = act(x [m,k] w [k,n] + bias [n] (may be NULL)).
+ * cgs_gen_convt4s2_*: ConvTranspose2d(4,2,1) over cat(A, B) [n,h,h,*] -> [n,2h,2h,co]: forward (+bias, act), data gradient
+ *   (dy = gradient at the PRE-activation output; da / db may be NULL), weight + bias gradient (dw [16*(ca+cb)*co], dbias [co]). */
+int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                        int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* w,
+                        const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
+int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
+                 const float* bias, float* out, cgs_stream_t stream);
+int cgs_gen_convt4s2_fwd(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, int32_t act, float slope,
+                         const float* a, const float* b, const float* w, const float* bias, float* out,
+                         cgs_stream_t stream);
+int cgs_gen_convt4s2_bwd_data(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, const float* dy,
+                              const float* w, float* da, float* db, cgs_stream_t stream);
+int cgs_gen_convt4s2_bwd_weight(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, const float* a,
+                                const float* b, const float* dy, float* dw, float* dbias, cgs_stream_t stream);
+
 /* ---- contrastive batch assembly on the device (main.py:344-356, 584-591) ------------------------------------------
  * dst [n,64,64,3] uint8: frame src[idx[i]] of a device-resident uint8 frame set, rolled circularly along the width:
  * dst[i][y][x] = src[idx[i]][y][(x + shift_px) mod 64].  Handler.shift_batch's "left" roll by s pixels is shift_px = s, its

@@ -386,3 +386,23 @@ def eval_saliency_iou(PC, X_u8: np.ndarray, Y: np.ndarray, salience_thresh: floa
     union = np.sum(A | B)
     iou = round(float(np.sum(A & B) / union), 3) if union else float("nan")
     return iou, salM, raw
+
+
+# --------------------------------------------------------------------------------------
+# legacy Unet(upsample=False) (nets.py:356-449): Conv + LeakyReLU(0.2) + MaxPool encoder, ConvTranspose2d decoder
+# --------------------------------------------------------------------------------------
+def unet_convt_apply(P: Params, X: torch.Tensor, critic: bool = False):
+    """Restates Unet.forward with upsample=False, pure=False (nets.py:398-449).  Returns (y, u0) or the critic value."""
+    act = lambda t: F.leaky_relu(t, 0.2)
+    p, h = [], X
+    for i in range(4):
+        h = F.max_pool2d(act(F.conv2d(h, P[f"enc_model.{i}.weight"], P[f"enc_model.{i}.bias"], padding=1)), 2)
+        p.append(h)
+    x4 = act(F.conv2d(p[3], P["enc_model.4.weight"], P["enc_model.4.bias"]))
+    if critic:
+        return F.linear(F.relu(F.linear(x4.flatten(1), P["critic.1.weight"], P["critic.1.bias"])), P["critic.3.weight"], P["critic.3.bias"])
+    u = act(F.conv_transpose2d(x4, P["dec_model.4.weight"], P["dec_model.4.bias"]))
+    for i in (3, 2, 1):
+        u = act(F.conv_transpose2d(torch.cat((u, p[i]), dim=1), P[f"dec_model.{i}.weight"], P[f"dec_model.{i}.bias"], stride=2, padding=1))
+    y = torch.sigmoid(F.conv_transpose2d(torch.cat((u, p[0]), dim=1), P["dec_model.0.weight"], P["dec_model.0.bias"], stride=2, padding=1))
+    return y, u

@@ -22,6 +22,7 @@ Fixtures (all float32 unless noted):
   g4_phase1_*.npz        phase-1 step: loss, grads, params after step 1 (mse and bce variants)
   g5_shift.npz           shift_batch under torch.manual_seed(k)
   g7_dropout.npz         phase-2 step with dropout 0.3 and the recorded keep-masks
+  g8_unet_convt.npz      legacy Unet(upsample=False) (ConvTranspose2d decoder, LeakyReLU(0.2)): weights, mask, u0, critic value
 """
 import json
 import os
@@ -263,6 +264,18 @@ for k in range(4):
         r = torch.cat((x[:, :, -xs:], x[:, :, :-xs]), dim=2)
     g5[f"rolled{k}"] = r.numpy(); g5[f"amount{k}"] = np.int64(xs); g5[f"left{k}"] = np.bool_(flag)
 np.savez(os.path.join(HERE, "g5_shift.npz"), **g5)
+
+# ---------------------------------------------------------------- G8: legacy Unet with the ConvTranspose2d decoder (nets.py:356-449)
+torch.manual_seed(5)
+unet = refnets.Unet(upsample=False)
+unet.eval()
+xu = frames(8, 4)
+with torch.no_grad():
+    yu, u0 = unet(to_nchw(xu), embeds=True)
+    cu = unet(to_nchw(xu), critic=True)
+g8 = {"X": xu, "y": yu.numpy(), "u0": u0.numpy(), "critic": cu.numpy()}
+g8.update(sd_np("sd", unet.state_dict()))
+np.savez(os.path.join(HERE, "g8_unet_convt.npz"), **g8)
 
 tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
 print("fixtures written, total bytes:", tot)

@@ -1,0 +1,159 @@
+"""GPU parity of the shape-generic kernels (csrc/gen.hip): NewCritic / UnetDecoder at chfak != 1 (the paper's chfak = 5 against
+the committed reference capture), the legacy Unet with its ConvTranspose2d decoder (reference capture G8), and the transposed
+convolution's forward / data gradient / weight gradient against torch's CPU autograd."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hourglass_ref as orc
+from test_gpu_kernels import rel_close, nhwc
+
+
+def test_oracle_unet_restatement_matches_reference_capture(golden):
+    g = golden("g8_unet_convt.npz")
+    P = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    with torch.no_grad():
+        y, u0 = orc.unet_convt_apply(P, orc.u8_to_nchw(g["X"]))
+        c = orc.unet_convt_apply(P, orc.u8_to_nchw(g["X"]), critic=True)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(u0.numpy(), g["u0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c.numpy(), g["critic"], rtol=1e-5, atol=1e-6)
+
+
+def test_chfak5_modules_match_reference_capture(golden):
+    """The paper's model size (channels 40/40/40/80/160): NewCritic(chfak=5) / UnetDecoder(chfak=5) in eval mode against the
+    capture of the reference classes (tests/golden/g2_eval_chfak5.npz) and against the oracle for every embed."""
+    from cgs_amd import nets
+    g = golden("g2_eval_chfak5.npz")
+    pc = orc.seeded_params(orc.critic_shapes(5), 11)
+    pm = orc.seeded_params(orc.masker_shapes(5), 12)
+    critic, masker = nets.NewCritic(chfak=5).to("cuda").eval(), nets.UnetDecoder(chfak=5).to("cuda").eval()
+    critic.load_state_dict(pc); masker.load_state_dict(pm)
+    X = orc.u8_to_nchw(g["X"])
+    with torch.no_grad():
+        pred, embeds = critic(X.cuda(), collect=True)
+        Z = masker(X.cuda(), embeds)
+        rp, re = orc.critic_apply(pc, X, collect=True)
+        rz, inter = orc.masker_apply(pm, X, re, return_all=True)
+    rel_close(pred.cpu().numpy(), g["pred"], "pred vs reference capture")
+    rel_close(Z.cpu().numpy(), g["Z"], "Z vs reference capture")
+    rel_close(embeds[4].cpu().numpy(), g["e4"], "e4 vs reference capture")
+    for i in range(4):
+        rel_close(embeds[i].cpu().numpy(), re[i].numpy(), f"e{i} vs oracle")
+    # round trip of the checkpoint contract at this size
+    for k, v in critic.state_dict().items():
+        np.testing.assert_array_equal(v.cpu().numpy(), pc[k].numpy())
+    with pytest.raises(NotImplementedError):
+        critic.train()(X.cuda().requires_grad_(True))
+
+
+@pytest.mark.parametrize("chfak,neck", [(1, 32), (2, 32), (3, 16)])
+def test_generic_forward_other_sizes_match_oracle(chfak, neck):
+    from cgs_amd import generic as gen, spec
+    dev = torch.device("cuda:0")
+    pc = orc.seeded_params(orc.critic_shapes(chfak, neck), 21)
+    pm = orc.seeded_params(orc.masker_shapes(chfak, neck), 22)
+    lc, lm = spec.critic_layout(chfak, neck), spec.masker_layout(chfak, neck)
+    fc, fm = torch.empty(lc.total, device=dev), torch.empty(lm.total, device=dev)
+    lc.flatten({k: v.to(dev) for k, v in pc.items()}, fc)
+    lm.flatten({k: v.to(dev) for k, v in pm.items()}, fm)
+    x_u8 = np.random.RandomState(4).randint(0, 256, (5, 64, 64, 3)).astype(np.uint8)
+    X = orc.u8_to_nchw(x_u8)
+    with torch.no_grad():
+        rp, re = orc.critic_apply(pc, X, collect=True)
+        rz, inter = orc.masker_apply(pm, X, re, return_all=True)
+    c = gen.critic_forward(fc, lc, torch.from_numpy(x_u8).to(dev), chfak, neck)          # uint8 loader
+    m = gen.masker_forward(fm, lm, torch.from_numpy(x_u8).to(dev), [c[f"e{i}"] for i in range(5)], chfak, neck)
+    for i in range(4):
+        rel_close(nhwc(c[f"e{i}"]), re[i].numpy(), f"e{i}")
+    rel_close(c["pred"].cpu().numpy(), rp[:, 0].numpy(), "pred")
+    for k in ("o3", "o2", "o1", "o0", "hm"):
+        rel_close(nhwc(m[k]), inter[k].numpy(), k)
+    rel_close(m["Z"].cpu().numpy(), rz[:, 0].numpy(), "Z")
+    if chfak == 1 and neck == 32:      # the generic and the specialised kernels agree on the default size
+        from cgs_amd import hourglass as hg
+        c1 = hg.critic_forward(fc, lc, torch.from_numpy(x_u8).to(dev), 5)
+        rel_close(c["pred"].cpu().numpy(), c1["pred"].cpu().numpy(), "generic vs specialised pred", rtol=1e-5)
+
+
+def test_generic_pool_argmax_first_index():
+    from cgs_amd import generic as gen
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(np.repeat(np.repeat(rs.rand(2, 4, 4, 8).astype(np.float32), 2, axis=1), 2, axis=2))   # 2x2 constant blocks
+    w = torch.zeros(3, 3, 8, 8); w[1, 1] = torch.eye(8)                                                      # identity conv
+    b = torch.zeros(8)
+    wd, bd = w.reshape(-1).to(dev), b.to(dev)
+    out, am = gen.conv3x3(x.to(dev), None, wd.data_ptr(), bd.data_ptr(), 8, act="lrelu", slope=0.2, pool=True, want_argmax=True)
+    ref, idx = F.max_pool2d(x.permute(0, 3, 1, 2), 2, return_indices=True)
+    np.testing.assert_allclose(nhwc(out), ref.numpy(), rtol=1e-6)
+    assert (am.cpu().numpy() == 0).all()          # every window is a 4-way tie: the first position wins, as max_pool2d
+
+
+def test_legacy_unet_convtranspose_matches_reference_capture(golden):
+    """nets.Unet(upsample=False): ConvTranspose2d(4,2,1) decoder + LeakyReLU(0.2) (nets.py:356-449) vs the reference class."""
+    from cgs_amd import nets
+    g = golden("g8_unet_convt.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    net = nets.Unet(upsample=False).to("cuda").eval()
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    X = orc.u8_to_nchw(g["X"]).cuda()
+    with torch.no_grad():
+        y, u0 = net(X, embeds=True)
+        c = net(X, critic=True)
+    rel_close(y.cpu().numpy(), g["y"], "mask")
+    rel_close(u0.cpu().numpy(), g["u0"], "u0")
+    rel_close(c.cpu().numpy(), g["critic"], "critic value")
+    with pytest.raises(NotImplementedError):
+        nets.Unet(upsample=True)
+
+
+@pytest.mark.parametrize("n,h,ca,cb,co", [(3, 4, 16, 16, 8), (2, 8, 8, 8, 8), (2, 16, 8, 8, 8), (1, 32, 8, 8, 1), (2, 8, 5, 0, 3)])
+def test_convtranspose_4_2_1_forward_and_gradients_vs_torch(n, h, ca, cb, co):
+    """cgs_gen_convt4s2_{fwd,bwd_data,bwd_weight} against F.conv_transpose2d(stride 2, padding 1) and its CPU autograd."""
+    from cgs_amd import generic as gen
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(n * 100 + h)
+    a = torch.from_numpy(rs.randn(n, ca, h, h).astype(np.float32)).requires_grad_(True)
+    b = torch.from_numpy(rs.randn(n, cb, h, h).astype(np.float32)).requires_grad_(True) if cb else None
+    W = torch.from_numpy((rs.randn(ca + cb, co, 4, 4) * 0.2).astype(np.float32)).requires_grad_(True)
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32)).requires_grad_(True)
+    cot = torch.from_numpy(rs.randn(n, co, 2 * h, 2 * h).astype(np.float32))
+    x = torch.cat((a, b), dim=1) if cb else a
+    pre = F.conv_transpose2d(x, W, bias, stride=2, padding=1)
+    out = F.leaky_relu(pre, 0.2)
+    (out * cot).sum().backward()
+    dpre = (cot * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.2))).detach()
+    to_d = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    wk = gen.convt_weight_to_kernel(W.detach()).to(dev)
+    got = gen.convt_fwd(to_d(a), to_d(b) if cb else None, wk, bias.detach().to(dev), act="lrelu", slope=0.2)
+    rel_close(nhwc(got), out.detach().numpy(), "forward")
+    da, db, dw, dbias = gen.convt_bwd(to_d(a), to_d(b) if cb else None, wk, to_d(dpre))
+    rel_close(nhwc(da), a.grad.numpy(), "d A")
+    if cb:
+        rel_close(nhwc(db), b.grad.numpy(), "d B")
+    rel_close(gen.convt_weight_from_kernel(dw.cpu(), ca + cb, co).numpy(), W.grad.numpy(), "d W")
+    rel_close(dbias.cpu().numpy(), bias.grad.numpy(), "d bias")
+
+
+def test_handler_generic_inference_chfak5(tmp_path, monkeypatch):
+    """`main.py -process --chfak 5`'s inner loop: Handler routes other model sizes to the generic forward kernels and refuses training."""
+    from cgs_amd import cli, handler
+    monkeypatch.chdir(tmp_path)
+    H = handler.Handler(cli.parse_args(["--model", "m", "--chfak", "5"]))
+    pc = orc.seeded_params(orc.critic_shapes(5), 11)
+    pm = orc.seeded_params(orc.masker_shapes(5), 12)
+    H.critic.load_state_dict(pc); H.masker.load_state_dict(pm)
+    x_u8 = np.random.RandomState(2).randint(0, 256, (6, 64, 64, 3)).astype(np.uint8)
+    pred, Z = H._engine(64).infer(torch.from_numpy(x_u8).cuda())
+    with torch.no_grad():
+        rp, re = orc.critic_apply(pc, orc.u8_to_nchw(x_u8), collect=True)
+        rz = orc.masker_apply(pm, orc.u8_to_nchw(x_u8), re)
+    rel_close(pred.cpu().numpy(), rp[:, 0].numpy(), "pred")
+    rel_close(Z.cpu().numpy(), rz[:, 0].numpy(), "Z")
+    with pytest.raises(NotImplementedError):
+        H._engine(64, training=True)

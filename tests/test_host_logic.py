@@ -93,8 +93,10 @@ def test_modules_fail_loudly_without_gpu_and_on_unsupported_shapes():
     c = nets.NewCritic()
     with pytest.raises(_lib.CgsError, match="no CPU fallback"):
         c(torch.zeros(2, 3, 64, 64))
+    c5 = nets.NewCritic(chfak=5)        # the paper's size: constructs, checkpoint-compatible; runs on the generic forward kernels
+    assert [(k, tuple(v.shape)) for k, v in c5.state_dict().items()] == [(k, s) for k, s in orc.critic_shapes(5)]
     with pytest.raises(NotImplementedError):
-        nets.NewCritic(chfak=5)
+        nets.NewCritic(dims=[4, 4, 4, 8])
     with pytest.raises(NotImplementedError):
         nets.UnetDecoder(upsample=False)
 
