@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer", "phase1", "cli-train"], default="train",
                     help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
                          "phase1 = critic regression step (main.py:183-200)")
+    ap.add_argument("--chfak", type=int, default=1, help="--mode infer only: other model sizes (5 = the paper's) run on the generic kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -168,12 +169,44 @@ def cli_train_mode(args):
                                                        "fused phase-2 step, N_A = N_B = 64, one epoch over the high-value set"}}), flush=True)
 
 
+def generic_infer_mode(args, dev, rank):
+    """Eval-mode critic + masker at chfak != 1 on the shape-generic kernels (chfak 5 = 186.6 MFLOP per image)."""
+    from cgs_amd import generic as gen, spec
+    from oracle import hourglass_ref as orc          # only for the seeded stand-in weights
+    cf, n = args.chfak, args.batch
+    lc, lm = spec.critic_layout(cf), spec.masker_layout(cf)
+    fc, fm = torch.empty(lc.total, device=dev), torch.empty(lm.total, device=dev)
+    lc.flatten({k: v.to(dev) for k, v in orc.seeded_params(orc.critic_shapes(cf), 11).items()}, fc)
+    lm.flatten({k: v.to(dev) for k, v in orc.seeded_params(orc.masker_shapes(cf), 12).items()}, fm)
+    A, _, _ = synthetic(n, rank, dev)
+
+    def run():
+        c = gen.critic_forward(fc, lc, A, cf)
+        return gen.masker_forward(fm, lm, A, [c[f"e{i}"] for i in range(5)], cf)["Z"]
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    flops = {5: 186.6e6}.get(cf)
+    print(json.dumps({"metric": f"Hourglass infer images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
+                      "unit": "images/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": dt * 1e3, "dtype": "f32", "data": "synthetic",
+                      "roofline": None if flops is None else {"bound": "mfma", "achieved": flops * n / dt / 1e12, "peak": 157.3,
+                                                              "unit": "TFLOP/s", "frac": flops * n / dt / 1e12 / 157.3, "traffic": None}}),
+          flush=True)
+
+
 def side_mode(args, dev, world, rank):
     """Secondary measurements of the same path (not the headline metric): inference and the phase-1 step."""
     from cgs_amd import engine
     if args.mode == "cli-train":
         return cli_train_mode(args)
     n = args.batch
+    if args.mode == "infer" and args.chfak != 1:
+        return generic_infer_mode(args, dev, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)

@@ -217,3 +217,14 @@ def test_saliency_restatement_shapes_and_clipping(g1):
     assert salM.max() <= 1.0 and raw.min() >= 0.0 and iou == 0.0
     iou2, _, _ = orc.eval_saliency_iou(pc, X, Y, salience_thresh=0.25)
     assert 0.0 <= iou2 <= 1.0
+
+
+def test_oracle_unet_restatement_matches_reference_capture(golden):
+    g = golden("g8_unet_convt.npz")
+    P = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    with torch.no_grad():
+        y, u0 = orc.unet_convt_apply(P, orc.u8_to_nchw(g["X"]))
+        c = orc.unet_convt_apply(P, orc.u8_to_nchw(g["X"]), critic=True)
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(u0.numpy(), g["u0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c.numpy(), g["critic"], rtol=1e-5, atol=1e-6)
