@@ -21,9 +21,11 @@ int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0,
                           const float* w2, const float* b2, float* z, hipStream_t st);
 int pconv_fwd_dispatch(int which, int n, const void* src, const uint8_t* mix_a, const uint8_t* mix_b, const float* mix_z, int mix_n_a,
                        const float* w, const float* bias, float* out, uint32_t* amask, hipStream_t st);
-// features.0 / features.3 forward on the matrix cores, two pixels per MFMA row (pconv.hip); CGS_PCONV=0: the VALU kernels (A/B)
+// features.0 / features.3 forward on the matrix cores, two pixels per MFMA row (pconv.hip).  OPT-IN (CGS_PCONV=1): parity-green,
+// but measured SLOWER than the VALU kernels at N = 512 (features.0 42-44 vs 31-34 us, features.3 26 vs 21 us): its workgroups
+// spend as long staging their tile as multiplying, and two rounds of workgroups per CU do not overlap the two.
 static bool use_pconv() {
-    static const bool on = [] { const char* e = std::getenv("CGS_PCONV"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char* e = std::getenv("CGS_PCONV"); return e && e[0] == '1'; }();
     return on;
 }
 static bool use_mconv() {

@@ -22,7 +22,11 @@ struct PConvParams {
     const float* w; const float* bias;
     float* out; uint32_t* amask;
     int n, ntiles, nblocks;
+    unsigned long long* dbg;
 };
+static unsigned long long* g_pconv_stamps = nullptr;
+extern "C" int dbg_pconv_stamps(unsigned long long* p) { g_pconv_stamps = p; return 0; }
+#define PSTAMP(k) do { if (P.dbg && tid == 0 && tile == (int)blockIdx.x) P.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // C: HW, CI, TH (strip rows), PS (LDS floats per pixel), SRC
 template <class C>
@@ -53,8 +57,10 @@ __global__ void __launch_bounds__(256) pconv_fwd_kernel(PConvParams P) {
         xt[(r * PW + (side ? PW - 1 : 0)) * PS + c] = 0.f;
     }
 
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 8] = __builtin_amdgcn_s_memtime();
     for (int tile = blockIdx.x; tile < P.ntiles; tile += P.nblocks) {
         const int img = tile / STRIPS, row0 = (tile % STRIPS) * TH;
+        PSTAMP(1);
         // ---- stage rows row0-1 .. row0+TH ----
         if constexpr (C::SRC == SRC_F32) {
             constexpr int NG = (TH + 2) * HW * (CI / 4);
@@ -108,6 +114,7 @@ __global__ void __launch_bounds__(256) pconv_fwd_kernel(PConvParams P) {
             }
         }
         __syncthreads();
+        PSTAMP(2);
         // ---- this wave's row pairs ----
 #pragma unroll 1
         for (int rp = 0; rp < RPW; ++rp) {
@@ -130,7 +137,7 @@ __global__ void __launch_bounds__(256) pconv_fwd_kernel(PConvParams P) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float v00 = fmaxf(acc0[j] + bias, 0.f), v10 = fmaxf(acc1[j] + bias, 0.f);
-                    const float o0 = __shfl_xor(v00, 8, 64), o1 = __shfl_xor(v10, 8, 64);     // the other column half
+                    const float o0 = dpp_ror8(v00), o1 = dpp_ror8(v10);                          // the other column half (lane ^ 8)
                     const float p0 = dsel ? o0 : v00, p1 = dsel ? v00 : o0, p2 = dsel ? o1 : v10, p3 = dsel ? v10 : o1;
                     float m = p0; uint32_t idx = 0;
                     if (p1 > m) { m = p1; idx = 1; }
@@ -147,7 +154,9 @@ __global__ void __launch_bounds__(256) pconv_fwd_kernel(PConvParams P) {
                 }
             }
         }
+        PSTAMP(3);
         __syncthreads();
+        PSTAMP(4);
     }
 }
 
@@ -168,7 +177,7 @@ static int launch_pconv(PConvParams P, hipStream_t st) {
 // which: 0 = features.0 on uint8 frames, 1 = features.0 on the virtual mixes, 2 = features.3
 int pconv_fwd_dispatch(int which, int n, const void* src, const uint8_t* mix_a, const uint8_t* mix_b, const float* mix_z, int mix_n_a,
                        const float* w, const float* bias, float* out, uint32_t* amask, hipStream_t st) {
-    PConvParams P{src, mix_a, mix_b, mix_z, mix_n_a, w, bias, out, amask, n, 0, 0};
+    PConvParams P{src, mix_a, mix_b, mix_z, mix_n_a, w, bias, out, amask, n, 0, 0, g_pconv_stamps};
     switch (which) {
         case 0: return launch_pconv<PEnc0U8>(P, st);
         case 1: return launch_pconv<PEnc0Mix>(P, st);

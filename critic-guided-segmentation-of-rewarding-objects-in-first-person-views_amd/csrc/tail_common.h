@@ -155,12 +155,22 @@ __device__ __forceinline__ float pool_quad(const frag4& acc, float bias, uint32_
     return m;
 }
 
+// Cross-lane moves on the vector ALU (DPP), no LDS round trip as ds_bpermute / __shfl have:
+//   dpp_xor1 / dpp_xor2: lane ^ 1, lane ^ 2 (quad permutes);  dpp_mirror8: lane i <-> 7 - i inside every group of 8 lanes;
+//   dpp_ror8: lane ^ 8 inside every row of 16 lanes.
+__device__ __forceinline__ uint32_t dpp_xor1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_xor2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t dpp_mirror8(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true); }
+__device__ __forceinline__ float dpp_ror8(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x128, 0xF, 0xF, true));
+}
+
 // OR of the 8 nibbles of channels 8*g .. 8*g+7 (lanes with consecutive lane & 7): every lane gets the packed word
 __device__ __forceinline__ uint32_t pack_nibbles(uint32_t idx, int ch) {
     uint32_t w = idx << (4 * (ch & 7));
-    w |= __shfl_xor(w, 1, 64);
-    w |= __shfl_xor(w, 2, 64);
-    w |= __shfl_xor(w, 4, 64);
+    w |= dpp_mirror8(w);
+    w |= dpp_xor1(w);
+    w |= dpp_xor2(w);
     return w;
 }
 

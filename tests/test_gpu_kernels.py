@@ -159,6 +159,26 @@ def test_pool_argmax_first_index_on_ties(ctx):
     assert ties_total > 5000, f"the tie set exercised only {ties_total} positive ties"
 
 
+def drop_near_tie_images(pc, x_u8, rel=3e-6):
+    """Two fp32 implementations that sum a convolution in different orders can disagree on WHICH element of a 2x2 window is
+    the maximum when its two largest values differ by a few ulps (not an exact tie); the pooling gradient then takes another
+    route and every upstream gradient moves by one window's worth.  Images containing such a window (float64 oracle, any of the
+    four pooling stages) are left out of the gradient comparisons; exact ties stay in (they must resolve identically)."""
+    F = torch.nn.functional
+    keep = np.ones(len(x_u8), bool)
+    with torch.no_grad():
+        h = orc.u8_to_nchw(x_u8).double()
+        for key in ("features.0", "features.3", "features.6", "features.10"):
+            pre = torch.relu(F.conv2d(h, pc[key + ".weight"].double(), pc[key + ".bias"].double(), padding=1))
+            n, c, hw = pre.shape[0], pre.shape[1], pre.shape[-1]
+            top2 = pre.unfold(2, 2, 2).unfold(3, 2, 2).reshape(n, c, hw // 2, hw // 2, 4).topk(2, dim=-1).values
+            gap = top2[..., 0] - top2[..., 1]
+            near = (gap > 0) & (gap < rel * top2[..., 0].abs()) & (top2[..., 0] > 0)
+            keep &= ~near.flatten(1).any(1).numpy()
+            h = F.max_pool2d(pre, 2)
+    return x_u8[keep]
+
+
 def _oracle_grads(ctx, x_u8, cot_pred, cot_embeds, cot_Z, f32_input=False):
     pc = orc.leafify(ctx["pc"])
     pm = orc.leafify(ctx["pm"])
@@ -179,6 +199,10 @@ def test_backward_matches_oracle_autograd(ctx, n, kind):
     hg, dev, lc, lm = ctx["hg"], ctx["dev"], ctx["lc"], ctx["lm"]
     rs = np.random.RandomState(n)
     x_u8 = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8) if kind == "noise" else tie_frames(n, 7)
+    if kind == "noise":
+        x_u8 = drop_near_tie_images(ctx["pc"], x_u8)
+    assert len(x_u8) >= n // 2
+    n = len(x_u8)
     cot_pred = torch.from_numpy(rs.randn(n).astype(np.float32))
     cot_Z = torch.from_numpy(rs.randn(n, 64, 64).astype(np.float32) * 0.1)
     shapes = [(n, 8, 32, 32), (n, 8, 16, 16), (n, 8, 8, 8), (n, 16, 4, 4), (n, 32, 1, 1)]
