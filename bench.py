@@ -35,9 +35,9 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def measured_traffic(n):
     """HBM bytes per step from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    FETCH_SIZE doubled per the gfx950 rule; tools/pmc_traffic.py).  None when no summary exists for this batch size:
-    counters cannot be collected from inside the timed run."""
-    path = os.path.join(REPO, "profiles", "r01_traffic.json")
+    FETCH_SIZE doubled for the 16-B/lane streaming kernels per the gfx950 rule; tools/sq_counters.sh + .py).  None when no
+    summary exists for this batch size: counters cannot be collected from inside the timed run."""
+    path = os.path.join(REPO, "profiles", "r02_traffic.json")
     try:
         with open(path) as fp:
             t = json.load(fp)
@@ -333,11 +333,15 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                        "ranks_seen_by_collective_backend": ranks_seen, "collective_backend": backend,
                        "gradient_allreduce": "one flat fp32 bucket (25 661 floats) per step between the two step graphs" if pg is not None else None},
+            # achieved / frac: ALGORITHMIC bytes of SURVEY 8(d)'s layer-granular model per second (the contract's definition), not
+            # bytes that crossed the HBM pins: the fused step moves fewer (traffic), see measured_hbm_GBs and fp32_TFLOPs
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
                          "kernel": "one phase-2 step = one HIP-graph launch",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n,
-                         "launch_ms": launch_ms},
+                         "launch_ms": launch_ms,
+                         "measured_hbm_GBs": (measured_traffic(n) / (launch_ms * 1e-3) / 1e9) if measured_traffic(n) else None,
+                         "fp32_TFLOPs": 86.75e6 * n / (launch_ms * 1e-3) / 1e12, "fp32_frac_of_157TF": 86.75e6 * n / (launch_ms * 1e-3) / 157.3e12},
             "final_losses": dict(zip(("critic", "replace", "inject", "l1", "l2", "total"), losses[:6])),
         }
         if world == 1 and not args.no_cpu_baseline:
