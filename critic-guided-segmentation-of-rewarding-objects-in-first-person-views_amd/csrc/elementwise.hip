@@ -373,6 +373,145 @@ __global__ void __launch_bounds__(256) gather_f32_kernel(const float* __restrict
     if (i < n) dst[i] = src[idx[i]];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Single-GPU step tail in ONE launch: slab reduction -> gradient -> Adam update of the same element (the value never leaves
+// the thread), plus, in one extra workgroup, the step's loss VALUES (they are logged, nothing on the device waits for them).
+// Every workgroup reads the step counter s at its start and uses t = s + 1 for Adam's bias correction; the workgroup that
+// finishes LAST (ticket counter) stores s + 1: nobody can see the new value early.  Saves the Adam and the losses launches.
+// ------------------------------------------------------------------------------------------------
+struct AdamArgs {
+    float* param; const float* grad_base; float* m; float* v;
+    float lr, b1, b2, eps;
+    unsigned int* ticket;
+};
+struct LossArgs {       // phase-2 loss values (see phase2_losses_kernel); n == 0: none
+    int n, nzpart, flags;
+    const float* pred; const float* y; const float* zpart;
+    float lfak, l1, l2, inv_nz;
+    float* losses;
+};
+
+__device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
+    __shared__ float lred[5][16];
+    const int tid = threadIdx.x, n = L.n;
+    const bool live = L.flags & 1, inject = L.flags & 2, bce = L.flags & 4;
+    float sc = 0.f, sr = 0.f, si = 0.f, z1 = 0.f, z2 = 0.f;
+    for (int i = tid; i < n; i += 1024) {
+        const float pb = L.pred[i], pa = L.pred[n + i], pr = L.pred[2 * n + i], yi = L.y[i];
+        if (live) {
+            if (bce) sc += -(yi * fmaxf(logf(pa), -100.f) + (1.f - yi) * fmaxf(logf(1.f - pa), -100.f));
+            else sc += (pa - yi) * (pa - yi);
+        }
+        sr += (pr - pb) * (pr - pb);
+        if (inject) { const float d = L.pred[3 * n + i] - pa; si += d * d; }
+    }
+    for (int i = tid; i < L.nzpart; i += 1024) { z1 += L.zpart[2 * i]; z2 += L.zpart[2 * i + 1]; }
+    sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si); z1 = wave_sum(z1); z2 = wave_sum(z2);
+    if ((tid & 63) == 0) { const int w = tid >> 6; lred[0][w] = sc; lred[1][w] = sr; lred[2][w] = si; lred[3][w] = z1; lred[4][w] = z2; }
+    __syncthreads();
+    if (tid == 0) {
+        float t[5];
+        for (int k = 0; k < 5; ++k) { float a = 0.f; for (int w = 0; w < 16; ++w) a += lred[k][w]; t[k] = a; }
+        const float inv_n = 1.f / (float)n;
+        const float c = t[0] * inv_n, r = t[1] * inv_n, i = t[2] * inv_n, n1 = L.l1 * t[3] * L.inv_nz, n2 = L.l2 * t[4] * L.inv_nz;
+        L.losses[0] = c; L.losses[1] = r; L.losses[2] = i; L.losses[3] = n1; L.losses[4] = n2;
+        L.losses[5] = (live ? L.lfak * c : 0.f) + r + i + n1 + n2;
+        L.losses[6] = 0.f; L.losses[7] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(1024) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
+                                                           AdamArgs A, LossArgs L) {
+    constexpr int SL = 32;
+    __shared__ float red[SL][33];
+    __shared__ float bc[2];                  // Adam's bias corrections for t = s + 1 (once per workgroup)
+    const bool loss_row = (int)blockIdx.y == njobs;
+    int row_blocks = 1;                      // workgroups of this grid row that have work (and therefore read *step)
+    cgs_reduce_job j{};
+    if (!loss_row) {
+        j = jobs[blockIdx.y];
+        row_blocks = (j.count + 31) / 32;
+    }
+    if ((int)blockIdx.x >= row_blocks) return;          // nothing to do: never reads the counter, not part of the ticket
+    const uint64_t s_old = *step;
+    if (loss_row) {
+        if (L.n > 0) phase2_loss_values(L);
+    } else {
+        if (threadIdx.x == 0) {
+            // 1 - b^t = -expm1(t ln b): no cancellation at small t, and no double-precision pow (its registers halve the
+            // occupancy of this 1024-thread workgroup: measured 46 vs 22 us for the whole kernel)
+            const float t = (float)(s_old + 1);
+            bc[0] = -expm1f(t * logf(A.b1));
+            bc[1] = sqrtf(-expm1f(t * logf(A.b2)));
+        }
+        const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+        const int i = blockIdx.x * 32 + col;
+        float s[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s[u] = 0.f;
+        if (i < j.count) {
+            const float* p = j.slab + i;
+            int b = sl;
+            for (; b + 15 * SL < j.nslab; b += 16 * SL) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
+            }
+            for (; b + 3 * SL < j.nslab; b += 4 * SL) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
+            }
+            for (; b < j.nslab; b += SL) s[0] += p[(size_t)b * j.stride];
+        }
+        red[sl][col] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+                       (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+        __syncthreads();
+        if (sl == 0 && i < j.count) {
+            float g = 0.f;
+#pragma unroll
+            for (int k = 0; k < SL; ++k) g += red[k][col];
+            j.dst[i] = g;                                          // the gradient stays observable (tests, DP)
+            const size_t e = (size_t)(j.dst + i - A.grad_base);      // element of the flat buffers
+            const float c1 = bc[0], c2s = bc[1];
+            const float mi = A.b1 * A.m[e] + (1.f - A.b1) * g;
+            const float vi = A.b2 * A.v[e] + (1.f - A.b2) * g * g;
+            A.m[e] = mi;
+            A.v[e] = vi;
+            A.param[e] -= (A.lr / c1) * (mi / (sqrtf(vi) / c2s + A.eps));
+        }
+    }
+    // ---- the last working workgroup to finish publishes the new step value (two-level ticket: per row, then over the rows) ----
+    // Only an ORDER is needed: this workgroup's read of *step (done: its value was consumed above / is pinned here) before its
+    // ticket increment; the relaxed device-scope atomics give that without a release fence (a __threadfence here writes the
+    // whole L2 back once per workgroup: measured +30 us).
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        asm volatile("" :: "s"(s_old));
+        unsigned int* row = A.ticket + 1 + blockIdx.y;
+        if (atomicAdd(row, 1u) == (unsigned int)row_blocks - 1) {
+            *row = 0u;
+            if (atomicAdd(A.ticket, 1u) == gridDim.y - 1) {
+                *A.ticket = 0u;
+                *step = s_old + 1;
+            }
+        }
+    }
+}
+
+extern "C" int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step, float* param,
+                               const float* grad_base, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                               uint32_t* ticket, int32_t n, const float* pred, const float* y, const float* zpart, int32_t nzpart,
+                               float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses, cgs_stream_t stream) {
+    if (!jobs || njobs <= 0 || max_count <= 0 || !step || !param || !grad_base || !m || !v || !ticket) return CGS_ERR_BADARG;
+    if (n > 0 && (!pred || !y || !zpart || !losses || nz <= 0)) return CGS_ERR_BADARG;
+    AdamArgs A{param, grad_base, m, v, lr, beta1, beta2, eps, ticket};
+    LossArgs L{n, nzpart, flags, pred, y, zpart, lfak, l1, l2, nz > 0 ? 1.f / (float)nz : 0.f, losses};
+    hipLaunchKernelGGL(reduce_adam_kernel, dim3((max_count + 31) / 32, njobs + 1), dim3(1024), 0, (hipStream_t)stream, jobs, njobs,
+                       step, A, L);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 extern "C" int cgs_gather_roll_u8(const uint8_t* src, const int64_t* idx, int32_t n, int32_t shift_px, uint8_t* dst,
                                   cgs_stream_t stream) {
     if (!src || !idx || !dst || n < 0 || shift_px < 0 || shift_px >= 64) return CGS_ERR_BADARG;

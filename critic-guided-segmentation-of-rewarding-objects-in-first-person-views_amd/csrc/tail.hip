@@ -384,6 +384,7 @@ struct TailEncBwdParams {
     cgs_tail_enc_weights w;
     const float* e1; const float* e2; const uint32_t* am2; const float* e3; const uint32_t* am3;
     const float* e4; const float* h1; const float* pred; const float* dpred;
+    const float* target; float loss_scale; int bce;
     const float* dE1; const float* dE2; const float* dE3; const float* d_o4; int n_add;
     float* de1;
     float* slab_head; float* slab_pw; float* slab10; float* slab6;
@@ -471,7 +472,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         const uint32_t lam3 = P.am3[(size_t)img * 32 + (tid >> 3)];           // word of pooled pixel tid >> 4, channel half (tid >> 3) & 1
         const float ldE3 = (P.dE3 && add) ? P.dE3[(size_t)img * 256 + tid] : 0.f;
         const float ev = P.e4[(size_t)img * 32 + o], hv = P.h1[(size_t)img * 32 + o];
-        const float pr = P.pred[img], dpr = P.dpred[img];
+        const float pr = P.pred[img];
+        float dpr = 0.f;          // d loss / d pred: given, or derived from the target (MSE / BCE terms of main.py:380-411)
+        if (P.dpred) dpr = P.dpred[img];
+        else if (P.target) {
+            const float tg = P.target[img];
+            dpr = P.bce ? P.loss_scale * (pr - tg) / fmaxf((1.f - pr) * pr, 1e-12f) : P.loss_scale * 2.f * (pr - tg);
+        }
         const float go4 = (has_pw && add) ? P.d_o4[(size_t)img * 32 + o] : 0.f;
         // head weights of this thread (L2-resident; reloaded per image rather than held in registers across the loop)
         const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
@@ -635,14 +642,14 @@ extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG
 
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                                 const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
-                                const float* dpred, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
-                                int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
+                                const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
+                                const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
                                 cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
-    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !dpred || !de1) return CGS_ERR_BADARG;
+    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
     if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, dE1, dE2, dE3, d_o4, n_add, de1,
+    TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1,
                        slab_head, slab_pw, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
     hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();

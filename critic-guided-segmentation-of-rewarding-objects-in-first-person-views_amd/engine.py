@@ -95,6 +95,10 @@ class HourglassEngine:
         self.dzpre = z(n, 64, 64)
         self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "cb_sep": {}, "p1": {}}
         self._infer_step = z(1, dt=torch.int64)              # -noevalmode: Dropout stream of inference batches
+        self._ticket = z(4096, dt=torch.int32)               # cgs_reduce_adam's last-workgroup counters (1 + one per job row)
+        # single GPU + tail kernels: the loss gradients at pred are derived inside the tail backward kernels and the step ends in
+        # ONE launch (slab reduction + Adam + loss values): two launches (losses, Adam) fewer on the critical path
+        self.fused_tail = hg.TAIL_BWD and not self.dp and os.environ.get("CGS_FUSED_STEP_TAIL", "1") != "0"
         self._graphs: Dict[str, object] = {}
         # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
         # the cross-queue joins cost what the overlap gains)
@@ -171,6 +175,8 @@ class HourglassEngine:
         return (0, self.total) if self.live else (self.off_m, self.total - self.off_m)
 
     def _adam(self):
+        if self.fused_tail:
+            return          # phase 2 on one GPU: Adam ran inside cgs_reduce_adam
         lo, cnt = self._opt_range()
         _lib.call("cgs_adam_flat", cnt, C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
                   C.c_void_p(self.m.data_ptr() + 4 * lo), C.c_void_p(self.v.data_ptr() + 4 * lo), _P(self.step_t),
@@ -217,8 +223,14 @@ class HourglassEngine:
             _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
             hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
-        _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
-                  flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
+        ft = self.fused_tail
+        if not ft:
+            _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
+                      flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
+        # (fused tail) targets of the three loss terms: replaced -> pred of B, injected -> pred of A (slots [B | A] = the first 2n
+        # entries of pred, aligned with the mix slots [rep | inj]); A -> y with weight lfak (or BCE)
+        loss_mix = (self.cbuf["pred"][:nmix], 1.0 / n, False) if ft else None
+        loss_a = (self.y, self.lfak / n, self.bce) if ft else None
         plan = self._plans.get("p2")
         first = plan is None
         if first:
@@ -232,8 +244,8 @@ class HourglassEngine:
         if hg.ENC0_MIX_FUSED:
             # features.0's backward carries the mix backward: the image gradients of the mixes never leave the chip
             hg.critic_backward(self.fc, self.lc, mixsrc, nmix, self._cview(2 * n, 2 * n + nmix),
-                               self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=None, dx_from=0,
-                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live,
+                               None if ft else self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=None, dx_from=0,
+                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live, loss=loss_mix,
                                mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre))
         else:
             hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
@@ -250,16 +262,16 @@ class HourglassEngine:
         if self.separate:
             # the skip gradients (and the bottleneck's) go into the SECOND critic; its own head sees no loss (dpred = 0)
             d_o4, d_emb[4] = d_emb[4], None
-            hg.critic_backward(self.fs, self.lc, A, n, self.sbuf, self._zero_dpred, ps, drop.shifted(4 * n), d_embeds=d_emb,
+            hg.critic_backward(self.fs, self.lc, A, n, self.sbuf, None if ft else self._zero_dpred, ps, drop.shifted(4 * n), d_embeds=d_emb,
                                n_add=n, ws=self._ws["cb_sep"], side=self.side,
                                pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
             if self.live:
-                hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), ws=self._ws["cb_a"],
-                                   side=self.side)
+                hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n),
+                                   ws=self._ws["cb_a"], side=self.side, loss=loss_a)
         elif self.live:
             d_o4, d_emb[4] = d_emb[4], None
-            hg.critic_backward(self.fc, self.lc, A, n, sa, self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
-                               n_add=n, ws=self._ws["cb_a"], side=self.side,
+            hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
+                               n_add=n, ws=self._ws["cb_a"], side=self.side, loss=loss_a,
                                pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
         self.side.join()
         if first:
@@ -272,7 +284,12 @@ class HourglassEngine:
             for slab, nsl, cnt, off in ps.jobs:
                 full.jobs.append((slab, nsl, cnt, self.off_s + off))
             self._plans["p2"] = full.build(self.grad)
-        self._plans["p2"].run(self.step_t)
+        if ft:      # reduction + Adam + loss values in one launch; the optimiser group is exactly the set of reduced elements
+            self._plans["p2"].run_adam(self.step_t, self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
+                                       self._ticket, loss=(n, self.cbuf["pred"], self.y, self.zsum, self.nzpart, self.lfak, self.L1,
+                                                           self.L2, flags, n * 4096, self.losses))
+        else:
+            self._plans["p2"].run(self.step_t)
 
     def phase2_step(self, A_u8: Optional[torch.Tensor] = None, B_u8: Optional[torch.Tensor] = None,
                     Y: Optional[torch.Tensor] = None):

@@ -183,6 +183,14 @@ class SlabPlan:
     def run(self, step: Optional[torch.Tensor] = None):
         _lib.call("cgs_reduce_slabs", _p(self._table), self._njobs, self._max, _p(step), _stream())
 
+    def run_adam(self, step, param, grad, m, v, lr, b1, b2, eps, ticket, loss=None):
+        """Reduction + Adam (+ the loss values) in one launch (single GPU).  loss = (n, pred, y, zpart, nzpart, lfak, l1, l2, flags,
+        nz, losses) or None."""
+        ls = loss if loss is not None else (0, None, None, None, 0, 0.0, 0.0, 0.0, 0, 0, None)
+        _lib.call("cgs_reduce_adam", _p(self._table), self._njobs, self._max, _p(step), _p(param), _p(grad), _p(m), _p(v),
+                  float(lr), float(b1), float(b2), float(eps), _p(ticket), int(ls[0]), _p(ls[1]), _p(ls[2]), _p(ls[3]), int(ls[4]),
+                  float(ls[5]), float(ls[6]), float(ls[7]), int(ls[8]), int(ls[9]), _p(ls[10]), _stream())
+
 
 # ------------------------------------------------------------------------------------------------
 # critic
@@ -241,7 +249,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None) -> Optional[torch.Tensor]:
+                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
     bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.
     mix_bwd = (A_u8, B_u8, Z, inject, l1_scale, l2_scale, dzpre): x are the replaced|injected mixes of n_a = len(A) images;
@@ -249,7 +257,11 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     from the decoder (valid for images < n_add; their buffers are reused as the running totals).
     dx: optional [n-dx_from,64,64,3] output for the image gradient of images >= dx_from.
     Weight-gradient slabs are registered in ``plan`` (dst offsets = this module's flat layout)."""
+    # dpred may be None with loss = (target [n], scale, bce): the tail kernel derives d loss / d pred itself
+    # (scale * 2 (pred - target), or the BCE form); both None = no loss on this pass's head.  Tail path only.
     mixin = isinstance(x, MixInput)
+    if dpred is None and not TAIL_BWD:
+        raise _lib.CgsError("critic_backward without dpred needs the tail kernels (CGS_TAIL_BWD=1)")
     if mixin and mix_bwd is None:
         raise _lib.CgsError("a MixInput critic input needs mix_bwd (features.0's backward consumes the virtual mixes)")
     u8 = (not mixin) and x.dtype == torch.uint8
@@ -279,7 +291,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         tw = tail_enc_weights(flat, lay, (pw_bwd[1].value, None) if use_pw else None)
         _lib.call("cgs_tail_enc_bwd", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
                   _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
-                  _p(d_embeds[1]) if has_add else None, _p(d_embeds[2]) if has_add else None,
+                  _p(loss[0]) if (dpred is None and loss is not None) else None, float(loss[1]) if loss is not None else 0.0,
+                  int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None, _p(d_embeds[2]) if has_add else None,
                   _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None, n_add if has_add else 0,
                   _p(d_cur), _p(sl_head), _p(sl_pw), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
                   drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())

@@ -179,12 +179,15 @@ int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, 
  *   slab_head [8192 + 32 + 1024 + 32 + 32 + 1]  (features.14 w,b | crit.1 w,b | crit.4 w,b -- contiguous in the flat buffer)
  *   slab_pw [1024 + 32] (dec_model.4, only with d_o4),  slab10 [1152 + 16] (features.10),  slab6 [576 + 8] (features.6);
  * a NULL slab pointer skips that store (data gradient only).
+ * The loss gradient at pred is either given (dpred [n]) or, with dpred = NULL, derived in the kernel from target [n]:
+ *   loss_scale * 2 (pred - target)   (MSE terms of main.py:380-411: loss_scale = weight / n), or with bce != 0
+ *   loss_scale * (pred - target) / (pred (1 - pred))  (binary cross-entropy, --threshrew);  target = NULL: zero.
  * cgs_tail_dec_bwd: dec_model.1/.2/.3 from do1 [n,16,16,8]: skip gradients dE1/dE2/dE3, d_o4 [n,32], and
  * cgs_tail_dec_bwd_slabs(n) slabs of slab1 [1152 + 8], slab2 [1728 + 8], slab3 [6912 + 16].                          */
 int cgs_tail_enc_bwd_slabs(int32_t n);
 int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                      const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
-                     const float* dpred, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
+                     const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
                      int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
                      cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
 int cgs_tail_dec_bwd_slabs(int32_t n);
@@ -223,6 +226,16 @@ typedef struct {
  * -- this is the per-iteration tick that Adam and the dropout masks read. */
 int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count,
                      uint64_t* step, cgs_stream_t stream);
+
+/* Single-GPU tail of a step in one launch: cgs_reduce_slabs, the Adam update (torch.optim.Adam defaults semantics as
+ * cgs_adam_flat, grad_scale 1) of every element a job writes -- param / m / v are indexed by (job.dst - grad_base) -- and, when
+ * n > 0, the loss values of cgs_phase2_losses (losses[8]; no dpred: the tail backward kernels derive it themselves).  *step is
+ * read by every workgroup and advanced by one by the LAST workgroup to finish (ticket: device uint32 [njobs + 2], zero before
+ * the first call; the kernel leaves it zero).                                                                                     */
+int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step, float* param,
+                    const float* grad_base, float* m, float* v, float lr, float beta1, float beta2, float eps,
+                    uint32_t* ticket, int32_t n, const float* pred, const float* y, const float* zpart, int32_t nzpart,
+                    float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses, cgs_stream_t stream);
 
 /* ---- features.0 backward of the replaced / injected passes + mix backward in one launch ----------------------
  * (main.py:395,406 backward chained onto convolution_backward of features.0).  n_a A-images; the mixes are images
