@@ -375,8 +375,9 @@ extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const 
 //   head backward (crit.4, crit.1, features.14, and the decoder's 1x1 conv when d_o4 is given) -> d e3
 //   -> re-expansion through the pool/ReLU nibbles -> features.10 weight + data gradient -> Dropout mask, + skip gradient
 //   -> re-expansion -> features.6 weight + data gradient (+ skip gradient) -> d e1 (memory, for features.3's backward).
-// Weight-gradient partials stay in registers across the workgroup's images; one slab per layer per workgroup:
-//   slab_head [w14 8192 | b14 32 | wl1 1024 | bl1 32 | wl2 32 | bl2 1], slab_pw [1024 | 32], slab10 [1152 | 16], slab6 [576 | 8].
+// The convolutions' weight-gradient partials stay in registers across the workgroup's images (one slab per layer per
+// workgroup: slab10 [1152 | 16], slab6 [576 | 8]); the head's weight gradients -- sums of outer products over the batch -- are
+// left to cgs_tail_head_wgrad below, which reads the per-image vectors this kernel writes to hvec.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kTailHeadSlab = 8192 + 32 + 1024 + 32 + 32 + 1, kTailPwSlab = 1024 + 32, kTailSlab10 = 1168, kTailSlab6 = 584;
 
@@ -387,14 +388,14 @@ struct TailEncBwdParams {
     const float* target; float loss_scale; int bce;
     const float* dE1; const float* dE2; const float* dE3; const float* d_o4; int n_add;
     float* de1;
-    float* slab_head; float* slab_pw; float* slab10; float* slab6;
+    float* hvec; float* slab10; float* slab6;
     cgs_dropout drop_e2, drop_e3, drop_h1;
     int n;
     int nblocks;
     unsigned long long* dbg;
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_enc_bwd_kernel(TailEncBwdParams P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P) {
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
@@ -428,12 +429,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
     // head weights in registers for all images: features.14 row k = tid, crit.1 / dec_model.4 row hk columns 4*part..+3
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
-    float acc4[32], accw1[4], accpw[4];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) acc4[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { accw1[j] = 0.f; accpw[j] = 0.f; }
-    float pb4 = 0.f, pb1 = 0.f, pw2 = 0.f, pb2 = 0.f, pbpw = 0.f;
     WgradAccK<T8x8, T8x16, 16> wg10;
     WgradAccK<T16x8, T16x8, 8> wg6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
@@ -514,17 +509,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // ---- head on shuffles, redundantly in every wave (a half-wave holds all 32 values of o) ----
         const float dz2 = dpr * pr * (1.f - pr);
         const float dh1 = hv > 0.f ? dz2 * wl2 * m2 : 0.f;
-        if (kg == 0) {
-            pw2 = fmaf(dz2, hv * m2, pw2);
-            pb1 += dh1;
-            pbpw += go4;
-            if (o == 0) pb2 += dz2;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ek = __shfl(ev, half + kg * 4 + j, 64);
-            accw1[j] = fmaf(ek, dh1, accw1[j]);
-            accpw[j] = fmaf(ek, go4, accpw[j]);
+        // the head's weight gradients are sums of outer products over the batch: they are left to cgs_tail_head_wgrad (one small
+        // MFMA GEMM over all images) -- here only the per-image vectors it needs are written (hvec [n][384]):
+        //   [0,256) dropout(e3)   [256,288) dz4   [288,320) dh1   [320,352) dz2 * h1 * mask   [352] dz2
+        if (P.hvec) {
+            float* hvp = P.hvec + (size_t)img * 384;
+            if (tid >= 128 && tid < 192) ((float4*)hvp)[tid - 128] = le23 * mk;
+            if (kg == 0) {
+                hvp[288 + o] = dh1;
+                hvp[320 + o] = dz2 * hv * m2;
+                if (o == 0) hvp[352] = dz2;
+            }
         }
         {   // d e4[hk] = sum_o' wl1[hk][o'] dh1[o'] + sum_j wpw[hk][j] d o4[j]: 8 lanes x 4 columns, then ReLU of features.14
             const float w1a[4] = {w1v.x, w1v.y, w1v.z, w1v.w}, wpa[4] = {wpv.x, wpv.y, wpv.z, wpv.w};
@@ -538,24 +533,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             part_sum += __shfl_xor(part_sum, 2, 64);
             part_sum += __shfl_xor(part_sum, 4, 64);
             const float ek = __shfl(ev, half + hk, 64);
-            if (part == 0) dz4s[hk] = ek > 0.f ? part_sum : 0.f;
+            if (part == 0) {
+                const float dz4 = ek > 0.f ? part_sum : 0.f;
+                dz4s[hk] = dz4;
+                if (P.hvec) P.hvec[(size_t)img * 384 + 256 + hk] = dz4;
+            }
         }
         __syncthreads();
         TAIL_STAMP(2);
-        // ---- d features.14 weights; d e3[k = tid] -> straight into features.10's pre-pool gradient tile ----
+        // ---- d e3[k = tid] -> straight into features.10's pre-pool gradient tile ----
         {
-            float4 w14r[8];                       // features.14 row k = tid (L2-resident), in flight during the weight-gradient update
+            float4 w14r[8];                       // features.14 row k = tid (L2-resident)
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) w14r[q4] = ((const float4*)(P.w.w14 + (size_t)tid * 32))[q4];
-            const float dzo = dz4s[o];
-            if (kg == 0) pb4 += dzo;
-#pragma unroll
-            for (int j = 0; j < 32; j += 4) {
-                const float4 xv = *(const float4*)(xs + kg * 32 + j);
-                acc4[j] = fmaf(xv.x, dzo, acc4[j]); acc4[j + 1] = fmaf(xv.y, dzo, acc4[j + 1]);
-                acc4[j + 2] = fmaf(xv.z, dzo, acc4[j + 2]); acc4[j + 3] = fmaf(xv.w, dzo, acc4[j + 3]);
-                if (j % 8 == 4) __builtin_amdgcn_sched_barrier(0);
-            }
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int q4 = 0; q4 < 8; ++q4) {
@@ -614,25 +604,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     // ---- one slab per layer for this workgroup ----
     __syncthreads();
     const size_t b = blockIdx.x;
-    if (P.slab_head) {
-        float* sl = P.slab_head + b * kTailHeadSlab;
-#pragma unroll
-        for (int j = 0; j < 32; ++j) sl[(kg * 32 + j) * 32 + o] = acc4[j];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sl[8192 + 32 + (kg * 4 + j) * 32 + o] = accw1[j];
-        if (tid < 32) {
-            sl[8192 + o] = pb4;
-            sl[8192 + 32 + 1024 + o] = pb1;
-            sl[8192 + 32 + 1024 + 32 + o] = pw2;
-            if (o == 0) sl[8192 + 32 + 1024 + 32 + 32] = pb2;
-        }
-    }
-    if (P.slab_pw) {
-        float* sl = P.slab_pw + b * kTailPwSlab;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sl[(kg * 4 + j) * 32 + o] = accpw[j];
-        if (tid < 32) sl[1024 + o] = pbpw;
-    }
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
     wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
@@ -643,15 +614,113 @@ extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                                 const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
                                 const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
-                                const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
+                                const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
                                 cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
     if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
     if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1,
-                       slab_head, slab_pw, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
+                       hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
     hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients of the critic head (features.14, crit.1, crit.4) and of the decoder's 1x1 conv (dec_model.4) for up to two
+// image ranges (the two critic passes of a step) as ONE small GEMM over the images on the matrix cores:
+//   dW14[k][o] = sum_img dropout(e3)[img][k] dz4[img][o]   dWl1[k][o] = sum e4[img][k] dh1[img][o]   dWpw[k][j] = sum e4[img][k] d_o4[img][j]
+//   db14 = sum dz4, dbl1 = sum dh1, dwl2 = sum dz2 h1 mask, dbl2 = sum dz2, dbpw = sum d_o4
+// from the vectors tail_enc_bwd left in hvec.  16 images per workgroup; slab_head [8192 | 32 | 1024 | 32 | 32 | 1], slab_pw [1024 | 32].
+// (Inside tail_enc_bwd these sums cost 40 accumulator registers per thread and one 37 KB slab per workgroup and pass.)
+// ------------------------------------------------------------------------------------------------
+struct HeadWgradRange { const float* hvec; const float* e4; const float* d_o4; int n, n_o4; };
+struct HeadWgradParams { HeadWgradRange r[2]; float* slab_head; float* slab_pw; };
+static constexpr int kHwIpb = 16;
+
+__global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) {
+    __shared__ __attribute__((aligned(16))) float xs[kHwIpb][260];      // +4: conflict-free column reads
+    __shared__ __attribute__((aligned(16))) float dz4[kHwIpb][32], dh1[kHwIpb][32], qv[kHwIpb][32], e4s[kHwIpb][36], do4[kHwIpb][32];
+    __shared__ float dz2s[kHwIpb];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int total = P.r[0].n + P.r[1].n, img0 = blockIdx.x * kHwIpb;
+    // ---- this workgroup's images -> LDS (zeros beyond the end) ----
+    for (int e = tid; e < kHwIpb * 96; e += 256) {       // 96 float4 of hvec per image
+        const int il = e / 96, q = e % 96, g = img0 + il;
+        float4 v = f4zero();
+        if (g < total) {
+            const HeadWgradRange& R = g < P.r[0].n ? P.r[0] : P.r[1];
+            const int i = g < P.r[0].n ? g : g - P.r[0].n;
+            if (q < 88 || q == 88) v = ((const float4*)(R.hvec + (size_t)i * 384))[q];
+        }
+        if (q < 64) *(float4*)&xs[il][4 * q] = v;
+        else if (q < 72) *(float4*)&dz4[il][4 * (q - 64)] = v;
+        else if (q < 80) *(float4*)&dh1[il][4 * (q - 72)] = v;
+        else if (q < 88) *(float4*)&qv[il][4 * (q - 80)] = v;
+        else if (q == 88) dz2s[il] = v.x;
+    }
+    for (int e = tid; e < kHwIpb * 16; e += 256) {        // e4 (8 float4) and d_o4 (8 float4) per image
+        const int il = e / 16, q = e % 16, g = img0 + il;
+        float4 v = f4zero();
+        if (g < total) {
+            const HeadWgradRange& R = g < P.r[0].n ? P.r[0] : P.r[1];
+            const int i = g < P.r[0].n ? g : g - P.r[0].n;
+            if (q < 8) v = ((const float4*)(R.e4 + (size_t)i * 32))[q];
+            else if (R.d_o4 && i < R.n_o4) v = ((const float4*)(R.d_o4 + (size_t)i * 32))[q - 8];
+        }
+        if (q < 8) *(float4*)&e4s[il][4 * q] = v; else *(float4*)&do4[il][4 * (q - 8)] = v;
+    }
+    __syncthreads();
+    float* sh = P.slab_head + (size_t)blockIdx.x * kTailHeadSlab;
+    float* sp = P.slab_pw ? P.slab_pw + (size_t)blockIdx.x * kTailPwSlab : nullptr;
+    // ---- 40 output tiles of 16 x 16 over 4 waves: 32 of dW14, 4 of dWl1, 4 of dWpw; K = 16 images = 4 k-steps ----
+    for (int t = wave; t < 40; t += 4) {
+        const bool w14 = t < 32, wl1 = t >= 32 && t < 36;
+        const int tt = w14 ? t : (wl1 ? t - 32 : t - 36);
+        const int mb = tt >> 1, nb = tt & 1;            // row block (k), column block (o)
+        frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < kHwIpb / 4; ++s4) {
+            const int il = 4 * s4 + kq;
+            const float a = w14 ? xs[il][16 * mb + l15] : e4s[il][16 * mb + l15];
+            const float b = w14 ? dz4[il][16 * nb + l15] : (wl1 ? dh1[il][16 * nb + l15] : do4[il][16 * nb + l15]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        float* dst = w14 ? sh : (wl1 ? sh + 8192 + 32 : sp);
+        if (dst) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[(16 * mb + 4 * kq + j) * 32 + 16 * nb + l15] = acc[j];
+        }
+    }
+    // ---- bias-like sums ----
+    if (tid < 32) {
+        float s4 = 0.f, s1 = 0.f, sq = 0.f, so = 0.f;
+#pragma unroll
+        for (int il = 0; il < kHwIpb; ++il) { s4 += dz4[il][tid]; s1 += dh1[il][tid]; sq += qv[il][tid]; so += do4[il][tid]; }
+        sh[8192 + tid] = s4;
+        sh[8192 + 32 + 1024 + tid] = s1;
+        sh[8192 + 32 + 1024 + 32 + tid] = sq;
+        if (sp) sp[1024 + tid] = so;
+        if (tid == 0) {
+            float sz = 0.f;
+#pragma unroll
+            for (int il = 0; il < kHwIpb; ++il) sz += dz2s[il];
+            sh[8192 + 32 + 1024 + 32 + 32] = sz;
+        }
+    }
+}
+
+extern "C" int cgs_tail_head_wgrad_slabs(int32_t n_total) { return n_total < 0 ? CGS_ERR_BADARG : (n_total + kHwIpb - 1) / kHwIpb; }
+
+extern "C" int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
+                                   const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
+                                   float* slab_pw, cgs_stream_t stream) {
+    if (n0 < 0 || n1 < 0 || !slab_head || (n0 > 0 && (!hvec0 || !e4_0)) || (n1 > 0 && (!hvec1 || !e4_1))) return CGS_ERR_BADARG;
+    if ((d_o4_0 || d_o4_1) && !slab_pw) return CGS_ERR_BADARG;
+    if (n0 + n1 == 0) return CGS_OK;
+    HeadWgradParams P{{{hvec0, e4_0, d_o4_0, n0, n_o4_0}, {hvec1, e4_1, d_o4_1, n1, n_o4_1}}, slab_head, slab_pw};
+    hipLaunchKernelGGL(tail_head_wgrad_kernel, dim3((n0 + n1 + kHwIpb - 1) / kHwIpb), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -150,8 +150,8 @@ class HourglassEngine:
         out1, out2 = {}, {}
         nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
         tail = hg.TAIL_BWD       # head / features.10 / features.6 slabs then come from the tail kernel's workgroups
-        specs = [("slab_head", (lambda n, first: lib.cgs_tail_enc_bwd_slabs(n)) if tail else (lambda n, first: lib.cgs_head_bwd_slabs(n)),
-                  hg.HEAD_SLAB)]
+        # (tail path: the head's slabs come from ONE cgs_tail_head_wgrad launch over both passes, allocated there)
+        specs = [] if tail else [("slab_head", lambda n, first: lib.cgs_head_bwd_slabs(n), hg.HEAD_SLAB)]
         for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
             def f(n, first, i=i, hw=hw, ca=ca, cb=cb, co=co, ups=ups, act=act, pool=pool):
                 d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
@@ -239,13 +239,14 @@ class HourglassEngine:
             self._ws["cb_mix"].update(self._sl_mix)
             self._ws["cb_a"].update(self._sl_a)
         pc = plan if first else hg.SlabPlan()   # job registration only matters the first time
+        sink_c = [] if hg.TAIL_BWD else None     # the critic's passes whose head weight gradients are formed together below
         # critic backward on the mixes: image gradient for the mask path (+ weight gradients when live)
         nz = float(n * 4096)
         if hg.ENC0_MIX_FUSED:
             # features.0's backward carries the mix backward: the image gradients of the mixes never leave the chip
             hg.critic_backward(self.fc, self.lc, mixsrc, nmix, self._cview(2 * n, 2 * n + nmix),
                                None if ft else self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=None, dx_from=0,
-                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live, loss=loss_mix,
+                               ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live, loss=loss_mix, head_sink=sink_c,
                                mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre))
         else:
             hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
@@ -267,12 +268,14 @@ class HourglassEngine:
                                pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
             if self.live:
                 hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n),
-                                   ws=self._ws["cb_a"], side=self.side, loss=loss_a)
+                                   ws=self._ws["cb_a"], side=self.side, loss=loss_a, head_sink=sink_c)
         elif self.live:
             d_o4, d_emb[4] = d_emb[4], None
             hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
-                               n_add=n, ws=self._ws["cb_a"], side=self.side, loss=loss_a,
+                               n_add=n, ws=self._ws["cb_a"], side=self.side, loss=loss_a, head_sink=sink_c,
                                pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
+        if sink_c:
+            hg.head_wgrad(sink_c, pc, self.lc, self._ws["cb_a"])
         self.side.join()
         if first:
             full = hg.SlabPlan()

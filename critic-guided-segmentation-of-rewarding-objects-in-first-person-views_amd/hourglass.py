@@ -244,12 +244,38 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     return o
 
 
+def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor]):
+    """Weight gradients of the critic head (+ the decoder's 1x1 conv) for the image ranges the tail backward kernel(s) left
+    behind: ranges = [(hvec, e4, d_o4 or None, n, n_o4, pw_bwd or None)], at most two; one small GEMM over the images."""
+    if not ranges:
+        return
+    assert len(ranges) <= 2
+    lib = _lib.load()
+    total = sum(r[3] for r in ranges)
+    nsl = lib.cgs_tail_head_wgrad_slabs(total)
+    dev = ranges[0][0].device
+    key = f"slab_head_{total}"
+    if ws.get(key) is None:
+        ws[key] = torch.empty((nsl, HEAD_SLAB), device=dev, dtype=torch.float32)
+    pwb = next((r[5] for r in ranges if r[5] is not None), None)
+    if pwb is not None and ws.get(key + "_pw") is None:
+        ws[key + "_pw"] = torch.empty((nsl, PW_SLAB), device=dev, dtype=torch.float32)
+    sl, slpw = ws[key], (ws[key + "_pw"] if pwb is not None else None)
+    r0 = ranges[0]
+    r1 = ranges[1] if len(ranges) > 1 else (None, None, None, 0, 0, None)
+    _lib.call("cgs_tail_head_wgrad", r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4],
+              _p(sl), _p(slpw), _stream())
+    plan.add(sl, nsl, HEAD_SLAB, lay.off("features.14.weight"))
+    if pwb is not None:
+        pwb[2].add(slpw, nsl, PW_SLAB, pwb[3])
+
+
 def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, saved: Dict[str, torch.Tensor],
                     dpred: torch.Tensor, plan: SlabPlan, drop: DropState = NO_DROP,
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None) -> Optional[torch.Tensor]:
+                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None, head_sink=None) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
     bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.
     mix_bwd = (A_u8, B_u8, Z, inject, l1_scale, l2_scale, dzpre): x are the replaced|injected mixes of n_a = len(A) images;
@@ -283,25 +309,26 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         # head + features.10 + features.6 backward in one tail kernel: d e1 (skip gradients included)
         use_pw = pw_bwd is not None and has_add
         nsl = lib.cgs_tail_enc_bwd_slabs(n)
-        sl_head = buf("slab_head", (nsl, HEAD_SLAB)) if need_wgrad else None
         sl10 = buf("slab_enc3", (nsl, 9 * 8 * 16 + 16)) if need_wgrad else None
         sl6 = buf("slab_enc2", (nsl, 9 * 8 * 8 + 8)) if need_wgrad else None
-        sl_pw = buf("slab_head_pw", (nsl, PW_SLAB)) if use_pw else None
+        hvec = buf("hvec", (n, 384)) if need_wgrad else None
         d_cur = buf("de1", (n, 16, 16, 8))
         tw = tail_enc_weights(flat, lay, (pw_bwd[1].value, None) if use_pw else None)
         _lib.call("cgs_tail_enc_bwd", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
                   _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
                   _p(loss[0]) if (dpred is None and loss is not None) else None, float(loss[1]) if loss is not None else 0.0,
-                  int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None, _p(d_embeds[2]) if has_add else None,
-                  _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None, n_add if has_add else 0,
-                  _p(d_cur), _p(sl_head), _p(sl_pw), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
+                  int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None,
+                  _p(d_embeds[2]) if has_add else None, _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None,
+                  n_add if has_add else 0, _p(d_cur), _p(hvec), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
                   drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
         if need_wgrad:
-            plan.add(sl_head, nsl, HEAD_SLAB, lay.off("features.14.weight"))
             plan.add(sl10, nsl, 9 * 8 * 16 + 16, lay.off("features.10.weight"))
             plan.add(sl6, nsl, 9 * 8 * 8 + 8, lay.off("features.6.weight"))
-        if use_pw:
-            pw_bwd[2].add(sl_pw, nsl, PW_SLAB, pw_bwd[3])
+            rng = (hvec, saved["e4"], pw_bwd[0] if use_pw else None, n, n_add if use_pw else 0, pw_bwd if use_pw else None)
+            if head_sink is not None:
+                head_sink.append(rng)            # the caller forms the head's weight gradients for all its passes at once
+            else:
+                head_wgrad([rng], plan, lay, ws)
         first_layer = 1
     # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
     if first_layer == 3:

@@ -175,10 +175,14 @@ int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, 
 /* Backward of the same layers.  cgs_tail_enc_bwd: one critic pass, from dpred [n] to de1 [n,16,16,8] (gradient w.r.t. e1,
  * input of features.3's backward).  dE1 / dE2 / dE3 (skip gradients from the decoder, shapes of e1 / e2 / e3) and d_o4 [n,32]
  * (gradient w.r.t. dec_model.4's output: its backward then runs here too) may be NULL; they are read for images < n_add.
- * Every workgroup writes one slab per layer: cgs_tail_enc_bwd_slabs(n) slabs of
+ * Every workgroup writes one slab per convolution: cgs_tail_enc_bwd_slabs(n) slabs of slab10 [1152 + 16] (features.10) and
+ * slab6 [576 + 8] (features.6); a NULL slab pointer skips that store (data gradient only).  The head's weight gradients are
+ * sums of outer products over the batch: the kernel leaves the per-image vectors in hvec [n,384] (may be NULL:
+ * [0,256) dropout(e3) | [256,288) dz4 | [288,320) dh1 | [320,352) dz2 h1 mask | [352] dz2) and cgs_tail_head_wgrad forms them
+ * for up to two image ranges (the critic passes of a step; d_o4_k [n_o4_k,32] = that range's decoder gradient or NULL) as one
+ * GEMM over the images: cgs_tail_head_wgrad_slabs(n0 + n1) slabs of
  *   slab_head [8192 + 32 + 1024 + 32 + 32 + 1]  (features.14 w,b | crit.1 w,b | crit.4 w,b -- contiguous in the flat buffer)
- *   slab_pw [1024 + 32] (dec_model.4, only with d_o4),  slab10 [1152 + 16] (features.10),  slab6 [576 + 8] (features.6);
- * a NULL slab pointer skips that store (data gradient only).
+ *   slab_pw [1024 + 32] (dec_model.4; required when a d_o4 is given).
  * The loss gradient at pred is either given (dpred [n]) or, with dpred = NULL, derived in the kernel from target [n]:
  *   loss_scale * 2 (pred - target)   (MSE terms of main.py:380-411: loss_scale = weight / n), or with bce != 0
  *   loss_scale * (pred - target) / (pred (1 - pred))  (binary cross-entropy, --threshrew);  target = NULL: zero.
@@ -188,8 +192,12 @@ int cgs_tail_enc_bwd_slabs(int32_t n);
 int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                      const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
                      const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
-                     int32_t n_add, float* de1, float* slab_head, float* slab_pw, float* slab10, float* slab6,
+                     int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
                      cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+int cgs_tail_head_wgrad_slabs(int32_t n_total);
+int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
+                        const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
+                        float* slab_pw, cgs_stream_t stream);
 int cgs_tail_dec_bwd_slabs(int32_t n);
 int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
