@@ -71,7 +71,7 @@ SIGNATURES = {
     "cgs_reduce_slabs": (i32, [vp, i32, i32, vp, vp]),
     "cgs_head_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, Dropout, Dropout, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_enc0_bwd_mix_slabs": (i32, [i32]),
-    "cgs_enc0_bwd_mix": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp]),
+    "cgs_enc0_bwd_mix": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp]),
     "cgs_head_bwd_slabs": (i32, [i32]),
     "cgs_head_bwd": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, Dropout, Dropout, vp, vp, vp, vp, vp, vp]),
     "cgs_pointwise_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -21,6 +21,7 @@ struct ConvParams {
     // replaced image's gradient: combine with the stash and write d(pre-sigmoid mask) of A-image q.n
     const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z; float* mix_dz;
     float mix_l1s, mix_l2s;
+    const float* mix_vf_pred;   // -staticnorm '' (main.py:415-418): the mask regulariser of A-image n is weighted by 1 - pred[n] (NULL: 1)
     int mix_phase, mix_inject;
     int mix_n_a;           // SRC_MIXC3: number of A-images (mix image n >= mix_n_a is the injected one of n - mix_n_a)
     float* zpart;          // masker.2 forward: optional per-workgroup partial sums (sum |z|, sum z^2) for the L1 / L2 mask losses
@@ -353,7 +354,12 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                                 }
                                 const float zi = P.mix_z[pix];
                                 const float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
-                                dsum += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;
+                                if (P.mix_vf_pred) {      // valuefak = 1 - pred (>= 0) weights |z| and, squared, z^2
+                                    const float vf = 1.f - P.mix_vf_pred[q.n];
+                                    dsum += P.mix_l1s * vf * sg + 2.f * P.mix_l2s * vf * vf * zi;
+                                } else {                  // (the same expression as cgs_mix_bwd: bit-identical results)
+                                    dsum += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;
+                                }
                                 P.mix_dz[pix] = dsum * zi * (1.f - zi);
                             }
                         } else {

@@ -128,6 +128,7 @@ struct MixBwdArgs {
     const uint8_t* a; const uint8_t* b; const float* z; float* dzpre;
     int n_a, inject;
     float l1s, l2s;
+    const float* vf_pred;
 };
 
 template <class CWG>
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvP
     }
     const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
     pd.stash = (float*)smem + stash_off;                 // [4 pixels x 3 channels][256 threads]
-    pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s;
+    pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
     if (M.inject) {
         pd.mix_phase = 1;                                // injected image: gradient to the stash
@@ -157,7 +158,7 @@ extern "C" int cgs_enc0_bwd_mix_slabs(int32_t n_mix) { return n_mix < 0 ? CGS_ER
 
 extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
                                 const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
-                                float l2_scale, float* dzpre, float* slab, cgs_stream_t stream) {
+                                float l2_scale, const float* valuefak_pred, float* dzpre, float* slab, cgs_stream_t stream) {
     if (n_a < 0 || !dy || !amask || !w || !a || !b || !z || !dzpre) return CGS_ERR_BADARG;
     if (mixed && !slab) return CGS_ERR_BADARG;           // `mixed` is only the weight gradient's input
     if (n_a == 0) return CGS_OK;
@@ -170,7 +171,7 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     pw.mix_a = a; pw.mix_b = b; pw.mix_z = z; pw.mix_n_a = n_a;
     ConvParams pd{};
     pd.src_a = dy; pd.amask_in = amask; pd.w = w; pd.n = n_mix;
-    MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale};
+    MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale, valuefak_pred};
     const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
     const int nbd = n_a * GD::STRIPS;
     size_t lw = wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();

@@ -125,7 +125,11 @@ __global__ void __launch_bounds__(256) phase2_losses_kernel(int n, const float* 
         }
     }
     float z1 = 0.f, z2 = 0.f;
-    for (int i = threadIdx.x; i < nzpart; i += 256) { z1 += zpart[2 * i]; z2 += zpart[2 * i + 1]; }
+    const int per_img = nzpart / n;      // flag bit 8 (-staticnorm ''): image i's partial sums weighted by 1 - pred_A[i] (and its square)
+    for (int i = threadIdx.x; i < nzpart; i += 256) {
+        const float vf = (flags & 8) ? 1.f - pred[n + i / per_img] : 1.f;
+        z1 += vf * zpart[2 * i]; z2 += vf * vf * zpart[2 * i + 1];
+    }
     sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si); z1 = wave_sum(z1); z2 = wave_sum(z2);
     if ((threadIdx.x & 63) == 0) {
         int w = threadIdx.x >> 6;
@@ -406,7 +410,11 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
         sr += (pr - pb) * (pr - pb);
         if (inject) { const float d = L.pred[3 * n + i] - pa; si += d * d; }
     }
-    for (int i = tid; i < L.nzpart; i += 1024) { z1 += L.zpart[2 * i]; z2 += L.zpart[2 * i + 1]; }
+    const int per_img = L.nzpart / n;
+    for (int i = tid; i < L.nzpart; i += 1024) {
+        const float vf = (L.flags & 8) ? 1.f - L.pred[n + i / per_img] : 1.f;
+        z1 += vf * L.zpart[2 * i]; z2 += vf * vf * L.zpart[2 * i + 1];
+    }
     sc = wave_sum(sc); sr = wave_sum(sr); si = wave_sum(si); z1 = wave_sum(z1); z2 = wave_sum(z2);
     if ((tid & 63) == 0) { const int w = tid >> 6; lred[0][w] = sc; lred[1][w] = sr; lred[2][w] = si; lred[3][w] = z1; lred[4][w] = z2; }
     __syncthreads();

@@ -36,7 +36,7 @@ class HourglassEngine:
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
                  process_group=None, share_with: "HourglassEngine" = None, overlap_wgrad: bool = False,
-                 separate: bool = False):
+                 separate: bool = False, staticnorm: bool = True):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -56,6 +56,7 @@ class HourglassEngine:
         # -separate (main.py:110-111, 390): a second critic supplies the masker's skip inputs; its parameters sit behind the
         # masker's, so "masker + sepcrit" (the frozen optimiser group, main.py:334) is one contiguous range too
         self.separate = bool(separate)
+        self.staticnorm = bool(staticnorm)     # False: main.py:415-418, the mask regulariser weighted per image by 1 - pred.detach()
         self.off_s = _align4(self.off_m + self.lm.total)
         self.total = self.off_s + self.lc.total if self.separate else self.off_m + self.lm.total
         z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
@@ -222,7 +223,7 @@ class HourglassEngine:
             mixsrc = self.mixed[:nmix]
             _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
             hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
-        flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
+        flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0) | (0 if self.staticnorm else 8)
         ft = self.fused_tail
         if not ft:
             _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
@@ -247,7 +248,8 @@ class HourglassEngine:
             hg.critic_backward(self.fc, self.lc, mixsrc, nmix, self._cview(2 * n, 2 * n + nmix),
                                None if ft else self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=None, dx_from=0,
                                ws=self._ws["cb_mix"], side=self.side, need_wgrad=self.live, loss=loss_mix, head_sink=sink_c,
-                               mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre))
+                               mix_bwd=(A, B, self.mbuf["Z"], self.inject, self.L1 / nz, self.L2 / nz, self.dzpre,
+                                        None if self.staticnorm else sa["pred"]))
         else:
             hg.critic_backward(self.fc, self.lc, self.mixed[:nmix], nmix, self._cview(2 * n, 2 * n + nmix),
                                self.dpred[2 * n:2 * n + nmix], pc, drop.shifted(2 * n), dx=self.dmixed[:nmix], dx_from=0,

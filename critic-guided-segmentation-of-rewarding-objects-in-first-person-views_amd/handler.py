@@ -20,6 +20,11 @@ from .engine import HourglassEngine
 from .nets import NewCritic, UnetDecoder
 
 
+def hg_mix_fused():
+    from . import hourglass
+    return hourglass.ENC0_MIX_FUSED
+
+
 def checkpoint_names(args):
     """Checkpoint file stems of the reference: ``k=v`` joined by '-' for TRUTHY values only (main.py:86-91), e.g.
     critic-rewidx=1-cepochs=15-datamode=trunk-datasize=100000-shift=12-chfak=1-dropout=0.3 / masker-mepochs=1-L1=0.5-inject=True."""
@@ -181,7 +186,7 @@ class Handler:
             first = next(iter(self._engines.values()), None)
             e = HourglassEngine(n, device=self.device, dropout=a.dropout, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject,
                                 live=live, threshrew=a.threshrew, share_with=first, process_group=self.pg,
-                                separate=bool(a.separate))
+                                separate=bool(a.separate), staticnorm=bool(a.staticnorm))
             if first is None:
                 # modules and engine share one parameter buffer from now on
                 e.adopt(self.critic, self.masker, self.sepcrit if a.separate else None)
@@ -198,9 +203,9 @@ class Handler:
     def _refuse_unbuilt_flags(self):
         """Flags the reference reads on this path that this build does not implement: refuse instead of training something else."""
         a = self.args
-        if not a.staticnorm:
-            raise NotImplementedError("-staticnorm '' (mask regulariser weighted by 1 - pred, main.py:415-418) is not implemented "
-                                      "by the HIP loss kernels; the engine uses valuefak = 1")
+        if not a.staticnorm and not hg_mix_fused():
+            raise NotImplementedError("-staticnorm '' (mask regulariser weighted by 1 - pred, main.py:415-418) needs the fused "
+                                      "features.0 + mix backward (CGS_ENC0_MIX_FUSED=1, the default)")
 
     def critic_pipe(self, mode="train", test=0):
         args = self.args

@@ -355,14 +355,15 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         cnt = 9 * ca * co + co
         wptr = C.c_void_p(fp + 4 * lay.off(key + ".weight"))
         if i == 0 and mix_bwd is not None:
-            A8, B8, Zm, inj, l1s, l2s, dzp = mix_bwd
+            A8, B8, Zm, inj, l1s, l2s, dzp = mix_bwd[:7]
+            vfp = mix_bwd[7] if len(mix_bwd) > 7 else None      # -staticnorm '': pred of A, the regulariser's per-image weight
             slab = None
             if need_wgrad:
                 nsl = lib.cgs_enc0_bwd_mix_slabs(n)
                 slab = buf("slab_enc0", (nsl, cnt))
                 plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
             _lib.call("cgs_enc0_bwd_mix", A8.shape[0], int(bool(inj)), _p(src) if (need_wgrad and not mixin) else None, _p(d_cur),
-                      _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(dzp), _p(slab), _stream())
+                      _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(vfp), _p(dzp), _p(slab), _stream())
             return None
         if need_wgrad and i in BOTH_ENC and (i > 0 or (dx is not None and dx_from == 0 and not u8)):
             # both halves in one launch: slab + d e{i-1} (dropout mask and decoder skip gradient fused)

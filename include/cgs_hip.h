@@ -256,7 +256,10 @@ int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count
 int cgs_enc0_bwd_mix_slabs(int32_t n_mix);
 int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
                      const float* w_hwio, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
-                     float l2_scale, float* dzpre, float* slab, cgs_stream_t stream);
+                     float l2_scale, const float* valuefak_pred, float* dzpre, float* slab, cgs_stream_t stream);
+/* valuefak_pred (may be NULL): -staticnorm '' of main.py:415-418 -- the regulariser terms of A-image i are weighted by
+ * (1 - valuefak_pred[i]) (L1) and its square (L2); with cgs_phase2_losses / cgs_reduce_adam the same weighting of the loss
+ * VALUES is selected by flag bit 8 (weights from pred[n + i], zpart holding nzpart / n partial pairs per image).        */
 
 /* ---- critic head: 4x4 valid conv + Linear + Linear (nets.py:184-194) -----------------
  *   e3     : [n,4,4,16] pooled embed (dropout `drop_in` fused into the load)

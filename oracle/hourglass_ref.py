@@ -188,7 +188,8 @@ def phase1_loss(Pc: Params, XP: torch.Tensor, Y: torch.Tensor, threshrew: float 
 
 def phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: torch.Tensor,
                 lfak: float = 5, L1: float = 0.5, L2: float = 0.0, inject: bool = True, live: bool = True,
-                threshrew: float = 0.0, p: float = 0.0, training: bool = True, masks=None, Ps: Optional[Params] = None):
+                threshrew: float = 0.0, p: float = 0.0, training: bool = True, masks=None, Ps: Optional[Params] = None,
+                staticnorm: bool = True):
     """Joint mask/critic objective of one phase-2 step (main.py:364-429, staticnorm => valuefak=1).
 
     ``masks`` (optional) = 4 lists of 3 dropout keep-masks for the passes [A, B, replaced, injected]
@@ -219,12 +220,13 @@ def phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: tor
         il = F.mse_loss(iv, pred.detach())
         total = total + il
         parts["inject"] = il
+    valuefak = 1 if staticnorm else 1 - pred.detach().view(-1, 1, 1, 1)      # main.py:415-418
     if L1:
-        nl = L1 * F.l1_loss(Z, torch.zeros_like(Z))
+        nl = L1 * F.l1_loss(valuefak * Z, torch.zeros_like(Z))
         total = total + nl
         parts["norm"] = nl
     if L2:
-        nl2 = L2 * F.mse_loss(Z, torch.zeros_like(Z))
+        nl2 = L2 * F.mse_loss(valuefak * Z, torch.zeros_like(Z))
         total = total + nl2
         parts["norm2"] = nl2
     return total, parts, Z, pred

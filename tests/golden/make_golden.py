@@ -128,7 +128,7 @@ np.savez(os.path.join(HERE, "g2_eval_chfak5.npz"), X=g25["X"], pred=g25["pred"],
 
 # ---------------------------------------------------------------- G3 / G7: phase-2 steps
 def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False, threshrew=0.0,
-           separate=False):
+           separate=False, staticnorm=True):
     from itertools import chain
     critic, masker = build(1, dropout=dropout)
     load_np(critic, "critic", g1); load_np(masker, "masker", g1)
@@ -180,11 +180,12 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
                 injected = B * (1 - Z) + Z * A
                 il = F.mse_loss(critic(injected).squeeze(), pred.detach())
                 loss = loss + il; parts[2] = il.item()
+            valuefak = 1 if staticnorm else 1 - pred.detach().view(-1, 1, 1, 1)     # main.py:415-418
             if L1:
-                nl = L1 * F.l1_loss(1 * Z, torch.zeros_like(Z))
+                nl = L1 * F.l1_loss(valuefak * Z, torch.zeros_like(Z))
                 loss = loss + nl; parts[3] = nl.item()
             if L2:
-                nl2 = L2 * F.mse_loss(1 * Z, torch.zeros_like(Z))
+                nl2 = L2 * F.mse_loss(valuefak * Z, torch.zeros_like(Z))
                 loss = loss + nl2; parts[4] = nl2.item()
             opti.zero_grad()
             loss.backward()
@@ -221,6 +222,7 @@ phase2("g3_train_noinject", inject=False)
 phase2("g3_train_frozen", live=False)
 phase2("g3_train_l2", L2=0.1)
 phase2("g3_train_bce", threshrew=0.5)
+phase2("g3_train_valuefak", staticnorm=False, L2=0.1)
 phase2("g3_train_separate", separate=True)
 phase2("g3_train_separate_frozen", separate=True, live=False)
 phase2("g7_dropout", steps=1, dropout=0.3, record_masks=True)

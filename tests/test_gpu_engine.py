@@ -29,7 +29,8 @@ def make_engine(g1, n, **kw):
     ("g3_train_noinject", dict(inject=False)),
     ("g3_train_frozen", dict(live=False)),
     ("g3_train_l2", dict(L2=0.1)),
-    ("g3_train_bce", dict(threshrew=0.5)),      # --threshrew: BCE live-critic loss (main.py:380-381)
+    ("g3_train_bce", dict(threshrew=0.5)),
+    ("g3_train_valuefak", dict(staticnorm=False, L2=0.1)),       # -staticnorm '': regulariser weighted by 1 - pred (main.py:415-418)      # --threshrew: BCE live-critic loss (main.py:380-381)
 ])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_phase2_matches_reference_capture(golden, g1, tag, kw, use_graph):

@@ -589,13 +589,13 @@ def test_enc0_backward_with_mix_backward_equals_two_launches(ctx, inject, wgrad)
     if wgrad:
         assert lib.cgs_enc0_bwd_mix_slabs(n_mix) == ns
         slab = torch.zeros(ns, 224, device=dev)
-    _lib.call("cgs_enc0_bwd_mix", n_a, int(inject), P(mixed) if wgrad else None, P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s,
+    _lib.call("cgs_enc0_bwd_mix", n_a, int(inject), P(mixed) if wgrad else None, P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, None,
               P(dz), P(slab), st)
     torch.cuda.synchronize()
     assert torch.equal(dz, dz_ref)
     if wgrad:
         assert torch.equal(slab, s_ref)
-    assert lib.cgs_enc0_bwd_mix(n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, P(dz), None, st) < 0
+    assert lib.cgs_enc0_bwd_mix(n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, None, P(dz), None, st) < 0
 
 
 def test_virtual_mixes_equal_materialised_mixes(ctx):
@@ -628,8 +628,8 @@ def test_virtual_mixes_equal_materialised_mixes(ctx):
     ns = lib.cgs_enc0_bwd_mix_slabs(2 * n_a)
     s_ref, s_vir = torch.zeros(ns, 224, device=dev), torch.zeros(ns, 224, device=dev)
     dz_ref, dz_vir = torch.empty(n_a, 64, 64, device=dev), torch.empty(n_a, 64, 64, device=dev)
-    _lib.call("cgs_enc0_bwd_mix", n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, P(dz_ref), P(s_ref), st)
-    _lib.call("cgs_enc0_bwd_mix", n_a, 1, None, P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, P(dz_vir), P(s_vir), st)
+    _lib.call("cgs_enc0_bwd_mix", n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, None, P(dz_ref), P(s_ref), st)
+    _lib.call("cgs_enc0_bwd_mix", n_a, 1, None, P(dy), P(am), w, P(A), P(B), P(Z), 1e-6, 0.0, None, P(dz_vir), P(s_vir), st)
     torch.cuda.synchronize()
     assert torch.equal(dz_ref, dz_vir)
     rel_close(s_vir.sum(0).cpu().numpy(), s_ref.sum(0).cpu().numpy(), "features.0 weight gradient on virtual mixes", rtol=1e-4)

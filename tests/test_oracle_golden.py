@@ -69,6 +69,7 @@ def test_eval_forward_chfak5(golden):
     ("g3_train_frozen", dict(live=False)),
     ("g3_train_l2", dict(L2=0.1)),
     ("g3_train_bce", dict(threshrew=0.5)),
+    ("g3_train_valuefak", dict(staticnorm=False, L2=0.1)),       # -staticnorm '': regulariser weighted by 1 - pred (main.py:415-418)
 ])
 def test_phase2_steps_match_reference(golden, g1, tag, kw):
     pc, pm = g1
