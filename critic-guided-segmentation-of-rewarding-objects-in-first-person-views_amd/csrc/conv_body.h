@@ -82,6 +82,11 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
         load_poolexp<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, q.row0, N, tid,
                                [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
         zero_halo_cols<G, PA>(ldsA, tid);
+    } else if constexpr (C::SRC == SRC_POOLEXP_DIFF) {
+        // gradient tile of (replaced image q.n) - (injected image q.n + mix_n_a): one data-gradient pass serves the mix backward
+        load_poolexp_diff<G, PA, 1>(ldsA, (const float4*)P.src_a, P.amask_in, n0, P.mix_n_a, P.mix_inject != 0, q.row0, N, tid,
+                                    [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); }, DUMP);
+        zero_halo_cols<G, PA>(ldsA, tid);
     } else if constexpr (C::SRC == SRC_DH) {
         // d(masker.0 output) is never read from memory here: it is rebuilt from dzpre (1 channel) and the LeakyReLU
         // mask of the saved activation, dH = LeakyReLU'(h) * conv_bwd(dzpre; masker.2), used as this kernel's input
@@ -349,7 +354,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                                 for (int o = 0; o < 3; ++o) {
                                     const int sh = 8 * (3 * (i & 1) + o);
                                     const float av = (float)((a6[i >> 1] >> sh) & 255) * s255, bv = (float)((b6[i >> 1] >> sh) & 255) * s255;
-                                    const float di = P.mix_inject ? P.stash[(i * 3 + o) * C::THREADS + qtid] : 0.f;
+                                    float di = 0.f;      // (SRC_POOLEXP_DIFF: v is already d_rep - d_inj)
+                                    if constexpr (C::SRC != SRC_POOLEXP_DIFF) di = P.mix_inject ? P.stash[(i * 3 + o) * C::THREADS + qtid] : 0.f;
                                     dsum = fmaf(bv - av, v[o] - di, dsum);
                                 }
                                 const float zi = P.mix_z[pix];

@@ -6,6 +6,7 @@
 // joins inside a HIP graph cost 6-10 us each on ROCm 7.2, more than they gain).
 #include "conv_body.h"
 #include "wgrad_body.h"
+#include <cstdlib>
 
 template <class CWG, class CDG>
 __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradParams pw, ConvParams pd, int nbw) {
@@ -124,6 +125,12 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
 // form (same data-gradient code, same arithmetic order in the mix part).
 // ------------------------------------------------------------------------------------------------
 struct DEnc0S : DEnc0 { static constexpr bool STASH = true; };
+// one pass over the DIFFERENCE of the replaced and the injected image's gradient tiles (conv_tile.h load_poolexp_diff)
+struct DEnc0D : DEnc0 { static constexpr bool STASH = true; static constexpr int SRC = SRC_POOLEXP_DIFF; };
+static bool enc0_diff() {
+    static const bool on = [] { const char* e = std::getenv("CGS_ENC0_DIFF"); return !(e && e[0] == '0'); }();
+    return on;
+}
 struct MixBwdArgs {
     const uint8_t* a; const uint8_t* b; const float* z; float* dzpre;
     int n_a, inject;
@@ -132,7 +139,7 @@ struct MixBwdArgs {
 };
 
 template <class CWG>
-__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, int stash_off) {
+__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, int stash_off, int diff) {
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -145,6 +152,12 @@ __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvP
     pd.stash = (float*)smem + stash_off;                 // [4 pixels x 3 channels][256 threads]
     pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
+    if (diff) {      // linear in dY: conv_bwd(dY_rep - dY_inj) in ONE pass (half the FMAs of the two-pass form; sums in another order)
+        pd.mix_phase = 2;
+        pd.mix_n_a = M.n_a;
+        conv3x3_body<DEnc0D, true>(pd, img * G::STRIPS + strip, smem);
+        return;
+    }
     if (M.inject) {
         pd.mix_phase = 1;                                // injected image: gradient to the stash
         conv3x3_body<DEnc0S, true>(pd, (M.n_a + img) * G::STRIPS + strip, smem);
@@ -180,10 +193,10 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     const size_t lds = base + 12 * 256 * sizeof(float);      // 41 KB tiles + 12 KB stash: three workgroups per CU
     if (mixed || !slab)        // materialised mixes (or no weight gradient at all)
         hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0F32>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
-                           (int)(base / sizeof(float)));
+                           (int)(base / sizeof(float)), (int)enc0_diff());
     else                       // weight-gradient input = the mixes recomputed from a, b, z in the tile loader
         hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0Mix>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
-                           (int)(base / sizeof(float)));
+                           (int)(base / sizeof(float)), (int)enc0_diff());
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

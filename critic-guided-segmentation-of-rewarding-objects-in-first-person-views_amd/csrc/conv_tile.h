@@ -18,7 +18,7 @@
 #pragma once
 #include "cgs_common.h"
 
-enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5, SRC_MIXC3 = 6 };
+enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5, SRC_MIXC3 = 6, SRC_POOLEXP_DIFF = 7 };
 
 // THREADS = quads per workgroup; CW = waves-groups that split the output-channel chunks of those quads
 // between them (small images: more waves per image); LT = threads that take part in the tile loads.
@@ -229,6 +229,39 @@ __device__ __forceinline__ void load_poolexp(float4* lds, const float4* __restri
             int r = 2 * j + (pos >> 1) - HALO;  // row inside the tile
             bool ok = r >= 0 && r < G::TH + 2 * HALO;
             lds[ok ? idx(p, img, r, 2 * px + (pos & 1)) : dump] = nib_select(v, nib, pos);
+        }
+    });
+}
+
+// The same re-expansion for the DIFFERENCE of two images' gradients, image n0 minus image n0 + n_off (when sub): the data gradient
+// of a convolution is linear in its input, so conv_bwd(dY_replaced) - conv_bwd(dY_injected) -- all the mix backward of
+// main.py:395,406 needs -- is ONE pass over the difference tile (each image contributes at most one non-zero per pooling window).
+template <class G, int PA, int HALO, class IdxF>
+__device__ __forceinline__ void load_poolexp_diff(float4* lds, const float4* __restrict__ dp, const uint32_t* __restrict__ am, int n0,
+                                                  int n_off, bool sub, int row0, int N, int tid, IdxF idx, int dump) {
+    static_assert(G::IMGS == 1, "one image per workgroup");
+    constexpr int HP = G::H / 2, WP = G::W / 2;
+    constexpr int JR = G::RQ + 2 * HALO;
+    constexpr int E = JR * WP * PA;
+    constexpr int AMW = (PA + 1) / 2;
+    const int pr0 = row0 / 2 - HALO;
+    for_elems<E, G::LT>(tid, [&](int e) {
+        int p = e % PA, px = (e / PA) % WP, j = e / (PA * WP);
+        int pr = pr0 + j;
+        bool in = n0 < N && pr >= 0 && pr < HP;
+        int pi = in ? (n0 * HP + pr) * WP + px : 0;
+        int pj = (in && sub) ? ((n0 + n_off) * HP + pr) * WP + px : 0;
+        float4 v = dp[pi * PA + p], u = dp[pj * PA + p];
+        uint32_t nib = (am[pi * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu;
+        uint32_t nbj = (am[pj * AMW + (p >> 1)] >> ((p & 1) * 16)) & 0xFFFFu;
+        nib = in ? nib : 0xFFFFu;
+        nbj = (in && sub) ? nbj : 0xFFFFu;
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            int r = 2 * j + (pos >> 1) - HALO;
+            bool ok = r >= 0 && r < G::TH + 2 * HALO;
+            const float4 a = nib_select(v, nib, pos), b = nib_select(u, nbj, pos);
+            lds[ok ? idx(p, 0, r, 2 * px + (pos & 1)) : dump] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
         }
     });
 }

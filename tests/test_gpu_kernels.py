@@ -592,7 +592,9 @@ def test_enc0_backward_with_mix_backward_equals_two_launches(ctx, inject, wgrad)
     _lib.call("cgs_enc0_bwd_mix", n_a, int(inject), P(mixed) if wgrad else None, P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, None,
               P(dz), P(slab), st)
     torch.cuda.synchronize()
-    assert torch.equal(dz, dz_ref)
+    # one data-gradient pass over the DIFFERENCE tile (conv_bwd_both.hip DEnc0D): same sums in another order
+    scale = float(dz_ref.abs().max()) + 1e-30
+    assert float((dz - dz_ref).abs().max()) <= 2e-5 * scale, float((dz - dz_ref).abs().max()) / scale
     if wgrad:
         assert torch.equal(slab, s_ref)
     assert lib.cgs_enc0_bwd_mix(n_a, 1, P(mixed), P(dy), P(am), w, P(A), P(B), P(Z), l1s, l2s, None, P(dz), None, st) < 0
