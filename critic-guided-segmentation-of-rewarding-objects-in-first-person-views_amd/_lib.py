@@ -87,6 +87,15 @@ SIGNATURES = {
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
+    "cgs_gen_flip_weights": (i32, [i32, i32, vp, vp, vp]),
+    "cgs_gen_conv3x3_bwd_data": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "cgs_gen_conv3x3_bwd_weight_slabs": (i32, [i32, i32, i32, i32]),
+    "cgs_gen_conv3x3_bwd_weight": (i32, [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen_cat_split": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "cgs_gen_grad_fix": (i32, [i64, vp, vp, i32, f32, vp, i64, Dropout, vp]),
+    "cgs_gen_dropout_fwd": (i32, [i64, vp, vp, Dropout, vp]),
+    "cgs_gen_gemm_ex": (i32, [i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i32, f32, i32, vp, vp]),
+    "cgs_gen_u8_to_f32": (i32, [i64, vp, vp, vp]),
     "cgs_gen_convt4s2_fwd": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_data": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -16,13 +16,12 @@ struct ConvParams {
     const float* a_post;
     const float* w2;       // SRC_DH: masker.2 weights [9][16]
     float* dh_out;         // SRC_DH: gradient w.r.t. the masker.0 output, written for the weight-gradient kernel
-    float* stash;          // STASH configs: LDS array [4 pixels x OCB][THREADS] that receives d_a instead of memory
-    // STASH configs, mix backward (conv_bwd_both.hip): phase 1 = keep d_a (injected image) in the stash; phase 2 = d_a is the
-    // replaced image's gradient: combine with the stash and write d(pre-sigmoid mask) of A-image q.n
+    // MIX_EPI configs, mix backward (conv_bwd_both.hip): the source tile is dY(replaced) - dY(injected), so d_a is
+    // d_rep - d_inj of A-image q.n; the epilogue turns it into d(pre-sigmoid mask) and nothing else is written
     const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z; float* mix_dz;
     float mix_l1s, mix_l2s;
     const float* mix_vf_pred;   // -staticnorm '' (main.py:415-418): the mask regulariser of A-image n is weighted by 1 - pred[n] (NULL: 1)
-    int mix_phase, mix_inject;
+    int mix_inject;
     int mix_n_a;           // SRC_MIXC3: number of A-images (mix image n >= mix_n_a is the injected one of n - mix_n_a)
     float* zpart;          // masker.2 forward: optional per-workgroup partial sums (sum |z|, sum z^2) for the L1 / L2 mask losses
     int n, n_addend;
@@ -31,10 +30,10 @@ struct ConvParams {
 
 enum { EPI_POOL = 0, EPI_PLAIN = 1, EPI_DGRAD = 2 };
 
-// optional config member: static constexpr bool STASH = true -> the data gradient w.r.t. source A stays on chip
-// (ConvParams::stash) for a following stage of the same workgroup (conv_bwd_both.hip: features.0 + mix backward)
-template <class C, class = void> struct stash_of { static constexpr bool value = false; };
-template <class C> struct stash_of<C, decltype((void)C::STASH)> { static constexpr bool value = C::STASH; };
+// optional config member: static constexpr bool MIX_EPI = true -> the data gradient w.r.t. source A stays in registers and
+// the epilogue writes the mix backward's d(pre-sigmoid mask) instead (conv_bwd_both.hip: features.0 + mix backward)
+template <class C, class = void> struct mix_epi_of { static constexpr bool value = false; };
+template <class C> struct mix_epi_of<C, decltype((void)C::MIX_EPI)> { static constexpr bool value = C::MIX_EPI; };
 
 // Cfg members: H,W,THREADS, SRC, CA, CB, UPS, WT (0 normal / 1 transposed), WCI, WCO (HWIO dims),
 // OC0, OC (logical output channel window), OCB (register block), EPI, ACT, OUT_A (dgrad: channels that
@@ -182,7 +181,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
         const int oc0 = C::OC0 + ch * C::OCB;
         if constexpr (C::EPI == EPI_DGRAD) {  // skip gradients nobody asked for (uniform branch)
             const bool is_a = oc0 < C::OUT_A;
-            if (is_a ? (P.out == nullptr && !stash_of<C>::value) : (P.out2 == nullptr)) continue;
+            if (is_a ? (P.out == nullptr && !mix_epi_of<C>::value) : (P.out2 == nullptr)) continue;
         }
         float acc[4][C::OCB];
 #pragma unroll
@@ -303,16 +302,14 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
             if (is_a) {
                 constexpr int CAO = C::OUT_A;  // channels per pixel of d_a
                 if (live) {
-                    // STASH phase 2: the quad's 2 x 6 frame bytes per row as one dword + one ushort (2-byte aligned), z per pixel
+                    // MIX_EPI: the quad's 2 x 6 frame bytes per row as one dword + one ushort (2-byte aligned), z per pixel
                     uint64_t a6[2] = {0, 0}, b6[2] = {0, 0};
-                    if constexpr (stash_of<C>::value) {
-                        if (P.mix_phase != 1) {
+                    if constexpr (mix_epi_of<C>::value) {
 #pragma unroll
-                            for (int r = 0; r < 2; ++r) {
-                                const size_t off = ((size_t)(q.n * G::H + y0 + r) * G::W + x0) * 3;
-                                a6[r] = (uint64_t)*(const uint32_t*)(P.mix_a + off) | ((uint64_t)*(const uint16_t*)(P.mix_a + off + 4) << 32);
-                                b6[r] = (uint64_t)*(const uint32_t*)(P.mix_b + off) | ((uint64_t)*(const uint16_t*)(P.mix_b + off + 4) << 32);
-                            }
+                        for (int r = 0; r < 2; ++r) {
+                            const size_t off = ((size_t)(q.n * G::H + y0 + r) * G::W + x0) * 3;
+                            a6[r] = (uint64_t)*(const uint32_t*)(P.mix_a + off) | ((uint64_t)*(const uint16_t*)(P.mix_a + off + 4) << 32);
+                            b6[r] = (uint64_t)*(const uint32_t*)(P.mix_b + off) | ((uint64_t)*(const uint16_t*)(P.mix_b + off + 4) << 32);
                         }
                     }
 #pragma unroll
@@ -341,33 +338,26 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
 #pragma unroll
                             for (int o = 0; o < C::OCB; ++o) v[o] += ad[o];
                         }
-                        if constexpr (stash_of<C>::value) {
-                            static_assert(NCHUNK == 1 && C::CW == 1 && C::OCB == 3, "one 3-channel chunk per thread");
-                            if (P.mix_phase == 1) {
+                        if constexpr (mix_epi_of<C>::value) {
+                            static_assert(NCHUNK == 1 && C::CW == 1 && C::OCB == 3 && C::SRC == SRC_POOLEXP_DIFF, "one 3-channel chunk per thread");
+                            // dzpre = [ sum_c (B - A)(d_rep - d_inj) + l1s sign(z) + 2 l2s z ] z (1 - z)   (= cgs_mix_bwd)
+                            const float s255 = 1.f / 255.f;
+                            float dsum = 0.f;
 #pragma unroll
-                                for (int o = 0; o < C::OCB; ++o) P.stash[(i * C::OCB + o) * C::THREADS + qtid] = v[o];
-                            } else {
-                                // dzpre = [ sum_c (B - A)(d_rep - d_inj) + l1s sign(z) + 2 l2s z ] z (1 - z)   (= cgs_mix_bwd)
-                                const float s255 = 1.f / 255.f;
-                                float dsum = 0.f;
-#pragma unroll
-                                for (int o = 0; o < 3; ++o) {
-                                    const int sh = 8 * (3 * (i & 1) + o);
-                                    const float av = (float)((a6[i >> 1] >> sh) & 255) * s255, bv = (float)((b6[i >> 1] >> sh) & 255) * s255;
-                                    float di = 0.f;      // (SRC_POOLEXP_DIFF: v is already d_rep - d_inj)
-                                    if constexpr (C::SRC != SRC_POOLEXP_DIFF) di = P.mix_inject ? P.stash[(i * 3 + o) * C::THREADS + qtid] : 0.f;
-                                    dsum = fmaf(bv - av, v[o] - di, dsum);
-                                }
-                                const float zi = P.mix_z[pix];
-                                const float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
-                                if (P.mix_vf_pred) {      // valuefak = 1 - pred (>= 0) weights |z| and, squared, z^2
-                                    const float vf = 1.f - P.mix_vf_pred[q.n];
-                                    dsum += P.mix_l1s * vf * sg + 2.f * P.mix_l2s * vf * vf * zi;
-                                } else {                  // (the same expression as cgs_mix_bwd: bit-identical results)
-                                    dsum += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;
-                                }
-                                P.mix_dz[pix] = dsum * zi * (1.f - zi);
+                            for (int o = 0; o < 3; ++o) {
+                                const int sh = 8 * (3 * (i & 1) + o);
+                                const float av = (float)((a6[i >> 1] >> sh) & 255) * s255, bv = (float)((b6[i >> 1] >> sh) & 255) * s255;
+                                dsum = fmaf(bv - av, v[o], dsum);
                             }
+                            const float zi = P.mix_z[pix];
+                            const float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
+                            if (P.mix_vf_pred) {      // valuefak = 1 - pred (>= 0) weights |z| and, squared, z^2
+                                const float vf = 1.f - P.mix_vf_pred[q.n];
+                                dsum += P.mix_l1s * vf * sg + 2.f * P.mix_l2s * vf * vf * zi;
+                            } else {                  // (the same expression as cgs_mix_bwd)
+                                dsum += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;
+                            }
+                            P.mix_dz[pix] = dsum * zi * (1.f - zi);
                         } else {
                             float* dst = P.out + pix * CAO + oc0;
                             if constexpr (C::OCB % 4 == 0) {

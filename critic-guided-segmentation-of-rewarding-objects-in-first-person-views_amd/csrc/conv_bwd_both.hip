@@ -116,21 +116,16 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// features.0 backward of the replaced / injected passes TOGETHER with the mix backward (main.py:395,406 backward):
-// a data-gradient workgroup takes the same strip of replaced image i and of injected image i one after the other,
-// keeps the first image gradient on chip (LDS stash) and writes d(pre-sigmoid mask) from the second pass's epilogue:
+// features.0 backward of the replaced / injected passes TOGETHER with the mix backward (main.py:395,406 backward).
+// The data gradient of a convolution is linear in dY and the mix backward only needs d_rep - d_inj, so a data-gradient
+// workgroup builds ONE gradient tile = expand(dY_rep) - expand(dY_inj) of its strip (conv_tile.h load_poolexp_diff), runs one
+// data-gradient pass and writes d(pre-sigmoid mask) from the epilogue:
 //   dzpre = [ sum_c (B - A) (d_rep - d_inj) + l1s sign(z) + 2 l2s z ] z (1 - z)
-// so the 2 x 25 MB image gradients are never stored and cgs_mix_bwd's pass over them disappears.  The weight-gradient
-// workgroups of features.0 (over all mixes) share the launch as in conv_bwd_both_kernel.  Bit-identical to the two-launch
-// form (same data-gradient code, same arithmetic order in the mix part).
+// so the 2 x 25 MB image gradients are never stored, cgs_mix_bwd's pass over them disappears and half of the two passes'
+// FMAs are never issued.  The weight-gradient workgroups of features.0 (over all mixes) share the launch as in
+// conv_bwd_both_kernel (bit-identical to it); dzpre equals the two-launch form up to the order of the sums.
 // ------------------------------------------------------------------------------------------------
-struct DEnc0S : DEnc0 { static constexpr bool STASH = true; };
-// one pass over the DIFFERENCE of the replaced and the injected image's gradient tiles (conv_tile.h load_poolexp_diff)
-struct DEnc0D : DEnc0 { static constexpr bool STASH = true; static constexpr int SRC = SRC_POOLEXP_DIFF; };
-static bool enc0_diff() {
-    static const bool on = [] { const char* e = std::getenv("CGS_ENC0_DIFF"); return !(e && e[0] == '0'); }();
-    return on;
-}
+struct DEnc0D : DEnc0 { static constexpr bool MIX_EPI = true; static constexpr int SRC = SRC_POOLEXP_DIFF; };
 struct MixBwdArgs {
     const uint8_t* a; const uint8_t* b; const float* z; float* dzpre;
     int n_a, inject;
@@ -139,7 +134,7 @@ struct MixBwdArgs {
 };
 
 template <class CWG>
-__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, int stash_off, int diff) {
+__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw) {
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -149,22 +144,10 @@ __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvP
         return;
     }
     const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
-    pd.stash = (float*)smem + stash_off;                 // [4 pixels x 3 channels][256 threads]
     pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
-    if (diff) {      // linear in dY: conv_bwd(dY_rep - dY_inj) in ONE pass (half the FMAs of the two-pass form; sums in another order)
-        pd.mix_phase = 2;
-        pd.mix_n_a = M.n_a;
-        conv3x3_body<DEnc0D, true>(pd, img * G::STRIPS + strip, smem);
-        return;
-    }
-    if (M.inject) {
-        pd.mix_phase = 1;                                // injected image: gradient to the stash
-        conv3x3_body<DEnc0S, true>(pd, (M.n_a + img) * G::STRIPS + strip, smem);
-        __syncthreads();                                 // everybody is done with the first pass's tiles
-    }
-    pd.mix_phase = 2;                                    // replaced image: combine, write dzpre of A-image `img`
-    conv3x3_body<DEnc0S, true>(pd, img * G::STRIPS + strip, smem);
+    pd.mix_n_a = M.n_a;
+    conv3x3_body<DEnc0D, true>(pd, img * G::STRIPS + strip, smem);
 }
 
 extern "C" int cgs_enc0_bwd_mix_slabs(int32_t n_mix) { return n_mix < 0 ? CGS_ERR_BADARG : both_slabs<WEnc0F32>(n_mix); }
@@ -188,15 +171,11 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
     const int nbd = n_a * GD::STRIPS;
     size_t lw = wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
-    size_t base = lw > ld ? lw : ld;
-    base = (base + 15) / 16 * 16;
-    const size_t lds = base + 12 * 256 * sizeof(float);      // 41 KB tiles + 12 KB stash: three workgroups per CU
+    const size_t lds = lw > ld ? lw : ld;                    // 41 KB: three workgroups per CU
     if (mixed || !slab)        // materialised mixes (or no weight gradient at all)
-        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0F32>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
-                           (int)(base / sizeof(float)), (int)enc0_diff());
+        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0F32>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
     else                       // weight-gradient input = the mixes recomputed from a, b, z in the tile loader
-        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0Mix>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw,
-                           (int)(base / sizeof(float)), (int)enc0_diff());
+        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0Mix>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

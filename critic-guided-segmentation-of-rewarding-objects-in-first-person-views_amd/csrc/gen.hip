@@ -10,25 +10,18 @@
 //   gen_gemm        : out[n][N] = act(X[n][K] W[K][N] + b): the 4x4 valid convolution at the bottleneck, the Linear layers,
 //                     the 1x1 convolution, ConvTranspose2d(4,1,0) on a 1x1 map.
 //   gen_convt4s2_*  : ConvTranspose2d(4, 2, 1) over cat(A, B): forward, data gradient, weight gradient (direct form).
-#include "tail_common.h"
+#include "gen_common.h"
 
 namespace {
 
 struct GenConvParams {
-    const void* src_a; const float* src_b; const float* w; const float* bias;
+    GenSrc src; const float* w; const float* bias;      // bias may be NULL (data gradient)
     float* out; uint8_t* argmax;
-    int n, hw, ca, cb, co, a_u8, ups, act, pool, th;
+    const float* addend; int n_addend;                  // pool = 0: out += addend for images < n_addend (same shape as out)
+    int n, hw, co, act, pool, th;
     float slope;
 };
 
-__device__ __forceinline__ float gen_act(float v, int act, float slope) {
-    if (act == CGS_ACT_RELU) return v > 0.f ? v : 0.f;
-    if (act == CGS_ACT_LRELU) return v > 0.f ? v : slope * v;
-    if (act == CGS_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
-    return v;
-}
-
-constexpr int GEN_KC = 16;            // input channels staged per chunk
 constexpr int GEN_MAX_TPW = 4;        // pixel tiles (16 pixels) per wave: strips hold <= 256 pixels
 
 // grid: ((image * strips + strip) * column blocks + column block); 256 threads
@@ -40,7 +33,8 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
     const int strips = H / TH, ncb = (P.co + 15) / 16;
     const int cbi = blockIdx.x % ncb, strip = (blockIdx.x / ncb) % strips, img = blockIdx.x / (ncb * strips);
     const int row0 = strip * TH;
-    const int pa4 = (P.ca + 3) & ~3, cp = pa4 + P.cb, ci_total = P.ca + P.cb;
+    const GenSrc& S = P.src;
+    const int cp = gen_pa4(S) + S.cb, ci_total = S.ca + S.cb;
     const int nchunk = (cp + GEN_KC - 1) / GEN_KC;
     const int col = cbi * 16 + l15;
     const int ntiles = TH * W / 16, QW = W / 2;
@@ -55,41 +49,9 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
         const int y = 2 * qy + ((l15 >> 1) & 1), x = 2 * qx + (l15 & 1);     // strip-local
         abase[i] = (y * PW + x) * GEN_KC + kq;
     }
-    const int su = P.ups, HB = H / su, WB = W / su;
 
     for (int ch = 0; ch < nchunk; ++ch) {
-        // ---- stage 16 channels of the strip (with halo) ----
-        const int ngrp = (TH + 2) * PW * (GEN_KC / 4);
-        for (int e = tid; e < ngrp; e += 256) {
-            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
-            const int y = row0 + r - 1, x = c - 1, k0 = ch * GEN_KC + 4 * g;
-            float4 v = f4zero();
-            if (y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
-                if (k0 < pa4) {
-                    const size_t pix = ((size_t)img * H + y) * W + x;
-                    if (P.a_u8) {
-                        const uint8_t* s = (const uint8_t*)P.src_a + pix * P.ca + k0;
-                        const float sc = 1.f / 255.f;
-                        v.x = s[0] * sc;
-                        if (k0 + 1 < P.ca) v.y = s[1] * sc;
-                        if (k0 + 2 < P.ca) v.z = s[2] * sc;
-                        if (k0 + 3 < P.ca) v.w = s[3] * sc;
-                    } else if ((P.ca & 3) == 0) {
-                        v = *(const float4*)((const float*)P.src_a + pix * P.ca + k0);
-                    } else {
-                        const float* s = (const float*)P.src_a + pix * P.ca + k0;
-                        v.x = s[0];
-                        if (k0 + 1 < P.ca) v.y = s[1];
-                        if (k0 + 2 < P.ca) v.z = s[2];
-                        if (k0 + 3 < P.ca) v.w = s[3];
-                    }
-                } else {
-                    const size_t pixb = ((size_t)img * HB + y / su) * WB + x / su;
-                    v = *(const float4*)(P.src_b + pixb * P.cb + (k0 - pa4));
-                }
-            }
-            *(float4*)(tile + (size_t)px * GEN_KC + 4 * g) = v;
-        }
+        gen_stage(tile, S, img, H, W, row0, TH, 1, ch, tid);      // 16 channels of the strip (with halo)
         __syncthreads();
         // ---- 9 taps x 4 k-steps; the weight operand of a k-step is shared by the wave's pixel tiles ----
 #pragma unroll 1
@@ -98,8 +60,7 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
             float b[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int k = ch * GEN_KC + 4 * s + kq;                 // padded channel index
-                const int ci = k < pa4 ? (k < P.ca ? k : -1) : (k < cp ? P.ca + (k - pa4) : -1);
+                const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
                 b[s] = (ci >= 0 && col < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col] : 0.f;
             }
 #pragma unroll
@@ -115,7 +76,7 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
     }
     // ---- epilogue ----
     if (col < P.co) {
-        const float bias = P.bias[col];
+        const float bias = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < GEN_MAX_TPW; ++i) {
             const int t = wave + 4 * i;
@@ -131,12 +92,16 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
                 }
                 const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
                 P.out[pp] = m;
-                if (P.argmax) P.argmax[pp] = (uint8_t)idx;
+                // (ReLU: a pooled value <= 0 passes no gradient -- marked in bit 2 for the backward loaders)
+                if (P.argmax) P.argmax[pp] = (uint8_t)(idx | ((P.act == CGS_ACT_RELU && !(m > 0.f)) ? 4 : 0));
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
-                    P.out[(((size_t)img * H + y) * W + x) * P.co + col] = gen_act(acc[i][j] + bias, P.act, P.slope);
+                    const size_t o = (((size_t)img * H + y) * W + x) * P.co + col;
+                    float v = gen_act(acc[i][j] + bias, P.act, P.slope);
+                    if (P.addend && img < P.n_addend) v += P.addend[o];
+                    P.out[o] = v;
                 }
             }
         }
@@ -268,23 +233,44 @@ __global__ void __launch_bounds__(256) gen_convt_bwd_weight_kernel(GenConvTParam
 
 }  // namespace
 
+static int gen_conv_launch(GenConvParams P, cgs_stream_t stream) {
+    P.th = gen_strip_rows(P.hw);
+    const int ncb = (P.co + 15) / 16, strips = P.hw / P.th;
+    const size_t lds = (size_t)(P.th + 2) * (P.hw + 2) * GEN_KC * sizeof(float);
+    hipLaunchKernelGGL(gen_conv3x3_fwd_kernel, dim3(P.n * strips * ncb), dim3(256), lds, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                    int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* w,
                                    const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
     if (n < 0 || !src_a || !w || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
     if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
-    if (hw != 4 && hw != 8 && hw != 16 && hw != 32 && hw != 64) return CGS_ERR_UNSUPPORTED;
+    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    int th = 256 / hw;                       // strips of <= 256 pixels
-    if (th > hw) th = hw;
-    if (th < 2) th = 2;
-    GenConvParams P{src_a, src_b, w, bias, out, argmax, n, hw, ca, cb, co, a_is_u8, cb > 0 ? ups : 1, act, pool, th, slope};
-    const int ncb = (co + 15) / 16, strips = hw / th;
-    const size_t lds = (size_t)(th + 2) * (hw + 2) * GEN_KC * sizeof(float);
-    hipLaunchKernelGGL(gen_conv3x3_fwd_kernel, dim3(n * strips * ncb), dim3(256), lds, (hipStream_t)stream, P);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
+    GenConvParams P{};
+    P.src = GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1};
+    P.w = w; P.bias = bias; P.out = out; P.argmax = argmax;
+    P.n = n; P.hw = hw; P.co = co; P.act = act; P.pool = pool; P.slope = slope;
+    return gen_conv_launch(P, stream);
+}
+
+// Data gradient of a 3x3 layer = the same convolution over the output gradient with the flipped, transposed kernel
+// (cgs_gen_flip_weights): d_cat [n,hw,hw,ci] = conv3x3(dY, wflip [9][co][ci]) (+ addend for images < n_addend).
+extern "C" int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, const float* dy, const uint8_t* dy_argmax,
+                                        const float* wflip, const float* addend, int32_t n_addend, float* d_cat,
+                                        cgs_stream_t stream) {
+    if (n < 0 || !dy || !wflip || !d_cat || co <= 0 || ci <= 0 || n_addend < 0) return CGS_ERR_BADARG;
+    if (dy_argmax && (co & 3)) return CGS_ERR_BADARG;
+    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return CGS_OK;
+    GenConvParams P{};
+    P.src = GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1};
+    P.w = wflip; P.out = d_cat; P.addend = addend; P.n_addend = n_addend;
+    P.n = n; P.hw = hw; P.co = ci; P.act = CGS_ACT_NONE;
+    return gen_conv_launch(P, stream);
 }
 
 extern "C" int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,

@@ -1,0 +1,304 @@
+// Training pass of the shape-generic family (chfak != 1: the paper's model is chfak = 5, docs/index.html:151, nets.py:166,184,190):
+// what the backward of NewCritic.forward / UnetDecoder.forward (nets.py:197-212, 494-523) needs besides the forward kernel of
+// gen.hip -- the data gradient of a 3x3 layer IS that kernel over the output gradient with flipped weights (cgs_gen_conv3x3_bwd_data).
+//
+//   gen_conv3x3_wgrad : dW[tap][ci][co] = sum over images, pixels of in[p + tap][ci] dY[p][co] (+ dbias) as an MFMA GEMM with the
+//                       pixels as the K dimension: persistent workgroups own a (16 input channels x 16 output channels) block for
+//                       all nine taps and a share of the images; one slab row per image share, summed by cgs_reduce_slabs.
+//   gen_flip_weights  : HWIO [tap][ci][co] -> [8 - tap][co][ci] (the data-gradient kernel's weight operand).
+//   gen_cat_split     : gradient of cat(A, nearest-up(B)): channels [0,ca) -> d_a, channels [ca,ca+cb) summed over the cells -> d_b.
+//   gen_grad_fix      : d = (d * dropout mask + addend) * act'(saved output): the element-wise steps between two layers.
+//   gen_dropout_fwd   : out = x * keep-mask / (1 - p)  (nets.py:179,183,192).
+//   gen_gemm_ex       : out[m][n] (+)= act(sum_k A(m,k) B(k,n) + bias[n]) with free strides (Linear layers, their data and weight
+//                       gradients: X W^T, X^T dY, column sums through a ones vector).
+//   gen_u8_to_f32     : frames / 255 (the weight gradient of features.0 reads A and the mixes from one fp32 buffer).
+#include "gen_common.h"
+
+namespace {
+
+struct GenWgradParams {
+    GenSrc in;          // the layer's input cat(A, up(B))
+    GenSrc dy;          // gradient at the pre-activation output: GEN_SRC_F32 [n,hw,hw,co] or GEN_SRC_POOLEXP (dE + argmax); ca = co
+    float* slab;        // [G][9 * ci_total * co + co]
+    int n, hw, th, G, ncib, ncob;
+};
+
+// grid: (image share g, input-channel block, output-channel block); 256 threads = 4 waves that split the pixel groups
+__global__ void __launch_bounds__(256) gen_conv3x3_wgrad_kernel(GenWgradParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
+    float* tin = (float*)gsm;                                  // [(TH + 2)][(W + 2)][16]
+    float* tdy = tin + (TH + 2) * PW * GEN_KC;                 // [TH][W][16]
+    const int cob = blockIdx.x % P.ncob, cib = (blockIdx.x / P.ncob) % P.ncib, g = blockIdx.x / (P.ncob * P.ncib);
+    const int co = P.dy.ca, ci_total = P.in.ca + P.in.cb;
+    const int ngroups = TH * W / 4, strips = H / TH;
+
+    frag4 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = frag4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    for (int img = g; img < P.n; img += P.G) {
+        for (int strip = 0; strip < strips; ++strip) {
+            gen_stage(tin, P.in, img, H, W, strip * TH, TH, 1, cib, tid);
+            gen_stage(tdy, P.dy, img, H, W, strip * TH, TH, 0, cob, tid);
+            __syncthreads();
+            for (int grp = wave; grp < ngroups; grp += 4) {
+                const int p0 = 4 * grp, y = p0 / W, x = p0 % W;          // 4 consecutive pixels of one row = the K slice
+                const float b = tdy[(p0 + kq) * GEN_KC + l15];
+                bsum += b;
+                const float* ap = tin + ((size_t)(y * PW + x + kq)) * GEN_KC + l15;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[((t / 3) * PW + t % 3) * GEN_KC], b, acc[t], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- the four waves' partial blocks summed through LDS (fixed order), then the slab row ----
+    float* red = (float*)gsm;                                  // [3 waves][37][64]
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((wave - 1) * 37 + 4 * t + j) * 64 + lane] = acc[t][j];
+        red[((wave - 1) * 37 + 36) * 64 + lane] = bsum;
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][j] += red[(w * 37 + 4 * t + j) * 64 + lane];
+            bsum += red[(w * 37 + 36) * 64 + lane];
+        }
+        const int col = cob * 16 + l15;
+        float* row = P.slab + (size_t)g * (9 * ci_total * co + co);
+        if (col < co) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = gen_real_channel(P.in, cib * GEN_KC + 4 * kq + j);
+                if (ci < 0) continue;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) row[((size_t)t * ci_total + ci) * co + col] = acc[t][j];
+            }
+        }
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (cib == 0 && kq == 0 && col < co) row[(size_t)9 * ci_total * co + col] = bsum;
+    }
+}
+
+__global__ void __launch_bounds__(256) gen_flip_weights_kernel(const float* __restrict__ w, int ci, int co, float* __restrict__ out) {
+    const int total = 9 * ci * co;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e % ci, c = (e / ci) % co, tap = e / (ci * co);
+        out[e] = w[((size_t)(8 - tap) * ci + i) * co + c];
+    }
+}
+
+struct GenSplitParams {
+    const float* dcat; float* d_a; float* d_b;
+    int n, hw, ca, cb, ups;
+};
+
+__global__ void __launch_bounds__(256) gen_cat_split_kernel(GenSplitParams P) {
+    const int ct = P.ca + P.cb, hb = P.hw / P.ups;
+    const size_t na = P.d_a ? (size_t)P.n * P.hw * P.hw * P.ca : 0, nb = P.d_b ? (size_t)P.n * hb * hb * P.cb : 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < na + nb; e += (size_t)gridDim.x * 256) {
+        if (e < na) {
+            const size_t pix = e / P.ca;
+            P.d_a[e] = P.dcat[pix * ct + e % P.ca];
+        } else {
+            const size_t f = e - na;
+            const int c = f % P.cb, xb = (f / P.cb) % hb, yb = (f / ((size_t)P.cb * hb)) % hb, img = f / ((size_t)P.cb * hb * hb);
+            float s = 0.f;
+            for (int dy = 0; dy < P.ups; ++dy)
+                for (int dx = 0; dx < P.ups; ++dx)
+                    s += P.dcat[(((size_t)img * P.hw + yb * P.ups + dy) * P.hw + xb * P.ups + dx) * ct + P.ca + c];
+            P.d_b[f] = s;
+        }
+    }
+}
+
+struct GenFixParams {
+    float* d; const float* saved; const float* addend;
+    long count, addend_count;
+    int act; float slope;
+    cgs_dropout drop;
+};
+
+__device__ __forceinline__ float gen_act_grad(float out, int act, float slope) {
+    if (act == CGS_ACT_RELU) return out > 0.f ? 1.f : 0.f;
+    if (act == CGS_ACT_LRELU) return out > 0.f ? 1.f : slope;
+    if (act == CGS_ACT_SIGMOID) return out * (1.f - out);
+    return 1.f;
+}
+
+// one thread per 4 consecutive floats (the dropout stream's unit)
+__global__ void __launch_bounds__(256) gen_grad_fix_kernel(GenFixParams P) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (4 * i4 >= P.count) return;
+    const DropCtx dc = drop_ctx(P.drop);
+    const float4 m = dc.on ? drop_mult4(dc, (uint32_t)i4) : make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = 4 * i4 + k;
+        if (i >= P.count) break;
+        float v = P.d[i] * f4get(m, k);
+        if (P.addend && i < P.addend_count) v += P.addend[i];
+        if (P.saved) v *= gen_act_grad(P.saved[i], P.act, P.slope);
+        P.d[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256) gen_dropout_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ out, long count4,
+                                                              cgs_dropout d) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    const DropCtx dc = drop_ctx(d);
+    out[i] = dc.on ? x[i] * drop_mult4(dc, (uint32_t)i) : x[i];
+}
+
+__global__ void __launch_bounds__(256) gen_u8_to_f32_kernel(const uint8_t* __restrict__ x, float* __restrict__ out, long count) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) out[i] = x[i] * (1.f / 255.f);
+}
+
+struct GenGemmExParams {
+    const float* x; const float* w; const float* bias; float* out;
+    int m, k, n, act, accumulate;
+    long sxm, sxk, swk, swn;
+    float slope;
+};
+
+// one wave per 16 x 16 output tile; A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn]
+__global__ void __launch_bounds__(64) gen_gemm_ex_kernel(GenGemmExParams P) {
+    const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
+    const int ntn = (P.n + 15) / 16;
+    const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
+    const int row = m0 + l15, col = n0 + l15;
+    const float* xr = P.x + (size_t)(row < P.m ? row : 0) * P.sxm;
+    const float* wc = P.w + (size_t)(col < P.n ? col : 0) * P.swn;
+    frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < P.k; k0 += 4) {
+        const int k = k0 + kq;
+        const float a = (row < P.m && k < P.k) ? xr[(size_t)k * P.sxk] : 0.f;
+        const float b = (col < P.n && k < P.k) ? wc[(size_t)k * P.swk] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    if (col < P.n) {
+        const float bias = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m0 + 4 * kq + j;
+            if (r < P.m) {
+                float* o = P.out + (size_t)r * P.n + col;
+                const float v = gen_act(acc[j] + bias, P.act, P.slope);
+                *o = P.accumulate ? *o + v : v;
+            }
+        }
+    }
+}
+
+int ew_blocks(size_t items) { size_t b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
+
+}  // namespace
+
+static int wgrad_groups(int n, int ncib, int ncob) {      // image shares: about 1024 workgroups in flight, at most one per image
+    int g = 1024 / (ncib * ncob);
+    if (g < 1) g = 1;
+    if (g > 64) g = 64;
+    return g < n ? g : n;
+}
+
+extern "C" int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co) {
+    if (n < 0 || ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
+    if (n == 0) return 0;
+    const int cp = ((ca + 3) & ~3) + cb;
+    return wgrad_groups(n, (cp + 15) / 16, (co + 15) / 16);
+}
+
+extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                          const void* src_a, const float* src_b, const float* dy, const uint8_t* dy_argmax,
+                                          float* slab, cgs_stream_t stream) {
+    if (n < 0 || !src_a || !dy || !slab || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
+    if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
+    if (dy_argmax && (co & 3)) return CGS_ERR_BADARG;
+    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return CGS_OK;
+    GenWgradParams P{};
+    P.in = GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1};
+    P.dy = GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1};
+    P.slab = slab; P.n = n; P.hw = hw; P.th = gen_strip_rows(hw);
+    const int cp = ((ca + 3) & ~3) + cb;
+    P.ncib = (cp + 15) / 16; P.ncob = (co + 15) / 16;
+    P.G = wgrad_groups(n, P.ncib, P.ncob);
+    size_t lds = ((size_t)(P.th + 2) * (hw + 2) + (size_t)P.th * hw) * GEN_KC * sizeof(float);
+    const size_t red = (size_t)3 * 37 * 64 * sizeof(float);
+    if (lds < red) lds = red;
+    hipLaunchKernelGGL(gen_conv3x3_wgrad_kernel, dim3(P.G * P.ncib * P.ncob), dim3(256), lds, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_flip_weights(int32_t ci, int32_t co, const float* w, float* wflip, cgs_stream_t stream) {
+    if (ci <= 0 || co <= 0 || !w || !wflip) return CGS_ERR_BADARG;
+    hipLaunchKernelGGL(gen_flip_weights_kernel, dim3(ew_blocks((size_t)9 * ci * co)), dim3(256), 0, (hipStream_t)stream, w, ci, co, wflip);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_cat_split(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t ups, const float* d_cat, float* d_a,
+                                 float* d_b, cgs_stream_t stream) {
+    if (n < 0 || hw <= 0 || ca < 0 || cb < 0 || !d_cat || (ups != 1 && ups != 2 && ups != 4) || hw % ups) return CGS_ERR_BADARG;
+    if ((d_a && ca == 0) || (d_b && cb == 0) || (!d_a && !d_b)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    GenSplitParams P{d_cat, d_a, d_b, n, hw, ca, cb, ups};
+    const size_t items = (d_a ? (size_t)n * hw * hw * ca : 0) + (d_b ? (size_t)n * (hw / ups) * (hw / ups) * cb : 0);
+    hipLaunchKernelGGL(gen_cat_split_kernel, dim3(ew_blocks(items)), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_grad_fix(int64_t count, float* d, const float* saved, int32_t act, float slope, const float* addend,
+                                int64_t addend_count, cgs_dropout drop, cgs_stream_t stream) {
+    if (count < 0 || !d || addend_count < 0 || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (count == 0) return CGS_OK;
+    GenFixParams P{d, saved, addend, (long)count, (long)addend_count, act, slope, drop};
+    const long c4 = (count + 3) / 4;
+    hipLaunchKernelGGL(gen_grad_fix_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_dropout_fwd(int64_t count, const float* x, float* out, cgs_dropout drop, cgs_stream_t stream) {
+    if (count < 0 || (count & 3) || !x || !out) return CGS_ERR_BADARG;
+    if (count == 0) return CGS_OK;
+    const long c4 = count / 4;
+    hipLaunchKernelGGL(gen_dropout_fwd_kernel, dim3((unsigned)((c4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)x, (float4*)out, c4, drop);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_u8_to_f32(int64_t count, const uint8_t* x, float* out, cgs_stream_t stream) {
+    if (count < 0 || !x || !out) return CGS_ERR_BADARG;
+    if (count == 0) return CGS_OK;
+    hipLaunchKernelGGL(gen_u8_to_f32_kernel, dim3(ew_blocks((size_t)count)), dim3(256), 0, (hipStream_t)stream, x, out, (long)count);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, int64_t sxm, int64_t sxk, const float* w,
+                               int64_t swk, int64_t swn, const float* bias, int32_t act, float slope, int32_t accumulate, float* out,
+                               cgs_stream_t stream) {
+    if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (m == 0) return CGS_OK;
+    GenGemmExParams P{x, w, bias, out, m, k, n, act, accumulate, (long)sxm, (long)sxk, (long)swk, (long)swn, slope};
+    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

@@ -27,62 +27,286 @@ def _p(t: Optional[torch.Tensor]):
 
 
 def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: int, co: int, act: str = "none",
-            slope: float = 0.01, pool: bool = False, ups: int = 2, want_argmax: bool = False):
-    """act(conv3x3(cat(a, up_ups(b))) + bias) (+ MaxPool2d(2)).  a: NHWC uint8 or fp32 [n,hw,hw,ca]; b: NHWC fp32 or None."""
+            slope: float = 0.01, pool: bool = False, ups: int = 2, want_argmax: bool = False, out: Optional[torch.Tensor] = None,
+            am: Optional[torch.Tensor] = None):
+    """act(conv3x3(cat(a, up_ups(b))) + bias) (+ MaxPool2d(2)).  a: NHWC uint8 or fp32 [n,hw,hw,ca]; b: NHWC fp32 or None.
+    out / am: optional preallocated outputs (am = the pooling argmax bytes, bit 2 set where a ReLU'd pooled value is <= 0)."""
     if not a.is_cuda or not a.is_contiguous() or a.dtype not in (torch.uint8, torch.float32):
         raise _lib.CgsError("generic conv: source A must be a contiguous uint8 / fp32 device tensor (no CPU fallback)")
     n, hw, ca = a.shape[0], a.shape[1], a.shape[3]
     cb = 0 if b is None else b.shape[-1]
     oh = hw // 2 if pool else hw
-    out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32)
-    am = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.uint8) if (pool and want_argmax) else None
+    if out is None:
+        out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32)
+    if am is None and pool and want_argmax:
+        am = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.uint8)
     _lib.call("cgs_gen_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], float(slope), int(pool), _p(a),
               _p(b), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _p(am), _s())
     return (out, am) if want_argmax else out
 
 
-def gemm(x: torch.Tensor, w_ptr: int, bias_ptr: int, k: int, n_out: int, act: str = "none", slope: float = 0.01) -> torch.Tensor:
+def gemm(x: torch.Tensor, w_ptr: int, bias_ptr: int, k: int, n_out: int, act: str = "none", slope: float = 0.01,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
     m = x.shape[0]
-    out = torch.empty((m, n_out), device=x.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((m, n_out), device=x.device, dtype=torch.float32)
     _lib.call("cgs_gen_gemm", m, k, n_out, _ACT[act], float(slope), _p(x), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _s())
     return out
 
 
-def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, chfak: int, neck: int = 32) -> Dict[str, torch.Tensor]:
-    """NewCritic.forward in eval mode (nets.py:197-212) for any chfak.  x: NHWC uint8 / fp32 [n,64,64,3].
-    Returns e0..e3 (NHWC), e4 [n,neck*chfak], h1, pred [n]."""
+def gemm_ex(m: int, k: int, n: int, x, sxm: int, sxk: int, w, swk: int, swn: int, out, bias=None, act: str = "none",
+            accumulate: bool = False):
+    """out [m,n] (+)= act(sum_k x[m sxm + k sxk] w[k swk + n swn] + bias); x / w / out / bias: tensors or raw device addresses."""
+    q = lambda t: t if isinstance(t, C.c_void_p) else (C.c_void_p(t) if isinstance(t, int) else _p(t))
+    _lib.call("cgs_gen_gemm_ex", m, k, n, q(x), sxm, sxk, q(w), swk, swn, q(bias), _ACT[act], 0.01, int(accumulate), q(out), _s())
+
+
+def grad_fix(d: torch.Tensor, saved: Optional[torch.Tensor] = None, act: str = "none", slope: float = 0.01,
+             addend: Optional[torch.Tensor] = None, drop: Optional[_lib.Dropout] = None):
+    """In place: d = (d * dropout multiplier + addend (on its leading elements)) * act'(saved output)."""
+    nd = drop if drop is not None else _lib.Dropout(0.0, 0, 0, None, 0, 0)
+    _lib.call("cgs_gen_grad_fix", d.numel(), _p(d), _p(saved), _ACT[act], float(slope), _p(addend),
+              0 if addend is None else addend.numel(), nd, _s())
+
+
+ENC_KEYS = ("features.0", "features.3", "features.6", "features.10")
+ENC_HW = (64, 32, 16, 8)
+DROP_SITE_E2, DROP_SITE_E3, DROP_SITE_H1 = 0, 1, 2       # the specialised engine's Philox sites (spec.py)
+
+
+def dims(chfak: int, neck: int = 32):
+    return [8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak], neck * chfak
+
+
+class NoDrop:
+    """Stand-in for hourglass.DropState with p = 0."""
+    p = 0.0
+
+    def desc(self, site, active=True, per_img4=0):
+        return _lib.Dropout(0.0, 0, 0, None, 0, 0)
+
+
+def critic_buffers(n: int, chfak: int, neck: int, dev, training: bool = False) -> Dict[str, torch.Tensor]:
+    """Activation buffers of n images: e0..e3 (pooled, pre-dropout), am0..am3, e4, h1, pred (+ e2d / e3d / h1d: the dropped tensors
+    the next layer consumed, kept for the weight gradients)."""
+    d, nb = dims(chfak, neck)
+    z = lambda *shape, dt=torch.float32: torch.zeros(shape, device=dev, dtype=dt)
+    o = {}
+    for i, hw in enumerate(ENC_HW):
+        o[f"e{i}"] = z(n, hw // 2, hw // 2, d[i])
+        o[f"am{i}"] = z(n, hw // 2, hw // 2, d[i], dt=torch.uint8)
+    o["e4"], o["h1"], o["pred"] = z(n, nb), z(n, nb), z(n)
+    if training:
+        o["e2d"], o["e3d"], o["h1d"] = z(n, 8, 8, d[2]), z(n, 4, 4, d[3]), z(n, nb)
+    return o
+
+
+def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, chfak: int, neck: int = 32,
+                   out: Optional[Dict[str, torch.Tensor]] = None, drop=None) -> Dict[str, torch.Tensor]:
+    """NewCritic.forward (nets.py:197-212) for any chfak.  x: NHWC uint8 / fp32 [n,64,64,3].  Eval mode unless `drop` (a
+    hourglass.DropState with p > 0) is given: Dropout then sits in front of features.10, features.14 and crit.4 as in the
+    reference (nets.py:179,183,192).  out: buffers from critic_buffers (allocated when omitted).
+    Returns e0..e3 (NHWC, before dropout), e4 [n,neck*chfak], h1, pred [n] (+ am*, e2d, e3d, h1d)."""
     fp = flat.data_ptr()
     off = lambda k: fp + 4 * lay.off(k)
-    dims = [8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
-    nb = neck * chfak
-    o, src = {}, x
-    for i, (key, co) in enumerate(zip(("features.0", "features.3", "features.6", "features.10"), dims)):
-        src = o[f"e{i}"] = conv3x3(src, None, off(key + ".weight"), off(key + ".bias"), co, act="relu", pool=True)
+    d, nb = dims(chfak, neck)
     n = x.shape[0]
-    e3 = o["e3"].reshape(n, 16 * dims[3])
-    o["e4"] = gemm(e3, off("features.14.weight"), off("features.14.bias"), 16 * dims[3], nb, act="relu")
-    o["h1"] = gemm(o["e4"], off("crit.1.weight"), off("crit.1.bias"), nb, nb, act="relu")
-    o["pred"] = gemm(o["h1"], off("crit.4.weight"), off("crit.4.bias"), nb, 1, act="sigmoid").reshape(n)
+    training = drop is not None and drop.p > 0.0
+    o = out if out is not None else critic_buffers(n, chfak, neck, x.device, training)
+    src = x
+    for i, (key, co) in enumerate(zip(ENC_KEYS, d)):
+        conv3x3(src, None, off(key + ".weight"), off(key + ".bias"), co, act="relu", pool=True, out=o[f"e{i}"], am=o[f"am{i}"])
+        src = o[f"e{i}"]
+        if training and i >= 2:
+            dst = o["e2d" if i == 2 else "e3d"]
+            _lib.call("cgs_gen_dropout_fwd", src[:n].numel(), _p(src), _p(dst),
+                      drop.desc(DROP_SITE_E2 if i == 2 else DROP_SITE_E3, True, src[0].numel() // 4), _s())
+            src = dst
+    gemm(src.reshape(n, 16 * d[3]), off("features.14.weight"), off("features.14.bias"), 16 * d[3], nb, act="relu", out=o["e4"])
+    gemm(o["e4"], off("crit.1.weight"), off("crit.1.bias"), nb, nb, act="relu", out=o["h1"])
+    h = o["h1"]
+    if training:
+        _lib.call("cgs_gen_dropout_fwd", n * nb, _p(h), _p(o["h1d"]), drop.desc(DROP_SITE_H1, True, nb // 4), _s())
+        h = o["h1d"]
+    gemm(h, off("crit.4.weight"), off("crit.4.bias"), nb, 1, act="sigmoid", out=o["pred"].view(n, 1))
     return o
+
+
+def masker_buffers(n: int, chfak: int, neck: int, dev, masker_channels: int = 16) -> Dict[str, torch.Tensor]:
+    d, nb = dims(chfak, neck)
+    z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
+    return {"o4": z(n, nb), "o3": z(n, 4, 4, d[3]), "o2": z(n, 8, 8, d[2]), "o1": z(n, 16, 16, d[1]), "o0": z(n, 32, 32, d[0]),
+            "hm": z(n, 64, 64, masker_channels), "Z": z(n, 64, 64)}
 
 
 def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], chfak: int, neck: int = 32,
-                   masker_channels: int = 16) -> Dict[str, torch.Tensor]:
+                   masker_channels: int = 16, out: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
     """UnetDecoder.forward (nets.py:494-523) for any chfak.  embeds = [e0..e3 NHWC, e4 [n,neck*chfak]]."""
     fp = flat.data_ptr()
     off = lambda k: fp + 4 * lay.off(k)
-    d = [8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
-    nb = neck * chfak
+    d, nb = dims(chfak, neck)
     n = x.shape[0]
-    o = {}
-    o["o4"] = gemm(embeds[4], off("dec_model.4.weight"), off("dec_model.4.bias"), nb, nb)
-    o["o3"] = conv3x3(embeds[3], o["o4"].reshape(n, 1, 1, nb), off("dec_model.3.weight"), off("dec_model.3.bias"), d[3], ups=4)
-    o["o2"] = conv3x3(embeds[2], o["o3"], off("dec_model.2.weight"), off("dec_model.2.bias"), d[2])
-    o["o1"] = conv3x3(embeds[1], o["o2"], off("dec_model.1.weight"), off("dec_model.1.bias"), d[1])
-    o["o0"] = conv3x3(embeds[0], o["o1"], off("dec_model.0.weight"), off("dec_model.0.bias"), d[0])
-    o["hm"] = conv3x3(x, o["o0"], off("masker.0.weight"), off("masker.0.bias"), masker_channels, act="lrelu", slope=0.01)
-    o["Z"] = conv3x3(o["hm"], None, off("masker.2.weight"), off("masker.2.bias"), 1, act="sigmoid").reshape(n, 64, 64)
+    o = out if out is not None else masker_buffers(n, chfak, neck, x.device, masker_channels)
+    gemm(embeds[4], off("dec_model.4.weight"), off("dec_model.4.bias"), nb, nb, out=o["o4"])
+    conv3x3(embeds[3], o["o4"].view(n, 1, 1, nb), off("dec_model.3.weight"), off("dec_model.3.bias"), d[3], ups=4, out=o["o3"])
+    conv3x3(embeds[2], o["o3"], off("dec_model.2.weight"), off("dec_model.2.bias"), d[2], out=o["o2"])
+    conv3x3(embeds[1], o["o2"], off("dec_model.1.weight"), off("dec_model.1.bias"), d[1], out=o["o1"])
+    conv3x3(embeds[0], o["o1"], off("dec_model.0.weight"), off("dec_model.0.bias"), d[0], out=o["o0"])
+    conv3x3(x, o["o0"], off("masker.0.weight"), off("masker.0.bias"), masker_channels, act="lrelu", slope=0.01, out=o["hm"])
+    conv3x3(o["hm"], None, off("masker.2.weight"), off("masker.2.bias"), 1, act="sigmoid", out=o["Z"].view(n, 64, 64, 1))
     return o
+
+
+# ------------------------------------------------------------------------------------------------
+# backward passes (training at chfak != 1)
+# ------------------------------------------------------------------------------------------------
+class Workspace(dict):
+    """Named scratch tensors that stay put between the eager warm-up step and the captured graph."""
+
+    def buf(self, name: str, shape, dev, dtype=torch.float32) -> torch.Tensor:
+        t = self.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self[name] = torch.zeros(tuple(shape), device=dev, dtype=dtype)
+        return t
+
+
+def _flip(ws: Workspace, flat: torch.Tensor, lay: Layout, key: str, ci: int, co: int) -> torch.Tensor:
+    wf = ws.buf("wflip_" + key, (9 * ci * co,), flat.device)
+    _lib.call("cgs_gen_flip_weights", ci, co, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")), _p(wf), _s())
+    return wf
+
+
+def _bwd_data(n, hw, co, ci, dy, am, wflip, out, addend=None):
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _p(dy), _p(am), _p(wflip), _p(addend),
+              0 if addend is None else addend.shape[0], _p(out), _s())
+
+
+def _wgrad(plan, ws: Workspace, tag: str, dst_off: int, n, hw, a, b, ups, dy, am, co):
+    """Weight + bias gradient of one 3x3 layer over n images: slab rows registered in `plan` for cgs_reduce_slabs."""
+    ca, cb = a.shape[-1], (0 if b is None else b.shape[-1])
+    nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_slabs(n, ca, cb, co)
+    cnt = 9 * (ca + cb) * co + co
+    slab = ws.buf("slab_" + tag, (nsl, cnt), a.device)
+    _lib.call("cgs_gen_conv3x3_bwd_weight", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _p(a), _p(b), _p(dy), _p(am),
+              _p(slab), _s())
+    plan.add(slab, nsl, cnt, dst_off)
+
+
+def critic_grad_buffers(n: int, chfak: int, neck: int, dev) -> Dict[str, torch.Tensor]:
+    d, nb = dims(chfak, neck)
+    z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
+    g = {f"dE{i}": z(n, hw // 2, hw // 2, d[i]) for i, hw in enumerate(ENC_HW)}
+    g["dz2"], g["dz1"], g["dz14"] = z(n), z(n, nb), z(n, nb)
+    return g
+
+
+def critic_backward_data(flat: torch.Tensor, lay: Layout, chfak: int, neck: int, s: Dict[str, torch.Tensor],
+                         g: Dict[str, torch.Tensor], dpred: torch.Tensor, ws: Workspace, drop=None,
+                         d_embeds: Optional[List[torch.Tensor]] = None, dx: Optional[torch.Tensor] = None):
+    """Data-gradient pass of critic_forward for the images of `s` (saved activations) from dpred [n] down to the gradients at
+    the pooled layer outputs g[dE3..dE0] and the head's pre-activation gradients g[dz2, dz1, dz14] -- everything the weight
+    gradients need.  d_embeds = [dE0..dE3, de4]: gradients arriving at the embeds from the decoder (for the leading images).
+    dx: optional [n,64,64,3] gradient w.r.t. the (fp32) input images."""
+    fp = flat.data_ptr()
+    off = lambda k: fp + 4 * lay.off(k)
+    d, nb = dims(chfak, neck)
+    n = dpred.shape[0]
+    drop = drop if drop is not None else NoDrop()
+    de = d_embeds if d_embeds is not None else [None] * 5
+    g["dz2"][:n].copy_(dpred)
+    grad_fix(g["dz2"][:n], saved=s["pred"], act="sigmoid")
+    gemm_ex(n, 1, nb, g["dz2"], 1, 0, off("crit.4.weight"), 0, 1, g["dz1"])                         # dh1 = dz2 (x) w2
+    grad_fix(g["dz1"][:n], saved=s["h1"], act="relu", drop=drop.desc(DROP_SITE_H1, True, nb // 4))
+    gemm_ex(n, nb, nb, g["dz1"], nb, 1, off("crit.1.weight"), 1, nb, g["dz14"])                     # de4 = dz1 W1^T
+    grad_fix(g["dz14"][:n], saved=s["e4"], act="relu", addend=de[4])
+    k14 = 16 * d[3]
+    gemm_ex(n, nb, k14, g["dz14"], nb, 1, off("features.14.weight"), 1, nb, g["dE3"])               # d(dropped e3)
+    p3 = drop.desc(DROP_SITE_E3, True, k14 // 4)
+    if p3.p > 0.0 or de[3] is not None:
+        grad_fix(g["dE3"][:n], addend=de[3], drop=p3)
+    for i in (3, 2, 1):
+        wf = _flip(ws, flat, lay, ENC_KEYS[i], d[i - 1], d[i])
+        dropped = i == 3 and drop.p > 0.0
+        _bwd_data(n, ENC_HW[i], d[i], d[i - 1], g[f"dE{i}"], s[f"am{i}"], wf, g[f"dE{i - 1}"],
+                  addend=None if dropped else de[i - 1])
+        if dropped:
+            grad_fix(g[f"dE{i - 1}"][:n], addend=de[i - 1], drop=drop.desc(DROP_SITE_E2, True, 64 * d[2] // 4))
+    if dx is not None:
+        wf = _flip(ws, flat, lay, ENC_KEYS[0], 3, d[0])
+        _bwd_data(n, 64, d[0], 3, g["dE0"], s["am0"], wf, dx)
+
+
+def critic_backward_weights(grad: torch.Tensor, goff: int, lay: Layout, chfak: int, neck: int, s: Dict[str, torch.Tensor],
+                            g: Dict[str, torch.Tensor], x: torch.Tensor, n: int, plan, ws: Workspace, tag: str,
+                            training: bool = False):
+    """Weight gradients of the critic over the n images of s / g / x (any number of passes' images, contiguous): the Linear
+    layers as GEMMs straight into grad[goff + ...], the 3x3 layers as slabs registered in `plan` (offsets goff + ...)."""
+    gp = grad.data_ptr() + 4 * goff
+    dst = lambda k: gp + 4 * lay.off(k)
+    d, nb = dims(chfak, neck)
+    ones = ws.buf(f"ones_{n}", (max(n, 1),), x.device)
+    ones.fill_(1.0)
+    h1 = s["h1d"] if training else s["h1"]
+    e3 = s["e3d"] if training else s["e3"]
+    e2 = s["e2d"] if training else s["e2"]
+    k14 = 16 * d[3]
+    gemm_ex(nb, n, 1, h1, 1, nb, g["dz2"], 1, 0, dst("crit.4.weight"))
+    gemm_ex(1, n, 1, ones, 0, 1, g["dz2"], 1, 0, dst("crit.4.bias"))
+    gemm_ex(nb, n, nb, s["e4"], 1, nb, g["dz1"], nb, 1, dst("crit.1.weight"))
+    gemm_ex(1, n, nb, ones, 0, 1, g["dz1"], nb, 1, dst("crit.1.bias"))
+    gemm_ex(k14, n, nb, e3, 1, k14, g["dz14"], nb, 1, dst("features.14.weight"))
+    gemm_ex(1, n, nb, ones, 0, 1, g["dz14"], nb, 1, dst("features.14.bias"))
+    srcs = [x, s["e0"], s["e1"], e2]
+    for i in range(4):
+        _wgrad(plan, ws, f"{tag}_enc{i}", goff + lay.off(ENC_KEYS[i] + ".weight"), n, ENC_HW[i], srcs[i], None, 2,
+               g[f"dE{i}"], s[f"am{i}"], d[i])
+
+
+def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: int, x: torch.Tensor, embeds: List[torch.Tensor],
+                    m: Dict[str, torch.Tensor], dzpre: torch.Tensor, chfak: int, neck: int, plan, ws: Workspace,
+                    masker_channels: int = 16, need_embed_grads: bool = True) -> List[Optional[torch.Tensor]]:
+    """Backward of masker_forward from dzpre [n,64,64] (gradient at the pre-sigmoid mask): weight gradients (slabs in `plan`,
+    the 1x1 bottleneck conv straight into grad) and the gradients [dE0, dE1, dE2, dE3, de4] at the embeds."""
+    fp = flat.data_ptr()
+    off = lambda k: fp + 4 * lay.off(k)
+    d, nb = dims(chfak, neck)
+    n, dev, mc = x.shape[0], x.device, masker_channels
+    dzp = dzpre.view(n, 64, 64, 1)
+    # masker.2 (16 -> 1, sigmoid handled by the caller) and the LeakyReLU(0.01) in front of it
+    _wgrad(plan, ws, "mask2", goff + lay.off("masker.2.weight"), n, 64, m["hm"], None, 2, dzp, None, 1)
+    d_hm = ws.buf("d_hm", (n, 64, 64, mc), dev)
+    _bwd_data(n, 64, 1, mc, dzp, None, _flip(ws, flat, lay, "masker.2", mc, 1), d_hm)
+    grad_fix(d_hm, saved=m["hm"], act="lrelu", slope=0.01)
+    # masker.0 over cat(X, up2(o0))
+    _wgrad(plan, ws, "mask0", goff + lay.off("masker.0.weight"), n, 64, x, m["o0"], 2, d_hm, None, mc)
+    dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)
+    _bwd_data(n, 64, mc, 3 + d[0], d_hm, None, _flip(ws, flat, lay, "masker.0", 3 + d[0], mc), dcat)
+    d_o = ws.buf("d_o0", (n, 32, 32, d[0]), dev)
+    _lib.call("cgs_gen_cat_split", n, 64, 3, d[0], 2, _p(dcat), None, _p(d_o), _s())
+    # linear trunk dec_model.0 .. dec_model.3 over cat(e_i, up(o_{i+1}))
+    d_emb: List[Optional[torch.Tensor]] = [None] * 5
+    lows = [m["o1"], m["o2"], m["o3"], m["o4"].view(n, 1, 1, nb)]
+    for i, hw in enumerate((32, 16, 8, 4)):
+        key, ups, low = f"dec_model.{i}", (4 if i == 3 else 2), lows[i]
+        ca, cb = d[i], low.shape[-1]
+        _wgrad(plan, ws, f"dec{i}", goff + lay.off(key + ".weight"), n, hw, embeds[i], low, ups, d_o, None, d[i])
+        dcat = ws.buf(f"dcat_d{i}", (n, hw, hw, ca + cb), dev)
+        _bwd_data(n, hw, d[i], ca + cb, d_o, None, _flip(ws, flat, lay, key, ca + cb, d[i]), dcat)
+        d_emb[i] = ws.buf(f"dEmb{i}", (n, hw, hw, ca), dev) if need_embed_grads else None
+        d_low = ws.buf(f"d_o{i + 1}", (n, hw // ups, hw // ups, cb), dev)
+        _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, _p(dcat), _p(d_emb[i]), _p(d_low), _s())
+        d_o = d_low
+    # dec_model.4: o4 = e4 W + b (1x1 convolution on the 1x1 map)
+    d_o4 = d_o.view(n, nb)
+    gp = grad.data_ptr() + 4 * goff
+    ones = ws.buf(f"ones_{n}", (max(n, 1),), dev)
+    ones.fill_(1.0)
+    gemm_ex(nb, n, nb, embeds[4], 1, nb, d_o4, nb, 1, gp + 4 * lay.off("dec_model.4.weight"))
+    gemm_ex(1, n, nb, ones, 0, 1, d_o4, nb, 1, gp + 4 * lay.off("dec_model.4.bias"))
+    if need_embed_grads:
+        d_emb[4] = ws.buf("dEmb4", (n, nb), dev)
+        gemm_ex(n, nb, nb, d_o4, nb, 1, off("dec_model.4.weight"), 1, nb, d_emb[4])
+    return d_emb
 
 
 # ------------------------------------------------------------------------------------------------

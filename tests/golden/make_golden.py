@@ -128,10 +128,14 @@ np.savez(os.path.join(HERE, "g2_eval_chfak5.npz"), X=g25["X"], pred=g25["pred"],
 
 # ---------------------------------------------------------------- G3 / G7: phase-2 steps
 def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=True, record_masks=False, threshrew=0.0,
-           separate=False, staticnorm=True):
+           separate=False, staticnorm=True, chfak=1):
     from itertools import chain
-    critic, masker = build(1, dropout=dropout)
-    load_np(critic, "critic", g1); load_np(masker, "masker", g1)
+    critic, masker = build(chfak, dropout=dropout)
+    if chfak == 1:
+        load_np(critic, "critic", g1); load_np(masker, "masker", g1)
+    else:       # other model sizes: the oracle's seeded stand-in weights (as g2_eval_chfak5)
+        critic.load_state_dict(orc.seeded_params(orc.critic_shapes(chfak), 21))
+        masker.load_state_dict(orc.seeded_params(orc.masker_shapes(chfak), 22))
     critic.train(); masker.train()
     sepcrit = None
     if separate:        # main.py:110-111: a second NewCritic; its embeds of A feed the masker (main.py:389-390)
@@ -205,7 +209,7 @@ def phase2(tag, steps=3, dropout=0.0, lfak=5, L1=0.5, L2=0.0, inject=True, live=
             opti.step()
             out[f"total{s}"] = np.float64(loss.item())
             out[f"parts{s}"] = parts
-            if s in (0, steps - 1):
+            if s in (0, steps - 1) and (chfak == 1 or s == steps - 1):
                 out.update(sd_np(f"step{s + 1}/critic", critic.state_dict()))
                 out.update(sd_np(f"step{s + 1}/masker", masker.state_dict()))
                 if separate:
@@ -226,6 +230,7 @@ phase2("g3_train_valuefak", staticnorm=False, L2=0.1)
 phase2("g3_train_separate", separate=True)
 phase2("g3_train_separate_frozen", separate=True, live=False)
 phase2("g7_dropout", steps=1, dropout=0.3, record_masks=True)
+phase2("g3_train_chfak2", steps=2, chfak=2)      # a model size the specialised kernels do not cover (generic kernels' training pass)
 
 
 # ---------------------------------------------------------------- G4: phase-1 step

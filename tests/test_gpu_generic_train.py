@@ -1,0 +1,282 @@
+"""GPU parity of the shape-generic TRAINING pass (csrc/gen_train.hip, cgs_amd/generic_engine.py): model sizes outside the specialised
+kernel set (chfak != 1; the paper's model is chfak = 5) -- the single kernels against torch's CPU autograd, the engine against the
+reference capture at chfak = 2 (tests/golden/g3_train_chfak2.npz) and against the CPU oracle (dropout with the kernels' own masks,
+frozen critic, -separate, chfak = 5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import hourglass_ref as orc
+from test_gpu_kernels import rel_close, nhwc
+from test_gpu_engine import split
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _hwio(w):   # OIHW -> flat HWIO
+    return w.permute(2, 3, 1, 0).contiguous().reshape(-1)
+
+
+@pytest.mark.parametrize("hw,ca,cb,co,ups,pool,u8", [
+    (8, 24, 0, 40, 2, True, False),       # pooled ReLU layer, channel counts that are not multiples of 16
+    (16, 8, 16, 24, 2, False, False),     # decoder layer: cat(skip, nearest-up(low))
+    (4, 16, 32, 16, 4, False, False),     # dec_model.3: the low source is the 1x1 bottleneck
+    (64, 3, 8, 16, 2, False, True),       # masker.0: uint8 frames + upsampled decoder output
+    (64, 16, 0, 1, 2, False, False),      # masker.2: one output channel
+    (32, 3, 0, 8, 2, True, False),        # image layer (3 channels, fp32)
+])
+def test_generic_conv_backward_kernels_vs_autograd(hw, ca, cb, co, ups, pool, u8):
+    """cgs_gen_conv3x3_bwd_data (with cgs_gen_flip_weights / cgs_gen_cat_split) and cgs_gen_conv3x3_bwd_weight (+ cgs_reduce_slabs)
+    against float64 autograd of conv2d(cat(a, up(b))) [-> ReLU -> MaxPool2d(2)]."""
+    from cgs_amd import _lib, generic as gen, hourglass as hg
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(hw * 131 + ca * 7 + co)
+    n = 5
+    if u8:
+        a_np = rs.randint(0, 256, (n, hw, hw, ca)).astype(np.uint8)
+        a_ref = torch.from_numpy(a_np).double().div(255.0).permute(0, 3, 1, 2).requires_grad_(True)
+    else:
+        a_np = rs.randn(n, hw, hw, ca).astype(np.float32)
+        a_ref = torch.from_numpy(a_np).double().permute(0, 3, 1, 2).requires_grad_(True)
+    b_np = rs.randn(n, hw // ups, hw // ups, cb).astype(np.float32) if cb else None
+    w = torch.from_numpy((rs.randn(co, ca + cb, 3, 3) * 0.2).astype(np.float32))
+    bias = torch.from_numpy(rs.randn(co).astype(np.float32) * 0.1)
+    # reference
+    wr, br = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    src = a_ref
+    b_ref = None
+    if cb:
+        b_ref = torch.from_numpy(b_np).double().permute(0, 3, 1, 2).requires_grad_(True)
+        src = torch.cat((a_ref, F.interpolate(b_ref, scale_factor=ups, mode="nearest")), 1)
+    y = F.conv2d(src, wr, br, padding=1)
+    out_ref = F.max_pool2d(F.relu(y), 2) if pool else y
+    dout = torch.from_numpy(rs.randn(*out_ref.shape).astype(np.float32))
+    out_ref.backward(dout.double())
+    # HIP: forward (for the argmax bytes), flipped weights, data gradient, split, weight gradient
+    a_d = torch.from_numpy(a_np).to(dev)
+    b_d = torch.from_numpy(b_np).to(dev) if cb else None
+    wk, bk = _hwio(w).to(dev), bias.to(dev)
+    am = None
+    if pool:
+        o, am = gen.conv3x3(a_d, b_d, wk.data_ptr(), bk.data_ptr(), co, act="relu", pool=True, ups=ups, want_argmax=True)
+        rel_close(nhwc(o), out_ref.detach().numpy(), "forward")
+    dy = dout.permute(0, 2, 3, 1).contiguous().to(dev)
+    ci = ca + cb
+    wf = torch.empty(9 * ci * co, device=dev)
+    _lib.call("cgs_gen_flip_weights", ci, co, _P(wk), _P(wf), _st())
+    dcat = torch.empty(n, hw, hw, ci, device=dev)
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wf), None, 0, _P(dcat), _st())
+    d_a = torch.empty(n, hw, hw, ca, device=dev)
+    d_b = torch.empty(n, hw // ups, hw // ups, cb, device=dev) if cb else None
+    _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, _P(dcat), _P(d_a), _P(d_b), _st())
+    rel_close(nhwc(d_a), a_ref.grad.numpy(), "d_a")      # (uint8 frames: gradient w.r.t. frame / 255)
+    if cb:
+        rel_close(nhwc(d_b), b_ref.grad.numpy(), "d_b")
+    nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_slabs(n, ca, cb, co)
+    cnt = 9 * ci * co + co
+    slab = torch.full((nsl, cnt), float("nan"), device=dev)
+    _lib.call("cgs_gen_conv3x3_bwd_weight", n, hw, ca, cb, co, int(u8), ups, _P(a_d), _P(b_d), _P(dy), _P(am), _P(slab), _st())
+    g = torch.zeros(cnt, device=dev)
+    plan = hg.SlabPlan()
+    plan.add(slab, nsl, cnt, 0)
+    plan.build(g).run()
+    dw = g[:9 * ci * co].reshape(3, 3, ci, co).permute(3, 2, 0, 1).cpu().numpy()
+    rel_close(dw, wr.grad.numpy(), "dW")
+    rel_close(g[9 * ci * co:].cpu().numpy(), br.grad.numpy(), "dbias")
+    # the addend of the data gradient (skip gradients arriving at the leading images)
+    add = torch.from_numpy(rs.randn(2, hw, hw, ci).astype(np.float32)).to(dev)
+    dcat2 = torch.empty_like(dcat)
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wf), _P(add), 2, _P(dcat2), _st())
+    exp = dcat.clone()
+    exp[:2] += add
+    assert torch.equal(dcat2, exp)
+
+
+def test_generic_gemm_ex_and_grad_fix():
+    from cgs_amd import _lib, generic as gen
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(3)
+    m, k, n = 37, 50, 21
+    x, w = rs.randn(m, k).astype(np.float32), rs.randn(k, n).astype(np.float32)
+    xd, wd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev)
+    out = torch.empty(m, n, device=dev)
+    gen.gemm_ex(m, k, n, xd, k, 1, wd, n, 1, out)
+    rel_close(out.cpu().numpy(), x.astype(np.float64) @ w, "x w")
+    out2 = torch.empty(m, k, device=dev)        # dY W^T
+    gen.gemm_ex(m, n, k, out, n, 1, wd, 1, n, out2)
+    rel_close(out2.cpu().numpy(), out.cpu().numpy().astype(np.float64) @ w.T, "dy w^T")
+    out3 = torch.empty(k, n, device=dev)        # X^T dY, then accumulated once more
+    gen.gemm_ex(k, m, n, xd, 1, k, out, n, 1, out3)
+    ref3 = x.T.astype(np.float64) @ out.cpu().numpy()
+    rel_close(out3.cpu().numpy(), ref3, "x^T dy")
+    gen.gemm_ex(k, m, n, xd, 1, k, out, n, 1, out3, accumulate=True)
+    rel_close(out3.cpu().numpy(), 2 * ref3, "accumulate")
+    # (d * mask + addend) * act'(saved)
+    cnt = 8 * 36
+    d = torch.from_numpy(rs.randn(cnt).astype(np.float32)).to(dev)
+    saved = torch.from_numpy(rs.randn(cnt).astype(np.float32)).to(dev)
+    add = torch.from_numpy(rs.randn(cnt // 2).astype(np.float32)).to(dev)
+    step = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    drop = _lib.Dropout(0.3, 1, 1234, step.data_ptr(), 16, 0)
+    mask = torch.empty(cnt, device=dev)
+    _lib.call("cgs_dropout_mask", drop, cnt, _P(mask), _st())
+    exp = d * mask
+    exp[:cnt // 2] += add
+    exp = exp * torch.where(saved > 0, torch.ones_like(saved), torch.full_like(saved, 0.01))
+    gen.grad_fix(d, saved=saved, act="lrelu", slope=0.01, addend=add, drop=drop)
+    assert torch.allclose(d, exp, rtol=1e-6, atol=1e-7)
+    xx = torch.from_numpy(rs.randn(cnt).astype(np.float32)).to(dev)
+    yy = torch.empty_like(xx)
+    _lib.call("cgs_gen_dropout_fwd", cnt, _P(xx), _P(yy), drop, _st())
+    assert torch.equal(yy, xx * mask)
+
+
+def make_generic_engine(chfak, n, neck=32, seeds=(21, 22), **kw):
+    from cgs_amd import generic_engine
+    pc, pm = orc.seeded_params(orc.critic_shapes(chfak, neck), seeds[0]), orc.seeded_params(orc.masker_shapes(chfak, neck), seeds[1])
+    e = generic_engine.GenericEngine(n, chfak=chfak, neck=neck, **kw)
+    e.load_state(pc, pm)
+    return e, pc, pm
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_generic_phase2_matches_reference_capture_chfak2(golden, use_graph):
+    g = golden("g3_train_chfak2.npz")
+    dev = torch.device("cuda:0")
+    e, pc, pm = make_generic_engine(2, 8, dropout=0.0, use_graph=use_graph)
+    A, B, Y = (torch.from_numpy(g[k]).to(dev) for k in ("A", "B", "Y"))
+    for s in range(2):
+        losses = e.phase2_step(A, B, Y).cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(losses[:5], g[f"parts{s}"], rtol=1e-3, atol=1e-7, err_msg=f"losses step {s}")
+        assert losses[5] == pytest.approx(float(g[f"total{s}"]), rel=1e-3)
+        if s == 0:
+            gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+            for k, v in split(g, "grad/masker").items():
+                rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
+            for k, v in split(g, "grad/critic").items():
+                rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
+            rel_close(e.mbuf["Z"].cpu().numpy(), g["Z0"][:, 0], "Z")
+    for k, v in split(g, "step2/critic").items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v, f"critic {k} after step 2", rtol=1e-3, atol_scale=1e-4)
+    for k, v in split(g, "step2/masker").items():
+        rel_close(e.masker_state()[k].cpu().numpy(), v, f"masker {k} after step 2", rtol=1e-3, atol_scale=1e-4)
+
+
+def _export_masks(e, n_slots, chfak, neck):
+    from cgs_amd import _lib
+    d3, d2, nb = 16 * chfak, 8 * chfak, neck * chfak
+    out = []
+    for site, per_img in ((0, (8, 8, d2)), (1, (4, 4, d3)), (2, (nb,))):
+        cnt = n_slots * int(np.prod(per_img))
+        buf = torch.empty(cnt, device=e.dev)
+        _lib.call("cgs_dropout_mask", e.drop.desc(site), cnt, _P(buf), _st())
+        mk = (buf.cpu().reshape((n_slots,) + per_img) != 0).float()
+        out.append(mk.permute(0, 3, 1, 2).contiguous() if len(per_img) == 3 else mk)
+    return out
+
+
+@pytest.mark.parametrize("chfak,neck,n,kw", [
+    (5, 32, 6, dict()),                         # the paper's model size, Dropout 0.3
+    (3, 16, 6, dict(inject=False, L2=0.1)),
+    (2, 32, 6, dict(live=False)),
+    (2, 32, 6, dict(threshrew=0.5)),
+])
+def test_generic_phase2_with_dropout_vs_oracle(chfak, neck, n, kw):
+    rs = np.random.RandomState(7)
+    dev = torch.device("cuda:0")
+    A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    if kw.get("threshrew"):
+        Y = (Y > 0.5).astype(np.float32)
+    e, pc, pm = make_generic_engine(chfak, n, neck=neck, dropout=0.3, use_graph=True, **kw)
+    masks = _export_masks(e, 4 * n, chfak, neck)
+    losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    sl = {"B": slice(0, n), "A": slice(n, 2 * n), "rep": slice(2 * n, 3 * n), "inj": slice(3 * n, 4 * n)}
+    omasks = [[m[sl[k]] for m in masks] for k in ("A", "B", "rep", "inj")]
+    okw = {k: v for k, v in kw.items()}
+    rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1, p=0.3, training=True,
+                           masks=omasks, **okw)[0]
+    parts = rec["parts"]
+    live = kw.get("live", True)
+    exp = [parts.get("critic", 0.0) if live else losses[0], parts["replace"], parts.get("inject", 0.0), parts["norm"], parts.get("norm2", 0.0)]
+    np.testing.assert_allclose(losses[:5], exp, rtol=1e-3, atol=1e-7)
+    gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+    for k, v in rec["grads_m"].items():
+        rel_close(gm[k].cpu().numpy(), v.numpy(), f"masker grad {k}")
+    if live:
+        for k, v in rec["grads_c"].items():
+            rel_close(gc[k].cpu().numpy(), v.numpy(), f"critic grad {k}")
+    for k, v in rec["params_c"].items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"critic {k} after the step", rtol=1e-3, atol_scale=1e-4)
+    for k, v in rec["params_m"].items():
+        rel_close(e.masker_state()[k].cpu().numpy(), v.numpy(), f"masker {k} after the step", rtol=1e-3, atol_scale=1e-4)
+    # graph replay of a second step == an eager engine's second step (same weights, same counter-based masks)
+    e2, _, _ = make_generic_engine(chfak, n, neck=neck, dropout=0.3, use_graph=False, **kw)
+    for eng in (e2,):
+        eng.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev))
+    l2a = e.phase2_step().clone()
+    l2b = e2.phase2_step().clone()
+    assert torch.equal(l2a, l2b)
+    assert torch.equal(e.flat, e2.flat)
+
+
+def test_generic_phase2_separate_critic_vs_oracle():
+    chfak, n = 2, 6
+    rs = np.random.RandomState(9)
+    dev = torch.device("cuda:0")
+    A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    from cgs_amd import generic_engine
+    pc, pm = orc.seeded_params(orc.critic_shapes(chfak), 21), orc.seeded_params(orc.masker_shapes(chfak), 22)
+    ps = orc.seeded_params(orc.critic_shapes(chfak), 23)
+    e = generic_engine.GenericEngine(n, chfak=chfak, dropout=0.0, separate=True)
+    e.load_state(pc, pm, ps)
+    losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1, Ps=ps)[0]
+    assert losses[5] == pytest.approx(rec["total"], rel=1e-3)
+    gs = e.lc.unflatten(e.gs)
+    for k, v in rec["grads_s"].items():
+        if v is None:      # the second critic's head sees no loss
+            assert float(gs[k].abs().max()) == 0.0
+        else:
+            rel_close(gs[k].cpu().numpy(), v.numpy(), f"sepcrit grad {k}")
+    for k, v in rec["params_s"].items():
+        rel_close(e.sepcrit_state()[k].cpu().numpy(), v.numpy(), f"sepcrit {k}", rtol=1e-3, atol_scale=1e-4)
+    for k, v in rec["params_c"].items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"critic {k}", rtol=1e-3, atol_scale=1e-4)
+
+
+def test_generic_phase1_and_saliency_vs_oracle():
+    chfak, n = 5, 6
+    rs = np.random.RandomState(11)
+    dev = torch.device("cuda:0")
+    X = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    e, pc, pm = make_generic_engine(chfak, n, dropout=0.0)
+    losses = e.phase1_step(torch.from_numpy(X).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    rec = orc.train_phase1(pc, [(orc.u8_to_nchw(X), torch.from_numpy(Y))], steps=1, p=0.0)[0]
+    assert losses[0] == pytest.approx(rec["loss"], rel=1e-3)
+    gc = e.lc.unflatten(e.gc)
+    for k, v in rec["grads"].items():
+        rel_close(gc[k].cpu().numpy(), v.numpy(), f"grad {k}")
+    for k, v in rec["params"].items():
+        rel_close(e.critic_state()[k].cpu().numpy(), v.numpy(), f"{k} after the step", rtol=1e-3, atol_scale=1e-4)
+    # saliency: d mean(pred) / dX (main.py:941-953) with the UPDATED weights
+    Xf = orc.u8_to_nchw(X).requires_grad_(True)
+    P = {k: v.cpu() for k, v in e.critic_state().items()}
+    orc.critic_apply(P, Xf).mean().backward()
+    pred, dx = e.saliency(torch.from_numpy(X).to(dev).float().div(255.0))
+    rel_close(nhwc(dx), Xf.grad.numpy(), "saliency gradient")

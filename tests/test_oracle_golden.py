@@ -95,6 +95,26 @@ def test_phase2_steps_match_reference(golden, g1, tag, kw):
                 np.testing.assert_allclose(recs[s - 1][which][k].numpy(), v.numpy(), rtol=1e-4, atol=2e-6, err_msg=f"{s}:{k}")
 
 
+def test_phase2_steps_match_reference_at_chfak2(golden):
+    """A model size the specialised kernels do not cover (chfak = 2: 16/16/16/32 channels, neck 64) -- the pin of the oracle for
+    the shape-generic kernels' training pass."""
+    g = golden("g3_train_chfak2.npz")
+    pc, pm = orc.seeded_params(orc.critic_shapes(2), 21), orc.seeded_params(orc.masker_shapes(2), 22)
+    A, B, Y = orc.u8_to_nchw(g["A"]), orc.u8_to_nchw(g["B"]), t(g["Y"])
+    recs = orc.train_phase2(pc, pm, [(A, B, Y)], steps=2)
+    for s in range(2):
+        assert recs[s]["total"] == pytest.approx(float(g[f"total{s}"]), rel=2e-5)
+    np.testing.assert_allclose(recs[0]["Z"].numpy(), g["Z0"], **TOL)
+    for which, gk in (("grads_c", "grad/critic"), ("grads_m", "grad/masker")):
+        ref = split(g, gk)
+        assert len(ref) == 14
+        for k, v in ref.items():
+            np.testing.assert_allclose(recs[0][which][k].numpy(), v.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    for which, gk in (("params_c", "step2/critic"), ("params_m", "step2/masker")):
+        for k, v in split(g, gk).items():
+            np.testing.assert_allclose(recs[1][which][k].numpy(), v.numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+
+
 @pytest.mark.parametrize("tag,live", [("g3_train_separate", True), ("g3_train_separate_frozen", False)])
 def test_phase2_separate_critic_matches_reference(golden, g1, tag, live):
     """-separate (main.py:110-111, 389-390): a second critic's embeds feed the masker; it joins the optimiser group."""
