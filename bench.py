@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer", "phase1", "cli-train"], default="train",
                     help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
                          "phase1 = critic regression step (main.py:183-200)")
-    ap.add_argument("--chfak", type=int, default=1, help="--mode infer only: other model sizes (5 = the paper's) run on the generic kernels")
+    ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
     return ap.parse_args()
@@ -169,20 +169,55 @@ def cli_train_mode(args):
                                                        "fused phase-2 step, N_A = N_B = 64, one epoch over the high-value set"}}), flush=True)
 
 
-def generic_infer_mode(args, dev, rank):
-    """Eval-mode critic + masker at chfak != 1 on the shape-generic kernels (chfak 5 = 186.6 MFLOP per image)."""
-    from cgs_amd import generic as gen, spec
-    from oracle import hourglass_ref as orc          # only for the seeded stand-in weights
+def seeded_state(layout, seed):
+    """Stand-in weights for model sizes without a committed checkpoint: U(+-1/sqrt(fan_in)) per tensor, reference key names / shapes."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    sd, bound = {}, 1.0
+    for key, seg in layout.segs.items():
+        if key.endswith(".weight"):
+            bound = 1.0 / float(np.prod(seg.ref_shape[1:])) ** 0.5
+        sd[key] = torch.from_numpy(rs.uniform(-bound, bound, size=seg.ref_shape).astype(np.float32))
+    return sd
+
+
+def model_flops(cf, neck=32):
+    """(critic forward, masker forward, features.0) FLOPs per image at channel factor cf (186.6 MFLOP forward at cf 5)."""
+    d, nb = [8 * cf, 8 * cf, 8 * cf, 16 * cf], neck * cf
+    l0 = 18 * 3 * d[0] * 4096
+    fc = l0 + 18 * (d[0] * d[1] * 1024 + d[1] * d[2] * 256 + d[2] * d[3] * 64) + 2 * (16 * d[3] * nb + nb * nb + nb)
+    fm = 2 * nb * nb + 18 * ((d[3] + nb) * d[3] * 16 + (d[2] + d[3]) * d[2] * 64 + (d[1] + d[2]) * d[1] * 256 +
+                             (d[0] + d[1]) * d[0] * 1024 + (3 + d[0]) * 16 * 4096 + 16 * 4096)
+    return fc, fm, l0
+
+
+def generic_mode(args, dev, rank):
+    """chfak != 1 on the shape-generic kernels (the paper's model is chfak 5): the phase-2 training step (--mode train) or the
+    eval-mode critic + masker (--mode infer), priced against the dense fp32 peak -- at 62 FLOP/B this size is compute-bound."""
+    from cgs_amd import generic as gen, generic_engine, spec
     cf, n = args.chfak, args.batch
     lc, lm = spec.critic_layout(cf), spec.masker_layout(cf)
-    fc, fm = torch.empty(lc.total, device=dev), torch.empty(lm.total, device=dev)
-    lc.flatten({k: v.to(dev) for k, v in orc.seeded_params(orc.critic_shapes(cf), 11).items()}, fc)
-    lm.flatten({k: v.to(dev) for k, v in orc.seeded_params(orc.masker_shapes(cf), 12).items()}, fm)
-    A, _, _ = synthetic(n, rank, dev)
+    fcf, fmf, l0 = model_flops(cf)
+    A, B, Y = synthetic(n, rank, dev)
+    if args.mode == "train":
+        eng = generic_engine.GenericEngine(n, chfak=cf, device=dev, dropout=args.dropout, use_graph=not args.no_graph)
+        eng.load_state(seeded_state(lc, 11), seeded_state(lm, 12))
+        eng.phase2_step(A, B, Y)
+        run = lambda: eng.phase2_step()
+        # critic forward on [B|A|rep|inj], masker forward; critic data gradients (features.0's only for the mixes) and weight
+        # gradients on [A|rep|inj]; masker data + weight gradients
+        flops = 4 * fcf + fmf + (6 * fcf - l0) + 2 * fmf
+        what = f"phase-2 step (main.py:344-463), N_A = N_B = {n}, dropout {args.dropout}, chfak {cf}: shape-generic MFMA kernels"
+    else:
+        fc, fm = torch.empty(lc.total, device=dev), torch.empty(lm.total, device=dev)
+        lc.flatten({k: v.to(dev) for k, v in seeded_state(lc, 11).items()}, fc)
+        lm.flatten({k: v.to(dev) for k, v in seeded_state(lm, 12).items()}, fm)
 
-    def run():
-        c = gen.critic_forward(fc, lc, A, cf)
-        return gen.masker_forward(fm, lm, A, [c[f"e{i}"] for i in range(5)], cf)["Z"]
+        def run():
+            c = gen.critic_forward(fc, lc, A, cf)
+            return gen.masker_forward(fm, lm, A, [c[f"e{i}"] for i in range(5)], cf)["Z"]
+        flops = fcf + fmf
+        what = f"eval-mode critic(collect) + masker forward, chfak {cf}: shape-generic MFMA kernels"
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -191,12 +226,12 @@ def generic_infer_mode(args, dev, rank):
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    flops = {5: 186.6e6}.get(cf)
-    print(json.dumps({"metric": f"Hourglass infer images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
-                      "unit": "images/s", "n_gpus": 1, "steps": args.steps, "ms_per_step": dt * 1e3, "dtype": "f32", "data": "synthetic",
-                      "roofline": None if flops is None else {"bound": "mfma", "achieved": flops * n / dt / 1e12, "peak": 157.3,
-                                                              "unit": "TFLOP/s", "frac": flops * n / dt / 1e12 / 157.3, "traffic": None}}),
-          flush=True)
+    ach = flops * n / dt / 1e12
+    print(json.dumps({"metric": f"Hourglass+critic {args.mode} images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
+                      "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+                      "higher_is_better": True, "dtype": "f32", "data": "synthetic", "config": {"workload": what, "batch": n},
+                      "roofline": {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                                   "traffic": None, "flops_per_image": flops}}), flush=True)
 
 
 def side_mode(args, dev, world, rank):
@@ -205,8 +240,6 @@ def side_mode(args, dev, world, rank):
     if args.mode == "cli-train":
         return cli_train_mode(args)
     n = args.batch
-    if args.mode == "infer" and args.chfak != 1:
-        return generic_infer_mode(args, dev, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
@@ -280,6 +313,10 @@ def main():
 
     from cgs_amd import engine
     n = args.batch
+    if args.chfak != 1:
+        if args.mode not in ("train", "infer") or world > 1:
+            raise SystemExit("--chfak != 1: --mode train / infer on one GPU (a secondary measurement; the headline is chfak 1)")
+        return generic_mode(args, dev, rank)
     if args.mode != "train":
         return side_mode(args, dev, world, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg)

@@ -62,7 +62,22 @@ class GenericEngine(HourglassEngine):
         if self.separate:
             self.fs, self.gs = self.flat[self.off_s:], self.grad[self.off_s:]
         self.drop = hg.DropState(self.p, (seed + 0x9E3779B97F4A7C15 * self.rank) & 0xFFFFFFFFFFFFFFFF, self.step_t)
-        n4 = 4 * n
+        self.losses = z(8)
+        self._allocated = False
+        self.ws = gen.Workspace()
+        self._infer_step = z(1, dt=torch.int64)
+        self.fused_tail = False
+        self._graphs: Dict[str, object] = {}
+        self._plans: Dict[str, hg.SlabPlan] = {}
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _alloc(self):
+        """Batch, activation and gradient buffers of the training step (first training call: an engine that only serves
+        inference never holds them)."""
+        if self._allocated:
+            return
+        n, n4 = self.n, 4 * self.n
+        z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
         self.ab = z(2 * n, 64, 64, 3, dt=torch.uint8)         # [B | A]
         self.y = z(n)
         self.x3 = z(3 * n, 64, 64, 3)                         # [A / 255 | replaced | injected]: the critic's fp32 inputs with gradients
@@ -78,15 +93,22 @@ class GenericEngine(HourglassEngine):
             self.sgbuf = gen.critic_grad_buffers(n, self.chfak, self.neck, self.dev)
             self._zero_dpred = z(n)
         self.nzpart = _lib.load().cgs_mix_fwd_partials(n, 4096)
-        self.zsum, self.losses, self.dpred = z(2 * self.nzpart), z(8), z(n4)
+        self.zsum, self.dpred = z(2 * self.nzpart), z(n4)
         self.dzpre = z(n, 64, 64)
-        self.ws = gen.Workspace()
-        self._infer_step = z(1, dt=torch.int64)
-        self.fused_tail = False
-        self._graphs: Dict[str, object] = {}
-        self._plans: Dict[str, hg.SlabPlan] = {}
+        self._allocated = True
 
-    # ---- helpers -----------------------------------------------------------------------------
+    def phase2_step(self, A_u8=None, B_u8=None, Y=None):
+        self._alloc()
+        return super().phase2_step(A_u8, B_u8, Y)
+
+    def phase1_step(self, X_u8=None, Y=None):
+        self._alloc()
+        return super().phase1_step(X_u8, Y)
+
+    def gather_contrastive(self, *a, **kw):
+        self._alloc()
+        return super().gather_contrastive(*a, **kw)
+
     def _view(self, buf: Dict[str, torch.Tensor], a: int, b: int) -> Dict[str, torch.Tensor]:
         return {k: t[a:b] for k, t in buf.items()}
 

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib, dataformat, parallel
 from .engine import HourglassEngine
+from .generic_engine import GenericEngine
 from .nets import NewCritic, UnetDecoder
 
 
@@ -145,48 +146,23 @@ class Handler:
         return torch.roll(X, shifts=Handler._shift_draw(self), dims=2)
 
     # ------------------------------------------------------------------ engines
-    class _GenericInference:
-        """Model sizes outside the specialised kernels (chfak != 1 / neck != 32): eval-mode critic (+ masker) on the shape-generic
-        forward kernels, same infer() contract as HourglassEngine."""
-
-        def __init__(self, h):
-            self.h = h
-
-        @torch.no_grad()
-        def infer(self, X, want_mask=True, train_mode=False, **_kw):
-            from . import generic as gen
-            h = self.h
-            if train_mode:
-                raise NotImplementedError("-noevalmode is implemented for chfak=1, neck=32 only")
-            c = gen.critic_forward(h.critic.flat.detach(), h.critic.layout, X.contiguous(), h.args.chfak, h.args.neck)
-            if not want_mask:
-                return c["pred"], None
-            src = c
-            if h.args.separate:
-                src = gen.critic_forward(h.sepcrit.flat.detach(), h.sepcrit.layout, X.contiguous(), h.args.chfak, h.args.neck)
-            m = gen.masker_forward(h.masker.flat.detach(), h.masker.layout, X.contiguous(), [src[f"e{i}"] for i in range(5)],
-                                   h.args.chfak, h.args.neck)
-            return c["pred"], m["Z"]
-
-        def saliency(self, X):
-            raise NotImplementedError("-salience is implemented for chfak=1, neck=32 only")
-
     def _generic_size(self):
         return self.args.chfak != 1 or self.args.neck != 32
 
     def _engine(self, n, live=True, training=False):
-        if self._generic_size():
-            if training:
-                raise NotImplementedError(f"training with --chfak {self.args.chfak} --neck {self.args.neck}: the fused training step is "
-                                          "built for chfak=1, neck=32; other sizes run inference (-process, -eval) on the generic kernels")
-            return Handler._GenericInference(self)
+        """The engine for batches of n images: the fused fixed-shape kernels at chfak = 1, neck = 32 (the code default), the
+        shape-generic ones for every other model size (the paper's chfak = 5)."""
         key = (n, live)
         if key not in self._engines:
             a = self.args
             first = next(iter(self._engines.values()), None)
-            e = HourglassEngine(n, device=self.device, dropout=a.dropout, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject,
-                                live=live, threshrew=a.threshrew, share_with=first, process_group=self.pg,
-                                separate=bool(a.separate), staticnorm=bool(a.staticnorm))
+            kw = dict(device=self.device, dropout=a.dropout, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject, live=live,
+                      threshrew=a.threshrew, share_with=first, process_group=self.pg, separate=bool(a.separate),
+                      staticnorm=bool(a.staticnorm))
+            if self._generic_size():
+                e = GenericEngine(n, chfak=a.chfak, neck=a.neck, **kw)
+            else:
+                e = HourglassEngine(n, **kw)
             if first is None:
                 # modules and engine share one parameter buffer from now on
                 e.adopt(self.critic, self.masker, self.sepcrit if a.separate else None)

@@ -91,16 +91,76 @@ class _HipModule(nn.Module):
 
 def _unsupported(what):
     raise NotImplementedError(f"{what} is not implemented by the HIP kernels of this build (width=64, dims=[8,8,8,16] x chfak, "
-                              "ReLU, max-pool, nearest upsampling are; training needs chfak=1, neck=32)")
+                              "ReLU, max-pool, nearest upsampling are)")
 
 
-def _generic_only_inference(mod, X):
-    """chfak != 1 / neck != 32 run on the shape-generic forward kernels (csrc/gen.hip): eval-mode inference only."""
-    if mod.training and getattr(mod, "dropout_p", 0.0) > 0.0:
-        raise NotImplementedError(f"{type(mod).__name__}(chfak={mod.chfak}): train-mode Dropout / backward are implemented for "
-                                  "chfak=1, neck=32 only; call .eval() (inference: -process, -eval) for other sizes")
-    if torch.is_grad_enabled() and (X.requires_grad or (mod.training and mod.flat.requires_grad)):
-        raise NotImplementedError(f"{type(mod).__name__}(chfak={mod.chfak}): no backward pass for this model size in this build")
+class _GenCriticFn(torch.autograd.Function):
+    """NewCritic at chfak != 1 / neck != 32 on the shape-generic kernels (generic.py): same contract as _CriticFn."""
+
+    @staticmethod
+    def forward(ctx, X, flat, mod, collect):
+        x = _to_nhwc(X)
+        n = x.shape[0]
+        drop = mod._drop_state()
+        out = gen.critic_forward(flat.detach(), mod.layout, x, mod.chfak, mod.neck, drop=drop if drop.p > 0.0 else None)
+        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out = mod, drop, n, collect, x, out
+        ctx.save_for_backward(flat)
+        pred = out["pred"].view(n, 1)
+        if not collect:
+            return pred
+        return (pred,) + tuple(out[f"e{i}"].permute(0, 3, 1, 2) for i in range(4)) + (out["e4"].view(n, -1, 1, 1),)
+
+    @staticmethod
+    def backward(ctx, dpred, *de):
+        (flat,) = ctx.saved_tensors
+        mod, n, dev = ctx.mod, ctx.n, flat.device
+        lay = mod.layout
+        dp = torch.zeros(n, device=dev) if dpred is None else dpred.reshape(n).to(torch.float32).contiguous()
+        d_embeds = None
+        if ctx.collect and any(d is not None for d in de):
+            d_embeds = [None if d is None else d.to(torch.float32).permute(0, 2, 3, 1).contiguous() for d in de[:4]]
+            d_embeds.append(None if de[4] is None else de[4].to(torch.float32).reshape(n, -1).contiguous())
+        training = ctx.drop.p > 0.0
+        g = gen.critic_grad_buffers(n, mod.chfak, mod.neck, dev)
+        dx = torch.empty((n, 64, 64, 3), device=dev) if ctx.needs_input_grad[0] else None
+        ws = gen.Workspace()
+        gen.critic_backward_data(flat.detach(), lay, mod.chfak, mod.neck, ctx.out, g, dp, ws, ctx.drop if training else None,
+                                 d_embeds=d_embeds, dx=dx)
+        grad = torch.zeros(lay.total, device=dev)
+        plan = hg.SlabPlan()
+        gen.critic_backward_weights(grad, 0, lay, mod.chfak, mod.neck, ctx.out, g, ctx.x, n, plan, ws, "mod", training=training)
+        plan.build(grad).run()
+        return (dx.permute(0, 3, 1, 2) if dx is not None else None), grad, None, None
+
+
+class _GenMaskerFn(torch.autograd.Function):
+    """UnetDecoder at chfak != 1 / neck != 32 on the shape-generic kernels: same contract as _MaskerFn."""
+
+    @staticmethod
+    def forward(ctx, X, e0, e1, e2, e3, e4, flat, mod):
+        x = _to_nhwc(X)
+        n = x.shape[0]
+        embeds = [e.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous() for e in (e0, e1, e2, e3)]
+        embeds.append(e4.detach().to(torch.float32).reshape(n, -1).contiguous())
+        m = gen.masker_forward(flat.detach(), mod.layout, x, embeds, mod.chfak, mod.neck, mod.masker_channels)
+        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m = mod, n, x, embeds, m
+        ctx.save_for_backward(flat)
+        return m["Z"].view(n, 1, 64, 64)
+
+    @staticmethod
+    def backward(ctx, dZ):
+        (flat,) = ctx.saved_tensors
+        mod, n = ctx.mod, ctx.n
+        lay = mod.layout
+        Z = ctx.m["Z"]
+        dzpre = (dZ.reshape(n, 64, 64).to(torch.float32) * Z * (1.0 - Z)).contiguous()   # sigmoid'
+        grad = torch.zeros(lay.total, device=flat.device)
+        plan = hg.SlabPlan()
+        d_emb = gen.masker_backward(flat.detach(), lay, grad, 0, ctx.x, ctx.embeds, ctx.m, dzpre, mod.chfak, mod.neck, plan,
+                                    gen.Workspace(), mod.masker_channels)
+        plan.build(grad).run()
+        de = [d.permute(0, 3, 1, 2) for d in d_emb[:4]] + [d_emb[4].view(n, -1, 1, 1)]
+        return (None,) + tuple(de) + (grad, None)
 
 
 class _CriticFn(torch.autograd.Function):
@@ -156,16 +216,8 @@ class NewCritic(_HipModule):
 
     def forward(self, X, collect=False):
         self._need_device()
-        if self._generic:
-            _generic_only_inference(self, X)
-            with torch.no_grad():
-                o = gen.critic_forward(self.flat.detach(), self.layout, _to_nhwc(X.to(self.flat.device)), self.chfak, self.neck)
-            n = X.shape[0]
-            pred = o["pred"].view(n, 1)
-            if not collect:
-                return pred
-            return pred, [o[f"e{i}"].permute(0, 3, 1, 2) for i in range(4)] + [o["e4"].view(n, -1, 1, 1)]
-        out = _CriticFn.apply(X.to(self.flat.device), self.flat, self, bool(collect))
+        fn = _GenCriticFn if self._generic else _CriticFn      # chfak != 1 / neck != 32: the shape-generic kernels
+        out = fn.apply(X.to(self.flat.device), self.flat, self, bool(collect))
         if collect:
             return out[0], list(out[1:])
         return out
@@ -217,19 +269,9 @@ class UnetDecoder(_HipModule):
     def forward(self, X, embeds):
         self._need_device()
         dev = self.flat.device
-        if self._generic:
-            _generic_only_inference(self, X)
-            if torch.is_grad_enabled() and any(t.requires_grad for t in embeds):
-                raise NotImplementedError(f"UnetDecoder(chfak={self.chfak}): no backward pass for this model size in this build")
-            with torch.no_grad():
-                n = X.shape[0]
-                emb = [t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).contiguous() for t in embeds[:4]]
-                emb.append(embeds[4].detach().to(dev, torch.float32).reshape(n, -1).contiguous())
-                m = gen.masker_forward(self.flat.detach(), self.layout, _to_nhwc(X.to(dev)), emb, self.chfak, self.neck,
-                                       self.masker_channels)
-            return m["Z"].view(n, 1, 64, 64)
         e = [t.to(dev) for t in embeds]
-        return _MaskerFn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)
+        fn = _GenMaskerFn if self._generic else _MaskerFn
+        return fn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)
 
 
 class Unet(nn.Module):

@@ -280,3 +280,65 @@ def test_generic_phase1_and_saliency_vs_oracle():
     orc.critic_apply(P, Xf).mean().backward()
     pred, dx = e.saliency(torch.from_numpy(X).to(dev).float().div(255.0))
     rel_close(nhwc(dx), Xf.grad.numpy(), "saliency gradient")
+
+
+def test_reference_style_training_loop_through_modules_chfak2(golden):
+    """main.py:360-463 against the module API at chfak = 2 (NewCritic / UnetDecoder on the shape-generic kernels, torch ops for the
+    mix and the losses, torch.optim.Adam): the reference capture's losses, gradients and parameters."""
+    from itertools import chain
+    from cgs_amd import nets
+    g = golden("g3_train_chfak2.npz")
+    critic, masker = nets.NewCritic(chfak=2, dropout=0.0).to("cuda").train(), nets.UnetDecoder(chfak=2).to("cuda").train()
+    critic.load_state_dict(orc.seeded_params(orc.critic_shapes(2), 21))
+    masker.load_state_dict(orc.seeded_params(orc.masker_shapes(2), 22))
+    opti = torch.optim.Adam(chain(critic.parameters(), masker.parameters()))
+    A, B = orc.u8_to_nchw(g["A"]).to("cuda"), orc.u8_to_nchw(g["B"]).to("cuda")
+    Y = torch.from_numpy(g["Y"]).to("cuda")
+    for s in range(2):
+        pred, embeds = critic(A, collect=True)
+        negpred = critic(B).squeeze().detach()
+        pred = pred.squeeze()
+        cl = F.mse_loss(pred, Y)
+        Z = masker(A, embeds)
+        rl = F.mse_loss(critic(A * (1 - Z) + Z * B).squeeze(), negpred)
+        il = F.mse_loss(critic(B * (1 - Z) + Z * A).squeeze(), pred.detach())
+        nl = 0.5 * F.l1_loss(Z, torch.zeros_like(Z))
+        loss = 5 * cl + rl + il + nl
+        opti.zero_grad()
+        loss.backward()
+        if s == 0:
+            gm, gc = masker.layout.unflatten(masker.flat.grad), critic.layout.unflatten(critic.flat.grad)
+            for k, v in split(g, "grad/masker").items():
+                rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
+            for k, v in split(g, "grad/critic").items():
+                rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
+        opti.step()
+        np.testing.assert_allclose([cl.item(), rl.item(), il.item(), nl.item()], g[f"parts{s}"][:4], rtol=1e-3, atol=1e-7)
+    for k, v in split(g, "step2/masker").items():
+        rel_close(masker.state_dict()[k].cpu().numpy(), v, f"masker {k} after 2 steps", atol_scale=1e-4)
+    for k, v in split(g, "step2/critic").items():
+        rel_close(critic.state_dict()[k].cpu().numpy(), v, f"critic {k} after 2 steps", atol_scale=1e-4)
+
+
+def test_cli_train_at_chfak2(tmp_path):
+    """`main.py -train --chfak 2`: both phases run on the shape-generic engine, the checkpoints carry the reference's names / shapes
+    at that size and the critic learns the synthetic bright/dark split."""
+    import os, subprocess, sys
+    from test_gpu_modules import _write_dataset, REPO
+    root = str(tmp_path)
+    X, Y = _write_dataset(root)
+    common = ["--model", "m", "--datasize", "1536", "--testsize", "512", "--cepochs", "6", "--mepochs", "1", "--chfak", "2"]
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-train"] + common, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    saves = os.listdir(os.path.join(root, "m", "saves"))
+    cpath = [f for f in saves if f.startswith("critic-") and "chfak=2" in f]
+    mpath = [f for f in saves if f.startswith("masker-")]
+    assert cpath and mpath, saves
+    pc = torch.load(os.path.join(root, "m", "saves", cpath[0]), map_location="cpu")
+    pm = torch.load(os.path.join(root, "m", "saves", mpath[0]), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in pc.items()] == [(k, s) for k, s in orc.critic_shapes(2)]
+    assert [(k, tuple(v.shape)) for k, v in pm.items()] == [(k, s) for k, s in orc.masker_shapes(2)]
+    with torch.no_grad():
+        p = orc.critic_apply(pc, orc.u8_to_nchw(X[:256])).squeeze(1).numpy()
+    assert np.corrcoef(p, Y[1, :256])[0, 1] > 0.9
