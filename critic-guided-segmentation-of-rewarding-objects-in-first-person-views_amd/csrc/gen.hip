@@ -11,6 +11,7 @@
 //                     the 1x1 convolution, ConvTranspose2d(4,1,0) on a 1x1 map.
 //   gen_convt4s2_*  : ConvTranspose2d(4, 2, 1) over cat(A, B): forward, data gradient, weight gradient (direct form).
 #include "gen_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -24,58 +25,96 @@ struct GenConvParams {
 
 constexpr int GEN_MAX_TPW = 4;        // pixel tiles (16 pixels) per wave: strips hold <= 256 pixels
 
-// grid: ((image * strips + strip) * column blocks + column block); 256 threads
-__global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
+// grid: ((image * strips + strip) * column-block groups + group); 256 threads.  A workgroup computes NCB (<= 3) blocks of 16 output
+// channels from one staged input tile: an A operand read from LDS feeds NCB MFMAs, a weight operand the wave's pixel tiles.
+template <int NCB, bool WLDS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) gen_conv3x3_fwd_kernel(GenConvParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 gsm[];
     float* tile = (float*)gsm;                      // [(th + 2)][(hw + 2)][GEN_KC]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
-    const int strips = H / TH, ncb = (P.co + 15) / 16;
-    const int cbi = blockIdx.x % ncb, strip = (blockIdx.x / ncb) % strips, img = blockIdx.x / (ncb * strips);
+    const int strips = H / TH, ncg = ((P.co + 15) / 16 + NCB - 1) / NCB;
+    const int cg = blockIdx.x % ncg, strip = (blockIdx.x / ncg) % strips, img = blockIdx.x / (ncg * strips);
     const int row0 = strip * TH;
     const GenSrc& S = P.src;
     const int cp = gen_pa4(S) + S.cb, ci_total = S.ca + S.cb;
     const int nchunk = (cp + GEN_KC - 1) / GEN_KC;
-    const int col = cbi * 16 + l15;
+    const int col0 = cg * NCB * 16 + l15;           // this lane's column in the group's first block (+16 per block)
     const int ntiles = TH * W / 16, QW = W / 2;
 
-    frag4 acc[GEN_MAX_TPW];
+    frag4 acc[GEN_MAX_TPW][NCB];
     int abase[GEN_MAX_TPW];
 #pragma unroll
     for (int i = 0; i < GEN_MAX_TPW; ++i) {
-        acc[i] = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) acc[i][c] = frag4{0.f, 0.f, 0.f, 0.f};
         const int t = wave + 4 * i;
         const int q = 4 * t + (l15 >> 2), qy = q / QW, qx = q % QW;
         const int y = 2 * qy + ((l15 >> 1) & 1), x = 2 * qx + (l15 & 1);     // strip-local
         abase[i] = (y * PW + x) * GEN_KC + kq;
     }
 
+    constexpr int NC = NCB == 2 ? 48 : 16 * NCB;                 // row stride of the weight tile (48: the 4 k-rows of a read hit 64 banks)
+    float* wl = tile + (TH + 2) * PW * GEN_KC;                   // [9 taps][16 channels][NC]
     for (int ch = 0; ch < nchunk; ++ch) {
-        gen_stage(tile, S, img, H, W, row0, TH, 1, ch, tid);      // 16 channels of the strip (with halo)
+        int ltid = tid;                                           // opaque per chunk: keeps the staging addresses of all
+        asm volatile("" : "+v"(ltid));                            // iterations from being hoisted out of this loop (registers)
+        gen_stage<2>(tile, S, img, H, W, row0, TH, 1, ch, ltid);     // 16 channels of the strip (with halo)
+        if constexpr (WLDS) {
+        // the chunk's weights: [tap][channel][NCB x 16 columns], zero for padding channels / columns (9 loads in flight at a time)
+#pragma unroll 1
+        for (int bt = 0; bt < NCB; ++bt) {
+            float wv[9];
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int e = ltid + 256 * (9 * bt + it), c = e % (16 * NCB), k = (e / (16 * NCB)) & 15, tap = e / (256 * NCB);
+                const int ci = gen_real_channel(S, ch * GEN_KC + k), col = cg * NCB * 16 + c;
+                wv[it] = (ci >= 0 && col < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col] : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < 9; ++it) {
+                const int e = ltid + 256 * (9 * bt + it), c = e % (16 * NCB), k = (e / (16 * NCB)) & 15, tap = e / (256 * NCB);
+                wl[(tap * 16 + k) * NC + c] = wv[it];
+            }
+        }
+        }
         __syncthreads();
-        // ---- 9 taps x 4 k-steps; the weight operand of a k-step is shared by the wave's pixel tiles ----
+        const int rem = cp - ch * GEN_KC, ksteps = rem >= GEN_KC ? 4 : (rem + 3) >> 2;      // (a partial last chunk: fewer k-steps)
+        // ---- 9 taps x k-steps: operands from LDS only; a weight operand is shared by the wave's pixel tiles ----
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * PW + tap % 3) * GEN_KC;
-            float b[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
-                b[s] = (ci >= 0 && col < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col] : 0.f;
-            }
+                if (s < ksteps) {
+                    float b[NCB];
+                    if constexpr (WLDS) {
 #pragma unroll
-            for (int i = 0; i < GEN_MAX_TPW; ++i) {
-                if (wave + 4 * i < ntiles) {
+                        for (int c = 0; c < NCB; ++c) b[c] = wl[(tap * 16 + 4 * s + kq) * NC + 16 * c + l15];
+                    } else {
+                        const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(tile[abase[i] + toff + 4 * s], b[s], acc[i], 0, 0, 0);
+                        for (int c = 0; c < NCB; ++c)
+                            b[c] = (ci >= 0 && col0 + 16 * c < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col0 + 16 * c] : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < GEN_MAX_TPW; ++i) {
+                        if (wave + 4 * i < ntiles) {
+                            const float a = tile[abase[i] + toff + 4 * s];
+#pragma unroll
+                            for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[i][c], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
         __syncthreads();
     }
     // ---- epilogue ----
-    if (col < P.co) {
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int col = col0 + 16 * c;
+        if (col >= P.co) continue;
         const float bias = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < GEN_MAX_TPW; ++i) {
@@ -83,11 +122,11 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
             if (t >= ntiles) continue;
             const int q = 4 * t + kq, qy = q / QW, qx = q % QW;
             if (P.pool) {
-                float m = gen_act(acc[i][0] + bias, P.act, P.slope);
+                float m = gen_act(acc[i][c][0] + bias, P.act, P.slope);
                 int idx = 0;
 #pragma unroll
                 for (int j = 1; j < 4; ++j) {
-                    const float v = gen_act(acc[i][j] + bias, P.act, P.slope);
+                    const float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
                     if (v > m) { m = v; idx = j; }
                 }
                 const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
@@ -99,7 +138,7 @@ __global__ void __launch_bounds__(256) gen_conv3x3_fwd_kernel(GenConvParams P) {
                 for (int j = 0; j < 4; ++j) {
                     const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
                     const size_t o = (((size_t)img * H + y) * W + x) * P.co + col;
-                    float v = gen_act(acc[i][j] + bias, P.act, P.slope);
+                    float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
                     if (P.addend && img < P.n_addend) v += P.addend[o];
                     P.out[o] = v;
                 }
@@ -236,8 +275,14 @@ __global__ void __launch_bounds__(256) gen_convt_bwd_weight_kernel(GenConvTParam
 static int gen_conv_launch(GenConvParams P, cgs_stream_t stream) {
     P.th = gen_strip_rows(P.hw);
     const int ncb = (P.co + 15) / 16, strips = P.hw / P.th;
-    const size_t lds = (size_t)(P.th + 2) * (P.hw + 2) * GEN_KC * sizeof(float);
-    hipLaunchKernelGGL(gen_conv3x3_fwd_kernel, dim3(P.n * strips * ncb), dim3(256), lds, (hipStream_t)stream, P);
+    // column blocks per workgroup: 3 (2 when that covers the layer exactly); one staged tile then feeds all of them
+    const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
+    static const bool wlds = [] { const char* e = std::getenv("CGS_GEN_WLDS"); return e && e[0] == '1'; }();
+    const size_t lds = ((size_t)(P.th + 2) * (P.hw + 2) * GEN_KC + (wlds ? (size_t)9 * 16 * (per == 2 ? 48 : 16 * per) : 0)) * sizeof(float);
+    const dim3 grid(P.n * strips * ((ncb + per - 1) / per));
+    auto k = wlds ? (per == 1 ? gen_conv3x3_fwd_kernel<1, true> : per == 2 ? gen_conv3x3_fwd_kernel<2, true> : gen_conv3x3_fwd_kernel<3, true>)
+                  : (per == 1 ? gen_conv3x3_fwd_kernel<1, false> : per == 2 ? gen_conv3x3_fwd_kernel<2, false> : gen_conv3x3_fwd_kernel<3, false>);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -29,51 +29,105 @@ __device__ __forceinline__ int gen_real_channel(const GenSrc& S, int k) {      /
 }
 
 // Stages channels [16 ch, 16 ch + 16) of rows row0 - halo .. row0 + th - 1 + halo (all columns, `halo` zero columns either side)
-// of image img into tile[(th + 2 halo)][(W + 2 halo)][16].  256 threads.
-__device__ __forceinline__ void gen_stage(float* tile, const GenSrc& S, int img, int H, int W, int row0, int th, int halo,
-                                          int ch, int tid) {
+// of image img into tile[(th + 2 halo)][(W + 2 halo)][16].  256 threads; a strip is <= 1584 float4 (7 per thread).
+// Written branch-free per source kind (clamped addresses, selects): every load of a thread is issued before the first conversion
+// or LDS store, so the latencies of the (up to 7) rounds overlap instead of adding up.
+enum { GEN_K_F32V4 = 0, GEN_K_F32S = 1, GEN_K_U8 = 2, GEN_K_POOLEXP = 3 };      // A source: float4-able fp32, odd-width fp32, uint8, pooled
+
+template <int KIND, bool HASB, int BATCH>
+__device__ __forceinline__ void gen_stage_impl(float* tile, const GenSrc& S, int img, int H, int W, int row0, int th, int halo,
+                                               int ch, int tid0) {
     const int PW = W + 2 * halo, pa4 = gen_pa4(S), cp = pa4 + S.cb;
     const int ngrp = (th + 2 * halo) * PW * (GEN_KC / 4);
     const int HB = H / S.ups, WB = W / S.ups;
-    for (int e = tid; e < ngrp; e += 256) {
+    // BATCH rounds of loads in flight at a time (7: all of them, registers permitting; 1: lowest register count)
+#pragma unroll 1
+    for (int bt = 0; bt * BATCH * 256 < ngrp; ++bt) {
+    const int tid = tid0 + bt * BATCH * 256;
+    float4 raw[BATCH];                    // F32V4 / POOLEXP / B part: the float4; F32S / U8: up to 4 scalars
+    float4 rawb[HASB && KIND != GEN_K_F32V4 ? BATCH : 1];
+    uint32_t am[KIND == GEN_K_POOLEXP ? BATCH : 1];
+#pragma unroll
+    for (int it = 0; it < BATCH; ++it) {
+        const int e0 = tid + 256 * it, e = e0 < ngrp ? e0 : 0;
         const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
         const int y = row0 + r - halo, x = c - halo, k0 = ch * GEN_KC + 4 * g;
-        float4 v = f4zero();
-        if (y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
-            if (k0 < pa4) {
-                const size_t pix = ((size_t)img * H + y) * W + x;
-                if (S.mode == GEN_SRC_U8) {
-                    const uint8_t* s = (const uint8_t*)S.a + pix * S.ca + k0;
-                    const float sc = 1.f / 255.f;
-                    v.x = s[0] * sc;
-                    if (k0 + 1 < S.ca) v.y = s[1] * sc;
-                    if (k0 + 2 < S.ca) v.z = s[2] * sc;
-                    if (k0 + 3 < S.ca) v.w = s[3] * sc;
-                } else if (S.mode == GEN_SRC_POOLEXP) {        // (ca % 4 == 0)
-                    const size_t pp = (((size_t)img * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * S.ca + k0;
-                    const float4 d = *(const float4*)((const float*)S.a + pp);
-                    const uint32_t am = *(const uint32_t*)(S.am + pp);
-                    const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
-                    v.x = (am & 255u) == pos ? d.x : 0.f;
-                    v.y = ((am >> 8) & 255u) == pos ? d.y : 0.f;
-                    v.z = ((am >> 16) & 255u) == pos ? d.z : 0.f;
-                    v.w = (am >> 24) == pos ? d.w : 0.f;
-                } else if ((S.ca & 3) == 0) {
-                    v = *(const float4*)((const float*)S.a + pix * S.ca + k0);
-                } else {
-                    const float* s = (const float*)S.a + pix * S.ca + k0;
-                    v.x = s[0];
-                    if (k0 + 1 < S.ca) v.y = s[1];
-                    if (k0 + 2 < S.ca) v.z = s[2];
-                    if (k0 + 3 < S.ca) v.w = s[3];
-                }
-            } else {
-                const size_t pixb = ((size_t)img * HB + y / S.ups) * WB + x / S.ups;
-                v = *(const float4*)(S.b + pixb * S.cb + (k0 - pa4));
-            }
+        const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
+        const size_t pix = ((size_t)img * H + yc) * W + xc;
+        const float* pb = nullptr;
+        if constexpr (HASB) {
+            int kb = k0 - pa4;
+            kb = kb < 0 ? 0 : (kb > S.cb - 4 ? S.cb - 4 : kb);
+            pb = S.b + (((size_t)img * HB + yc / S.ups) * WB + xc / S.ups) * S.cb + kb;
         }
-        *(float4*)(tile + (size_t)px * GEN_KC + 4 * g) = v;
+        if constexpr (KIND == GEN_K_F32V4) {
+            const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
+            const float* pa = (const float*)S.a + pix * S.ca + ka;
+            if constexpr (HASB) pa = k0 < pa4 ? pa : pb;
+            raw[it] = *(const float4*)pa;
+        } else if constexpr (KIND == GEN_K_POOLEXP) {
+            const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
+            const size_t pp = (((size_t)img * (H / 2) + (yc >> 1)) * (W / 2) + (xc >> 1)) * S.ca + ka;
+            raw[it] = *(const float4*)((const float*)S.a + pp);
+            am[it] = *(const uint32_t*)(S.am + pp);
+        } else {
+            const int c0 = k0 < S.ca ? k0 : S.ca - 1, c1 = k0 + 1 < S.ca ? k0 + 1 : S.ca - 1, c2 = k0 + 2 < S.ca ? k0 + 2 : S.ca - 1,
+                      c3 = k0 + 3 < S.ca ? k0 + 3 : S.ca - 1;
+            if constexpr (KIND == GEN_K_U8) {
+                const uint8_t* s = (const uint8_t*)S.a + pix * S.ca;
+                raw[it] = make_float4((float)s[c0], (float)s[c1], (float)s[c2], (float)s[c3]);
+            } else {
+                const float* s = (const float*)S.a + pix * S.ca;
+                raw[it] = make_float4(s[c0], s[c1], s[c2], s[c3]);
+            }
+            if constexpr (HASB) rawb[it] = *(const float4*)pb;
+        }
     }
+#pragma unroll
+    for (int it = 0; it < BATCH; ++it) {
+        const int e = tid + 256 * it;
+        if (e < ngrp) {
+            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
+            const int y = row0 + r - halo, x = c - halo, k0 = ch * GEN_KC + 4 * g;
+            const bool inb = y >= 0 && y < H && x >= 0 && x < W && k0 < cp;
+            float4 v = raw[it];
+            if constexpr (KIND == GEN_K_POOLEXP) {
+                const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
+                v.x = (am[it] & 255u) == pos ? v.x : 0.f;
+                v.y = ((am[it] >> 8) & 255u) == pos ? v.y : 0.f;
+                v.z = ((am[it] >> 16) & 255u) == pos ? v.z : 0.f;
+                v.w = (am[it] >> 24) == pos ? v.w : 0.f;
+            } else if constexpr (KIND == GEN_K_F32S || KIND == GEN_K_U8) {
+                const float sc = KIND == GEN_K_U8 ? 1.f / 255.f : 1.f;
+                v.x = k0 < S.ca ? v.x * sc : 0.f;
+                v.y = k0 + 1 < S.ca ? v.y * sc : 0.f;
+                v.z = k0 + 2 < S.ca ? v.z * sc : 0.f;
+                v.w = k0 + 3 < S.ca ? v.w * sc : 0.f;
+                if constexpr (HASB) {      // (component-wise: a select between the two ARRAYS would index them dynamically)
+                    const float4 rb = rawb[it];
+                    const bool isa = k0 < pa4;
+                    v.x = isa ? v.x : rb.x; v.y = isa ? v.y : rb.y; v.z = isa ? v.z : rb.z; v.w = isa ? v.w : rb.w;
+                }
+            }
+            *(float4*)(tile + (size_t)e * 4) = inb ? v : f4zero();
+        }
+    }
+    }
+}
+
+template <int BATCH>
+__device__ __forceinline__ void gen_stage(float* tile, const GenSrc& S, int img, int H, int W, int row0, int th, int halo,
+                                          int ch, int tid) {
+    // (uniform dispatch: one specialised, branch-free body per source kind)
+    if (S.mode == GEN_SRC_POOLEXP) return gen_stage_impl<GEN_K_POOLEXP, false, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+    if (S.cb > 0) {
+        if (S.mode == GEN_SRC_U8) return gen_stage_impl<GEN_K_U8, true, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+        if (S.ca & 3) return gen_stage_impl<GEN_K_F32S, true, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+        return gen_stage_impl<GEN_K_F32V4, true, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+    }
+    if (S.mode == GEN_SRC_U8) return gen_stage_impl<GEN_K_U8, false, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+    if (S.ca & 3) return gen_stage_impl<GEN_K_F32S, false, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
+    return gen_stage_impl<GEN_K_F32V4, false, BATCH>(tile, S, img, H, W, row0, th, halo, ch, tid);
 }
 
 static inline int gen_strip_rows(int hw) {      // strips of <= 256 pixels, at least 2 rows

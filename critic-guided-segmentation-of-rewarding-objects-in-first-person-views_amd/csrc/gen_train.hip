@@ -23,72 +23,121 @@ struct GenWgradParams {
     int n, hw, th, G, ncib, ncob;
 };
 
-// grid: (image share g, input-channel block, output-channel block); 256 threads = 4 waves that split the pixel groups
-__global__ void __launch_bounds__(256) gen_conv3x3_wgrad_kernel(GenWgradParams P) {
+// grid: (image share g, input-channel block, group of NCOB output-channel blocks); 256 threads = 4 waves that split the pixel
+// groups.  One staged input chunk meets NCOB (<= 3) staged chunks of dY: an A operand read from LDS feeds NCOB MFMAs.
+// SMALL (9 (ca + cb) <= 32, i.e. the image layer): the GEMM's rows are the (tap, channel) pairs -- 2 row blocks instead of 9 taps
+// x one mostly empty block of 16 channels.
+template <int NCOB, bool SMALL>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) gen_conv3x3_wgrad_kernel(GenWgradParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    constexpr int NT = SMALL ? 2 : 9, NV = 4 * NT + 1;          // row blocks; floats per lane and column block in the reduction
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
     float* tin = (float*)gsm;                                  // [(TH + 2)][(W + 2)][16]
-    float* tdy = tin + (TH + 2) * PW * GEN_KC;                 // [TH][W][16]
-    const int cob = blockIdx.x % P.ncob, cib = (blockIdx.x / P.ncob) % P.ncib, g = blockIdx.x / (P.ncob * P.ncib);
+    float* tdy = tin + (TH + 2) * PW * GEN_KC;                 // [NCOB][TH][W][16]
+    const int DYT = TH * W * GEN_KC;
+    const int cog = blockIdx.x % P.ncob, cib = (blockIdx.x / P.ncob) % P.ncib, g = blockIdx.x / (P.ncob * P.ncib);      // (ncob = groups)
     const int co = P.dy.ca, ci_total = P.in.ca + P.in.cb;
     const int ngroups = TH * W / 4, strips = H / TH;
-
-    frag4 acc[9];
+    const int nblk = (co + 15) / 16;
+    int aoff[NT];                                              // this lane's A-operand offset inside the tile, per row block
+    bool aok[NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = frag4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
+    for (int t = 0; t < NT; ++t) {
+        if constexpr (SMALL) {
+            const int m = 16 * t + l15, tap = m / ci_total;
+            aok[t] = m < 9 * ci_total;
+            aoff[t] = aok[t] ? ((tap / 3) * PW + tap % 3) * GEN_KC + m % ci_total : 0;
+        } else {
+            aok[t] = true;
+            aoff[t] = ((t / 3) * PW + t % 3) * GEN_KC + l15;
+        }
+    }
+
+    frag4 acc[NT][NCOB];
+    float bsum[NCOB];
+#pragma unroll
+    for (int c = 0; c < NCOB; ++c) {
+        bsum[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][c] = frag4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int img = g; img < P.n; img += P.G) {
         for (int strip = 0; strip < strips; ++strip) {
-            gen_stage(tin, P.in, img, H, W, strip * TH, TH, 1, cib, tid);
-            gen_stage(tdy, P.dy, img, H, W, strip * TH, TH, 0, cob, tid);
+            int ltid = tid;                                    // opaque per strip: the staging addresses of all iterations are
+            asm volatile("" : "+v"(ltid));                     // recomputed here instead of living in registers across the loops
+            gen_stage<7>(tin, P.in, img, H, W, strip * TH, TH, 1, cib, ltid);
+#pragma unroll 1
+            for (int c = 0; c < NCOB; ++c)
+                if (cog * NCOB + c < nblk) gen_stage<7>(tdy + c * DYT, P.dy, img, H, W, strip * TH, TH, 0, cog * NCOB + c, ltid);
             __syncthreads();
             for (int grp = wave; grp < ngroups; grp += 4) {
                 const int p0 = 4 * grp, y = p0 / W, x = p0 % W;          // 4 consecutive pixels of one row = the K slice
-                const float b = tdy[(p0 + kq) * GEN_KC + l15];
-                bsum += b;
-                const float* ap = tin + ((size_t)(y * PW + x + kq)) * GEN_KC + l15;
+                float b[NCOB];
 #pragma unroll
-                for (int t = 0; t < 9; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[((t / 3) * PW + t % 3) * GEN_KC], b, acc[t], 0, 0, 0);
+                for (int c = 0; c < NCOB; ++c) {
+                    b[c] = (cog * NCOB + c < nblk) ? tdy[c * DYT + (p0 + kq) * GEN_KC + l15] : 0.f;
+                    bsum[c] += b[c];
+                }
+                const float* ap = tin + ((size_t)(y * PW + x + kq)) * GEN_KC;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    float a = ap[aoff[t]];
+                    if constexpr (SMALL) a = aok[t] ? a : 0.f;
+#pragma unroll
+                    for (int c = 0; c < NCOB; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[t][c], 0, 0, 0);
+                }
             }
             __syncthreads();
         }
     }
-    // ---- the four waves' partial blocks summed through LDS (fixed order), then the slab row ----
-    float* red = (float*)gsm;                                  // [3 waves][37][64]
-    if (wave > 0) {
+    // ---- the four waves' partial blocks summed through LDS (fixed order), one column block at a time; then the slab row ----
+    float* red = (float*)gsm;                                  // [3 waves][NV][64]
+    float* row = P.slab + (size_t)g * (9 * ci_total * co + co);
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+    for (int c = 0; c < NCOB; ++c) {
+        if (wave > 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) red[((wave - 1) * 37 + 4 * t + j) * 64 + lane] = acc[t][j];
-        red[((wave - 1) * 37 + 36) * 64 + lane] = bsum;
-    }
-    __syncthreads();
-    if (wave == 0) {
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t][j] += red[(w * 37 + 4 * t + j) * 64 + lane];
-            bsum += red[(w * 37 + 36) * 64 + lane];
+                for (int j = 0; j < 4; ++j) red[((wave - 1) * NV + 4 * t + j) * 64 + lane] = acc[t][c][j];
+            red[((wave - 1) * NV + 4 * NT) * 64 + lane] = bsum[c];
         }
-        const int col = cob * 16 + l15;
-        float* row = P.slab + (size_t)g * (9 * ci_total * co + co);
-        if (col < co) {
+        __syncthreads();
+        if (wave == 0) {
+            float bs = bsum[c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ci = gen_real_channel(P.in, cib * GEN_KC + 4 * kq + j);
-                if (ci < 0) continue;
+            for (int w = 0; w < 3; ++w) {
 #pragma unroll
-                for (int t = 0; t < 9; ++t) row[((size_t)t * ci_total + ci) * co + col] = acc[t][j];
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[t][c][j] += red[(w * NV + 4 * t + j) * 64 + lane];
+                bs += red[(w * NV + 4 * NT) * 64 + lane];
             }
+            const int col = (cog * NCOB + c) * 16 + l15;
+            if (col < co) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (SMALL) {      // row m = tap * ci_total + ci: the slab's own order
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int m = 16 * t + 4 * kq + j;
+                            if (m < 9 * ci_total) row[(size_t)m * co + col] = acc[t][c][j];
+                        }
+                    } else {
+                        const int ci = gen_real_channel(P.in, cib * GEN_KC + 4 * kq + j);
+                        if (ci < 0) continue;
+#pragma unroll
+                        for (int t = 0; t < 9; ++t) row[((size_t)t * ci_total + ci) * co + col] = acc[t][c][j];
+                    }
+                }
+            }
+            bs += __shfl_xor(bs, 16, 64);
+            bs += __shfl_xor(bs, 32, 64);
+            if (cib == 0 && kq == 0 && col < co) row[(size_t)9 * ci_total * co + col] = bs;
         }
-        bsum += __shfl_xor(bsum, 16, 64);
-        bsum += __shfl_xor(bsum, 32, 64);
-        if (cib == 0 && kq == 0 && col < co) row[(size_t)9 * ci_total * co + col] = bsum;
+        __syncthreads();
     }
 }
 
@@ -207,18 +256,20 @@ int ew_blocks(size_t items) { size_t b = (items + 255) / 256; return (int)(b < 1
 
 }  // namespace
 
-static int wgrad_groups(int n, int ncib, int ncob) {      // image shares: about 1024 workgroups in flight, at most one per image
-    int g = 1024 / (ncib * ncob);
-    if (g < 1) g = 1;
-    if (g > 64) g = 64;
+static int wgrad_per(int co) {      // blocks of 16 output channels per workgroup
+    const int nblk = (co + 15) / 16;
+    return nblk == 1 ? 1 : ((nblk == 2 || nblk == 4) ? 2 : 3);
+}
+static int wgrad_groups(int n, int ncib, int ncog) {      // image shares: about 1024 workgroups in flight, at most one per image
+    int g = (1024 + ncib * ncog - 1) / (ncib * ncog);
     return g < n ? g : n;
 }
 
 extern "C" int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co) {
     if (n < 0 || ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
     if (n == 0) return 0;
-    const int cp = ((ca + 3) & ~3) + cb;
-    return wgrad_groups(n, (cp + 15) / 16, (co + 15) / 16);
+    const int cp = ((ca + 3) & ~3) + cb, per = wgrad_per(co);
+    return wgrad_groups(n, (cp + 15) / 16, ((co + 15) / 16 + per - 1) / per);
 }
 
 extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
@@ -233,13 +284,17 @@ extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int
     P.in = GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1};
     P.dy = GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1};
     P.slab = slab; P.n = n; P.hw = hw; P.th = gen_strip_rows(hw);
-    const int cp = ((ca + 3) & ~3) + cb;
-    P.ncib = (cp + 15) / 16; P.ncob = (co + 15) / 16;
+    const int cp = ((ca + 3) & ~3) + cb, per = wgrad_per(co);
+    P.ncib = (cp + 15) / 16; P.ncob = ((co + 15) / 16 + per - 1) / per;
     P.G = wgrad_groups(n, P.ncib, P.ncob);
-    size_t lds = ((size_t)(P.th + 2) * (hw + 2) + (size_t)P.th * hw) * GEN_KC * sizeof(float);
+    size_t lds = ((size_t)(P.th + 2) * (hw + 2) + (size_t)per * P.th * hw) * GEN_KC * sizeof(float);
     const size_t red = (size_t)3 * 37 * 64 * sizeof(float);
     if (lds < red) lds = red;
-    hipLaunchKernelGGL(gen_conv3x3_wgrad_kernel, dim3(P.G * P.ncib * P.ncob), dim3(256), lds, (hipStream_t)stream, P);
+    const dim3 grid(P.G * P.ncib * P.ncob);
+    const bool small = cb == 0 && 9 * ca <= 32;       // the image layer: (tap, channel) pairs as the GEMM's rows
+    auto k = small ? (per == 1 ? gen_conv3x3_wgrad_kernel<1, true> : per == 2 ? gen_conv3x3_wgrad_kernel<2, true> : gen_conv3x3_wgrad_kernel<3, true>)
+                   : (per == 1 ? gen_conv3x3_wgrad_kernel<1, false> : per == 2 ? gen_conv3x3_wgrad_kernel<2, false> : gen_conv3x3_wgrad_kernel<3, false>);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
