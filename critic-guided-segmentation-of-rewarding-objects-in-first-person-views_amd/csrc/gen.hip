@@ -163,11 +163,20 @@ __global__ void __launch_bounds__(64) gen_gemm_kernel(GenGemmParams P) {
     const int row = m0 + l15, col = n0 + l15;
     const float* xr = P.x + (size_t)(row < P.m ? row : 0) * P.k;
     frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < P.k; k0 += 4) {
-        const int k = k0 + kq;
-        const float a = (row < P.m && k < P.k) ? xr[k] : 0.f;
-        const float b = (col < P.n && k < P.k) ? P.w[(size_t)k * P.n + col] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    const bool rok = row < P.m, cok = col < P.n;
+    const float* wc = P.w + (cok ? col : 0);
+    for (int k0 = 0; k0 < P.k; k0 += 32) {          // 8 k-steps per round: 16 independent loads in flight, then 8 MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq, kc = k < P.k ? k : P.k - 1;
+            a[u] = xr[kc];
+            b[u] = wc[(size_t)kc * P.n];
+            a[u] = (rok && k < P.k) ? a[u] : 0.f;
+            b[u] = (cok && k < P.k) ? b[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
     if (col < P.n) {
         const float bias = P.bias ? P.bias[col] : 0.f;

@@ -223,29 +223,45 @@ struct GenGemmExParams {
     float slope;
 };
 
-// one wave per 16 x 16 output tile; A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn]
-__global__ void __launch_bounds__(64) gen_gemm_ex_kernel(GenGemmExParams P) {
-    const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
+// one workgroup per 16 x 16 output tile, its 4 waves split the K rounds (summed in wave order through LDS);
+// A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn]
+__global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
+    __shared__ float red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
     const int ntn = (P.n + 15) / 16;
     const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
     const int row = m0 + l15, col = n0 + l15;
     const float* xr = P.x + (size_t)(row < P.m ? row : 0) * P.sxm;
     const float* wc = P.w + (size_t)(col < P.n ? col : 0) * P.swn;
     frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < P.k; k0 += 4) {
-        const int k = k0 + kq;
-        const float a = (row < P.m && k < P.k) ? xr[(size_t)k * P.sxk] : 0.f;
-        const float b = (col < P.n && k < P.k) ? wc[(size_t)k * P.swk] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    const bool rok = row < P.m, cok = col < P.n;
+    for (int k0 = 32 * wave; k0 < P.k; k0 += 128) {          // 8 k-steps per round: 16 independent loads in flight, then 8 MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq, kc = k < P.k ? k : P.k - 1;
+            a[u] = xr[(size_t)kc * P.sxk];
+            b[u] = wc[(size_t)kc * P.swk];
+            a[u] = (rok && k < P.k) ? a[u] : 0.f;
+            b[u] = (cok && k < P.k) ? b[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
     }
-    if (col < P.n) {
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[wave - 1][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0 && col < P.n) {
         const float bias = P.bias ? P.bias[col] : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = m0 + 4 * kq + j;
             if (r < P.m) {
                 float* o = P.out + (size_t)r * P.n + col;
-                const float v = gen_act(acc[j] + bias, P.act, P.slope);
+                const float sum = ((acc[j] + red[0][j][lane]) + red[1][j][lane]) + red[2][j][lane];
+                const float v = gen_act(sum + bias, P.act, P.slope);
                 *o = P.accumulate ? *o + v : v;
             }
         }
@@ -353,7 +369,7 @@ extern "C" int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, 
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (m == 0) return CGS_OK;
     GenGemmExParams P{x, w, bias, out, m, k, n, act, accumulate, (long)sxm, (long)sxk, (long)swk, (long)swn, slope};
-    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -153,8 +153,16 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
     conv3x3(embeds[1], o["o2"], off("dec_model.1.weight"), off("dec_model.1.bias"), d[1], out=o["o1"])
     conv3x3(embeds[0], o["o1"], off("dec_model.0.weight"), off("dec_model.0.bias"), d[0], out=o["o0"])
     conv3x3(x, o["o0"], off("masker.0.weight"), off("masker.0.bias"), masker_channels, act="lrelu", slope=0.01, out=o["hm"])
-    conv3x3(o["hm"], None, off("masker.2.weight"), off("masker.2.bias"), 1, act="sigmoid", out=o["Z"].view(n, 64, 64, 1))
+    if masker_channels == 16:      # the mask layer (16 -> 1) has the same shape at every chfak: the fixed-shape kernel
+        _lib.call("cgs_conv3x3_fwd", C.byref(_mask2_desc(n)), _p(o["hm"]), None, C.c_void_p(off("masker.2.weight")),
+                  C.c_void_p(off("masker.2.bias")), _p(o["Z"]), None, _s())
+    else:
+        conv3x3(o["hm"], None, off("masker.2.weight"), off("masker.2.bias"), 1, act="sigmoid", out=o["Z"].view(n, 64, 64, 1))
     return o
+
+
+def _mask2_desc(n: int) -> _lib.ConvDesc:
+    return _lib.ConvDesc(n, 64, 64, 16, 0, 1, _lib.SRC_F32, 2, _lib.ACT_SIGMOID, 0, _lib.Dropout(0.0, 0, 0, None, 0, 0))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -273,10 +281,19 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
     n, dev, mc = x.shape[0], x.device, masker_channels
     dzp = dzpre.view(n, 64, 64, 1)
     # masker.2 (16 -> 1, sigmoid handled by the caller) and the LeakyReLU(0.01) in front of it
-    _wgrad(plan, ws, "mask2", goff + lay.off("masker.2.weight"), n, 64, m["hm"], None, 2, dzp, None, 1)
     d_hm = ws.buf("d_hm", (n, 64, 64, mc), dev)
-    _bwd_data(n, 64, 1, mc, dzp, None, _flip(ws, flat, lay, "masker.2", mc, 1), d_hm)
-    grad_fix(d_hm, saved=m["hm"], act="lrelu", slope=0.01)
+    if mc == 16:       # fixed-shape kernels of the mask layer (LeakyReLU' fused into the data gradient)
+        d2 = _mask2_desc(n)
+        nsl = _lib.load().cgs_conv3x3_bwd_weight_slabs(C.byref(d2))
+        slab = ws.buf("slab_mask2", (nsl, 9 * mc + 1), dev)
+        _lib.call("cgs_conv3x3_bwd_weight", C.byref(d2), _p(m["hm"]), None, _p(dzpre), None, _p(slab), _s())
+        plan.add(slab, nsl, 9 * mc + 1, goff + lay.off("masker.2.weight"))
+        _lib.call("cgs_conv3x3_bwd_data", C.byref(d2), _p(dzpre), None, C.c_void_p(off("masker.2.weight")), _p(m["hm"]), _lib.ACT_LRELU,
+                  None, 0, _p(d_hm), None, _s())
+    else:
+        _wgrad(plan, ws, "mask2", goff + lay.off("masker.2.weight"), n, 64, m["hm"], None, 2, dzp, None, 1)
+        _bwd_data(n, 64, 1, mc, dzp, None, _flip(ws, flat, lay, "masker.2", mc, 1), d_hm)
+        grad_fix(d_hm, saved=m["hm"], act="lrelu", slope=0.01)
     # masker.0 over cat(X, up2(o0))
     _wgrad(plan, ws, "mask0", goff + lay.off("masker.0.weight"), n, 64, x, m["o0"], 2, d_hm, None, mc)
     dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)
