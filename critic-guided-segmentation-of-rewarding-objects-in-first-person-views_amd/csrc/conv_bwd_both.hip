@@ -5,16 +5,16 @@
 // the rest run the VALU data-gradient body, so the two overlap on the chip without a second stream (cross-queue
 // joins inside a HIP graph cost 6-10 us each on ROCm 7.2, more than they gain).
 #include "conv_body.h"
-#include "wgrad_body.h"
+#include "wgrad_sparse.h"
 #include <cstdlib>
 
-template <class CWG, class CDG>
+template <class CWG, class CDG, bool SPARSE>
 __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradParams pw, ConvParams pd, int nbw) {
     static_assert(CWG::G::THREADS == CDG::THREADS * CDG::CW, "both halves use the same workgroup size");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     if ((int)blockIdx.x < nbw) {
         constexpr int SLAB = (9 * (CWG::CA + CWG::CB) + 1) * CWG::CO;
-        wgrad_body<CWG>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+        wgrad_dispatch<CWG, SPARSE>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
     } else {
         conv3x3_body<CDG, false>(pd, blockIdx.x - nbw, smem);
     }
@@ -31,11 +31,19 @@ struct WMask0F32x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC 
 static constexpr int kMaxBothWgradBlocks = 256;
 static constexpr int kMaxBothWgradBlocksBig = 512;
 
+static constexpr int kMaxBothSparseBlocks = 512;     // the sparse form is latency-bound: more, smaller workgroups
+template <class CWG>
+static constexpr bool both_sparse_ok = sparse_cfg<CWG>::ok;
 template <class CWG>
 static int both_slabs(int n) {
     using GW = typename CWG::G;
     int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
     int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
+    if (both_sparse_ok<CWG> && wgrad_sparse_enabled()) {
+        static const int cap32 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH_BLOCKS"); return e ? atoi(e) : 256; }();
+        static const int cap64 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH0_BLOCKS"); return e ? atoi(e) : kMaxBothSparseBlocks; }();
+        cap = GW::H >= 64 ? cap64 : cap32;
+    }
     return tiles < cap ? tiles : cap;
 }
 
@@ -48,8 +56,17 @@ static int launch_both(WgradParams pw, const ConvParams& pd, hipStream_t st) {
     int nbw = both_slabs<CWG>(pw.n);
     int nbd = (GD::IMGS == 1) ? pd.n * GD::STRIPS : (pd.n + GD::IMGS - 1) / GD::IMGS;
     pw.ntiles = tiles;
-    size_t lw = wgrad_lds_bytes<CWG>(), ld = conv_lds_bytes<CDG>();
-    hipLaunchKernelGGL((conv_bwd_both_kernel<CWG, CDG>), dim3(nbw + nbd), dim3(GW::THREADS), lw > ld ? lw : ld, st, pw, pd, nbw);
+    const size_t ld = conv_lds_bytes<CDG>();
+    if constexpr (sparse_cfg<CWG>::ok) {
+        if (wgrad_sparse_enabled()) {
+            const size_t lw = wgrad_any_lds_bytes<CWG, true>();
+            hipLaunchKernelGGL((conv_bwd_both_kernel<CWG, CDG, true>), dim3(nbw + nbd), dim3(GW::THREADS), lw > ld ? lw : ld, st, pw, pd, nbw);
+            CGS_HIP_CHECK_LAUNCH();
+            return CGS_OK;
+        }
+    }
+    const size_t lw = wgrad_lds_bytes<CWG>();
+    hipLaunchKernelGGL((conv_bwd_both_kernel<CWG, CDG, false>), dim3(nbw + nbd), dim3(GW::THREADS), lw > ld ? lw : ld, st, pw, pd, nbw);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -133,14 +150,14 @@ struct MixBwdArgs {
     const float* vf_pred;
 };
 
-template <class CWG>
+template <class CWG, bool SPARSE>
 __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw) {
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     if ((int)blockIdx.x < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;
-        wgrad_body<CWG>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+        wgrad_dispatch<CWG, SPARSE>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
         return;
     }
     const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
@@ -170,12 +187,14 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale, valuefak_pred};
     const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
     const int nbd = n_a * GD::STRIPS;
-    size_t lw = wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
-    const size_t lds = lw > ld ? lw : ld;                    // 41 KB: three workgroups per CU
-    if (mixed || !slab)        // materialised mixes (or no weight gradient at all)
-        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0F32>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
-    else                       // weight-gradient input = the mixes recomputed from a, b, z in the tile loader
-        hipLaunchKernelGGL(enc0_bwd_mix_kernel<WEnc0Mix>, dim3(nbw + nbd), dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
+    const bool sp = wgrad_sparse_enabled() != 0;
+    const size_t lw = sp ? wgrad_any_lds_bytes<WEnc0F32, true>() : wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
+    const size_t lds = lw > ld ? lw : ld;                    // 41 KB (data-gradient tile): three workgroups per CU
+    const dim3 grid(nbw + nbd);
+    auto k = (mixed || !slab)       // materialised mixes (or no weight gradient at all) / mixes recomputed in the tile loader
+                 ? (sp ? enc0_bwd_mix_kernel<WEnc0F32, true> : enc0_bwd_mix_kernel<WEnc0F32, false>)
+                 : (sp ? enc0_bwd_mix_kernel<WEnc0Mix, true> : enc0_bwd_mix_kernel<WEnc0Mix, false>);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -11,7 +11,7 @@
 // LDS tiles keep the NHWC order of global memory: X tile [img][TH+2][W+2][CI] with the concat of the
 // skip input and the nearest-upsampled low-res input materialised (zero halo), dY tile [img][TH][W][CO].
 // Lanes (r = lane&15, pixel = lane>>4) then read consecutive floats: bank-conflict free.
-#include "wgrad_body.h"
+#include "wgrad_sparse.h"
 
 static constexpr int kMaxWgradBlocks = 1024;
 
@@ -20,14 +20,41 @@ static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMG
 template <class G>
 static int wg_blocks(int n) { int t = wg_tiles<G>(n); return t < kMaxWgradBlocks ? t : kMaxWgradBlocks; }
 
+template <class C, bool SPARSE>
+__global__ void __launch_bounds__(C::G::THREADS) wgrad_any_kernel(WgradParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    constexpr int SLAB = (9 * (C::CA + C::CB) + 1) * C::CO;
+    wgrad_dispatch<C, SPARSE>(P, blockIdx.x, gridDim.x, P.ntiles, P.slab + (size_t)blockIdx.x * SLAB, smem);
+}
+
+// the sparse form is latency-bound with small tiles: more workgroups in flight than the MFMA form wants
+static constexpr int kMaxSparseBlocks = 512;
+template <class C>
+static int wg_blocks_any(int n) {
+    using G = typename C::G;
+    if (sparse_cfg<C>::ok && wgrad_sparse_enabled()) {
+        static const int cap = [] { const char* e = std::getenv("CGS_SPARSE_BLOCKS"); return e ? atoi(e) : kMaxSparseBlocks; }();
+        int t = wg_tiles<G>(n);
+        return t < cap ? t : cap;
+    }
+    return wg_blocks<G>(n);
+}
+
 template <class C>
 static int launch_wgrad(WgradParams P, hipStream_t st) {
     using G = typename C::G;
-    constexpr int CI = C::CA + C::CB;
-    size_t lds = wgrad_lds_bytes<C>();
     P.ntiles = wg_tiles<G>(P.n);
     if (P.ntiles == 0) return CGS_OK;
-    hipLaunchKernelGGL(wgrad_kernel<C>, dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
+    if constexpr (sparse_cfg<C>::ok) {
+        if (wgrad_sparse_enabled()) {
+            const size_t lds = wgrad_any_lds_bytes<C, true>();
+            hipLaunchKernelGGL((wgrad_any_kernel<C, true>), dim3(wg_blocks_any<C>(P.n)), dim3(G::THREADS), lds, st, P);
+            CGS_HIP_CHECK_LAUNCH();
+            return CGS_OK;
+        }
+    }
+    const size_t lds = wgrad_lds_bytes<C>();
+    hipLaunchKernelGGL((wgrad_any_kernel<C, false>), dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -41,7 +68,7 @@ static bool wdesc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int
 extern "C" int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d) {
     if (!d || d->n < 0) return CGS_ERR_BADARG;
     const int n = d->n;
-#define SLABS(CFG) return wg_blocks<typename CFG::G>(n)
+#define SLABS(CFG) return wg_blocks_any<CFG>(n)
     if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, 1)) SLABS(WEnc0U8);
     if (wdesc_is(d, 64, 3, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc0F32);
     if (wdesc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, 1)) SLABS(WEnc1);

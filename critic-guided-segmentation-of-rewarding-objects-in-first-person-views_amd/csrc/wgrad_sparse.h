@@ -1,0 +1,284 @@
+// Weight gradient of a max-pooled ReLU layer (features.0: 3 -> 8 at 64x64, features.3: 8 -> 8 at 32x32) from the SPARSE
+// pre-pool gradient.  Behind MaxPool2d(2) + ReLU only ONE position of every 2x2 window carries a gradient (and none where the
+// pooled value is <= 0), per output channel: the dense product  dW[tap][ci][co] = sum_p X[p + tap][ci] dY[p][co]  (what the MFMA
+// form computes, 3 of 4 rows of dY being zero, half of every 16-wide tile being padding at co = 8) collapses to
+//     dW[tap][ci][co] = sum_cells X[p(cell, co) + tap][ci] * dE[cell][co],       p(cell, co) = the window's argmax position
+// -- a quarter of the multiply-adds, on the VALU: one thread per (pool cell, output channel) pair reads the 3x3 input patch
+// at ITS argmax position from the LDS tile (float4 per pixel slot: 9 or 18 reads) and keeps the full [9][CI] block of its
+// output channel in registers; the pairs of a lane are reduced by lane shuffles once per workgroup.  LDS-read-bound.
+#pragma once
+#include "wgrad_body.h"
+#include <cstdlib>
+
+// H = W = 64 (CA = 3, sources: uint8 frames, the virtual mixes, fp32 images) or 32 (CA = 8, fp32); CO = 8; 256 threads
+template <int H_, int CA_, int SRC_>
+struct SpCfg {
+    static constexpr int H = H_, W = H_, CA = CA_, SRC = SRC_, CO = 8, THREADS = 256;
+    static constexpr int S = (CA + 3) / 4;                     // float4 slots per pixel
+    static constexpr int CPR = W / 2, CROWS = 128 / CPR;       // pool cells per row; cell rows per tile (128 cells = 1024 pairs)
+    static constexpr int TH = 2 * CROWS, STRIPS = H / TH, TRA = TH + 2;
+    static constexpr int PW = (S == 1) ? W + 4 : W + 2;        // pixel slots per row
+    // row stride in dwords.  CA = 3: 274 = 2 (mod 8): the lanes of a wave read the slots of 8 neighbouring cells (8 dwords apart),
+    // either pixel column of the window (+4) and either row (+274 = 18 mod 64): all 32 addresses fall into different banks for
+    // each of the 3 dwords read; rows are then 8-byte aligned (reads: b64 + b32).  CA = 8: 272 (16-byte aligned b128 reads).
+    static constexpr int RS = (S == 1) ? 274 : 272;
+    static constexpr int NACC = 9 * CA + 1;                    // + the bias row
+    static_assert((H == 64 && CA == 3) || (H == 32 && CA == 8), "features.0 / features.3");
+    static_assert(PW * S * 4 <= RS, "row stride");
+};
+
+template <class C>
+static constexpr size_t wgrad_sparse_lds_bytes() {
+    constexpr size_t tile = (size_t)C::TRA * C::RS * 4 + 16, red = (size_t)C::NACC * 256 * 4;
+    return tile > red ? tile : red;
+}
+
+// Processes tiles tile0, tile0 + tstride, ... < tend (tile = image * STRIPS + strip) and writes ONE slab [9 CA + 1][8].
+template <class C>
+__device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const int tile0, const int tstride, const int tend,
+                                                  float* slab, float4* smem) {
+    constexpr int W = C::W, H = C::H, S = C::S, PW = C::PW, TH = C::TH, CA = C::CA;
+    constexpr int HP = H / 2, WP = W / 2;
+    float* xt = (float*)smem;                                  // [TRA] rows of RS dwords, [PW][S] float4 slots in a row
+    constexpr int RS = C::RS;
+    auto slot_store = [&](int r, int slot, const float4& v) {  // (rows may be only 8-byte aligned)
+        float2* q = (float2*)(xt + r * RS + 4 * slot);
+        q[0] = make_float2(v.x, v.y);
+        q[1] = make_float2(v.z, v.w);
+    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int co = tid & 7, cell0 = tid >> 3;                  // pairs of this thread: cells cell0 + 32 k, k = 0..3
+    const int N = P.n;
+
+    // the zero halo columns are written once: no tile ever stores there
+    for (int e = tid; e < C::TRA * (PW - W) * S; e += 256) {
+        const int s = e % S, c = (e / S) % (PW - W), r = e / (S * (PW - W));
+        slot_store(r, (c == 0 ? 0 : W + c) * S + s, f4zero());
+    }
+
+    // ---- X tile: fetch (global -> registers) / commit (registers -> LDS); interior columns 1..W of rows row0-1 .. row0+TH ----
+    constexpr int NG = C::TRA * W / 4;                         // CA = 3: groups of 4 pixels (12 bytes / 3 dwords)
+    constexpr int ITG = (NG + 255) / 256;
+    constexpr int NF = C::TRA * W * S, ITF = (NF + 255) / 256; // CA = 8 (or fp32 images): float4 elements
+    // what is fetched for a tile: its X rows (raw) and its pairs (gradient at the pooled output, argmax nibble).  TWO tiles are in
+    // flight: a tile's FMA phase is much shorter than a memory round trip, one tile ahead leaves the loop latency-bound.
+    struct Stage {
+        uint32_t ga[ITG][3], gb[ITG][3];
+        float4 gz[ITG];
+        float4 gf[(C::SRC == WSRC_F32) ? ITF : 1];
+        float pval[4];
+        uint32_t pnib[4];
+    };
+    Stage stg[2];
+    auto fetch = [&](int tile, Stage& R) {
+        auto& ga = R.ga; auto& gb = R.gb; auto& gz = R.gz; auto& gf = R.gf; auto& pval = R.pval; auto& pnib = R.pnib;
+        const int n = tile / C::STRIPS, row0 = (tile % C::STRIPS) * TH;
+        {
+            const int crow0 = (tile % C::STRIPS) * C::CROWS;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cell = cell0 + 32 * k, cy = crow0 + cell / C::CPR, cx = cell % C::CPR;
+                const int pi = (n * HP + cy) * WP + cx;
+                pval[k] = P.dy[(size_t)pi * 8 + co];
+                pnib[k] = (P.amask[pi] >> (4 * co)) & 15u;
+            }
+        }
+        if constexpr (C::SRC == WSRC_F32 && CA == 8) {
+#pragma unroll
+            for (int it = 0; it < ITF; ++it) {
+                int e = tid + 256 * it; e = e < NF ? e : NF - 1;
+                const int s = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
+                const bool in = y >= 0 && y < H;
+                gf[it] = ((const float4*)P.src_a)[in ? ((n * H + y) * W + x) * S + s : 0];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITG; ++it) {
+                int e = tid + 256 * it; e = e < NG ? e : NG - 1;
+                const int g = e % (W / 4), r = e / (W / 4), y = row0 + r - 1;
+                const bool in = y >= 0 && y < H;
+                int nn = n;
+                if constexpr (C::SRC == WSRC_MIX) nn = n >= P.mix_n_a ? n - P.mix_n_a : n;       // mixes of A-image nn
+                const int pix = in ? (nn * H + y) * W + 4 * g : 0;
+                if constexpr (C::SRC == WSRC_MIX) {
+                    const uint32_t* a32 = (const uint32_t*)P.mix_a + (pix * 3) / 4;
+                    const uint32_t* b32 = (const uint32_t*)P.mix_b + (pix * 3) / 4;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) { ga[it][d] = a32[d]; gb[it][d] = b32[d]; }
+                    gz[it] = *(const float4*)(P.mix_z + pix);
+                } else if constexpr (C::SRC == WSRC_U8) {
+                    const uint32_t* a32 = (const uint32_t*)P.src_a + (pix * 3) / 4;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d) ga[it][d] = a32[d];
+                } else {      // fp32 image, 3 channels: 12 floats = 3 float4
+                    const float4* f = (const float4*)((const float*)P.src_a + (size_t)pix * 3);
+                    const float4 v0 = f[0], v1 = f[1], v2 = f[2];
+                    ga[it][0] = __float_as_uint(v0.x); ga[it][1] = __float_as_uint(v0.y); ga[it][2] = __float_as_uint(v0.z);
+                    gb[it][0] = __float_as_uint(v0.w); gb[it][1] = __float_as_uint(v1.x); gb[it][2] = __float_as_uint(v1.y);
+                    gz[it] = make_float4(v1.z, v1.w, v2.x, v2.y);
+                    gf[0] = make_float4(v2.z, v2.w, 0.f, 0.f);
+                }
+            }
+        }
+    };
+    auto commit = [&](int tile, const Stage& R) {
+        auto& ga = R.ga; auto& gb = R.gb; auto& gz = R.gz; auto& gf = R.gf;
+        const int n = tile / C::STRIPS, row0 = (tile % C::STRIPS) * TH;
+        if constexpr (C::SRC == WSRC_F32 && CA == 8) {
+#pragma unroll
+            for (int it = 0; it < ITF; ++it) {
+                const int e = tid + 256 * it;
+                if (e < NF) {
+                    const int s = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
+                    slot_store(r, (x + 1) * S + s, (y >= 0 && y < H) ? gf[it] : f4zero());
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITG; ++it) {
+                const int e = tid + 256 * it;
+                if (e < NG) {
+                    const int g = e % (W / 4), r = e / (W / 4), y = row0 + r - 1;
+                    const bool in = y >= 0 && y < H;
+                    float4 px[4];
+                    if constexpr (C::SRC == WSRC_F32) {
+                        static_assert(ITG == 1, "fp32 images: one group of 4 pixels per thread");
+                        px[0] = make_float4(__uint_as_float(ga[it][0]), __uint_as_float(ga[it][1]), __uint_as_float(ga[it][2]), 0.f);
+                        px[1] = make_float4(__uint_as_float(gb[it][0]), __uint_as_float(gb[it][1]), __uint_as_float(gb[it][2]), 0.f);
+                        px[2] = make_float4(gz[it].x, gz[it].y, gz[it].z, 0.f);
+                        px[3] = make_float4(gz[it].w, gf[0].x, gf[0].y, 0.f);
+                    } else {
+                        const float sc = 1.f / 255.f;
+                        const bool inj = C::SRC == WSRC_MIX && n >= P.mix_n_a;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            float m[3];
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const int byte = 3 * k + c;
+                                float av = ((ga[it][byte >> 2] >> (8 * (byte & 3))) & 255u) * sc;
+                                if constexpr (C::SRC == WSRC_MIX) {
+                                    float bv = ((gb[it][byte >> 2] >> (8 * (byte & 3))) & 255u) * sc;
+                                    if (inj) { const float t = av; av = bv; bv = t; }
+                                    const float zi = f4get(gz[it], k);
+                                    m[c] = av * (1.f - zi) + zi * bv;
+                                } else {
+                                    m[c] = av;
+                                }
+                            }
+                            px[k] = make_float4(m[0], m[1], m[2], 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) slot_store(r, 4 * g + k + 1, in ? px[k] : f4zero());
+                }
+            }
+        }
+    };
+
+    float acc[9][CA];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CA; ++c) acc[t][c] = 0.f;
+
+    auto process = [&](int tile, Stage& R) {
+        float val[4];
+        uint32_t nib[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { val[k] = R.pval[k]; nib[k] = R.pnib[k]; }
+        commit(tile, R);
+        __syncthreads();
+        if (tile + 2 * tstride < tend) fetch(tile + 2 * tstride, R);      // the stage is free again: two tiles ahead
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cell = cell0 + 32 * k, cyl = cell / C::CPR, cx = cell % C::CPR;
+            const bool dead = nib[k] > 3u;
+            const float v = dead ? 0.f : val[k];
+            const int pos = dead ? 0 : (int)nib[k];
+            const float* p = xt + (2 * cyl + (pos >> 1)) * RS + (2 * cx + (pos & 1)) * 4 * S;      // patch origin (tile has the halo)
+            bsum += v;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float* q = p + (t / 3) * RS + (t % 3) * 4 * S + 4 * s;
+                    if constexpr (CA % 4 == 0) {
+                        const float4 x = *(const float4*)q;
+                        acc[t][4 * s] = fmaf(x.x, v, acc[t][4 * s]);
+                        acc[t][4 * s + 1] = fmaf(x.y, v, acc[t][4 * s + 1]);
+                        acc[t][4 * s + 2] = fmaf(x.z, v, acc[t][4 * s + 2]);
+                        acc[t][4 * s + 3] = fmaf(x.w, v, acc[t][4 * s + 3]);
+                    } else {
+                        const float2 x01 = *(const float2*)q;
+                        const float x2 = q[2];
+                        acc[t][0] = fmaf(x01.x, v, acc[t][0]);
+                        acc[t][1] = fmaf(x01.y, v, acc[t][1]);
+                        acc[t][2] = fmaf(x2, v, acc[t][2]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    };
+    int tile = tile0;
+    if (tile < tend) fetch(tile, stg[0]);
+    if (tile + tstride < tend) fetch(tile + tstride, stg[1]);
+    while (tile < tend) {
+        process(tile, stg[0]);
+        tile += tstride;
+        if (tile >= tend) break;
+        process(tile, stg[1]);
+        tile += tstride;
+    }
+
+    // ---- every lane's block through LDS, then thread (row, co) sums the 32 lanes of its output channel in a fixed order ----
+    float* red = (float*)smem;                                 // [NACC][256]
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < CA; ++c) red[(t * CA + c) * 256 + tid] = acc[t][c];
+    red[9 * CA * 256 + tid] = bsum;
+    __syncthreads();
+    for (int i = tid; i < C::NACC * 8; i += 256) {
+        const int r = i >> 3, c = i & 7;
+        const float* src = red + r * 256 + c;                  // lanes c, c + 8, ...: stride 8 floats
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) v += src[8 * j];
+        slab[i] = v;
+    }
+    __syncthreads();   // the LDS region may be reused by a following stage
+}
+
+// ---- which MFMA weight-gradient configurations have a sparse form (same tiles: image x strips of 8 / 16 rows) ----
+template <class CWG> struct sparse_cfg { static constexpr bool ok = false; using type = void; };
+template <> struct sparse_cfg<WEnc0U8> { static constexpr bool ok = true; using type = SpCfg<64, 3, WSRC_U8>; };
+template <> struct sparse_cfg<WEnc0F32> { static constexpr bool ok = true; using type = SpCfg<64, 3, WSRC_F32>; };
+template <> struct sparse_cfg<WEnc0Mix> { static constexpr bool ok = true; using type = SpCfg<64, 3, WSRC_MIX>; };
+template <> struct sparse_cfg<WEnc1> { static constexpr bool ok = true; using type = SpCfg<32, 8, WSRC_F32>; };
+
+// SPARSE is a compile-time choice per kernel instance (a kernel that carries both bodies pays the registers and the LDS of the
+// bigger one); the host picks the instance (CGS_WGRAD_SPARSE, default on where a sparse form exists).
+template <class CWG, bool SPARSE>
+__device__ __forceinline__ void wgrad_dispatch(const WgradParams& P, const int tile0, const int tstride, const int tend,
+                                               float* slab, float4* smem) {
+    if constexpr (SPARSE) {
+        static_assert(sparse_cfg<CWG>::ok && CWG::G::THREADS == 256 && CWG::G::STRIPS == sparse_cfg<CWG>::type::STRIPS, "same tiling");
+        wgrad_sparse_body<typename sparse_cfg<CWG>::type>(P, tile0, tstride, tend, slab, smem);
+    } else {
+        wgrad_body<CWG>(P, tile0, tstride, tend, slab, smem);
+    }
+}
+
+template <class CWG, bool SPARSE>
+static constexpr size_t wgrad_any_lds_bytes() {
+    if constexpr (SPARSE) return wgrad_sparse_lds_bytes<typename sparse_cfg<CWG>::type>();
+    else return wgrad_lds_bytes<CWG>();
+}
+
+static inline int wgrad_sparse_enabled() {
+    static const int on = [] { const char* e = std::getenv("CGS_WGRAD_SPARSE"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on;
+}
