@@ -33,7 +33,8 @@ template <class C>
 static int wg_blocks_any(int n) {
     using G = typename C::G;
     if (sparse_cfg<C>::ok && wgrad_sparse_enabled()) {
-        static const int cap = [] { const char* e = std::getenv("CGS_SPARSE_BLOCKS"); return e ? atoi(e) : kMaxSparseBlocks; }();
+        static const int ecap = [] { const char* e = std::getenv("CGS_SPARSE_BLOCKS"); return e ? atoi(e) : 0; }();
+        const int cap = ecap ? ecap : (G::H >= 64 ? 2 * kMaxSparseBlocks : kMaxSparseBlocks);      // measured: 1024 / 512
         int t = wg_tiles<G>(n);
         return t < cap ? t : cap;
     }
