@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer", "phase1", "cli-train"], default="train",
                     help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
                          "phase1 = critic regression step (main.py:183-200)")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="stand-alone weight-gradient kernels on a second stream (parallel graph branch)")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=8)
@@ -319,7 +320,8 @@ def main():
         return generic_mode(args, dev, rank)
     if args.mode != "train":
         return side_mode(args, dev, world, rank)
-    eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg)
+    eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg,
+                                 overlap_wgrad=args.overlap_wgrad)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
     eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture
