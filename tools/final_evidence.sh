@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (GPU box): tools/final_evidence.sh   -> everything the round's profiles/ files are made from, under gpurun_out/final/
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/final
+mkdir -p $out
+cd $root
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { tail -5 $out/smoke.log; exit 1; }
+python bench.py > $out/bench.json 2> $out/bench.err || exit 1
+python bench.py --chfak 5 --steps 20 --warmup 3 > $out/bench_chfak5_train.json 2>/dev/null || exit 1
+python bench.py --chfak 5 --mode infer --steps 20 --warmup 3 > $out/bench_chfak5_infer.json 2>/dev/null || exit 1
+python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 > $out/bench_infer2048.json 2>/dev/null || exit 1
+python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16-mask-head > $out/bench_infer2048_f16head.json 2>/dev/null || exit 1
+python bench.py --mode cli-train > $out/bench_cli_train.json 2>/dev/null || exit 1
+python bench.py --mode phase1 > $out/bench_phase1.json 2>/dev/null || exit 1
+tools/prof.sh final/prof || exit 1
+tools/prof_generic.sh final/prof_chfak5 > $out/prof_chfak5.txt 2>&1 || exit 1
+tools/sq_counters.sh final/pmc || exit 1
+python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.csv && python tools/traffic_from_counters.py gpurun_out/final/sq_counters.csv gpurun_out/final/traffic.json 512
+tail -1 $out/bench.json | cut -c1-300
