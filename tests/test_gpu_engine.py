@@ -269,3 +269,31 @@ def test_saliency_gradient_matches_oracle_autograd(g1):
     assert np.abs(got - want).max() <= 1e-3 * scale + 1e-9, (np.abs(got - want).max(), scale)
     # the map the reference thresholds: |grad| summed over the colour channels
     np.testing.assert_allclose(np.abs(got).sum(-1), np.abs(want).sum(-1), rtol=2e-3, atol=2e-3 * scale)
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 33])
+def test_ragged_batch_sizes_vs_oracle(g1, n):
+    """The last batch of an epoch has any size (main.py's DataLoader keeps it): phase 2 and phase 1 at odd / tiny n against the
+    oracle -- losses, all gradients (weight-gradient tiles, slab counts and the image loops of the tail kernels all depend on n)."""
+    rs = np.random.RandomState(100 + n)
+    dev = torch.device("cuda:0")
+    A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    pc, pm = g1
+    e = make_engine(g1, n, dropout=0.0)
+    losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    rec = orc.train_phase2(pc, pm, [(orc.u8_to_nchw(A), orc.u8_to_nchw(B), torch.from_numpy(Y))], steps=1)[0]
+    assert losses[5] == pytest.approx(rec["total"], rel=1e-3)
+    gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+    for k, v in rec["grads_c"].items():
+        rel_close(gc[k].cpu().numpy(), v.numpy(), f"critic grad {k} (n={n})")
+    for k, v in rec["grads_m"].items():
+        rel_close(gm[k].cpu().numpy(), v.numpy(), f"masker grad {k} (n={n})")
+    e1 = make_engine(g1, n, dropout=0.0)
+    l1 = e1.phase1_step(torch.from_numpy(A).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    r1 = orc.train_phase1(pc, [(orc.u8_to_nchw(A), torch.from_numpy(Y))], steps=1, p=0.0)[0]
+    assert l1[0] == pytest.approx(r1["loss"], rel=1e-3)
+    g1c = e1.lc.unflatten(e1.gc)
+    for k, v in r1["grads"].items():
+        rel_close(g1c[k].cpu().numpy(), v.numpy(), f"phase-1 grad {k} (n={n})")
