@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer", "phase1", "cli-train"], default="train",
                     help="train = the headline phase-2 step (default); infer = eval-mode critic+masker (main.py:1130-1151); "
                          "phase1 = critic regression step (main.py:183-200)")
+    ap.add_argument("--fp16", action="store_true",
+                    help="--mode infer only: BASELINE config 4 -- fp16 activations and weights in every layer, fp32 accumulation (opt-in precision)")
     ap.add_argument("--overlap-wgrad", action="store_true", help="stand-alone weight-gradient kernels on a second stream (parallel graph branch)")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,6 +211,12 @@ def generic_mode(args, dev, rank):
         # gradients on [A|rep|inj]; masker data + weight gradients
         flops = 4 * fcf + fmf + (6 * fcf - l0) + 2 * fmf
         what = f"phase-2 step (main.py:344-463), N_A = N_B = {n}, dropout {args.dropout}, chfak {cf}: shape-generic MFMA kernels"
+    elif args.fp16:
+        eng = generic_engine.GenericEngine(n, chfak=cf, device=dev, dropout=args.dropout)
+        eng.load_state(seeded_state(lc, 11), seeded_state(lm, 12))
+        run = lambda: eng.infer(A, fp16=True)
+        flops = fcf + fmf
+        what = f"eval-mode critic(collect) + masker forward, chfak {cf}: fp16 activations / weights, fp32 accumulate (priced against the fp32 peak)"
     else:
         fc, fm = torch.empty(lc.total, device=dev), torch.empty(lm.total, device=dev)
         lc.flatten({k: v.to(dev) for k, v in seeded_state(lc, 11).items()}, fc)
@@ -245,8 +253,11 @@ def side_mode(args, dev, world, rank):
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
     if args.mode == "infer":
-        run = lambda: eng.infer(A, fp16_mask_head=args.fp16_mask_head)
+        run = lambda: eng.infer(A, fp16_mask_head=args.fp16_mask_head, fp16=args.fp16)
         bytes_per_img, what = 1.126e6, "eval-mode critic(collect)+masker forward, fp32 (SURVEY 8d: 0.563 MB/img at fp16 -> 1.126 MB fp32)"
+        if args.fp16:
+            bytes_per_img, what = 0.563e6, ("eval-mode critic(collect)+masker forward, fp16 activations and weights in every layer, fp32 "
+                                           "accumulate (BASELINE config 4; SURVEY 8d: 0.563 MB/img at fp16)")
         if args.fp16_mask_head:
             what += "; masker.0 GEMM with fp16 operands / fp32 accumulate, everything else fp32"
     else:
@@ -264,7 +275,8 @@ def side_mode(args, dev, world, rank):
     ach = bytes_per_img * n / dt / 1e9
     print(json.dumps({"metric": f"Hourglass {args.mode} images/sec, 64x64x3 batch={n}", "value": n / dt, "unit": "images/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
-                      "dtype": "f32+f16 mask-head operands" if (args.mode == "infer" and args.fp16_mask_head) else "f32",
+                      "dtype": "f16 (f32 accumulate)" if (args.mode == "infer" and args.fp16) else
+                               ("f32+f16 mask-head operands" if (args.mode == "infer" and args.fp16_mask_head) else "f32"),
                       "data": "synthetic", "config": {"workload": what, "batch": n},
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                    "traffic": None}}), flush=True)

@@ -96,6 +96,10 @@ SIGNATURES = {
     "cgs_gen_dropout_fwd": (i32, [i64, vp, vp, Dropout, vp]),
     "cgs_gen_gemm_ex": (i32, [i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i32, f32, i32, vp, vp]),
     "cgs_gen_u8_to_f32": (i32, [i64, vp, vp, vp]),
+    "cgs_gen16_packed_weight_halves": (i64, [i32, i32, i32]),
+    "cgs_gen16_pack_weights": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_gen16_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen16_gemm": (i32, [i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_fwd": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_data": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -16,6 +16,8 @@ def build_parser():
                  "-grabcut", "-crf", "-directeval", "-soft", "-resimages", "-noevalmode", "-eval", "-process", "-test",
                  "-concatenated", "-softmask"):
         p.add_argument(flag, action="store_true")
+    # (this build's own switch, not a flag of the reference) -process / -eval with fp16 activations and weights, fp32 accumulation
+    p.add_argument("-fp16", action="store_true")
     for flag in ("-masker", "-critic", "-cload", "-mload", "-staticnorm", "-visbesteval", "-salglobal"):
         p.add_argument(flag, type=bool, default=True)
     p.add_argument("--salience-thresh", type=float, default="1.5")

@@ -1,0 +1,241 @@
+// fp16 inference family (BASELINE.json config 4: "-process inference-only mask path ... fp16 conv kernels"): every layer of
+// NewCritic.forward / UnetDecoder.forward (nets.py:197-212, 494-523; main.py:1130-1151) with fp16 activations in HBM and LDS, fp16
+// weights, fp32 accumulation on v_mfma_f32_16x16x16_f16 (K = 16 per instruction: one MFMA per tap and 16-channel chunk), for any
+// channel factor (runtime channel counts, like gen.hip).  An opt-in precision mode: the fp32 path stays the default everywhere.
+//
+//   gen16_pack_weights : HWIO fp32 [9][ci][co] -> fp16 [tap][chunk][quad][padded co][4]: the B operand of a lane (4 consecutive
+//                        input channels of one output channel) is one 8-byte load, a wave's loads are contiguous.
+//   gen16_conv3x3      : conv3x3(cat(A, nearest-up(B))) + bias + act (+ MaxPool2d(2)); A uint8 (frames, /255 fused) or fp16 NHWC,
+//                        B fp16 NHWC; output fp16 NHWC, or fp32 for the mask layer.  LDS tile [rows][cols][4 quads of 4 halves]
+//                        with the quad index XOR-swizzled by the row parity: the 8-byte A-operand reads of a wave's two pixel
+//                        rows land in different bank halves.
+//   gen16_gemm         : Linear layers / the 4x4 valid convolution / the 1x1 convolution on fp16 or fp32 rows, fp32 weights.
+#include "gen_common.h"
+
+namespace {
+
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half_t;
+
+struct Gen16ConvParams {
+    const void* a; const half_t* b; const half_t* w16; const float* bias;
+    void* out;                 // fp16 NHWC (out_f32 = 0) or fp32
+    int a_u8, ca, cb, ups, n, hw, co, act, pool, th, out_f32;
+    float slope;
+};
+
+__device__ __forceinline__ int g16_pa4(const Gen16ConvParams& P) { return (P.ca + 3) & ~3; }
+
+__global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __restrict__ w, int ca, int cb, int co, half_t* __restrict__ out) {
+    const int pa4 = (ca + 3) & ~3, cp = pa4 + cb, nchunk = (cp + 15) / 16, ncol = (co + 15) / 16 * 16, ci_total = ca + cb;
+    const int total = 9 * nchunk * 4 * ncol * 4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e & 3, col = (e >> 2) % ncol, q = ((e >> 2) / ncol) & 3, ch = ((e >> 2) / (ncol * 4)) % nchunk, tap = (e >> 2) / (ncol * 4 * nchunk);
+        const int k = ch * 16 + 4 * q + j;
+        const int ci = k < pa4 ? (k < ca ? k : -1) : (k < cp ? ca + (k - pa4) : -1);
+        out[e] = (half_t)((ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
+    }
+}
+
+constexpr int G16_MAX_TPW = 4;
+
+// grid: ((image * strips + strip) * column-block groups + group); 256 threads; NCB blocks of 16 output channels per workgroup
+template <int NCB, bool A_U8, bool HASB>
+__global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    half_t* tile = (half_t*)gsm;                    // [(th + 2)][(hw + 2)][4 quads (swizzled)][4 halves]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+    const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
+    const int ncolb = (P.co + 15) / 16, ncg = (ncolb + NCB - 1) / NCB, ncol = ncolb * 16, strips = H / TH;
+    const int cg = blockIdx.x % ncg, strip = (blockIdx.x / ncg) % strips, img = blockIdx.x / (ncg * strips);
+    const int row0 = strip * TH;
+    const int pa4 = g16_pa4(P), cp = pa4 + P.cb, nchunk = (cp + 15) / 16;
+    const int ntiles = TH * W / 16, QW = W / 2;
+    const int HB = H / P.ups, WB = W / P.ups;
+
+    frag4 acc[G16_MAX_TPW][NCB];
+    int apix[G16_MAX_TPW], apar[G16_MAX_TPW];       // the lane's pixel (tile coordinates, before the tap offset) and its row parity
+#pragma unroll
+    for (int i = 0; i < G16_MAX_TPW; ++i) {
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) acc[i][c] = frag4{0.f, 0.f, 0.f, 0.f};
+        const int t = wave + 4 * i;
+        const int q = 4 * t + (l15 >> 2), qy = q / QW, qx = q % QW;
+        const int y = 2 * qy + ((l15 >> 1) & 1), x = 2 * qx + (l15 & 1);     // strip-local
+        apix[i] = y * PW + x;
+        apar[i] = y & 1;
+    }
+    const half_t* wl = P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 4;      // + ((tap * nchunk + ch) * 4) * ncol * 4
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        // ---- stage 16 channels of the strip (halo included) as halves: one 8-byte quad per (pixel, quad) ----
+        // (a rolled loop on purpose: this kernel lives on occupancy -- 28 VGPRs; batching the rounds' loads or preloading the
+        //  nine taps' weights raised the register count and made it 1.1x / 2x slower)
+        const int ngrp = (TH + 2) * PW * 4;
+        for (int e = tid; e < ngrp; e += 256) {
+            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
+            const int y = row0 + r - 1, x = c - 1, k0 = ch * 16 + 4 * g;
+            half4_t v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            if (y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
+                if (k0 < pa4) {
+                    const size_t pix = ((size_t)img * H + y) * W + x;
+                    if constexpr (A_U8) {
+                        const uint8_t* s8 = (const uint8_t*)P.a + pix * P.ca + k0;
+                        const float sc = 1.f / 255.f;
+                        v[0] = (half_t)(s8[0] * sc);
+                        if (k0 + 1 < P.ca) v[1] = (half_t)(s8[1] * sc);
+                        if (k0 + 2 < P.ca) v[2] = (half_t)(s8[2] * sc);
+                        if (k0 + 3 < P.ca) v[3] = (half_t)(s8[3] * sc);
+                    } else {
+                        v = *(const half4_t*)((const half_t*)P.a + pix * P.ca + k0);       // (ca % 4 == 0)
+                    }
+                } else if constexpr (HASB) {
+                    const size_t pixb = ((size_t)img * HB + y / P.ups) * WB + x / P.ups;
+                    v = *(const half4_t*)(P.b + pixb * P.cb + (k0 - pa4));
+                }
+            }
+            *(half4_t*)(tile + ((size_t)px * 4 + (g ^ ((r & 1) << 1))) * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ty = tap / 3, toff = ty * PW + tap % 3;
+            half4_t b[NCB];
+            const half_t* wp = wl + (size_t)((tap * nchunk + ch) * 4) * ncol * 4;
+#pragma unroll
+            for (int c = 0; c < NCB; ++c)
+                b[c] = (cg * NCB * 16 + 16 * c + l15 < ncol) ? *(const half4_t*)(wp + 64 * c) : half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+#pragma unroll
+            for (int i = 0; i < G16_MAX_TPW; ++i) {
+                if (wave + 4 * i < ntiles) {
+                    const int qpos = kq ^ (((apar[i] + ty) & 1) << 1);
+                    const half4_t a = *(const half4_t*)(tile + ((size_t)(apix[i] + toff) * 4 + qpos) * 4);
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b[c], acc[i][c], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D[m = 4 kq + j][n = l15] ----
+#pragma unroll
+    for (int c = 0; c < NCB; ++c) {
+        const int col = cg * NCB * 16 + 16 * c + l15;
+        if (col >= P.co) continue;
+        const float bias = P.bias[col];
+#pragma unroll
+        for (int i = 0; i < G16_MAX_TPW; ++i) {
+            const int t = wave + 4 * i;
+            if (t >= ntiles) continue;
+            const int q = 4 * t + kq, qy = q / QW, qx = q % QW;
+            if (P.pool) {
+                float m = gen_act(acc[i][c][0] + bias, P.act, P.slope);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) m = fmaxf(m, gen_act(acc[i][c][j] + bias, P.act, P.slope));
+                const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
+                if (P.out_f32) ((float*)P.out)[pp] = m; else ((half_t*)P.out)[pp] = (half_t)m;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
+                    const size_t o = (((size_t)img * H + y) * W + x) * P.co + col;
+                    const float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
+                    if (P.out_f32) ((float*)P.out)[o] = v; else ((half_t*)P.out)[o] = (half_t)v;
+                }
+            }
+        }
+    }
+}
+
+struct Gen16GemmParams {
+    const void* x; const float* w; const float* bias; void* out;
+    int m, k, n, act, x_f16, out_f16;
+    float slope;
+};
+
+// out[m][n] = act(sum_k x[m][k] w[k][n] + bias[n]); one wave per 16 x 16 tile, fp32 MFMA on converted rows (tiny layers)
+__global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
+    const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
+    const int ntn = (P.n + 15) / 16;
+    const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
+    const int row = m0 + l15, col = n0 + l15;
+    const bool rok = row < P.m, cok = col < P.n;
+    const size_t xoff = (size_t)(rok ? row : 0) * P.k;
+    const float* wc = P.w + (cok ? col : 0);
+    frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < P.k; k0 += 32) {
+        float a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int k = k0 + 4 * u + kq, kc = k < P.k ? k : P.k - 1;
+            a[u] = P.x_f16 ? (float)((const half_t*)P.x)[xoff + kc] : ((const float*)P.x)[xoff + kc];
+            b[u] = wc[(size_t)kc * P.n];
+            a[u] = (rok && k < P.k) ? a[u] : 0.f;
+            b[u] = (cok && k < P.k) ? b[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (cok) {
+        const float bias = P.bias ? P.bias[col] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m0 + 4 * kq + j;
+            if (r < P.m) {
+                const float v = gen_act(acc[j] + bias, P.act, P.slope);
+                if (P.out_f16) ((half_t*)P.out)[(size_t)r * P.n + col] = (half_t)v; else ((float*)P.out)[(size_t)r * P.n + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_t co) {
+    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
+    const int cp = ((ca + 3) & ~3) + cb;
+    return (int64_t)9 * ((cp + 15) / 16) * 4 * ((co + 15) / 16 * 16) * 4;
+}
+
+extern "C" int cgs_gen16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
+    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !w16) return CGS_ERR_BADARG;
+    const int64_t total = cgs_gen16_packed_weight_halves(ca, cb, co);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gen16_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ca, cb, co, (half_t*)w16);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                     int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
+                                     const void* w16, const float* bias, void* out, cgs_stream_t stream) {
+    if (n < 0 || !src_a || !w16 || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
+    if (!a_is_u8 && (ca & 3)) return CGS_ERR_BADARG;                  // fp16 sources are read 4 channels at a time
+    if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
+    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
+    if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    Gen16ConvParams P{src_a, (const half_t*)src_b, (const half_t*)w16, bias, out, a_is_u8, ca, cb, cb > 0 ? ups : 1, n, hw, co, act, pool,
+                      gen_strip_rows(hw), out_is_f32, slope};
+    const int ncb = (co + 15) / 16, strips = hw / P.th;
+    const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
+    const size_t lds = (size_t)(P.th + 2) * (hw + 2) * 16 * sizeof(half_t);
+    const dim3 grid(n * strips * ((ncb + per - 1) / per));
+#define G16K(NCB_) (a_is_u8 ? (cb > 0 ? gen16_conv3x3_kernel<NCB_, true, true> : gen16_conv3x3_kernel<NCB_, true, false>) \
+                            : (cb > 0 ? gen16_conv3x3_kernel<NCB_, false, true> : gen16_conv3x3_kernel<NCB_, false, false>))
+    auto k = per == 1 ? G16K(1) : (per == 2 ? G16K(2) : G16K(3));
+#undef G16K
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_f16, int32_t out_is_f16,
+                              const void* x, const float* w, const float* bias, void* out, cgs_stream_t stream) {
+    if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (m == 0) return CGS_OK;
+    Gen16GemmParams P{x, w, bias, out, m, k, n, act, x_is_f16, out_is_f16, slope};
+    hipLaunchKernelGGL(gen16_gemm_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

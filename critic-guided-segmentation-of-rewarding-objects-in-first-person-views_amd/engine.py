@@ -101,6 +101,9 @@ class HourglassEngine:
         # ONE launch (slab reduction + Adam + loss values): two launches (losses, Adam) fewer on the critical path
         self.fused_tail = hg.TAIL_BWD and not self.dp and os.environ.get("CGS_FUSED_STEP_TAIL", "1") != "0"
         self._graphs: Dict[str, object] = {}
+        # parameter version (shared by engines that share the parameters): the fp16 inference path repacks its weight copies when it moves
+        self._pver = share_with._pver if share_with is not None else [0]
+        self._w16 = None
         # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
         # the cross-queue joins cost what the overlap gains)
         self.side = hg.SideStream(torch.cuda.Stream(device=self.dev) if overlap_wgrad else None)
@@ -115,6 +118,7 @@ class HourglassEngine:
         if sepcrit_sd is not None:
             self.lc.flatten({k: v.to(self.dev) for k, v in sepcrit_sd.items()}, self.fs)
         parallel.broadcast_params_(self.flat, self.pg)    # replicas start identical
+        self._pver[0] += 1
 
     def critic_state(self):
         return self.lc.unflatten(self.fc)
@@ -137,6 +141,7 @@ class HourglassEngine:
         masker_module.flat.data = self.fm
         if sepcrit_module is not None:
             sepcrit_module.flat.data = self.fs
+        self._pver[0] += 1
 
     def reset_optimizer(self):
         self.m.zero_(); self.v.zero_(); self.step_t.zero_()
@@ -309,6 +314,7 @@ class HourglassEngine:
         if Y is not None:
             self.y.copy_(Y.to(torch.float32), non_blocking=True)
         self._run("p2", self._phase2_fwd_bwd)
+        self._pver[0] += 1
         return self.losses
 
     def gather_contrastive(self, Xpos: torch.Tensor, Xneg: torch.Tensor, ypos: torch.Tensor, yneg: torch.Tensor,
@@ -357,6 +363,7 @@ class HourglassEngine:
         if Y is not None:
             self.y.copy_(Y.to(torch.float32), non_blocking=True)
         self._run("p1", self._phase1_fwd_bwd)
+        self._pver[0] += 1
         return self.losses
 
     # ---- execution: eager first call (allocates workspaces, builds job tables), then HIP-graph replay ----
@@ -412,13 +419,34 @@ class HourglassEngine:
         return c["pred"], dx
 
     # ---- inference (main.py:1130-1151) -----------------------------------------------------------
+    def _infer_f16(self, X: torch.Tensor, want_mask: bool, chfak: int, neck: int):
+        """BASELINE config 4: every layer with fp16 activations / weights, fp32 accumulation (csrc/gen_f16.hip)."""
+        from . import generic as gen
+        if self._w16 is None:
+            self._w16 = gen.F16Weights()
+        w16 = self._w16.get(self.fc, self.lc, self.fm, self.lm, chfak, neck, 16, (self._pver[0], self.separate))
+        X = X.contiguous()
+        emb = None
+        if self.separate and want_mask:
+            if getattr(self, "_w16s", None) is None:
+                self._w16s = gen.F16Weights()
+            ws = self._w16s.get(self.fs, self.lc, None, None, chfak, neck, 16, self._pver[0])
+            _, _, emb = gen.infer_f16(self.fs, self.lc, None, None, X, chfak, neck, ws)
+        pred, Z, _ = gen.infer_f16(self.fc, self.lc, self.fm if want_mask else None, self.lm, X, chfak, neck, w16, embeds_from=emb)
+        return pred, Z
+
     @torch.no_grad()
-    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False):
+    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False, fp16: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
         Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM.
+        fp16 (opt-in, uint8 frames, eval mode): fp16 activations and weights in every layer, fp32 accumulation (~1e-3 abs in Z).
         train_mode (-noevalmode, main.py:1109-1118): Dropout stays active, a fresh mask per call.
         With a second critic (-separate, main.py:1140-1142) the masker's inputs come from it."""
         hg._chk_img(X, 0, "infer input")
+        if fp16:
+            if train_mode or fp16_mask_head:
+                raise _lib.CgsError("fp16 inference is an eval-mode path of its own (no Dropout, no fp16_mask_head)")
+            return self._infer_f16(X, want_mask, 1, 32)
         b = X.shape[0]
         drop = hg.NO_DROP
         if train_mode and self.p > 0.0:

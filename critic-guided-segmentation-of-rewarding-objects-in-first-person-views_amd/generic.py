@@ -166,6 +166,88 @@ def _mask2_desc(n: int) -> _lib.ConvDesc:
 
 
 # ------------------------------------------------------------------------------------------------
+# fp16 inference (BASELINE config 4): fp16 activations and weights, fp32 accumulation (csrc/gen_f16.hip); any chfak
+# ------------------------------------------------------------------------------------------------
+class F16Weights:
+    """The fp16 operand copies of the 3x3 layers' weights for one parameter state (repacked when `version` moves on)."""
+
+    def __init__(self):
+        self.version = None
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def get(self, flat_c: torch.Tensor, lc: Layout, flat_m: Optional[torch.Tensor], lm: Optional[Layout], chfak: int, neck: int,
+            masker_channels: int, version) -> Dict[str, torch.Tensor]:
+        if self.version == version and self.w:
+            return self.w
+        d, nb = dims(chfak, neck)
+        shapes = {"features.0": (3, 0, d[0]), "features.3": (d[0], 0, d[1]), "features.6": (d[1], 0, d[2]), "features.10": (d[2], 0, d[3])}
+        if flat_m is not None:
+            shapes.update({"dec_model.3": (d[3], nb, d[3]), "dec_model.2": (d[2], d[3], d[2]), "dec_model.1": (d[1], d[2], d[1]),
+                           "dec_model.0": (d[0], d[1], d[0]), "masker.0": (3, d[0], masker_channels), "masker.2": (masker_channels, 0, 1)})
+        self.w = {}
+        for key, (ca, cb, co) in shapes.items():
+            flat, lay = (flat_c, lc) if key.startswith("features") else (flat_m, lm)
+            nh = _lib.load().cgs_gen16_packed_weight_halves(ca, cb, co)
+            w16 = torch.empty(nh, device=flat.device, dtype=torch.float16)
+            _lib.call("cgs_gen16_pack_weights", ca, cb, co, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")), _p(w16), _s())
+            self.w[key] = w16
+        self.version = version
+        return self.w
+
+
+def _conv16(a, b, w16, bias_ptr, co, act="none", slope=0.01, pool=False, ups=2, out_f32=False):
+    n, hw, ca = a.shape[0], a.shape[1], a.shape[3]
+    cb = 0 if b is None else b.shape[-1]
+    oh = hw // 2 if pool else hw
+    out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32 if out_f32 else torch.float16)
+    _lib.call("cgs_gen16_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], float(slope), int(pool), int(out_f32),
+              _p(a), _p(b), _p(w16), C.c_void_p(bias_ptr), _p(out), _s())
+    return out
+
+
+def _gemm16(x, w_ptr, bias_ptr, k, n_out, act="none", out_f16=True):
+    m = x.shape[0]
+    out = torch.empty((m, n_out), device=x.device, dtype=torch.float16 if out_f16 else torch.float32)
+    _lib.call("cgs_gen16_gemm", m, k, n_out, _ACT[act], 0.01, int(x.dtype == torch.float16), int(out_f16), _p(x), C.c_void_p(w_ptr),
+              C.c_void_p(bias_ptr), _p(out), _s())
+    return out
+
+
+def infer_f16(flat_c: torch.Tensor, lc: Layout, flat_m: Optional[torch.Tensor], lm: Optional[Layout], x_u8: torch.Tensor, chfak: int,
+              neck: int, w16: Dict[str, torch.Tensor], masker_channels: int = 16, embeds_from=None):
+    """Eval-mode critic (+ masker) with fp16 activations / weights and fp32 accumulation.  x_u8: NHWC uint8 [n,64,64,3].
+    Returns (pred [n] fp32, Z [n,64,64] fp32 or None, embeds) -- embeds (fp16 e0..e3, e4) feed a masker call (-separate)."""
+    if x_u8.dtype != torch.uint8 or not x_u8.is_cuda or not x_u8.is_contiguous():
+        raise _lib.CgsError("fp16 inference reads the uint8 frames (NHWC, contiguous, on the device)")
+    cp = flat_c.data_ptr()
+    offc = lambda k: cp + 4 * lc.off(k)
+    d, nb = dims(chfak, neck)
+    n = x_u8.shape[0]
+    e, src = [], x_u8
+    for key, co in zip(ENC_KEYS, d):
+        src = _conv16(src, None, w16[key], offc(key + ".bias"), co, act="relu", pool=True)
+        e.append(src)
+    e4 = _gemm16(e[3].reshape(n, 16 * d[3]), offc("features.14.weight"), offc("features.14.bias"), 16 * d[3], nb, act="relu")
+    h1 = _gemm16(e4, offc("crit.1.weight"), offc("crit.1.bias"), nb, nb, act="relu")
+    pred = _gemm16(h1, offc("crit.4.weight"), offc("crit.4.bias"), nb, 1, act="sigmoid", out_f16=False).reshape(n)
+    emb = e + [e4]
+    if flat_m is None:
+        return pred, None, emb
+    if embeds_from is not None:
+        emb = embeds_from
+    mp = flat_m.data_ptr()
+    offm = lambda k: mp + 4 * lm.off(k)
+    o4 = _gemm16(emb[4], offm("dec_model.4.weight"), offm("dec_model.4.bias"), nb, nb)
+    o3 = _conv16(emb[3], o4.view(n, 1, 1, nb), w16["dec_model.3"], offm("dec_model.3.bias"), d[3], ups=4)
+    o2 = _conv16(emb[2], o3, w16["dec_model.2"], offm("dec_model.2.bias"), d[2])
+    o1 = _conv16(emb[1], o2, w16["dec_model.1"], offm("dec_model.1.bias"), d[1])
+    o0 = _conv16(emb[0], o1, w16["dec_model.0"], offm("dec_model.0.bias"), d[0])
+    hm = _conv16(x_u8, o0, w16["masker.0"], offm("masker.0.bias"), masker_channels, act="lrelu", slope=0.01)
+    Z = _conv16(hm, None, w16["masker.2"], offm("masker.2.bias"), 1, act="sigmoid", out_f32=True).reshape(n, 64, 64)
+    return pred, Z, emb
+
+
+# ------------------------------------------------------------------------------------------------
 # backward passes (training at chfak != 1)
 # ------------------------------------------------------------------------------------------------
 class Workspace(dict):

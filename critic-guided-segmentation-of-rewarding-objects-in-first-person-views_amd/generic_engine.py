@@ -69,6 +69,8 @@ class GenericEngine(HourglassEngine):
         self.fused_tail = False
         self._graphs: Dict[str, object] = {}
         self._plans: Dict[str, hg.SlabPlan] = {}
+        self._pver = share_with._pver if share_with is not None else [0]
+        self._w16 = None
 
     # ---- helpers -----------------------------------------------------------------------------
     def _alloc(self):
@@ -198,10 +200,14 @@ class GenericEngine(HourglassEngine):
 
     # ---- inference (main.py:1130-1151) -----------------------------------------------------------
     @torch.no_grad()
-    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False):
+    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False, fp16: bool = False):
         hg._chk_img(X, 0, "infer input")
         if fp16_mask_head:
             raise NotImplementedError("the fp16-operand mask head is a chfak=1 kernel")
+        if fp16:
+            if train_mode:
+                raise _lib.CgsError("fp16 inference is an eval-mode path (no Dropout)")
+            return self._infer_f16(X, want_mask, self.chfak, self.neck)
         X = X.contiguous()
         drop = None
         if train_mode and self.p > 0.0:

@@ -356,7 +356,10 @@ class Handler:
             if args.salience:           # main.py:1136-1147: |d mean(pred) / d batch| summed over the colour channels
                 _p, dx = eng.saliency(batch)
                 salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
-            pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # -noevalmode: Dropout stays on (main.py:1109-1118)
+            if getattr(args, "fp16", False):     # (this build's switch) BASELINE config 4: fp16 layers on the uint8 frames
+                pred, Z = eng.infer((batch * 255.0).round().to(torch.uint8), fp16=True)
+            else:
+                pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # -noevalmode: Dropout stays on (main.py:1109-1118)
             preds.append(pred.cpu().numpy())
             M.append(Z.cpu().numpy()[:, None])
         print()

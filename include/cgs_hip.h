@@ -383,6 +383,21 @@ int cgs_gen_dropout_fwd(int64_t count, const float* x, float* out, cgs_dropout d
 int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, int64_t sxm, int64_t sxk, const float* w, int64_t swk,
                     int64_t swn, const float* bias, int32_t act, float slope, int32_t accumulate, float* out, cgs_stream_t stream);
 int cgs_gen_u8_to_f32(int64_t count, const uint8_t* x, float* out, cgs_stream_t stream);
+
+/* ---- fp16 inference family (csrc/gen_f16.hip): BASELINE config 4, "-process inference-only mask path ... fp16 conv kernels" --------
+ * Every layer of the eval-mode forward (nets.py:197-212, 494-523; main.py:1130-1151) with fp16 activations (NHWC) and fp16 weights,
+ * fp32 accumulation on v_mfma_f32_16x16x16_f16, runtime channel counts (any chfak).  Opt-in: ~1e-3 absolute in the masks.
+ * cgs_gen16_pack_weights: HWIO fp32 w [9][ca+cb][co] -> the kernel's fp16 operand layout (cgs_gen16_packed_weight_halves halves).
+ * cgs_gen16_conv3x3_fwd: out = act(conv3x3(cat(A, nearest-up_ups(B))) + bias) (+ MaxPool2d(2)); A uint8 (/255 fused) or fp16
+ *   (ca % 4 == 0), B fp16; out fp16, or fp32 when out_is_f32.
+ * cgs_gen16_gemm: out [m,n] = act(x [m,k] w [k,n] + bias), x fp16 or fp32, w / bias fp32, out fp16 or fp32.                         */
+int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_t co);
+int cgs_gen16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream);
+int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups, int32_t act,
+                          float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16,
+                          const float* bias, void* out, cgs_stream_t stream);
+int cgs_gen16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_f16, int32_t out_is_f16, const void* x,
+                   const float* w, const float* bias, void* out, cgs_stream_t stream);
 int cgs_gen_convt4s2_fwd(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, int32_t act, float slope,
                          const float* a, const float* b, const float* w, const float* bias, float* out,
                          cgs_stream_t stream);

@@ -147,3 +147,39 @@ def test_handler_generic_inference_chfak5(tmp_path, monkeypatch):
     rel_close(Z.cpu().numpy(), rz[:, 0].numpy(), "Z")
     from cgs_amd import generic_engine
     assert isinstance(H._engine(64, training=True), generic_engine.GenericEngine)
+
+
+@pytest.mark.parametrize("chfak,neck,n", [(1, 32, 64), (5, 32, 12), (2, 16, 9)])
+def test_fp16_inference_error_distribution_vs_fp32_oracle(g1, chfak, neck, n):
+    """BASELINE config 4 (fp16 conv kernels): fp16 activations / weights, fp32 accumulation in EVERY layer (csrc/gen_f16.hip) against
+    the fp32 oracle: the error distribution of the masks and the critic values (opt-in precision mode, so an absolute bound, not
+    the 1e-3 relative one of the fp32 path).  chfak 1 runs on the fused engine's parameters, the others on GenericEngine."""
+    from cgs_amd import engine, generic_engine
+    dev = torch.device("cuda:0")
+    if chfak == 1:
+        pc, pm = g1
+        e = engine.HourglassEngine(8, dropout=0.0)
+    else:
+        pc, pm = orc.seeded_params(orc.critic_shapes(chfak, neck), 11), orc.seeded_params(orc.masker_shapes(chfak, neck), 12)
+        e = generic_engine.GenericEngine(8, chfak=chfak, neck=neck, dropout=0.0)
+    e.load_state(pc, pm)
+    rs = np.random.RandomState(5)
+    x = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    x[0, 16:40, 8:56] = 200        # a flat patch: ties in the pooling windows
+    pred, Z = e.infer(torch.from_numpy(x).to(dev), fp16=True)
+    with torch.no_grad():
+        rp, re = orc.critic_apply(pc, orc.u8_to_nchw(x), collect=True)
+        rz = orc.masker_apply(pm, orc.u8_to_nchw(x), re)[:, 0].numpy()
+    dz = np.abs(Z.cpu().numpy().astype(np.float64) - rz)
+    dp = np.abs(pred.cpu().numpy().astype(np.float64) - rp[:, 0].numpy())
+    print(f"fp16 inference chfak {chfak}: |dZ| max {dz.max():.2e} p99.9 {np.quantile(dz, 0.999):.2e} mean {dz.mean():.2e}; |dpred| max {dp.max():.2e}")
+    assert dz.max() < 2e-2 and np.quantile(dz, 0.999) < 5e-3 and dz.mean() < 1e-3
+    assert dp.max() < 5e-3
+    # thresholded masks (what -process writes) differ on a vanishing fraction of the pixels
+    assert ((Z.cpu().numpy() > 0.5) != (rz > 0.5)).mean() < 2e-3
+    # the weight copies follow the parameters: a training step changes the fp16 result
+    A = torch.from_numpy(x[:8]).to(dev)
+    e.phase2_step(A, torch.from_numpy(x[:8][::-1].copy()).to(dev), torch.rand(8, device=dev))
+    pred2, _ = e.infer(torch.from_numpy(x).to(dev), fp16=True)
+    p32, _ = e.infer(torch.from_numpy(x).to(dev))
+    assert float((pred2 - p32).abs().max()) < 5e-3 and not torch.equal(pred2, pred)
