@@ -56,6 +56,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) g
 
     constexpr int NC = NCB == 2 ? 48 : 16 * NCB;                 // row stride of the weight tile (48: the 4 k-rows of a read hit 64 banks)
     float* wl = tile + (TH + 2) * PW * GEN_KC;                   // [9 taps][16 channels][NC]
+    gen_zero_halo_cols(tile, W, TH, 1, tid);                      // (the staging writes the interior columns only)
     for (int ch = 0; ch < nchunk; ++ch) {
         int ltid = tid;                                           // opaque per chunk: keeps the staging addresses of all
         asm volatile("" : "+v"(ltid));                            // iterations from being hoisted out of this loop (registers)

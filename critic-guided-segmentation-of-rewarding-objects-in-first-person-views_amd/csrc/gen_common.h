@@ -28,90 +28,98 @@ __device__ __forceinline__ int gen_real_channel(const GenSrc& S, int k) {      /
     return k < pa4 ? (k < S.ca ? k : -1) : (k < pa4 + S.cb ? S.ca + (k - pa4) : -1);
 }
 
-// Stages channels [16 ch, 16 ch + 16) of rows row0 - halo .. row0 + th - 1 + halo (all columns, `halo` zero columns either side)
-// of image img into tile[(th + 2 halo)][(W + 2 halo)][16].  256 threads; a strip is <= 1584 float4 (7 per thread).
-// Written branch-free per source kind (clamped addresses, selects): every load of a thread is issued before the first conversion
-// or LDS store, so the latencies of the (up to 7) rounds overlap instead of adding up.
+// Stages channels [16 ch, 16 ch + 16) of rows row0 - halo .. row0 + th - 1 + halo of image img into
+// tile[(th + 2 halo)][(W + 2 halo)][16].  ONLY the interior columns are written: the `halo` columns either side are zero for
+// every tile -- gen_zero_halo_cols() writes them once per workgroup.  256 threads.
+// The loop is VALU-bound, not latency-bound (s_memtime stamps: half of a workgroup's life, ~170 instructions per element when the
+// element index was decomposed by divisions): so a tile row is W x 4 quads = a power of two of elements, a thread keeps ONE
+// (column, quad) for all rows (256 / (4 W) rows per round), all index math is shifts, element offsets are 32-bit, and each source
+// kind has its own branch-free body (clamped addresses, selects) so the loads of a round's BATCH rows are in flight together.
 enum { GEN_K_F32V4 = 0, GEN_K_F32S = 1, GEN_K_U8 = 2, GEN_K_POOLEXP = 3 };      // A source: float4-able fp32, odd-width fp32, uint8, pooled
+
+__device__ __forceinline__ void gen_zero_halo_cols(float* tile, int W, int th, int halo, int tid) {
+    const int PW = W + 2 * halo;
+    for (int e = tid; e < (th + 2 * halo) * 2 * halo * 4; e += 256) {
+        const int g = e & 3, side = (e >> 2) % (2 * halo), r = (e >> 2) / (2 * halo);
+        const int c = side < halo ? side : W + side;
+        *(float4*)(tile + ((size_t)(r * PW + c) * 4 + g) * 4) = f4zero();
+    }
+}
 
 template <int KIND, bool HASB, int BATCH>
 __device__ __forceinline__ void gen_stage_impl(float* tile, const GenSrc& S, int img, int H, int W, int row0, int th, int halo,
-                                               int ch, int tid0) {
-    const int PW = W + 2 * halo, pa4 = gen_pa4(S), cp = pa4 + S.cb;
-    const int ngrp = (th + 2 * halo) * PW * (GEN_KC / 4);
-    const int HB = H / S.ups, WB = W / S.ups;
-    // BATCH rounds of loads in flight at a time (7: all of them, registers permitting; 1: lowest register count)
+                                               int ch, int tid) {
+    const int PW = W + 2 * halo, pa4 = gen_pa4(S), cp = pa4 + S.cb, rows = th + 2 * halo;
+    const int lw = __builtin_ctz(W) + 2;                         // log2 of the elements per tile row (W pixels x 4 quads)
+    const int ush = S.ups == 4 ? 2 : (S.ups == 2 ? 1 : 0), HB = H >> ush, WB = W >> ush;
+    const int rpi = lw >= 8 ? 1 : (256 >> lw);                   // tile rows per round of 256 threads
+    const int g = tid & 3, x = (tid & ((1 << lw) - 1)) >> 2, rsub = lw >= 8 ? 0 : tid >> lw;
+    const int k0 = ch * GEN_KC + 4 * g;
+    const bool kok = k0 < cp, isa = k0 < pa4;
+    // this thread's channel offsets (the same for every row)
+    const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;               // F32V4 / POOLEXP
+    int kb = k0 - pa4;
+    kb = kb < 0 ? 0 : (kb > S.cb - 4 ? S.cb - 4 : kb);
+    const int c0 = k0 < S.ca ? k0 : S.ca - 1, c1 = k0 + 1 < S.ca ? k0 + 1 : S.ca - 1, c2 = k0 + 2 < S.ca ? k0 + 2 : S.ca - 1,
+              c3 = k0 + 3 < S.ca ? k0 + 3 : S.ca - 1;
+    float* const dst0 = tile + ((size_t)(halo + x) * 4 + g) * 4;      // + r * PW * 16
 #pragma unroll 1
-    for (int bt = 0; bt * BATCH * 256 < ngrp; ++bt) {
-    const int tid = tid0 + bt * BATCH * 256;
-    float4 raw[BATCH];                    // F32V4 / POOLEXP / B part: the float4; F32S / U8: up to 4 scalars
-    float4 rawb[HASB && KIND != GEN_K_F32V4 ? BATCH : 1];
-    uint32_t am[KIND == GEN_K_POOLEXP ? BATCH : 1];
+    for (int rb = 0; rb < rows; rb += rpi * BATCH) {
+        float4 raw[BATCH];                    // F32V4 / POOLEXP / B part: the float4; F32S / U8: up to 4 scalars
+        [[maybe_unused]] float4 rawb[HASB && KIND != GEN_K_F32V4 ? BATCH : 1];
+        [[maybe_unused]] uint32_t am[KIND == GEN_K_POOLEXP ? BATCH : 1];
 #pragma unroll
-    for (int it = 0; it < BATCH; ++it) {
-        const int e0 = tid + 256 * it, e = e0 < ngrp ? e0 : 0;
-        const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
-        const int y = row0 + r - halo, x = c - halo, k0 = ch * GEN_KC + 4 * g;
-        const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y), xc = x < 0 ? 0 : (x >= W ? W - 1 : x);
-        const size_t pix = ((size_t)img * H + yc) * W + xc;
-        const float* pb = nullptr;
-        if constexpr (HASB) {
-            int kb = k0 - pa4;
-            kb = kb < 0 ? 0 : (kb > S.cb - 4 ? S.cb - 4 : kb);
-            pb = S.b + (((size_t)img * HB + yc / S.ups) * WB + xc / S.ups) * S.cb + kb;
-        }
-        if constexpr (KIND == GEN_K_F32V4) {
-            const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
-            const float* pa = (const float*)S.a + pix * S.ca + ka;
-            if constexpr (HASB) pa = k0 < pa4 ? pa : pb;
-            raw[it] = *(const float4*)pa;
-        } else if constexpr (KIND == GEN_K_POOLEXP) {
-            const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
-            const size_t pp = (((size_t)img * (H / 2) + (yc >> 1)) * (W / 2) + (xc >> 1)) * S.ca + ka;
-            raw[it] = *(const float4*)((const float*)S.a + pp);
-            am[it] = *(const uint32_t*)(S.am + pp);
-        } else {
-            const int c0 = k0 < S.ca ? k0 : S.ca - 1, c1 = k0 + 1 < S.ca ? k0 + 1 : S.ca - 1, c2 = k0 + 2 < S.ca ? k0 + 2 : S.ca - 1,
-                      c3 = k0 + 3 < S.ca ? k0 + 3 : S.ca - 1;
-            if constexpr (KIND == GEN_K_U8) {
-                const uint8_t* s = (const uint8_t*)S.a + pix * S.ca;
-                raw[it] = make_float4((float)s[c0], (float)s[c1], (float)s[c2], (float)s[c3]);
+        for (int it = 0; it < BATCH; ++it) {
+            const int r = rb + it * rpi + rsub, y = row0 + r - halo;
+            const int yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            const uint32_t pix = (uint32_t)((img * H + yc) * W + x);
+            const float* pb = nullptr;
+            if constexpr (HASB) pb = S.b + ((uint32_t)((img * HB + (yc >> ush)) * WB + (x >> ush)) * (uint32_t)S.cb + kb);
+            if constexpr (KIND == GEN_K_F32V4) {
+                const float* pa = (const float*)S.a + (pix * (uint32_t)S.ca + ka);
+                if constexpr (HASB) pa = isa ? pa : pb;
+                raw[it] = *(const float4*)pa;
+            } else if constexpr (KIND == GEN_K_POOLEXP) {
+                const uint32_t pp = (uint32_t)((img * (H >> 1) + (yc >> 1)) * (W >> 1) + (x >> 1)) * (uint32_t)S.ca + ka;
+                raw[it] = *(const float4*)((const float*)S.a + pp);
+                am[it] = *(const uint32_t*)(S.am + pp);
             } else {
-                const float* s = (const float*)S.a + pix * S.ca;
-                raw[it] = make_float4(s[c0], s[c1], s[c2], s[c3]);
-            }
-            if constexpr (HASB) rawb[it] = *(const float4*)pb;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < BATCH; ++it) {
-        const int e = tid + 256 * it;
-        if (e < ngrp) {
-            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
-            const int y = row0 + r - halo, x = c - halo, k0 = ch * GEN_KC + 4 * g;
-            const bool inb = y >= 0 && y < H && x >= 0 && x < W && k0 < cp;
-            float4 v = raw[it];
-            if constexpr (KIND == GEN_K_POOLEXP) {
-                const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
-                v.x = (am[it] & 255u) == pos ? v.x : 0.f;
-                v.y = ((am[it] >> 8) & 255u) == pos ? v.y : 0.f;
-                v.z = ((am[it] >> 16) & 255u) == pos ? v.z : 0.f;
-                v.w = (am[it] >> 24) == pos ? v.w : 0.f;
-            } else if constexpr (KIND == GEN_K_F32S || KIND == GEN_K_U8) {
-                const float sc = KIND == GEN_K_U8 ? 1.f / 255.f : 1.f;
-                v.x = k0 < S.ca ? v.x * sc : 0.f;
-                v.y = k0 + 1 < S.ca ? v.y * sc : 0.f;
-                v.z = k0 + 2 < S.ca ? v.z * sc : 0.f;
-                v.w = k0 + 3 < S.ca ? v.w * sc : 0.f;
-                if constexpr (HASB) {      // (component-wise: a select between the two ARRAYS would index them dynamically)
-                    const float4 rb = rawb[it];
-                    const bool isa = k0 < pa4;
-                    v.x = isa ? v.x : rb.x; v.y = isa ? v.y : rb.y; v.z = isa ? v.z : rb.z; v.w = isa ? v.w : rb.w;
+                if constexpr (KIND == GEN_K_U8) {
+                    const uint8_t* s = (const uint8_t*)S.a + pix * (uint32_t)S.ca;
+                    raw[it] = make_float4((float)s[c0], (float)s[c1], (float)s[c2], (float)s[c3]);
+                } else {
+                    const float* s = (const float*)S.a + pix * (uint32_t)S.ca;
+                    raw[it] = make_float4(s[c0], s[c1], s[c2], s[c3]);
                 }
+                if constexpr (HASB) rawb[it] = *(const float4*)pb;
             }
-            *(float4*)(tile + (size_t)e * 4) = inb ? v : f4zero();
         }
-    }
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            const int r = rb + it * rpi + rsub, y = row0 + r - halo;
+            if (r < rows) {
+                const bool inb = kok && y >= 0 && y < H;
+                float4 v = raw[it];
+                if constexpr (KIND == GEN_K_POOLEXP) {
+                    const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
+                    v.x = (am[it] & 255u) == pos ? v.x : 0.f;
+                    v.y = ((am[it] >> 8) & 255u) == pos ? v.y : 0.f;
+                    v.z = ((am[it] >> 16) & 255u) == pos ? v.z : 0.f;
+                    v.w = (am[it] >> 24) == pos ? v.w : 0.f;
+                } else if constexpr (KIND == GEN_K_F32S || KIND == GEN_K_U8) {
+                    const float sc = KIND == GEN_K_U8 ? 1.f / 255.f : 1.f;
+                    v.x = k0 < S.ca ? v.x * sc : 0.f;
+                    v.y = k0 + 1 < S.ca ? v.y * sc : 0.f;
+                    v.z = k0 + 2 < S.ca ? v.z * sc : 0.f;
+                    v.w = k0 + 3 < S.ca ? v.w * sc : 0.f;
+                    if constexpr (HASB) {      // (component-wise: a select between the two ARRAYS would index them dynamically)
+                        const float4 rb4 = rawb[it];
+                        v.x = isa ? v.x : rb4.x; v.y = isa ? v.y : rb4.y; v.z = isa ? v.z : rb4.z; v.w = isa ? v.w : rb4.w;
+                    }
+                }
+                *(float4*)(dst0 + (size_t)r * PW * GEN_KC) = inb ? v : f4zero();
+            }
+        }
     }
 }
 

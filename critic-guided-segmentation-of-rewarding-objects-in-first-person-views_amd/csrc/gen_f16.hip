@@ -22,7 +22,11 @@ struct Gen16ConvParams {
     void* out;                 // fp16 NHWC (out_f32 = 0) or fp32
     int a_u8, ca, cb, ups, n, hw, co, act, pool, th, out_f32;
     float slope;
+    unsigned long long* dbg;   // debug hook (dbg_gen16_stamps): s_memtime at the stage boundaries of the first 4096 workgroups
 };
+
+unsigned long long* g_gen16_stamps = nullptr;
+#define G16_STAMP(k) do { if (P.dbg && tid == 0 && blockIdx.x < 4096) P.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ int g16_pa4(const Gen16ConvParams& P) { return (P.ca + 3) & ~3; }
 
@@ -51,8 +55,10 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
     const int row0 = strip * TH;
     const int pa4 = g16_pa4(P), cp = pa4 + P.cb, nchunk = (cp + 15) / 16;
     const int ntiles = TH * W / 16, QW = W / 2;
-    const int HB = H / P.ups, WB = W / P.ups;
+    const int ush = P.ups == 4 ? 2 : (P.ups == 2 ? 1 : 0), HB = H >> ush, WB = W >> ush;
+    const int lw = __builtin_ctz(W) + 2;                 // log2 of the interior elements per tile row (W pixels x 4 quads)
 
+    G16_STAMP(0);
     frag4 acc[G16_MAX_TPW][NCB];
     int apix[G16_MAX_TPW], apar[G16_MAX_TPW];       // the lane's pixel (tile coordinates, before the tap offset) and its row parity
 #pragma unroll
@@ -67,36 +73,52 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
     }
     const half_t* wl = P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 4;      // + ((tap * nchunk + ch) * 4) * ncol * 4
 
+    for (int e = tid; e < (TH + 2) * 2 * 4; e += 256) {      // the two halo columns: zero for every chunk, written once
+        const int g = e & 3, side = (e >> 2) & 1, r = e >> 3;
+        *(half4_t*)(tile + ((size_t)(r * PW + (side ? W + 1 : 0)) * 4 + g) * 4) = half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    }
     for (int ch = 0; ch < nchunk; ++ch) {
         // ---- stage 16 channels of the strip (halo included) as halves: one 8-byte quad per (pixel, quad) ----
         // (a rolled loop on purpose: this kernel lives on occupancy -- 28 VGPRs; batching the rounds' loads or preloading the
         //  nine taps' weights raised the register count and made it 1.1x / 2x slower)
-        const int ngrp = (TH + 2) * PW * 4;
-        for (int e = tid; e < ngrp; e += 256) {
-            const int g = e & 3, px = e >> 2, c = px % PW, r = px / PW;
-            const int y = row0 + r - 1, x = c - 1, k0 = ch * 16 + 4 * g;
-            half4_t v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-            if (y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
-                if (k0 < pa4) {
-                    const size_t pix = ((size_t)img * H + y) * W + x;
-                    if constexpr (A_U8) {
-                        const uint8_t* s8 = (const uint8_t*)P.a + pix * P.ca + k0;
-                        const float sc = 1.f / 255.f;
-                        v[0] = (half_t)(s8[0] * sc);
-                        if (k0 + 1 < P.ca) v[1] = (half_t)(s8[1] * sc);
-                        if (k0 + 2 < P.ca) v[2] = (half_t)(s8[2] * sc);
-                        if (k0 + 3 < P.ca) v[3] = (half_t)(s8[3] * sc);
-                    } else {
-                        v = *(const half4_t*)((const half_t*)P.a + pix * P.ca + k0);       // (ca % 4 == 0)
+        // Row-wise, shift-only index math (the staging is VALU-bound: s_memtime stamps put it at half of a workgroup's life when
+        // the element index was decomposed by divisions): a tile row is W x 4 quads = a power of two of elements, a thread keeps
+        // ONE (column, quad) for all rows; only the interior columns are written (the halo columns were zeroed once above).
+        {
+            const int rows = TH + 2, rpi = lw >= 8 ? 1 : (256 >> lw);
+            const int g = tid & 3, x = (tid & ((1 << lw) - 1)) >> 2, rsub = lw >= 8 ? 0 : tid >> lw;
+            const int k0 = ch * 16 + 4 * g;
+            const bool kok = k0 < cp, isa = k0 < pa4;
+            half_t* const dst0 = tile + ((size_t)(1 + x) * 4) * 4;
+            for (int rb = 0; rb < rows; rb += rpi) {
+                const int r = rb + rsub, y = row0 + r - 1;
+                if (r < rows) {
+                    half4_t v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                    if (kok && y >= 0 && y < H) {
+                        if (isa) {
+                            const uint32_t pix = (uint32_t)((img * H + y) * W + x);
+                            if constexpr (A_U8) {
+                                const uint8_t* s8 = (const uint8_t*)P.a + pix * (uint32_t)P.ca + k0;
+                                const float sc = 1.f / 255.f;
+                                v[0] = (half_t)(s8[0] * sc);
+                                if (k0 + 1 < P.ca) v[1] = (half_t)(s8[1] * sc);
+                                if (k0 + 2 < P.ca) v[2] = (half_t)(s8[2] * sc);
+                                if (k0 + 3 < P.ca) v[3] = (half_t)(s8[3] * sc);
+                            } else {
+                                v = *(const half4_t*)((const half_t*)P.a + (pix * (uint32_t)P.ca + k0));       // (ca % 4 == 0)
+                            }
+                        } else if constexpr (HASB) {
+                            const uint32_t pixb = (uint32_t)((img * HB + (y >> ush)) * WB + (x >> ush));
+                            v = *(const half4_t*)(P.b + (pixb * (uint32_t)P.cb + (k0 - pa4)));
+                        }
                     }
-                } else if constexpr (HASB) {
-                    const size_t pixb = ((size_t)img * HB + y / P.ups) * WB + x / P.ups;
-                    v = *(const half4_t*)(P.b + pixb * P.cb + (k0 - pa4));
+                    *(half4_t*)(dst0 + ((size_t)r * PW * 4 + (g ^ ((r & 1) << 1))) * 4) = v;
                 }
             }
-            *(half4_t*)(tile + ((size_t)px * 4 + (g ^ ((r & 1) << 1))) * 4) = v;
         }
+        G16_STAMP(1);
         __syncthreads();
+        G16_STAMP(2);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int ty = tap / 3, toff = ty * PW + tap % 3;
@@ -115,8 +137,10 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
                 }
             }
         }
+        G16_STAMP(3);
         __syncthreads();
     }
+    G16_STAMP(4);
     // ---- epilogue: D[m = 4 kq + j][n = l15] ----
 #pragma unroll
     for (int c = 0; c < NCB; ++c) {
@@ -145,6 +169,7 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
             }
         }
     }
+    G16_STAMP(5);
 }
 
 struct Gen16GemmParams {
@@ -191,6 +216,8 @@ __global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
 
 }  // namespace
 
+extern "C" int dbg_gen16_stamps(unsigned long long* p) { g_gen16_stamps = p; return CGS_OK; }
+
 extern "C" int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
     const int cp = ((ca + 3) & ~3) + cb;
@@ -216,7 +243,7 @@ extern "C" int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t 
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     Gen16ConvParams P{src_a, (const half_t*)src_b, (const half_t*)w16, bias, out, a_is_u8, ca, cb, cb > 0 ? ups : 1, n, hw, co, act, pool,
-                      gen_strip_rows(hw), out_is_f32, slope};
+                      gen_strip_rows(hw), out_is_f32, slope, g_gen16_stamps};
     const int ncb = (co + 15) / 16, strips = hw / P.th;
     const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
     const size_t lds = (size_t)(P.th + 2) * (hw + 2) * 16 * sizeof(half_t);

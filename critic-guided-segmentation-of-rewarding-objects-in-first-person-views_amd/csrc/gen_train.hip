@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) g
         for (int t = 0; t < NT; ++t) acc[t][c] = frag4{0.f, 0.f, 0.f, 0.f};
     }
 
+    gen_zero_halo_cols(tin, W, TH, 1, tid);                    // (the staging writes the interior columns only)
     for (int img = g; img < P.n; img += P.G) {
         for (int strip = 0; strip < strips; ++strip) {
             int ltid = tid;                                    // opaque per strip: the staging addresses of all iterations are
