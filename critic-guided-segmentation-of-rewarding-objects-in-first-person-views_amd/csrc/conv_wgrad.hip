@@ -18,7 +18,11 @@ static constexpr int kMaxWgradBlocks = 1024;
 template <class G>
 static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMGS - 1) / G::IMGS; }
 template <class G>
-static int wg_blocks(int n) { int t = wg_tiles<G>(n); return t < kMaxWgradBlocks ? t : kMaxWgradBlocks; }
+static int wg_blocks(int n) {
+    static const int cap = [] { const char* e = std::getenv("CGS_WGRAD_BLOCKS"); return e ? atoi(e) : kMaxWgradBlocks; }();
+    int t = wg_tiles<G>(n);
+    return t < cap ? t : cap;
+}
 
 template <class C, bool SPARSE>
 __global__ void __launch_bounds__(C::G::THREADS) wgrad_any_kernel(WgradParams P) {
