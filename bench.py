@@ -238,7 +238,8 @@ def generic_mode(args, dev, rank):
     ach = flops * n / dt / 1e12
     print(json.dumps({"metric": f"Hourglass+critic {args.mode} images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
                       "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
-                      "higher_is_better": True, "dtype": "f32", "data": "synthetic", "config": {"workload": what, "batch": n},
+                      "higher_is_better": True, "dtype": "f16 (f32 accumulate)" if (args.fp16 and args.mode == "infer") else "f32",
+                      "data": "synthetic", "config": {"workload": what, "batch": n},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
                                    "traffic": None, "flops_per_image": flops}}), flush=True)
 
