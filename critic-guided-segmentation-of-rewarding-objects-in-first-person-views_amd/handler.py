@@ -48,24 +48,17 @@ class Handler:
         self.rank, local, self.world = parallel.env_world()
         self.device = f"cuda:{local}" if self.world > 1 else "cuda"
         print("device:", self.device)
-        self.models = dict()
-        self.criticname = "critic"
-        self.maskername = "masker"
-        self.ious = 0, 0
-        self.bestepoch = 0
+        # attribute names, directory layout and checkpoint file names are the reference's (main.py:66-107): they are the contract
+        self.criticname, self.maskername = "critic", "masker"
+        self.ious, self.bestepoch = (0, 0), 0
         self.reset_models()
-        self.models[self.criticname] = self.critic
-        self.models[self.maskername] = self.masker
+        self.models = {self.criticname: self.critic, self.maskername: self.masker}
         self.critic_args, self.masker_args = checkpoint_names(args)
-        self.path = f"{args.name}/"
-        self.train_path = self.path + "train/"
-        self.result_path = self.path + "results/"
-        self.save_path = self.path + "saves/"
-        self.data_path = "runs/data/straight/"
-        self.save_paths = {
-            self.criticname: f"{self.save_path}critic-{self.critic_args}.pt",
-            self.maskername: f"{self.save_path}masker-{self.masker_args}.pt",
-        }
+        root = f"{args.name}/"
+        self.path, self.data_path = root, "runs/data/straight/"
+        self.train_path, self.result_path, self.save_path = (root + sub for sub in ("train/", "results/", "saves/"))
+        self.save_paths = {name: f"{self.save_path}{name}-{tag}.pt"
+                           for name, tag in ((self.criticname, self.critic_args), (self.maskername, self.masker_args))}
         self._engines = {}
 
     # ------------------------------------------------------------------ models / checkpoints
@@ -77,28 +70,24 @@ class Handler:
             self.sepcrit = NewCritic(bottleneck=args.neck, chfak=args.chfak, dropout=args.dropout).to(self.device)
 
     def load_models(self, modelnames=[]):
-        if not modelnames:
-            modelnames = self.models.keys()
-        for model in modelnames:
-            save_path = self.save_paths[model]
-            if not os.path.exists(save_path):
+        """Loads the named checkpoints (all when empty); False at the first missing file (main.py:130-141)."""
+        for name in (modelnames or list(self.models)):
+            ckpt = self.save_paths[name]
+            if not os.path.isfile(ckpt):
                 if not self.args.train:
-                    print(f"{save_path} not found")
+                    print(f"{ckpt} not found")
                 return False
-            print("loading:", save_path)
-            self.models[model].load_state_dict(torch.load(save_path, map_location=torch.device(self.device)))
+            print("loading:", ckpt)
+            self.models[name].load_state_dict(torch.load(ckpt, map_location=torch.device(self.device)))
         return True
 
     def save_models(self, modelnames=[]):
         if self.rank != 0:          # replicas are identical: one writer
             return
         os.makedirs(self.save_path, exist_ok=True)
-        if not modelnames:
-            modelnames = self.models.keys()
-        for model in modelnames:
-            save_path = self.save_paths[model]
-            print("saving:", save_path)
-            torch.save(self.models[model].state_dict(), save_path)
+        for name in (modelnames or list(self.models)):
+            print("saving:", self.save_paths[name])
+            torch.save(self.models[name].state_dict(), self.save_paths[name])
 
     # ------------------------------------------------------------------ data
     def collect_data(self):
@@ -115,15 +104,12 @@ class Handler:
         return X, Y, I
 
     def load_data(self, batch_size=64):
-        args = self.args
+        """Train / test split (the last --testsize frames are the test set) and the --threshrew binarisation (main.py:113-128)."""
         X, Y, I = self.collect_data()
-        train = slice(0, -args.testsize)
-        test = slice(-args.testsize, None)
-        self.X, self.Y, self.I = X[train], Y[:, train], I[train]
-        self.XX, self.YY, self.II = X[test], Y[:, test], I[test]
-        if args.threshrew:
-            self.Y = (self.Y > args.threshrew).astype(np.float64)
-            self.YY = (self.YY > args.threshrew).astype(np.float64)
+        cut, thr = -self.args.testsize, self.args.threshrew
+        label = (lambda y: (y > thr).astype(np.float64)) if thr else (lambda y: y)
+        self.X, self.Y, self.I = X[:cut], label(Y[:, :cut]), I[:cut]
+        self.XX, self.YY, self.II = X[cut:], label(Y[:, cut:]), I[cut:]
         print("dataset shapes", X.shape, Y.shape, self.X.shape, self.Y.shape)
         self.batch_size = batch_size
 
@@ -342,71 +328,82 @@ class Handler:
             raise NotImplementedError("-noevalmode together with -salience (Dropout inside the saliency backward) is not implemented")
         if args.process_salience and not args.salience:
             raise ValueError("-process_salience needs -salience (the reference collects the maps only then, main.py:1136-1147)")
+        files = os.listdir(folder)
+        frames = np.stack([np.array(Image.open(os.path.join(folder, f)))[..., :3] for f in files]) / 255.0     # NHWC float64 in [0,1]
+        stems = [f.rsplit(".", 1)[0] for f in files if "." in f]
+        fp16 = bool(getattr(args, "fp16", False))      # (this build's switch) BASELINE config 4: fp16 layers on the uint8 frames
+
+        def to_device(chunk):
+            t = torch.from_numpy(chunk).float().to(self.device)
+            return (t * 255.0).round().to(torch.uint8) if fp16 else t
+
+        preds, M, sal = self._sweep_masks(frames, to_device, "segmentation in progress", want_saliency=bool(args.salience), fp16=fp16)
+        print()
+        print("postprocessing...")
+        # one column per output kind, in the reference's order; the file name of a column is its POSITION in `kinds` (main.py:1212-1223)
+        cols = [M]
+        if args.binarymaskthreshold:
+            cols.append(M >= args.binarymaskthreshold)
+        if args.process_salience:       # main.py:1176-1197
+            cols += list(self._saliency_post(sal, preds, args.salience_thresh, args.salglobal))
+        kinds = ("raw-mask", "thresholded-mask", "crf-mask", "saliency-map", "thresholded-saliency", "crf-saliency")
+        out_dir = args.mask_output_imgs
+        os.makedirs(out_dir, exist_ok=True)
+        to_u8 = lambda a: (a * 255).astype(np.uint8)
+        grey_rgb = [np.repeat(c, 3, axis=1).transpose(0, 2, 3, 1) for c in cols]          # [n,1,64,64] -> [n,64,64,3]
+        for i, stem in enumerate(stems[:len(frames)]):
+            if args.concatenated:       # frame | column 1 | column 2 ... side by side
+                strip = np.concatenate([to_u8(frames[i])] + [to_u8(g[i]) for g in grey_rgb], axis=1)
+                Image.fromarray(strip).save(f"{out_dir}/{stem}_with_mask.png")
+            else:
+                for kind, g in zip(kinds, grey_rgb):
+                    Image.fromarray(to_u8(g[i])).save(f"{out_dir}/{stem}-{kind}.png")
+        return M
+
+    def _sweep_masks(self, X, to_device, progress, want_saliency=False, fp16=False, batchsize=128):
+        """The inference loop shared by -process and -eval (main.py:1130-1151, 900-953): eval-mode critic + masker over X in batches
+        of 128, optionally the saliency baseline |d mean(pred) / d batch| summed over the colour channels.
+        Returns (preds [n], masks [n,1,64,64], saliency [n,1,64,64] or None) as numpy."""
+        args = self.args
         self.critic.eval()
         self.masker.eval()
         eng = self._engine(2 * 32)
-        batchsize = 128
-        img_names = os.listdir(folder)
-        X = np.stack([np.array(Image.open(f"{folder}/{name}"))[..., :3] for name in img_names]) / 255.0
-        img_names = [a[:-1 - a[::-1].index(".")] for a in img_names if "." in a]
-        M, preds, salM = [], [], []
-        for bidx in range(0, len(X), batchsize):
-            print("segmentation in progress", round(bidx / len(X), 2), end="%\r")
-            batch = torch.from_numpy(X[bidx:bidx + batchsize]).float().to(self.device)   # NHWC fp32 in [0,1]
-            if args.salience:           # main.py:1136-1147: |d mean(pred) / d batch| summed over the colour channels
-                _p, dx = eng.saliency(batch)
-                salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
-            if getattr(args, "fp16", False):     # (this build's switch) BASELINE config 4: fp16 layers on the uint8 frames
-                pred, Z = eng.infer((batch * 255.0).round().to(torch.uint8), fp16=True)
+        preds, masks, sal = [], [], []
+        for lo in range(0, len(X), batchsize):
+            print(progress, round(lo / len(X), 2), end="%\r")
+            batch = to_device(X[lo:lo + batchsize])
+            if want_saliency:
+                _unused, dx = eng.saliency(batch)
+                sal.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
+            if fp16:
+                pred, Z = eng.infer(batch, fp16=True)
             else:
                 pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # -noevalmode: Dropout stays on (main.py:1109-1118)
             preds.append(pred.cpu().numpy())
-            M.append(Z.cpu().numpy()[:, None])
-        print()
-        print("postprocessing...")
-        M = np.concatenate(M, axis=0)
-        preds = np.concatenate(preds, axis=0)
-        allM = [M]
-        if args.binarymaskthreshold:
-            allM.append(M >= args.binarymaskthreshold)
-        if args.process_salience:       # main.py:1176-1197 (file names follow the reference's column list by POSITION)
-            allM.extend(self._saliency_post(np.concatenate(salM, axis=0), preds, args.salience_thresh, args.salglobal))
-        outpath = args.mask_output_imgs
-        os.makedirs(outpath, exist_ok=True)
-        masks = np.stack([X] + [np.concatenate((m, m, m), axis=1).transpose(0, 2, 3, 1) for m in allM], axis=1)
-        columns = ["raw-mask", "thresholded-mask", "crf-mask", "saliency-map", "thresholded-saliency", "crf-saliency"]
-        for fidx in range(masks.shape[0]):
-            if args.concatenated:
-                array = np.concatenate((masks[fidx] * 255).astype(np.uint8), axis=-2)
-                Image.fromarray(array).save(f"{outpath}/{img_names[fidx]}_with_mask.png")
-            else:
-                for midx in range(1, masks.shape[1]):
-                    Image.fromarray((masks[fidx, midx] * 255).astype(np.uint8)).save(
-                        f"{outpath}/{img_names[fidx]}-{columns[midx - 1]}.png")
-        return M
+            masks.append(Z.cpu().numpy()[:, None])
+        cat = lambda parts: np.concatenate(parts, axis=0)
+        return cat(preds), cat(masks), (cat(sal) if want_saliency else None)
 
     @staticmethod
     def _saliency_post(salM, preds, thresh, salglobal):
-        """main.py:976-1003 / 1176-1197: normalise the |gradient| maps (global mean x thresh, or each map's k-th sorted
-        value), weight by the critic's prediction, clip at 1, threshold.  Returns (salM, salhardM uint8)."""
-        import sys as _sys
+        """main.py:976-1003 / 1176-1197: normalise the |gradient| maps (by the global mean of the non-negative part x thresh, or by
+        each map's k-th smallest value), weight them by the critic's prediction, clip at 1, threshold.  Returns (maps, hard uint8)."""
+        tiny = np.finfo(np.float64).tiny                      # (= sys.float_info.min: keeps 0 / 0 finite)
         if salglobal:
-            norm = (salM * (salM >= 0)).mean() * thresh
+            scale = np.where(salM >= 0, salM, 0.0).mean() * thresh
         else:
-            k = int(salM.shape[-1] * salM.shape[-2] * thresh)
-            norm = np.sort(salM.reshape(salM.shape[0], 1, -1), axis=-1)[:, :, k, None, None]
-        salM = salM / (norm + _sys.float_info.min)
-        salM = salM * preds[:, None, None, None]
-        salM[(salM >= 1)] = 1
-        return salM, (salM > thresh).astype(np.uint8)
+            n, hw = salM.shape[0], salM.shape[-1] * salM.shape[-2]
+            scale = np.sort(salM.reshape(n, 1, hw), axis=-1)[:, :, int(hw * thresh), None, None]
+        out = np.minimum(salM / (scale + tiny) * preds.reshape(-1, 1, 1, 1), 1.0)
+        return out, (out > thresh).astype(np.uint8)
 
     # ------------------------------------------------------------------ -eval: IoU on the labelled red-trees set
     @staticmethod
     def get_iou(A, B):
-        """main.py:1265-1270: |A & B| / |A | B| over the whole set, rounded to 3 digits."""
-        intersection = np.sum(A & B)
-        union = np.sum(A | B)
-        return round(float(intersection / union), 3) if union else float("nan")
+        """Intersection over union of two boolean stacks taken over the WHOLE set, 3 digits (main.py:1265-1270)."""
+        A, B = np.asarray(A, dtype=bool), np.asarray(B, dtype=bool)
+        both, either = np.count_nonzero(A & B), np.count_nonzero(A | B)
+        return round(both / either, 3) if either else float("nan")
 
     def eval(self, folder="", vis=False):
         """main.py:891-1020 without CRF / videos: masks of `red-trees/X.npy[100:5000:2]` (batch 128, eval mode), thresholded
@@ -418,37 +415,22 @@ class Handler:
             raise NotImplementedError("-noevalmode together with -salience (Dropout inside the saliency backward) is not implemented")
         if args.crf or args.resimages or folder or vis:
             raise NotImplementedError("-crf / -resimages / folder / video evaluation are outside this build's scope")
-        evaldatapath = "red-trees/"
-        X = np.load(evaldatapath + "X.npy")                       # uint8 [n,64,64,3] (the reference divides by 255 here)
-        Y = np.expand_dims(np.all(np.load(evaldatapath + "Y.npy"), axis=-1), axis=-1)
-        X = X[100:5000:2]
-        Y = Y[100:5000:2]
-        self.critic.eval()
-        self.masker.eval()
-        eng = self._engine(2 * 32)
-        batchsize = 128
-        M, salM, preds = [], [], []
-        for bidx in range(0, len(X), batchsize):
-            print("eval at", bidx / len(X), end="\r")
-            xb = X[bidx:bidx + batchsize]
-            batch = torch.from_numpy(np.ascontiguousarray(xb)).to(self.device)
-            if batch.dtype != torch.uint8 or args.salience:
-                batch = (batch.double() / 255.0).float()            # main.py:921,939 (float64 / 255 -> float32)
-            if args.salience:
-                _p, dx = eng.saliency(batch)
-                salM.append(dx.abs().sum(dim=-1)[:, None].cpu().numpy())
-            pred, Z = eng.infer(batch, train_mode=bool(args.noevalmode))      # main.py:900-909
-            preds.append(pred.cpu().numpy())
-            M.append(Z.cpu().numpy()[:, None])
-        M = np.concatenate(M, axis=0)
-        preds = np.concatenate(preds, axis=0)
-        hardM = M > args.eval_thresh
-        Yc = Y.transpose(0, 3, 1, 2)
-        ious = [self.get_iou(hardM.squeeze(), Yc.squeeze())]
-        if args.salience:
-            salM, salhardM = self._saliency_post(np.concatenate(salM, axis=0), preds, args.salience_thresh, args.salglobal)
-            ious.append(self.get_iou(salhardM.squeeze(), Yc.squeeze()))
-        print(f"\nRESULTS", ious)
+        pick = slice(100, 5000, 2)                                        # the reference's evaluation subset
+        frames = np.load("red-trees/X.npy")[pick]                         # uint8 [n,64,64,3] (the reference divides by 255 here)
+        truth = np.load("red-trees/Y.npy")[pick].all(axis=-1)             # [n,64,64] bool: all three label channels set
+        want_sal = bool(args.salience)
+
+        def to_device(chunk):
+            t = torch.from_numpy(np.ascontiguousarray(chunk)).to(self.device)
+            # uint8 frames go to the kernels as they are (/255 fused); the saliency backward needs the float batch (main.py:921,939)
+            return (t.double() / 255.0).float() if (t.dtype != torch.uint8 or want_sal) else t
+
+        preds, M, sal = self._sweep_masks(frames, to_device, "eval at", want_saliency=want_sal)
+        ious = [self.get_iou(M[:, 0] > args.eval_thresh, truth)]
+        if want_sal:
+            _maps, hard = self._saliency_post(sal, preds, args.salience_thresh, args.salglobal)
+            ious.append(self.get_iou(hard[:, 0], truth))
+        print("\nRESULTS", ious)
         return ious
 
     # ------------------------------------------------------------------ helpers
