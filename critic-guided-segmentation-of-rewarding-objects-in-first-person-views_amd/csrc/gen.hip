@@ -82,6 +82,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) g
         __syncthreads();
         const int rem = cp - ch * GEN_KC, ksteps = rem >= GEN_KC ? 4 : (rem + 3) >> 2;      // (a partial last chunk: fewer k-steps)
         // ---- 9 taps x k-steps: operands from LDS only; a weight operand is shared by the wave's pixel tiles ----
+        // (the weight operand of a k-step comes from L1/L2: it is requested ONE k-step ahead, so its round trip overlaps the
+        //  previous step's MFMAs instead of standing in front of its own -- 36 serial round trips per chunk otherwise)
+        auto load_b = [&](float (&bv)[NCB], int tap, int s) {
+            if constexpr (WLDS) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) bv[c] = wl[(tap * 16 + 4 * s + kq) * NC + 16 * c + l15];
+            } else {
+                const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
+#pragma unroll
+                for (int c = 0; c < NCB; ++c)
+                    bv[c] = (ci >= 0 && col0 + 16 * c < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col0 + 16 * c] : 0.f;
+            }
+        };
+        float bn[NCB];
+        load_b(bn, 0, 0);
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap) {
             const int toff = ((tap / 3) * PW + tap % 3) * GEN_KC;
@@ -89,15 +104,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) g
             for (int s = 0; s < 4; ++s) {
                 if (s < ksteps) {
                     float b[NCB];
-                    if constexpr (WLDS) {
 #pragma unroll
-                        for (int c = 0; c < NCB; ++c) b[c] = wl[(tap * 16 + 4 * s + kq) * NC + 16 * c + l15];
-                    } else {
-                        const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
-#pragma unroll
-                        for (int c = 0; c < NCB; ++c)
-                            b[c] = (ci >= 0 && col0 + 16 * c < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col0 + 16 * c] : 0.f;
-                    }
+                    for (int c = 0; c < NCB; ++c) b[c] = bn[c];
+                    if (s + 1 < ksteps) load_b(bn, tap, s + 1);
+                    else if (tap < 8) load_b(bn, tap + 1, 0);
 #pragma unroll
                     for (int i = 0; i < GEN_MAX_TPW; ++i) {
                         if (wave + 4 * i < ntiles) {
