@@ -637,7 +637,7 @@ extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const 
 // ------------------------------------------------------------------------------------------------
 struct HeadWgradRange { const float* hvec; const float* e4; const float* d_o4; int n, n_o4; };
 struct HeadWgradParams { HeadWgradRange r[2]; float* slab_head; float* slab_pw; };
-static constexpr int kHwIpb = 16;
+static constexpr int kHwIpb = 8;      // images per workgroup (8: 192 workgroups at 1536 images; 16 left most CUs idle)
 
 __global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) {
     __shared__ __attribute__((aligned(16))) float xs[kHwIpb][260];      // +4: conflict-free column reads
