@@ -8,7 +8,6 @@ Per phase-2 step:  critic fwd [B|A] -> masker fwd A -> mixes (materialised, fp32
   -> critic data-gradient pass on [rep|inj] (down to the images) -> mix backward -> masker backward
   -> critic data-gradient pass on A (skip gradients added) -> ONE weight-gradient pass of the critic over [A|rep|inj]
   -> slab reduction [-> all-reduce] -> Adam."""
-import ctypes as C
 import os
 from typing import Dict
 
@@ -17,7 +16,6 @@ import torch
 from . import _lib
 from . import generic as gen
 from . import hourglass as hg
-from . import parallel
 from .engine import HourglassEngine, _align4
 from .spec import critic_layout, masker_layout
 

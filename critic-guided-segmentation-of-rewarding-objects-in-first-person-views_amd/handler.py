@@ -3,14 +3,10 @@
 HIP engine.  Same method names, same checkpoint / dataset file naming, same output file names.
 
 Out of scope here: MineRL collection (``collect_data`` only reads an existing
-gz-pickle), CRF, videos / PNG debug grids, the ``-eval`` IoU path (section 8 f2).
+gz-pickle), CRF, videos / PNG debug grids.  ``-eval`` (section 8 f2) is carried over without CRF / videos.
 """
-import gzip
 import math
 import os
-import pickle
-import sys
-from itertools import chain
 
 import numpy as np
 import torch
