@@ -107,6 +107,7 @@ class HourglassEngine:
         # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
         # the cross-queue joins cost what the overlap gains)
         self.side = hg.SideStream(torch.cuda.Stream(device=self.dev) if overlap_wgrad else None)
+        self.b_side = hg.SideStream(torch.cuda.Stream(device=self.dev)) if os.environ.get("CGS_B_SIDE") == "1" else None
         self._plans: Dict[str, hg.SlabPlan] = {}
 
     # ---- parameters --------------------------------------------------------------------------
@@ -208,8 +209,16 @@ class HourglassEngine:
         fm_ptr = self.fm.data_ptr()
         pw = (C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")), C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")),
               self._o4_full)
-        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n),
-                          pw=None if self.separate else pw)
+        if self.b_side is not None and not self.separate:
+            # critic(B) is only needed at the loss: on a second stream (a parallel branch of the graph) it overlaps the
+            # masker's forward chain, and the critical path starts with half-size launches on A alone
+            with self.b_side.fork():
+                hg.critic_forward(self.fc, self.lc, B, n, drop.shifted(0), out=self._cview(0, n))
+            pwa = (pw[0], pw[1], self.mbuf["o4"])
+            hg.critic_forward(self.fc, self.lc, A, n, drop.shifted(n), out=self._cview(n, 2 * n), pw=pwa)
+        else:
+            hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n),
+                              pw=None if self.separate else pw)
         sa = self._cview(n, 2 * n)
         if self.separate:     # main.py:389-390: the masker's inputs come from the second critic's pass over A
             pws = (pw[0], pw[1], self.mbuf["o4"])
@@ -228,6 +237,8 @@ class HourglassEngine:
             mixsrc = self.mixed[:nmix]
             _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
             hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
+        if self.b_side is not None:
+            self.b_side.join()           # pred of B (the replace loss's target) is needed from here on
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0) | (0 if self.staticnorm else 8)
         ft = self.fused_tail
         if not ft:
