@@ -342,3 +342,59 @@ def test_cli_train_at_chfak2(tmp_path):
     with torch.no_grad():
         p = orc.critic_apply(pc, orc.u8_to_nchw(X[:256])).squeeze(1).numpy()
     assert np.corrcoef(p, Y[1, :256])[0, 1] > 0.9
+
+
+GEN_DP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch
+import torch.distributed as dist
+import cgs_amd
+from cgs_amd import parallel, generic_engine
+from oracle import hourglass_ref as orc          # (test infrastructure: the seeded stand-in weights)
+pg = parallel.init_from_env("gloo")              # 2 ranks share the one GPU of the box
+rank, _, world = parallel.env_world()
+pc, pm = orc.seeded_params(orc.critic_shapes(2), 21), orc.seeded_params(orc.masker_shapes(2), 22)
+rs = np.random.RandomState(3)
+n = 16
+A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).cuda()
+Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
+sl = parallel.shard_slice(n, rank, world)
+e = generic_engine.GenericEngine(n // world, chfak=2, dropout=0.0, process_group=pg)
+e.load_state(pc, pm)
+for _ in range(2):
+    e.phase2_step(A[sl], B[sl], Y[sl])
+torch.cuda.synchronize()
+flat = e.flat.cpu()
+others = [torch.empty_like(flat) for _ in range(world)]
+dist.all_gather(others, flat)
+assert all(torch.equal(o, others[0]) for o in others), "replicas diverged"
+if rank == 0:
+    np.save({out!r}, flat.numpy())
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_generic_engine_data_parallel_world2(tmp_path):
+    """GenericEngine (chfak 2) under data parallelism: two ranks (gloo rendezvous, both on this box's GPU), half the batch each,
+    2 steps: replicas stay bit-identical and match the single-process full-batch run."""
+    import os, subprocess, sys
+    from test_gpu_modules import REPO
+    out = str(tmp_path / "gen_dp_flat.npy")
+    script = tmp_path / "gen_dp_worker.py"
+    script.write_text(GEN_DP_WORKER.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    rs = np.random.RandomState(3)
+    n = 16
+    dev = torch.device("cuda:0")
+    A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    Y = torch.from_numpy(rs.rand(n).astype(np.float32)).to(dev)
+    e, _, _ = make_generic_engine(2, n, dropout=0.0)
+    for _ in range(2):
+        e.phase2_step(A, B, Y)
+    rel_close(np.load(out), e.flat.cpu().numpy(), "generic DP(2) parameters vs single process", rtol=1e-3, atol_scale=1e-4)
