@@ -3,6 +3,11 @@
 #pragma once
 #include "conv_tile.h"
 
+// 1: the FMA block of every 3x3 kernel runs on the matrix cores (mfma_plane, conv_tile.h); 0: on the vector ALU (fma_plane)
+#ifndef CGS_CONV_MFMA4
+#define CGS_CONV_MFMA4 1
+#endif
+
 struct ConvParams {
     const void* src_a;
     const float* src_b;
@@ -167,7 +172,10 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
     // Retire padding threads now (no barrier follows).  Besides saving work this keeps the compiler from
     // sinking the whole FMA block into the `if (live)` store region, which would leave every weight read
     // of the kernel live at once.  (The x4-upsample gradient sums across lanes, so it keeps all lanes.)
-    constexpr bool ALL_LANES = (C::EPI == EPI_DGRAD && C::UPS == 4);
+    // (matrix-core path: v_mfma ignores EXEC and broadcasts its weight operand from the lanes of one block, so every lane
+    //  must keep running -- and hold valid weight registers -- until the last MFMA; the stores below are guarded by `live`)
+    constexpr bool MFMA4 = CGS_CONV_MFMA4 && C::SRC != SRC_SCALAR;
+    constexpr bool ALL_LANES = (C::EPI == EPI_DGRAD && C::UPS == 4) || MFMA4;
     if constexpr (!ALL_LANES && !FUSED) {
         if (!live) return;
     }
@@ -189,6 +197,51 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
 #pragma unroll
             for (int o = 0; o < C::OCB; ++o) acc[i][o] = 0.f;
 
+        if constexpr (MFMA4) {
+            constexpr int OCG = (C::OCB + 3) / 4, CIN = C::CA + C::CB, NREG = (9 * CIN + 15) / 16;
+            constexpr int PA_FULL = C::CA / 4, REM = C::CA % 4;
+            float wreg[OCG][NREG];       // lane 4*b + i of register k: weight of step 16*k + b (= tap * CIN + ci), channel oc0 + 4*g + i
+            {
+                const int lb = (tid & 63) >> 2, li = tid & 3;
+#pragma unroll
+                for (int g = 0; g < OCG; ++g)
+#pragma unroll
+                    for (int k = 0; k < NREG; ++k) {
+                        const int step = 16 * k + lb, o = 4 * g + li;
+                        const bool ok = step < 9 * CIN && o < C::OCB;
+                        const int st = ok ? step : 0;
+                        const float wv = wf(st / CIN, st % CIN, oc0 + (ok ? o : 0));
+                        wreg[g][k] = ok ? wv : 0.f;
+                    }
+            }
+            frag4 a4[4][OCG];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < OCG; ++g) a4[i][g] = frag4{0.f, 0.f, 0.f, 0.f};
+            static_for<PA_FULL>([&](auto PAI) {
+                constexpr int pa = decltype(PAI)::value;
+                float4 pt[4][4];
+                read_patch_a<G>(pt, ldsA, pa, q, pcx);
+                mfma_plane<OCG, 4, CIN, 4 * pa, NREG>(a4, pt, wreg);
+            });
+            if constexpr (REM > 0) {
+                float4 pt[4][4];
+                read_patch_a<G>(pt, ldsA, PA_FULL, q, pcx);
+                mfma_plane<OCG, REM, CIN, 4 * PA_FULL, NREG>(a4, pt, wreg);
+            }
+            static_for<PB>([&](auto PBI) {
+                constexpr int pb = decltype(PBI)::value;
+                float4 pt[4][4];
+                if constexpr (C::UPS == 2) read_patch_b2<G>(pt, ldsB, pb, q);
+                else read_patch_b4<G>(pt, ldsB, pb, q);
+                mfma_plane<OCG, 4, CIN, C::CA + 4 * pb, NREG>(a4, pt, wreg);
+            });
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int o = 0; o < C::OCB; ++o) acc[i][o] = a4[i][o / 4][o % 4];
+        } else {
         if constexpr (C::SRC == SRC_SCALAR) {
             const float* t = (const float*)ldsA;
             float pt[4][4];
@@ -220,6 +273,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
                 else read_patch_b4<G>(pt, ldsB, pb, q);
                 fma_plane<C::OCB, 4>(acc, pt, wf, C::CA + 4 * pb, oc0);
             }
+        }
         }
 
         // ---------------- epilogues ----------------

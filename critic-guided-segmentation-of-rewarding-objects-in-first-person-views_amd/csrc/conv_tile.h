@@ -17,6 +17,8 @@
 //   * weights come from the constant address space (s_load -> SGPR operands of v_fmac_f32).
 #pragma once
 #include "cgs_common.h"
+#include <utility>
+#include <type_traits>
 
 enum { SRC_F32 = 0, SRC_U8C3 = 1, SRC_F32C3 = 2, SRC_POOLEXP = 3, SRC_SCALAR = 4, SRC_DH = 5, SRC_MIXC3 = 6, SRC_POOLEXP_DIFF = 7 };
 
@@ -324,6 +326,44 @@ __device__ __forceinline__ void fma_plane(float (&acc)[4][OCB], const float4 (&p
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same step on the matrix cores: v_mfma_f32_4x4x1_16B_f32 with the A operand broadcast from one of its 16 blocks
+// (cbsz = 4, abid = block) computes   D[lane][r] += A[4*abid + r] * B[lane]   (r = 0..3): with B = the lane's input value of
+// one (tap, input channel) and A = the four weights of one output-channel group, ONE instruction is the quad position's 4
+// FMAs of that step for all 64 lanes, at the full fp32 rate (tools/mfma4_peak.hip: 150 TFLOP/s sustained vs 115 for
+// v_fma_f32) with no padding rows or columns at 8 (or 3) channels.  A weight REGISTER holds 16 blocks = 16 (tap, channel)
+// steps of a channel group: lane 4*b + i of register k carries w[step 16*k + b][group's channel i]; the whole 8 -> 8 layer
+// is 9 registers.  An exact fp32 FMA chain in the same (tap, channel) order as fma_plane.
+// ------------------------------------------------------------------------------------------------
+typedef float frag4 __attribute__((ext_vector_type(4)));
+
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// steps (tap, ci) are numbered tap * CIN + ci over ALL input channels of the layer (both sources)
+template <int OCG, int NCH, int CIN, int CI0, int NREG>
+__device__ __forceinline__ void mfma_plane(frag4 (&acc)[4][OCG], const float4 (&pt)[4][4], const float (&wreg)[OCG][NREG]) {
+    static_for<9 * NCH>([&](auto S) {
+        constexpr int s = decltype(S)::value, tap = s / NCH, c = s % NCH, ky = tap / 3, kx = tap % 3;
+        constexpr int step = tap * CIN + CI0 + c, reg = step / 16, abid = step % 16;
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) {
+                const float x = f4get(pt[oy + ky][ox + kx], c);
+#pragma unroll
+                for (int g = 0; g < OCG; ++g)
+                    acc[oy * 2 + ox][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[g][reg], x, acc[oy * 2 + ox][g], 4, abid, 0);
+            }
+    });
 }
 
 template <int OCB, class WF>
