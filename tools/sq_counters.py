@@ -9,7 +9,10 @@ root, out = sys.argv[1], sys.argv[2]
 
 
 def load(sub):
-    f = max(glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    found = glob.glob(f"{root}/{sub}/**/*counter_collection.csv", recursive=True)
+    if not found:          # pass not collected (tools/sq_quick.sh runs the two SQ passes only)
+        return {}
+    f = max(found, key=os.path.getmtime)
     rows = list(csv.DictReader(open(f)))
     disp = collections.OrderedDict()
     for r in rows:
