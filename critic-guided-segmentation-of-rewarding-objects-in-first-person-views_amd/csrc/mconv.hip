@@ -657,14 +657,7 @@ int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, con
     return img_kind == CGS_SRC_U8 ? launch_mask_infer<WSRC_U8, false>(P, st) : launch_mask_infer<WSRC_F32, false>(P, st);
 }
 
-// training form: also stores h and the per-tile (sum |z|, sum z^2); zpart holds 2 * mask_train_partials(n) floats
-int mask_train_partials(int n) { return n * MaskInferGeo::STRIPS; }
-int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
-                      const float* b2, float* h, float* z, float* zpart, hipStream_t st) {
-    if (n <= 0) return CGS_OK;
-    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, h, zpart};
-    return img_kind == CGS_SRC_U8 ? launch_mask_infer<WSRC_U8, true>(P, st) : launch_mask_infer<WSRC_F32, true>(P, st);
-}
+// (the training form -- h stored, Z and the mask-loss partial sums from the same launch -- is csrc/mask_fwd.hip)
 
 template <int SRC>
 static int launch_mask0_fwd(Mask0FwdParams P, hipStream_t st) {

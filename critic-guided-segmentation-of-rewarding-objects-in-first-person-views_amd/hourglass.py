@@ -25,7 +25,7 @@ ENC0_MIX_FUSED = os.environ.get("CGS_ENC0_MIX_FUSED", "1") != "0"   # features.0
 MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
 # training forward: masker.0 + masker.2 in one kernel (h stored once).  Measured equal to the two-kernel form at N = 512 (103 us vs
 # 60 + 40 us: the one-kernel form holds 80 KB of LDS, 2 workgroups per CU, and its phases serialise), so it is opt-in for now.
-MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "0") != "0"
+MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "1") != "0"
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
 TAIL_FWD = os.environ.get("CGS_TAIL_FWD", "1") != "0"
 TAIL_BWD = os.environ.get("CGS_TAIL_BWD", "1") != "0"
