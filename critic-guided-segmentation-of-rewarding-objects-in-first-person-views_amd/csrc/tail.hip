@@ -16,7 +16,7 @@
 //
 // Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
 // masks these kernels draw.
-#include "tail_common.h"
+#include "tail4.h"
 #include <cstdlib>
 
 namespace {
@@ -77,23 +77,28 @@ struct TailEncFwdParams {
     unsigned long long* dbg;
 };
 
+// (round 3) features.6 and features.10 on v_mfma_f32_4x4x1 with lane = pixel (tail4.h): 216 instead of 90 x 4 MFMA-cycles-worth
+// of instructions per wave and image, 36 16-byte LDS reads instead of ~360 dword reads.
+using X1P = TileP<16, 16, 8, 8, 148>;     // e1
+using X2P = TileP<8, 8, 8, 8, 84>;        // dropout(e2)
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P) {
-    __shared__ __attribute__((aligned(16))) float x1[T16x8::FLOATS];     // e1 tile
-    __shared__ __attribute__((aligned(16))) float x2[T8x8::FLOATS];      // dropout(e2) tile
-    __shared__ __attribute__((aligned(16))) float w6s[72 * 8], w10s[72 * 16];
+    __shared__ __attribute__((aligned(16))) float x1[X1P::FLOATS];
+    __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
     __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
     __shared__ float red[8][32], es[32], hs[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
-    const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5;
     const DropCtx d2 = drop_ctx(P.drop_e2), d3 = drop_ctx(P.drop_e3), dh = drop_ctx(P.drop_h1);
 
-    // ---- once per workgroup: conv weights -> LDS (natural HWIO), halos -> 0, head weights -> registers ----
-    tile_zero<T16x8>(x1, tid);
-    tile_zero<T8x8>(x2, tid);
-    for (int e = tid; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
-    for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
+    // ---- once per workgroup: halos -> 0, conv weights -> registers (features.6: both channel groups; features.10: this wave's
+    //      four output channels), head weights -> registers ----
+    tilep_zero<X1P>(x1, tid);
+    tilep_zero<X2P>(x2, tid);
+    float wr6[2][5], wr10[1][5];
+    fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
+    fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
     float w4r[32], w1r[4], wpr[4];
 #pragma unroll
     for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
@@ -102,58 +107,68 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         w1r[j] = P.w.wl1[(kg * 4 + j) * 32 + o];
         wpr[j] = P.o4 ? P.w.wpw[(kg * 4 + j) * 32 + o] : 0.f;
     }
-    const float b6 = P.w.b6[l15 & 7], b10 = P.w.b10[l15];
+    const cgs_cptr b6c = cgs_to_const(P.w.b6), b10c = cgs_to_const(P.w.b10);
     const float b14 = P.w.b14[o], bl1 = P.w.bl1[o], wl2 = P.w.wl2[o], bl2 = P.w.bl2[0], bpw = P.o4 ? P.w.bpw[o] : 0.f;
+    const PxPos pa = px16(wave, lane), pb = px8(lane);
     __syncthreads();
 
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
-        int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
-        asm volatile("" : "+v"(lz));
-        const int lane_i = lane + lz;
         // ---- e1 -> tile interior (512 float4) ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(x1 + T16x8::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+            *(float4*)(x1 + X1P::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
         }
         __syncthreads();
         TAIL_STAMP(2);
-        // ---- features.6 + ReLU + pool: 16 tiles ----
-        conv_tiles<T16x8, 0, 8, 1>(
-            x1, [&](int tap, int c, int) { return w6s[(tap * 8 + c) * 8 + (l15 & 7)]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                uint32_t idx;
-                const float m = pool_quad(acc[0], b6, idx);
-                const uint32_t word = pack_nibbles(l15 < 8 ? idx : 0u, l15);
-                if (l15 < 8) {
-                    P.e2[((size_t)img * 64 + q) * 8 + l15] = m;
-                    x2[T8x8::at(q >> 3, q & 7) + l15] = m;
-                    if (l15 == 0) P.am2[(size_t)img * 64 + q] = word;
-                }
-            },
-            wave, lane_i);
+        // ---- features.6 + ReLU + pool: this wave's 64 pixels, all 8 channels ----
+        {
+            frag4 a6[2] = {frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}};
+            conv_px<X1P, 0, 8, 8, 0, 2, 5>(a6, x1, pa.y, pa.x, wr6);
+            float m[8];
+            uint32_t word = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uint32_t nib;
+                m[c] = quad_pool(fmaxf(a6[c >> 2][c & 3] + b6c[c], 0.f), pa.pos, nib);
+                word |= nib << (4 * c);
+            }
+            // the quad's four lanes hold the same pooled values: lanes 0 / 1 store the two halves to e2, lanes 2 / 3 to the tile
+            const float4 sel = (pa.pos & 1) ? make_float4(m[4], m[5], m[6], m[7]) : make_float4(m[0], m[1], m[2], m[3]);
+            if (pa.pos < 2) ((float4*)P.e2)[((size_t)img * 64 + pa.q) * 2 + pa.pos] = sel;
+            else *(float4*)(x2 + X2P::at(pa.qy, pa.qx) + 4 * (pa.pos & 1)) = sel;
+            if (pa.pos == 0) P.am2[(size_t)img * 64 + pa.q] = word;
+        }
         __syncthreads();
         TAIL_STAMP(3);
         if (d2.on && tid < 128) {       // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
             const int q = tid >> 1, p = tid & 1;
-            float4* v = (float4*)(x2 + T8x8::at(q >> 3, q & 7) + 4 * p);
+            float4* v = (float4*)(x2 + X2P::at(q >> 3, q & 7) + 4 * p);
             *v = *v * drop_mult4(d2, (uint32_t)(img * 128 + tid));
         }
         __syncthreads();
         TAIL_STAMP(4);
-        // ---- features.10 + ReLU + pool: 4 tiles, one per wave ----
-        conv_tiles<T8x8, 0, 8, 1>(
-            x2, [&](int tap, int c, int) { return w10s[(tap * 8 + c) * 16 + l15]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                uint32_t idx;
-                const float m = pool_quad(acc[0], b10, idx);
-                const uint32_t word = pack_nibbles(idx, l15);
-                P.e3[((size_t)img * 16 + q) * 16 + l15] = m;
-                xs[q * 16 + l15] = m * drop1(d3, (uint32_t)((img * 16 + q) * 16 + l15));
-                if ((l15 & 7) == 0) P.am3[((size_t)img * 16 + q) * 2 + (l15 >> 3)] = word;
-            },
-            wave, lane_i);
+        // ---- features.10 + ReLU + pool: all 64 pixels of the 8x8 map, this wave's 4 output channels ----
+        {
+            frag4 a10[1] = {frag4{0.f, 0.f, 0.f, 0.f}};
+            conv_px<X2P, 0, 8, 8, 0, 1, 5>(a10, x2, pb.y, pb.x, wr10);
+            float m[4];
+            uint32_t half = 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                uint32_t nib;
+                m[r] = quad_pool(fmaxf(a10[0][r] + b10c[4 * wave + r], 0.f), pb.pos, nib);
+                half |= nib << (4 * r);
+            }
+            if (pb.pos == 0) {
+                const float4 mv = make_float4(m[0], m[1], m[2], m[3]);
+                const uint32_t i4 = (uint32_t)((img * 16 + pb.q) * 4 + wave);      // float4 index of channels 4w .. 4w+3 of pooled pixel q
+                ((float4*)P.e3)[i4] = mv;
+                ((float4*)xs)[pb.q * 4 + wave] = d3.on ? mv * drop_mult4(d3, i4) : mv;
+                ((uint16_t*)P.am3)[(size_t)i4] = (uint16_t)half;                    // nibbles of channels 4w .. 4w+3: 16-bit quarter of the pixel's two words
+            }
+        }
         __syncthreads();
         TAIL_STAMP(5);
         // ---- features.14 (256 -> 32) + ReLU: thread (o, kg) sums k = 32*kg .. +31 ----

@@ -20,8 +20,10 @@ struct SpCfg {
     static constexpr int PW = (S == 1) ? W + 4 : W + 2;        // pixel slots per row
     // row stride in dwords.  CA = 3: 274 = 2 (mod 8): the lanes of a wave read the slots of 8 neighbouring cells (8 dwords apart),
     // either pixel column of the window (+4) and either row (+274 = 18 mod 64): all 32 addresses fall into different banks for
-    // each of the 3 dwords read; rows are then 8-byte aligned (reads: b64 + b32).  CA = 8: 272 (16-byte aligned b128 reads).
-    static constexpr int RS = (S == 1) ? 274 : 272;
+    // each of the 3 dwords read; rows are then 8-byte aligned (reads: b64 + b32).  CA = 8: 276 = 20 (mod 64), 16-byte aligned: the b128
+    // reads of a 16-lane group (2 cells x 2 columns x 2 rows) cover banks 0-3, 8-11, 16-19, 24-27 | 20-23, 28-31, 36-39, 44-47 (272 put
+    // the second row on the first row's banks: 2-way conflicts).
+    static constexpr int RS = (S == 1) ? 274 : 276;
     static constexpr int NACC = 9 * CA + 1;                    // + the bias row
     static_assert((H == 64 && CA == 3) || (H == 32 && CA == 8), "features.0 / features.3");
     static_assert(PW * S * 4 <= RS, "row stride");
