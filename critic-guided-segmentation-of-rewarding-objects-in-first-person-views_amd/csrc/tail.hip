@@ -96,9 +96,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     //      four output channels), head weights -> registers ----
     tilep_zero<X1P>(x1, tid);
     tilep_zero<X2P>(x2, tid);
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
     float wr6[2][5], wr10[1][5];
     fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
     fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
     float w4r[32], w1r[4], wpr[4];
 #pragma unroll
     for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
@@ -110,6 +112,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const cgs_cptr b6c = cgs_to_const(P.w.b6), b10c = cgs_to_const(P.w.b10);
     const float b14 = P.w.b14[o], bl1 = P.w.bl1[o], wl2 = P.w.wl2[o], bl2 = P.w.bl2[0], bpw = P.o4 ? P.w.bpw[o] : 0.f;
     const PxPos pa = px16(wave, lane), pb = px8(lane);
+    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
@@ -759,9 +762,11 @@ struct TailDecBwdParams {
     unsigned long long* dbg;
 };
 
+using T1Q = TileP<16, 16, 16, 16, 304>;   // cat(e1, up(o2)): only the weight gradient's dword reads (2 taps x 4 channel groups on 32 banks)
+using D1Q = TileP<16, 16, 8, 8, 148>;     // d o1: data gradient (b128 reads) and the weight gradient's B operand
 struct TailDecBwdLds {
-    static constexpr int T1 = 0, T2 = T1 + T16x16::FLOATS, T3 = T2 + T8x24::FLOATS, D1 = T3 + T4x48::FLOATS,
-                         D2 = D1 + T16x8::FLOATS, D3 = D2 + T8x8::FLOATS, W1 = D3 + T4x16::FLOATS, W2 = W1 + 144 * 8,
+    static constexpr int T1 = 0, T2 = T1 + T1Q::FLOATS, T3 = T2 + T8x24::FLOATS, D1 = T3 + T4x48::FLOATS,
+                         D2 = D1 + D1Q::FLOATS, D3 = D2 + T8x8::FLOATS, W1 = D3 + T4x16::FLOATS, W2 = W1 + 144 * 8,
                          RED = W2 + 216 * 8, FLOATS = RED + 4 * 32;
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
 };
@@ -777,14 +782,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15;
 
-    tile_zero<T16x16>(t1, tid); tile_zero<T8x24>(t2, tid); tile_zero<T4x48>(t3, tid);
-    tile_zero<T16x8>(dy1, tid); tile_zero<T8x8>(dy2, tid); tile_zero<T4x16>(dy3, tid);
+    tilep_zero<T1Q>(t1, tid); tile_zero<T8x24>(t2, tid); tile_zero<T4x48>(t3, tid);
+    tilep_zero<D1Q>(dy1, tid); tile_zero<T8x8>(dy2, tid); tile_zero<T4x16>(dy3, tid);
     for (int e = tid; e < 144 * 8 / 4; e += 256) ((float4*)w1s)[e] = ((const float4*)P.w.w1)[e];
     for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
-    WgradAcc<T16x16, T16x8, 8, 3> wg1;
+    // dec_model.1 on v_mfma_f32_4x4x1 (tail4.h): data gradient with lane = pixel (weights W^T in 20 registers), weight gradient as
+    // outer products with the blocks as (tap, channel group) combinations (6 accumulators, pixels split over the waves)
+    WgradTapBlk<T1Q, D1Q, 4, 2> wg1;
+    wg1.init(lane);
+    float bs1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // bias gradient of dec_model.1: this lane's pixels
+    const PxPos pa = px16(wave, lane);
     WgradAcc<T8x24, T8x8, 8, 4> wg2;
     WgradAcc<T4x48, T4x16, 16, 7> wg3;
-    wg1.init(wave, lane); wg2.init(wave, lane); wg3.init(wave, lane);
+    wg2.init(wave, lane); wg3.init(wave, lane);
     __syncthreads();
 
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
@@ -796,15 +806,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(t1 + T16x16::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
-            *(float4*)(dy1 + T16x8::at(y, x) + 4 * p) = ((const float4*)P.do1)[(size_t)img * 512 + e];
+            *(float4*)(t1 + T1Q::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+            *(float4*)(dy1 + D1Q::at(y, x) + 4 * p) = ((const float4*)P.do1)[(size_t)img * 512 + e];
         }
         if (tid < 128) {
             const int p = tid & 1, x = (tid >> 1) & 7, y = tid >> 4;
             *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = ((const float4*)P.e2)[(size_t)img * 128 + tid];
             const float4 v = ((const float4*)P.o2)[(size_t)img * 128 + tid];            // up(o2) -> channels 8..15 of t1
 #pragma unroll
-            for (int d = 0; d < 4; ++d) *(float4*)(t1 + T16x16::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
+            for (int d = 0; d < 4; ++d) *(float4*)(t1 + T1Q::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
         } else if (tid < 192) {
             const int e = tid - 128, p = e & 3, x = (e >> 2) & 3, y = e >> 4;
             *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = ((const float4*)P.e3)[(size_t)img * 64 + e];
@@ -819,20 +829,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         TAIL_STAMP(2);
         // ---- dec_model.1 ----
-        wg1.accumulate(t1, dy1, lane_i);
-        conv_tiles<T16x8, 0, 8, 1>(
-            dy1, [&](int tap, int c, int) { return w1s[((8 - tap) * 16 + l15) * 8 + c]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                const int qy = q >> 3, qx = q & 7;
-                if (l15 < 8) {
+        wg1.accumulate(t1 + T1Q::at(4 * wave - 1, -1), dy1 + D1Q::at(4 * wave, 0), lane_i);
+        {
+            frag4 a[4] = {frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}};
+            float wd1[4][5];        // W^T in 20 registers, re-read from LDS per image (held across the loop they cost the occupancy)
+            fill_wreg<4, 5, 72>(wd1, lane_i, [&](int step, int ci) { return w1s[((step >> 3) * 16 + ci) * 8 + (step & 7)]; });
+            conv_px<D1Q, 0, 8, 8, 0, 4, 5, true>(a, dy1, pa.y, pa.x, wd1);
+            float4* de = (float4*)(P.dE1 + ((size_t)img * 256 + pa.y * 16 + pa.x) * 8);       // skip gradient: channels 0..7
+            de[0] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
+            de[1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
+            float s[8];                                                                   // upsample backward: sum over the 2x2 cell
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        P.dE1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j];
-                } else {
-                    dy2[T8x8::at(qy, qx) + l15 - 8] = (acc[0][0] + acc[0][1]) + (acc[0][2] + acc[0][3]);
-                }
-            },
-            wave, lane_i);
+            for (int c = 0; c < 8; ++c) s[c] = quad_sum(a[2 + (c >> 2)][c & 3]);
+            if (pa.pos < 2)
+                *(float4*)(dy2 + T8x8::at(pa.qy, pa.qx) + 4 * pa.pos) = pa.pos ? make_float4(s[4], s[5], s[6], s[7]) : make_float4(s[0], s[1], s[2], s[3]);
+            const float4 d0 = *(const float4*)(dy1 + D1Q::at(pa.y, pa.x)), d1v = *(const float4*)(dy1 + D1Q::at(pa.y, pa.x) + 4);
+            bs1[0] += d0.x; bs1[1] += d0.y; bs1[2] += d0.z; bs1[3] += d0.w;
+            bs1[4] += d1v.x; bs1[5] += d1v.y; bs1[6] += d1v.z; bs1[7] += d1v.w;
+        }
         __syncthreads();
         TAIL_STAMP(3);
         // ---- dec_model.2 ----
@@ -859,10 +873,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (tid < 192) {
             const int ci = tid % 48, q = tid / 48, qy = q >> 1, qx = q & 1;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
+            // (the weights of tap t+1 are requested before tap t is multiplied: one L2 round trip instead of nine in a row)
+            const float4* wr0 = (const float4*)(P.w.w3 + ((size_t)8 * 48 + ci) * 16);
+            float4 wn[4] = {wr0[0], wr0[1], wr0[2], wr0[3]};
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap) {
-                const float4* wr = (const float4*)(P.w.w3 + ((size_t)(8 - tap) * 48 + ci) * 16);
-                const float4 wv[4] = {wr[0], wr[1], wr[2], wr[3]};
+                const float4 wv[4] = {wn[0], wn[1], wn[2], wn[3]};
+                if (tap < 8) {
+                    const float4* wr = (const float4*)(P.w.w3 + ((size_t)(7 - tap) * 48 + ci) * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) wn[k] = wr[k];
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int y = 2 * qy + (j >> 1) + tap / 3 - 1, x = 2 * qx + (j & 1) + tap % 3 - 1;   // -1 .. 4: inside the halo tile
@@ -890,7 +911,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         TAIL_STAMP(6);
     }
     const size_t b = blockIdx.x;
-    if (P.slab1) wg1.store(P.slab1 + b * kTailSlabD1, wave, lane);
+    // dec_model.1's slab [9*16*8 | 8]; the bias row is the sum of the lanes' pixel sums
+    __syncthreads();
+    wg1.reduce_store(P.slab1 ? P.slab1 + b * kTailSlabD1 : nullptr, sm, wave, lane, tid);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float v = wave_sum(bs1[c]);
+        if (lane == 0) red[c * 4 + wave] = v;
+    }
+    __syncthreads();
+    if (tid < 8 && P.slab1) P.slab1[b * kTailSlabD1 + 1152 + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     if (P.slab2) wg2.store(P.slab2 + b * kTailSlabD2, wave, lane);
     if (P.slab3) wg3.store(P.slab3 + b * kTailSlabD3, wave, lane);
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();

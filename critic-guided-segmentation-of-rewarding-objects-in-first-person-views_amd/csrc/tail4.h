@@ -32,7 +32,6 @@ struct TileP {
             }
         return true;
     }
-    static_assert(conflict_free(), "b128 reads of a 16-lane group (8 columns x 2 rows) must not share banks");
 };
 
 template <class T>
@@ -83,6 +82,7 @@ __device__ __forceinline__ void fill_wreg(float (&wreg)[NG][NREG], int lane, F f
 template <class T, int CH0, int KCH, int CIN, int COFF, int NG, int NREG, bool FLIP = false>
 __device__ __forceinline__ void conv_px(frag4 (&acc)[NG], const float* tile, int y, int x, const float (&wreg)[NG][NREG]) {
     static_assert(KCH % 4 == 0 && CH0 % 4 == 0, "whole float4 planes");
+    static_assert(T::conflict_free(), "b128 reads of a 16-lane group (8 columns x 2 rows) must not share banks");
     const float* base = tile + T::at(y, x) + CH0;
     t4_static_for<9>([&](auto TAP) {
         constexpr int tap = decltype(TAP)::value, ky = tap / 3 - 1, kx = tap % 3 - 1;
@@ -119,3 +119,119 @@ __device__ __forceinline__ float quad_pool(float v, int pos, uint32_t& nib) {
     nib = m > 0.f ? code : 15u;
     return m;
 }
+
+// ---- weight gradient as outer products (v_mfma_f32_4x4x1 without broadcast): block b of a step = pixel (row, column b) of a
+// 16-wide map (one row per step), A = 4 input channels CH0.. of the X tile at a tap, B = 4 output-gradient channels of the dY tile.
+// acc[tap][cog] (lane 4b + j, register r) = sum over block b's pixels of X[p + tap][CH0 + r] dY[p][4 cog + j]; the 16 blocks are
+// added by wg_block_sum() when the workgroup stores its slab.  The X tile's pixel slot is padded (PS = 20 for 16 channels) so the
+// 8 pixels x 4 dwords a 32-lane group reads fall on 32 different banks.
+template <class TX, class TY, int CH0, int NCOG>
+__device__ __forceinline__ void wgrad_outer16(frag4 (&acc)[9][NCOG], const float* xt, const float* dyt, int lane) {
+    static_assert(TX::W == 16 && TY::W == 16 && TX::H == TY::H, "one map row = the 16 blocks of a step");
+    const int b = lane >> 2, i = lane & 3;
+    const float* ap0 = xt + TX::at(-1, b - 1) + CH0 + i;        // tap (0, 0) of row 0
+    const float* bp0 = dyt + TY::at(0, b) + i;
+    float av[2][9], bv[2][NCOG];
+    auto ld = [&](auto ROW, int buf) {
+        constexpr int row = decltype(ROW)::value;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) av[buf][t] = ap0[(row + t / 3) * TX::PITCH + (t % 3) * TX::PS];
+#pragma unroll
+        for (int g = 0; g < NCOG; ++g) bv[buf][g] = bp0[row * TY::PITCH + 4 * g];
+    };
+    ld(std::integral_constant<int, 0>{}, 0);
+    t4_static_for<TX::H>([&](auto ROW) {
+        constexpr int row = decltype(ROW)::value;
+        if constexpr (row + 1 < TX::H) ld(std::integral_constant<int, row + 1>{}, (row + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);       // the next row's operands are read while this row's MFMAs issue
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int g = 0; g < NCOG; ++g)
+                acc[t][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[row & 1][t], bv[row & 1][g], acc[t][g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+// sum of the 16 blocks of a wave (lanes with equal lane & 3): rotates inside a row of 16 lanes, then across the 4 rows
+__device__ __forceinline__ float wg_block_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));     // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));     // row_ror:8
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---- the same weight gradient with the BLOCKS as (tap, input-channel group) combinations and one pixel per step: block c of
+// register G = combination 16 G + c = (tap, channels 4 cig ..), A = X[p + tap][4 cig + i] (a per-lane constant offset from the
+// pixel), B = dY[p][4 cog + j] (the same in every block).  A block accumulates ITS weights over the pixels, so nothing is summed
+// across blocks afterwards and the whole 16 -> 8 layer is 6 accumulators (24 registers) instead of 72; 36 of the 48 block slots
+// are used (a quarter more instructions than the pixel-block form).  Pixel slot 16 floats, row pitch = 16 (mod 32): the 8 blocks a
+// 32-lane group reads (2 taps x 4 channel groups) cover all 32 banks.  Wave w walks the 64 pixels of rows 4w .. 4w+3.
+template <class TX, class TY, int NCIG, int NCOG>
+struct WgradTapBlk {
+    static constexpr int NCOMB = 9 * NCIG, NG = (NCOMB + 15) / 16;
+    static_assert(TX::W == 16 && TY::W == 16 && TX::PS % 32 == 16 && TX::PITCH % 32 == 16, "bank layout");
+    frag4 acc[NG][NCOG];
+    int offa[NG];
+    __device__ __forceinline__ void init(int lane) {
+        const int b = lane >> 2, i = lane & 3;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int c = 16 * g + b, cc = c < NCOMB ? c : 0, tap = cc / NCIG, cig = cc % NCIG;
+            offa[g] = (tap / 3) * TX::PITCH + (tap % 3) * TX::PS + 4 * cig + i;
+#pragma unroll
+            for (int k = 0; k < NCOG; ++k) acc[g][k] = frag4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    // xt0 / dy0: tile addresses of pixel (row 4w - 1, column -1) of X and of pixel (row 4w, column 0) of dY
+    __device__ __forceinline__ void accumulate(const float* xt0, const float* dy0, int lane) {
+        const int j = lane & 3;
+#pragma unroll 1
+        for (int yy = 0; yy < 4; ++yy) {            // (rows as a real loop: 64 unrolled steps made the register allocator give up)
+            const float* xr = xt0 + yy * TX::PITCH;
+            const float* dr = dy0 + yy * TY::PITCH + j;
+            float av[2][NG], bv[2][NCOG];
+            auto ld = [&](auto S, int buf) {
+                constexpr int x = decltype(S)::value;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) av[buf][g] = xr[x * TX::PS + offa[g]];
+#pragma unroll
+                for (int k = 0; k < NCOG; ++k) bv[buf][k] = dr[x * TY::PS + 4 * k];
+            };
+            ld(std::integral_constant<int, 0>{}, 0);
+            t4_static_for<16>([&](auto S) {
+                constexpr int x = decltype(S)::value;
+                if constexpr (x + 1 < 16) ld(std::integral_constant<int, x + 1>{}, (x + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int k = 0; k < NCOG; ++k)
+                        acc[g][k] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[x & 1][g], bv[x & 1][k], acc[g][k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+    // sum of the 4 waves through `scratch` (>= 4 * NG * NCOG * 256 floats of LDS), rows tap * CI + ci of a [9 CI][CO] slab
+    __device__ __forceinline__ void reduce_store(float* slab, float* scratch, int wave, int lane, int tid) const {
+        constexpr int CI = 4 * NCIG, CO = 4 * NCOG;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int k = 0; k < NCOG; ++k)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) scratch[(((wave * NG + g) * NCOG + k) * 4 + r) * 64 + lane] = acc[g][k][r];
+        __syncthreads();
+        for (int e = tid; e < NG * NCOG * 256; e += 256) {
+            const int ln = e & 63, r = (e >> 6) & 3, k = (e >> 8) % NCOG, g = (e >> 8) / NCOG;
+            const int c = 16 * g + (ln >> 2);
+            if (c < NCOMB && slab) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) v += scratch[(((w * NG + g) * NCOG + k) * 4 + r) * 64 + ln];
+                slab[((c / NCIG) * CI + 4 * (c % NCIG) + r) * CO + 4 * k + (ln & 3)] = v;
+            }
+        }
+        __syncthreads();
+    }
+};
