@@ -59,6 +59,24 @@ __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d) {
     return c;
 }
 
+// The same, branch-free: the step counter is read unconditionally (from `safe`, any readable 8-byte-aligned device address, when the
+// layer has no Dropout), so several contexts' loads are in flight together instead of one round trip per conditional block.
+__device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d, const void* safe) {
+    DropCtx c;
+    c.on = d.p > 0.f;
+    c.p = d.p;
+    c.scale = c.on ? 1.f / (1.f - d.p) : 1.f;
+    c.site = d.site;
+    c.base = d.base;
+    c.key = make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+    const bool have = c.on && d.step;
+    const uint64_t* sp = have ? (const uint64_t*)d.step : (const uint64_t*)safe;
+    const uint64_t s = have ? *sp : (*sp & 0ull);
+    c.step_lo = (uint32_t)s;
+    c.step_hi = (uint32_t)(s >> 32);
+    return c;
+}
+
 // Multipliers (0 or 1/(1-p)) for the four consecutive floats whose float4 index is idx4.
 __device__ __forceinline__ float4 drop_mult4(const DropCtx& c, uint32_t idx4) {
     uint4 r = philox4x32_10(make_uint4(idx4 + c.base, c.site, c.step_lo, c.step_hi), c.key);

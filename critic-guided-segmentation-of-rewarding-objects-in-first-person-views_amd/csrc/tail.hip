@@ -90,7 +90,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int o = tid & 31, kg = tid >> 5;
-    const DropCtx d2 = drop_ctx(P.drop_e2), d3 = drop_ctx(P.drop_e3), dh = drop_ctx(P.drop_h1);
+    // the first image's loads and the Dropout step counters are requested before anything else: they fly during the set-up below
+    int img = blockIdx.x;
+    float4 pe[2] = {f4zero(), f4zero()};
+    if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
+    const DropCtx d2 = drop_ctx(P.drop_e2, P.w.b6), d3 = drop_ctx(P.drop_e3, P.w.b6), dh = drop_ctx(P.drop_h1, P.w.b6);
 
     // ---- once per workgroup: halos -> 0, conv weights -> registers (features.6: both channel groups; features.10: this wave's
     //      four output channels), head weights -> registers ----
@@ -101,9 +105,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
     fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
-    float w4r[32], w1r[4], wpr[4];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
+    float w1r[4], wpr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         w1r[j] = P.w.wl1[(kg * 4 + j) * 32 + o];
@@ -115,15 +117,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
-    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
+    for (; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
-        // ---- e1 -> tile interior (512 float4) ----
+        // ---- e1 -> tile interior (512 float4), then the next image's loads ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(x1 + X1P::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+            *(float4*)(x1 + X1P::at(y, x) + 4 * p) = pe[it];
         }
         __syncthreads();
+        if (img + P.nblocks < P.n) {
+            pe[0] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid];
+            pe[1] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid + 256];
+        }
         TAIL_STAMP(2);
         // ---- features.6 + ReLU + pool: this wave's 64 pixels, all 8 channels ----
         {
@@ -143,6 +149,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             else *(float4*)(x2 + X2P::at(pa.qy, pa.qx) + 4 * (pa.pos & 1)) = sel;
             if (pa.pos == 0) P.am2[(size_t)img * 64 + pa.q] = word;
         }
+        // features.14's weights of this thread (L2-resident): requested here, used two stages later (held across the image loop
+        // they cost the registers of the convolution stages)
+        float w4r[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
         __syncthreads();
         TAIL_STAMP(3);
         if (d2.on && tid < 128) {       // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
@@ -269,25 +280,42 @@ struct TailDecFwdParams {
     unsigned long long* dbg;
 };
 
+using T1F = TileP<16, 16, 16, 16, 292>;     // cat(e1, up(o2)) of the forward decoder tail (2-way conflicts on the b128 reads accepted)
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P) {
-    __shared__ __attribute__((aligned(16))) float t1[T16x16::FLOATS];
+    __shared__ __attribute__((aligned(16))) float t1[T1F::FLOATS];
     __shared__ __attribute__((aligned(16))) float t2[T8x24::FLOATS];
     __shared__ __attribute__((aligned(16))) float t3[T4x48::FLOATS];
-    __shared__ __attribute__((aligned(16))) float w2s[216 * 8], w1s[144 * 8];
+    __shared__ __attribute__((aligned(16))) float w2s[216 * 8];
     __shared__ float part[4][16][16];       // dec_model.3: the waves split K, partial [pixel][co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15, kq = lane >> 4;
+    // the first image's loads are requested before the set-up (and the next image's as soon as the tiles are filled)
+    int img = blockIdx.x;
+    float4 pe1a = f4zero(), pe1b = f4zero(), pe2 = f4zero(), pe3 = f4zero(), po4 = f4zero();
+#define DEC_FWD_FETCH(im)                                                                                         \
+    do {                                                                                                          \
+        pe1a = ((const float4*)P.e1)[(size_t)(im) * 512 + tid]; pe1b = ((const float4*)P.e1)[(size_t)(im) * 512 + tid + 256]; \
+        pe2 = ((const float4*)P.e2)[(size_t)(im) * 128 + (tid & 127)];                                            \
+        pe3 = ((const float4*)P.e3)[(size_t)(im) * 64 + (tid & 63)];                                              \
+        po4 = ((const float4*)P.o4)[(size_t)(im) * 8 + (tid & 7)];                                                \
+    } while (0)
+    if (img < P.n) DEC_FWD_FETCH(img);
 
-    tile_zero<T16x16>(t1, tid);
+    tilep_zero<T1F>(t1, tid);
     tile_zero<T8x24>(t2, tid);
     tile_zero<T4x48>(t3, tid);
     for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
-    for (int e = tid; e < 144 * 8 / 4; e += 256) ((float4*)w1s)[e] = ((const float4*)P.w.w1)[e];
-    const float b2 = P.w.b2[l15 & 7], b1 = P.w.b1[l15 & 7];
+    // dec_model.1 on v_mfma_f32_4x4x1 with lane = pixel (tail4.h): both channel groups' weights in 18 registers
+    float wr1[2][9];
+    fill_wreg<2, 9, 144>(wr1, lane, [&](int step, int co) { return P.w.w1[step * 8 + co]; });
+    const PxPos pa = px16(wave, lane);
+    const cgs_cptr b1c = cgs_to_const(P.w.b1);
+    const float b2 = P.w.b2[l15 & 7];
     __syncthreads();
 
-    for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
+    for (; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
@@ -296,19 +324,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(t1 + T16x16::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
+            *(float4*)(t1 + T1F::at(y, x) + 4 * p) = it ? pe1b : pe1a;
         }
         if (tid < 128) {
             const int p = tid & 1, x = (tid >> 1) & 7, y = tid >> 4;
-            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = ((const float4*)P.e2)[(size_t)img * 128 + tid];
+            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = pe2;
         } else if (tid < 192) {
             const int e = tid - 128, p = e & 3, x = (e >> 2) & 3, y = e >> 4;
-            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = ((const float4*)P.e3)[(size_t)img * 64 + e];
+            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = pe3;
         }
         if (tid < 128) {         // up4(o4): every pixel of the 4x4 map sees the bottleneck vector
             const int p = tid & 7, pix = tid >> 3;
-            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p) = ((const float4*)P.o4)[(size_t)img * 8 + p];
+            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p) = po4;
         }
+        if (img + P.nblocks < P.n) DEC_FWD_FETCH(img + P.nblocks);
         __syncthreads();
         TAIL_STAMP(2);
         // ---- dec_model.3: one 16-pixel tile, K = 9 x 48; wave w takes channels 12w .. 12w+11 of every tap ----
@@ -351,25 +380,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                         const float v = acc[0][j] + b2;
                         P.o2[((size_t)img * 64 + y * 8 + x) * 8 + l15] = v;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) t1[T16x16::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + l15] = v;
+                        for (int d = 0; d < 4; ++d) t1[T1F::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + l15] = v;
                     }
                 }
             },
             wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
-        // ---- dec_model.1: 16 tiles ----
-        conv_tiles<T16x16, 0, 16, 1>(
-            t1, [&](int tap, int c, int) { return w1s[(tap * 16 + c) * 8 + (l15 & 7)]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                if (l15 < 8) {
-                    const int qy = q >> 3, qx = q & 7;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        P.o1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[0][j] + b1;
-                }
-            },
-            wave, lane_i);
+        // ---- dec_model.1: this wave's 64 pixels, all 8 channels ----
+        {
+            frag4 a[2] = {frag4{b1c[0], b1c[1], b1c[2], b1c[3]}, frag4{b1c[4], b1c[5], b1c[6], b1c[7]}};
+            conv_px<T1F, 0, 16, 16, 0, 2, 9, false, true>(a, t1, pa.y, pa.x, wr1);
+            float4* dst = (float4*)(P.o1 + ((size_t)img * 256 + pa.y * 16 + pa.x) * 8);
+            dst[0] = make_float4(a[0][0], a[0][1], a[0][2], a[0][3]);
+            dst[1] = make_float4(a[1][0], a[1][1], a[1][2], a[1][3]);
+        }
         __syncthreads();
         TAIL_STAMP(6);
     }
@@ -435,7 +460,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5, half = lane & 32;
     const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
-    const DropCtx d2_ = drop_ctx(P.drop_e2), d3_ = drop_ctx(P.drop_e3), dh_ = drop_ctx(P.drop_h1);
+    const DropCtx d2_ = drop_ctx(P.drop_e2, P.w.w6), d3_ = drop_ctx(P.drop_e3, P.w.w6), dh_ = drop_ctx(P.drop_h1, P.w.w6);
     const bool has_pw = P.d_o4 != nullptr;
 
     tile_zero<T16x8>(x1, tid);

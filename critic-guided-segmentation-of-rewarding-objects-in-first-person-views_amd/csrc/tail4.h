@@ -79,10 +79,11 @@ __device__ __forceinline__ void fill_wreg(float (&wreg)[NG][NREG], int lane, F f
 // acc[g] += sum over the 9 taps and the KCH channels CH0.. of the tile pixels around (y, x); the weight step of (tap, channel c
 // of the tile) is tap * CIN + COFF + c  (CIN = all input channels of the layer, COFF = where this tile's channel 0 sits among
 // them).  FLIP: tap t multiplies the pixel at offset -(t - center) (data gradient: flipped kernel).
-template <class T, int CH0, int KCH, int CIN, int COFF, int NG, int NREG, bool FLIP = false>
+template <class T, int CH0, int KCH, int CIN, int COFF, int NG, int NREG, bool FLIP = false, bool ALLOW_2WAY = false>
 __device__ __forceinline__ void conv_px(frag4 (&acc)[NG], const float* tile, int y, int x, const float (&wreg)[NG][NREG]) {
     static_assert(KCH % 4 == 0 && CH0 % 4 == 0, "whole float4 planes");
-    static_assert(T::conflict_free(), "b128 reads of a 16-lane group (8 columns x 2 rows) must not share banks");
+    // (16-channel tiles have no conflict-free pitch at a 16-float slot; a 20-float slot would cost 10 KB of LDS: 2-way is accepted there)
+    static_assert(ALLOW_2WAY || T::conflict_free(), "b128 reads of a 16-lane group (8 columns x 2 rows) must not share banks");
     const float* base = tile + T::at(y, x) + CH0;
     t4_static_for<9>([&](auto TAP) {
         constexpr int tap = decltype(TAP)::value, ky = tap / 3 - 1, kx = tap % 3 - 1;
