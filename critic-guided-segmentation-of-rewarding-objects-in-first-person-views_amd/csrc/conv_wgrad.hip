@@ -13,6 +13,10 @@
 // Lanes (r = lane&15, pixel = lane>>4) then read consecutive floats: bank-conflict free.
 #include "wgrad_sparse.h"
 
+// dec_model.0 (16 -> 8 channels at 32x32): outer products on v_mfma_f32_4x4x1 (wgrad_dec0.hip)
+int wgrad_dec0_slabs(int n);
+int wgrad_dec0_launch(int n, const float* e0, const float* o1, const float* dy, float* slab, hipStream_t st);
+
 static constexpr int kMaxWgradBlocks = 1024;
 
 template <class G>
@@ -82,7 +86,7 @@ extern "C" int cgs_conv3x3_bwd_weight_slabs(const cgs_conv_desc* d) {
     if (wdesc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, 0)) SLABS(WDec3);
     if (wdesc_is(d, 8, 8, 16, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec2);
     if (wdesc_is(d, 16, 8, 8, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec1);
-    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) SLABS(WDec0);
+    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) return wgrad_dec0_slabs(n);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, 0)) SLABS(WMask0U8);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) SLABS(WMask0F32);
     if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) return wg_blocks<WMask2G>(n);
@@ -107,7 +111,7 @@ extern "C" int cgs_conv3x3_bwd_weight(const cgs_conv_desc* d, const void* src_a,
     if (wdesc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, 0)) return launch_wgrad<WDec3>(P, st);
     if (wdesc_is(d, 8, 8, 16, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec2>(P, st);
     if (wdesc_is(d, 16, 8, 8, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec1>(P, st);
-    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) return launch_wgrad<WDec0>(P, st);
+    if (wdesc_is(d, 32, 8, 8, 8, CGS_SRC_F32, 2, 0)) return wgrad_dec0_launch(d->n, (const float*)src_a, src_b, dy, slab, st);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_U8, 2, 0)) return launch_wgrad<WMask0U8>(P, st);
     if (wdesc_is(d, 64, 3, 8, 16, CGS_SRC_F32, 2, 0)) return launch_wgrad<WMask0F32>(P, st);
     if (wdesc_is(d, 64, 16, 0, 1, CGS_SRC_F32, 2, 0)) {
