@@ -40,8 +40,8 @@ static int both_slabs(int n) {
     int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
     int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
     if (both_sparse_ok<CWG> && wgrad_sparse_enabled()) {
-        static const int cap32 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH_BLOCKS"); return e ? atoi(e) : 192; }();
-        static const int cap64 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH0_BLOCKS"); return e ? atoi(e) : 384; }();
+        static const int cap32 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH_BLOCKS"); return e ? atoi(e) : 256; }();
+        static const int cap64 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH0_BLOCKS"); return e ? atoi(e) : 512; }();
         cap = GW::H >= 64 ? cap64 : cap32;
     }
     return tiles < cap ? tiles : cap;

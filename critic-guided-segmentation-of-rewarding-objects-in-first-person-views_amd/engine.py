@@ -435,13 +435,15 @@ class HourglassEngine:
         from . import generic as gen
         if self._w16 is None:
             self._w16 = gen.F16Weights()
-        w16 = self._w16.get(self.fc, self.lc, self.fm, self.lm, chfak, neck, 16, (self._pver[0], self.separate))
+        # the cache key also carries the flat buffer's torch version counter: module.load_state_dict / an external optimiser change the
+        # weights through torch ops without going through this engine (its own kernels write through raw pointers and bump _pver)
+        w16 = self._w16.get(self.fc, self.lc, self.fm, self.lm, chfak, neck, 16, (self._pver[0], self.flat._version, self.separate))
         X = X.contiguous()
         emb = None
         if self.separate and want_mask:
             if getattr(self, "_w16s", None) is None:
                 self._w16s = gen.F16Weights()
-            ws = self._w16s.get(self.fs, self.lc, None, None, chfak, neck, 16, self._pver[0])
+            ws = self._w16s.get(self.fs, self.lc, None, None, chfak, neck, 16, (self._pver[0], self.flat._version))
             _, _, emb = gen.infer_f16(self.fs, self.lc, None, None, X, chfak, neck, ws)
         pred, Z, _ = gen.infer_f16(self.fc, self.lc, self.fm if want_mask else None, self.lm, X, chfak, neck, w16, embeds_from=emb)
         return pred, Z

@@ -131,14 +131,16 @@ class Handler:
     def _generic_size(self):
         return self.args.chfak != 1 or self.args.neck != 32
 
-    def _engine(self, n, live=True, training=False):
+    def _engine(self, n, live=True, training=False, dropout=None):
         """The engine for batches of n images: the fused fixed-shape kernels at chfak = 1, neck = 32 (the code default), the
-        shape-generic ones for every other model size (the paper's chfak = 5)."""
-        key = (n, live)
+        shape-generic ones for every other model size (the paper's chfak = 5).  dropout: override of --dropout (0 after a
+        -directeval evaluation, which leaves the reference's modules in eval mode for the rest of the training)."""
+        a = self.args
+        p_drop = a.dropout if dropout is None else dropout
+        key = (n, live, p_drop)
         if key not in self._engines:
-            a = self.args
             first = next(iter(self._engines.values()), None)
-            kw = dict(device=self.device, dropout=a.dropout, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject, live=live,
+            kw = dict(device=self.device, dropout=p_drop, lfak=a.lfak, L1=a.L1, L2=a.L2, inject=a.inject, live=live,
                       threshrew=a.threshrew, share_with=first, process_group=self.pg, separate=bool(a.separate),
                       staticnorm=bool(a.staticnorm))
             if self._generic_size():
@@ -173,20 +175,25 @@ class Handler:
             return
         result_path = self.path + "critic/"
         os.makedirs(result_path, exist_ok=True)
-        with open(result_path + "log.txt", "w") as log_file:
-            log_file.write(f"{self.args}\n\n")
+        if self.rank == 0:                        # (data parallel: one writer)
+            with open(result_path + "log.txt", "w") as log_file:
+                log_file.write(f"{self.args}\n\n")
         llog = []
         self.critic.train()
-        self._engine(self.batch_size, training=True)
+        # -directeval (main.py:179-180): Handler.eval() puts critic and masker into eval mode and never back (main.py:900-902; the
+        # re-.train() at main.py:1019-1020 is commented out), so -- unless -noevalmode -- the reference then trains with Dropout OFF
+        self._p1_dropout = 0.0 if (args.directeval and not args.noevalmode) else None
+        self._engine(self.batch_size, training=True, dropout=self._p1_dropout)
         self._reset_adam()                       # a fresh torch.optim.Adam(critic.parameters()) (main.py:178)
-        if args.directeval:                      # main.py:179-180
+        if args.directeval:
             self.eval()
-            self.critic.train()
+            if args.noevalmode:
+                self.critic.train()
         for epoch in range(int(mode == "test") or args.cepochs):
             for b_idx, (X, Y) in enumerate(self._batches()):
                 if args.shift:
                     X = self.shift_batch(X)
-                eng = self._engine(len(X))
+                eng = self._engine(len(X), dropout=self._p1_dropout)
                 losses = eng.phase1_step(X.contiguous().to(self.device, non_blocking=True), Y.to(self.device, non_blocking=True))
                 if not b_idx % 10:
                     val = float(losses[0])       # the only host sync, every 10th batch
@@ -194,7 +201,8 @@ class Handler:
                     print(f"critic e{epoch + 1} b{b_idx}", val, end="\r")
             if not (epoch + 1) % args.saveevery:
                 self.save_models(modelnames=[self.criticname])
-            self._plot(result_path + "_loss.png", {"Train Loss": llog})
+            if self.rank == 0:                    # (data parallel: one writer)
+                self._plot(result_path + "_loss.png", {"Train Loss": llog})
         print()
 
     # ------------------------------------------------------------------ contrastive split
@@ -231,6 +239,10 @@ class Handler:
         else:
             print("no critic provided -> using random pos and neg frames")
             positives = torch.rand(len(self.X)) > 0.5
+            if self.world > 1:                    # every rank must hold the same split (same set sizes, same number of steps)
+                flag = positives.to(torch.uint8).to(self.device)
+                torch.distributed.broadcast(flag, src=0, group=self.pg)
+                positives = flag.cpu().bool()
             negatives = ~positives
             preds = torch.cat((positives, negatives), dim=0)
         npos, nneg = int(positives.sum()), int(negatives.sum())
@@ -271,21 +283,37 @@ class Handler:
         self.critic.train()
         self.masker.train()
         n = 2 * self.contrastive_batchsize
-        eng = self._engine(n, live=args.live, training=True)
+        # -directeval (main.py:337-338) leaves the modules in eval mode (see critic_pipe): the training that follows runs without Dropout
+        eng = self._engine(n, live=args.live, training=True, dropout=0.0 if (args.directeval and not args.noevalmode) else None)
         self._reset_adam()                       # a fresh Adam over critic+masker (live) or masker (frozen)
-        if args.directeval:                      # main.py:337-338
+        if args.directeval:
             self.eval()
-            self.critic.train()
-            self.masker.train()
-        idx_host = torch.empty(2 * n, dtype=torch.int64).pin_memory()
+            if args.noevalmode:
+                self.critic.train()
+                self.masker.train()
+        # The host runs ahead of the device (it only syncs every 10th step): ONE pinned buffer would be overwritten with later draws
+        # while earlier asynchronous uploads are still queued, and several steps would train on the same (or a torn) index set.
+        # A ring of pinned buffers, each reused only after ITS upload's event has completed, keeps one fresh draw per step.
+        ring = 16
+        idx_hosts = [torch.empty(2 * n, dtype=torch.int64).pin_memory() for _ in range(ring)]
+        idx_events = [None] * ring
         idx_dev = torch.empty(2 * n, dtype=torch.int64, device=self.device)
+        self._last_idx_draws = []                # (debug / tests) the host draws of the last few steps, in order
         names = ["replace", "inject", "norm", "live-critic"]
         steps, steps_t0, t0, dt = 0, 0, time.perf_counter(), 0.0
         for epoch in range(args.mepochs):
             for b_idx in range(math.ceil(self.Xpos.shape[0] / self.contrastive_batchsize)):
                 Hidx, Lidx, Cidx = self.get_contrastive_idxs()
+                slot = steps % ring
+                if idx_events[slot] is not None:
+                    idx_events[slot].synchronize()                   # the upload that last used this buffer has finished
+                idx_host = idx_hosts[slot]
                 idx_host.copy_(torch.from_numpy(np.concatenate((Hidx, Lidx, Cidx))))
                 idx_dev.copy_(idx_host, non_blocking=True)
+                idx_events[slot] = torch.cuda.Event()
+                idx_events[slot].record()
+                if getattr(self, "_record_idx_draws", False):
+                    self._last_idx_draws.append(idx_host.clone())
                 roll = self._shift_draw() if args.shift else 0      # torch.roll(X, roll, dims=2): dst[x] = src[x - roll]
                 eng.gather_contrastive(self._Xpos_d, self._Xneg_d, self._ypos_d, self._yneg_d, idx_dev, shift_px=(-roll) % 64)
                 losses = eng.phase2_step()

@@ -173,8 +173,9 @@ def test_fp16_inference_error_distribution_vs_fp32_oracle(g1, chfak, neck, n):
     dz = np.abs(Z.cpu().numpy().astype(np.float64) - rz)
     dp = np.abs(pred.cpu().numpy().astype(np.float64) - rp[:, 0].numpy())
     print(f"fp16 inference chfak {chfak}: |dZ| max {dz.max():.2e} p99.9 {np.quantile(dz, 0.999):.2e} mean {dz.mean():.2e}; |dpred| max {dp.max():.2e}")
-    assert dz.max() < 2e-2 and np.quantile(dz, 0.999) < 5e-3 and dz.mean() < 1e-3
-    assert dp.max() < 5e-3
+    # measured (G1 / seeded weights): max 1.7-2.7e-5, p99.9 1.3-2.0e-5, mean 3.0-4.9e-6, |dpred| 2-9e-6: bounds ~3x above
+    assert dz.max() < 1e-4 and np.quantile(dz, 0.999) < 6e-5 and dz.mean() < 1.5e-5
+    assert dp.max() < 4e-5
     # thresholded masks (what -process writes) differ on a vanishing fraction of the pixels
     assert ((Z.cpu().numpy() > 0.5) != (rz > 0.5)).mean() < 2e-3
     # the weight copies follow the parameters: a training step changes the fp16 result
@@ -183,3 +184,39 @@ def test_fp16_inference_error_distribution_vs_fp32_oracle(g1, chfak, neck, n):
     pred2, _ = e.infer(torch.from_numpy(x).to(dev), fp16=True)
     p32, _ = e.infer(torch.from_numpy(x).to(dev))
     assert float((pred2 - p32).abs().max()) < 5e-3 and not torch.equal(pred2, pred)
+
+
+def test_config4_batch2048_fp16_inference_vs_fp32_oracle(g1):
+    """BASELINE config 4 AT ITS STATED SIZE: the -process inference path on 2048 frames with fp16 conv kernels, both forms -- every
+    layer fp16 (engine.infer(fp16=True), csrc/gen_f16.hip) and fp16 operands in the masker.0 GEMM only (fp16_mask_head=True) --
+    against the fp32 CPU oracle on the same frames.  The bounds are ~3x the measured distribution on the G1 weights (printed), so
+    a regression of the kernels' precision by a factor of a few fails here."""
+    from cgs_amd import engine
+    dev = torch.device("cuda:0")
+    pc, pm = g1
+    e = engine.HourglassEngine(8, dropout=0.0)
+    e.load_state(pc, pm)
+    rs = np.random.RandomState(9)
+    x = rs.randint(0, 256, (2048, 64, 64, 3)).astype(np.uint8)
+    x[:256] = (x[:256] * 0.25).astype(np.uint8)          # a darker population: a spread of critic values
+    x[300, 16:40, 8:56] = 200                            # flat patches: pooling ties
+    with torch.no_grad():
+        rp, rz = [], []
+        for b in range(0, 2048, 256):
+            p, emb = orc.critic_apply(pc, orc.u8_to_nchw(x[b:b + 256]), collect=True)
+            rp.append(p[:, 0]); rz.append(orc.masker_apply(pm, orc.u8_to_nchw(x[b:b + 256]), emb)[:, 0])
+        rp, rz = torch.cat(rp).numpy(), torch.cat(rz).numpy()
+    xd = torch.from_numpy(x).to(dev)
+    p32, z32 = e.infer(xd)
+    rel_close(z32.cpu().numpy(), rz, "fp32 Z at batch 2048")
+    rel_close(p32.cpu().numpy(), rp, "fp32 pred at batch 2048")
+    for name, kw, zmax, zmean, pmax in (("all layers fp16", dict(fp16=True), 1e-4, 1.5e-5, 4e-5),
+                                        ("fp16 masker.0 operands", dict(fp16_mask_head=True), 8e-5, 1e-5, 1e-6)):
+        pred, Z = e.infer(xd, **kw)
+        dz = np.abs(Z.cpu().numpy().astype(np.float64) - rz)
+        dp = np.abs(pred.cpu().numpy().astype(np.float64) - rp)
+        print(f"config 4, batch 2048, {name}: |dZ| max {dz.max():.2e} p99.9 {np.quantile(dz, 0.999):.2e} mean {dz.mean():.2e}; "
+              f"|dpred| max {dp.max():.2e}; Z range [{rz.min():.3f}, {rz.max():.3f}]")
+        assert dz.max() < zmax and dz.mean() < zmean, name
+        assert dp.max() < pmax, name
+        assert ((Z.cpu().numpy() > 0.5) != (rz > 0.5)).mean() < 1e-3

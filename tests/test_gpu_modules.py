@@ -365,3 +365,45 @@ def test_extract_contrastive_split_matches_oracle(tmp_path, g1, monkeypatch):
     np.testing.assert_allclose(H._ypos_d.cpu().numpy(), H.Ypos[args.rewidx].astype(np.float32))
     Hi, Li, Ci = H.get_contrastive_idxs()
     assert len(Hi) == 32 and len(Li) == 32 and len(Ci) == 64 and Hi.max() < len(H.Xpos) and max(Li.max(), Ci.max()) < len(H.Xneg)
+
+
+def test_mask_training_uses_one_fresh_index_draw_per_step(tmp_path, g1, monkeypatch):
+    """Handler.segmentation_training (main.py:344-356): the host runs ahead of the device (one sync per 10 steps), so the
+    per-step index upload must not be overwritten before it has been copied: the B batch the device assembled in EVERY step
+    equals Xneg[the host's draw of that step] (B is not rolled), and consecutive steps differ."""
+    from cgs_amd import cli, engine, handler
+    monkeypatch.chdir(tmp_path)
+    pc, pm = g1
+    rs = np.random.RandomState(7)
+    n = 3000
+    X = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    X[: n // 2] = (X[: n // 2] * 0.3).astype(np.uint8)
+    Y = rs.rand(7, n)
+    with torch.no_grad():
+        want = torch.cat([orc.critic_apply(pc, orc.u8_to_nchw(X[b:b + 250])).squeeze(1) for b in range(0, n, 250)]).numpy()
+    hi, lo = float(np.quantile(want, 0.6)), float(np.quantile(want, 0.4))
+    args = cli.parse_args(["--model", "m", "--high-rew-thresh", repr(hi), "--low-rew-thresh", repr(lo), "--mepochs", "1"])
+    H = handler.Handler(args)
+    H.critic.load_state_dict(pc); H.masker.load_state_dict(pm)
+    H.X, H.Y = X, Y
+    H._record_idx_draws = True
+    seen = []
+    real = engine.HourglassEngine.phase2_step
+
+    def spy(self, *a, **k):
+        seen.append(self.ab[:self.n].clone())       # B of this step, as assembled on the device (stream-ordered copy)
+        return real(self, *a, **k)
+    monkeypatch.setattr(engine.HourglassEngine, "phase2_step", spy)
+    H.segmentation_training()
+    torch.cuda.synchronize()
+    draws = H._last_idx_draws
+    assert len(seen) == len(draws) >= 30
+    nb = 2 * H.contrastive_batchsize
+    Xneg = torch.from_numpy(H.Xneg)
+    same_as_prev = 0
+    for k, (b_dev, idx) in enumerate(zip(seen, draws)):
+        want_b = Xneg[idx[nb:2 * nb]]
+        assert torch.equal(b_dev.cpu(), want_b), f"step {k}: the device batch is not the host's draw of that step"
+        if k and torch.equal(draws[k], draws[k - 1]):
+            same_as_prev += 1
+    assert same_as_prev == 0
