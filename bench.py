@@ -61,7 +61,9 @@ def parse():
                          "phase1 = critic regression step (main.py:183-200)")
     ap.add_argument("--fp16", action="store_true",
                     help="--mode infer only: BASELINE config 4 -- fp16 activations and weights in every layer, fp32 accumulation (opt-in precision)")
-    ap.add_argument("--overlap-wgrad", action="store_true", help="stand-alone weight-gradient kernels on a second stream (parallel graph branch)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="--gpus 1 only: create a ONE-rank RCCL group and keep the data-parallel launch form (step graph -> all-reduce -> Adam): "
+                         "rehearses the N > 1 code path on a 1-GPU box")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -351,7 +353,7 @@ def main():
     dev = torch.device("cuda", local)
     pg = None
     ranks_seen, backend = 1, None
-    if world > 1 or os.environ.get("CGS_BENCH_FORCE_PG") == "1":     # (forced: a 1-rank RCCL group, to rehearse the N>1 code path)
+    if world > 1 or args.force_pg:     # (forced: a 1-rank RCCL group, to rehearse the N>1 code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -368,7 +370,7 @@ def main():
     if args.mode != "train":
         return side_mode(args, dev, world, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg,
-                                 overlap_wgrad=args.overlap_wgrad)
+                                 force_allreduce=args.force_pg)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
     eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture

@@ -6,7 +6,6 @@
 // joins inside a HIP graph cost 6-10 us each on ROCm 7.2, more than they gain).
 #include "conv_body.h"
 #include "wgrad_sparse.h"
-#include <cstdlib>
 
 template <class CWG, class CDG, bool SPARSE>
 __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradParams pw, ConvParams pd, int nbw) {
@@ -40,9 +39,7 @@ static int both_slabs(int n) {
     int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
     int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
     if (both_sparse_ok<CWG> && wgrad_sparse_enabled()) {
-        static const int cap32 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH_BLOCKS"); return e ? atoi(e) : 256; }();
-        static const int cap64 = [] { const char* e = std::getenv("CGS_SPARSE_BOTH0_BLOCKS"); return e ? atoi(e) : 512; }();
-        cap = GW::H >= 64 ? cap64 : cap32;
+        cap = GW::H >= 64 ? 512 : 256;      // persistent sparse workgroups (swept on the step, tools/sweep_sparse.sh, round 3)
     }
     return tiles < cap ? tiles : cap;
 }

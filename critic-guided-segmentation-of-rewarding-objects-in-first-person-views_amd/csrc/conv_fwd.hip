@@ -4,7 +4,6 @@
 //   backward: the same core with transposed/flipped weights; pool/ReLU gradient re-expansion in the
 //             loader; dropout, LeakyReLU', skip-gradient add and upsample-backward sums in the epilogue.
 #include "conv_body.h"
-#include <cstdlib>
 
 // layers routed to the MFMA implicit-GEMM kernels (mconv.hip); CGS_MCONV=0 keeps them on the VALU kernels (A/B)
 int mconv_fwd_dispatch(int which, int n, const void* src_a, const float* src_b, const float* w, const float* bias, float* out,
@@ -19,19 +18,9 @@ int mask_train_launch(int n, int img_kind, const void* img, const float* o0, con
                       const float* b2, float* h, float* z, float* zpart, hipStream_t st);
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st);
-int pconv_fwd_dispatch(int which, int n, const void* src, const uint8_t* mix_a, const uint8_t* mix_b, const float* mix_z, int mix_n_a,
-                       const float* w, const float* bias, float* out, uint32_t* amask, hipStream_t st);
-// features.0 / features.3 forward on the matrix cores, two pixels per MFMA row (pconv.hip).  OPT-IN (CGS_PCONV=1): parity-green,
-// but measured SLOWER than the VALU kernels at N = 512 (features.0 42-44 vs 31-34 us, features.3 26 vs 21 us): its workgroups
-// spend as long staging their tile as multiplying, and two rounds of workgroups per CU do not overlap the two.
-static bool use_pconv() {
-    static const bool on = [] { const char* e = std::getenv("CGS_PCONV"); return e && e[0] == '1'; }();
-    return on;
-}
-static bool use_mconv() {
-    static const bool on = [] { const char* e = std::getenv("CGS_MCONV"); return !(e && e[0] == '0'); }();
-    return on;
-}
+// (round 2's opt-in two-pixels-per-MFMA-row form of features.0 / features.3 -- measured slower -- lives in tools/experiments/pconv.hip,
+//  outside the product library; the 3x3 layers now run on v_mfma_f32_4x4x1 inside conv3x3_body)
+static constexpr bool use_mconv() { return true; }      // the layers with a matrix-core implicit-GEMM kernel always use it
 
 template <class C>
 static int launch_conv(const ConvParams& P, hipStream_t st) {
@@ -69,18 +58,15 @@ extern "C" int cgs_conv3x3_fwd(const cgs_conv_desc* d, const void* src_a, const 
               d->drop_a.p == 0.f))
             return CGS_ERR_UNSUPPORTED;
         P.src_a = nullptr; P.mix_a = m->a; P.mix_b = m->b; P.mix_z = m->z; P.mix_n_a = m->n_a;
-        if (use_pconv()) return pconv_fwd_dispatch(1, d->n, nullptr, m->a, m->b, m->z, m->n_a, w, bias, out, amask, st);
         return launch_conv<FEnc0Mix>(P, st);
     }
     const int R = CGS_ACT_RELU, L = CGS_ACT_LRELU, S = CGS_ACT_SIGMOID, NO = CGS_ACT_NONE;
     if (d->drop_a.p > 0.f && !(desc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, R, 1))) return CGS_ERR_UNSUPPORTED;
     if (desc_is(d, 64, 3, 0, 8, CGS_SRC_U8, 2, R, 1))
-        return use_pconv() ? pconv_fwd_dispatch(0, d->n, src_a, nullptr, nullptr, nullptr, 0, w, bias, out, amask, st)
-                           : launch_conv<FEnc0U8>(P, st);
+        return launch_conv<FEnc0U8>(P, st);
     if (desc_is(d, 64, 3, 0, 8, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc0F32>(P, st);
     if (desc_is(d, 32, 8, 0, 8, CGS_SRC_F32, 2, R, 1))
-        return use_pconv() ? pconv_fwd_dispatch(2, d->n, src_a, nullptr, nullptr, nullptr, 0, w, bias, out, amask, st)
-                           : launch_conv<FEnc1>(P, st);
+        return launch_conv<FEnc1>(P, st);
     if (desc_is(d, 16, 8, 0, 8, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc2>(P, st);
     if (desc_is(d, 8, 8, 0, 16, CGS_SRC_F32, 2, R, 1)) return launch_conv<FEnc3>(P, st);
     if (desc_is(d, 4, 16, 32, 16, CGS_SRC_F32, 4, NO, 0))

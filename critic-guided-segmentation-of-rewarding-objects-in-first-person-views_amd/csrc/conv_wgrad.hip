@@ -23,9 +23,8 @@ template <class G>
 static int wg_tiles(int n) { return (G::IMGS == 1) ? n * G::STRIPS : (n + G::IMGS - 1) / G::IMGS; }
 template <class G>
 static int wg_blocks(int n) {
-    static const int cap = [] { const char* e = std::getenv("CGS_WGRAD_BLOCKS"); return e ? atoi(e) : kMaxWgradBlocks; }();
     int t = wg_tiles<G>(n);
-    return t < cap ? t : cap;
+    return t < kMaxWgradBlocks ? t : kMaxWgradBlocks;
 }
 
 template <class C, bool SPARSE>
@@ -41,8 +40,7 @@ template <class C>
 static int wg_blocks_any(int n) {
     using G = typename C::G;
     if (sparse_cfg<C>::ok && wgrad_sparse_enabled()) {
-        static const int ecap = [] { const char* e = std::getenv("CGS_SPARSE_BLOCKS"); return e ? atoi(e) : 0; }();
-        const int cap = ecap ? ecap : (G::H >= 64 ? 2 * kMaxSparseBlocks : kMaxSparseBlocks);      // measured: 1024 / 512
+        const int cap = G::H >= 64 ? 2 * kMaxSparseBlocks : kMaxSparseBlocks;      // measured: 1024 / 512
         int t = wg_tiles<G>(n);
         return t < cap ? t : cap;
     }

@@ -479,13 +479,15 @@ __global__ void __launch_bounds__(1024) reduce_adam_kernel(const cgs_reduce_job*
 #pragma unroll
             for (int k = 0; k < SL; ++k) g += red[k][col];
             j.dst[i] = g;                                          // the gradient stays observable (tests, DP)
-            const size_t e = (size_t)(j.dst + i - A.grad_base);      // element of the flat buffers
-            const float c1 = bc[0], c2s = bc[1];
-            const float mi = A.b1 * A.m[e] + (1.f - A.b1) * g;
-            const float vi = A.b2 * A.v[e] + (1.f - A.b2) * g * g;
-            A.m[e] = mi;
-            A.v[e] = vi;
-            A.param[e] -= (A.lr / c1) * (mi / (sqrtf(vi) / c2s + A.eps));
+            if (A.param) {      // (NULL: data parallel -- the all-reduce of the gradient comes first, Adam is a launch of its own)
+                const size_t e = (size_t)(j.dst + i - A.grad_base);      // element of the flat buffers
+                const float c1 = bc[0], c2s = bc[1];
+                const float mi = A.b1 * A.m[e] + (1.f - A.b1) * g;
+                const float vi = A.b2 * A.v[e] + (1.f - A.b2) * g * g;
+                A.m[e] = mi;
+                A.v[e] = vi;
+                A.param[e] -= (A.lr / c1) * (mi / (sqrtf(vi) / c2s + A.eps));
+            }
         }
     }
     // ---- the last working workgroup to finish publishes the new step value (two-level ticket: per row, then over the rows) ----
@@ -510,7 +512,8 @@ extern "C" int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_
                                const float* grad_base, float* m, float* v, float lr, float beta1, float beta2, float eps,
                                uint32_t* ticket, int32_t n, const float* pred, const float* y, const float* zpart, int32_t nzpart,
                                float lfak, float l1, float l2, int32_t flags, int64_t nz, float* losses, cgs_stream_t stream) {
-    if (!jobs || njobs <= 0 || max_count <= 0 || !step || !param || !grad_base || !m || !v || !ticket) return CGS_ERR_BADARG;
+    // param == NULL: reduction (+ loss values, + step tick) only -- the data-parallel form, followed by the all-reduce and cgs_adam_flat
+    if (!jobs || njobs <= 0 || max_count <= 0 || !step || !grad_base || !ticket || (param && (!m || !v))) return CGS_ERR_BADARG;
     if (n > 0 && (!pred || !y || !zpart || !losses || nz <= 0)) return CGS_ERR_BADARG;
     AdamArgs A{param, grad_base, m, v, lr, beta1, beta2, eps, ticket};
     LossArgs L{n, nzpart, flags, pred, y, zpart, lfak, l1, l2, nz > 0 ? 1.f / (float)nz : 0.f, losses};

@@ -11,7 +11,6 @@
 //                     the 1x1 convolution, ConvTranspose2d(4,1,0) on a 1x1 map.
 //   gen_convt4s2_*  : ConvTranspose2d(4, 2, 1) over cat(A, B): forward, data gradient, weight gradient (direct form).
 #include "gen_common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -297,7 +296,7 @@ static int gen_conv_launch(GenConvParams P, cgs_stream_t stream) {
     const int ncb = (P.co + 15) / 16, strips = P.hw / P.th;
     // column blocks per workgroup: 3 (2 when that covers the layer exactly); one staged tile then feeds all of them
     const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
-    static const bool wlds = [] { const char* e = std::getenv("CGS_GEN_WLDS"); return e && e[0] == '1'; }();
+    constexpr bool wlds = false;      // weights through LDS: measured slower (occupancy 6 -> 4 workgroups per CU), DESIGN.md section 7
     const size_t lds = ((size_t)(P.th + 2) * (P.hw + 2) * GEN_KC + (wlds ? (size_t)9 * 16 * (per == 2 ? 48 : 16 * per) : 0)) * sizeof(float);
     const dim3 grid(P.n * strips * ((ncb + per - 1) / per));
     auto k = wlds ? (per == 1 ? gen_conv3x3_fwd_kernel<1, true> : per == 2 ? gen_conv3x3_fwd_kernel<2, true> : gen_conv3x3_fwd_kernel<3, true>)

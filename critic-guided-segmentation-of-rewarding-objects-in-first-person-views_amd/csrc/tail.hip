@@ -17,7 +17,6 @@
 // Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
 // masks these kernels draw.
 #include "tail4.h"
-#include <cstdlib>
 
 namespace {
 
@@ -44,13 +43,8 @@ __device__ __forceinline__ float drop1(const DropCtx& dc, uint32_t i) {
 }
 
 int tail_blocks(int n, int cap) { return n < cap ? n : cap; }
-int env_cap(const char* name, int dflt) {
-    const char* e = std::getenv(name);
-    const int v = e ? atoi(e) : dflt;
-    return v > 0 ? v : dflt;
-}
-int tail_fwd_cap() { static const int cap = env_cap("CGS_TAIL_FWD_BLOCKS", 1024); return cap; }
-int tail_bwd_cap() { static const int cap = env_cap("CGS_TAIL_BWD_BLOCKS", 512); return cap; }
+int tail_fwd_cap() { return 1024; }      // persistent workgroups: swept on the step (round 2)
+int tail_bwd_cap() { return 512; }
 
 unsigned long long* g_tail_stamps = nullptr;     // debug: per-workgroup stage time stamps (tools/tail_stamps.py)
 

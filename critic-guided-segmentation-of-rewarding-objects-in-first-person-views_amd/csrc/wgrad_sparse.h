@@ -8,7 +8,6 @@
 // output channel in registers; the pairs of a lane are reduced by lane shuffles once per workgroup.  LDS-read-bound.
 #pragma once
 #include "wgrad_body.h"
-#include <cstdlib>
 
 // H = W = 64 (CA = 3, sources: uint8 frames, the virtual mixes, fp32 images) or 32 (CA = 8, fp32); CO = 8; 256 threads
 template <int H_, int CA_, int SRC_>
@@ -280,7 +279,4 @@ static constexpr size_t wgrad_any_lds_bytes() {
     else return wgrad_lds_bytes<CWG>();
 }
 
-static inline int wgrad_sparse_enabled() {
-    static const int on = [] { const char* e = std::getenv("CGS_WGRAD_SPARSE"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on;
-}
+static inline int wgrad_sparse_enabled() { return 1; }     // (round 2 kept the dense MFMA form behind an environment switch)

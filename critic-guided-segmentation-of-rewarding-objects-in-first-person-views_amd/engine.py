@@ -10,7 +10,6 @@ Data parallelism: one process per GPU, each with its own N images; the only exch
 of the flat gradient buffer (25 661 floats) between the slab reduction and Adam.
 """
 import ctypes as C
-import os
 from typing import Dict, Optional
 
 import torch
@@ -35,8 +34,8 @@ class HourglassEngine:
     def __init__(self, n: int, device="cuda:0", dropout: float = 0.3, lfak: float = 5, L1: float = 0.5, L2: float = 0.0,
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
-                 process_group=None, share_with: "HourglassEngine" = None, overlap_wgrad: bool = False,
-                 separate: bool = False, staticnorm: bool = True):
+                 process_group=None, share_with: "HourglassEngine" = None, separate: bool = False, staticnorm: bool = True,
+                 force_allreduce: bool = False):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -48,9 +47,9 @@ class HourglassEngine:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
-        # data parallel: the all-reduce sits between the step graph and the Adam graph.  CGS_FORCE_ALLREDUCE=1 keeps that
-        # three-launch form for a 1-rank group too (rehearsal of the RCCL path on a 1-GPU box).
-        self.dp = process_group is not None and (self.world > 1 or os.environ.get("CGS_FORCE_ALLREDUCE") == "1")
+        # data parallel: the all-reduce sits between the step graph and the Adam graph.  force_allreduce keeps that
+        # form for a 1-rank group too (rehearsal of the RCCL path on a 1-GPU box).
+        self.dp = process_group is not None and (self.world > 1 or force_allreduce)
         self.lc, self.lm = critic_layout(), masker_layout()
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         # -separate (main.py:110-111, 390): a second critic supplies the masker's skip inputs; its parameters sit behind the
@@ -97,17 +96,17 @@ class HourglassEngine:
         self._ws = {"mb": {}, "cb_mix": {}, "cb_a": {}, "cb_sep": {}, "p1": {}}
         self._infer_step = z(1, dt=torch.int64)              # -noevalmode: Dropout stream of inference batches
         self._ticket = z(4096, dt=torch.int32)               # cgs_reduce_adam's last-workgroup counters (1 + one per job row)
-        # single GPU + tail kernels: the loss gradients at pred are derived inside the tail backward kernels and the step ends in
-        # ONE launch (slab reduction + Adam + loss values): two launches (losses, Adam) fewer on the critical path
-        self.fused_tail = hg.TAIL_BWD and not self.dp and os.environ.get("CGS_FUSED_STEP_TAIL", "1") != "0"
+        # the loss gradients at pred are derived inside the tail backward kernels and the step ends in ONE launch: slab reduction
+        # + loss values + Adam on one GPU; under data parallelism slab reduction + loss values, then the all-reduce, then ONE Adam
+        # launch (round 3: the data-parallel step is the single-GPU step + one launch + the collective)
+        self.fused_tail = hg.TAIL_BWD
         self._graphs: Dict[str, object] = {}
         # parameter version (shared by engines that share the parameters): the fp16 inference path repacks its weight copies when it moves
         self._pver = share_with._pver if share_with is not None else [0]
         self._w16 = None
-        # optional second stream for the weight-gradient kernels (measured neutral under graph replay on ROCm 7.2:
-        # the cross-queue joins cost what the overlap gains)
-        self.side = hg.SideStream(torch.cuda.Stream(device=self.dev) if overlap_wgrad else None)
-        self.b_side = hg.SideStream(torch.cuda.Stream(device=self.dev)) if os.environ.get("CGS_B_SIDE") == "1" else None
+        # (second streams inside the step graph -- weight gradients, critic(B) -- were measured neutral to slower on ROCm 7.2: the
+        #  cross-queue joins cost what the overlap gains; the hooks stay as no-ops)
+        self.side = hg.SideStream(None)
         self._plans: Dict[str, hg.SlabPlan] = {}
 
     # ---- parameters --------------------------------------------------------------------------
@@ -181,8 +180,8 @@ class HourglassEngine:
         """(first float, count) of the optimiser group: everything when live, else masker (+ sepcrit) (main.py:330-334)."""
         return (0, self.total) if self.live else (self.off_m, self.total - self.off_m)
 
-    def _adam(self):
-        if self.fused_tail:
+    def _adam(self, tag="p2"):
+        if self.fused_tail and not self.dp and tag == "p2":
             return          # phase 2 on one GPU: Adam ran inside cgs_reduce_adam
         lo, cnt = self._opt_range()
         _lib.call("cgs_adam_flat", cnt, C.c_void_p(self.flat.data_ptr() + 4 * lo), C.c_void_p(self.grad.data_ptr() + 4 * lo),
@@ -209,16 +208,8 @@ class HourglassEngine:
         fm_ptr = self.fm.data_ptr()
         pw = (C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.weight")), C.c_void_p(fm_ptr + 4 * self.lm.off("dec_model.4.bias")),
               self._o4_full)
-        if self.b_side is not None and not self.separate:
-            # critic(B) is only needed at the loss: on a second stream (a parallel branch of the graph) it overlaps the
-            # masker's forward chain, and the critical path starts with half-size launches on A alone
-            with self.b_side.fork():
-                hg.critic_forward(self.fc, self.lc, B, n, drop.shifted(0), out=self._cview(0, n))
-            pwa = (pw[0], pw[1], self.mbuf["o4"])
-            hg.critic_forward(self.fc, self.lc, A, n, drop.shifted(n), out=self._cview(n, 2 * n), pw=pwa)
-        else:
-            hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n),
-                              pw=None if self.separate else pw)
+        hg.critic_forward(self.fc, self.lc, self.ab, 2 * n, drop.shifted(0), out=self._cview(0, 2 * n),
+                          pw=None if self.separate else pw)
         sa = self._cview(n, 2 * n)
         if self.separate:     # main.py:389-390: the masker's inputs come from the second critic's pass over A
             pws = (pw[0], pw[1], self.mbuf["o4"])
@@ -237,8 +228,6 @@ class HourglassEngine:
             mixsrc = self.mixed[:nmix]
             _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(self.mbuf["Z"]), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
             hg.critic_forward(self.fc, self.lc, mixsrc, nmix, drop.shifted(2 * n), out=self._cview(2 * n, 2 * n + nmix))
-        if self.b_side is not None:
-            self.b_side.join()           # pred of B (the replace loss's target) is needed from here on
         flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0) | (0 if self.staticnorm else 8)
         ft = self.fused_tail
         if not ft:
@@ -306,7 +295,8 @@ class HourglassEngine:
                 full.jobs.append((slab, nsl, cnt, self.off_s + off))
             self._plans["p2"] = full.build(self.grad)
         if ft:      # reduction + Adam + loss values in one launch; the optimiser group is exactly the set of reduced elements
-            self._plans["p2"].run_adam(self.step_t, self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
+            # (data parallel: param = None -> reduction + loss values + step tick; the all-reduce and one Adam launch follow)
+            self._plans["p2"].run_adam(self.step_t, None if self.dp else self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps,
                                        self._ticket, loss=(n, self.cbuf["pred"], self.y, self.zsum, self.nzpart, self.lfak, self.L1,
                                                            self.L2, flags, n * 4096, self.losses))
         else:

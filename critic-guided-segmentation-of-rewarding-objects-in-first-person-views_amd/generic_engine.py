@@ -8,7 +8,6 @@ Per phase-2 step:  critic fwd [B|A] -> masker fwd A -> mixes (materialised, fp32
   -> critic data-gradient pass on [rep|inj] (down to the images) -> mix backward -> masker backward
   -> critic data-gradient pass on A (skip gradients added) -> ONE weight-gradient pass of the critic over [A|rep|inj]
   -> slab reduction [-> all-reduce] -> Adam."""
-import os
 from typing import Dict
 
 import torch
@@ -27,7 +26,8 @@ class GenericEngine(HourglassEngine):
     def __init__(self, n: int, chfak: int = 5, neck: int = 32, device="cuda:0", dropout: float = 0.3, lfak: float = 5,
                  L1: float = 0.5, L2: float = 0.0, inject: bool = True, live: bool = True, threshrew: float = 0.0,
                  seed: int = 0x5EED, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
-                 process_group=None, share_with: "GenericEngine" = None, separate: bool = False, staticnorm: bool = True):
+                 process_group=None, share_with: "GenericEngine" = None, separate: bool = False, staticnorm: bool = True,
+                 force_allreduce: bool = False):
         if not torch.cuda.is_available():
             raise _lib.CgsError("GenericEngine needs an MI355X (HIP device); there is no CPU fallback")
         if not staticnorm:
@@ -42,7 +42,7 @@ class GenericEngine(HourglassEngine):
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
-        self.dp = process_group is not None and (self.world > 1 or os.environ.get("CGS_FORCE_ALLREDUCE") == "1")
+        self.dp = process_group is not None and (self.world > 1 or force_allreduce)
         self.lc, self.lm = critic_layout(self.chfak, self.neck), masker_layout(self.chfak, self.neck)
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         self.separate, self.staticnorm = bool(separate), True

@@ -18,18 +18,19 @@ from .spec import (DEC_LAYERS, DROP_SITE_E2, DROP_SITE_E3, DROP_SITE_H1, ENC_LAY
 
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 HEAD_SLAB = 8192 + 32 + 1024 + 32 + 32 + 1
+# Which kernel forms the step is composed of.  These are the build's fixed configuration (round 3: environment switches removed);
+# the per-layer forms they replaced stay reachable through the C ABI and are parity-tested there (tests/test_gpu_kernels.py).
 # small layers: weight- and data-gradient halves share one launch (csrc/conv_bwd_both.hip)
-BWD_BOTH = os.environ.get("CGS_BWD_BOTH", "1") != "0"
-MASK_INFER_FUSED = os.environ.get("CGS_MASK_INFER_FUSED", "1") != "0"   # inference: masker.0 + masker.2 in one kernel
-ENC0_MIX_FUSED = os.environ.get("CGS_ENC0_MIX_FUSED", "1") != "0"   # features.0 backward + mix backward in one launch
-MASK_HEAD_FUSED = os.environ.get("CGS_MASK_HEAD_FUSED", "1") != "0"   # masker.2+masker.0 data gradients in one pass
-# training forward: masker.0 + masker.2 in one kernel (h stored once).  Measured equal to the two-kernel form at N = 512 (103 us vs
-# 60 + 40 us: the one-kernel form holds 80 KB of LDS, 2 workgroups per CU, and its phases serialise), so it is opt-in for now.
-MASK_TRAIN_FUSED = os.environ.get("CGS_MASK_TRAIN_FUSED", "1") != "0"
+BWD_BOTH = True
+MASK_INFER_FUSED = True   # inference: masker.0 + masker.2 in one kernel
+ENC0_MIX_FUSED = True   # features.0 backward + mix backward in one launch
+MASK_HEAD_FUSED = True   # masker.2+masker.0 data gradients in one pass
+# training forward: masker.0 + masker.2 in one kernel on v_mfma_f32_4x4x1 (csrc/mask_fwd.hip, round 3: 68 us vs 60 + 38 us)
+MASK_TRAIN_FUSED = True
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
-TAIL_FWD = os.environ.get("CGS_TAIL_FWD", "1") != "0"
-TAIL_BWD = os.environ.get("CGS_TAIL_BWD", "1") != "0"
-_both = os.environ.get("CGS_BWD_BOTH_LAYERS", "c3,c2,c1,c0,d3,d2,d1")   # measured: d0 and m0 do not gain
+TAIL_FWD = True
+TAIL_BWD = True
+_both = "c3,c2,c1,c0,d3,d2,d1"   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
 _DEC_TAG = {0: "d3", 1: "d2", 2: "d1", 3: "d0", 4: "m0", 5: "m2"}

@@ -239,7 +239,8 @@ int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_coun
  * cgs_adam_flat, grad_scale 1) of every element a job writes -- param / m / v are indexed by (job.dst - grad_base) -- and, when
  * n > 0, the loss values of cgs_phase2_losses (losses[8]; no dpred: the tail backward kernels derive it themselves).  *step is
  * read by every workgroup and advanced by one by the LAST workgroup to finish (ticket: device uint32 [njobs + 2], zero before
- * the first call; the kernel leaves it zero).                                                                                     */
+ * the first call; the kernel leaves it zero).  param == NULL: reduction, loss values and step tick only -- the data-parallel form:
+ * the all-reduce of the gradient follows, then cgs_adam_flat (which reads the advanced *step).                                       */
 int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step, float* param,
                     const float* grad_base, float* m, float* v, float lr, float beta1, float beta2, float eps,
                     uint32_t* ticket, int32_t n, const float* pred, const float* y, const float* zpart, int32_t nzpart,

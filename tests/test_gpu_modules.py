@@ -303,10 +303,10 @@ def test_rccl_path_one_rank_rehearsal():
     """bench.py with a ONE-rank RCCL group and the data-parallel launch form forced (step graph -> in-place device all-reduce
     -> Adam graph): init_process_group("nccl", device_id=...), the collective on the device buffer between the two HIP graphs,
     the barrier and the max-over-ranks timing all execute on this 1-GPU box; its cost shows as the step-time difference."""
-    env = dict(os.environ, CGS_BENCH_FORCE_PG="1", CGS_FORCE_ALLREDUCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    r = subprocess.run(cmd + ["--force-pg"], capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_seen_by_collective_backend"] == 1
@@ -318,7 +318,8 @@ def test_rccl_path_one_rank_rehearsal():
     extra_ms = line["ms_per_step"] - base["ms_per_step"]
     print(f"three-launch form with a 1-rank RCCL all-reduce: {line['ms_per_step']:.3f} ms vs {base['ms_per_step']:.3f} ms single graph "
           f"(+{extra_ms * 1e3:.0f} us per step)")
-    assert extra_ms < 0.25, "the all-reduce between the two graphs must stay well below the 6x-at-8-GPUs budget"
+    # round 3: the data-parallel step = the single-GPU step + ONE Adam launch + the collective (the loss / reduction tail stays fused)
+    assert extra_ms < 0.04, "step graph -> all-reduce -> Adam must cost at most a few tens of microseconds over the single-GPU step"
 
 
 def test_bench_gpus_flag_starts_ranks_or_refuses():

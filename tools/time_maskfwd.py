@@ -17,4 +17,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(100): call()
 e1.record(); torch.cuda.synchronize()
-print(f"mask_train_fwd n={n} var={os.environ.get('CGS_MASKFWD_VAR', '0')}: {e0.elapsed_time(e1) / 100 * 1e3:7.1f} us")
+print(f"mask_train_fwd n={n}: {e0.elapsed_time(e1) / 100 * 1e3:7.1f} us")
