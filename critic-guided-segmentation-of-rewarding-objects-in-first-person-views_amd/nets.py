@@ -274,14 +274,152 @@ class UnetDecoder(_HipModule):
         return fn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)
 
 
+class _UnetFn(torch.autograd.Function):
+    """nets.Unet(upsample=False) forward + backward on the shape-generic HIP kernels (csrc/gen.hip, gen_train.hip): Conv2d +
+    LeakyReLU(0.2) + MaxPool2d encoder (cgs_gen_conv3x3_*), the 4x4 bottleneck convolution, the critic's Linear layers and the
+    ConvTranspose2d(.,.,4,1,0) on the 1x1 map as GEMMs (cgs_gen_gemm_ex), ConvTranspose2d(4,2,1) over cat(decoder, pooled encoder)
+    (cgs_gen_convt4s2_*).  No arithmetic of the path runs in torch ops; torch only re-lays-out the weights / gradients between the
+    reference's parameter shapes and the kernels' (HWIO conv weights, [ky][kx][ci][co] transposed-conv weights)."""
+
+    @staticmethod
+    def forward(ctx, net, X, mode, *params):
+        dev = params[0].device
+        ew, eb = [params[2 * i] for i in range(5)], [params[2 * i + 1] for i in range(5)]
+        dw, db = [params[10 + 2 * i] for i in range(5)], [params[11 + 2 * i] for i in range(5)]
+        cw1, cb1, cw2, cb2 = params[20:24]
+        x = _to_nhwc(X.to(dev))
+        n = x.shape[0]
+        k = lambda t: t.detach().permute(2, 3, 1, 0).contiguous().reshape(-1)        # OIHW -> HWIO
+        ewk = [k(w) for w in ew]
+        p, am, src = [], [], x
+        for i in range(4):       # x_i = LeakyReLU(0.2)(conv); p_i = MaxPool2d(2)(x_i)   (nets.py:405-419)
+            o, a = gen.conv3x3(src, None, ewk[i].data_ptr(), eb[i].detach().contiguous().data_ptr(), ew[i].shape[0], act="lrelu", slope=0.2,
+                               pool=True, want_argmax=True)
+            p.append(o); am.append(a); src = o
+        nb, e3 = ew[4].shape[0], ew[3].shape[0]
+        x4 = gen.gemm(p[3].reshape(n, -1), ewk[4].data_ptr(), eb[4].detach().contiguous().data_ptr(), 16 * e3, nb, act="lrelu", slope=0.2)
+        ctx.net, ctx.mode, ctx.n = net, mode, n
+        ctx.set_materialize_grads(False)
+        if mode == "critic":
+            w1, w2 = cw1.detach().t().contiguous(), cw2.detach().t().contiguous()
+            h = gen.gemm(x4, w1.data_ptr(), cb1.detach().contiguous().data_ptr(), nb, 32, act="relu")
+            c = gen.gemm(h, w2.data_ptr(), cb2.detach().contiguous().data_ptr(), 32, 1)
+            torch.cuda.current_stream().synchronize()      # temporaries of this call (re-laid-out weights) die with it
+            ctx.save_for_backward(x, *p, *am, x4, h, *[t.detach() for t in params])
+            return c
+        d3 = dw[4].shape[1]
+        wk4 = dw[4].detach().permute(0, 2, 3, 1).contiguous().reshape(nb, 16 * d3)      # [ci][ky][kx][co]
+        u = [None] * 4
+        u[3] = gen.gemm(x4, wk4.data_ptr(), db[4].detach().repeat(16).contiguous().data_ptr(), nb, 16 * d3, act="lrelu",
+                        slope=0.2).reshape(n, 4, 4, d3)
+        for i in (3, 2, 1):      # u_{i-1} = LeakyReLU(0.2)(dec[i](cat(u_i, p_i)))   (nets.py:437-443)
+            u[i - 1] = gen.convt_fwd(u[i], p[i], gen.convt_weight_to_kernel(dw[i].detach()), db[i].detach().contiguous(), act="lrelu", slope=0.2)
+        y = gen.convt_fwd(u[0], p[0], gen.convt_weight_to_kernel(dw[0].detach()), db[0].detach().contiguous(), act="sigmoid")
+        torch.cuda.current_stream().synchronize()
+        ctx.save_for_backward(x, *p, *am, x4, *u, y, *[t.detach() for t in params])
+        return y.permute(0, 3, 1, 2), u[0].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        sv = ctx.saved_tensors
+        n, mode = ctx.n, ctx.mode
+        x, p, am, x4 = sv[0], list(sv[1:5]), list(sv[5:9]), sv[9]
+        params = sv[-24:]
+        ew, eb = [params[2 * i] for i in range(5)], [params[2 * i + 1] for i in range(5)]
+        dw, db = [params[10 + 2 * i] for i in range(5)], [params[11 + 2 * i] for i in range(5)]
+        cw1, cb1, cw2, cb2 = params[20:24]
+        dev = x.device
+        grads = [None] * 24
+        nb, e3 = ew[4].shape[0], ew[3].shape[0]
+        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
+        ones = torch.ones(max(16 * n, 64), device=dev, dtype=torch.float32)
+
+        def colsum(t2d):          # [rows, cols] -> [cols] (column sums on the GEMM kernel: ones^T . t)
+            rows, cols = t2d.shape
+            out = z(cols)
+            gen.gemm_ex(1, rows, cols, ones, 0, 1, t2d, cols, 1, out)
+            return out
+
+        def linear_bwd(xin, w_t, g):      # y = xin [n,k] . w_t [k,m]: returns (d xin, dW^T [k,m], db [m]); g = gradient at y [n,m]
+            kk, m = w_t.shape
+            dwt = z(kk, m)
+            gen.gemm_ex(kk, n, m, xin, 1, kk, g, m, 1, dwt)                  # xin^T . g
+            dxin = z(n, kk)
+            gen.gemm_ex(n, m, kk, g, m, 1, w_t, 1, m, dxin)                  # g . w_t^T
+            return dxin, dwt, colsum(g)
+
+        dskip = [None] * 4        # gradients arriving at p_i from the decoder (NHWC)
+        if mode == "critic":
+            h = sv[10]
+            gc = gouts[0].contiguous().to(torch.float32).reshape(n, 1).clone()
+            w1t, w2t = cw1.t().contiguous(), cw2.t().contiguous()
+            dh, dw2t, db2 = linear_bwd(h, w2t, gc)
+            gen.grad_fix(dh, h, act="relu")
+            dx4, dw1t, db1 = linear_bwd(x4, w1t, dh)
+            grads[20], grads[21], grads[22], grads[23] = dw1t.t().contiguous(), db1, dw2t.t().contiguous(), db2
+        else:
+            u, y = list(sv[10:14]), sv[14]
+            gy = gouts[0].permute(0, 2, 3, 1).contiguous().to(torch.float32).clone()          # NHWC [n,64,64,1]
+            gen.grad_fix(gy, y, act="sigmoid")
+            g = gy
+            for i in (0, 1, 2, 3):   # dec[i]: ConvTranspose2d(4,2,1) over cat(u_i, p_i)
+                wk = gen.convt_weight_to_kernel(dw[i])
+                du, dp_i, dwk, dbi = gen.convt_bwd(u[i], p[i], wk, g)
+                ci, co = dw[i].shape[0], dw[i].shape[1]
+                grads[10 + 2 * i], grads[11 + 2 * i] = gen.convt_weight_from_kernel(dwk, ci, co), dbi
+                dskip[i] = dp_i
+                if i == 0 and len(gouts) > 1 and gouts[1] is not None:      # gradient at the returned embed u0
+                    gen.grad_fix(du, None, addend=gouts[1].permute(0, 2, 3, 1).contiguous().to(torch.float32))
+                gen.grad_fix(du, u[i], act="lrelu", slope=0.2)
+                g = du
+            # dec[4]: ConvTranspose2d(bottleneck, d3, 4, 1, 0) on the 1x1 map = x4 [n,nb] . wk4 [nb, 16 d3]
+            d3 = dw[4].shape[1]
+            wk4 = dw[4].permute(0, 2, 3, 1).contiguous().reshape(nb, 16 * d3)
+            dx4, dwk4, _ = linear_bwd(x4, wk4, g.reshape(n, 16 * d3))
+            grads[18] = dwk4.reshape(nb, 4, 4, d3).permute(0, 3, 1, 2).contiguous()
+            grads[19] = colsum(g.reshape(n * 16, d3))
+        # ---- encoder: the 4x4 bottleneck convolution, then conv + LeakyReLU(0.2) + pool x 4 ----
+        gen.grad_fix(dx4, x4, act="lrelu", slope=0.2)
+        wk = ew[4].permute(2, 3, 1, 0).contiguous().reshape(16 * e3, nb)
+        dp3, dwk, dbe = linear_bwd(p[3].reshape(n, 16 * e3), wk, dx4)
+        grads[8], grads[9] = dwk.reshape(4, 4, e3, nb).permute(3, 2, 0, 1).contiguous(), dbe
+        g = dp3.reshape(p[3].shape)
+        lib = _lib.load()
+        for i in (3, 2, 1, 0):
+            if dskip[i] is not None:
+                gen.grad_fix(g, None, addend=dskip[i])
+            gen.grad_fix(g, p[i], act="lrelu", slope=0.2)          # pool(lrelu(.)) = lrelu(pool(.)): the pooled output carries the sign
+            src = x if i == 0 else p[i - 1]
+            hw, ca, co = src.shape[1], src.shape[3], ew[i].shape[0]
+            nsl = lib.cgs_gen_conv3x3_bwd_weight_slabs(n, ca, 0, co)
+            cnt = 9 * ca * co + co
+            slab = z(nsl, cnt)
+            _lib.call("cgs_gen_conv3x3_bwd_weight", n, hw, ca, 0, co, 0, 2, gen._p(src), None, gen._p(g), gen._p(am[i]), gen._p(slab), gen._s())
+            flat = z(cnt)
+            plan = hg.SlabPlan()
+            plan.add(slab, nsl, cnt, 0)
+            plan.build(flat).run(None)
+            grads[2 * i] = flat[:9 * ca * co].reshape(3, 3, ca, co).permute(3, 2, 0, 1).contiguous()
+            grads[2 * i + 1] = flat[9 * ca * co:].clone()
+            if i > 0:
+                wkf = ew[i].permute(2, 3, 1, 0).contiguous().reshape(-1)
+                wflip = z(9 * ca * co)
+                _lib.call("cgs_gen_flip_weights", ca, co, gen._p(wkf), gen._p(wflip), gen._s())
+                dsrc = z(*src.shape)
+                gen._bwd_data(n, hw, co, ca, g, am[i], wflip, dsrc)
+                g = dsrc
+        torch.cuda.current_stream().synchronize()          # temporaries (re-laid-out weights, slabs) die with this call
+        return (None, None, None) + tuple(grads)
+
+
 class Unet(nn.Module):
     """The legacy single-module hourglass (nets.py:356-449; `main.py` never builds it, TrainHandler.__init__old did): Conv2d +
     LeakyReLU(0.2) + MaxPool2d encoder, bottleneck 4x4 convolution, and -- with ``upsample=False``, the form implemented
     here -- a ConvTranspose2d decoder: ConvTranspose2d(bottleneck, 16, 4, 1, 0) on the 1x1 map, then three
     ConvTranspose2d(., ., 4, 2, 1) over cat(decoder, pooled encoder) with LeakyReLU(0.2), a last one into the sigmoid mask.
     Same constructor, parameter names (``enc_model.N`` / ``dec_model.N`` / ``critic.N``) and default initialisation order as the
-    reference, so checkpoints and seeds interchange; the modules below only HOLD the parameters, the arithmetic runs on the
-    shape-generic HIP kernels (forward pass; cgs_gen_convt4s2_bwd_* carry the transposed convolution's gradients)."""
+    reference, so checkpoints and seeds interchange; the modules below only HOLD the parameters, the arithmetic -- forward AND
+    backward (round 3: _UnetFn) -- runs on the shape-generic HIP kernels."""
 
     def __init__(self, width=64, edims=[8, 8, 8, 16], ddims=[8, 8, 8, 16], bottleneck=32, colorchs=3, chfak=1,
                  activation=nn.ReLU, pool="max", upsample=True, pure=False):
@@ -310,9 +448,19 @@ class Unet(nn.Module):
         w0 = self.enc_model[0].weight
         if not w0.is_cuda:
             raise _lib.CgsError("Unet: parameters are on the CPU; the HIP kernels need a GPU (call .to('cuda')), there is no CPU fallback")
-        if torch.is_grad_enabled() and (X.requires_grad or self.training):
-            raise NotImplementedError("Unet: forward pass only in this build (call .eval() / torch.no_grad()); the transposed "
-                                      "convolution's gradient kernels are exposed as cgs_gen_convt4s2_bwd_data / _bwd_weight")
+        if torch.is_grad_enabled() and any(q.requires_grad for q in self.parameters()):
+            if X.requires_grad:
+                _unsupported("Unet: a gradient w.r.t. the input image (parameters' gradients only)")
+            params = []
+            for m in self.enc_model:
+                params += [m.weight, m.bias]
+            for m in self.dec_model:
+                params += [m.weight, m.bias]
+            params += [self.critic[1].weight, self.critic[1].bias, self.critic[3].weight, self.critic[3].bias]
+            if critic:
+                return _UnetFn.apply(self, X, "critic", *params)
+            y, u0 = _UnetFn.apply(self, X, "mask", *params)
+            return (y, u0) if embeds else y
         with torch.no_grad():
             x = _to_nhwc(X.to(w0.device))
             n = x.shape[0]

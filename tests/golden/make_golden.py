@@ -23,6 +23,7 @@ Fixtures (all float32 unless noted):
   g5_shift.npz           shift_batch under torch.manual_seed(k)
   g7_dropout.npz         phase-2 step with dropout 0.3 and the recorded keep-masks
   g8_unet_convt.npz      legacy Unet(upsample=False) (ConvTranspose2d decoder, LeakyReLU(0.2)): weights, mask, u0, critic value
+  g8_unet_train.npz      the same class, one training step: loss = MSE(mask, target) + MSE(critic, target), all 24 parameter gradients
 """
 import json
 import os
@@ -283,6 +284,23 @@ with torch.no_grad():
 g8 = {"X": xu, "y": yu.numpy(), "u0": u0.numpy(), "critic": cu.numpy()}
 g8.update(sd_np("sd", unet.state_dict()))
 np.savez(os.path.join(HERE, "g8_unet_convt.npz"), **g8)
+
+# one training step of the same class (train mode; it has no Dropout): loss = MSE(mask, target) + MSE(critic value, target),
+# all 24 parameter gradients -- pins the ConvTranspose2d / LeakyReLU(0.2) backward of nets.Unet(upsample=False)
+unet.train()
+for q in unet.parameters():
+    q.grad = None
+tgt = torch.from_numpy(np.random.RandomState(6).rand(xu.shape[0], 1, 64, 64).astype(np.float32))
+ytc = torch.from_numpy(np.random.RandomState(7).rand(xu.shape[0]).astype(np.float32))
+yt = unet(to_nchw(xu))
+ct = unet(to_nchw(xu), critic=True).squeeze()
+lmask, lcrit = F.mse_loss(yt, tgt), F.mse_loss(ct, ytc)
+(lmask + lcrit).backward()
+g8t = {"X": xu, "target_mask": tgt.numpy(), "target_critic": ytc.numpy(), "loss_mask": np.float64(lmask.item()), "loss_critic": np.float64(lcrit.item())}
+g8t.update(sd_np("sd", unet.state_dict()))
+for k, v in unet.named_parameters():
+    g8t["grad/" + k] = v.grad.numpy().copy()
+np.savez(os.path.join(HERE, "g8_unet_train.npz"), **g8t)
 
 tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".npz", ".json")))
 print("fixtures written, total bytes:", tot)

@@ -220,3 +220,37 @@ def test_config4_batch2048_fp16_inference_vs_fp32_oracle(g1):
         assert dz.max() < zmax and dz.mean() < zmean, name
         assert dp.max() < pmax, name
         assert ((Z.cpu().numpy() > 0.5) != (rz > 0.5)).mean() < 1e-3
+
+
+def test_legacy_unet_trains_through_the_module_vs_reference_capture(golden):
+    """nets.Unet(upsample=False) under autograd (nets.py:356-449, built at TrainHandler.py:159-161): one
+    training step of the REFERENCE class (loss = MSE(mask, target) + MSE(critic value, target), captured by make_golden.py) --
+    the two losses and all 24 parameter gradients, through ConvTranspose2d(4,2,1) / (4,1,0), LeakyReLU(0.2), MaxPool2d and the
+    critic's Linear layers, every one on the HIP kernels (_UnetFn).  Then an optimiser step through torch.optim.Adam moves the
+    parameters the module API holds."""
+    from cgs_amd import nets
+    g = golden("g8_unet_train.npz")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    net = nets.Unet(upsample=False).to("cuda").train()
+    net.load_state_dict(sd)
+    X = orc.u8_to_nchw(g["X"]).cuda()
+    tgt, ytc = torch.from_numpy(g["target_mask"]).cuda(), torch.from_numpy(g["target_critic"]).cuda()
+    opt = torch.optim.Adam(net.parameters())
+    y = net(X)
+    c = net(X, critic=True).squeeze()
+    lmask, lcrit = F.mse_loss(y, tgt), F.mse_loss(c, ytc)
+    np.testing.assert_allclose(float(lmask), float(g["loss_mask"]), rtol=1e-5)
+    np.testing.assert_allclose(float(lcrit), float(g["loss_critic"]), rtol=1e-5)
+    (lmask + lcrit).backward()
+    names = [k for k, _ in net.named_parameters()]
+    assert len(names) == 24
+    for k, q in net.named_parameters():
+        assert q.grad is not None, k
+        rel_close(q.grad.cpu().numpy(), g["grad/" + k], "grad " + k, rtol=1e-3, atol_scale=5e-5)
+    before = {k: q.detach().clone() for k, q in net.named_parameters()}
+    opt.step()
+    assert all(not torch.equal(before[k], q.detach()) for k, q in net.named_parameters())
+    # eval-mode forward still matches after the step's parameters are in place (no stale weight copies)
+    with torch.no_grad():
+        y2 = net.eval()(X)
+    assert torch.isfinite(y2).all() and not torch.equal(y2, y.detach())

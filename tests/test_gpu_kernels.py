@@ -10,15 +10,25 @@ pytestmark = pytest.mark.gpu
 from oracle import hourglass_ref as orc
 
 
+REL_REPORT = {}       # what -> worst PURE relative error over the elements above 1 % of the tensor's maximum (summary test below)
+
+
 def rel_close(got, ref, what, rtol=1e-3, atol_scale=2e-5):
+    """|got - ref| <= rtol |ref| + atol_scale max|ref| elementwise.  The absolute term only covers values near zero; the worst
+    pure-relative error of the elements that carry the tensor (>= 1 % of its maximum) is recorded and shown on failure."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
-    atol = atol_scale * max(1e-12, float(np.abs(ref).max()))
+    mx = max(1e-12, float(np.abs(ref).max()))
+    atol = atol_scale * mx
     err = np.abs(got - ref)
+    big = np.abs(ref) >= 1e-2 * mx
+    worst_rel = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
+    REL_REPORT[what] = max(REL_REPORT.get(what, 0.0), worst_rel)
     bad = err > (rtol * np.abs(ref) + atol)
     assert not bad.any(), (f"{what}: {bad.sum()}/{bad.size} outside tol; max err {err.max():.3e} "
-                           f"(ref max {np.abs(ref).max():.3e}) at {np.unravel_index(err.argmax(), err.shape)}")
+                           f"(ref max {np.abs(ref).max():.3e}) at {np.unravel_index(err.argmax(), err.shape)}; "
+                           f"worst pure-relative error over |ref| >= 1% of max: {worst_rel:.3e}")
 
 
 def nhwc(t):  # device NHWC tensor -> numpy NCHW
@@ -176,6 +186,10 @@ def drop_near_tie_images(pc, x_u8, rel=3e-6):
             near = (gap > 0) & (gap < rel * top2[..., 0].abs()) & (top2[..., 0] > 0)
             keep &= ~near.flatten(1).any(1).numpy()
             h = F.max_pool2d(pre, 2)
+    dropped = int((~keep).sum())
+    print(f"drop_near_tie_images: {dropped} of {len(x_u8)} images hold a near-tie pooling window and are left out")
+    # a loader / indexing bug that only hits some images must not be able to hide behind this filter
+    assert dropped <= max(1, len(x_u8) // 10), f"{dropped} of {len(x_u8)} images dropped as near ties: more than 10 %"
     return x_u8[keep]
 
 
@@ -646,3 +660,15 @@ def test_virtual_mixes_equal_materialised_mixes(ctx):
     zz = zout.double()
     np.testing.assert_allclose(zpart[:, 0].double().sum().item(), zz.abs().sum().item(), rtol=1e-5)
     np.testing.assert_allclose(zpart[:, 1].double().sum().item(), (zz * zz).sum().item(), rtol=1e-5)
+
+
+def test_zz_relative_error_summary():
+    """Runs last in this module: per-tensor worst PURE relative error (elements >= 1 % of the tensor's maximum) of every rel_close
+    comparison made above -- the number the 1e-3 claim is about, without the absolute term that only protects values near zero."""
+    assert REL_REPORT, "no comparison ran before the summary"
+    worst = sorted(REL_REPORT.items(), key=lambda kv: -kv[1])
+    for what, v in worst[:12]:
+        print(f"worst pure-relative error {v:.2e}  {what}")
+    # tolerance at 1 % of the maximum: 1e-3 + 2e-5 / 1e-2 (parameters after optimiser steps: 1e-4 scale -> 1.1e-2)
+    assert worst[0][1] < 1.2e-2
+    assert sum(v > 3e-3 for _, v in worst) <= max(2, len(worst) // 20), "more than a few tensors are off by over 3e-3 relative"
