@@ -79,6 +79,7 @@ SIGNATURES = {
     "cgs_pointwise_bwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_mix_fwd": (i32, [i32, i32, vp, vp, vp, i32, vp, vp, vp]),
     "cgs_mix_bwd": (i32, [i32, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp]),
+    "cgs_mix_bwd_weighted": (i32, [i32, i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp]),
     "cgs_mix_fwd_partials": (i32, [i32, i32]),
     "cgs_phase2_losses": (i32, [i32, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp, vp, vp]),
     "cgs_phase1_loss": (i32, [i32, vp, vp, i32, vp, vp, vp]),

@@ -52,9 +52,12 @@ __global__ void __launch_bounds__(256) mix_fwd_kernel(int groups, int rep_groups
 
 __global__ void __launch_bounds__(256) mix_bwd_kernel(int groups, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                                                       const float4* __restrict__ z, const float4* __restrict__ dmixed,
-                                                      int inject, float l1s, float l2s, float4* __restrict__ dzpre) {
+                                                      int inject, float l1s, float l2s, float4* __restrict__ dzpre,
+                                                      const float* __restrict__ vf_pred, int groups_per_img) {
     int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= groups) return;
+    // -staticnorm '' (main.py:415-418): the regulariser of A-image i is weighted by valuefak = 1 - pred[i] (L1) and its square (L2)
+    const float vf = vf_pred ? 1.f - vf_pred[g / groups_per_img] : 1.f;
     float av[12], bv[12];
     unpack12(a[3 * g], a[3 * g + 1], a[3 * g + 2], av);
     unpack12(b[3 * g], b[3 * g + 1], b[3 * g + 2], bv);
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) mix_bwd_kernel(int groups, const uint32_t
         for (int c = 0; c < 3; ++c) d = fmaf(bv[3 * p + c] - av[3 * p + c], dr[3 * p + c] - di[3 * p + c], d);
         float zi = zv[p];
         float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
-        d += l1s * sg + 2.f * l2s * zi;
+        d += l1s * vf * sg + 2.f * l2s * vf * vf * zi;
         o[p] = d * zi * (1.f - zi);
     }
     dzpre[g] = make_float4(o[0], o[1], o[2], o[3]);
@@ -278,7 +281,20 @@ extern "C" int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_
     if (groups == 0) return CGS_OK;
     hipLaunchKernelGGL(mix_bwd_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, groups,
                        (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, (const float4*)dmixed, inject, l1_scale,
-                       l2_scale, (float4*)dzpre);
+                       l2_scale, (float4*)dzpre, (const float*)nullptr, hw / 4);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_mix_bwd_weighted(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, const float* dmixed,
+                                    int32_t inject, float l1_scale, float l2_scale, const float* valuefak_pred, float* dzpre,
+                                    cgs_stream_t stream) {
+    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !dmixed || !dzpre) return CGS_ERR_BADARG;
+    int groups = n * (hw / 4);
+    if (groups == 0) return CGS_OK;
+    hipLaunchKernelGGL(mix_bwd_kernel, dim3((groups + 255) / 256), dim3(256), 0, (hipStream_t)stream, groups,
+                       (const uint32_t*)a, (const uint32_t*)b, (const float4*)z, (const float4*)dmixed, inject, l1_scale,
+                       l2_scale, (float4*)dzpre, valuefak_pred, hw / 4);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -30,8 +30,6 @@ class GenericEngine(HourglassEngine):
                  force_allreduce: bool = False):
         if not torch.cuda.is_available():
             raise _lib.CgsError("GenericEngine needs an MI355X (HIP device); there is no CPU fallback")
-        if not staticnorm:
-            raise NotImplementedError("-staticnorm '' (mask regulariser weighted by 1 - pred) is built into the chfak=1 kernels only")
         _lib.load()
         self.n, self.dev = int(n), torch.device(device)
         self.chfak, self.neck = int(chfak), int(neck)
@@ -45,7 +43,7 @@ class GenericEngine(HourglassEngine):
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
         self.lc, self.lm = critic_layout(self.chfak, self.neck), masker_layout(self.chfak, self.neck)
         self.off_c, self.off_m = 0, _align4(self.lc.total)
-        self.separate, self.staticnorm = bool(separate), True
+        self.separate, self.staticnorm = bool(separate), bool(staticnorm)
         self.off_s = _align4(self.off_m + self.lm.total)
         self.total = self.off_s + self.lc.total if self.separate else self.off_m + self.lm.total
         z = lambda *s, dt=torch.float32: torch.zeros(s, device=self.dev, dtype=dt)
@@ -142,7 +140,7 @@ class GenericEngine(HourglassEngine):
         _lib.call("cgs_mix_fwd", n, 4096, _P(A), _P(B), _P(Z), int(self.inject), _P(self.mixed), _P(self.zsum), _S())
         smix = self._view(self.cbuf, 2 * n, 2 * n + nmix)
         self._fwd(self.fc, self.mixed[:nmix], smix, drop.shifted(2 * n))
-        flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0)
+        flags = (1 if self.live else 0) | (2 if self.inject else 0) | (4 if self.bce else 0) | (0 if self.staticnorm else 8)
         _lib.call("cgs_phase2_losses", n, _P(self.cbuf["pred"]), _P(self.y), _P(self.zsum), self.nzpart, self.lfak, self.L1, self.L2,
                   flags, n * 4096, _P(self.losses), _P(self.dpred), _S())
         plan = hg.SlabPlan()
@@ -150,8 +148,9 @@ class GenericEngine(HourglassEngine):
         self._bwd_data(self.fc, smix, self._view(self.gbuf, 2 * n, 2 * n + nmix), self.dpred[2 * n:2 * n + nmix], drop.shifted(2 * n),
                        dx=self.dmixed[:nmix])
         nz = float(n * 4096)
-        _lib.call("cgs_mix_bwd", n, 4096, _P(A), _P(B), _P(Z), _P(self.dmixed), int(self.inject), self.L1 / nz, self.L2 / nz,
-                  _P(self.dzpre), _S())
+        # -staticnorm '' (main.py:415-418): the regulariser of A-image i weighted by 1 - pred[i].detach()
+        _lib.call("cgs_mix_bwd_weighted", n, 4096, _P(A), _P(B), _P(Z), _P(self.dmixed), int(self.inject), self.L1 / nz, self.L2 / nz,
+                  None if self.staticnorm else _P(self.cbuf["pred"][n:2 * n]), _P(self.dzpre), _S())
         d_emb = gen.masker_backward(self.fm, self.lm, self.grad, self.off_m, A, embeds, self.mbuf, self.dzpre, self.chfak, self.neck,
                                     plan, self.ws, need_embed_grads=self.live or self.separate)
         if self.separate:     # the skip gradients go into the SECOND critic; its own head sees no loss

@@ -312,6 +312,11 @@ int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const
 int cgs_mix_bwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z,
                 const float* dmixed, int32_t inject, float l1_scale, float l2_scale,
                 float* dzpre, cgs_stream_t stream);
+/* The same with -staticnorm '' (main.py:415-418): the regulariser terms of A-image i are weighted by valuefak = 1 - valuefak_pred[i]
+ * (L1) and its square (L2); valuefak_pred [n] (the detached critic values of A) may be NULL (= cgs_mix_bwd).  hw = pixels per image. */
+int cgs_mix_bwd_weighted(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, const float* dmixed,
+                         int32_t inject, float l1_scale, float l2_scale, const float* valuefak_pred, float* dzpre,
+                         cgs_stream_t stream);
 
 /* ---- losses (main.py:380-384,400,411,421-429 and main.py:192-195) --------------------
  * pred layout [4n]: slots [B | A | replaced | injected].  y [n].  zpart/nzpart from cgs_mix_fwd.

@@ -231,7 +231,8 @@ phase2("g3_train_valuefak", staticnorm=False, L2=0.1)
 phase2("g3_train_separate", separate=True)
 phase2("g3_train_separate_frozen", separate=True, live=False)
 phase2("g7_dropout", steps=1, dropout=0.3, record_masks=True)
-phase2("g3_train_chfak2", steps=2, chfak=2)      # a model size the specialised kernels do not cover (generic kernels' training pass)
+phase2("g3_train_chfak2", steps=2, chfak=2)
+phase2("g3_train_chfak2_valuefak", steps=2, chfak=2, staticnorm=False, L2=0.1)   # -staticnorm '' on the generic kernels      # a model size the specialised kernels do not cover (generic kernels' training pass)
 
 
 # ---------------------------------------------------------------- G4: phase-1 step

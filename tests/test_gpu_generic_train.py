@@ -150,11 +150,13 @@ def make_generic_engine(chfak, n, neck=32, seeds=(21, 22), **kw):
     return e, pc, pm
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_generic_phase2_matches_reference_capture_chfak2(golden, use_graph):
-    g = golden("g3_train_chfak2.npz")
+@pytest.mark.parametrize("use_graph,fixture,kw", [(False, "g3_train_chfak2.npz", {}), (True, "g3_train_chfak2.npz", {}),
+                                                  # -staticnorm '' (main.py:415-418) on the generic kernels: regulariser weighted by 1 - pred
+                                                  (True, "g3_train_chfak2_valuefak.npz", dict(staticnorm=False, L2=0.1))])
+def test_generic_phase2_matches_reference_capture_chfak2(golden, use_graph, fixture, kw):
+    g = golden(fixture)
     dev = torch.device("cuda:0")
-    e, pc, pm = make_generic_engine(2, 8, dropout=0.0, use_graph=use_graph)
+    e, pc, pm = make_generic_engine(2, 8, dropout=0.0, use_graph=use_graph, **kw)
     A, B, Y = (torch.from_numpy(g[k]).to(dev) for k in ("A", "B", "Y"))
     for s in range(2):
         losses = e.phase2_step(A, B, Y).cpu().numpy().astype(np.float64)
