@@ -65,6 +65,9 @@ def parse():
                     help="--gpus 1 only: create a ONE-rank RCCL group and keep the data-parallel launch form (step graph -> all-reduce -> Adam): "
                          "rehearses the N > 1 code path on a 1-GPU box")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
+    ap.add_argument("--config", type=int, default=0,
+                    help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart), eval-mode "
+                         "forward on the bf16 kernels, batch 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--prime-s", type=float, default=0.4,
@@ -280,6 +283,32 @@ def generic_mode(args, dev, rank):
                                    "traffic": None, "flops_per_image": flops}}), flush=True)
 
 
+def config5_mode(args, dev):
+    """BASELINE config 5 (side line): 128x128x3 frames, batch 256, bf16 storage / fp32 accumulate, the build-defined six-stage variant."""
+    from cgs_amd import hourglass128
+    from oracle import hourglass_ref as orc          # only for the seeded stand-in weights (shape tables + RandomState draw)
+    n = 256 if args.batch == 512 else args.batch
+    net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev)
+    X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    for _ in range(max(args.warmup, 3)):
+        net.infer(X)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.infer(X)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    el, flops = hourglass128.Hourglass128.model_cost()
+    ach = 2.0 * el * n / dt / 1e9          # bf16: 2 bytes per element of the layer-granular traffic model
+    print(json.dumps({"metric": "Hourglass-128 (build-defined) inference images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                      "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
+                      "config": {"workload": "BASELINE config 5: eval-mode critic + mask forward of the six-stage 128x128 variant (no reference "
+                                             "counterpart, parity unpinned), bf16 activations and weights, MFMA GEMM for the 1x1 pointwise layer", "batch": n},
+                      "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                   "algorithmic_elements_per_image": el, "flops_per_image": flops}}), flush=True)
+
+
 def side_mode(args, dev, world, rank):
     """Secondary measurements of the same path (not the headline metric): inference and the phase-1 step."""
     from cgs_amd import engine
@@ -363,6 +392,10 @@ def main():
 
     from cgs_amd import engine
     n = args.batch
+    if args.config == 5:
+        if world > 1:
+            raise SystemExit("--config 5 is a one-GPU side measurement")
+        return config5_mode(args, dev)
     if args.chfak != 1:
         if args.mode not in ("train", "infer") or world > 1:
             raise SystemExit("--chfak != 1: --mode train / infer on one GPU (a secondary measurement; the headline is chfak 1)")

@@ -101,6 +101,9 @@ SIGNATURES = {
     "cgs_gen16_pack_weights": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_gen16_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen16_gemm": (i32, [i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_genbf16_pack_weights": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_genbf16_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_genbf16_gemm": (i32, [i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_fwd": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_data": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -14,11 +14,30 @@
 
 namespace {
 
+// 16-bit element types: IEEE half (config 4) and bfloat16 (config 5: the build-defined 128x128 variant, hourglass128.py).  Both are
+// stored as raw 16-bit words; E16<BF> converts and picks the MFMA (v_mfma_f32_16x16x16_f16 / v_mfma_f32_16x16x16_bf16: K = 16 keeps the
+// 16-channel chunk of this family -- gfx950's K = 32 bf16 form would be half padding at the 8- and 16-channel layers of chfak 1).
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half_t;
+typedef short short4_t __attribute__((ext_vector_type(4)));
+template <bool BF> struct E16;
+template <> struct E16<false> {
+    using T = half_t; using V4 = half4_t;
+    __device__ static __forceinline__ T cvt(float f) { return (half_t)f; }
+    __device__ static __forceinline__ float up(T v) { return (float)v; }
+    __device__ static __forceinline__ V4 zero() { return V4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}; }
+    __device__ static __forceinline__ frag4 mfma(V4 a, V4 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <> struct E16<true> {
+    using T = __bf16; using V4 = short4_t;
+    __device__ static __forceinline__ T cvt(float f) { return (__bf16)f; }          // v_cvt_pk_bf16_f32: round to nearest even
+    __device__ static __forceinline__ float up(T v) { return (float)v; }
+    __device__ static __forceinline__ V4 zero() { return V4{0, 0, 0, 0}; }
+    __device__ static __forceinline__ frag4 mfma(V4 a, V4 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
 
 struct Gen16ConvParams {
-    const void* a; const half_t* b; const half_t* w16; const float* bias;
+    const void* a; const void* b; const void* w16; const float* bias;
     void* out;                 // fp16 NHWC (out_f32 = 0) or fp32
     int a_u8, ca, cb, ups, n, hw, co, act, pool, th, out_f32;
     float slope;
@@ -30,22 +49,26 @@ unsigned long long* g_gen16_stamps = nullptr;
 
 __device__ __forceinline__ int g16_pa4(const Gen16ConvParams& P) { return (P.ca + 3) & ~3; }
 
-__global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __restrict__ w, int ca, int cb, int co, half_t* __restrict__ out) {
+template <bool BF>
+__global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __restrict__ w, int ca, int cb, int co, typename E16<BF>::T* __restrict__ out) {
     const int pa4 = (ca + 3) & ~3, cp = pa4 + cb, nchunk = (cp + 15) / 16, ncol = (co + 15) / 16 * 16, ci_total = ca + cb;
     const int total = 9 * nchunk * 4 * ncol * 4;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int j = e & 3, col = (e >> 2) % ncol, q = ((e >> 2) / ncol) & 3, ch = ((e >> 2) / (ncol * 4)) % nchunk, tap = (e >> 2) / (ncol * 4 * nchunk);
         const int k = ch * 16 + 4 * q + j;
         const int ci = k < pa4 ? (k < ca ? k : -1) : (k < cp ? ca + (k - pa4) : -1);
-        out[e] = (half_t)((ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
+        out[e] = E16<BF>::cvt((ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
     }
 }
 
 constexpr int G16_MAX_TPW = 4;
 
 // grid: ((image * strips + strip) * column-block groups + group); 256 threads; NCB blocks of 16 output channels per workgroup
-template <int NCB, bool A_U8, bool HASB>
+template <int NCB, bool A_U8, bool HASB, bool BF>
 __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
+    using EL = E16<BF>;
+    using half_t = typename EL::T;          // (the names below say "half": either 16-bit type)
+    using half4_t = typename EL::V4;
     extern __shared__ __attribute__((aligned(16))) float4 gsm[];
     half_t* tile = (half_t*)gsm;                    // [(th + 2)][(hw + 2)][4 quads (swizzled)][4 halves]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
@@ -71,11 +94,11 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
         apix[i] = y * PW + x;
         apar[i] = y & 1;
     }
-    const half_t* wl = P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 4;      // + ((tap * nchunk + ch) * 4) * ncol * 4
+    const half_t* wl = (const half_t*)P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 4;      // + ((tap * nchunk + ch) * 4) * ncol * 4
 
     for (int e = tid; e < (TH + 2) * 2 * 4; e += 256) {      // the two halo columns: zero for every chunk, written once
         const int g = e & 3, side = (e >> 2) & 1, r = e >> 3;
-        *(half4_t*)(tile + ((size_t)(r * PW + (side ? W + 1 : 0)) * 4 + g) * 4) = half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+        *(half4_t*)(tile + ((size_t)(r * PW + (side ? W + 1 : 0)) * 4 + g) * 4) = EL::zero();
     }
     for (int ch = 0; ch < nchunk; ++ch) {
         // ---- stage 16 channels of the strip (halo included) as halves: one 8-byte quad per (pixel, quad) ----
@@ -86,34 +109,39 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
         // ONE (column, quad) for all rows; only the interior columns are written (the halo columns were zeroed once above).
         {
             const int rows = TH + 2, rpi = lw >= 8 ? 1 : (256 >> lw);
-            const int g = tid & 3, x = (tid & ((1 << lw) - 1)) >> 2, rsub = lw >= 8 ? 0 : tid >> lw;
+            const int g = tid & 3, rsub = lw >= 8 ? 0 : tid >> lw;
             const int k0 = ch * 16 + 4 * g;
             const bool kok = k0 < cp, isa = k0 < pa4;
+            // (W = 128, the build-defined config-5 variant: a tile row is 512 (column, quad) elements: two column passes per thread)
+            for (int x = (tid & ((1 << (lw < 8 ? lw : 8)) - 1)) >> 2; x < W; x += 64) {
             half_t* const dst0 = tile + ((size_t)(1 + x) * 4) * 4;
             for (int rb = 0; rb < rows; rb += rpi) {
                 const int r = rb + rsub, y = row0 + r - 1;
                 if (r < rows) {
-                    half4_t v = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                    half4_t v = EL::zero();
                     if (kok && y >= 0 && y < H) {
                         if (isa) {
                             const uint32_t pix = (uint32_t)((img * H + y) * W + x);
                             if constexpr (A_U8) {
                                 const uint8_t* s8 = (const uint8_t*)P.a + pix * (uint32_t)P.ca + k0;
                                 const float sc = 1.f / 255.f;
-                                v[0] = (half_t)(s8[0] * sc);
-                                if (k0 + 1 < P.ca) v[1] = (half_t)(s8[1] * sc);
-                                if (k0 + 2 < P.ca) v[2] = (half_t)(s8[2] * sc);
-                                if (k0 + 3 < P.ca) v[3] = (half_t)(s8[3] * sc);
+                                half_t t4[4] = {EL::cvt(s8[0] * sc), EL::cvt(0.f), EL::cvt(0.f), EL::cvt(0.f)};
+                                if (k0 + 1 < P.ca) t4[1] = EL::cvt(s8[1] * sc);
+                                if (k0 + 2 < P.ca) t4[2] = EL::cvt(s8[2] * sc);
+                                if (k0 + 3 < P.ca) t4[3] = EL::cvt(s8[3] * sc);
+                                v = *(const half4_t*)t4;
                             } else {
                                 v = *(const half4_t*)((const half_t*)P.a + (pix * (uint32_t)P.ca + k0));       // (ca % 4 == 0)
                             }
                         } else if constexpr (HASB) {
                             const uint32_t pixb = (uint32_t)((img * HB + (y >> ush)) * WB + (x >> ush));
-                            v = *(const half4_t*)(P.b + (pixb * (uint32_t)P.cb + (k0 - pa4)));
+                            v = *(const half4_t*)((const half_t*)P.b + (pixb * (uint32_t)P.cb + (k0 - pa4)));
                         }
                     }
                     *(half4_t*)(dst0 + ((size_t)r * PW * 4 + (g ^ ((r & 1) << 1))) * 4) = v;
                 }
+            }
+            if (W <= 64) break;
             }
         }
         G16_STAMP(1);
@@ -126,14 +154,14 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
             const half_t* wp = wl + (size_t)((tap * nchunk + ch) * 4) * ncol * 4;
 #pragma unroll
             for (int c = 0; c < NCB; ++c)
-                b[c] = (cg * NCB * 16 + 16 * c + l15 < ncol) ? *(const half4_t*)(wp + 64 * c) : half4_t{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+                b[c] = (cg * NCB * 16 + 16 * c + l15 < ncol) ? *(const half4_t*)(wp + 64 * c) : EL::zero();
 #pragma unroll
             for (int i = 0; i < G16_MAX_TPW; ++i) {
                 if (wave + 4 * i < ntiles) {
                     const int qpos = kq ^ (((apar[i] + ty) & 1) << 1);
                     const half4_t a = *(const half4_t*)(tile + ((size_t)(apix[i] + toff) * 4 + qpos) * 4);
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b[c], acc[i][c], 0, 0, 0);
+                    for (int c = 0; c < NCB; ++c) acc[i][c] = EL::mfma(a, b[c], acc[i][c]);
                 }
             }
         }
@@ -157,14 +185,14 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
 #pragma unroll
                 for (int j = 1; j < 4; ++j) m = fmaxf(m, gen_act(acc[i][c][j] + bias, P.act, P.slope));
                 const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
-                if (P.out_f32) ((float*)P.out)[pp] = m; else ((half_t*)P.out)[pp] = (half_t)m;
+                if (P.out_f32) ((float*)P.out)[pp] = m; else ((half_t*)P.out)[pp] = EL::cvt(m);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
                     const size_t o = (((size_t)img * H + y) * W + x) * P.co + col;
                     const float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
-                    if (P.out_f32) ((float*)P.out)[o] = v; else ((half_t*)P.out)[o] = (half_t)v;
+                    if (P.out_f32) ((float*)P.out)[o] = v; else ((half_t*)P.out)[o] = EL::cvt(v);
                 }
             }
         }
@@ -179,7 +207,10 @@ struct Gen16GemmParams {
 };
 
 // out[m][n] = act(sum_k x[m][k] w[k][n] + bias[n]); one wave per 16 x 16 tile, fp32 MFMA on converted rows (tiny layers)
+template <bool BF>
 __global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
+    using EL = E16<BF>;
+    using half_t = typename EL::T;
     const int lane = threadIdx.x, l15 = lane & 15, kq = lane >> 4;
     const int ntn = (P.n + 15) / 16;
     const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
@@ -193,7 +224,7 @@ __global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int k = k0 + 4 * u + kq, kc = k < P.k ? k : P.k - 1;
-            a[u] = P.x_f16 ? (float)((const half_t*)P.x)[xoff + kc] : ((const float*)P.x)[xoff + kc];
+            a[u] = P.x_f16 ? EL::up(((const half_t*)P.x)[xoff + kc]) : ((const float*)P.x)[xoff + kc];
             b[u] = wc[(size_t)kc * P.n];
             a[u] = (rok && k < P.k) ? a[u] : 0.f;
             b[u] = (cok && k < P.k) ? b[u] : 0.f;
@@ -208,7 +239,7 @@ __global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
             const int r = m0 + 4 * kq + j;
             if (r < P.m) {
                 const float v = gen_act(acc[j] + bias, P.act, P.slope);
-                if (P.out_f16) ((half_t*)P.out)[(size_t)r * P.n + col] = (half_t)v; else ((float*)P.out)[(size_t)r * P.n + col] = v;
+                if (P.out_f16) ((half_t*)P.out)[(size_t)r * P.n + col] = EL::cvt(v); else ((float*)P.out)[(size_t)r * P.n + col] = v;
             }
         }
     }
@@ -224,45 +255,74 @@ extern "C" int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_
     return (int64_t)9 * ((cp + 15) / 16) * 4 * ((co + 15) / 16 * 16) * 4;
 }
 
-extern "C" int cgs_gen16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
+static int gen16_pack(bool bf, int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !w16) return CGS_ERR_BADARG;
     const int64_t total = cgs_gen16_packed_weight_halves(ca, cb, co);
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(gen16_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ca, cb, co, (half_t*)w16);
+    if (bf) hipLaunchKernelGGL(gen16_pack_weights_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ca, cb, co, (__bf16*)w16);
+    else hipLaunchKernelGGL(gen16_pack_weights_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ca, cb, co, (half_t*)w16);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
+extern "C" int cgs_gen16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
+    return gen16_pack(false, ca, cb, co, w, w16, stream);
+}
+extern "C" int cgs_genbf16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
+    return gen16_pack(true, ca, cb, co, w, w16, stream);
+}
 
-extern "C" int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
-                                     int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
-                                     const void* w16, const float* bias, void* out, cgs_stream_t stream) {
+template <bool BF>
+static int gen16_conv(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups, int32_t act, float slope,
+                      int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16, const float* bias, void* out,
+                      cgs_stream_t stream) {
     if (n < 0 || !src_a || !w16 || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
-    if (!a_is_u8 && (ca & 3)) return CGS_ERR_BADARG;                  // fp16 sources are read 4 channels at a time
+    if (!a_is_u8 && (ca & 3)) return CGS_ERR_BADARG;                  // 16-bit sources are read 4 channels at a time
     if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
-    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
+    if (!(gen_hw_ok(hw) || hw == 128)) return CGS_ERR_UNSUPPORTED;    // 128: the build-defined config-5 variant
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    Gen16ConvParams P{src_a, (const half_t*)src_b, (const half_t*)w16, bias, out, a_is_u8, ca, cb, cb > 0 ? ups : 1, n, hw, co, act, pool,
+    Gen16ConvParams P{src_a, src_b, w16, bias, out, a_is_u8, ca, cb, cb > 0 ? ups : 1, n, hw, co, act, pool,
                       gen_strip_rows(hw), out_is_f32, slope, g_gen16_stamps};
     const int ncb = (co + 15) / 16, strips = hw / P.th;
     const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
-    const size_t lds = (size_t)(P.th + 2) * (hw + 2) * 16 * sizeof(half_t);
+    const size_t lds = (size_t)(P.th + 2) * (hw + 2) * 16 * 2;
     const dim3 grid(n * strips * ((ncb + per - 1) / per));
-#define G16K(NCB_) (a_is_u8 ? (cb > 0 ? gen16_conv3x3_kernel<NCB_, true, true> : gen16_conv3x3_kernel<NCB_, true, false>) \
-                            : (cb > 0 ? gen16_conv3x3_kernel<NCB_, false, true> : gen16_conv3x3_kernel<NCB_, false, false>))
+#define G16K(NCB_) (a_is_u8 ? (cb > 0 ? gen16_conv3x3_kernel<NCB_, true, true, BF> : gen16_conv3x3_kernel<NCB_, true, false, BF>) \
+                            : (cb > 0 ? gen16_conv3x3_kernel<NCB_, false, true, BF> : gen16_conv3x3_kernel<NCB_, false, false, BF>))
     auto k = per == 1 ? G16K(1) : (per == 2 ? G16K(2) : G16K(3));
 #undef G16K
     hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
+extern "C" int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                     int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
+                                     const void* w16, const float* bias, void* out, cgs_stream_t stream) {
+    if (hw == 128) return CGS_ERR_UNSUPPORTED;          // fp16 = the reference's 64x64 model (config 4)
+    return gen16_conv<false>(n, hw, ca, cb, co, a_is_u8, ups, act, slope, pool, out_is_f32, src_a, src_b, w16, bias, out, stream);
+}
+extern "C" int cgs_genbf16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                       int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
+                                       const void* w16, const float* bias, void* out, cgs_stream_t stream) {
+    return gen16_conv<true>(n, hw, ca, cb, co, a_is_u8, ups, act, slope, pool, out_is_f32, src_a, src_b, w16, bias, out, stream);
+}
 
-extern "C" int cgs_gen16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_f16, int32_t out_is_f16,
-                              const void* x, const float* w, const float* bias, void* out, cgs_stream_t stream) {
+static int gen16_gemm(bool bf, int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_16, int32_t out_is_16, const void* x,
+                      const float* w, const float* bias, void* out, cgs_stream_t stream) {
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (m == 0) return CGS_OK;
-    Gen16GemmParams P{x, w, bias, out, m, k, n, act, x_is_f16, out_is_f16, slope};
-    hipLaunchKernelGGL(gen16_gemm_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(64), 0, (hipStream_t)stream, P);
+    Gen16GemmParams P{x, w, bias, out, m, k, n, act, x_is_16, out_is_16, slope};
+    const dim3 grid(((m + 15) / 16) * ((n + 15) / 16));
+    if (bf) hipLaunchKernelGGL(gen16_gemm_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(gen16_gemm_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+extern "C" int cgs_gen16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_f16, int32_t out_is_f16,
+                              const void* x, const float* w, const float* bias, void* out, cgs_stream_t stream) {
+    return gen16_gemm(false, m, k, n, act, slope, x_is_f16, out_is_f16, x, w, bias, out, stream);
+}
+extern "C" int cgs_genbf16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_bf16, int32_t out_is_bf16,
+                                const void* x, const float* w, const float* bias, void* out, cgs_stream_t stream) {
+    return gen16_gemm(true, m, k, n, act, slope, x_is_bf16, out_is_bf16, x, w, bias, out, stream);
 }

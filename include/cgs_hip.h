@@ -404,6 +404,18 @@ int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t
                           const float* bias, void* out, cgs_stream_t stream);
 int cgs_gen16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_f16, int32_t out_is_f16, const void* x,
                    const float* w, const float* bias, void* out, cgs_stream_t stream);
+
+/* ---- bfloat16 form of the same family (BASELINE config 5: "128x128x3 frames ... bf16 with MFMA 1x1 pointwise") -----------------------
+ * The same kernels with bf16 activations / weights (fp32 accumulation on v_mfma_f32_16x16x16_bf16), additionally at map size 128:
+ * the build-defined six-stage 128x128 Hourglass (hourglass128.py; the reference cannot run 128x128 inputs -- nets.py:184,189-190 --
+ * so this variant has no reference counterpart: parity unpinned, checked against the build's own fp32 restatement in oracle/).
+ * Operand layout and packed size as cgs_gen16_* (cgs_gen16_packed_weight_halves 16-bit words).                                       */
+int cgs_genbf16_pack_weights(int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream);
+int cgs_genbf16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups, int32_t act,
+                            float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16,
+                            const float* bias, void* out, cgs_stream_t stream);
+int cgs_genbf16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_bf16, int32_t out_is_bf16, const void* x,
+                     const float* w, const float* bias, void* out, cgs_stream_t stream);
 int cgs_gen_convt4s2_fwd(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, int32_t act, float slope,
                          const float* a, const float* b, const float* w, const float* bias, float* out,
                          cgs_stream_t stream);

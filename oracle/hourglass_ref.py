@@ -408,3 +408,55 @@ def unet_convt_apply(P: Params, X: torch.Tensor, critic: bool = False):
         u = act(F.conv_transpose2d(torch.cat((u, p[i]), dim=1), P[f"dec_model.{i}.weight"], P[f"dec_model.{i}.bias"], stride=2, padding=1))
     y = torch.sigmoid(F.conv_transpose2d(torch.cat((u, p[0]), dim=1), P["dec_model.0.weight"], P["dec_model.0.bias"], stride=2, padding=1))
     return y, u
+
+
+# ------------------------------------------------------------------------------------------------
+# BUILD-DEFINED 128x128 variant (BASELINE config 5) -- NOT a restatement of the reference: the reference cannot run 128x128 frames
+# (its 4x4 valid convolution nets.py:184 would see 8x8 and Flatten -> Linear nets.py:189-190 shape-errors).
+# One extra Conv2d(8,8,3)+ReLU+MaxPool stage in front of the encoder and one extra Upsample+cat+Conv2d stage behind the decoder keep
+# every other layer's shape.  PARITY UNPINNED: this fp32 CPU form is only the self-consistency check of the bf16 HIP path
+# (critic-..._amd/hourglass128.py); nothing in the reference pins it.
+# ------------------------------------------------------------------------------------------------
+ENC128_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
+
+
+def critic128_shapes(chfak: int = 1, neck: int = 32):
+    d = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
+    b = neck * chfak
+    out, cin = [], 3
+    for key, cout in zip(ENC128_KEYS, d):
+        out += [(key + ".weight", (cout, cin, 3, 3)), (key + ".bias", (cout,))]
+        cin = cout
+    out += [("features.17.weight", (b, d[4], 4, 4)), ("features.17.bias", (b,)),
+            ("crit.1.weight", (b, b)), ("crit.1.bias", (b,)), ("crit.4.weight", (1, b)), ("crit.4.bias", (1,))]
+    return out
+
+
+def masker128_shapes(chfak: int = 1, neck: int = 32, masker_channels: int = 16):
+    e = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
+    b = neck * chfak
+    return [("dec_model.0.weight", (e[0], e[0] + e[1], 3, 3)), ("dec_model.0.bias", (e[0],)),       # 64x64
+            ("dec_model.1.weight", (e[1], e[1] + e[2], 3, 3)), ("dec_model.1.bias", (e[1],)),       # 32x32
+            ("dec_model.2.weight", (e[2], e[2] + e[3], 3, 3)), ("dec_model.2.bias", (e[2],)),       # 16x16
+            ("dec_model.3.weight", (e[3], e[3] + e[4], 3, 3)), ("dec_model.3.bias", (e[3],)),       # 8x8
+            ("dec_model.4.weight", (e[4], e[4] + b, 3, 3)), ("dec_model.4.bias", (e[4],)),          # 4x4
+            ("dec_model.5.weight", (b, b, 1, 1)), ("dec_model.5.bias", (b,)),                       # 1x1 (the pointwise GEMM)
+            ("masker.0.weight", (masker_channels, 3 + e[0], 3, 3)), ("masker.0.bias", (masker_channels,)),
+            ("masker.2.weight", (1, masker_channels, 3, 3)), ("masker.2.bias", (1,))]
+
+
+def hourglass128_apply(Pc: Params, Pm: Params, X: torch.Tensor):
+    """Eval-mode critic value and mask of the 128x128 variant.  X: NCHW fp32 [n,3,128,128] in [0,1]."""
+    h, emb = X, []
+    for key in ENC128_KEYS:
+        h = F.max_pool2d(F.relu(F.conv2d(h, Pc[key + ".weight"], Pc[key + ".bias"], padding=1)), 2)
+        emb.append(h)
+    e5 = F.relu(F.conv2d(h, Pc["features.17.weight"], Pc["features.17.bias"]))
+    hid = F.relu(F.linear(e5.flatten(1), Pc["crit.1.weight"], Pc["crit.1.bias"]))
+    pred = torch.sigmoid(F.linear(hid, Pc["crit.4.weight"], Pc["crit.4.bias"]))
+    o = F.conv2d(e5, Pm["dec_model.5.weight"], Pm["dec_model.5.bias"])
+    o = F.conv2d(torch.cat((emb[4], _up2(_up2(o))), 1), Pm["dec_model.4.weight"], Pm["dec_model.4.bias"], padding=1)
+    for i in (3, 2, 1, 0):
+        o = F.conv2d(torch.cat((emb[i], _up2(o)), 1), Pm[f"dec_model.{i}.weight"], Pm[f"dec_model.{i}.bias"], padding=1)
+    hm = F.leaky_relu(F.conv2d(torch.cat((X, _up2(o)), 1), Pm["masker.0.weight"], Pm["masker.0.bias"], padding=1), 0.01)
+    return pred, torch.sigmoid(F.conv2d(hm, Pm["masker.2.weight"], Pm["masker.2.bias"], padding=1))

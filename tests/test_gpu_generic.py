@@ -254,3 +254,29 @@ def test_legacy_unet_trains_through_the_module_vs_reference_capture(golden):
     with torch.no_grad():
         y2 = net.eval()(X)
     assert torch.isfinite(y2).all() and not torch.equal(y2, y.detach())
+
+
+@pytest.mark.parametrize("n", [5, 16])
+def test_config5_128x128_bf16_forward_vs_build_restatement(n):
+    """BASELINE config 5: the build-defined six-stage 128x128 Hourglass on the bf16 kernels (hourglass128.py, csrc/gen_f16.hip with
+    bf16 elements) against the build's own fp32 CPU restatement (oracle.hourglass128_apply).  There is no reference counterpart
+    (nets.py:184,189-190 cannot take 128x128): PARITY UNPINNED, a self-consistency check with the bf16 tolerance stated here:
+    |dZ| < 6e-4 max, < 1e-4 mean; |dpred| < 1e-4 -- three times the measured 2.0e-4 / 3.5e-5 / 2.7e-5 (bf16 has 8 significant bits;
+    the masks of these weights lie in [0.43, 0.51])."""
+    from cgs_amd import hourglass128
+    pc = orc.seeded_params(orc.critic128_shapes(), 31)
+    pm = orc.seeded_params(orc.masker128_shapes(), 32)
+    rs = np.random.RandomState(n)
+    x = rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)
+    x[0, 40:90, 20:100] = 180           # a flat patch
+    net = hourglass128.Hourglass128(pc, pm)
+    pred, Z = net.infer(torch.from_numpy(x).cuda())
+    with torch.no_grad():
+        rp, rz = orc.hourglass128_apply(pc, pm, torch.from_numpy(x).permute(0, 3, 1, 2).float() / 255.0)
+    dz = np.abs(Z.cpu().numpy().astype(np.float64) - rz[:, 0].numpy())
+    dp = np.abs(pred.cpu().numpy().astype(np.float64) - rp[:, 0].numpy())
+    print(f"config 5 (128x128, bf16), n={n}: |dZ| max {dz.max():.2e} p99.9 {np.quantile(dz, 0.999):.2e} mean {dz.mean():.2e}; |dpred| max {dp.max():.2e}; "
+          f"Z range [{float(rz.min()):.3f}, {float(rz.max()):.3f}]")
+    assert dz.max() < 6e-4 and dz.mean() < 1e-4
+    assert dp.max() < 1e-4
+    assert Z.shape == (n, 128, 128) and pred.shape == (n,)
