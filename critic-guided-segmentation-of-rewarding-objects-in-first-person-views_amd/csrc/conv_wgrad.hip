@@ -12,6 +12,7 @@
 // skip input and the nearest-upsampled low-res input materialised (zero halo), dY tile [img][TH][W][CO].
 // Lanes (r = lane&15, pixel = lane>>4) then read consecutive floats: bank-conflict free.
 #include "wgrad_sparse.h"
+#include "head_wgrad.h"
 
 // dec_model.0 (16 -> 8 channels at 32x32): outer products on v_mfma_f32_4x4x1 (wgrad_dec0.hip)
 int wgrad_dec0_slabs(int n);
@@ -62,6 +63,37 @@ static int launch_wgrad(WgradParams P, hipStream_t st) {
     }
     const size_t lds = wgrad_lds_bytes<C>();
     hipLaunchKernelGGL((wgrad_any_kernel<C, false>), dim3(wg_blocks<G>(P.n)), dim3(G::THREADS), lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// features.0's weight gradient on the uint8 frames (the A pass) and the critic head's weight gradients in ONE launch: the head GEMM
+// is a latency-bound 8 us launch of < 200 workgroups that only the step's final reduction waits for; as extra workgroups of this
+// launch it disappears behind the sparse gather (round 3: one dependent launch less on the critical path).
+__global__ void __launch_bounds__(256) wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    if ((int)blockIdx.x < nbw) {
+        constexpr int SLAB = (9 * 3 + 1) * 8;
+        wgrad_dispatch<WEnc0U8, true>(P, blockIdx.x, nbw, P.ntiles, P.slab + (size_t)blockIdx.x * SLAB, smem);
+    } else {
+        tail_head_wgrad_body(H, blockIdx.x - nbw);
+    }
+}
+
+extern "C" int cgs_enc0_wgrad_u8_with_head(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                           int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                           int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                           float* slab_head, float* slab_pw, cgs_stream_t stream) {
+    if (n <= 0 || !x_u8 || !dy || !amask || !slab) return CGS_ERR_BADARG;
+    if (n0 < 0 || n1 < 0 || n0 + n1 == 0 || !slab_head || (n0 > 0 && (!hvec0 || !e4_0)) || (n1 > 0 && (!hvec1 || !e4_1))) return CGS_ERR_BADARG;
+    if ((d_o4_0 || d_o4_1) && !slab_pw) return CGS_ERR_BADARG;
+    WgradParams P{};
+    P.src_a = x_u8; P.dy = dy; P.amask = amask; P.slab = slab; P.n = n;
+    P.ntiles = wg_tiles<WEnc0U8::G>(n);
+    HeadWgradParams H{{{hvec0, e4_0, d_o4_0, n0, n_o4_0}, {hvec1, e4_1, d_o4_1, n1, n_o4_1}}, slab_head, slab_pw};
+    const int nbw = wg_blocks_any<WEnc0U8>(n), nbh = (n0 + n1 + kHwIpb - 1) / kHwIpb;
+    const size_t lds = wgrad_any_lds_bytes<WEnc0U8, true>();
+    hipLaunchKernelGGL(wgrad_enc0u8_head_kernel, dim3(nbw + nbh), dim3(256), lds, (hipStream_t)stream, P, H, nbw);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -17,6 +17,7 @@
 // Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
 // masks these kernels draw.
 #include "tail4.h"
+#include "head_wgrad.h"
 
 namespace {
 
@@ -416,7 +417,7 @@ extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const 
 // workgroup: slab10 [1152 | 16], slab6 [576 | 8]); the head's weight gradients -- sums of outer products over the batch -- are
 // left to cgs_tail_head_wgrad below, which reads the per-image vectors this kernel writes to hvec.
 // ------------------------------------------------------------------------------------------------
-static constexpr int kTailHeadSlab = 8192 + 32 + 1024 + 32 + 32 + 1, kTailPwSlab = 1024 + 32, kTailSlab10 = 1168, kTailSlab6 = 584;
+static constexpr int kTailSlab10 = 1168, kTailSlab6 = 584;
 
 struct TailEncBwdParams {
     cgs_tail_enc_weights w;
@@ -672,81 +673,7 @@ extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const 
 // from the vectors tail_enc_bwd left in hvec.  16 images per workgroup; slab_head [8192 | 32 | 1024 | 32 | 32 | 1], slab_pw [1024 | 32].
 // (Inside tail_enc_bwd these sums cost 40 accumulator registers per thread and one 37 KB slab per workgroup and pass.)
 // ------------------------------------------------------------------------------------------------
-struct HeadWgradRange { const float* hvec; const float* e4; const float* d_o4; int n, n_o4; };
-struct HeadWgradParams { HeadWgradRange r[2]; float* slab_head; float* slab_pw; };
-static constexpr int kHwIpb = 8;      // images per workgroup (8: 192 workgroups at 1536 images; 16 left most CUs idle)
-
-__global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) {
-    __shared__ __attribute__((aligned(16))) float xs[kHwIpb][260];      // +4: conflict-free column reads
-    __shared__ __attribute__((aligned(16))) float dz4[kHwIpb][32], dh1[kHwIpb][32], qv[kHwIpb][32], e4s[kHwIpb][36], do4[kHwIpb][32];
-    __shared__ float dz2s[kHwIpb];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int total = P.r[0].n + P.r[1].n, img0 = blockIdx.x * kHwIpb;
-    // ---- this workgroup's images -> LDS (zeros beyond the end) ----
-    for (int e = tid; e < kHwIpb * 96; e += 256) {       // 96 float4 of hvec per image
-        const int il = e / 96, q = e % 96, g = img0 + il;
-        float4 v = f4zero();
-        if (g < total) {
-            const HeadWgradRange& R = g < P.r[0].n ? P.r[0] : P.r[1];
-            const int i = g < P.r[0].n ? g : g - P.r[0].n;
-            if (q < 88 || q == 88) v = ((const float4*)(R.hvec + (size_t)i * 384))[q];
-        }
-        if (q < 64) *(float4*)&xs[il][4 * q] = v;
-        else if (q < 72) *(float4*)&dz4[il][4 * (q - 64)] = v;
-        else if (q < 80) *(float4*)&dh1[il][4 * (q - 72)] = v;
-        else if (q < 88) *(float4*)&qv[il][4 * (q - 80)] = v;
-        else if (q == 88) dz2s[il] = v.x;
-    }
-    for (int e = tid; e < kHwIpb * 16; e += 256) {        // e4 (8 float4) and d_o4 (8 float4) per image
-        const int il = e / 16, q = e % 16, g = img0 + il;
-        float4 v = f4zero();
-        if (g < total) {
-            const HeadWgradRange& R = g < P.r[0].n ? P.r[0] : P.r[1];
-            const int i = g < P.r[0].n ? g : g - P.r[0].n;
-            if (q < 8) v = ((const float4*)(R.e4 + (size_t)i * 32))[q];
-            else if (R.d_o4 && i < R.n_o4) v = ((const float4*)(R.d_o4 + (size_t)i * 32))[q - 8];
-        }
-        if (q < 8) *(float4*)&e4s[il][4 * q] = v; else *(float4*)&do4[il][4 * (q - 8)] = v;
-    }
-    __syncthreads();
-    float* sh = P.slab_head + (size_t)blockIdx.x * kTailHeadSlab;
-    float* sp = P.slab_pw ? P.slab_pw + (size_t)blockIdx.x * kTailPwSlab : nullptr;
-    // ---- 40 output tiles of 16 x 16 over 4 waves: 32 of dW14, 4 of dWl1, 4 of dWpw; K = 16 images = 4 k-steps ----
-    for (int t = wave; t < 40; t += 4) {
-        const bool w14 = t < 32, wl1 = t >= 32 && t < 36;
-        const int tt = w14 ? t : (wl1 ? t - 32 : t - 36);
-        const int mb = tt >> 1, nb = tt & 1;            // row block (k), column block (o)
-        frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s4 = 0; s4 < kHwIpb / 4; ++s4) {
-            const int il = 4 * s4 + kq;
-            const float a = w14 ? xs[il][16 * mb + l15] : e4s[il][16 * mb + l15];
-            const float b = w14 ? dz4[il][16 * nb + l15] : (wl1 ? dh1[il][16 * nb + l15] : do4[il][16 * nb + l15]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
-        }
-        float* dst = w14 ? sh : (wl1 ? sh + 8192 + 32 : sp);
-        if (dst) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dst[(16 * mb + 4 * kq + j) * 32 + 16 * nb + l15] = acc[j];
-        }
-    }
-    // ---- bias-like sums ----
-    if (tid < 32) {
-        float s4 = 0.f, s1 = 0.f, sq = 0.f, so = 0.f;
-#pragma unroll
-        for (int il = 0; il < kHwIpb; ++il) { s4 += dz4[il][tid]; s1 += dh1[il][tid]; sq += qv[il][tid]; so += do4[il][tid]; }
-        sh[8192 + tid] = s4;
-        sh[8192 + 32 + 1024 + tid] = s1;
-        sh[8192 + 32 + 1024 + 32 + tid] = sq;
-        if (sp) sp[1024 + tid] = so;
-        if (tid == 0) {
-            float sz = 0.f;
-#pragma unroll
-            for (int il = 0; il < kHwIpb; ++il) sz += dz2s[il];
-            sh[8192 + 32 + 1024 + 32 + 32] = sz;
-        }
-    }
-}
+__global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) { tail_head_wgrad_body(P, blockIdx.x); }
 
 extern "C" int cgs_tail_head_wgrad_slabs(int32_t n_total) { return n_total < 0 ? CGS_ERR_BADARG : (n_total + kHwIpb - 1) / kHwIpb; }
 

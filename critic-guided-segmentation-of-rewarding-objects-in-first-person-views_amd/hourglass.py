@@ -248,7 +248,11 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
 def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor]):
     """Weight gradients of the critic head (+ the decoder's 1x1 conv) for the image ranges the tail backward kernel(s) left
     behind: ranges = [(hvec, e4, d_o4 or None, n, n_o4, pw_bwd or None)], at most two; one small GEMM over the images."""
+    enc0 = next((r["enc0"] for r in ranges if isinstance(r, dict)), None)     # a deferred features.0 weight gradient (uint8 frames)
+    ranges = [r for r in ranges if not isinstance(r, dict)]
     if not ranges:
+        if enc0 is not None:
+            raise _lib.CgsError("head_wgrad: a deferred features.0 weight gradient needs a head range to ride with")
         return
     assert len(ranges) <= 2
     lib = _lib.load()
@@ -264,8 +268,13 @@ def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor
     sl, slpw = ws[key], (ws[key + "_pw"] if pwb is not None else None)
     r0 = ranges[0]
     r1 = ranges[1] if len(ranges) > 1 else (None, None, None, 0, 0, None)
-    _lib.call("cgs_tail_head_wgrad", r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4],
-              _p(sl), _p(slpw), _stream())
+    if enc0 is not None:
+        n_e, x_e, dy_e, am_e, slab_e = enc0
+        _lib.call("cgs_enc0_wgrad_u8_with_head", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4],
+                  r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw), _stream())
+    else:
+        _lib.call("cgs_tail_head_wgrad", r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4],
+                  _p(sl), _p(slpw), _stream())
     plan.add(sl, nsl, HEAD_SLAB, lay.off("features.14.weight"))
     if pwb is not None:
         pwb[2].add(slpw, nsl, PW_SLAB, pwb[3])
@@ -384,8 +393,12 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         if need_wgrad:
             slab = buf(f"slab_enc{i}", (nsl, cnt))
-            with side.fork():
-                _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
+            if i == 0 and head_sink is not None and u8:
+                # features.0 on the uint8 frames: launched together with the head's weight gradients (head_wgrad below)
+                head_sink.append({"enc0": (n, src, d_cur, saved["am0"], slab)})
+            else:
+                with side.fork():
+                    _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
             plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
         if i > 0:   # d e{i-1} = conv_bwd * dropout mask + decoder skip gradient (fused epilogue)
             nxt = buf(f"de{i - 1}", (n, hw, hw, ca))

@@ -198,6 +198,12 @@ int cgs_tail_head_wgrad_slabs(int32_t n_total);
 int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
                         const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
                         float* slab_pw, cgs_stream_t stream);
+/* cgs_conv3x3_bwd_weight of features.0 on n uint8 frames (slab: cgs_conv3x3_bwd_weight_slabs rows of [224]) and cgs_tail_head_wgrad
+ * (same arguments) as ONE launch: the head's small GEMM rides along as extra workgroups.                                        */
+int cgs_enc0_wgrad_u8_with_head(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                float* slab_head, float* slab_pw, cgs_stream_t stream);
 int cgs_tail_dec_bwd_slabs(int32_t n);
 int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
