@@ -412,12 +412,14 @@ struct LossArgs {       // phase-2 loss values (see phase2_losses_kernel); n == 
     float* losses;
 };
 
+template <int THREADS>
 __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
+    constexpr int NW = THREADS / 64;
     __shared__ float lred[5][16];
     const int tid = threadIdx.x, n = L.n;
     const bool live = L.flags & 1, inject = L.flags & 2, bce = L.flags & 4;
     float sc = 0.f, sr = 0.f, si = 0.f, z1 = 0.f, z2 = 0.f;
-    for (int i = tid; i < n; i += 1024) {
+    for (int i = tid; i < n; i += THREADS) {
         const float pb = L.pred[i], pa = L.pred[n + i], pr = L.pred[2 * n + i], yi = L.y[i];
         if (live) {
             if (bce) sc += -(yi * fmaxf(logf(pa), -100.f) + (1.f - yi) * fmaxf(logf(1.f - pa), -100.f));
@@ -427,7 +429,7 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
         if (inject) { const float d = L.pred[3 * n + i] - pa; si += d * d; }
     }
     const int per_img = L.nzpart / n;
-    for (int i = tid; i < L.nzpart; i += 1024) {
+    for (int i = tid; i < L.nzpart; i += THREADS) {
         const float vf = (L.flags & 8) ? 1.f - L.pred[n + i / per_img] : 1.f;
         z1 += vf * L.zpart[2 * i]; z2 += vf * vf * L.zpart[2 * i + 1];
     }
@@ -436,7 +438,7 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
     __syncthreads();
     if (tid == 0) {
         float t[5];
-        for (int k = 0; k < 5; ++k) { float a = 0.f; for (int w = 0; w < 16; ++w) a += lred[k][w]; t[k] = a; }
+        for (int k = 0; k < 5; ++k) { float a = 0.f; for (int w = 0; w < NW; ++w) a += lred[k][w]; t[k] = a; }
         const float inv_n = 1.f / (float)n;
         const float c = t[0] * inv_n, r = t[1] * inv_n, i = t[2] * inv_n, n1 = L.l1 * t[3] * L.inv_nz, n2 = L.l2 * t[4] * L.inv_nz;
         L.losses[0] = c; L.losses[1] = r; L.losses[2] = i; L.losses[3] = n1; L.losses[4] = n2;
@@ -445,9 +447,9 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
     }
 }
 
-__global__ void __launch_bounds__(1024) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
-                                                           AdamArgs A, LossArgs L) {
-    constexpr int SL = 32;
+template <int SL>
+__global__ void __launch_bounds__(32 * SL) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
+                                                              AdamArgs A, LossArgs L) {
     __shared__ float red[SL][33];
     __shared__ float bc[2];                  // Adam's bias corrections for t = s + 1 (once per workgroup)
     const bool loss_row = (int)blockIdx.y == njobs;
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(1024) reduce_adam_kernel(const cgs_reduce_job*
     if ((int)blockIdx.x >= row_blocks) return;          // nothing to do: never reads the counter, not part of the ticket
     const uint64_t s_old = *step;
     if (loss_row) {
-        if (L.n > 0) phase2_loss_values(L);
+        if (L.n > 0) phase2_loss_values<32 * SL>(L);
     } else {
         if (threadIdx.x == 0) {
             // 1 - b^t = -expm1(t ln b): no cancellation at small t, and no double-precision pow (its registers halve the
@@ -533,7 +535,10 @@ extern "C" int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_
     if (n > 0 && (!pred || !y || !zpart || !losses || nz <= 0)) return CGS_ERR_BADARG;
     AdamArgs A{param, grad_base, m, v, lr, beta1, beta2, eps, ticket};
     LossArgs L{n, nzpart, flags, pred, y, zpart, lfak, l1, l2, nz > 0 ? 1.f / (float)nz : 0.f, losses};
-    hipLaunchKernelGGL(reduce_adam_kernel, dim3((max_count + 31) / 32, njobs + 1), dim3(1024), 0, (hipStream_t)stream, jobs, njobs,
+    // 16 slab lanes x 32 columns per workgroup: the ~800 working workgroups of a phase-2 step are all resident at once
+    // (1024-thread workgroups needed 1.6 rounds of the chip's 2 x 256 slots)
+    constexpr int SL = 16;
+    hipLaunchKernelGGL(reduce_adam_kernel<SL>, dim3((max_count + 31) / 32, njobs + 1), dim3(32 * SL), 0, (hipStream_t)stream, jobs, njobs,
                        step, A, L);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;

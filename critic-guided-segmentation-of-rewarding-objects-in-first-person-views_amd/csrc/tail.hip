@@ -458,18 +458,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const DropCtx d2_ = drop_ctx(P.drop_e2, P.w.w6), d3_ = drop_ctx(P.drop_e3, P.w.w6), dh_ = drop_ctx(P.drop_h1, P.w.w6);
     const bool has_pw = P.d_o4 != nullptr;
 
-    tile_zero<T16x8>(x1, tid);
-    tile_zero<T8x8>(x2, tid);
-    tile_zero<T16x8>(dy2, tid);
-    tile_zero<T8x16>(dy3, tid);
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
-    for (int e = tid; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
-    for (int e = tid; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
-    // head weights in registers for all images: features.14 row k = tid, crit.1 / dec_model.4 row hk columns 4*part..+3
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
+    // (the once-per-workgroup LDS set-up -- zero halos, convolution weights -- runs inside the first iteration, BEHIND the first
+    //  image's global loads: the set-up then costs no memory latency of its own)
     WgradAccK<T8x8, T8x16, 16> wg10;
     WgradAccK<T16x8, T16x8, 8> wg6;
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     wg10.init(lane);
     wg6.init(lane);
 
@@ -517,6 +509,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
         const float4 wpv = has_pw ? *(const float4*)(P.w.wpw + hk * 32 + 4 * part) : f4zero();
         const float wl2 = P.w.wl2[o];
+        if (img == (int)blockIdx.x) {        // first image of this workgroup (uniform): the set-up, with the loads above in flight
+            const int ts = tid + lz;         // (opaque: the set-up's addresses must not become loop invariants held in registers)
+            tile_zero<T16x8>(x1, ts);
+            tile_zero<T8x8>(x2, ts);
+            tile_zero<T16x8>(dy2, ts);
+            tile_zero<T8x16>(dy3, ts);
+            TAIL_STAMP(12);
+            for (int e = ts; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
+            for (int e = ts; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
+            __syncthreads();                 // the zeroes land before any thread's tile commit below
+            TAIL_STAMP(13);
+        }
         // Dropout multipliers while the loads are in flight
         __builtin_amdgcn_sched_barrier(0);        // (one Philox at a time: interleaved they spill)
         float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -728,10 +732,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15;
 
-    tilep_zero<T1Q>(t1, tid); tile_zero<T8x24>(t2, tid); tile_zero<T4x48>(t3, tid);
-    tilep_zero<D1Q>(dy1, tid); tile_zero<T8x8>(dy2, tid); tile_zero<T4x16>(dy3, tid);
-    for (int e = tid; e < 144 * 8 / 4; e += 256) ((float4*)w1s)[e] = ((const float4*)P.w.w1)[e];
-    for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
+    // (the once-per-workgroup LDS set-up -- zero halos, dec_model.1 / .2 weights -- runs inside the first iteration, behind the
+    //  first image's global loads)
     // dec_model.1 on v_mfma_f32_4x4x1 (tail4.h): data gradient with lane = pixel (weights W^T in 20 registers), weight gradient as
     // outer products with the blocks as (tap, channel group) combinations (6 accumulators, pixels split over the waves)
     WgradTapBlk<T1Q, D1Q, 4, 2> wg1;
@@ -741,36 +743,61 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     WgradAcc<T8x24, T8x8, 8, 4> wg2;
     WgradAcc<T4x48, T4x16, 16, 7> wg3;
     wg2.init(wave, lane); wg3.init(wave, lane);
-    __syncthreads();
 
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
         const int lane_i = lane + lz;
-        // ---- layer inputs (skip ++ upsampled) and d o1 -> tiles ----
+        // ---- every global load of this image, back to back (scalars, not arrays: see tail_enc_bwd) ----
+        const float4 le1a = ((const float4*)P.e1)[(size_t)img * 512 + tid], le1b = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256];
+        const float4 ld1a = ((const float4*)P.do1)[(size_t)img * 512 + tid], ld1b = ((const float4*)P.do1)[(size_t)img * 512 + tid + 256];
+        float4 lsk = f4zero(), lup = f4zero(), lo4 = f4zero();
+        if (tid < 128) {
+            lsk = ((const float4*)P.e2)[(size_t)img * 128 + tid];
+            lup = ((const float4*)P.o2)[(size_t)img * 128 + tid];
+            lo4 = ((const float4*)P.o4)[(size_t)img * 8 + (tid & 7)];
+        } else if (tid < 192) {
+            lsk = ((const float4*)P.e3)[(size_t)img * 64 + tid - 128];
+            lup = ((const float4*)P.o3)[(size_t)img * 64 + tid - 128];
+        }
+        if (img == (int)blockIdx.x) {        // first image of this workgroup (uniform): the set-up, with the loads above in flight
+            const int ts = tid + lz;         // (opaque: the set-up's addresses must not become loop invariants held in registers)
+            float4 wv[3];                    // dec_model.1: 288 float4, dec_model.2: 432 float4 -> 720 = 2 full rounds + 208
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(t1 + T1Q::at(y, x) + 4 * p) = ((const float4*)P.e1)[(size_t)img * 512 + e];
-            *(float4*)(dy1 + D1Q::at(y, x) + 4 * p) = ((const float4*)P.do1)[(size_t)img * 512 + e];
+            for (int k = 0; k < 3; ++k) {
+                const int e = ts + 256 * k;
+                wv[k] = e < 288 ? ((const float4*)P.w.w1)[e] : (e < 720 ? ((const float4*)P.w.w2)[e - 288] : f4zero());
+            }
+            tilep_zero<T1Q>(t1, ts); tile_zero<T8x24>(t2, ts); tile_zero<T4x48>(t3, ts);
+            tilep_zero<D1Q>(dy1, ts); tile_zero<T8x8>(dy2, ts); tile_zero<T4x16>(dy3, ts);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = ts + 256 * k;
+                if (e < 720) ((float4*)w1s)[e] = wv[k];          // w1s | w2s are contiguous (L::W2 = L::W1 + 144 * 8)
+            }
+            __syncthreads();                 // the zeroes land before any thread's tile commit below
+        }
+        // ---- layer inputs (skip ++ upsampled) and d o1 -> tiles ----
+        {
+            const int p = tid & 1, x = (tid >> 1) & 15, y = tid >> 5;          // float4 index e = tid and tid + 256 (8 rows further)
+            *(float4*)(t1 + T1Q::at(y, x) + 4 * p) = le1a;
+            *(float4*)(t1 + T1Q::at(y + 8, x) + 4 * p) = le1b;
+            *(float4*)(dy1 + D1Q::at(y, x) + 4 * p) = ld1a;
+            *(float4*)(dy1 + D1Q::at(y + 8, x) + 4 * p) = ld1b;
         }
         if (tid < 128) {
             const int p = tid & 1, x = (tid >> 1) & 7, y = tid >> 4;
-            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = ((const float4*)P.e2)[(size_t)img * 128 + tid];
-            const float4 v = ((const float4*)P.o2)[(size_t)img * 128 + tid];            // up(o2) -> channels 8..15 of t1
+            *(float4*)(t2 + T8x24::at(y, x) + 4 * p) = lsk;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) *(float4*)(t1 + T1Q::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
+            for (int d = 0; d < 4; ++d) *(float4*)(t1 + T1Q::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = lup;     // up(o2) -> channels 8..15 of t1
+            const int p4 = tid & 7, pix = tid >> 3;
+            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p4) = lo4;
         } else if (tid < 192) {
             const int e = tid - 128, p = e & 3, x = (e >> 2) & 3, y = e >> 4;
-            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = ((const float4*)P.e3)[(size_t)img * 64 + e];
-            const float4 v = ((const float4*)P.o3)[(size_t)img * 64 + e];               // up(o3) -> channels 8..23 of t2
+            *(float4*)(t3 + T4x48::at(y, x) + 4 * p) = lsk;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) *(float4*)(t2 + T8x24::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = v;
-        }
-        if (tid < 128) {
-            const int p = tid & 7, pix = tid >> 3;
-            *(float4*)(t3 + T4x48::at(pix >> 2, pix & 3) + 16 + 4 * p) = ((const float4*)P.o4)[(size_t)img * 8 + p];
+            for (int d = 0; d < 4; ++d) *(float4*)(t2 + T8x24::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + 4 * p) = lup;   // up(o3) -> channels 8..23 of t2
         }
         __syncthreads();
         TAIL_STAMP(2);
