@@ -6,10 +6,15 @@ mkdir -p $out
 cd $root
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { tail -5 $out/smoke.log; exit 1; }
 python bench.py > $out/bench.json 2> $out/bench.err || exit 1
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_driver_cmd.json 2>/dev/null || exit 1
+python bench.py --force-pg --no-cpu-baseline > $out/bench_force_pg.json 2>/dev/null || exit 1
 python bench.py --chfak 5 --steps 20 --warmup 3 > $out/bench_chfak5_train.json 2>/dev/null || exit 1
 python bench.py --chfak 5 --mode infer --steps 20 --warmup 3 > $out/bench_chfak5_infer.json 2>/dev/null || exit 1
+python bench.py --chfak 5 --mode infer --fp16 --steps 20 --warmup 3 > $out/bench_chfak5_infer_f16.json 2>/dev/null || exit 1
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 > $out/bench_infer2048.json 2>/dev/null || exit 1
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16-mask-head > $out/bench_infer2048_f16head.json 2>/dev/null || exit 1
+python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16 > $out/bench_infer2048_f16all.json 2>/dev/null || exit 1
+python bench.py --config 5 > $out/bench_config5.json 2>/dev/null || exit 1
 python bench.py --mode cli-train > $out/bench_cli_train.json 2>/dev/null || exit 1
 python bench.py --mode phase1 > $out/bench_phase1.json 2>/dev/null || exit 1
 tools/prof.sh final/prof || exit 1
