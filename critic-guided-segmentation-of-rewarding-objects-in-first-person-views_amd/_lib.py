@@ -87,6 +87,8 @@ SIGNATURES = {
     "cgs_adam_flat": (i32, [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, vp]),
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
+    "cgs_gen_conv_packed_floats": (i64, [i32, i32, i32]),
+    "cgs_gen_conv_pack_weights": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "cgs_gen_flip_weights": (i32, [i32, i32, vp, vp, vp]),

@@ -14,149 +14,6 @@
 
 namespace {
 
-struct GenConvParams {
-    GenSrc src; const float* w; const float* bias;      // bias may be NULL (data gradient)
-    float* out; uint8_t* argmax;
-    const float* addend; int n_addend;                  // pool = 0: out += addend for images < n_addend (same shape as out)
-    int n, hw, co, act, pool, th;
-    float slope;
-};
-
-constexpr int GEN_MAX_TPW = 4;        // pixel tiles (16 pixels) per wave: strips hold <= 256 pixels
-
-// grid: ((image * strips + strip) * column-block groups + group); 256 threads.  A workgroup computes NCB (<= 3) blocks of 16 output
-// channels from one staged input tile: an A operand read from LDS feeds NCB MFMAs, a weight operand the wave's pixel tiles.
-template <int NCB, bool WLDS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) gen_conv3x3_fwd_kernel(GenConvParams P) {
-    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
-    float* tile = (float*)gsm;                      // [(th + 2)][(hw + 2)][GEN_KC]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-    const int H = P.hw, W = P.hw, TH = P.th, PW = W + 2;
-    const int strips = H / TH, ncg = ((P.co + 15) / 16 + NCB - 1) / NCB;
-    const int cg = blockIdx.x % ncg, strip = (blockIdx.x / ncg) % strips, img = blockIdx.x / (ncg * strips);
-    const int row0 = strip * TH;
-    const GenSrc& S = P.src;
-    const int cp = gen_pa4(S) + S.cb, ci_total = S.ca + S.cb;
-    const int nchunk = (cp + GEN_KC - 1) / GEN_KC;
-    const int col0 = cg * NCB * 16 + l15;           // this lane's column in the group's first block (+16 per block)
-    const int ntiles = TH * W / 16, QW = W / 2;
-
-    frag4 acc[GEN_MAX_TPW][NCB];
-    int abase[GEN_MAX_TPW];
-#pragma unroll
-    for (int i = 0; i < GEN_MAX_TPW; ++i) {
-#pragma unroll
-        for (int c = 0; c < NCB; ++c) acc[i][c] = frag4{0.f, 0.f, 0.f, 0.f};
-        const int t = wave + 4 * i;
-        const int q = 4 * t + (l15 >> 2), qy = q / QW, qx = q % QW;
-        const int y = 2 * qy + ((l15 >> 1) & 1), x = 2 * qx + (l15 & 1);     // strip-local
-        abase[i] = (y * PW + x) * GEN_KC + kq;
-    }
-
-    constexpr int NC = NCB == 2 ? 48 : 16 * NCB;                 // row stride of the weight tile (48: the 4 k-rows of a read hit 64 banks)
-    float* wl = tile + (TH + 2) * PW * GEN_KC;                   // [9 taps][16 channels][NC]
-    gen_zero_halo_cols(tile, W, TH, 1, tid);                      // (the staging writes the interior columns only)
-    for (int ch = 0; ch < nchunk; ++ch) {
-        int ltid = tid;                                           // opaque per chunk: keeps the staging addresses of all
-        asm volatile("" : "+v"(ltid));                            // iterations from being hoisted out of this loop (registers)
-        gen_stage<2>(tile, S, img, H, W, row0, TH, 1, ch, ltid);     // 16 channels of the strip (with halo)
-        if constexpr (WLDS) {
-        // the chunk's weights: [tap][channel][NCB x 16 columns], zero for padding channels / columns (9 loads in flight at a time)
-#pragma unroll 1
-        for (int bt = 0; bt < NCB; ++bt) {
-            float wv[9];
-#pragma unroll
-            for (int it = 0; it < 9; ++it) {
-                const int e = ltid + 256 * (9 * bt + it), c = e % (16 * NCB), k = (e / (16 * NCB)) & 15, tap = e / (256 * NCB);
-                const int ci = gen_real_channel(S, ch * GEN_KC + k), col = cg * NCB * 16 + c;
-                wv[it] = (ci >= 0 && col < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col] : 0.f;
-            }
-#pragma unroll
-            for (int it = 0; it < 9; ++it) {
-                const int e = ltid + 256 * (9 * bt + it), c = e % (16 * NCB), k = (e / (16 * NCB)) & 15, tap = e / (256 * NCB);
-                wl[(tap * 16 + k) * NC + c] = wv[it];
-            }
-        }
-        }
-        __syncthreads();
-        const int rem = cp - ch * GEN_KC, ksteps = rem >= GEN_KC ? 4 : (rem + 3) >> 2;      // (a partial last chunk: fewer k-steps)
-        // ---- 9 taps x k-steps: operands from LDS only; a weight operand is shared by the wave's pixel tiles ----
-        // (the weight operand of a k-step comes from L1/L2: it is requested ONE k-step ahead, so its round trip overlaps the
-        //  previous step's MFMAs instead of standing in front of its own -- 36 serial round trips per chunk otherwise)
-        auto load_b = [&](float (&bv)[NCB], int tap, int s) {
-            if constexpr (WLDS) {
-#pragma unroll
-                for (int c = 0; c < NCB; ++c) bv[c] = wl[(tap * 16 + 4 * s + kq) * NC + 16 * c + l15];
-            } else {
-                const int ci = gen_real_channel(S, ch * GEN_KC + 4 * s + kq);
-#pragma unroll
-                for (int c = 0; c < NCB; ++c)
-                    bv[c] = (ci >= 0 && col0 + 16 * c < P.co) ? P.w[((size_t)tap * ci_total + ci) * P.co + col0 + 16 * c] : 0.f;
-            }
-        };
-        float bn[NCB];
-        load_b(bn, 0, 0);
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = ((tap / 3) * PW + tap % 3) * GEN_KC;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                if (s < ksteps) {
-                    float b[NCB];
-#pragma unroll
-                    for (int c = 0; c < NCB; ++c) b[c] = bn[c];
-                    if (s + 1 < ksteps) load_b(bn, tap, s + 1);
-                    else if (tap < 8) load_b(bn, tap + 1, 0);
-#pragma unroll
-                    for (int i = 0; i < GEN_MAX_TPW; ++i) {
-                        if (wave + 4 * i < ntiles) {
-                            const float a = tile[abase[i] + toff + 4 * s];
-#pragma unroll
-                            for (int c = 0; c < NCB; ++c) acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c], acc[i][c], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- epilogue ----
-#pragma unroll
-    for (int c = 0; c < NCB; ++c) {
-        const int col = col0 + 16 * c;
-        if (col >= P.co) continue;
-        const float bias = P.bias ? P.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < GEN_MAX_TPW; ++i) {
-            const int t = wave + 4 * i;
-            if (t >= ntiles) continue;
-            const int q = 4 * t + kq, qy = q / QW, qx = q % QW;
-            if (P.pool) {
-                float m = gen_act(acc[i][c][0] + bias, P.act, P.slope);
-                int idx = 0;
-#pragma unroll
-                for (int j = 1; j < 4; ++j) {
-                    const float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
-                    if (v > m) { m = v; idx = j; }
-                }
-                const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
-                P.out[pp] = m;
-                // (ReLU: a pooled value <= 0 passes no gradient -- marked in bit 2 for the backward loaders)
-                if (P.argmax) P.argmax[pp] = (uint8_t)(idx | ((P.act == CGS_ACT_RELU && !(m > 0.f)) ? 4 : 0));
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int y = row0 + 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
-                    const size_t o = (((size_t)img * H + y) * W + x) * P.co + col;
-                    float v = gen_act(acc[i][c][j] + bias, P.act, P.slope);
-                    if (P.addend && img < P.n_addend) v += P.addend[o];
-                    P.out[o] = v;
-                }
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // out[m][n] = act(sum_k X[m][k] W[k][n] + bias[n]);  one wave per 16 x 16 output tile (v_mfma_f32_16x16x4_f32)
 // ------------------------------------------------------------------------------------------------
@@ -291,50 +148,53 @@ __global__ void __launch_bounds__(256) gen_convt_bwd_weight_kernel(GenConvTParam
 
 }  // namespace
 
-static int gen_conv_launch(GenConvParams P, cgs_stream_t stream) {
-    P.th = gen_strip_rows(P.hw);
-    const int ncb = (P.co + 15) / 16, strips = P.hw / P.th;
-    // column blocks per workgroup: 3 (2 when that covers the layer exactly); one staged tile then feeds all of them
-    const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
-    constexpr bool wlds = false;      // weights through LDS: measured slower (occupancy 6 -> 4 workgroups per CU), DESIGN.md section 7
-    const size_t lds = ((size_t)(P.th + 2) * (P.hw + 2) * GEN_KC + (wlds ? (size_t)9 * 16 * (per == 2 ? 48 : 16 * per) : 0)) * sizeof(float);
-    const dim3 grid(P.n * strips * ((ncb + per - 1) / per));
-    auto k = wlds ? (per == 1 ? gen_conv3x3_fwd_kernel<1, true> : per == 2 ? gen_conv3x3_fwd_kernel<2, true> : gen_conv3x3_fwd_kernel<3, true>)
-                  : (per == 1 ? gen_conv3x3_fwd_kernel<1, false> : per == 2 ? gen_conv3x3_fwd_kernel<2, false> : gen_conv3x3_fwd_kernel<3, false>);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
+// the 3x3 convolution: lane = pixel on v_mfma_f32_4x4x1 (gen4.hip, round 3)
+struct Gen4Launch {
+    GenSrc src; const float* wp; const float* bias; float* out; uint8_t* argmax; const float* addend;
+    int n_addend, n, hw, co, act, pool;
+    float slope;
+};
+int gen4_conv_launch(const Gen4Launch& L, hipStream_t st);
+long gen4_packed_floats(int ca, int cb, int co);
+int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, hipStream_t st);
+
+extern "C" int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co) {
+    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
+    return gen4_packed_floats(ca, cb, co);
+}
+
+extern "C" int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
+                                         cgs_stream_t stream) {
+    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !wp || (transposed && cb)) return CGS_ERR_BADARG;
+    return gen4_pack_launch(ca, cb, co, transposed ? 1 : 0, w, wp, (hipStream_t)stream);
 }
 
 extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
-                                   int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* w,
+                                   int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                                    const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
-    if (n < 0 || !src_a || !w || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
+    if (n < 0 || !src_a || !wp || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
     if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    GenConvParams P{};
-    P.src = GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1};
-    P.w = w; P.bias = bias; P.out = out; P.argmax = argmax;
-    P.n = n; P.hw = hw; P.co = co; P.act = act; P.pool = pool; P.slope = slope;
-    return gen_conv_launch(P, stream);
+    Gen4Launch L{GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1}, wp, bias, out, argmax,
+                 nullptr, 0, n, hw, co, act, pool, slope};
+    return gen4_conv_launch(L, (hipStream_t)stream);
 }
 
-// Data gradient of a 3x3 layer = the same convolution over the output gradient with the flipped, transposed kernel
-// (cgs_gen_flip_weights): d_cat [n,hw,hw,ci] = conv3x3(dY, wflip [9][co][ci]) (+ addend for images < n_addend).
+// Data gradient of a 3x3 layer = the same convolution over the output gradient with the flipped, transposed kernel:
+// d_cat [n,hw,hw,ci] = conv3x3(dY [co channels], wp) (+ addend for images < n_addend), wp = cgs_gen_conv_pack_weights(co, 0, ci,
+// transposed = 1, the layer's HWIO weights).
 extern "C" int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, const float* dy, const uint8_t* dy_argmax,
-                                        const float* wflip, const float* addend, int32_t n_addend, float* d_cat,
+                                        const float* wp, const float* addend, int32_t n_addend, float* d_cat,
                                         cgs_stream_t stream) {
-    if (n < 0 || !dy || !wflip || !d_cat || co <= 0 || ci <= 0 || n_addend < 0) return CGS_ERR_BADARG;
+    if (n < 0 || !dy || !wp || !d_cat || co <= 0 || ci <= 0 || n_addend < 0) return CGS_ERR_BADARG;
     if (dy_argmax && (co & 3)) return CGS_ERR_BADARG;
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (n == 0) return CGS_OK;
-    GenConvParams P{};
-    P.src = GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1};
-    P.w = wflip; P.out = d_cat; P.addend = addend; P.n_addend = n_addend;
-    P.n = n; P.hw = hw; P.co = ci; P.act = CGS_ACT_NONE;
-    return gen_conv_launch(P, stream);
+    Gen4Launch L{GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1}, wp, nullptr, d_cat, nullptr,
+                 addend, n_addend, n, hw, ci, CGS_ACT_NONE, 0, 0.f};
+    return gen4_conv_launch(L, (hipStream_t)stream);
 }
 
 extern "C" int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,

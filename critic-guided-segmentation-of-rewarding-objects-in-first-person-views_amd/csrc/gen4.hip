@@ -1,0 +1,513 @@
+// Shape-generic 3x3 convolution (forward and data gradient) on v_mfma_f32_4x4x1_16B_f32 with lane = PIXEL (round 3).
+//
+// Replaces the 16x16x4 implicit GEMM of gen.hip (round 2) behind the same C entry points (cgs_gen_conv3x3_fwd,
+// cgs_gen_conv3x3_bwd_data): NewCritic / UnetDecoder at chfak != 1 or neck != 32 (nets.py:161-212, 453-523) and the legacy Unet.
+//
+// The instruction with its A operand broadcast from one block (cbsz = 4, abid = block) computes
+//     D[lane][r] += A[4 * abid + r] * B[lane]                 (64 lanes x 4 results x 1 k-step, 512 FLOP in 8 cycles),
+// so with lane = pixel, B = the pixel's input value of one (tap, channel) step and A = the four weights of one output-channel
+// group the GEMM's granularity is 4 output channels x 1 k-step x 64 pixels: nothing is padded at 40 channels (the 16-wide tiles
+// of the 16x16x4 form run 48 columns for 40), at 3 input channels (27 k-steps, not 36) or at 3 output channels (the data gradient
+// of the image layer: one group of 4, not a 16-wide tile).  A weight REGISTER holds 16 steps (lane 4 * cin + i = channel cin of
+// the staged 16-channel chunk, output channel 4 g + i): one conflict-free ds_read_b32 per (tap, group); one ds_read_b128 of the
+// input tile (channel-planar float4 slots) feeds 4 steps x NG groups = up to 40 instructions.
+//
+// Workgroup = 4 waves = 256 pixels in quad order (lane = 4 * quad + 2 * dy + dx: MaxPool2d(2) is two DPP quad permutes):
+//   hw = 64: 4 rows of one image;  32: 8 rows;  16: one image;  8: four images;  4: sixteen images.
+// Per 16-channel chunk of the input: stage the tile -> barrier -> 9 taps x <= 16 channels x NG groups of MFMAs -> barrier.
+// The weights never pass through LDS: cgs_gen_conv_pack_weights lays them out as register images ([chunk][tap][group][64 lanes],
+// zero for padding channels / columns) and a wave loads the NG registers of the NEXT tap with one coalesced 256-byte load each
+// while the current tap multiplies (the images are L2-resident and shared by every wave of the launch).
+// Output channels beyond 4 * NG (NG <= 10) are further passes = further workgroups over the same tile (blockIdx picks the pass).
+// Epilogue: bias + activation (+ MaxPool2d(2) and the argmax byte), then through LDS so that a workgroup's output -- one
+// contiguous block of NHWC memory -- leaves in full lines (the lane = pixel registers would store 16-byte pieces 4 * co bytes apart).
+#include "gen_common.h"
+#include "tail4.h"
+
+namespace {
+
+struct Gen4Params {
+    GenSrc src; const float* wp; const float* bias;     // wp: packed weights (gen4_pack_kernel); bias may be NULL (data gradient)
+    float* out; uint8_t* argmax;
+    const float* addend; int n_addend;                  // pool = 0: out += addend for images < n_addend (same shape as out)
+    int n, hw, co, act, pool;
+    float slope;
+    int imgs, th, pw, rows, lw, npass, ngt;             // ngt: output-channel groups of 4 of the whole layer
+    int dbuf;                                           // 1: two tile buffers (chunk c + 1 is staged while chunk c multiplies)                  // tile geometry (host): images per tile, rows per image, padded width, imgs * (th + 2)
+    unsigned long long* dbg;                            // debug: per-workgroup phase stamps (tools/gen4_stamps.py), NULL in the product path
+};
+unsigned long long* g_gen4_stamps = nullptr;
+#define G4_STAMP(k) do { if (P.dbg && tid == 0 && blockIdx.x < 4096) P.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+
+// ---- input tile: channel-planar, tile[(plane * rows + row) * pw + col] (float4 = 4 channels of one pixel), col 0 = left halo ----
+// Element e = tid + 256 * round -> (plane g, column x) are the THREAD's for every round (a tile row is W << lp <= 256 elements),
+// only the tile row moves: everything that depends on (g, x) alone is computed once per chunk, a round costs one row clamp and
+// one multiply-add per load.  (The staging runs beside other waves' MFMAs, which own the SIMD's issue slots: its cost is its
+// instruction count.)
+template <int KIND, bool HASB>
+__device__ __forceinline__ void gen4_stage(float4* tile, const GenSrc& S, const Gen4Params& P, int img0, int row0, int ch, int tid) {
+    constexpr int BATCH = 6;        // every load of a chunk in flight together (a tile is <= 6 rounds of 256 elements)
+    const int H = P.hw, W = P.hw, lw = P.lw;
+    const int pa4 = gen_pa4(S), cp = pa4 + S.cb;
+    const int rem = cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
+    const int lp = np == 1 ? 0 : (np == 2 ? 1 : 2);
+    const int rpi = P.th + 2;
+    const int rpr = 256 >> (lp + lw);                          // tile rows per round of 256 threads (>= 1)
+    const int g = tid & ((1 << lp) - 1), x = (tid >> lp) & (W - 1), rsub = tid >> (lp + lw);
+    const int ush = S.ups == 4 ? 2 : (S.ups == 2 ? 1 : 0), HB = H >> ush, WB = W >> ush;
+    const int k0 = ch * GEN_KC + 4 * g;
+    const bool isa = k0 < pa4, kok = k0 < cp;
+    // per-thread source offsets (floats / bytes) of row 0 of image 0
+    const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
+    int kb = k0 - pa4;
+    kb = kb < 0 ? 0 : (kb > S.cb - 4 ? S.cb - 4 : kb);
+    const uint32_t offa = (uint32_t)x * (uint32_t)S.ca, offb = (uint32_t)(x >> ush) * (uint32_t)S.cb + kb;
+    const uint32_t offp = (uint32_t)(x >> 1) * (uint32_t)S.ca + ka;                       // POOLEXP: pooled map
+    const uint32_t rsa = (uint32_t)W * (uint32_t)S.ca, rsb = (uint32_t)WB * (uint32_t)S.cb, rsp = (uint32_t)(W >> 1) * (uint32_t)S.ca;
+    const int c0 = k0 < S.ca ? k0 : S.ca - 1, c1 = k0 + 1 < S.ca ? k0 + 1 : S.ca - 1, c2 = k0 + 2 < S.ca ? k0 + 2 : S.ca - 1,
+              c3 = k0 + 3 < S.ca ? k0 + 3 : S.ca - 1;
+    float4* const dst0 = tile + g * (P.rows * P.pw) + x + 1;
+#pragma unroll 1
+    for (int rb = rsub; rb < P.rows; rb += rpr * BATCH) {
+        float4 raw[BATCH];
+        [[maybe_unused]] float4 rawb[HASB && KIND != GEN_K_F32V4 ? BATCH : 1];
+        [[maybe_unused]] uint32_t am[KIND == GEN_K_POOLEXP ? BATCH : 1];
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            int r = rb + it * rpr;
+            r = r < P.rows ? r : P.rows - 1;
+            const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
+            const int y = row0 + rr - 1, yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            int img = img0 + il;
+            img = img < P.n ? img : P.n - 1;
+            const float* pb = nullptr;
+            if constexpr (HASB) pb = S.b + ((uint32_t)(img * HB + (yc >> ush)) * rsb + offb);
+            if constexpr (KIND == GEN_K_F32V4) {
+                const float* pa = (const float*)S.a + ((uint32_t)(img * H + yc) * rsa + offa + ka);
+                if constexpr (HASB) pa = isa ? pa : pb;
+                raw[it] = *(const float4*)pa;
+            } else if constexpr (KIND == GEN_K_POOLEXP) {
+                const uint32_t pp = (uint32_t)(img * (H >> 1) + (yc >> 1)) * rsp + offp;
+                raw[it] = *(const float4*)((const float*)S.a + pp);
+                am[it] = *(const uint32_t*)(S.am + pp);
+            } else {
+                const uint32_t po = (uint32_t)(img * H + yc) * rsa + offa;
+                if constexpr (KIND == GEN_K_U8) {
+                    const uint8_t* sp = (const uint8_t*)S.a + po;
+                    raw[it] = make_float4((float)sp[c0], (float)sp[c1], (float)sp[c2], (float)sp[c3]);
+                } else {
+                    const float* sp = (const float*)S.a + po;
+                    raw[it] = make_float4(sp[c0], sp[c1], sp[c2], sp[c3]);
+                }
+                if constexpr (HASB) rawb[it] = *(const float4*)pb;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            const int r = rb + it * rpr;
+            if (r < P.rows) {
+                const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
+                const int y = row0 + rr - 1;
+                const bool inb = kok && y >= 0 && y < H && img0 + il < P.n;
+                float4 v = raw[it];
+                if constexpr (KIND == GEN_K_POOLEXP) {
+                    const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
+                    v.x = (am[it] & 255u) == pos ? v.x : 0.f;
+                    v.y = ((am[it] >> 8) & 255u) == pos ? v.y : 0.f;
+                    v.z = ((am[it] >> 16) & 255u) == pos ? v.z : 0.f;
+                    v.w = (am[it] >> 24) == pos ? v.w : 0.f;
+                } else if constexpr (KIND == GEN_K_F32S || KIND == GEN_K_U8) {
+                    const float sc = KIND == GEN_K_U8 ? 1.f / 255.f : 1.f;
+                    v.x = k0 < S.ca ? v.x * sc : 0.f;
+                    v.y = k0 + 1 < S.ca ? v.y * sc : 0.f;
+                    v.z = k0 + 2 < S.ca ? v.z * sc : 0.f;
+                    v.w = k0 + 3 < S.ca ? v.w * sc : 0.f;
+                    if constexpr (HASB) {
+                        const float4 rb4 = rawb[it];
+                        v.x = isa ? v.x : rb4.x; v.y = isa ? v.y : rb4.y; v.z = isa ? v.z : rb4.z; v.w = isa ? v.w : rb4.w;
+                    }
+                }
+                dst0[r * P.pw] = inb ? v : f4zero();
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void gen4_stage_any(float4* tile, const GenSrc& S, const Gen4Params& P, int img0, int row0, int ch, int tid) {
+    if (S.mode == GEN_SRC_POOLEXP) return gen4_stage<GEN_K_POOLEXP, false>(tile, S, P, img0, row0, ch, tid);
+    if (S.cb > 0) {
+        if (S.mode == GEN_SRC_U8) return gen4_stage<GEN_K_U8, true>(tile, S, P, img0, row0, ch, tid);
+        if (S.ca & 3) return gen4_stage<GEN_K_F32S, true>(tile, S, P, img0, row0, ch, tid);
+        return gen4_stage<GEN_K_F32V4, true>(tile, S, P, img0, row0, ch, tid);
+    }
+    if (S.mode == GEN_SRC_U8) return gen4_stage<GEN_K_U8, false>(tile, S, P, img0, row0, ch, tid);
+    if (S.ca & 3) return gen4_stage<GEN_K_F32S, false>(tile, S, P, img0, row0, ch, tid);
+    return gen4_stage<GEN_K_F32V4, false>(tile, S, P, img0, row0, ch, tid);
+}
+
+// ---- weights as register images: wp[((chunk * 9 + tap) * ngp + g) * 64 + 4 * cin + i] = w[tap][channel cin of the chunk][4 g + i],
+// ngp = passes x groups per pass (gen4_groups), zero for the groups past the layer's last ----
+// transposed = 0: w = HWIO [9][ca + cb][co] (forward).  transposed = 1 (cb = 0): w = HWIO [9][co][ca] of the LAYER whose data
+// gradient this is (ca = its output channels = dY's, co = its input channels), read with the taps reversed.
+struct Gen4PackParams { const float* w; float* wp; int ca, cb, co, transposed, total, ngp; };
+__global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
+    const int pa4 = (P.ca + 3) & ~3, ngt = P.ngp, ci_total = P.ca + P.cb;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) {
+        const int lane = e & 63, r = e >> 6, g = r % ngt, tap = (r / ngt) % 9, ch = r / (ngt * 9);
+        const int k = ch * GEN_KC + (lane >> 2), col = 4 * g + (lane & 3);
+        const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
+        float v = 0.f;
+        if (real >= 0 && col < P.co)
+            v = P.transposed ? P.w[((size_t)(8 - tap) * P.co + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
+        P.wp[e] = v;
+    }
+}
+
+template <int NG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8 ? 3 : 4, NG > 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
+    extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const GenSrc& S = P.src;
+    const int H = P.hw, W = P.hw, lw = P.lw;
+    const int pass = blockIdx.x % P.npass, tileid = blockIdx.x / P.npass;
+    const int strips = P.imgs == 1 ? H / P.th : 1;
+    const int img0 = P.imgs == 1 ? tileid / strips : tileid * P.imgs;
+    const int row0 = P.imgs == 1 ? (tileid % strips) * P.th : 0;
+    const int pstride = P.rows * P.pw;
+    float4* tile = g4sm;
+    const int pa4 = gen_pa4(S), cp = pa4 + S.cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
+    const int g0 = pass * NG;
+
+    // this wave's weight registers: register image (chunk, tap, group g0 + g) = 64 consecutive floats; the packed buffer holds
+    // npass * NG groups per (chunk, tap) (zero past the layer's last), so group g is an immediate offset of 256 g bytes
+    const int ngp = P.npass * NG;
+    const float* wlane = P.wp + (size_t)g0 * 64 + lane;
+    auto wload = [&](float (&dst)[NG], int ct) {          // ct = chunk * 9 + tap
+        const float* q = wlane + (size_t)(ct * ngp) * 64;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) dst[g] = q[g * 64];
+    };
+    float w0[NG], w1[NG];
+    wload(w0, 0);
+    G4_STAMP(0);
+
+    // this lane's pixel
+    const int p = wave * 64 + lane, q = p >> 2, pos = p & 3;
+    const int lqi = (lw - 1) + (P.th == 4 ? 1 : (P.th == 8 ? 2 : 3));        // log2(quads per image part) = log2((th / 2) * (hw / 2))
+    const int il = q >> lqi, qi = q & ((1 << lqi) - 1), qy = qi >> (lw - 1), qx = qi & ((W >> 1) - 1);
+    const int y = 2 * qy + (pos >> 1), x = 2 * qx + (pos & 1);
+    const int base = (il * (P.th + 2) + y + 1) * P.pw + x + 1;
+
+    // zero halo columns (col 0 and col W + 1) of all four planes (of both buffers), once
+    const int nbuf = P.dbuf ? 2 : 1;
+    for (int e = tid; e < nbuf * 4 * P.rows * 2; e += 256) {
+        const int side = e & 1, r = e >> 1;          // r over 4 * rows (plane-major rows are contiguous; the buffers follow each other)
+        tile[r * P.pw + (side ? W + 1 : 0)] = f4zero();
+    }
+
+    frag4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = frag4{0.f, 0.f, 0.f, 0.f};
+
+    // Two tile buffers (dbuf): chunk c + 1 is staged BEFORE chunk c multiplies, one barrier per chunk -- a wave's staging (global
+    // latency, address arithmetic) then overlaps the other waves' matrix instructions instead of standing between two barriers.
+    float4* const tile0 = g4sm;
+    if (P.dbuf) {
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
+        gen4_stage_any(tile0, S, P, img0, row0, 0, ltid);
+        __syncthreads();
+    }
+    for (int ch = 0; ch < nchunk; ++ch) {
+        int ltid = tid;                         // opaque per chunk: keeps the staging addresses from being hoisted out of the loop
+        asm volatile("" : "+v"(ltid));
+        if (P.dbuf) {
+            tile = tile0 + (ch & 1) * 4 * pstride;
+            if (ch + 1 < nchunk) gen4_stage_any(tile0 + ((ch + 1) & 1) * 4 * pstride, S, P, img0, row0, ch + 1, ltid);
+            if (ch < 3) G4_STAMP(1 + 5 * ch);
+        } else {
+            gen4_stage_any(tile, S, P, img0, row0, ch, ltid);
+            if (ch < 3) G4_STAMP(1 + 5 * ch);
+            __syncthreads();
+        }
+        if (ch < 3) G4_STAMP(3 + 5 * ch);
+        const int rem = cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
+        int lbase = base;
+        asm volatile("" : "+v"(lbase));
+        const int ct0 = ch * 9;
+        // The tap loop per plane count NP (compile-time: straight-line matrix code -- with the plane / channel tests as run-time
+        // branches inside the loop the compiler copies all accumulators at every merge).  Padding channels (A's tail when ca is not
+        // a multiple of 4) multiply zeros by zero weights.
+        // Taps as a REAL loop, two per trip (static rotation of the weight registers): the unrolled 9-tap body is 1440 matrix
+        // instructions -- more code than the instruction cache holds with four workgroups at different places in it.  A tap's
+        // weights are requested one tap ahead; its plane reads (one LDS round trip per tap) hide behind the other waves.
+        auto taps = [&](auto NPC) {
+            constexpr int NP = decltype(NPC)::value;
+            auto readx = [&](float4 (&xr)[NP], int tap) {
+                const int a0 = lbase + (tap / 3 - 1) * P.pw + (tap % 3 - 1);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * pstride + a0];
+            };
+            auto mac = [&](const float (&w)[NG], const float4 (&xr)[NP]) {
+                t4_static_for<NP>([&](auto PL) {
+                    constexpr int pl = decltype(PL)::value;
+                    t4_static_for<4>([&](auto CC) {
+                        constexpr int c = decltype(CC)::value;
+                        const float xv = f4get(xr[pl], c);
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[g], xv, acc[g], 4, 4 * pl + c, 0);
+                    });
+                });
+            };
+            float4 xr[NP];
+#pragma unroll 1
+            for (int tap = 0; tap < 8; tap += 2) {
+                wload(w1, ct0 + tap + 1);
+                readx(xr, tap);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(w0, xr);
+                __builtin_amdgcn_sched_barrier(0);
+                wload(w0, ct0 + tap + 2);
+                readx(xr, tap + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mac(w1, xr);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ch + 1 < nchunk) wload(w1, ct0 + 9);            // the next chunk's tap 0 (moved to w0 below, behind the staging)
+            readx(xr, 8);
+            __builtin_amdgcn_sched_barrier(0);
+            mac(w0, xr);
+        };
+        if (np == 4) taps(std::integral_constant<int, 4>{});
+        else if (np == 3) taps(std::integral_constant<int, 3>{});
+        else if (np == 2) taps(std::integral_constant<int, 2>{});
+        else taps(std::integral_constant<int, 1>{});
+        if (ch + 1 < nchunk) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) w0[g] = w1[g];
+        }
+        if (ch < 3) G4_STAMP(4 + 5 * ch);
+        __syncthreads();
+        if (ch < 3) G4_STAMP(5 + 5 * ch);
+    }
+
+    // ---- epilogue: activation, (max-pool + argmax byte | addend), NHWC stores through LDS ----
+    const int img = img0 + il;
+    const bool live = img < P.n;
+    const int gy = row0 + y;
+    int ngv = P.ngt - g0;                        // valid groups of this pass
+    ngv = ngv < NG ? ngv : NG;
+    const bool vec = !(P.co & 3);
+    float* ot = (float*)g4sm;                    // the tile area is free now (barrier above)
+    constexpr int pitch = 4 * NG + 4;
+    const float slope = P.slope;
+    auto epilogue = [&](auto ACT) {
+        constexpr int act = decltype(ACT)::value;
+        // (the bias is added AFTER the products, as every other kernel of this library does)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 4 * (g0 + g) + r;
+                acc[g][r] += (P.bias && col < P.co) ? cgs_to_const(P.bias)[col] : 0.f;
+            }
+        }
+        auto fact = [&](float v) -> float {
+            if constexpr (act == CGS_ACT_RELU) return fmaxf(v, 0.f);
+            else if constexpr (act == CGS_ACT_LRELU) return v > 0.f ? v : slope * v;
+            else if constexpr (act == CGS_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+            else return v;
+        };
+        // copy-out mapping: 16 lanes per pixel (lanes g < ngv carry one 4-channel group each), 16 pixels per round
+        const int cg = tid & 15, cpx = tid >> 4;
+        if (vec && P.pool) {
+            // pooled map of the tile: 64 pixels, contiguous in memory (image-major, row-major)
+            uint32_t* ct = (uint32_t*)(ot + 64 * pitch);
+            const int hwq = (P.th >> 1) * (W >> 1);                               // pooled pixels per image part of the tile
+            const int lin = il * hwq + (y >> 1) * (W >> 1) + (x >> 1);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < ngv) {
+                    float m[4];
+                    uint32_t word = 0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = fact(acc[g][r]);
+                        float mm = fmaxf(v, dppf_xor1(v));
+                        mm = fmaxf(mm, dppf_xor2(mm));
+                        uint32_t cd = (v == mm) ? (uint32_t)pos : 4u;
+                        cd = min(cd, dpp_xor1(cd));
+                        cd = min(cd, dpp_xor2(cd));
+                        m[r] = mm;
+                        word |= ((cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u)) << (8 * r);
+                    }
+                    if (pos == 0) {
+                        *(float4*)(ot + lin * pitch + 4 * g) = make_float4(m[0], m[1], m[2], m[3]);
+                        ct[lin * NG + g] = word;
+                    }
+                }
+            }
+            __syncthreads();
+            const size_t pix0 = P.imgs == 1 ? ((size_t)img0 * (H >> 1) + (row0 >> 1)) * (W >> 1) : (size_t)img0 * (H >> 1) * (W >> 1);
+            const size_t pixend = (size_t)P.n * (H >> 1) * (W >> 1);
+            if (cg < ngv) {
+                float* po = P.out + (pix0 + cpx) * P.co + 4 * (g0 + cg);
+                uint8_t* pa = P.argmax ? P.argmax + (pix0 + cpx) * P.co + 4 * (g0 + cg) : nullptr;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = cpx + 16 * k;
+                    if (pix0 + px < pixend) {
+                        *(float4*)(po + (size_t)16 * k * P.co) = *(const float4*)(ot + px * pitch + 4 * cg);
+                        if (pa) *(uint32_t*)(pa + (size_t)16 * k * P.co) = ct[px * NG + cg];
+                    }
+                }
+            }
+        } else if (!P.pool) {
+            // the tile's 256 pixels are contiguous in memory
+            const int hwp = P.th * W;                                             // pixels per image part of the tile
+            const int lin = il * hwp + y * W + x;
+            const size_t pix0 = P.imgs == 1 ? ((size_t)img0 * H + row0) * W : (size_t)img0 * H * W;
+            const size_t pixend = (size_t)P.n * H * W;
+            const size_t addend_end = P.addend ? (size_t)P.n_addend * H * W : 0;
+            {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    if (g < ngv)
+                        *(float4*)(ot + lin * pitch + 4 * g) = make_float4(fact(acc[g][0]), fact(acc[g][1]), fact(acc[g][2]), fact(acc[g][3]));
+                __syncthreads();
+                const size_t hp0 = pix0;
+                if (vec) {
+                    if (cg < ngv) {
+                        const size_t o0 = (hp0 + cpx) * P.co + 4 * (g0 + cg);
+#pragma unroll 4
+                        for (int k = 0; k < 16; ++k) {
+                            const int px = cpx + 16 * k;
+                            const size_t gp = hp0 + px, o = o0 + (size_t)16 * k * P.co;
+                            if (gp < pixend) {
+                                float4 t = *(const float4*)(ot + px * pitch + 4 * cg);
+                                if (gp < addend_end) { const float4 a = *(const float4*)(P.addend + o); t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+                                *(float4*)(P.out + o) = t;
+                            }
+                        }
+                    }
+                } else {      // channel counts that are not multiples of 4 (3: the image layer's data gradient; 3 + c: cat(image, .))
+                    int nch = P.co - 4 * g0;
+                    nch = nch < 4 * ngv ? nch : 4 * ngv;
+                    for (int f = tid; f < 256 * nch; f += 256) {
+                        const int px = f / nch, c = f - px * nch;
+                        const size_t gp = hp0 + px;
+                        if (gp < pixend) {
+                            const size_t o = gp * P.co + 4 * g0 + c;
+                            float t = ot[px * pitch + c];
+                            if (gp < addend_end) t += P.addend[o];
+                            P.out[o] = t;
+                        }
+                    }
+                }
+            }
+        } else {
+            // max-pooled layers whose channel count is not a multiple of 4 (none in the Hourglass): scalar stores
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int col = 4 * (g0 + g);
+                if (col >= P.co) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fact(acc[g][r]);
+                    float mm = fmaxf(v, dppf_xor1(v));
+                    mm = fmaxf(mm, dppf_xor2(mm));
+                    uint32_t cd = (v == mm) ? (uint32_t)pos : 4u;
+                    cd = min(cd, dpp_xor1(cd));
+                    cd = min(cd, dpp_xor2(cd));
+                    const uint32_t code = (cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u);
+                    if (live && pos == 0 && col + r < P.co) {
+                        const size_t pp = (((size_t)img * (H >> 1) + (gy >> 1)) * (W >> 1) + (x >> 1)) * P.co + col + r;
+                        P.out[pp] = mm;
+                        if (P.argmax) P.argmax[pp] = (uint8_t)code;
+                    }
+                }
+            }
+        }
+    };
+    if (P.act == CGS_ACT_RELU) epilogue(std::integral_constant<int, CGS_ACT_RELU>{});
+    else if (P.act == CGS_ACT_LRELU) epilogue(std::integral_constant<int, CGS_ACT_LRELU>{});
+    else if (P.act == CGS_ACT_SIGMOID) epilogue(std::integral_constant<int, CGS_ACT_SIGMOID>{});
+    else epilogue(std::integral_constant<int, CGS_ACT_NONE>{});
+    G4_STAMP(31);
+}
+
+}  // namespace
+extern "C" int dbg_gen4_stamps(unsigned long long* stamps) { g_gen4_stamps = stamps; return CGS_OK; }
+
+// ---- launchers (gen.hip's C entry points call these) ----
+struct Gen4Launch {
+    GenSrc src; const float* wp; const float* bias; float* out; uint8_t* argmax; const float* addend;
+    int n_addend, n, hw, co, act, pool;
+    float slope;
+};
+
+// output-channel groups of 4: passes (workgroups over the same tile) x groups per pass (the kernel's NG)
+static void gen4_groups(int co, int& npass, int& ng) {
+    const int ngt = (co + 3) / 4;
+    npass = (ngt + 9) / 10;
+    const int per = (ngt + npass - 1) / npass;
+    ng = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 6 ? 6 : per <= 8 ? 8 : 10;
+}
+
+long gen4_packed_floats(int ca, int cb, int co) {
+    int npass, ng;
+    gen4_groups(co, npass, ng);
+    const int cp = ((ca + 3) & ~3) + cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
+    return (long)nchunk * 9 * npass * ng * 64;
+}
+
+int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, hipStream_t st) {
+    const long total = gen4_packed_floats(ca, cb, co);
+    int npass, ng;
+    gen4_groups(co, npass, ng);
+    Gen4PackParams P{w, wp, ca, cb, co, transposed, (int)total, npass * ng};
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(gen4_pack_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
+    Gen4Params P{};
+    P.src = L.src; P.wp = L.wp; P.bias = L.bias; P.out = L.out; P.argmax = L.argmax; P.addend = L.addend; P.n_addend = L.n_addend;
+    P.n = L.n; P.hw = L.hw; P.co = L.co; P.act = L.act; P.pool = L.pool; P.slope = L.slope;
+    const int hw = L.hw;
+    P.lw = hw == 64 ? 6 : hw == 32 ? 5 : hw == 16 ? 4 : hw == 8 ? 3 : 2;
+    P.imgs = hw >= 16 ? 1 : (hw == 8 ? 4 : 16);
+    P.th = hw >= 16 ? 256 / hw : hw;
+    // padded width in float4 slots: 8 (mod 16) where the tile is wide enough, so the two rows a 16-lane group reads sit 128 bytes apart
+    P.pw = hw >= 16 ? ((hw + 2 + 7) / 16) * 16 + 8 : hw + 2;
+    P.rows = P.imgs * (P.th + 2);
+    P.dbg = g_gen4_stamps;
+    P.ngt = (L.co + 3) / 4;
+    int ng;
+    gen4_groups(L.co, P.npass, ng);
+    const int tiles = P.imgs == 1 ? L.n * (hw / P.th) : (L.n + P.imgs - 1) / P.imgs;
+    // LDS: the input tile -- two buffers when there is more than one chunk and three (NG = 10) / four workgroups still fit a CU;
+    // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling: 64 pixels + 64 x ng argmax words)
+    const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
+    const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
+    const size_t budget = (size_t)(160 * 1024) / (ng > 8 ? 3 : 4) - 512;
+    P.dbuf = (cp > GEN_KC && 2 * tile_bytes <= budget) ? 1 : 0;
+    size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
+    const size_t epi = L.pool ? (size_t)64 * (4 * ng + 4 + ng) * sizeof(float) : (size_t)256 * (4 * ng + 4) * sizeof(float);
+    lds = lds > epi ? lds : epi;
+    const dim3 grid(tiles * P.npass);
+#define G4_LAUNCH(NG_) hipLaunchKernelGGL(gen4_conv3x3_kernel<NG_>, grid, dim3(256), lds, st, P)
+    switch (ng) {
+        case 1: G4_LAUNCH(1); break;
+        case 2: G4_LAUNCH(2); break;
+        case 4: G4_LAUNCH(4); break;
+        case 6: G4_LAUNCH(6); break;
+        case 8: G4_LAUNCH(8); break;
+        default: G4_LAUNCH(10); break;
+    }
+#undef G4_LAUNCH
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}

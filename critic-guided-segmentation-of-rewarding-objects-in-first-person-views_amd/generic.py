@@ -26,6 +26,24 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_PACKED: Dict[tuple, torch.Tensor] = {}
+
+
+def pack_weights(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool = False) -> torch.Tensor:
+    """HWIO 3x3 weights at w_ptr -> the convolution kernel's operand form (cgs_gen_conv_pack_weights).  transposed: w_ptr is the
+    [9][co][ca] weight of the layer whose DATA GRADIENT is wanted (ca = its output channels, co = its input channels).  One scratch
+    tensor per (device, shape): the pack and the convolution that reads it are consecutive launches of one stream."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), ca, cb, co)
+    wp = _PACKED.get(key)
+    if wp is None:
+        nfl = int(_lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
+        if nfl <= 0:
+            raise _lib.CgsError(f"generic conv: no packed form for ca={ca} cb={cb} co={co}")
+        wp = _PACKED[key] = torch.empty(nfl, device=dev, dtype=torch.float32)
+    _lib.call("cgs_gen_conv_pack_weights", ca, cb, co, int(transposed), C.c_void_p(w_ptr), _p(wp), _s())
+    return wp
+
+
 def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: int, co: int, act: str = "none",
             slope: float = 0.01, pool: bool = False, ups: int = 2, want_argmax: bool = False, out: Optional[torch.Tensor] = None,
             am: Optional[torch.Tensor] = None):
@@ -40,8 +58,9 @@ def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: in
         out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32)
     if am is None and pool and want_argmax:
         am = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.uint8)
+    wp = pack_weights(w_ptr, ca, cb, co, a.device)
     _lib.call("cgs_gen_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], float(slope), int(pool), _p(a),
-              _p(b), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _p(am), _s())
+              _p(b), _p(wp), C.c_void_p(bias_ptr), _p(out), _p(am), _s())
     return (out, am) if want_argmax else out
 
 
@@ -260,14 +279,15 @@ class Workspace(dict):
         return t
 
 
-def _flip(ws: Workspace, flat: torch.Tensor, lay: Layout, key: str, ci: int, co: int) -> torch.Tensor:
-    wf = ws.buf("wflip_" + key, (9 * ci * co,), flat.device)
-    _lib.call("cgs_gen_flip_weights", ci, co, C.c_void_p(flat.data_ptr() + 4 * lay.off(key + ".weight")), _p(wf), _s())
-    return wf
+def _flip(ws: Workspace, flat: torch.Tensor, lay: Layout, key: str, ci: int, co: int) -> int:
+    """The layer's HWIO weight pointer: _bwd_data packs it (taps reversed, channels transposed) for the data-gradient pass."""
+    return flat.data_ptr() + 4 * lay.off(key + ".weight")
 
 
-def _bwd_data(n, hw, co, ci, dy, am, wflip, out, addend=None):
-    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _p(dy), _p(am), _p(wflip), _p(addend),
+def _bwd_data(n, hw, co, ci, dy, am, w_ptr: int, out, addend=None):
+    """d_cat [n,hw,hw,ci] of a 3x3 layer with HWIO weights [9][ci][co] at w_ptr from the gradient dy at its output."""
+    wp = pack_weights(w_ptr, co, 0, ci, dy.device, transposed=True)
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _p(dy), _p(am), _p(wp), _p(addend),
               0 if addend is None else addend.shape[0], _p(out), _s())
 
 

@@ -403,10 +403,8 @@ class _UnetFn(torch.autograd.Function):
             grads[2 * i + 1] = flat[9 * ca * co:].clone()
             if i > 0:
                 wkf = ew[i].permute(2, 3, 1, 0).contiguous().reshape(-1)
-                wflip = z(9 * ca * co)
-                _lib.call("cgs_gen_flip_weights", ca, co, gen._p(wkf), gen._p(wflip), gen._s())
                 dsrc = z(*src.shape)
-                gen._bwd_data(n, hw, co, ca, g, am[i], wflip, dsrc)
+                gen._bwd_data(n, hw, co, ca, g, am[i], wkf.data_ptr(), dsrc)
                 g = dsrc
         torch.cuda.current_stream().synchronize()          # temporaries (re-laid-out weights, slabs) die with this call
         return (None, None, None) + tuple(grads)

@@ -354,21 +354,30 @@ int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stre
  * NewCritic / UnetDecoder with chfak != 1 (nets.py:166,184,190; the paper's model is chfak = 5) and the legacy `Unet` with its
  * ConvTranspose2d(4,2,1) decoder and LeakyReLU(0.2) (nets.py:356-449).  NHWC fp32 (source A optionally uint8, /255 fused),
  * runtime channel counts, weights in kernel layout (HWIO; [k][n] for GEMMs; [ky][kx][ci][co] for the transposed conv).
- * cgs_gen_conv3x3_fwd: out = act(conv3x3(cat(A [ca], nearest-up_ups(B [cb])), w) + bias), hw in {4,8,16,32,64}; pool = 1:
+ * cgs_gen_conv_pack_weights: HWIO w [9][ca+cb][co] -> the convolution's weight operand wp (cgs_gen_conv_packed_floats floats:
+ *   register images [16-channel chunk][tap][4-channel output group][64 lanes], zero for padding, csrc/gen4.hip).  transposed = 1
+ *   (cb = 0): w is the HWIO weight [9][co][ca] of the LAYER whose data gradient is wanted (ca = its output channels = dY's, co =
+ *   its input channels): wp is then the operand of cgs_gen_conv3x3_bwd_data (taps reversed, channels transposed).
+ * cgs_gen_conv3x3_fwd: out = act(conv3x3(cat(A [ca], nearest-up_ups(B [cb])), wp) + bias), hw in {4,8,16,32,64}; pool = 1:
  *   MaxPool2d(2) of it, out [n,hw/2,hw/2,co] and argmax [same] = position 0..3 of the first maximum in bits 0-1 (may be NULL).
  * cgs_gen_gemm: out [m,n] = act(x [m,k] w [k,n] + bias [n] (may be NULL)).
  * cgs_gen_convt4s2_*: ConvTranspose2d(4,2,1) over cat(A, B) [n,h,h,*] -> [n,2h,2h,co]: forward (+bias, act), data gradient
  *   (dy = gradient at the PRE-activation output; da / db may be NULL), weight + bias gradient (dw [16*(ca+cb)*co], dbias [co]). */
+int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co);
+int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
+                              cgs_stream_t stream);
 int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
-                        int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* w,
+                        int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                         const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
 int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
                  const float* bias, float* out, cgs_stream_t stream);
 
 /* Training pass at chfak != 1 (csrc/gen_train.hip; backward of nets.py:197-212, 494-523 for any channel count).
  * cgs_gen_conv3x3_fwd's argmax byte carries bit 2 (value >= 4) where a ReLU'd pooled value is <= 0: no gradient there.
- * cgs_gen_flip_weights: HWIO w [9][ci][co] -> wflip [9][co][ci] with the taps reversed (the data gradient's weight operand).
- * cgs_gen_conv3x3_bwd_data: d_cat [n,hw,hw,ci] = conv3x3(dY, wflip) (+ addend [n_addend,hw,hw,ci] for images < n_addend).  dY is the
+ * cgs_gen_flip_weights: HWIO w [9][ci][co] -> wflip [9][co][ci] with the taps reversed (the data gradient's kernel in HWIO form:
+ *   cgs_gen_conv_pack_weights(co, 0, ci, 0, wflip) == cgs_gen_conv_pack_weights(co, 0, ci, 1, w)).
+ * cgs_gen_conv3x3_bwd_data: d_cat [n,hw,hw,ci] = conv3x3(dY, wp) (+ addend [n_addend,hw,hw,ci] for images < n_addend), wp =
+ *   cgs_gen_conv_pack_weights(co, 0, ci, transposed = 1, the layer's HWIO weights).  dY is the
  *   gradient at the pre-activation output [n,hw,hw,co], or -- dy_argmax != NULL, a max-pooled ReLU layer -- the gradient dE
  *   [n,hw/2,hw/2,co] at the pooled output with the forward pass's argmax bytes (re-expanded in the tile loader).
  * cgs_gen_conv3x3_bwd_weight: one slab row [9*(ca+cb)*co | co] (HWIO dW, dbias) per image share, cgs_gen_conv3x3_bwd_weight_slabs
@@ -382,7 +391,7 @@ int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, cons
  * cgs_gen_u8_to_f32: out = x / 255.                                                                                         */
 int cgs_gen_flip_weights(int32_t ci, int32_t co, const float* w, float* wflip, cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, const float* dy, const uint8_t* dy_argmax,
-                             const float* wflip, const float* addend, int32_t n_addend, float* d_cat, cgs_stream_t stream);
+                             const float* wp, const float* addend, int32_t n_addend, float* d_cat, cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co);
 int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                const void* src_a, const float* src_b, const float* dy, const uint8_t* dy_argmax, float* slab,

@@ -73,10 +73,16 @@ def test_generic_conv_backward_kernels_vs_autograd(hw, ca, cb, co, ups, pool, u8
         rel_close(nhwc(o), out_ref.detach().numpy(), "forward")
     dy = dout.permute(0, 2, 3, 1).contiguous().to(dev)
     ci = ca + cb
+    # the data gradient's operand two ways: the layer's weights packed transposed == the flipped weights packed as a forward kernel
+    nfl = int(_lib.load().cgs_gen_conv_packed_floats(co, 0, ci))
     wf = torch.empty(9 * ci * co, device=dev)
     _lib.call("cgs_gen_flip_weights", ci, co, _P(wk), _P(wf), _st())
+    wp, wp2 = torch.empty(nfl, device=dev), torch.empty(nfl, device=dev)
+    _lib.call("cgs_gen_conv_pack_weights", co, 0, ci, 1, _P(wk), _P(wp), _st())
+    _lib.call("cgs_gen_conv_pack_weights", co, 0, ci, 0, _P(wf), _P(wp2), _st())
+    assert torch.equal(wp, wp2)
     dcat = torch.empty(n, hw, hw, ci, device=dev)
-    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wf), None, 0, _P(dcat), _st())
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wp), None, 0, _P(dcat), _st())
     d_a = torch.empty(n, hw, hw, ca, device=dev)
     d_b = torch.empty(n, hw // ups, hw // ups, cb, device=dev) if cb else None
     _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, _P(dcat), _P(d_a), _P(d_b), _st())
@@ -97,7 +103,7 @@ def test_generic_conv_backward_kernels_vs_autograd(hw, ca, cb, co, ups, pool, u8
     # the addend of the data gradient (skip gradients arriving at the leading images)
     add = torch.from_numpy(rs.randn(2, hw, hw, ci).astype(np.float32)).to(dev)
     dcat2 = torch.empty_like(dcat)
-    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wf), _P(add), 2, _P(dcat2), _st())
+    _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _P(dy), _P(am), _P(wp), _P(add), 2, _P(dcat2), _st())
     exp = dcat.clone()
     exp[:2] += add
     assert torch.equal(dcat2, exp)
