@@ -21,8 +21,7 @@
 // Output channels beyond 4 * NG (NG <= 10) are further passes = further workgroups over the same tile (blockIdx picks the pass).
 // Epilogue: bias + activation (+ MaxPool2d(2) and the argmax byte), then through LDS so that a workgroup's output -- one
 // contiguous block of NHWC memory -- leaves in full lines (the lane = pixel registers would store 16-byte pieces 4 * co bytes apart).
-#include "gen_common.h"
-#include "tail4.h"
+#include "gen4_common.h"
 
 namespace {
 
@@ -33,117 +32,11 @@ struct Gen4Params {
     int n, hw, co, act, pool;
     float slope;
     int imgs, th, pw, rows, lw, npass, ngt;             // ngt: output-channel groups of 4 of the whole layer
-    int dbuf;                                           // 1: two tile buffers (chunk c + 1 is staged while chunk c multiplies)                  // tile geometry (host): images per tile, rows per image, padded width, imgs * (th + 2)
+    int dbuf;                                           // 1: two tile buffers (chunk c + 1 is staged while chunk c multiplies)
     unsigned long long* dbg;                            // debug: per-workgroup phase stamps (tools/gen4_stamps.py), NULL in the product path
 };
 unsigned long long* g_gen4_stamps = nullptr;
 #define G4_STAMP(k) do { if (P.dbg && tid == 0 && blockIdx.x < 4096) P.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-
-// ---- input tile: channel-planar, tile[(plane * rows + row) * pw + col] (float4 = 4 channels of one pixel), col 0 = left halo ----
-// Element e = tid + 256 * round -> (plane g, column x) are the THREAD's for every round (a tile row is W << lp <= 256 elements),
-// only the tile row moves: everything that depends on (g, x) alone is computed once per chunk, a round costs one row clamp and
-// one multiply-add per load.  (The staging runs beside other waves' MFMAs, which own the SIMD's issue slots: its cost is its
-// instruction count.)
-template <int KIND, bool HASB>
-__device__ __forceinline__ void gen4_stage(float4* tile, const GenSrc& S, const Gen4Params& P, int img0, int row0, int ch, int tid) {
-    constexpr int BATCH = 6;        // every load of a chunk in flight together (a tile is <= 6 rounds of 256 elements)
-    const int H = P.hw, W = P.hw, lw = P.lw;
-    const int pa4 = gen_pa4(S), cp = pa4 + S.cb;
-    const int rem = cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
-    const int lp = np == 1 ? 0 : (np == 2 ? 1 : 2);
-    const int rpi = P.th + 2;
-    const int rpr = 256 >> (lp + lw);                          // tile rows per round of 256 threads (>= 1)
-    const int g = tid & ((1 << lp) - 1), x = (tid >> lp) & (W - 1), rsub = tid >> (lp + lw);
-    const int ush = S.ups == 4 ? 2 : (S.ups == 2 ? 1 : 0), HB = H >> ush, WB = W >> ush;
-    const int k0 = ch * GEN_KC + 4 * g;
-    const bool isa = k0 < pa4, kok = k0 < cp;
-    // per-thread source offsets (floats / bytes) of row 0 of image 0
-    const int ka = k0 > S.ca - 4 ? S.ca - 4 : k0;
-    int kb = k0 - pa4;
-    kb = kb < 0 ? 0 : (kb > S.cb - 4 ? S.cb - 4 : kb);
-    const uint32_t offa = (uint32_t)x * (uint32_t)S.ca, offb = (uint32_t)(x >> ush) * (uint32_t)S.cb + kb;
-    const uint32_t offp = (uint32_t)(x >> 1) * (uint32_t)S.ca + ka;                       // POOLEXP: pooled map
-    const uint32_t rsa = (uint32_t)W * (uint32_t)S.ca, rsb = (uint32_t)WB * (uint32_t)S.cb, rsp = (uint32_t)(W >> 1) * (uint32_t)S.ca;
-    const int c0 = k0 < S.ca ? k0 : S.ca - 1, c1 = k0 + 1 < S.ca ? k0 + 1 : S.ca - 1, c2 = k0 + 2 < S.ca ? k0 + 2 : S.ca - 1,
-              c3 = k0 + 3 < S.ca ? k0 + 3 : S.ca - 1;
-    float4* const dst0 = tile + g * (P.rows * P.pw) + x + 1;
-#pragma unroll 1
-    for (int rb = rsub; rb < P.rows; rb += rpr * BATCH) {
-        float4 raw[BATCH];
-        [[maybe_unused]] float4 rawb[HASB && KIND != GEN_K_F32V4 ? BATCH : 1];
-        [[maybe_unused]] uint32_t am[KIND == GEN_K_POOLEXP ? BATCH : 1];
-#pragma unroll
-        for (int it = 0; it < BATCH; ++it) {
-            int r = rb + it * rpr;
-            r = r < P.rows ? r : P.rows - 1;
-            const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
-            const int y = row0 + rr - 1, yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
-            int img = img0 + il;
-            img = img < P.n ? img : P.n - 1;
-            const float* pb = nullptr;
-            if constexpr (HASB) pb = S.b + ((uint32_t)(img * HB + (yc >> ush)) * rsb + offb);
-            if constexpr (KIND == GEN_K_F32V4) {
-                const float* pa = (const float*)S.a + ((uint32_t)(img * H + yc) * rsa + offa + ka);
-                if constexpr (HASB) pa = isa ? pa : pb;
-                raw[it] = *(const float4*)pa;
-            } else if constexpr (KIND == GEN_K_POOLEXP) {
-                const uint32_t pp = (uint32_t)(img * (H >> 1) + (yc >> 1)) * rsp + offp;
-                raw[it] = *(const float4*)((const float*)S.a + pp);
-                am[it] = *(const uint32_t*)(S.am + pp);
-            } else {
-                const uint32_t po = (uint32_t)(img * H + yc) * rsa + offa;
-                if constexpr (KIND == GEN_K_U8) {
-                    const uint8_t* sp = (const uint8_t*)S.a + po;
-                    raw[it] = make_float4((float)sp[c0], (float)sp[c1], (float)sp[c2], (float)sp[c3]);
-                } else {
-                    const float* sp = (const float*)S.a + po;
-                    raw[it] = make_float4(sp[c0], sp[c1], sp[c2], sp[c3]);
-                }
-                if constexpr (HASB) rawb[it] = *(const float4*)pb;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < BATCH; ++it) {
-            const int r = rb + it * rpr;
-            if (r < P.rows) {
-                const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
-                const int y = row0 + rr - 1;
-                const bool inb = kok && y >= 0 && y < H && img0 + il < P.n;
-                float4 v = raw[it];
-                if constexpr (KIND == GEN_K_POOLEXP) {
-                    const uint32_t pos = (uint32_t)(((y & 1) << 1) | (x & 1));
-                    v.x = (am[it] & 255u) == pos ? v.x : 0.f;
-                    v.y = ((am[it] >> 8) & 255u) == pos ? v.y : 0.f;
-                    v.z = ((am[it] >> 16) & 255u) == pos ? v.z : 0.f;
-                    v.w = (am[it] >> 24) == pos ? v.w : 0.f;
-                } else if constexpr (KIND == GEN_K_F32S || KIND == GEN_K_U8) {
-                    const float sc = KIND == GEN_K_U8 ? 1.f / 255.f : 1.f;
-                    v.x = k0 < S.ca ? v.x * sc : 0.f;
-                    v.y = k0 + 1 < S.ca ? v.y * sc : 0.f;
-                    v.z = k0 + 2 < S.ca ? v.z * sc : 0.f;
-                    v.w = k0 + 3 < S.ca ? v.w * sc : 0.f;
-                    if constexpr (HASB) {
-                        const float4 rb4 = rawb[it];
-                        v.x = isa ? v.x : rb4.x; v.y = isa ? v.y : rb4.y; v.z = isa ? v.z : rb4.z; v.w = isa ? v.w : rb4.w;
-                    }
-                }
-                dst0[r * P.pw] = inb ? v : f4zero();
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void gen4_stage_any(float4* tile, const GenSrc& S, const Gen4Params& P, int img0, int row0, int ch, int tid) {
-    if (S.mode == GEN_SRC_POOLEXP) return gen4_stage<GEN_K_POOLEXP, false>(tile, S, P, img0, row0, ch, tid);
-    if (S.cb > 0) {
-        if (S.mode == GEN_SRC_U8) return gen4_stage<GEN_K_U8, true>(tile, S, P, img0, row0, ch, tid);
-        if (S.ca & 3) return gen4_stage<GEN_K_F32S, true>(tile, S, P, img0, row0, ch, tid);
-        return gen4_stage<GEN_K_F32V4, true>(tile, S, P, img0, row0, ch, tid);
-    }
-    if (S.mode == GEN_SRC_U8) return gen4_stage<GEN_K_U8, false>(tile, S, P, img0, row0, ch, tid);
-    if (S.ca & 3) return gen4_stage<GEN_K_F32S, false>(tile, S, P, img0, row0, ch, tid);
-    return gen4_stage<GEN_K_F32V4, false>(tile, S, P, img0, row0, ch, tid);
-}
 
 // ---- weights as register images: wp[((chunk * 9 + tap) * ngp + g) * 64 + 4 * cin + i] = w[tap][channel cin of the chunk][4 g + i],
 // ngp = passes x groups per pass (gen4_groups), zero for the groups past the layer's last ----
@@ -175,6 +68,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
     const int row0 = P.imgs == 1 ? (tileid % strips) * P.th : 0;
     const int pstride = P.rows * P.pw;
     float4* tile = g4sm;
+    const G4Geo geo{P.n, P.hw, P.lw, P.imgs, P.th};
+    auto stage = [&](float4* dst, int ch, int ltid) {      // channel-planar tile: dst[(plane * rows + row) * pw + col], col 0 = left halo
+        gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+    };
     const int pa4 = gen_pa4(S), cp = pa4 + S.cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
     const int g0 = pass * NG;
 
@@ -215,7 +112,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
     if (P.dbuf) {
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
-        gen4_stage_any(tile0, S, P, img0, row0, 0, ltid);
+        stage(tile0, 0, ltid);
         __syncthreads();
     }
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -223,10 +120,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
         asm volatile("" : "+v"(ltid));
         if (P.dbuf) {
             tile = tile0 + (ch & 1) * 4 * pstride;
-            if (ch + 1 < nchunk) gen4_stage_any(tile0 + ((ch + 1) & 1) * 4 * pstride, S, P, img0, row0, ch + 1, ltid);
+            if (ch + 1 < nchunk) stage(tile0 + ((ch + 1) & 1) * 4 * pstride, ch + 1, ltid);
             if (ch < 3) G4_STAMP(1 + 5 * ch);
         } else {
-            gen4_stage_any(tile, S, P, img0, row0, ch, ltid);
+            stage(tile, ch, ltid);
             if (ch < 3) G4_STAMP(1 + 5 * ch);
             __syncthreads();
         }
