@@ -286,6 +286,9 @@ def _flip(ws: Workspace, flat: torch.Tensor, lay: Layout, key: str, ci: int, co:
 
 def _bwd_data(n, hw, co, ci, dy, am, w_ptr: int, out, addend=None):
     """d_cat [n,hw,hw,ci] of a 3x3 layer with HWIO weights [9][ci][co] at w_ptr from the gradient dy at its output."""
+    for t in (dy, am, out, addend):
+        if t is not None and not t.is_contiguous():
+            raise _lib.CgsError("generic conv backward: dy / argmax / out / addend must be contiguous NHWC device tensors")
     wp = pack_weights(w_ptr, co, 0, ci, dy.device, transposed=True)
     _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _p(dy), _p(am), _p(wp), _p(addend),
               0 if addend is None else addend.shape[0], _p(out), _s())

@@ -1,0 +1,125 @@
+"""GPU parity of the lane = pixel shape-generic 3x3 convolution (csrc/gen4.hip) on its own: every tile geometry (hw 4 .. 64,
+multi-image tiles with a ragged last tile), every source kind (fp32 / odd-width fp32 / uint8, with and without a nearest-upsampled
+second source, pooled gradient + argmax bytes), channel counts that are not multiples of 4 or 16 on either side, several output
+passes, the max-pool epilogue with its argmax / no-gradient byte, the addend, and the data-gradient operand -- against torch's
+conv2d on the CPU in float64 (the reference's own numeric backend, nets.py:170-183 / 480-489 layer forms)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_kernels import rel_close
+
+
+def _ref_conv(a, b, ups, w_hwio, bias, act, slope, pool):
+    xa = (a.double() / 255.0 if a.dtype == torch.uint8 else a.double()).permute(0, 3, 1, 2)
+    xin = xa if b is None else torch.cat([xa, F.interpolate(b.double().permute(0, 3, 1, 2), scale_factor=ups, mode="nearest")], 1)
+    ci, co = w_hwio.shape[1], w_hwio.shape[2]
+    wt = w_hwio.double().view(3, 3, ci, co).permute(3, 2, 0, 1).contiguous()
+    y = F.conv2d(xin, wt, bias.double(), padding=1)
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "lrelu":
+        y = F.leaky_relu(y, slope)
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    idx = None
+    if pool:
+        y, idx = F.max_pool2d(y, 2, return_indices=True)
+    return y.permute(0, 2, 3, 1).float(), idx
+
+
+@pytest.mark.parametrize("n,hw,ca,cb,ups,co,act,pool,u8", [
+    (3, 64, 3, 0, 1, 40, "relu", True, True),        # features.0 at chfak 5: uint8 frames, 27 k-steps, 10 output groups
+    (3, 64, 3, 0, 1, 8, "relu", True, False),        # odd-width fp32 source (the mixes)
+    (5, 32, 40, 0, 1, 40, "relu", True, False),      # three chunks (16, 16, 8)
+    (5, 16, 24, 0, 1, 24, "relu", True, False),      # chfak 3: 6 groups
+    (6, 8, 40, 0, 1, 80, "relu", True, False),       # four images per tile (ragged: 6), two output passes
+    (19, 4, 16, 32, 4, 16, "none", False, False),    # sixteen images per tile (ragged: 19), x4 upsampled second source
+    (6, 8, 8, 16, 2, 8, "none", False, False),
+    (3, 16, 40, 40, 2, 40, "none", False, False),
+    (2, 32, 16, 16, 2, 16, "lrelu", False, False),
+    (2, 64, 3, 40, 2, 16, "lrelu", False, True),     # masker.0: uint8 image + upsampled decoder channels
+    (2, 64, 3, 8, 2, 16, "lrelu", False, False),     # ... with an fp32 image
+    (2, 64, 16, 0, 1, 1, "sigmoid", False, False),   # one output channel
+    (2, 32, 8, 0, 1, 6, "relu", True, False),        # pooled, channel count not a multiple of 4 (scalar epilogue)
+    (2, 32, 12, 0, 1, 43, "none", False, False),     # 11 groups: two passes, scalar copy-out
+    (2, 16, 160, 0, 1, 160, "relu", True, False),    # ten chunks, four passes
+])
+def test_gen4_forward_matches_float64_conv2d(n, hw, ca, cb, ups, co, act, pool, u8):
+    from cgs_amd import generic as gen
+    rs = np.random.RandomState(hw * 1000 + ca * 10 + co)
+    dev = torch.device("cuda:0")
+    a = torch.from_numpy(rs.randint(0, 256, (n, hw, hw, ca)).astype(np.uint8)) if u8 else torch.from_numpy(rs.randn(n, hw, hw, ca).astype(np.float32))
+    b = torch.from_numpy(rs.randn(n, hw // ups, hw // ups, cb).astype(np.float32)) if cb else None
+    w = torch.from_numpy((rs.randn(9, ca + cb, co) / (3.0 * np.sqrt(ca + cb))).astype(np.float32))
+    bias = torch.from_numpy((0.1 * rs.randn(co)).astype(np.float32))
+    ref, idx = _ref_conv(a, b, ups, w, bias, act, 0.2, pool)
+    wd, bd = w.to(dev), bias.to(dev)
+    out = gen.conv3x3(a.to(dev), None if b is None else b.to(dev), wd.data_ptr(), bd.data_ptr(), co, act=act, slope=0.2, pool=pool, ups=ups,
+                      want_argmax=pool)
+    if pool:
+        out, am = out
+        am = am.cpu().numpy()
+        # argmax position inside the 2x2 window (row-major), bit 2 where the pooled ReLU value is not positive
+        oy, ox = np.divmod(idx.permute(0, 2, 3, 1).numpy(), hw)
+        pos = (oy % 2) * 2 + (ox % 2)
+        refv = ref.numpy()
+        live = refv > 0
+        # exact agreement wherever the window's maximum is unique in float32 (random data: everywhere but the ReLU-dead windows)
+        assert ((am & 3) == pos)[live].mean() > 0.999
+        assert ((am & 4) != 0)[~live].all() and ((am & 4) == 0)[live].all()
+    rel_close(out.cpu().numpy(), ref.numpy(), "forward")
+
+
+@pytest.mark.parametrize("n,hw,ci,co,pooled", [
+    (3, 64, 3, 40, True),       # the image layer's data gradient: 3 output channels (one group, scalar copy-out), pooled gradient source
+    (5, 32, 40, 40, True),
+    (6, 8, 40, 80, True),
+    (19, 4, 48, 16, False),
+    (2, 64, 43, 16, False),     # masker.0: d cat(image, decoder channels)
+    (3, 16, 80, 40, False),
+])
+def test_gen4_data_gradient_matches_autograd(n, hw, ci, co, pooled):
+    """cgs_gen_conv_pack_weights(transposed = 1) + cgs_gen_conv3x3_bwd_data vs float64 autograd of conv2d (+ ReLU + max-pool), with the
+    addend on the leading images."""
+    from cgs_amd import generic as gen
+    rs = np.random.RandomState(hw + ci + co)
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(rs.randn(n, ci, hw, hw)).double().requires_grad_(True)
+    w_hwio = torch.from_numpy((rs.randn(9, ci, co) / (3.0 * np.sqrt(ci))).astype(np.float32))
+    wt = w_hwio.double().view(3, 3, ci, co).permute(3, 2, 0, 1).contiguous()
+    y = F.conv2d(x, wt, None, padding=1)
+    if pooled:
+        yp, idx = F.max_pool2d(F.relu(y), 2, return_indices=True)
+        dout = torch.from_numpy(rs.randn(*yp.shape))
+        yp.backward(dout)
+        oy, ox = np.divmod(idx.permute(0, 2, 3, 1).numpy(), hw)
+        am = ((oy % 2) * 2 + (ox % 2)).astype(np.uint8)
+        am[(yp.detach().permute(0, 2, 3, 1).numpy() <= 0)] |= 4
+        am_d = torch.from_numpy(np.ascontiguousarray(am)).to(dev)
+    else:
+        dout = torch.from_numpy(rs.randn(*y.shape))
+        y.backward(dout)
+        am_d = None
+    dy = dout.float().permute(0, 2, 3, 1).contiguous().to(dev)
+    add = torch.from_numpy(rs.randn(2, hw, hw, ci).astype(np.float32)).to(dev)
+    out = torch.full((n, hw, hw, ci), float("nan"), device=dev)
+    wd = w_hwio.to(dev)
+    gen._bwd_data(n, hw, co, ci, dy, am_d, wd.data_ptr(), out, addend=add)
+    ref = x.grad.permute(0, 2, 3, 1).float().numpy().copy()
+    ref[:2] += add.cpu().numpy()
+    rel_close(out.cpu().numpy(), ref, "data gradient + addend")
+
+
+def test_gen4_rejects_bad_arguments():
+    from cgs_amd import _lib
+    lib = _lib.load()
+    assert lib.cgs_gen_conv_packed_floats(40, 0, 40) == 3 * 9 * 10 * 64
+    assert lib.cgs_gen_conv_packed_floats(3, 40, 16) == 3 * 9 * 4 * 64
+    assert lib.cgs_gen_conv_packed_floats(40, 6, 40) < 0          # second source: whole groups of 4 channels
+    assert lib.cgs_gen_conv_pack_weights(8, 4, 8, 1, C.c_void_p(16), C.c_void_p(16), None) < 0      # transposed: one source only
