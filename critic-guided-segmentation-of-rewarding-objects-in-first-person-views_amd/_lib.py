@@ -53,10 +53,12 @@ SIGNATURES = {
     "cgs_mask_infer_fwd_f16": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_train_fwd_partials": (i32, [i32]),
     "cgs_mask_train_fwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_mask_train_fwd_packed": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_head_bwd_slabs": (i32, [i32]),
     "cgs_mask_head_bwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_tail_enc_fwd": (i32, [i32, C.POINTER(TailEncWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, Dropout, Dropout, Dropout, vp]),
     "cgs_tail_dec_fwd": (i32, [i32, C.POINTER(TailDecWeights), vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_tail_dec_fwd_pack": (i32, [i32, C.POINTER(TailDecWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_tail_enc_bwd_slabs": (i32, [i32]),
     "cgs_tail_enc_bwd": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, vp]),
     "cgs_tail_head_wgrad_slabs": (i32, [i32]),

@@ -15,7 +15,7 @@ int mask_infer_launch(int n, int img_kind, const void* img, const float* o0, con
                       const float* b2, float* z, hipStream_t st);
 int mask_train_partials(int n);
 int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
-                      const float* b2, float* h, float* z, float* zpart, hipStream_t st);
+                      const float* b2, float* h, float* z, float* zpart, const float* w0_pack, hipStream_t st);
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st);
 // (round 2's opt-in two-pixels-per-MFMA-row form of features.0 / features.3 -- measured slower -- lives in tools/experiments/pconv.hip,
@@ -150,11 +150,17 @@ extern "C" int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const
 
 extern "C" int cgs_mask_train_fwd_partials(int32_t n) { return n < 0 ? CGS_ERR_BADARG : mask_train_partials(n); }
 
-extern "C" int cgs_mask_train_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
-                                  const float* w_m2, const float* b_m2, float* h, float* z, float* zpart, cgs_stream_t stream) {
+extern "C" int cgs_mask_train_fwd_packed(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                         const float* w_m2, const float* b_m2, float* h, float* z, float* zpart, const float* w_m0_pack,
+                                         cgs_stream_t stream) {
     if (n < 0 || !x || !o0 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !h || !z || !zpart) return CGS_ERR_BADARG;
     if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
-    return mask_train_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, h, z, zpart, (hipStream_t)stream);
+    return mask_train_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, h, z, zpart, w_m0_pack, (hipStream_t)stream);
+}
+
+extern "C" int cgs_mask_train_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                  const float* w_m2, const float* b_m2, float* h, float* z, float* zpart, cgs_stream_t stream) {
+    return cgs_mask_train_fwd_packed(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, h, z, zpart, nullptr, stream);
 }
 
 extern "C" int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0,

@@ -23,7 +23,8 @@ struct MaskFwdParams {
     const float* w0; const float* b0; const float* w2; const float* b2;
     float* h; float* z; float* zpart;
     int n;
-    unsigned long long* dbg;      // debug: per-workgroup phase time stamps (tools/maskfwd_stamps.py), NULL in the product path
+    unsigned long long* dbg;
+    const float* w0_pack;         // optional: the weight registers below, built once by the launch before this one (tail.hip: mask0_pack_weights)      // debug: per-workgroup phase time stamps (tools/maskfwd_stamps.py), NULL in the product path
 };
 
 namespace {
@@ -126,12 +127,25 @@ __global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {
         }
     };
     fetch(0);                  // the first strip's loads fly while the weight registers are set up
+    float wimg[4][2];        // [group][reg]: block b of reg k = step 16 k + b = tap * 3 + ci
+    float wups[4][4][2];     // [position][group][reg]: block b of reg k: source pixel (ry = k, rx = b >> 3), channel b & 7
+    if (P.w0_pack) {
+        // built once per step by the previous launch: 40 coalesced loads instead of an LDS copy, a barrier and ~140 gathers per image
+        const float* wp = P.w0_pack + lane;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) wimg[g][k] = wp[(g * 2 + k) * 64];
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos)
+#pragma unroll
+                for (int ry = 0; ry < 2; ++ry) wups[pos][g][ry] = wp[(8 + (pos * 4 + g) * 2 + ry) * 64];
+        }
+    } else {
     // ---- weight registers (once per image): masker.0's 1584 floats through LDS, each lane gathers / pre-sums its own ----
     float* wst = (float*)ldsA;
     for (int e = tid; e < 9 * 11 * 16; e += 256) wst[e] = P.w0[e];
     __syncthreads();
-    float wimg[4][2];        // [group][reg]: block b of reg k = step 16 k + b = tap * 3 + ci
-    float wups[4][4][2];     // [position][group][reg]: block b of reg k: source pixel (ry = k, rx = b >> 3), channel b & 7
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -161,6 +175,7 @@ __global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {
             }
             __builtin_amdgcn_sched_barrier(0);     // (bounded live range of the gathered values: the first strip's loads are in flight too)
         }
+    }
     }
     float w2r[3];            // [tap group]: block b = channel b: w2[tap 4 g + i][channel]
 #pragma unroll
@@ -355,9 +370,9 @@ __global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {
 // training form of the mask head forward: h [n,64,64,16], z [n,64,64], zpart [mask_train_partials(n)][2]
 int mask_train_partials(int n) { return n; }
 int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
-                      const float* b2, float* h, float* z, float* zpart, hipStream_t st) {
+                      const float* b2, float* h, float* z, float* zpart, const float* w0_pack, hipStream_t st) {
     if (n <= 0) return CGS_OK;
-    MaskFwdParams P{img, o0, w0, b0, w2, b2, h, z, zpart, n, g_maskfwd_stamps};
+    MaskFwdParams P{img, o0, w0, b0, w2, b2, h, z, zpart, n, g_maskfwd_stamps, w0_pack};
     if (img_kind == CGS_SRC_U8) hipLaunchKernelGGL(mask_fwd_kernel<SRC_U8C3>, dim3(n), dim3(256), 0, st, P);
     else hipLaunchKernelGGL(mask_fwd_kernel<SRC_F32C3>, dim3(n), dim3(256), 0, st, P);
     CGS_HIP_CHECK_LAUNCH();

@@ -273,7 +273,43 @@ struct TailDecFwdParams {
     int n;
     int nblocks;
     unsigned long long* dbg;
+    const float* m0_w; float* m0_pack;      // rider (optional): masker.0's weight registers of the mask-head forward kernel, packed once
 };
+
+// The mask head forward (mask_fwd.hip) multiplies with per-lane weight REGISTERS: wimg[4][2] (image channels, block b of register k
+// = step 16 k + b = tap * 3 + channel) and wups[4][4][2] (upsampled channels with the nearest-upsample folded: per output position
+// the taps that fall on the same source pixel pre-summed).  Each of its 512 workgroups used to rebuild them from masker.0's HWIO
+// weights (LDS copy + ~140 gathers + sums: 11 k of a workgroup's 122 k cycles); one spare workgroup of the launch BEFORE it builds
+// them once: pack[k * 64 + lane], k = 0..7 wimg[g][r] (g * 2 + r), 8..39 wups[pos][g][ry] ((pos * 4 + g) * 2 + ry).
+__device__ __forceinline__ void mask0_pack_weights(const float* __restrict__ w0, float* __restrict__ pack, int lane) {
+    const int lb = lane >> 2, li = lane & 3;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int step = 16 * k + lb;
+            pack[(g * 2 + k) * 64 + lane] = step < 27 ? w0[((step / 3) * 11 + step % 3) * 16 + 4 * g + li] : 0.f;
+        }
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            const int oy = pos >> 1, ox = pos & 1;
+#pragma unroll
+            for (int ry = 0; ry < 2; ++ry) {
+                const int rx = lb >> 3, ci = lb & 7;
+                const int ky0 = (oy == 0) ? (ry == 0 ? 0 : 1) : (ry == 0 ? 0 : 2), ky1 = (oy == 0) ? (ry == 0 ? 0 : 2) : (ry == 0 ? 1 : 2);
+                const int kx0 = (ox == 0) ? (rx == 0 ? 0 : 1) : (rx == 0 ? 0 : 2), kx1 = (ox == 0) ? (rx == 0 ? 0 : 2) : (rx == 0 ? 1 : 2);
+                auto wv = [&](int ky, int kx) { return w0[((ky * 3 + kx) * 11 + 3 + ci) * 16 + 4 * g + li]; };
+                const float w00 = wv(ky0, kx0), w01 = wv(ky0, kx1), w10 = wv(ky1, kx0), w11 = wv(ky1, kx1);
+                const bool my = ky1 > ky0, mx = kx1 > kx0;
+                float sum = w00;                     // (the order of mask_fwd_kernel's own set-up: bit-identical registers)
+                sum += mx ? w01 : 0.f;
+                sum += my ? w10 : 0.f;
+                sum += (mx && my) ? w11 : 0.f;
+                pack[(8 + (pos * 4 + g) * 2 + ry) * 64 + lane] = sum;
+            }
+        }
+    }
+}
 
 using T1F = TileP<16, 16, 16, 16, 292>;     // cat(e1, up(o2)) of the forward decoder tail (2-way conflicts on the b128 reads accepted)
 
@@ -284,6 +320,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     __shared__ __attribute__((aligned(16))) float w2s[216 * 8];
     __shared__ float part[4][16][16];       // dec_model.3: the waves split K, partial [pixel][co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)blockIdx.x == P.nblocks) {          // the rider workgroup (launched only when m0_pack is given)
+        if (wave == 0) mask0_pack_weights(P.m0_w, P.m0_pack, lane);
+        return;
+    }
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15, kq = lane >> 4;
     // the first image's loads are requested before the set-up (and the next image's as soon as the tiles are filled)
@@ -396,16 +436,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
-extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
-                                const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream) {
-    if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1) return CGS_ERR_BADARG;
+extern "C" int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                                     const float* o4, float* o3, float* o2, float* o1, const float* w_m0, float* m0_pack,
+                                     cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1 || (m0_pack && !w_m0)) return CGS_ERR_BADARG;
     if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr};
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr,
+                       w_m0, m0_pack};
     const int blocks = tail_blocks(n, tail_fwd_cap());
-    hipLaunchKernelGGL(tail_dec_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(tail_dec_fwd_kernel, dim3(blocks + (m0_pack ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                                const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream) {
+    return cgs_tail_dec_fwd_pack(n, w, e1, e2, e3, o4, o3, o2, o1, nullptr, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

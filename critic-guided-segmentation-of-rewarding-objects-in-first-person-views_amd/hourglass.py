@@ -449,8 +449,14 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             if o.get(nm) is None:
                 o[nm] = torch.empty(shp, device=dev, dtype=torch.float32)
         tw = tail_dec_weights(flat, lay)
-        _lib.call("cgs_tail_dec_fwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
-                  _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), _stream())
+        m0pack = None
+        if keep_hm and MASK_TRAIN_FUSED and zpart is not None:
+            # the mask head forward's weight registers, built once by a spare workgroup of this launch (the mask head follows two launches later)
+            m0pack = o.get("m0pack")
+            if m0pack is None:
+                m0pack = o["m0pack"] = torch.empty(40 * 64, device=dev, dtype=torch.float32)
+        _lib.call("cgs_tail_dec_fwd_pack", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
+                  _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack), _stream())
         prev = o["o1"]
     for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
         if TAIL_FWD and name in ("o3", "o2", "o1"):
@@ -472,10 +478,10 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             for k, shp in (("hm", (n, 64, 64, 16)), ("Z", (n, 64, 64))):
                 if o.get(k) is None:
                     o[k] = torch.empty(shp, device=dev, dtype=torch.float32)
-            _lib.call("cgs_mask_train_fwd", n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
+            _lib.call("cgs_mask_train_fwd_packed", n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
                       C.c_void_p(fp + 4 * lay.off("masker.0.weight")), C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
                       C.c_void_p(fp + 4 * lay.off("masker.2.weight")), C.c_void_p(fp + 4 * lay.off("masker.2.bias")),
-                      _p(o["hm"]), _p(o["Z"]), _p(zpart), _stream())
+                      _p(o["hm"]), _p(o["Z"]), _p(zpart), _p(o.get("m0pack")) if TAIL_FWD else None, _stream())
             return o
         shape = (n, hw, hw) if co == 1 else (n, hw, hw, co)
         if o.get(name) is None:

@@ -136,6 +136,11 @@ int cgs_mask_train_fwd_partials(int32_t n);
 int cgs_mask_train_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
                        const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* h, float* z,
                        float* zpart, cgs_stream_t stream);
+/* The same with masker.0's per-lane weight registers (40 x 64 floats) taken from w_m0_pack instead of rebuilt by every workgroup;
+ * cgs_tail_dec_fwd_pack -- the launch before it on the training path -- builds them in one spare workgroup (w_m0_pack = NULL: as above). */
+int cgs_mask_train_fwd_packed(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio, const float* b_m0,
+                              const float* w_m2, const float* b_m2, float* h, float* z, float* zpart, const float* w_m0_pack,
+                              cgs_stream_t stream);
 
 /* Same contract with fp16 OPERANDS for the masker.0 GEMM (v_mfma_f32_16x16x16_f16, fp32 accumulate; masker.2 stays
  * fp32): BASELINE config 4 ("-process inference-only, fp16 conv kernels").  Opt-in: z differs from the fp32 result by
@@ -171,6 +176,10 @@ int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, 
                      cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
 int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
+/* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
+ * forward's weight registers m0_pack [40 * 64] (cgs_mask_train_fwd_packed).                                                     */
+int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                          const float* o4, float* o3, float* o2, float* o1, const float* w_m0, float* m0_pack, cgs_stream_t stream);
 
 /* Backward of the same layers.  cgs_tail_enc_bwd: one critic pass, from dpred [n] to de1 [n,16,16,8] (gradient w.r.t. e1,
  * input of features.3's backward).  dE1 / dE2 / dE3 (skip gradients from the decoder, shapes of e1 / e2 / e3) and d_o4 [n,32]
