@@ -277,8 +277,8 @@ static int wgrad_per(int co) {      // blocks of 16 output channels per workgrou
     const int nblk = (co + 15) / 16;
     return nblk == 1 ? 1 : ((nblk == 2 || nblk == 4) ? 2 : 3);
 }
-static int wgrad_groups(int n, int ncib, int ncog) {      // image shares: about 1024 workgroups in flight, at most one per image
-    int g = (1024 + ncib * ncog - 1) / (ncib * ncog);
+static int wgrad_groups(int n, int ncib, int ncog) {      // image shares: about 1536 workgroups (three rounds of two per CU; swept on the chfak-5 step, tools/sweep_genwgrad.sh: 512: 9.33, 768: 8.74, 1024: 8.82, 1536: 8.51, 2048: 8.66, 3072: 8.59 ms), at most one per image
+    int g = (1536 + ncib * ncog - 1) / (ncib * ncog);
     return g < n ? g : n;
 }
 
