@@ -18,6 +18,7 @@
 // masks these kernels draw.
 #include "tail4.h"
 #include "head_wgrad.h"
+#include "wgrad_dec0.h"
 
 namespace {
 
@@ -478,6 +479,7 @@ struct TailEncBwdParams {
     int n;
     int nblocks;
     unsigned long long* dbg;
+    WDec0Params rider;      // optional: dec_model.0's weight gradient as spare workgroups of this launch (rider.slab != NULL)
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P) {
@@ -485,17 +487,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
     constexpr int OX1 = 0, OX2 = OX1 + T16x8::FLOATS, ODY2 = OX2 + T8x8::FLOATS, ODY3 = ODY2 + T16x8::FLOATS, OEND = ODY3 + T8x16::FLOATS;
-    __shared__ __attribute__((aligned(16))) float tiles[OEND];           // after the loop: scratch of the weight-gradient reduction
+    // one LDS block, carved by hand: the rider workgroups below (dec_model.0's weight gradient) use the same bytes their own way
+    constexpr int OW6 = (OEND + 3) & ~3, OW10 = OW6 + 72 * 8, OXS = OW10 + 72 * 16, OM2 = OXS + 256, OD2 = OM2 + 512, OO1 = OD2 + 512,
+                  OAM2 = OO1 + 2048, ODZ4 = OAM2 + 64, OALL = ODZ4 + 32;
+    constexpr int LDS_ALL = OALL > kWD0LdsFloats ? OALL : kWD0LdsFloats;
+    __shared__ __attribute__((aligned(16))) float lds_all[LDS_ALL];
+    if ((int)blockIdx.x >= P.nblocks) {          // riders (launched only when rider.slab is given): see cgs_tail_enc_bwd_rider
+        wgrad_dec0_body(P.rider, (int)blockIdx.x - P.nblocks, (int)gridDim.x - P.nblocks, lds_all);
+        return;
+    }
+    float* tiles = lds_all;                                              // after the loop: scratch of the weight-gradient reduction
     float* x1 = tiles + OX1;       // e1: X of features.6
     float* x2 = tiles + OX2;       // dropout(e2): X of features.10
     float* dy2 = tiles + ODY2;     // gradient at features.6's pre-pool output
     float* dy3 = tiles + ODY3;     // gradient at features.10's pre-pool output
-    __shared__ __attribute__((aligned(16))) float w6s[72 * 8], w10s[72 * 16];
-    __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat
-    __shared__ __attribute__((aligned(16))) float m2s[512], d2s[512];    // Dropout multipliers of e2; skip gradient dE2
-    __shared__ __attribute__((aligned(16))) float o1s[2048];             // d e1 before the coalesced store
-    __shared__ uint32_t am2s[64];
-    __shared__ float dz4s[32];
+    float* w6s = lds_all + OW6; float* w10s = lds_all + OW10;
+    float* xs = lds_all + OXS;                                           // dropout(e3), flat
+    float* m2s = lds_all + OM2; float* d2s = lds_all + OD2;              // Dropout multipliers of e2; skip gradient dE2
+    float* o1s = lds_all + OO1;                                          // d e1 before the coalesced store
+    uint32_t* am2s = (uint32_t*)(lds_all + OAM2);
+    float* dz4s = lds_all + ODZ4;
     static_assert(OEND >= 4 * 5 * 256, "reduction scratch fits the tile area");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
@@ -700,20 +711,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
 extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }
 
+// cgs_tail_enc_bwd with dec_model.0's weight gradient (cgs_conv3x3_bwd_weight of that layer: n_r images, skip input e0_r [n_r,32,32,8],
+// low-resolution input o1_r [n_r,16,16,8], output gradient dy_r [n_r,32,32,8], slab_r [nslab_r][1160]) as nslab_r SPARE workgroups of
+// the launch: a tail launch at N = 512 is one image per workgroup and two workgroups per CU -- a third fits (168 registers, 50 KB of
+// LDS each) and only the step's final reduction waits for that gradient.  slab_r = NULL: plain cgs_tail_enc_bwd.
+extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                                      const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                                      const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
+                                      const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
+                                      float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                                      int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                                      cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
+    if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
+    if (slab_r && (n_r <= 0 || !e0_r || !o1_r || !dy_r || nslab_r <= 0 || nslab_r > n_r * kStrips)) return CGS_ERR_BADARG;
+    if (n == 0) return slab_r ? CGS_ERR_BADARG : CGS_OK;
+    TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1,
+                       hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
+                       WDec0Params{e0_r, o1_r, dy_r, slab_r, n_r, n_r * kStrips}};
+    const int riders = slab_r ? nslab_r : 0;
+    hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                                 const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
                                 const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
                                 const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
                                 cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
-    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
-    if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
-    if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
-    if (n == 0) return CGS_OK;
-    TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1,
-                       hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr};
-    hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), 0, (hipStream_t)stream, P);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
+    return cgs_tail_enc_bwd_rider(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
+                                  slab10, slab6, drop_e2, drop_e3, drop_h1, 0, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

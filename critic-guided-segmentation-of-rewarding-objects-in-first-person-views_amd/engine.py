@@ -264,8 +264,11 @@ class HourglassEngine:
         pm = hg.SlabPlan()
         # live: the 1x1 bottleneck conv's backward runs inside the critic head kernel (frozen: no critic backward on A,
         # the masker does it itself)
+        # (live critic, one module: dec_model.0's weight gradient rides in the A pass's tail backward launch below)
+        defer = [] if (self.live and not self.separate and hg.TAIL_BWD) else None
         d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side,
-                                   pw_in_head=self.live or self.separate)
+                                   pw_in_head=self.live or self.separate, defer_dec0=defer)
+        rider = defer[0] if defer else None
         ps = hg.SlabPlan()
         if self.separate:
             # the skip gradients (and the bottleneck's) go into the SECOND critic; its own head sees no loss (dpred = 0)
@@ -280,7 +283,7 @@ class HourglassEngine:
             d_o4, d_emb[4] = d_emb[4], None
             hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
                                n_add=n, ws=self._ws["cb_a"], side=self.side, loss=loss_a, head_sink=sink_c,
-                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")))
+                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")), rider=rider)
         if sink_c:
             hg.head_wgrad(sink_c, pc, self.lc, self._ws["cb_a"])
         self.side.join()

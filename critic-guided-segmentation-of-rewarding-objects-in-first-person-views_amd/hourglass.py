@@ -30,6 +30,9 @@ MASK_TRAIN_FUSED = True
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
 TAIL_FWD = True
 TAIL_BWD = True
+# dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
+DEC0_WGRAD_RIDER = True
+DEC0_RIDERS = 256
 _both = "c3,c2,c1,c0,d3,d2,d1"   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
@@ -285,7 +288,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None, head_sink=None) -> Optional[torch.Tensor]:
+                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None, head_sink=None, rider=None) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
     bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.
     mix_bwd = (A_u8, B_u8, Z, inject, l1_scale, l2_scale, dzpre): x are the replaced|injected mixes of n_a = len(A) images;
@@ -324,13 +327,16 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         hvec = buf("hvec", (n, 384)) if need_wgrad else None
         d_cur = buf("de1", (n, 16, 16, 8))
         tw = tail_enc_weights(flat, lay, (pw_bwd[1].value, None) if use_pw else None)
-        _lib.call("cgs_tail_enc_bwd", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
+        rd = rider if rider is not None else (0, None, None, None, None, 0)      # (n, e0, o1, dy, slab, rows): dec_model.0's weight gradient
+        _lib.call("cgs_tail_enc_bwd_rider", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
                   _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
                   _p(loss[0]) if (dpred is None and loss is not None) else None, float(loss[1]) if loss is not None else 0.0,
                   int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None,
                   _p(d_embeds[2]) if has_add else None, _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None,
                   n_add if has_add else 0, _p(d_cur), _p(hvec), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
-                  drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
+                  drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
+                  int(rd[0]), _p(rd[1]), _p(rd[2]), _p(rd[3]), _p(rd[4]), int(rd[5]), _stream())
+        rider = None
         if need_wgrad:
             plan.add(sl10, nsl, 9 * 8 * 16 + 16, lay.off("features.10.weight"))
             plan.add(sl6, nsl, 9 * 8 * 8 + 8, lay.off("features.6.weight"))
@@ -340,6 +346,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             else:
                 head_wgrad([rng], plan, lay, ws)
         first_layer = 1
+    if rider is not None:
+        raise _lib.CgsError("critic_backward: a deferred dec_model.0 weight gradient needs the tail backward launch to ride with")
     # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
     if first_layer == 3:
       if True:
@@ -503,7 +511,7 @@ def zpart_count(n: int) -> int:
 def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,
                     saved: Dict[str, torch.Tensor], dzpre: torch.Tensor, plan: SlabPlan,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    pw_in_head: bool = False) -> List[torch.Tensor]:
+                    pw_in_head: bool = False, defer_dec0: Optional[list] = None) -> List[torch.Tensor]:
     """dzpre: gradient w.r.t. the mask head's PRE-sigmoid output [n,64,64].
     Returns [dE0, dE1, dE2, dE3, dE4]: gradients w.r.t. the encoder embeds (skip connections).
     pw_in_head: stop at the bottleneck -- the 5th entry is then d o4 [n,32] (gradient w.r.t. the 1x1 conv's OUTPUT) and
@@ -590,8 +598,14 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
         slab = buf(f"slab_dec{li}", (nsl, cnt))
-        with side.fork():
-            _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
+        if li == 3 and defer_dec0 is not None and DEC0_WGRAD_RIDER:
+            # dec_model.0's weight gradient: only the final reduction waits for it -- the caller hands it to the last critic pass's tail
+            # launch, whose spare workgroup slots compute it (critic_backward(rider=...)): one persistent rider per CU
+            nsl = min(nsl, DEC0_RIDERS)
+            defer_dec0.append((n, srcs_a[li], srcs_b[li], dy, slab, nsl))
+        else:
+            with side.fork():
+                _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(srcs_a[li]), _p(srcs_b[li]), _p(dy), None, _p(slab), _stream())
         plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
         if head_fused:
             # (VALU build) masker.2 data gradient rebuilt inside the masker.0 data-gradient kernel

@@ -203,6 +203,16 @@ int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, 
                      const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2, const float* dE3, const float* d_o4,
                      int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
                      cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+/* The same with dec_model.0's weight gradient (cgs_conv3x3_bwd_weight of that layer over n_r images: skip input e0_r [n_r,32,32,8],
+ * low-resolution input o1_r [n_r,16,16,8], output gradient dy_r [n_r,32,32,8], slab_r [nslab_r][1160], nslab_r <= 4 n_r) computed by
+ * nslab_r spare workgroups of the launch (slab_r = NULL: none).                                                                    */
+int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                           const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                           const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2,
+                           const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
+                           cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                           int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                           cgs_stream_t stream);
 int cgs_tail_head_wgrad_slabs(int32_t n_total);
 int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
                         const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
