@@ -96,6 +96,7 @@ SIGNATURES = {
     "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "cgs_gen_flip_weights": (i32, [i32, i32, vp, vp, vp]),
     "cgs_gen_conv3x3_bwd_data": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
+    "cgs_gen_conv3x3_bwd_data_split": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_conv3x3_bwd_weight_slabs": (i32, [i32, i32, i32, i32]),
     "cgs_gen_conv3x3_bwd_weight": (i32, [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_cat_split": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp]),

@@ -153,6 +153,7 @@ struct Gen4Launch {
     GenSrc src; const float* wp; const float* bias; float* out; uint8_t* argmax; const float* addend;
     int n_addend, n, hw, co, act, pool;
     float slope;
+    float* out2; int split_ca, split_ups;
 };
 int gen4_conv_launch(const Gen4Launch& L, hipStream_t st);
 long gen4_packed_floats(int ca, int cb, int co);
@@ -178,7 +179,7 @@ extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     Gen4Launch L{GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1}, wp, bias, out, argmax,
-                 nullptr, 0, n, hw, co, act, pool, slope};
+                 nullptr, 0, n, hw, co, act, pool, slope, nullptr, 0, 0};
     return gen4_conv_launch(L, (hipStream_t)stream);
 }
 
@@ -193,7 +194,20 @@ extern "C" int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (n == 0) return CGS_OK;
     Gen4Launch L{GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1}, wp, nullptr, d_cat, nullptr,
-                 addend, n_addend, n, hw, ci, CGS_ACT_NONE, 0, 0.f};
+                 addend, n_addend, n, hw, ci, CGS_ACT_NONE, 0, 0.f, nullptr, 0, 0};
+    return gen4_conv_launch(L, (hipStream_t)stream);
+}
+
+// The data gradient of a layer over cat(A [ca], nearest-up_ups(B [cb])) written straight as d_a [n,hw,hw,ca] (may be NULL) and d_b
+// [n,hw/ups,hw/ups,cb] (the sum over each ups x ups cell) -- cgs_gen_conv3x3_bwd_data + cgs_gen_cat_split without the d_cat tensor.
+// CGS_ERR_UNSUPPORTED when the kernel's output passes do not fall on one side of the split each (the caller then takes the two-step form).
+extern "C" int cgs_gen_conv3x3_bwd_data_split(int32_t n, int32_t hw, int32_t co, int32_t ca, int32_t cb, int32_t ups, const float* dy,
+                                              const float* wp, float* d_a, float* d_b, cgs_stream_t stream) {
+    if (n < 0 || !dy || !wp || !d_b || co <= 0 || ca <= 0 || cb <= 0 || (ca & 3) || (cb & 3)) return CGS_ERR_BADARG;
+    if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return CGS_OK;
+    Gen4Launch L{GenSrc{dy, nullptr, nullptr, GEN_SRC_F32, co, 0, 1}, wp, nullptr, d_a, nullptr, nullptr, 0, n, hw, ca + cb, CGS_ACT_NONE, 0, 0.f,
+                 d_b, ca, ups};
     return gen4_conv_launch(L, (hipStream_t)stream);
 }
 

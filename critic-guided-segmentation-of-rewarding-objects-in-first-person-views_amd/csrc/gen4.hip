@@ -33,6 +33,9 @@ struct Gen4Params {
     float slope;
     int imgs, th, pw, rows, lw, npass, ngt;             // ngt: output-channel groups of 4 of the whole layer
     int dbuf;                                           // 1: two tile buffers (chunk c + 1 is staged while chunk c multiplies)
+    // split (data gradient of a layer over cat(A [split_ca], nearest-up(B))): passes below split_ca write d_a = out with row stride
+    // split_ca, passes above it write the cell sums (the upsample's backward) to out2 [n, hw >> split_ush, hw >> split_ush, co - split_ca]
+    float* out2; int split_ca, split_ush;
     unsigned long long* dbg;                            // debug: per-workgroup phase stamps (tools/gen4_stamps.py), NULL in the product path
 };
 unsigned long long* g_gen4_stamps = nullptr;
@@ -259,6 +262,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
                     }
                 }
             }
+        } else if (P.split_ca > 0 && 4 * g0 >= P.split_ca) {
+            // second source of a cat: the gradient of nearest-up(B) is the sum over each ups x ups cell -- a quad of lanes (ups = 2) or the
+            // 16 lanes of a 4x4 image (ups = 4).  The tile's cells are contiguous in memory like a pooled map.
+            const int ush = P.split_ush, cbn = P.co - P.split_ca;
+            const int wq = W >> ush, cells_img = (P.th >> ush) * wq;
+            const int lin = il * cells_img + (y >> ush) * wq + (x >> ush);
+            const bool writer = ush == 1 ? pos == 0 : (lane & 15) == 0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < ngv) {
+                    float c4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = quad_sum(acc[g][r]);
+                        if (ush == 2) { v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); }
+                        c4[r] = v;
+                    }
+                    if (writer) *(float4*)(ot + lin * pitch + 4 * g) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+                }
+            }
+            __syncthreads();
+            const int ncell = 256 >> (2 * ush);
+            const size_t pix0 = P.imgs == 1 ? ((size_t)img0 * (H >> ush) + (row0 >> ush)) * wq : (size_t)img0 * (H >> ush) * wq;
+            const size_t pixend = (size_t)P.n * (H >> ush) * wq;
+            if (cg < ngv) {
+                for (int px = cpx; px < ncell; px += 16) {
+                    if (pix0 + px < pixend)
+                        *(float4*)(P.out2 + (pix0 + px) * cbn + (4 * (g0 + cg) - P.split_ca)) = *(const float4*)(ot + px * pitch + 4 * cg);
+                }
+            }
         } else if (!P.pool) {
             // the tile's 256 pixels are contiguous in memory
             const int hwp = P.th * W;                                             // pixels per image part of the tile
@@ -274,12 +307,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
                 __syncthreads();
                 const size_t hp0 = pix0;
                 if (vec) {
-                    if (cg < ngv) {
-                        const size_t o0 = (hp0 + cpx) * P.co + 4 * (g0 + cg);
+                    const int ostride = P.split_ca > 0 ? P.split_ca : P.co;      // (split: this pass lies below split_ca: d_a's own row stride)
+                    if (cg < ngv && P.out) {
+                        const size_t o0 = (hp0 + cpx) * ostride + 4 * (g0 + cg);
 #pragma unroll 4
                         for (int k = 0; k < 16; ++k) {
                             const int px = cpx + 16 * k;
-                            const size_t gp = hp0 + px, o = o0 + (size_t)16 * k * P.co;
+                            const size_t gp = hp0 + px, o = o0 + (size_t)16 * k * ostride;
                             if (gp < pixend) {
                                 float4 t = *(const float4*)(ot + px * pitch + 4 * cg);
                                 if (gp < addend_end) { const float4 a = *(const float4*)(P.addend + o); t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
@@ -341,6 +375,7 @@ struct Gen4Launch {
     GenSrc src; const float* wp; const float* bias; float* out; uint8_t* argmax; const float* addend;
     int n_addend, n, hw, co, act, pool;
     float slope;
+    float* out2; int split_ca, split_ups;      // (optional: data gradient of a cat layer written as d_a / cell-summed d_b)
 };
 
 // output-channel groups of 4: passes (workgroups over the same tile) x groups per pass (the kernel's NG)
@@ -384,6 +419,14 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     P.ngt = (L.co + 3) / 4;
     int ng;
     gen4_groups(L.co, P.npass, ng);
+    if (L.split_ca > 0) {
+        // every output pass must lie on one side of the split, whole 4-channel groups on both sides, no pooling / addend / activation
+        const int ush = L.split_ups == 4 ? 2 : (L.split_ups == 2 ? 1 : -1);
+        if (ush < 0 || (L.split_ca % (4 * ng)) || ((L.co - L.split_ca) & 3) || L.co <= L.split_ca || L.pool || L.addend || !L.out2 ||
+            (ush == 2 && hw != 4) || hw < (1 << ush))
+            return CGS_ERR_UNSUPPORTED;
+        P.out2 = L.out2; P.split_ca = L.split_ca; P.split_ush = ush;
+    }
     const int tiles = P.imgs == 1 ? L.n * (hw / P.th) : (L.n + P.imgs - 1) / P.imgs;
     // LDS: the input tile -- two buffers when there is more than one chunk and three (NG = 10) / four workgroups still fit a CU;
     // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling: 64 pixels + 64 x ng argmax words)

@@ -412,11 +412,17 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
         key, ups, low = f"dec_model.{i}", (4 if i == 3 else 2), lows[i]
         ca, cb = d[i], low.shape[-1]
         _wgrad(plan, ws, f"dec{i}", goff + lay.off(key + ".weight"), n, hw, embeds[i], low, ups, d_o, None, d[i])
-        dcat = ws.buf(f"dcat_d{i}", (n, hw, hw, ca + cb), dev)
-        _bwd_data(n, hw, d[i], ca + cb, d_o, None, _flip(ws, flat, lay, key, ca + cb, d[i]), dcat)
         d_emb[i] = ws.buf(f"dEmb{i}", (n, hw, hw, ca), dev) if need_embed_grads else None
         d_low = ws.buf(f"d_o{i + 1}", (n, hw // ups, hw // ups, cb), dev)
-        _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, _p(dcat), _p(d_emb[i]), _p(d_low), _s())
+        # d_cat straight as (skip gradient, cell-summed low-resolution gradient) where the kernel's output passes allow it
+        wp = pack_weights(_flip(ws, flat, lay, key, ca + cb, d[i]), d[i], 0, ca + cb, dev, transposed=True)
+        rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, hw, d[i], ca, cb, ups, _p(d_o), _p(wp), _p(d_emb[i]), _p(d_low), _s())
+        if rc == _lib.ERR_UNSUPPORTED:
+            dcat = ws.buf(f"dcat_d{i}", (n, hw, hw, ca + cb), dev)
+            _bwd_data(n, hw, d[i], ca + cb, d_o, None, _flip(ws, flat, lay, key, ca + cb, d[i]), dcat)
+            _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, _p(dcat), _p(d_emb[i]), _p(d_low), _s())
+        else:
+            _lib.check(rc, "cgs_gen_conv3x3_bwd_data_split")
         d_o = d_low
     # dec_model.4: o4 = e4 W + b (1x1 convolution on the 1x1 map)
     d_o4 = d_o.view(n, nb)

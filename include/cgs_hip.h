@@ -411,6 +411,11 @@ int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, cons
 int cgs_gen_flip_weights(int32_t ci, int32_t co, const float* w, float* wflip, cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, const float* dy, const uint8_t* dy_argmax,
                              const float* wp, const float* addend, int32_t n_addend, float* d_cat, cgs_stream_t stream);
+/* d_cat of a layer over cat(A [ca], nearest-up_ups(B [cb])) written straight as d_a [n,hw,hw,ca] (NULL: not wanted) and d_b
+ * [n,hw/ups,hw/ups,cb] (sum over each ups x ups cell): cgs_gen_conv3x3_bwd_data + cgs_gen_cat_split without the d_cat tensor; wp as for
+ * cgs_gen_conv3x3_bwd_data with ci = ca + cb.  CGS_ERR_UNSUPPORTED when ca is not a multiple of the kernel's output pass width. */
+int cgs_gen_conv3x3_bwd_data_split(int32_t n, int32_t hw, int32_t co, int32_t ca, int32_t cb, int32_t ups, const float* dy,
+                                   const float* wp, float* d_a, float* d_b, cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co);
 int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                const void* src_a, const float* src_b, const float* dy, const uint8_t* dy_argmax, float* slab,

@@ -123,3 +123,46 @@ def test_gen4_rejects_bad_arguments():
     assert lib.cgs_gen_conv_packed_floats(3, 40, 16) == 3 * 9 * 4 * 64
     assert lib.cgs_gen_conv_packed_floats(40, 6, 40) < 0          # second source: whole groups of 4 channels
     assert lib.cgs_gen_conv_pack_weights(8, 4, 8, 1, C.c_void_p(16), C.c_void_p(16), None) < 0      # transposed: one source only
+
+
+@pytest.mark.parametrize("n,hw,co,ca,cb,ups", [
+    (3, 32, 40, 40, 40, 2),      # dec_model.0 at chfak 5: two passes of 10 groups, one per side
+    (5, 16, 24, 24, 24, 2),      # chfak 3
+    (19, 4, 80, 80, 160, 4),     # dec_model.3: x4 cells = whole 4x4 images, ragged last tile
+    (6, 8, 40, 40, 80, 2),
+])
+def test_gen4_split_data_gradient_equals_two_step_form(n, hw, co, ca, cb, ups):
+    """cgs_gen_conv3x3_bwd_data_split (d_a and the cell-summed d_b written by the convolution's epilogue) against
+    cgs_gen_conv3x3_bwd_data + cgs_gen_cat_split: d_a bit-identical, d_b up to the order of the cell sum."""
+    from cgs_amd import _lib, generic as gen
+    rs = np.random.RandomState(n + hw + co)
+    dev = torch.device("cuda:0")
+    dy = torch.from_numpy(rs.randn(n, hw, hw, co).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rs.randn(9, ca + cb, co) / (3.0 * np.sqrt(ca + cb))).astype(np.float32)).to(dev)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    dcat = torch.empty(n, hw, hw, ca + cb, device=dev)
+    gen._bwd_data(n, hw, co, ca + cb, dy, None, w.data_ptr(), dcat)
+    da_ref = torch.empty(n, hw, hw, ca, device=dev)
+    db_ref = torch.empty(n, hw // ups, hw // ups, cb, device=dev)
+    _lib.call("cgs_gen_cat_split", n, hw, ca, cb, ups, P(dcat), P(da_ref), P(db_ref), gen._s())
+    wp = gen.pack_weights(w.data_ptr(), co, 0, ca + cb, dev, transposed=True)
+    d_a = torch.full_like(da_ref, float("nan"))
+    d_b = torch.full_like(db_ref, float("nan"))
+    _lib.call("cgs_gen_conv3x3_bwd_data_split", n, hw, co, ca, cb, ups, P(dy), P(wp), P(d_a), P(d_b), gen._s())
+    assert torch.equal(d_a, da_ref)
+    rel_close(d_b.cpu().numpy(), db_ref.cpu().numpy(), "cell-summed low-resolution gradient")
+    # the skip gradient is optional
+    d_b2 = torch.full_like(db_ref, float("nan"))
+    _lib.call("cgs_gen_conv3x3_bwd_data_split", n, hw, co, ca, cb, ups, P(dy), P(wp), None, P(d_b2), gen._s())
+    assert torch.equal(d_b2, d_b)
+
+
+def test_gen4_split_refuses_passes_that_straddle_the_split():
+    from cgs_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    t = torch.zeros(1 << 16, device=dev)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    # 16 + 16 channels = 8 groups = ONE pass of 8: both sides in one workgroup
+    assert lib.cgs_gen_conv3x3_bwd_data_split(1, 8, 16, 16, 16, 2, P(t), P(t), P(t), P(t), None) == _lib.ERR_UNSUPPORTED
+    assert lib.cgs_gen_conv3x3_bwd_data_split(1, 8, 16, 6, 16, 2, P(t), P(t), P(t), P(t), None) == _lib.ERR_BADARG
