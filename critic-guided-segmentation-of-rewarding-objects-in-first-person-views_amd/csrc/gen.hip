@@ -157,7 +157,7 @@ struct Gen4Launch {
 };
 int gen4_conv_launch(const Gen4Launch& L, hipStream_t st);
 long gen4_packed_floats(int ca, int cb, int co);
-int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, hipStream_t st);
+int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st);
 
 extern "C" int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
@@ -167,7 +167,16 @@ extern "C" int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co
 extern "C" int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
                                          cgs_stream_t stream) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !wp || (transposed && cb)) return CGS_ERR_BADARG;
-    return gen4_pack_launch(ca, cb, co, transposed ? 1 : 0, w, wp, (hipStream_t)stream);
+    return gen4_pack_launch(ca, cb, co, transposed ? 1 : 0, w, wp, co, 0, (hipStream_t)stream);
+}
+
+// The data gradient's operand for a WINDOW of the layer's input channels: w = HWIO [9][ci_layer][co_layer]; the packed operand maps dY
+// (co_layer channels) to d(input channels [ci_off, ci_off + ci_n)) -- e.g. only the decoder channels of cat(image, up(o0)), whose image
+// part needs no gradient.
+extern "C" int cgs_gen_conv_pack_weights_window(int32_t co_layer, int32_t ci_layer, int32_t ci_off, int32_t ci_n, const float* w, float* wp,
+                                                cgs_stream_t stream) {
+    if (co_layer <= 0 || ci_layer <= 0 || ci_off < 0 || ci_n <= 0 || ci_off + ci_n > ci_layer || !w || !wp) return CGS_ERR_BADARG;
+    return gen4_pack_launch(co_layer, 0, ci_n, 1, w, wp, ci_layer, ci_off, (hipStream_t)stream);
 }
 
 extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
@@ -203,7 +212,7 @@ extern "C" int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32
 // CGS_ERR_UNSUPPORTED when the kernel's output passes do not fall on one side of the split each (the caller then takes the two-step form).
 extern "C" int cgs_gen_conv3x3_bwd_data_split(int32_t n, int32_t hw, int32_t co, int32_t ca, int32_t cb, int32_t ups, const float* dy,
                                               const float* wp, float* d_a, float* d_b, cgs_stream_t stream) {
-    if (n < 0 || !dy || !wp || !d_b || co <= 0 || ca <= 0 || cb <= 0 || (ca & 3) || (cb & 3)) return CGS_ERR_BADARG;
+    if (n < 0 || !dy || !wp || !d_b || co <= 0 || ca < 0 || cb <= 0 || (ca & 3) || (cb & 3) || (ca == 0 && d_a)) return CGS_ERR_BADARG;
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (n == 0) return CGS_OK;
     Gen4Launch L{GenSrc{dy, nullptr, nullptr, GEN_SRC_F32, co, 0, 1}, wp, nullptr, d_a, nullptr, nullptr, 0, n, hw, ca + cb, CGS_ACT_NONE, 0, 0.f,

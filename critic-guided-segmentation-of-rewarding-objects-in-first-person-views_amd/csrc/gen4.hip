@@ -43,9 +43,10 @@ unsigned long long* g_gen4_stamps = nullptr;
 
 // ---- weights as register images: wp[((chunk * 9 + tap) * ngp + g) * 64 + 4 * cin + i] = w[tap][channel cin of the chunk][4 g + i],
 // ngp = passes x groups per pass (gen4_groups), zero for the groups past the layer's last ----
-// transposed = 0: w = HWIO [9][ca + cb][co] (forward).  transposed = 1 (cb = 0): w = HWIO [9][co][ca] of the LAYER whose data
-// gradient this is (ca = its output channels = dY's, co = its input channels), read with the taps reversed.
-struct Gen4PackParams { const float* w; float* wp; int ca, cb, co, transposed, total, ngp; };
+// transposed = 0: w = HWIO [9][ca + cb][co] (forward).  transposed = 1 (cb = 0): w = HWIO [9][ci_layer][ca] of the LAYER whose data
+// gradient this is (ca = its output channels = dY's), read with the taps reversed; the operand covers the layer's input channels
+// [ci_off, ci_off + co) (the whole layer: ci_off = 0, co = ci_layer).
+struct Gen4PackParams { const float* w; float* wp; int ca, cb, co, transposed, total, ngp, ci_layer, ci_off; };
 __global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
     const int pa4 = (P.ca + 3) & ~3, ngt = P.ngp, ci_total = P.ca + P.cb;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) {
@@ -54,7 +55,7 @@ __global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
         const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
         float v = 0.f;
         if (real >= 0 && col < P.co)
-            v = P.transposed ? P.w[((size_t)(8 - tap) * P.co + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
+            v = P.transposed ? P.w[((size_t)(8 - tap) * P.ci_layer + P.ci_off + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
         P.wp[e] = v;
     }
 }
@@ -262,7 +263,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
                     }
                 }
             }
-        } else if (P.split_ca > 0 && 4 * g0 >= P.split_ca) {
+        } else if (P.out2 && 4 * g0 >= P.split_ca) {
             // second source of a cat: the gradient of nearest-up(B) is the sum over each ups x ups cell -- a quad of lanes (ups = 2) or the
             // 16 lanes of a 4x4 image (ups = 4).  The tile's cells are contiguous in memory like a pooled map.
             const int ush = P.split_ush, cbn = P.co - P.split_ca;
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
                 __syncthreads();
                 const size_t hp0 = pix0;
                 if (vec) {
-                    const int ostride = P.split_ca > 0 ? P.split_ca : P.co;      // (split: this pass lies below split_ca: d_a's own row stride)
+                    const int ostride = P.out2 ? P.split_ca : P.co;      // (split: this pass lies below split_ca: d_a's own row stride)
                     if (cg < ngv && P.out) {
                         const size_t o0 = (hp0 + cpx) * ostride + 4 * (g0 + cg);
 #pragma unroll 4
@@ -393,11 +394,11 @@ long gen4_packed_floats(int ca, int cb, int co) {
     return (long)nchunk * 9 * npass * ng * 64;
 }
 
-int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, hipStream_t st) {
+int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st) {
     const long total = gen4_packed_floats(ca, cb, co);
     int npass, ng;
     gen4_groups(co, npass, ng);
-    Gen4PackParams P{w, wp, ca, cb, co, transposed, (int)total, npass * ng};
+    Gen4PackParams P{w, wp, ca, cb, co, transposed, (int)total, npass * ng, ci_layer, ci_off};
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(gen4_pack_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, P);
     CGS_HIP_CHECK_LAUNCH();
@@ -419,10 +420,11 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     P.ngt = (L.co + 3) / 4;
     int ng;
     gen4_groups(L.co, P.npass, ng);
-    if (L.split_ca > 0) {
-        // every output pass must lie on one side of the split, whole 4-channel groups on both sides, no pooling / addend / activation
+    if (L.out2) {
+        // every output pass must lie on one side of the split (split_ca = 0: everything is cell-summed), whole 4-channel groups on both
+        // sides, no pooling / addend / activation
         const int ush = L.split_ups == 4 ? 2 : (L.split_ups == 2 ? 1 : -1);
-        if (ush < 0 || (L.split_ca % (4 * ng)) || ((L.co - L.split_ca) & 3) || L.co <= L.split_ca || L.pool || L.addend || !L.out2 ||
+        if (ush < 0 || (L.split_ca % (4 * ng)) || ((L.co - L.split_ca) & 3) || L.co <= L.split_ca || L.pool || L.addend ||
             (ush == 2 && hw != 4) || hw < (1 << ush))
             return CGS_ERR_UNSUPPORTED;
         P.out2 = L.out2; P.split_ca = L.split_ca; P.split_ush = ush;

@@ -401,10 +401,19 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
         grad_fix(d_hm, saved=m["hm"], act="lrelu", slope=0.01)
     # masker.0 over cat(X, up2(o0))
     _wgrad(plan, ws, "mask0", goff + lay.off("masker.0.weight"), n, 64, x, m["o0"], 2, d_hm, None, mc)
-    dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)
-    _bwd_data(n, 64, mc, 3 + d[0], d_hm, None, _flip(ws, flat, lay, "masker.0", 3 + d[0], mc), dcat)
+    # only the decoder channels of cat(X, up2(o0)) need a gradient: the operand covers input channels [3, 3 + d0) and the epilogue sums
+    # the 2x2 cells (no d_cat tensor, no gradient for the image channels)
     d_o = ws.buf("d_o0", (n, 32, 32, d[0]), dev)
-    _lib.call("cgs_gen_cat_split", n, 64, 3, d[0], 2, _p(dcat), None, _p(d_o), _s())
+    nfl = int(_lib.load().cgs_gen_conv_packed_floats(mc, 0, d[0]))
+    wpw = ws.buf("wp_m0_window", (nfl,), dev)
+    _lib.call("cgs_gen_conv_pack_weights_window", mc, 3 + d[0], 3, d[0], C.c_void_p(off("masker.0.weight")), _p(wpw), _s())
+    rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, 64, mc, 0, d[0], 2, _p(d_hm), _p(wpw), None, _p(d_o), _s())
+    if rc == _lib.ERR_UNSUPPORTED:
+        dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)
+        _bwd_data(n, 64, mc, 3 + d[0], d_hm, None, _flip(ws, flat, lay, "masker.0", 3 + d[0], mc), dcat)
+        _lib.call("cgs_gen_cat_split", n, 64, 3, d[0], 2, _p(dcat), None, _p(d_o), _s())
+    else:
+        _lib.check(rc, "cgs_gen_conv3x3_bwd_data_split")
     # linear trunk dec_model.0 .. dec_model.3 over cat(e_i, up(o_{i+1}))
     d_emb: List[Optional[torch.Tensor]] = [None] * 5
     lows = [m["o1"], m["o2"], m["o3"], m["o4"].view(n, 1, 1, nb)]

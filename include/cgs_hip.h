@@ -385,6 +385,10 @@ int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stre
 int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co);
 int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
                               cgs_stream_t stream);
+/* The data gradient's operand for a window of the layer's input channels: w = HWIO [9][ci_layer][co_layer]; wp
+ * (cgs_gen_conv_packed_floats(co_layer, 0, ci_n) floats) maps dY to d(input channels [ci_off, ci_off + ci_n)).                   */
+int cgs_gen_conv_pack_weights_window(int32_t co_layer, int32_t ci_layer, int32_t ci_off, int32_t ci_n, const float* w, float* wp,
+                                     cgs_stream_t stream);
 int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                         int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                         const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
@@ -413,7 +417,8 @@ int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, cons
                              const float* wp, const float* addend, int32_t n_addend, float* d_cat, cgs_stream_t stream);
 /* d_cat of a layer over cat(A [ca], nearest-up_ups(B [cb])) written straight as d_a [n,hw,hw,ca] (NULL: not wanted) and d_b
  * [n,hw/ups,hw/ups,cb] (sum over each ups x ups cell): cgs_gen_conv3x3_bwd_data + cgs_gen_cat_split without the d_cat tensor; wp as for
- * cgs_gen_conv3x3_bwd_data with ci = ca + cb.  CGS_ERR_UNSUPPORTED when ca is not a multiple of the kernel's output pass width. */
+ * cgs_gen_conv3x3_bwd_data with ci = ca + cb (ca = 0, d_a = NULL: the operand of a channel window that lies entirely in B,
+ * cgs_gen_conv_pack_weights_window).  CGS_ERR_UNSUPPORTED when ca is not a multiple of the kernel's output pass width.          */
 int cgs_gen_conv3x3_bwd_data_split(int32_t n, int32_t hw, int32_t co, int32_t ca, int32_t cb, int32_t ups, const float* dy,
                                    const float* wp, float* d_a, float* d_b, cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co);

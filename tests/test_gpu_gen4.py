@@ -166,3 +166,24 @@ def test_gen4_split_refuses_passes_that_straddle_the_split():
     # 16 + 16 channels = 8 groups = ONE pass of 8: both sides in one workgroup
     assert lib.cgs_gen_conv3x3_bwd_data_split(1, 8, 16, 16, 16, 2, P(t), P(t), P(t), P(t), None) == _lib.ERR_UNSUPPORTED
     assert lib.cgs_gen_conv3x3_bwd_data_split(1, 8, 16, 6, 16, 2, P(t), P(t), P(t), P(t), None) == _lib.ERR_BADARG
+
+
+def test_gen4_window_operand_gives_the_second_source_gradient_alone():
+    """masker.0's backward: only the decoder channels of cat(image, up2(o0)) need a gradient -- the operand of input channels [3, 3 + c)
+    (cgs_gen_conv_pack_weights_window) with the all-cell-sum epilogue against the full d_cat + cgs_gen_cat_split."""
+    from cgs_amd import _lib, generic as gen
+    rs = np.random.RandomState(5)
+    dev = torch.device("cuda:0")
+    n, hw, mc, c = 3, 64, 16, 40
+    dy = torch.from_numpy(rs.randn(n, hw, hw, mc).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rs.randn(9, 3 + c, mc) / 20.0).astype(np.float32)).to(dev)
+    P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    dcat = torch.empty(n, hw, hw, 3 + c, device=dev)
+    gen._bwd_data(n, hw, mc, 3 + c, dy, None, w.data_ptr(), dcat)
+    db_ref = torch.empty(n, hw // 2, hw // 2, c, device=dev)
+    _lib.call("cgs_gen_cat_split", n, hw, 3, c, 2, P(dcat), None, P(db_ref), gen._s())
+    wp = torch.empty(int(_lib.load().cgs_gen_conv_packed_floats(mc, 0, c)), device=dev)
+    _lib.call("cgs_gen_conv_pack_weights_window", mc, 3 + c, 3, c, P(w), P(wp), gen._s())
+    d_b = torch.full_like(db_ref, float("nan"))
+    _lib.call("cgs_gen_conv3x3_bwd_data_split", n, hw, mc, 0, c, 2, P(dy), P(wp), None, P(d_b), gen._s())
+    rel_close(d_b.cpu().numpy(), db_ref.cpu().numpy(), "d o0")
