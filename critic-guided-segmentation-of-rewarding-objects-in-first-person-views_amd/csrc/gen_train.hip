@@ -142,6 +142,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) g
     }
 }
 
+#include "gen_wgrad_rows.h"
+
 __global__ void __launch_bounds__(256) gen_flip_weights_kernel(const float* __restrict__ w, int ci, int co, float* __restrict__ out) {
     const int total = 9 * ci * co;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -285,8 +287,65 @@ static int wgrad_groups(int n, int ncib, int ncog) {      // image shares: about
 extern "C" int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co) {
     if (n < 0 || ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
     if (n == 0) return 0;
+    const GenWrPlan wr = gen_wr_plan(n, ca, cb, co);
+    if (wr.ok) return wr.G;
     const int cp = ((ca + 3) & ~3) + cb, per = wgrad_per(co);
     return wgrad_groups(n, (cp + 15) / 16, ((co + 15) / 16 + per - 1) / per);
+}
+
+// the row-block form (gen_wgrad_rows.h): chunk geometry from the map size, LDS for two buffers; false: does not fit
+template <int NCOB, int RBW, bool POOLED>
+static int launch_wgrad_rows(const GenWrParams& P, size_t lds, int grid, hipStream_t st) {
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_rows_kernel<NCOB, RBW, POOLED>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((gen_wgrad_rows_kernel<NCOB, RBW, POOLED>), dim3(grid), dim3(512), lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+template <int NCOB, bool POOLED>
+static int launch_wgrad_rows_r(int rbw, const GenWrParams& P, size_t lds, int grid, hipStream_t st) {
+    if (rbw == 3) return launch_wgrad_rows<NCOB, 3, POOLED>(P, lds, grid, st);
+    if (rbw == 6) return launch_wgrad_rows<NCOB, 6, POOLED>(P, lds, grid, st);
+    return launch_wgrad_rows<NCOB, 7, POOLED>(P, lds, grid, st);
+}
+static int wgrad_rows(const GenWrPlan& wr, int n, int hw, int ca, int cb, int co, int a_is_u8, int ups, const void* a, const float* b,
+                      const float* dy, const uint8_t* am, float* slab, hipStream_t st) {
+    GenWrParams P{};
+    P.a = a; P.b = b; P.dy = dy; P.am = am; P.slab = slab;
+    P.n = n; P.hw = hw; P.lw = __builtin_ctz(hw); P.ca = ca; P.cb = cb; P.ush = ups == 4 ? 2 : (ups == 2 ? 1 : 0); P.co = co;
+    P.a_u8 = a_is_u8; P.nrg = wr.nrg;
+    P.G = wr.G; P.nsl = wr.nsl; P.ncs = wr.ncs; P.cs = wr.cs; P.cw = wr.cw;
+    // chunk: the most pixels (512 ... 8 per pixel phase; th rows of one image, whole images below 16 x 16) whose two buffers fit
+    // the LDS and whose quads fit the staging registers (6 or 9 + 3 per thread)
+    const int nph = 8 / wr.nrg;
+    int th = 0, imgs = 0;
+    size_t lds = 0;
+    for (int px = 512; px >= 8 * nph; px >>= 1) {
+        if (hw * hw >= px) { imgs = 1; th = px / hw; if (th < 2) { th = 0; continue; } }
+        else { imgs = px / (hw * hw); th = hw; }
+        const size_t inf = (size_t)imgs * (th + 2) * (hw + 2) * wr.cs;
+        const size_t dyf = (size_t)imgs * (am ? (th / 2) * (hw / 2) : th * hw) * wr.cw;
+        const size_t buf = (inf + dyf + (am ? dyf / 4 : 0) + 64 + 3) & ~(size_t)3;
+        lds = 2 * buf * sizeof(float);
+        P.buf_floats = (int)buf;
+        // staging registers: a thread holds KI pixels of one main quad column, KO odd quads (a uint8 / odd-width A), KD dY pixels
+        const bool odd_a = (ca & 3) || a_is_u8;
+        const int q4 = wr.cs / 4, qo = odd_a ? (((ca + 3) / 4) < q4 ? (ca + 3) / 4 : q4) : 0, qm = q4 - qo, qd = wr.cw / 4;
+        const int npx = imgs * (th + 2) * hw, npd = imgs * (am ? (th / 2) * (hw / 2) : th * hw);
+        const int ki = wr.ncob == 1 ? 9 : 6;
+        const bool fits = (qm == 0 || npx <= ki * (512 / qm)) && npx * qo <= 2 * 512 && npd <= 3 * (512 / qd);
+        if (lds <= 158 * 1024 && fits) break;
+        th = 0;
+    }
+    if (!th) return CGS_ERR_UNSUPPORTED;
+    const size_t red = (size_t)7 * (4 * wr.rbw + 1) * 64 * sizeof(float);      // the final sum over the pixel phases, per column block
+    if (lds < red) lds = red;
+    P.imgs = imgs; P.th = th; P.parts = hw / th;
+    P.units = ((n + imgs - 1) / imgs) * P.parts;
+    const int grid = P.G * P.nsl * P.ncs;
+    if (am) return wr.ncob == 1 ? launch_wgrad_rows_r<1, true>(wr.rbw, P, lds, grid, st) : launch_wgrad_rows_r<3, true>(wr.rbw, P, lds, grid, st);
+    return wr.ncob == 1 ? launch_wgrad_rows_r<1, false>(wr.rbw, P, lds, grid, st) : launch_wgrad_rows_r<3, false>(wr.rbw, P, lds, grid, st);
 }
 
 extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
@@ -297,13 +356,18 @@ extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int
     if (dy_argmax && (co & 3)) return CGS_ERR_BADARG;
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (n == 0) return CGS_OK;
+    const GenWrPlan wr = gen_wr_plan(n, ca, cb, co);
+    if (wr.ok) {
+        const int rc = wgrad_rows(wr, n, hw, ca, cb, co, a_is_u8, cb > 0 ? ups : 1, src_a, src_b, dy, dy_argmax, slab, (hipStream_t)stream);
+        if (rc != CGS_ERR_UNSUPPORTED) return rc;
+    }
     GenWgradParams P{};
     P.in = GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1};
     P.dy = GenSrc{dy, nullptr, dy_argmax, dy_argmax ? GEN_SRC_POOLEXP : GEN_SRC_F32, co, 0, 1};
     P.slab = slab; P.n = n; P.hw = hw; P.th = gen_strip_rows(hw);
     const int cp = ((ca + 3) & ~3) + cb, per = wgrad_per(co);
     P.ncib = (cp + 15) / 16; P.ncob = ((co + 15) / 16 + per - 1) / per;
-    P.G = wgrad_groups(n, P.ncib, P.ncob);
+    P.G = wr.ok ? wr.G : wgrad_groups(n, P.ncib, P.ncob);       // (the slab count is a function of the channel counts alone)
     size_t lds = ((size_t)(P.th + 2) * (hw + 2) + (size_t)per * P.th * hw) * GEN_KC * sizeof(float);
     const size_t red = (size_t)3 * 37 * 64 * sizeof(float);
     if (lds < red) lds = red;
