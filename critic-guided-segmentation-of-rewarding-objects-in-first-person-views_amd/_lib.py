@@ -104,6 +104,7 @@ SIGNATURES = {
     "cgs_gen_grad_fix": (i32, [i64, vp, vp, i32, f32, vp, i64, Dropout, vp]),
     "cgs_gen_dropout_fwd": (i32, [i64, vp, vp, Dropout, vp]),
     "cgs_gen_gemm_ex": (i32, [i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i32, f32, i32, vp, vp]),
+    "cgs_gen_gemm_ex_splitk": (i32, [i32, i32, i32, vp, i64, i64, vp, i64, i64, i32, vp, vp]),
     "cgs_gen_u8_to_f32": (i32, [i64, vp, vp, vp]),
     "cgs_gen16_packed_weight_halves": (i64, [i32, i32, i32]),
     "cgs_gen16_pack_weights": (i32, [i32, i32, i32, vp, vp, vp]),

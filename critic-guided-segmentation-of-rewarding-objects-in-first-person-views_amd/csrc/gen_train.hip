@@ -224,9 +224,10 @@ struct GenGemmExParams {
     int m, k, n, act, accumulate;
     long sxm, sxk, swk, swn;
     float slope;
+    int kper;           // > 0: split K -- blockIdx.y owns k in [y kper, (y + 1) kper) and writes its partial product to out + y m n
 };
 
-// one workgroup per 16 x 16 output tile, its 4 waves split the K rounds (summed in wave order through LDS);
+// one workgroup per 16 x 16 output tile (x K share), its 4 waves split the K rounds (summed in wave order through LDS);
 // A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn]
 __global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
     __shared__ float red[3][4][64];
@@ -238,15 +239,16 @@ __global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
     const float* wc = P.w + (size_t)(col < P.n ? col : 0) * P.swn;
     frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
     const bool rok = row < P.m, cok = col < P.n;
-    for (int k0 = 32 * wave; k0 < P.k; k0 += 128) {          // 8 k-steps per round: 16 independent loads in flight, then 8 MFMAs
+    const int kb = P.kper > 0 ? (int)blockIdx.y * P.kper : 0, ke = P.kper > 0 ? min(P.k, kb + P.kper) : P.k;
+    for (int k0 = kb + 32 * wave; k0 < ke; k0 += 128) {      // 8 k-steps per round: 16 independent loads in flight, then 8 MFMAs
         float a[8], b[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int k = k0 + 4 * u + kq, kc = k < P.k ? k : P.k - 1;
+            const int k = k0 + 4 * u + kq, kc = k < ke ? k : ke - 1;
             a[u] = xr[(size_t)kc * P.sxk];
             b[u] = wc[(size_t)kc * P.swk];
-            a[u] = (rok && k < P.k) ? a[u] : 0.f;
-            b[u] = (cok && k < P.k) ? b[u] : 0.f;
+            a[u] = (rok && k < ke) ? a[u] : 0.f;
+            b[u] = (cok && k < ke) ? b[u] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
         for (int j = 0; j < 4; ++j) {
             const int r = m0 + 4 * kq + j;
             if (r < P.m) {
-                float* o = P.out + (size_t)r * P.n + col;
+                float* o = P.out + (size_t)blockIdx.y * (P.kper > 0 ? (size_t)P.m * P.n : 0) + (size_t)r * P.n + col;
                 const float sum = ((acc[j] + red[0][j][lane]) + red[1][j][lane]) + red[2][j][lane];
                 const float v = gen_act(sum + bias, P.act, P.slope);
                 *o = P.accumulate ? *o + v : v;
@@ -433,8 +435,18 @@ extern "C" int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, 
                                cgs_stream_t stream) {
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (m == 0) return CGS_OK;
-    GenGemmExParams P{x, w, bias, out, m, k, n, act, accumulate, (long)sxm, (long)sxk, (long)swk, (long)swn, slope};
+    GenGemmExParams P{x, w, bias, out, m, k, n, act, accumulate, (long)sxm, (long)sxk, (long)swk, (long)swn, slope, 0};
     hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gen_gemm_ex_splitk(int32_t m, int32_t k, int32_t n, const float* x, int64_t sxm, int64_t sxk, const float* w,
+                                      int64_t swk, int64_t swn, int32_t nsplit, float* slab, cgs_stream_t stream) {
+    if (m < 0 || k <= 0 || n <= 0 || !x || !w || !slab || nsplit < 1 || nsplit > 65535) return CGS_ERR_BADARG;
+    if (m == 0) return CGS_OK;
+    GenGemmExParams P{x, w, nullptr, slab, m, k, n, CGS_ACT_NONE, 0, (long)sxm, (long)sxk, (long)swk, (long)swn, 0.f, (k + nsplit - 1) / nsplit};
+    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16), nsplit), dim3(256), 0, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

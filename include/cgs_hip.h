@@ -432,6 +432,11 @@ int cgs_gen_grad_fix(int64_t count, float* d, const float* saved, int32_t act, f
 int cgs_gen_dropout_fwd(int64_t count, const float* x, float* out, cgs_dropout drop, cgs_stream_t stream);
 int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, int64_t sxm, int64_t sxk, const float* w, int64_t swk,
                     int64_t swn, const float* bias, int32_t act, float slope, int32_t accumulate, float* out, cgs_stream_t stream);
+/* Split-K form for the long reductions over the batch (X^T dY of the Linear layers, column sums): K share y of nsplit writes its
+ * partial product to slab[y][m*n]; the rows are summed in order by cgs_reduce_slabs with the 3x3 layers' slabs
+ * (reference: the autograd of nn.Linear, nets.py:187-194, 462-464). */
+int cgs_gen_gemm_ex_splitk(int32_t m, int32_t k, int32_t n, const float* x, int64_t sxm, int64_t sxk, const float* w,
+                           int64_t swk, int64_t swn, int32_t nsplit, float* slab, cgs_stream_t stream);
 int cgs_gen_u8_to_f32(int64_t count, const uint8_t* x, float* out, cgs_stream_t stream);
 
 /* ---- fp16 inference family (csrc/gen_f16.hip): BASELINE config 4, "-process inference-only mask path ... fp16 conv kernels" --------

@@ -305,16 +305,24 @@ def test_rccl_path_one_rank_rehearsal():
     the barrier and the max-over-ranks timing all execute on this 1-GPU box; its cost shows as the step-time difference."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "50", "--warmup", "10", "--no-cpu-baseline"]
-    r = subprocess.run(cmd + ["--force-pg"], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "200", "--warmup", "20", "--no-cpu-baseline"]
+    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+
+    def run(args, e):
+        r = subprocess.run(cmd + args, capture_output=True, text=True, env=e, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    # two runs of each form, interleaved, the faster one counts: the difference of two 0.6 ms steps is compared with 40 us while
+    # the clocks of a fresh box drift by a few per cent between processes
+    pg, single = [], []
+    for _ in range(2):
+        pg.append(run(["--force-pg"], env))
+        single.append(run([], plain))
+    line = min(pg, key=lambda d: d["ms_per_step"])
+    base = min(single, key=lambda d: d["ms_per_step"])
     assert line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_seen_by_collective_backend"] == 1
     assert np.isfinite(line["final_losses"]["total"]) and line["n_gpus"] == 1
-    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r0 = subprocess.run(cmd, capture_output=True, text=True, env=plain, timeout=900)
-    assert r0.returncode == 0, r0.stderr[-3000:]
-    base = json.loads([ln for ln in r0.stdout.splitlines() if ln.startswith("{")][-1])
     extra_ms = line["ms_per_step"] - base["ms_per_step"]
     print(f"three-launch form with a 1-rank RCCL all-reduce: {line['ms_per_step']:.3f} ms vs {base['ms_per_step']:.3f} ms single graph "
           f"(+{extra_ms * 1e3:.0f} us per step)")
