@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
 }
 
 template <int NG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8 ? 3 : 4, NG > 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GenSrc& S = P.src;
@@ -222,32 +222,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
         // copy-out mapping: 16 lanes per pixel (lanes g < ngv carry one 4-channel group each), 16 pixels per round
         const int cg = tid & 15, cpx = tid >> 4;
         if (vec && P.pool) {
-            // pooled map of the tile: 64 pixels, contiguous in memory (image-major, row-major)
-            uint32_t* ct = (uint32_t*)(ot + 64 * pitch);
-            const int hwq = (P.th >> 1) * (W >> 1);                               // pooled pixels per image part of the tile
-            const int lin = il * hwq + (y >> 1) * (W >> 1) + (x >> 1);
+            // The tile's pixel p = 4 q + pos is position pos of 2x2 cell q, and cell q is pooled pixel q of the tile (64 pixels,
+            // contiguous in memory, image-major / row-major).  Every lane writes its activations to LDS; the copy-out threads
+            // (16 per pooled pixel, one 4-channel group each) take the maximum and the argmax code of the cell's four values --
+            // once per output, where a quad of lanes used to do it four times over with DPP (11 vector instructions per channel
+            // and lane: as much issue time as the layer's matrix instructions at 3 input channels).
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (g < ngv) {
-                    float m[4];
-                    uint32_t word = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = fact(acc[g][r]);
-                        float mm = fmaxf(v, dppf_xor1(v));
-                        mm = fmaxf(mm, dppf_xor2(mm));
-                        uint32_t cd = (v == mm) ? (uint32_t)pos : 4u;
-                        cd = min(cd, dpp_xor1(cd));
-                        cd = min(cd, dpp_xor2(cd));
-                        m[r] = mm;
-                        word |= ((cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u)) << (8 * r);
-                    }
-                    if (pos == 0) {
-                        *(float4*)(ot + lin * pitch + 4 * g) = make_float4(m[0], m[1], m[2], m[3]);
-                        ct[lin * NG + g] = word;
-                    }
-                }
-            }
+            for (int g = 0; g < NG; ++g)
+                if (g < ngv)
+                    *(float4*)(ot + p * pitch + 4 * g) = make_float4(fact(acc[g][0]), fact(acc[g][1]), fact(acc[g][2]), fact(acc[g][3]));
             __syncthreads();
             const size_t pix0 = P.imgs == 1 ? ((size_t)img0 * (H >> 1) + (row0 >> 1)) * (W >> 1) : (size_t)img0 * (H >> 1) * (W >> 1);
             const size_t pixend = (size_t)P.n * (H >> 1) * (W >> 1);
@@ -258,8 +241,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 8
                 for (int k = 0; k < 4; ++k) {
                     const int px = cpx + 16 * k;
                     if (pix0 + px < pixend) {
-                        *(float4*)(po + (size_t)16 * k * P.co) = *(const float4*)(ot + px * pitch + 4 * cg);
-                        if (pa) *(uint32_t*)(pa + (size_t)16 * k * P.co) = ct[px * NG + cg];
+                        const float* cell = ot + 4 * px * pitch + 4 * cg;
+                        const float4 v0 = *(const float4*)cell, v1 = *(const float4*)(cell + pitch), v2 = *(const float4*)(cell + 2 * pitch),
+                                     v3 = *(const float4*)(cell + 3 * pitch);
+                        auto one = [&](float a, float b, float c, float d, float& mm) -> uint32_t {
+                            mm = fmaxf(fmaxf(a, b), fmaxf(c, d));
+                            const uint32_t cd = a == mm ? 0u : (b == mm ? 1u : (c == mm ? 2u : (d == mm ? 3u : 4u)));      // first position holding the maximum
+                            return (cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u);
+                        };
+                        float4 m;
+                        uint32_t word = one(v0.x, v1.x, v2.x, v3.x, m.x);
+                        word |= one(v0.y, v1.y, v2.y, v3.y, m.y) << 8;
+                        word |= one(v0.z, v1.z, v2.z, v3.z, m.z) << 16;
+                        word |= one(v0.w, v1.w, v2.w, v3.w, m.w) << 24;
+                        *(float4*)(po + (size_t)16 * k * P.co) = m;
+                        if (pa) *(uint32_t*)(pa + (size_t)16 * k * P.co) = word;
                     }
                 }
             }
@@ -431,13 +427,13 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     }
     const int tiles = P.imgs == 1 ? L.n * (hw / P.th) : (L.n + P.imgs - 1) / P.imgs;
     // LDS: the input tile -- two buffers when there is more than one chunk and three (NG = 10) / four workgroups still fit a CU;
-    // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling: 64 pixels + 64 x ng argmax words)
+    // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling included: the cells' maxima are taken by the copy-out threads)
     const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
     const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
     const size_t budget = (size_t)(160 * 1024) / (ng > 8 ? 3 : 4) - 512;
     P.dbuf = (cp > GEN_KC && 2 * tile_bytes <= budget) ? 1 : 0;
     size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
-    const size_t epi = L.pool ? (size_t)64 * (4 * ng + 4 + ng) * sizeof(float) : (size_t)256 * (4 * ng + 4) * sizeof(float);
+    const size_t epi = (size_t)256 * (4 * ng + 4) * sizeof(float);
     lds = lds > epi ? lds : epi;
     const dim3 grid(tiles * P.npass);
 #define G4_LAUNCH(NG_) hipLaunchKernelGGL(gen4_conv3x3_kernel<NG_>, grid, dim3(256), lds, st, P)

@@ -1,5 +1,5 @@
 """Phase timing of gen4_conv3x3_kernel (debug hook dbg_gen4_stamps): mean s_memtime deltas between the phase boundaries of the
-first 4096 workgroups for one layer shape.  Usage (GPU box): python tools/gen4_stamps.py [hw ca cb co n]"""
+first 4096 workgroups for one layer shape.  Usage (GPU box): python tools/gen4_stamps.py [hw ca cb co n [u8] [pool]]"""
 import ctypes as C
 import os
 import sys
@@ -15,11 +15,12 @@ hw, ca, cb, co, n = (int(v) for v in sys.argv[1:6]) if len(sys.argv) > 5 else (3
 dev = torch.device("cuda:0")
 lib = _lib.load()
 lib.dbg_gen4_stamps.argtypes = [C.c_void_p]
-a = torch.randn(n, hw, hw, ca, device=dev)
+u8, pool = "u8" in sys.argv, "pool" in sys.argv
+a = torch.randint(0, 256, (n, hw, hw, ca), device=dev, dtype=torch.uint8) if u8 else torch.randn(n, hw, hw, ca, device=dev)
 b = torch.randn(n, hw // 2, hw // 2, cb, device=dev) if cb else None
 w = torch.randn(9, ca + cb, co, device=dev) * 0.05
 bias = torch.zeros(co, device=dev)
-run = lambda: generic.conv3x3(a, b, w.data_ptr(), bias.data_ptr(), co, act="relu", pool=False, ups=2)
+run = lambda: generic.conv3x3(a, b, w.data_ptr(), bias.data_ptr(), co, act="relu", pool=pool, ups=2, want_argmax=pool)
 for _ in range(3):
     run()
 torch.cuda.synchronize()
