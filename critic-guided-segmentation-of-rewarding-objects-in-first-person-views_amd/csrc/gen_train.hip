@@ -319,7 +319,7 @@ static int wgrad_rows(const GenWrPlan& wr, int n, int hw, int ca, int cb, int co
     P.a_u8 = a_is_u8; P.nrg = wr.nrg;
     P.G = wr.G; P.nsl = wr.nsl; P.ncs = wr.ncs; P.cs = wr.cs; P.cw = wr.cw;
     // chunk: the most pixels (512 ... 8 per pixel phase; th rows of one image, whole images below 16 x 16) whose two buffers fit
-    // the LDS and whose quads fit the staging registers (6 or 9 + 3 per thread)
+    // the LDS and whose quads fit the staging registers (7 or 9 + 3 per thread)
     const int nph = 8 / wr.nrg;
     int th = 0, imgs = 0;
     size_t lds = 0;
@@ -335,7 +335,7 @@ static int wgrad_rows(const GenWrPlan& wr, int n, int hw, int ca, int cb, int co
         const bool odd_a = (ca & 3) || a_is_u8;
         const int q4 = wr.cs / 4, qo = odd_a ? (((ca + 3) / 4) < q4 ? (ca + 3) / 4 : q4) : 0, qm = q4 - qo, qd = wr.cw / 4;
         const int npx = imgs * (th + 2) * hw, npd = imgs * (am ? (th / 2) * (hw / 2) : th * hw);
-        const int ki = wr.ncob == 1 ? 9 : 6;
+        const int ki = wr.ncob == 1 ? 9 : 7;
         const bool fits = (qm == 0 || npx <= ki * (512 / qm)) && npx * qo <= 2 * 512 && npd <= 3 * (512 / qd);
         if (lds <= 158 * 1024 && fits) break;
         th = 0;

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
     // store() writes them to the other LDS buffer afterwards (rows outside the image and absent images as zeros).
     // (LDS-DMA -- global_load_lds, 16 bytes per lane -- needs no registers but measured ~10 bytes per cycle and CU on this path:
     //  6.5 k of a chunk's 25 k cycles went into issuing 7 such instructions per wave.)
-    constexpr int KI = NCOB == 1 ? 9 : 6, KD = 3, KO = 2;      // (a single column block leaves the registers for a larger chunk)
+    constexpr int KI = NCOB == 1 ? 9 : 7, KD = 3, KO = 2;      // (a single column block leaves the registers for a larger chunk)
     // Thread -> element maps without divisions in the chunk loop (vector ALU work is not hidden behind the matrix instructions):
     //   main quads (16-byte loads: an fp32 A of whole quads, B): thread = (pixel lane pl, quad column qc), qc fastest; its k-th
     //     element is pixel pl + PL k of the chunk's NPX = imgs (th + 2) W in-tile pixels;
