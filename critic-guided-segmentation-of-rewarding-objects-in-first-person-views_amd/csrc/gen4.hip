@@ -426,6 +426,19 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
         P.out2 = L.out2; P.split_ca = L.split_ca; P.split_ush = ush;
     }
     const int tiles = P.imgs == 1 ? L.n * (hw / P.th) : (L.n + P.imgs - 1) / P.imgs;
+    // Few tiles (the 4x4 and 8x8 maps: 16 / 4 images per tile -- dec_model.3 at n = 512 is 32 tiles x 2 passes on 256 CUs): more passes
+    // of fewer groups over the same tile until every CU has a workgroup.  The packed weights are [chunk][tap][all groups][64], so any
+    // split of the padded group count into passes reads the same buffer.
+    {
+        const int ngp = P.npass * ng;
+        static const int cand[] = {8, 6, 4, 2, 1};
+        for (int i = 0; i < 5 && tiles * P.npass < 256; ++i) {
+            const int c = cand[i];
+            if (c >= ng || ngp % c) continue;
+            if (L.out2 && (L.split_ca % (4 * c))) continue;
+            ng = c; P.npass = ngp / c;
+        }
+    }
     // LDS: the input tile -- two buffers when there is more than one chunk and three (NG = 10) / four workgroups still fit a CU;
     // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling included: the cells' maxima are taken by the copy-out threads)
     const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
