@@ -37,13 +37,15 @@ def measured_traffic(n):
     """HBM bytes per step from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     FETCH_SIZE doubled for the 16-B/lane streaming kernels per the gfx950 rule; tools/sq_counters.sh + .py).  None when no
     summary exists for this batch size: counters cannot be collected from inside the timed run."""
-    path = os.path.join(REPO, "profiles", "r02_traffic.json")
-    try:
-        with open(path) as fp:
-            t = json.load(fp)
-        return t["traffic_bytes_per_step"] if t.get("n_images") == n else None
-    except (OSError, ValueError, KeyError):
-        return None
+    for name in ("r03_e_traffic.json", "r03_d_traffic.json", "r02_traffic.json"):      # the newest summary of the shipped kernels first
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as fp:
+                t = json.load(fp)
+            if t.get("n_images") == n:
+                return t["traffic_bytes_per_step"]
+        except (OSError, ValueError, KeyError):
+            continue
+    return None
 
 
 def parse():
