@@ -93,6 +93,7 @@ SIGNATURES = {
     "cgs_gen_conv_packed_floats": (i64, [i32, i32, i32]),
     "cgs_gen_conv_pack_weights": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_pack_weights_window": (i32, [i32, i32, i32, i32, vp, vp, vp]),
+    "cgs_gen_conv_pack_batch": (i32, [vp, i32, vp]),
     "cgs_gen_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "cgs_gen_flip_weights": (i32, [i32, i32, vp, vp, vp]),

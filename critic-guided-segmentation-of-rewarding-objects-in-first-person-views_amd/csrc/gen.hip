@@ -158,6 +158,8 @@ struct Gen4Launch {
 int gen4_conv_launch(const Gen4Launch& L, hipStream_t st);
 long gen4_packed_floats(int ca, int cb, int co);
 int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st);
+struct Gen4PackJob { const float* w; float* wp; int ca, cb, co, transposed, ci_layer, ci_off; };
+int gen4_pack_batch_launch(const Gen4PackJob* jobs, int njobs, hipStream_t st);
 
 extern "C" int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
@@ -177,6 +179,28 @@ extern "C" int cgs_gen_conv_pack_weights_window(int32_t co_layer, int32_t ci_lay
                                                 cgs_stream_t stream) {
     if (co_layer <= 0 || ci_layer <= 0 || ci_off < 0 || ci_n <= 0 || ci_off + ci_n > ci_layer || !w || !wp) return CGS_ERR_BADARG;
     return gen4_pack_launch(co_layer, 0, ci_n, 1, w, wp, ci_layer, ci_off, (hipStream_t)stream);
+}
+
+// Every 3x3 layer's operand of one step in one launch: job i packs like cgs_gen_conv_pack_weights (ci_layer = 0) or
+// cgs_gen_conv_pack_weights_window (ci_layer > 0: ca = the layer's output channels, co = the window's width).
+extern "C" int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njobs, cgs_stream_t stream) {
+    static_assert(sizeof(cgs_gen_pack_job) == sizeof(Gen4PackJob), "job layout");
+    if (njobs < 0 || (njobs > 0 && !jobs)) return CGS_ERR_BADARG;
+    if (njobs == 0) return CGS_OK;
+    Gen4PackJob tmp[64];
+    for (int j0 = 0; j0 < njobs; j0 += 64) {
+        const int nb = njobs - j0 < 64 ? njobs - j0 : 64;
+        for (int j = 0; j < nb; ++j) {
+            const cgs_gen_pack_job& J = jobs[j0 + j];
+            if (!J.w || !J.wp || J.ca <= 0 || J.cb < 0 || J.co <= 0 || (J.cb & 3) || (J.transposed && J.cb)) return CGS_ERR_BADARG;
+            if (J.ci_layer > 0 && (!J.transposed || J.ci_off < 0 || J.ci_off + J.co > J.ci_layer)) return CGS_ERR_BADARG;
+            // (a whole-layer operand: the forward form reads w as [9][ca + cb][co]; the transposed one as [9][co][ca])
+            tmp[j] = Gen4PackJob{J.w, J.wp, J.ca, J.cb, J.co, J.transposed ? 1 : 0, J.ci_layer > 0 ? J.ci_layer : J.co, J.ci_layer > 0 ? J.ci_off : 0};
+        }
+        const int rc = gen4_pack_batch_launch(tmp, nb, (hipStream_t)stream);
+        if (rc != CGS_OK) return rc;
+    }
+    return CGS_OK;
 }
 
 extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,

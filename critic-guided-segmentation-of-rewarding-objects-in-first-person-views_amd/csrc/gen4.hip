@@ -60,6 +60,23 @@ __global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
     }
 }
 
+// every layer's operand of one training step in ONE launch (25 launches of ~4.7 us each otherwise): blockIdx.y = job
+constexpr int G4_PACK_BATCH = 32;
+struct Gen4PackBatch { Gen4PackParams job[G4_PACK_BATCH]; };
+__global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
+    const Gen4PackParams& P = B.job[blockIdx.y];
+    const int pa4 = (P.ca + 3) & ~3, ngt = P.ngp, ci_total = P.ca + P.cb;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) {
+        const int lane = e & 63, r = e >> 6, g = r % ngt, tap = (r / ngt) % 9, ch = r / (ngt * 9);
+        const int k = ch * GEN_KC + (lane >> 2), col = 4 * g + (lane & 3);
+        const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
+        float v = 0.f;
+        if (real >= 0 && col < P.co)
+            v = P.transposed ? P.w[((size_t)(8 - tap) * P.ci_layer + P.ci_off + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
+        P.wp[e] = v;
+    }
+}
+
 template <int NG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
@@ -398,6 +415,28 @@ int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, flo
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(gen4_pack_kernel, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, st, P);
     CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+struct Gen4PackJob { const float* w; float* wp; int ca, cb, co, transposed, ci_layer, ci_off; };      // (= cgs_gen_pack_job of cgs_hip.h)
+int gen4_pack_batch_launch(const Gen4PackJob* jobs, int njobs, hipStream_t st) {
+    for (int j0 = 0; j0 < njobs; j0 += G4_PACK_BATCH) {
+        Gen4PackBatch B{};
+        const int nb = njobs - j0 < G4_PACK_BATCH ? njobs - j0 : G4_PACK_BATCH;
+        long most = 0;
+        for (int j = 0; j < nb; ++j) {
+            const Gen4PackJob& J = jobs[j0 + j];
+            int npass, ng;
+            gen4_groups(J.co, npass, ng);
+            const long total = gen4_packed_floats(J.ca, J.cb, J.co);
+            B.job[j] = Gen4PackParams{J.w, J.wp, J.ca, J.cb, J.co, J.transposed, (int)total, npass * ng, J.ci_layer, J.ci_off};
+            most = total > most ? total : most;
+        }
+        int blocks = (int)((most + 255) / 256);
+        blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+        hipLaunchKernelGGL(gen4_pack_batch_kernel, dim3(blocks, nb), dim3(256), 0, st, B);
+        CGS_HIP_CHECK_LAUNCH();
+    }
     return CGS_OK;
 }
 

@@ -29,19 +29,100 @@ def _p(t: Optional[torch.Tensor]):
 _PACKED: Dict[tuple, torch.Tensor] = {}
 
 
+class PackJob(C.Structure):          # = cgs_gen_pack_job (include/cgs_hip.h)
+    _fields_ = [("w", C.c_void_p), ("wp", C.c_void_p), ("ca", C.c_int32), ("cb", C.c_int32), ("co", C.c_int32), ("transposed", C.c_int32),
+                ("ci_layer", C.c_int32), ("ci_off", C.c_int32)]
+
+
+class PackPlan:
+    """The 3x3 layers' weight operands of ONE training step, packed by one launch at the start of the step (the parameters only change
+    in the optimiser step at its end).  First step: recording -- every pack_weights call packs as usual, into a buffer of its own, and
+    registers its job.  After freeze(): launch() packs all of them at once and pack_weights returns the registered buffers."""
+
+    def __init__(self):
+        self.jobs: Dict[tuple, torch.Tensor] = {}
+        self.order: List[tuple] = []
+        self.frozen = False
+        self._table = None
+
+    def freeze(self):
+        self.frozen = True
+        arr = (PackJob * max(len(self.order), 1))()
+        for i, key in enumerate(self.order):
+            w_ptr, ca, cb, co, transposed, ci_layer, ci_off = key
+            arr[i] = PackJob(w_ptr, self.jobs[key].data_ptr(), ca, cb, co, transposed, ci_layer, ci_off)
+        self._table = arr
+
+    def launch(self):
+        if self.order:
+            _lib.call("cgs_gen_conv_pack_batch", C.cast(self._table, C.c_void_p), len(self.order), _s())
+
+
+_PLAN: Optional[PackPlan] = None
+
+
+class pack_plan:
+    """with pack_plan(plan): ... -- the body's pack_weights calls go through `plan` (see PackPlan)."""
+
+    def __init__(self, plan: Optional[PackPlan]):
+        self.plan = plan
+
+    def __enter__(self):
+        global _PLAN
+        self.prev, _PLAN = _PLAN, self.plan
+        if self.plan is not None and self.plan.frozen:
+            self.plan.launch()
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _PLAN
+        if self.plan is not None and not self.plan.frozen and exc[0] is None:
+            self.plan.freeze()
+        _PLAN = self.prev
+        return False
+
+
+def _pack(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool, ci_layer: int, ci_off: int, scratch_key) -> torch.Tensor:
+    """One packed operand: ci_layer == 0 -> cgs_gen_conv_pack_weights(ca, cb, co, transposed); ci_layer > 0 -> the window form
+    cgs_gen_conv_pack_weights_window(co_layer = ca, ci_layer, ci_off, ci_n = co)."""
+    plan = _PLAN
+    key = (int(w_ptr), ca, cb, co, int(transposed), ci_layer, ci_off)
+    if plan is not None and plan.frozen:
+        wp = plan.jobs.get(key)
+        if wp is not None:
+            return wp                                   # packed by the plan's launch at the start of this step
+    nfl = int(_lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
+    if nfl <= 0:
+        raise _lib.CgsError(f"generic conv: no packed form for ca={ca} cb={cb} co={co}")
+    if plan is not None and not plan.frozen:
+        wp = plan.jobs.get(key)
+        if wp is None:
+            wp = plan.jobs[key] = torch.empty(nfl, device=dev, dtype=torch.float32)
+            plan.order.append(key)
+    else:
+        wp = _PACKED.get(scratch_key)
+        if wp is None:
+            wp = _PACKED[scratch_key] = torch.empty(nfl, device=dev, dtype=torch.float32)
+    if ci_layer > 0:
+        _lib.call("cgs_gen_conv_pack_weights_window", ca, ci_layer, ci_off, co, C.c_void_p(w_ptr), _p(wp), _s())
+    else:
+        _lib.call("cgs_gen_conv_pack_weights", ca, cb, co, int(transposed), C.c_void_p(w_ptr), _p(wp), _s())
+    return wp
+
+
 def pack_weights(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool = False) -> torch.Tensor:
     """HWIO 3x3 weights at w_ptr -> the convolution kernel's operand form (cgs_gen_conv_pack_weights).  transposed: w_ptr is the
     [9][co][ca] weight of the layer whose DATA GRADIENT is wanted (ca = its output channels, co = its input channels).  One scratch
-    tensor per (device, shape): the pack and the convolution that reads it are consecutive launches of one stream."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), ca, cb, co)
-    wp = _PACKED.get(key)
-    if wp is None:
-        nfl = int(_lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
-        if nfl <= 0:
-            raise _lib.CgsError(f"generic conv: no packed form for ca={ca} cb={cb} co={co}")
-        wp = _PACKED[key] = torch.empty(nfl, device=dev, dtype=torch.float32)
-    _lib.call("cgs_gen_conv_pack_weights", ca, cb, co, int(transposed), C.c_void_p(w_ptr), _p(wp), _s())
-    return wp
+    tensor per (device, shape): the pack and the convolution that reads it are consecutive launches of one stream -- or, inside a
+    pack_plan, the plan's buffer for this layer."""
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    return _pack(w_ptr, ca, cb, co, dev, transposed, 0, 0, (di, ca, cb, co))
+
+
+def pack_weights_window(w_ptr: int, co_layer: int, ci_layer: int, ci_off: int, ci_n: int, dev) -> torch.Tensor:
+    """The data gradient's operand for input channels [ci_off, ci_off + ci_n) of a layer (cgs_gen_conv_pack_weights_window)."""
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    return _pack(w_ptr, co_layer, 0, ci_n, dev, True, ci_layer, ci_off, (di, "window", co_layer, ci_layer, ci_off, ci_n))
 
 
 def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: int, co: int, act: str = "none",
@@ -417,9 +498,7 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
     # only the decoder channels of cat(X, up2(o0)) need a gradient: the operand covers input channels [3, 3 + d0) and the epilogue sums
     # the 2x2 cells (no d_cat tensor, no gradient for the image channels)
     d_o = ws.buf("d_o0", (n, 32, 32, d[0]), dev)
-    nfl = int(_lib.load().cgs_gen_conv_packed_floats(mc, 0, d[0]))
-    wpw = ws.buf("wp_m0_window", (nfl,), dev)
-    _lib.call("cgs_gen_conv_pack_weights_window", mc, 3 + d[0], 3, d[0], C.c_void_p(off("masker.0.weight")), _p(wpw), _s())
+    wpw = pack_weights_window(off("masker.0.weight"), mc, 3 + d[0], 3, d[0], dev)
     rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, 64, mc, 0, d[0], 2, _p(d_hm), _p(wpw), None, _p(d_o), _s())
     if rc == _lib.ERR_UNSUPPORTED:
         dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)

@@ -65,6 +65,7 @@ class GenericEngine(HourglassEngine):
         self.fused_tail = False
         self._graphs: Dict[str, object] = {}
         self._plans: Dict[str, hg.SlabPlan] = {}
+        self._packplans: Dict[str, gen.PackPlan] = {}
         self._pver = share_with._pver if share_with is not None else [0]
         self._w16 = None
 
@@ -124,6 +125,11 @@ class GenericEngine(HourglassEngine):
 
     # ---- phase 2 -----------------------------------------------------------------------------
     def _phase2_fwd_bwd(self):
+        # (every 3x3 layer's weight operand of the step in one launch at its start: gen.PackPlan)
+        with gen.pack_plan(self._packplans.setdefault("p2", gen.PackPlan())):
+            self._phase2_body()
+
+    def _phase2_body(self):
         n = self.n
         nmix = 2 * n if self.inject else n
         drop = self.drop
@@ -169,6 +175,10 @@ class GenericEngine(HourglassEngine):
 
     # ---- phase 1 -----------------------------------------------------------------------------
     def _phase1_fwd_bwd(self):
+        with gen.pack_plan(self._packplans.setdefault("p1", gen.PackPlan())):
+            self._phase1_body()
+
+    def _phase1_body(self):
         n = self.n
         X = self.ab[:n]
         s, g = self._view(self.cbuf, 0, n), self._view(self.gbuf, 0, n)

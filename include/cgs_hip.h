@@ -389,6 +389,15 @@ int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transp
  * (cgs_gen_conv_packed_floats(co_layer, 0, ci_n) floats) maps dY to d(input channels [ci_off, ci_off + ci_n)).                   */
 int cgs_gen_conv_pack_weights_window(int32_t co_layer, int32_t ci_layer, int32_t ci_off, int32_t ci_n, const float* w, float* wp,
                                      cgs_stream_t stream);
+
+/* All 3x3 layers' operands of one training step in ONE launch (the step packs ~25 of them: weights change at every Adam step).
+ * Job i is cgs_gen_conv_pack_weights(ca, cb, co, transposed, w, wp) when ci_layer == 0 and
+ * cgs_gen_conv_pack_weights_window(ca, ci_layer, ci_off, co, w, wp) when ci_layer > 0 (transposed must be 1).  jobs: HOST array. */
+typedef struct cgs_gen_pack_job {
+    const float* w; float* wp;
+    int32_t ca, cb, co, transposed, ci_layer, ci_off;
+} cgs_gen_pack_job;
+int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njobs, cgs_stream_t stream);
 int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                         int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                         const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
