@@ -307,6 +307,7 @@ static int launch_wgrad_rows(const GenWrParams& P, size_t lds, int grid, hipStre
 }
 template <int NCOB, bool POOLED>
 static int launch_wgrad_rows_r(int rbw, const GenWrParams& P, size_t lds, int grid, hipStream_t st) {
+    if (rbw == 2) return launch_wgrad_rows<NCOB, 2, POOLED>(P, lds, grid, st);
     if (rbw == 3) return launch_wgrad_rows<NCOB, 3, POOLED>(P, lds, grid, st);
     if (rbw == 6) return launch_wgrad_rows<NCOB, 6, POOLED>(P, lds, grid, st);
     return launch_wgrad_rows<NCOB, 7, POOLED>(P, lds, grid, st);
@@ -326,14 +327,15 @@ static int wgrad_rows(const GenWrPlan& wr, int n, int hw, int ca, int cb, int co
     for (int px = 512; px >= 8 * nph; px >>= 1) {
         if (hw * hw >= px) { imgs = 1; th = px / hw; if (th < 2) { th = 0; continue; } }
         else { imgs = px / (hw * hw); th = hw; }
-        const size_t inf = (size_t)imgs * (th + 2) * (hw + 2) * wr.cs;
+        const size_t inf = ((size_t)imgs * (th + 2) * (hw + 2) * wr.cs + 3) & ~(size_t)3;
         const size_t dyf = (size_t)imgs * (am ? (th / 2) * (hw / 2) : th * hw) * wr.cw;
         const size_t buf = (inf + dyf + (am ? dyf / 4 : 0) + 64 + 3) & ~(size_t)3;
         lds = 2 * buf * sizeof(float);
         P.buf_floats = (int)buf;
         // staging registers: a thread holds KI pixels of one main quad column, KO odd quads (a uint8 / odd-width A), KD dY pixels
         const bool odd_a = (ca & 3) || a_is_u8;
-        const int q4 = wr.cs / 4, qo = odd_a ? (((ca + 3) / 4) < q4 ? (ca + 3) / 4 : q4) : 0, qm = q4 - qo, qd = wr.cw / 4;
+        const bool narrow = cb == 0 && ca < 4;
+        const int q4 = narrow ? 1 : wr.cs / 4, qo = odd_a ? (((ca + 3) / 4) < q4 ? (ca + 3) / 4 : q4) : 0, qm = q4 - qo, qd = wr.cw / 4;
         const int npx = imgs * (th + 2) * hw, npd = imgs * (am ? (th / 2) * (hw / 2) : th * hw);
         const int ki = wr.ncob == 1 ? 9 : 7;
         const bool fits = (qm == 0 || npx <= ki * (512 / qm)) && npx * qo <= 2 * 512 && npd <= 3 * (512 / qd);

@@ -38,15 +38,18 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
     const int rg = wave & (nrg - 1), ph = wave >> lnrg;        // row group (row blocks rg + nrg r), pixel phase (groups nph i + ph)
     const int W = P.hw, H = P.hw, PW = W + 2, th = P.th, imgs = P.imgs, lw = P.lw;
     const int cos = blockIdx.x % P.ncs, sl = (blockIdx.x / P.ncs) % P.nsl, g = blockIdx.x / (P.ncs * P.nsl);
-    const int ca4 = (P.ca + 3) & ~3, ci_total = P.ca + P.cb, ci_pad = ca4 + P.cb;     // (A's channels padded to whole quads, then B's)
+    // (A's channels padded to whole quads, then B's; a lone A of fewer than 4 channels -- the frames -- keeps its width: 27 rows
+    //  = 2 row blocks instead of 36 = 3)
+    const bool narrow = P.cb == 0 && P.ca < 4;
+    const int ca4 = narrow ? P.ca : (P.ca + 3) & ~3, ci_total = P.ca + P.cb, ci_pad = ca4 + P.cb;
     const int ks0 = sl * P.cs, csl = min(P.cs, ci_pad - ks0);             // this workgroup's (padded) input channels [ks0, ks0 + csl)
     const int cs0 = cos * P.cw, cwl = min(P.cw, P.co - cs0);               // and output channels [cs0, cs0 + cwl)
     const int IMS = (th + 2) * PW * csl;                                   // in-tile floats per image slot
-    const int INF = imgs * IMS;
+    const int INF = (imgs * IMS + 3) & ~3;                                 // (dY behind it stays 16-byte aligned)
     const int DPX = POOLED ? (th >> 1) * (W >> 1) : th * W;                // dY tile pixels per image slot
     const int DYF = imgs * DPX * cwl;
     const int BUF = P.buf_floats;
-    const int q4 = csl >> 2, qd = cwl >> 2;
+    const int q4 = narrow ? 1 : csl >> 2, qd = cwl >> 2;                   // staged elements per pixel (quads; narrow: the pixel's csl floats)
     const int ush = P.ush, HB = H >> ush, WB = W >> ush;
     const int u0 = (int)((long)g * P.units / P.G), u1 = (int)((long)(g + 1) * P.units / P.G);
     const bool do_bias = sl == 0 && rg == 0;
@@ -73,10 +76,18 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
     }
 
     // ---- the halo columns of both buffers are zero for every chunk: written once ----
-    for (int e = tid; e < 2 * imgs * (th + 2) * 2 * q4; e += 512) {
-        const int q = e % q4, side = (e / q4) & 1, rr = (e / (2 * q4)) % (imgs * (th + 2)), bf = e / (2 * q4 * imgs * (th + 2));
-        const int t = rr / (th + 2), r = rr - t * (th + 2);
-        *(float4*)(sm + bf * BUF + t * IMS + (r * PW + (side ? W + 1 : 0)) * csl + 4 * q) = f4zero();
+    if (narrow) {
+        for (int e = tid; e < 2 * imgs * (th + 2) * 2 * csl; e += 512) {
+            const int j = e % csl, side = (e / csl) & 1, rr = (e / (2 * csl)) % (imgs * (th + 2)), bf = e / (2 * csl * imgs * (th + 2));
+            const int t = rr / (th + 2), r = rr - t * (th + 2);
+            sm[bf * BUF + t * IMS + (r * PW + (side ? W + 1 : 0)) * csl + j] = 0.f;
+        }
+    } else {
+        for (int e = tid; e < 2 * imgs * (th + 2) * 2 * q4; e += 512) {
+            const int q = e % q4, side = (e / q4) & 1, rr = (e / (2 * q4)) % (imgs * (th + 2)), bf = e / (2 * q4 * imgs * (th + 2));
+            const int t = rr / (th + 2), r = rr - t * (th + 2);
+            *(float4*)(sm + bf * BUF + t * IMS + (r * PW + (side ? W + 1 : 0)) * csl + 4 * q) = f4zero();
+        }
     }
 
     // Staging of chunk u: every thread owns up to KI quads (16 bytes) of the in-tile and KD of dY (+ KD argmax words of a pooled
@@ -92,7 +103,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
     //     run that path beside every 16-byte load): element = tid + 512 k over NPX qo;
     //   dY quads: thread = (pixel lane pld, quad column qcd).
     const bool odd_a = (P.ca & 3) || P.a_u8;
-    const int qA = min(max((ca4 - ks0) >> 2, 0), q4);                 // A quads per pixel in this slice
+    const int qA = narrow ? 1 : min(max((ca4 - ks0) >> 2, 0), q4);   // A quads per pixel in this slice
     const int qo = odd_a ? qA : 0, qm = q4 - qo;                      // odd / main quads per pixel
     const int NPX = imgs * (th + 2) * W;
     const int PL = qm ? 512 / qm : 0, qc = qm ? tid % qm : 0, pl = qm ? tid / qm : 512;
@@ -196,7 +207,14 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
                     const int p = mQO ? (int)__umulhi((uint32_t)e, mQO) : e;
                     int t, r, px;
                     pixel(p, t, r, px);
-                    *(float4*)(tin + t * IMS + (r * PW + 1 + px) * csl + 4 * (e - p * qo)) = sto[k];
+                    float* dst = tin + t * IMS + (r * PW + 1 + px) * csl;
+                    if (narrow) {
+                        dst[0] = sto[k].x;
+                        if (csl > 1) dst[1] = sto[k].y;
+                        if (csl > 2) dst[2] = sto[k].z;
+                    } else {
+                        *(float4*)(dst + 4 * (e - p * qo)) = sto[k];
+                    }
                 }
             }
         }
@@ -345,34 +363,40 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
 }
 
 struct GenWrPlan { int ok, nsl, cs, ncs, cw, ncob, rbw, nrg, G; };
-// row groups and row blocks per wave for a slice of cs <= 48 (padded) channels: the instantiated block counts are 3, 6, 7
+// row groups and row blocks per wave for a slice of cs <= 48 (padded) channels: the instantiated block counts are 2, 3, 6, 7
 static void gen_wr_rows(int cs, int& nrg, int& rbw) {
     const int nrb = (9 * cs + 15) / 16;
     nrg = nrb > 14 ? 4 : (nrb > 7 ? 2 : 1);
     const int r = (nrb + nrg - 1) / nrg;
-    rbw = r <= 3 ? 3 : (r <= 6 ? 6 : 7);
+    rbw = r <= 2 ? 2 : (r <= 3 ? 3 : (r <= 6 ? 6 : 7));
 }
 
 // slicing of the channels (depends on the channel counts only: the slab count must be known without the map size)
 static GenWrPlan gen_wr_plan(int n, int ca, int cb, int co) {
     GenWrPlan p{};
-    const int ci = ((ca + 3) & ~3) + cb;              // padded channel space
-    if ((cb & 3) || (co & 3) || ci < 4) return p;
-    // input-channel slices: <= 48 channels (27 row blocks, 7 per row group); the candidate with the fewest computed rows wins
-    int best = 0, bestrows = 1 << 30;
-    const int nmin = (ci + 47) / 48;
-    for (int nsl = nmin; nsl <= nmin + 2 && nsl * 4 <= ci + 3; ++nsl) {
-        const int cs = (((ci + nsl - 1) / nsl) + 3) & ~3;
-        if ((nsl - 1) * cs >= ci) continue;
-        int nrg, rbw;
-        gen_wr_rows(cs, nrg, rbw);
-        const int rows = nsl * nrg * rbw;
-        if (rows < bestrows) { bestrows = rows; best = nsl; }
+    const bool narrow = cb == 0 && ca < 4;            // the frames: 9 x 3 rows, unpadded
+    const int ci = narrow ? ca : ((ca + 3) & ~3) + cb; // padded channel space
+    if ((cb & 3) || (co & 3) || ci < 1) return p;
+    if (narrow) {
+        p.nsl = 1; p.cs = ca;
+        gen_wr_rows(p.cs, p.nrg, p.rbw);
+    } else {
+        // input-channel slices: <= 48 channels (27 row blocks, 7 per row group); the candidate with the fewest computed rows wins
+        int best = 0, bestrows = 1 << 30;
+        const int nmin = (ci + 47) / 48;
+        for (int nsl = nmin; nsl <= nmin + 2 && nsl * 4 <= ci + 3; ++nsl) {
+            const int cs = (((ci + nsl - 1) / nsl) + 3) & ~3;
+            if ((nsl - 1) * cs >= ci) continue;
+            int nrg, rbw;
+            gen_wr_rows(cs, nrg, rbw);
+            const int rows = nsl * nrg * rbw;
+            if (rows < bestrows) { bestrows = rows; best = nsl; }
+        }
+        if (!best) return p;
+        p.nsl = best;
+        p.cs = (((ci + best - 1) / best) + 3) & ~3;
+        gen_wr_rows(p.cs, p.nrg, p.rbw);
     }
-    if (!best) return p;
-    p.nsl = best;
-    p.cs = (((ci + best - 1) / best) + 3) & ~3;
-    gen_wr_rows(p.cs, p.nrg, p.rbw);
     // output-channel slices: <= 48 channels (the LDS budget of the 4x4 maps: 8 image slots of 6 x 6 x 48 floats + dY, twice)
     p.ncs = (co + 47) / 48;
     p.cw = (((co + p.ncs - 1) / p.ncs) + 3) & ~3;
