@@ -251,29 +251,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
             __syncthreads();
             const size_t pix0 = P.imgs == 1 ? ((size_t)img0 * (H >> 1) + (row0 >> 1)) * (W >> 1) : (size_t)img0 * (H >> 1) * (W >> 1);
             const size_t pixend = (size_t)P.n * (H >> 1) * (W >> 1);
-            if (cg < ngv) {
-                float* po = P.out + (pix0 + cpx) * P.co + 4 * (g0 + cg);
-                uint8_t* pa = P.argmax ? P.argmax + (pix0 + cpx) * P.co + 4 * (g0 + cg) : nullptr;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int px = cpx + 16 * k;
-                    if (pix0 + px < pixend) {
-                        const float* cell = ot + 4 * px * pitch + 4 * cg;
-                        const float4 v0 = *(const float4*)cell, v1 = *(const float4*)(cell + pitch), v2 = *(const float4*)(cell + 2 * pitch),
-                                     v3 = *(const float4*)(cell + 3 * pitch);
-                        auto one = [&](float a, float b, float c, float d, float& mm) -> uint32_t {
-                            mm = fmaxf(fmaxf(a, b), fmaxf(c, d));
-                            const uint32_t cd = a == mm ? 0u : (b == mm ? 1u : (c == mm ? 2u : (d == mm ? 3u : 4u)));      // first position holding the maximum
-                            return (cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u);
-                        };
-                        float4 m;
-                        uint32_t word = one(v0.x, v1.x, v2.x, v3.x, m.x);
-                        word |= one(v0.y, v1.y, v2.y, v3.y, m.y) << 8;
-                        word |= one(v0.z, v1.z, v2.z, v3.z, m.z) << 16;
-                        word |= one(v0.w, v1.w, v2.w, v3.w, m.w) << 24;
-                        *(float4*)(po + (size_t)16 * k * P.co) = m;
-                        if (pa) *(uint32_t*)(pa + (size_t)16 * k * P.co) = word;
-                    }
+            // items (pooled pixel, group) in memory order, 256 per round: every thread works (16 fixed lanes per pixel left 6 of them idle at
+            // 10 groups); item / ngv by a multiply (exact for item < 1024, ngv <= 10)
+            const uint32_t rngv = 65536u / (uint32_t)ngv + 1u;
+            for (int item = tid; item < 64 * ngv; item += 256) {
+                const int px = (int)(((uint32_t)item * rngv) >> 16), ig = item - px * ngv;
+                if (pix0 + px < pixend) {
+                    const float* cell = ot + 4 * px * pitch + 4 * ig;
+                    const float4 v0 = *(const float4*)cell, v1 = *(const float4*)(cell + pitch), v2 = *(const float4*)(cell + 2 * pitch),
+                                 v3 = *(const float4*)(cell + 3 * pitch);
+                    auto one = [&](float a, float b, float c, float d, float& mm) -> uint32_t {
+                        mm = fmaxf(fmaxf(a, b), fmaxf(c, d));
+                        const uint32_t cd = a == mm ? 0u : (b == mm ? 1u : (c == mm ? 2u : (d == mm ? 3u : 4u)));      // first position holding the maximum
+                        return (cd & 3u) | ((act == CGS_ACT_RELU && !(mm > 0.f)) ? 4u : 0u);
+                    };
+                    float4 m;
+                    uint32_t word = one(v0.x, v1.x, v2.x, v3.x, m.x);
+                    word |= one(v0.y, v1.y, v2.y, v3.y, m.y) << 8;
+                    word |= one(v0.z, v1.z, v2.z, v3.z, m.z) << 16;
+                    word |= one(v0.w, v1.w, v2.w, v3.w, m.w) << 24;
+                    const size_t o = (pix0 + px) * P.co + 4 * (g0 + ig);
+                    *(float4*)(P.out + o) = m;
+                    if (P.argmax) *(uint32_t*)(P.argmax + o) = word;
                 }
             }
         } else if (P.out2 && 4 * g0 >= P.split_ca) {
@@ -322,14 +321,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
                 const size_t hp0 = pix0;
                 if (vec) {
                     const int ostride = P.out2 ? P.split_ca : P.co;      // (split: this pass lies below split_ca: d_a's own row stride)
-                    if (cg < ngv && P.out) {
-                        const size_t o0 = (hp0 + cpx) * ostride + 4 * (g0 + cg);
-#pragma unroll 4
-                        for (int k = 0; k < 16; ++k) {
-                            const int px = cpx + 16 * k;
-                            const size_t gp = hp0 + px, o = o0 + (size_t)16 * k * ostride;
+                    if (P.out) {
+                        // items (pixel, group) in memory order, 256 per round (see the pooled copy-out)
+                        const uint32_t rngv = 65536u / (uint32_t)ngv + 1u;
+#pragma unroll 2
+                        for (int item = tid; item < 256 * ngv; item += 256) {
+                            const int px = (int)(((uint32_t)item * rngv) >> 16), ig = item - px * ngv;
+                            const size_t gp = hp0 + px, o = gp * ostride + 4 * (g0 + ig);
                             if (gp < pixend) {
-                                float4 t = *(const float4*)(ot + px * pitch + 4 * cg);
+                                float4 t = *(const float4*)(ot + px * pitch + 4 * ig);
                                 if (gp < addend_end) { const float4 a = *(const float4*)(P.addend + o); t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
                                 *(float4*)(P.out + o) = t;
                             }
