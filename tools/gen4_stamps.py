@@ -40,6 +40,6 @@ names[31] = "end"
 print(f"{live.sum()} workgroups; shape hw={hw} ca={ca} cb={cb} co={co} n={n}")
 prev = cols[0]
 for c in cols[1:]:
-    print(f"  {names.get(prev, prev):>22s} -> {names.get(c, c):<22s} {np.mean(st[:, c] - st[:, prev]):9.0f} ticks")
+    print(f"  {str(names.get(prev, prev)):>22s} -> {str(names.get(c, c)):<22s} {np.mean(st[:, c] - st[:, prev]):9.0f} ticks")
     prev = c
 print("  total", np.mean(st[:, cols[-1]] - st[:, cols[0]]))
