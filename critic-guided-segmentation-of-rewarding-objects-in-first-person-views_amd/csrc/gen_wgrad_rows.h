@@ -3,18 +3,19 @@
 // as an MFMA GEMM (v_mfma_f32_16x16x4_f32) whose ROWS are the flattened (tap, ci) pairs of one input-channel slice and whose columns
 // are one output-channel slice; the pixels are the K dimension.  What it changes against gen_conv3x3_wgrad_kernel:
 //   * rows = 9 * cs flattened: 40 channels are 23 row blocks of 16 (98 % useful) instead of 9 taps x 3 blocks of 16 (83 %);
-//   * the 8 waves of a workgroup are (at >= 15 row blocks) 4 row groups x 2 pixel phases: a wave owns up to 7 row blocks x NCOB column blocks (18-21 matrix
-//     instructions per 9-12 LDS reads; fp32 MFMA and vector ALU instructions do not overlap on a SIMD, so the address / select work
-//     per matrix instruction is what the loop is built to minimise), one staged chunk feeds
-//     (9 cs / 16) x NCOB accumulator blocks instead of 9 x NCOB, so a staged byte is used 2-3 times as often;
+//   * the 8 waves of a workgroup are (at >= 15 row blocks) 4 row groups x 2 pixel phases: a wave owns up to 7 row blocks x NCOB column
+//     blocks (18-21 matrix instructions per 9-12 LDS reads; fp32 MFMA and vector ALU instructions do not overlap on a SIMD, so the
+//     address / select work per matrix instruction is what the loop is built to minimise), and one staged chunk feeds (9 cs / 16) x NCOB
+//     accumulator blocks instead of 9 x NCOB: a staged byte is used 2-3 times as often;
 //   * the next chunk's global loads are issued into registers before the matrix instructions of the current chunk and written to a
-//     second LDS buffer after them: one barrier per chunk of 128 pixels, loads never waited for in the open;
+//     second LDS buffer after them: one barrier per chunk of 128-512 pixels, loads never waited for in the open;
 //   * the gradient of a pooled layer is staged RAW (dE at the pooled resolution + the argmax bytes, a quarter of the elements)
 //     and expanded when the B operand is read;
 //   * one workgroup per CU, persistent over a contiguous range of chunks: ~256 slab rows per layer instead of 512-1536.
-// Sources: A fp32 or uint8 NHWC of any width (padded to whole quads in the tile) + nearest-upsampled B (cb % 4 == 0); co % 4 == 0
-// (single-channel outputs stay on gen_conv3x3_wgrad_kernel).  Few-channel layers (the frames: 9 x 4 rows = 3 row blocks) give
-// all eight waves the same rows and an eighth of the pixels each: nrg row groups x 8 / nrg pixel phases.
+// Sources: A fp32 or uint8 NHWC of any width (padded to whole quads in the tile; a lone A of fewer than 4 channels keeps its width) +
+// nearest-upsampled B (cb % 4 == 0); co % 4 == 0 (single-channel outputs stay on gen_conv3x3_wgrad_kernel).  Few-channel layers (the
+// frames: 9 x 3 rows = 2 row blocks) give all eight waves the same rows and an eighth of the pixels each: nrg row groups x 8 / nrg
+// pixel phases.
 #pragma once
 
 struct GenWrParams {
@@ -25,7 +26,7 @@ struct GenWrParams {
     int a_u8;                             // A is uint8
     int nrg;                              // row groups (1, 2 or 4) x 8 / nrg pixel phases = the 8 waves
     int G, nsl, ncs, cs, cw;              // chunk shares; input-channel slices of cs channels; output-channel slices of cw channels
-    int imgs, th, parts, units;           // chunk = imgs images x th rows (128 pixels); parts = hw / th; units = chunks in the job
+    int imgs, th, parts, units;           // chunk = imgs images x th rows (128 .. 512 pixels); parts = hw / th; units = chunks in the job
     int buf_floats;                       // floats per LDS buffer
 };
 
