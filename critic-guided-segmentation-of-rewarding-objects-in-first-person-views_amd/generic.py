@@ -150,7 +150,11 @@ def gemm(x: torch.Tensor, w_ptr: int, bias_ptr: int, k: int, n_out: int, act: st
     m = x.shape[0]
     if out is None:
         out = torch.empty((m, n_out), device=x.device, dtype=torch.float32)
-    _lib.call("cgs_gen_gemm", m, k, n_out, _ACT[act], float(slope), _p(x), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _s())
+    if k >= 256:       # long reductions (features.14: k = 16 x 16 chfak): four waves per tile split K (one wave walks it in 40 rounds of loads)
+        _lib.call("cgs_gen_gemm_ex", m, k, n_out, _p(x), k, 1, C.c_void_p(w_ptr), n_out, 1, C.c_void_p(bias_ptr), _ACT[act], float(slope), 0,
+                  _p(out), _s())
+    else:
+        _lib.call("cgs_gen_gemm", m, k, n_out, _ACT[act], float(slope), _p(x), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _s())
     return out
 
 
