@@ -31,6 +31,10 @@ __device__ __forceinline__ void gen4_stage(const G4Dst& D, const GenSrc& S, cons
     np = np < npmax ? np : npmax;
     const int lp = np == 1 ? 0 : (np == 2 ? 1 : 2);
     const int rpi = P.th + 2 * halo, rows = P.imgs * rpi;
+    // tile row -> image slot: r / rpi by a multiply (exact for r < 2048, rpi <= 66); a single-image tile never divides.  (As a plain
+    // `r / rpi` selected against 0 the division ran for every element of every tile: ~300 of a staging call's ~530 vector instructions.)
+    const bool multi = P.imgs > 1;
+    const uint32_t mrpi = 65536u / (uint32_t)rpi + 1u;
     const int rpr = 256 >> (lp + lw);                          // tile rows per round of 256 threads (>= 1)
     const int g = tid & ((1 << lp) - 1), x = (tid >> lp) & (W - 1), rsub = tid >> (lp + lw);
     const int ush = S.ups == 4 ? 2 : (S.ups == 2 ? 1 : 0), HB = H >> ush, WB = W >> ush;
@@ -55,7 +59,7 @@ __device__ __forceinline__ void gen4_stage(const G4Dst& D, const GenSrc& S, cons
         for (int it = 0; it < BATCH; ++it) {
             int r = rb + it * rpr;
             r = r < rows ? r : rows - 1;
-            const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
+            const int il = multi ? (int)(((uint32_t)r * mrpi) >> 16) : 0, rr = r - il * rpi;
             const int y = row0 + rr - halo, yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
             int img = img0 + il;
             img = img < P.n ? img : P.n - 1;
@@ -85,7 +89,7 @@ __device__ __forceinline__ void gen4_stage(const G4Dst& D, const GenSrc& S, cons
         for (int it = 0; it < BATCH; ++it) {
             const int r = rb + it * rpr;
             if (r < rows) {
-                const int il = P.imgs == 1 ? 0 : r / rpi, rr = r - il * rpi;
+                const int il = multi ? (int)(((uint32_t)r * mrpi) >> 16) : 0, rr = r - il * rpi;
                 const int y = row0 + rr - halo;
                 const bool inb = kok && y >= 0 && y < H && img0 + il < P.n;
                 float4 v = raw[it];
