@@ -37,7 +37,7 @@ def measured_traffic(n):
     """HBM bytes per step from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
     FETCH_SIZE doubled for the 16-B/lane streaming kernels per the gfx950 rule; tools/sq_counters.sh + .py).  None when no
     summary exists for this batch size: counters cannot be collected from inside the timed run."""
-    for name in ("r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r02_traffic.json"):      # the newest summary of the shipped kernels first
+    for name in ("r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r02_traffic.json"):      # the newest summary of the shipped kernels first
         try:
             with open(os.path.join(REPO, "profiles", name)) as fp:
                 t = json.load(fp)
