@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
             const int tap = m / csl, ci = m - tap * csl;
             o += ((tap / 3) * PW + tap % 3) * csl + ci;
         }
-        aoff[r] = o;
+        aoff[r] = 4 * o;                 // BYTE offsets: the loop adds the group's base with one instruction per read
     }
     frag4 acc[RBW][NCOB];
     float bsum[NCOB];
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
         const int t = grp >> lgpi, rem = grp & (gpi - 1), y = rem >> lgw, x0 = (rem & ((W >> 2) - 1)) << 2;
         const float* ap = tin + (t * IMS + (y * PW + x0) * csl);
 #pragma unroll
-        for (int r = 0; r < RBW; ++r) a[r] = ap[aoff[r]];
+        for (int r = 0; r < RBW; ++r) a[r] = *(const float*)((const char*)ap + aoff[r]);
         if constexpr (POOLED) {
             const int pp = (t * (th >> 1) + (y >> 1)) * (W >> 1) + (x0 >> 1);                  // (uniform)
             const float* bp = tdy + pp * cwl + bl;
