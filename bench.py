@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--force-pg", action="store_true",
                     help="--gpus 1 only: create a ONE-rank RCCL group and keep the data-parallel launch form (step graph -> all-reduce -> Adam): "
                          "rehearses the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--dp-eager-allreduce", action="store_true",
+                    help="data parallel: keep the gradient all-reduce OUTSIDE the HIP graphs (step graph -> eager all-reduce -> Adam graph, the "
+                         "round-3 form); default = the collective is captured into the step graph when the RCCL trial capture succeeds")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--config", type=int, default=0,
                     help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart), eval-mode "
@@ -391,6 +394,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
         pg = dist.group.WORLD
         ranks_seen, backend = dist.get_world_size(), dist.get_backend()
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the collective backend sees {ranks_seen} ranks")
 
     from cgs_amd import engine
     n = args.batch
@@ -405,10 +410,12 @@ def main():
     if args.mode != "train":
         return side_mode(args, dev, world, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg,
-                                 force_allreduce=args.force_pg)
+                                 force_allreduce=args.force_pg, dp_graph=not args.dp_eager_allreduce)
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
     eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture
+    if pg is not None:
+        print(f"[bench] rank {rank}: all-reduce inside the step graph: {eng.dp_single_graph} ({eng.dp_capture_note})", file=sys.stderr, flush=True)
 
     def barrier():
         if pg is not None:
@@ -416,14 +423,26 @@ def main():
         torch.cuda.synchronize()
 
     # setup, untimed: replay the captured step until the clocks have settled from idle (a fresh box starts the 15 ms of a
-    # --steps 20 run at its idle clocks otherwise); these are real training steps, like the warm-up steps that follow
+    # --steps 20 run at its idle clocks otherwise).  The priming COUNT is a fixed function of --prime-s (a nominal 0.65 ms per
+    # step), identical on every rank: under data parallelism each step issues a gradient all-reduce, so ranks must not decide
+    # from their own wall clocks how many steps (= collectives) they run.  The parameters / optimiser state are put back to the
+    # state right after the capture step afterwards, so the warm-up and timed steps train from the G1 weights, not from a
+    # state a thousand steps into fitting one fixed batch.
+    snap = eng.snapshot_state()
+    barrier()
     primed = 0
-    tp = time.perf_counter()
-    while time.perf_counter() - tp < args.prime_s:
+    nprime = int(-(-args.prime_s / 0.65e-3 // 50)) * 50 if args.prime_s > 0 else 0
+    while primed < nprime:
         for _ in range(50):
             eng.phase2_step()
         primed += 50
         torch.cuda.synchronize()
+    eng.restore_state(snap)
+    if pg is not None:
+        # untimed collectives on the gradient bucket itself (RCCL sets channels up lazily on the first calls of a size)
+        for _ in range(5):
+            eng._allreduce()
+        eng.grad.zero_()
     for _ in range(args.warmup):
         eng.phase2_step()
     barrier()
@@ -438,11 +457,15 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (graph launches go to this stream)
     losses = eng.losses.cpu().tolist()
-    print(f"[bench] rank {rank}: {args.steps} steps in {wall:.3f}s", file=sys.stderr, flush=True)
+    print(f"[bench] rank {rank}: {args.steps} steps in {wall:.4f}s = {wall * 1e3 / args.steps:.4f} ms/step (wall), "
+          f"{dev_ms / args.steps:.4f} ms/step (HIP events)", file=sys.stderr, flush=True)
+    per_rank_ms = [wall * 1e3 / args.steps]
     if world > 1:
-        t = torch.tensor([wall], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        wall = float(t.item())
+        t = torch.zeros(world, device=dev, dtype=torch.float64)
+        t[rank] = wall
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+        per_rank_ms = [float(x) * 1e3 / args.steps for x in t.tolist()]
+        wall = float(t.max().item())                      # MAX over ranks
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
         launch_ms = dev_ms / args.steps
@@ -464,7 +487,10 @@ def main():
                        "dropout": args.dropout, "lfak": 5, "L1": 0.5, "inject": True, "live": True,
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "priming_steps_untimed": primed,
                        "ranks_seen_by_collective_backend": ranks_seen, "collective_backend": backend,
-                       "gradient_allreduce": "one flat fp32 bucket (25 661 floats) per step between the two step graphs" if pg is not None else None},
+                       "per_rank_ms_per_step": per_rank_ms, "allreduce_in_step_graph": bool(getattr(eng, "dp_single_graph", False)),
+                       "gradient_allreduce": (("one flat fp32 bucket (25 661 floats) per step, " +
+                                               ("recorded in the step's HIP graph (one graph launch per step)" if eng.dp_single_graph
+                                                else f"eager between the two step graphs ({eng.dp_capture_note})")) if pg is not None else None)},
             # achieved / frac: ALGORITHMIC bytes of SURVEY 8(d)'s layer-granular model per second (the contract's definition), not
             # bytes that crossed the HBM pins: the fused step moves fewer (traffic), see measured_hbm_GBs and fp32_TFLOPs
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -39,7 +39,7 @@ static int both_slabs(int n) {
     int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
     int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
     if (both_sparse_ok<CWG> && wgrad_sparse_enabled()) {
-        cap = GW::H >= 64 ? 512 : 256;      // persistent sparse workgroups (swept on the step, tools/sweep_sparse.sh, round 3)
+        cap = GW::H >= 64 ? 512 : 256;      // persistent sparse workgroups (swept on the step in round 3)
     }
     return tiles < cap ? tiles : cap;
 }

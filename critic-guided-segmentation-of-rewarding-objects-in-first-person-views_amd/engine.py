@@ -35,7 +35,7 @@ class HourglassEngine:
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
                  process_group=None, share_with: "HourglassEngine" = None, separate: bool = False, staticnorm: bool = True,
-                 force_allreduce: bool = False):
+                 force_allreduce: bool = False, dp_graph: bool = True):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -50,6 +50,9 @@ class HourglassEngine:
         # data parallel: the all-reduce sits between the step graph and the Adam graph.  force_allreduce keeps that
         # form for a 1-rank group too (rehearsal of the RCCL path on a 1-GPU box).
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
+        # dp_graph: record the all-reduce into the step's HIP graph when the backend allows it (RCCL); False keeps the round-3 form
+        # step graph -> eager all-reduce -> Adam graph
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = bool(dp_graph), False, None
         self.lc, self.lm = critic_layout(), masker_layout()
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         # -separate (main.py:110-111, 390): a second critic supplies the masker's skip inputs; its parameters sit behind the
@@ -145,6 +148,17 @@ class HourglassEngine:
 
     def reset_optimizer(self):
         self.m.zero_(); self.v.zero_(); self.step_t.zero_()
+
+    def snapshot_state(self):
+        """Copies of (parameters, Adam m, v, step counter): restore_state() puts them back in place (the captured HIP graphs keep
+        pointing at the same buffers)."""
+        return tuple(t.clone() for t in (self.flat, self.m, self.v, self.step_t))
+
+    def restore_state(self, snap):
+        with torch.no_grad():
+            for dst, src in zip((self.flat, self.m, self.v, self.step_t), snap):
+                dst.copy_(src)
+        self._pver[0] += 1
 
     # ---- helpers -----------------------------------------------------------------------------
     def _cview(self, a: int, b: int) -> Dict[str, torch.Tensor]:
@@ -386,6 +400,14 @@ class HourglassEngine:
                 return
             # the warm-up was a real step; capture the static sequence for all later steps
             torch.cuda.synchronize()
+            if self.dp and self._collective_capturable():
+                # data parallel, RCCL: the all-reduce is captured too -- the whole step (kernels -> collective -> Adam) is ONE graph launch
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                    body(); allred(); adam()
+                self.dp_single_graph = True
+                self._graphs[tag] = (g1, None, False)
+                return
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 body()
@@ -396,16 +418,46 @@ class HourglassEngine:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     adam()
-            self._graphs[tag] = (g1, g2)
+            self._graphs[tag] = (g1, g2, self.dp)
             return
         if g == "eager":
             body(); allred(); adam()
             return
-        g1, g2 = g
+        g1, g2, eager_allred = g
         g1.replay()
-        if g2 is not None:
+        if eager_allred:
             allred()
             g2.replay()
+
+    def _collective_capturable(self) -> bool:
+        """True when the gradient all-reduce can be recorded into the step's HIP graph: the RCCL backend on device memory (gloo
+        rehearsals stage through the host) and a trial capture + replay of a small all-reduce on this group succeeds.  The reason for
+        a refusal is kept in self.dp_capture_note (bench.py prints it)."""
+        if not self.dp_graph:
+            self.dp_capture_note = "disabled by the caller (dp_graph=False)"
+            return False
+        if getattr(self, "_capturable", None) is not None:
+            return self._capturable
+        import torch.distributed as dist
+        ok = False
+        if dist.get_backend(self.pg) != "nccl":
+            self.dp_capture_note = f"backend {dist.get_backend(self.pg)} reduces through the host"
+        else:
+            try:
+                t = torch.ones(64, device=self.dev)
+                dist.all_reduce(t, group=self.pg)                  # communicator + channels set up outside the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    dist.all_reduce(t, group=self.pg)
+                g.replay()
+                torch.cuda.synchronize()
+                ok = bool(torch.isfinite(t).all().item()) and float(t[0].item()) == float(self.world) ** 2
+                self.dp_capture_note = "trial capture + replay ok" if ok else f"trial replay gave {float(t[0].item())}, expected {self.world ** 2}"
+            except Exception as e:       # noqa: BLE001 -- any failure means: keep the collective outside the graphs
+                self.dp_capture_note = f"trial capture failed: {type(e).__name__}: {e}"
+        self._capturable = ok
+        return ok
 
     # ---- saliency baseline (main.py:941-953): |d mean(pred) / d X| summed over the colour channels ----------------
     def saliency(self, X: torch.Tensor):

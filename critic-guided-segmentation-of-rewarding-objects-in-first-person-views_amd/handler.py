@@ -165,7 +165,7 @@ class Handler:
         a = self.args
         if not a.staticnorm and not hg_mix_fused():
             raise NotImplementedError("-staticnorm '' (mask regulariser weighted by 1 - pred, main.py:415-418) needs the fused "
-                                      "features.0 + mix backward (CGS_ENC0_MIX_FUSED=1, the default)")
+                                      "features.0 + mix backward (hourglass.ENC0_MIX_FUSED, this build's fixed configuration)")
 
     def critic_pipe(self, mode="train", test=0):
         args = self.args

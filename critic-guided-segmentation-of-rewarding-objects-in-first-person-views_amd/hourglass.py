@@ -8,7 +8,6 @@ Reference map:
   *_backward       what loss.backward() does for those modules (main.py:198,462)
 """
 import ctypes as C
-import os
 from typing import Dict, List, Optional
 
 import torch

@@ -359,8 +359,11 @@ class _UnetFn(torch.autograd.Function):
             grads[20], grads[21], grads[22], grads[23] = dw1t.t().contiguous(), db1, dw2t.t().contiguous(), db2
         else:
             u, y = list(sv[10:14]), sv[14]
-            gy = gouts[0].permute(0, 2, 3, 1).contiguous().to(torch.float32).clone()          # NHWC [n,64,64,1]
-            gen.grad_fix(gy, y, act="sigmoid")
+            if gouts[0] is None:      # only the returned embed u0 feeds the loss (set_materialize_grads(False)): zero gradient at the mask
+                gy = torch.zeros_like(y)
+            else:
+                gy = gouts[0].permute(0, 2, 3, 1).contiguous().to(torch.float32).clone()      # NHWC [n,64,64,1]
+                gen.grad_fix(gy, y, act="sigmoid")
             g = gy
             for i in (0, 1, 2, 3):   # dec[i]: ConvTranspose2d(4,2,1) over cat(u_i, p_i)
                 wk = gen.convt_weight_to_kernel(dw[i])

@@ -662,13 +662,15 @@ def test_virtual_mixes_equal_materialised_mixes(ctx):
     np.testing.assert_allclose(zpart[:, 1].double().sum().item(), (zz * zz).sum().item(), rtol=1e-5)
 
 
-def test_zz_relative_error_summary():
-    """Runs last in this module: per-tensor worst PURE relative error (elements >= 1 % of the tensor's maximum) of every rel_close
-    comparison made above -- the number the 1e-3 claim is about, without the absolute term that only protects values near zero."""
-    assert REL_REPORT, "no comparison ran before the summary"
-    worst = sorted(REL_REPORT.items(), key=lambda kv: -kv[1])
-    for what, v in worst[:12]:
-        print(f"worst pure-relative error {v:.2e}  {what}")
-    # tolerance at 1 % of the maximum: 1e-3 + 2e-5 / 1e-2 (parameters after optimiser steps: 1e-4 scale -> 1.1e-2)
-    assert worst[0][1] < 1.2e-2
-    assert sum(v > 3e-3 for _, v in worst) <= max(2, len(worst) // 20), "more than a few tensors are off by over 3e-3 relative"
+def rel_kind(what):
+    """Category of a comparison by its label: parameters after optimiser steps (Adam divides by sqrt(v): a gradient error near a
+    zero gradient is amplified), gradients, or forward tensors."""
+    w = what.lower()
+    if " after " in w or "parameters" in w or w.endswith(" flat") or w.endswith(" m") or w.endswith(" v"):
+        return "param"
+    if "grad" in w or w.startswith("d") or "slab" in w or "dw" in w or "bwd" in w or "backward" in w:
+        return "grad"
+    return "fwd"
+
+
+REL_LIMIT = {"fwd": 1e-3, "grad": 2e-3, "param": 1.1e-2}
