@@ -41,6 +41,7 @@ class GenericEngine(HourglassEngine):
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = True, False, None     # see HourglassEngine
         self.lc, self.lm = critic_layout(self.chfak, self.neck), masker_layout(self.chfak, self.neck)
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         self.separate, self.staticnorm = bool(separate), bool(staticnorm)
