@@ -9,7 +9,7 @@ from test_gpu_kernels import REL_REPORT, REL_LIMIT, rel_kind
 def test_relative_error_summary():
     """Runs last of the whole GPU suite (file name order): per-tensor worst PURE relative error (elements >= 1 % of the tensor's maximum) of every rel_close
     comparison the suite made (every GPU test module goes through test_gpu_kernels.rel_close) -- the number the 1e-3 claim is about, without the absolute term that only protects values near zero.
-    Asserted per category: forward tensors <= 1e-3, gradients <= 2e-3, parameters after optimiser steps <= 1.1e-2 (their check
+    Asserted per category: forward tensors <= 1e-3, gradients <= 2e-3, parameters after optimiser steps <= 5e-3 (measured worst 3.3e-3; their check
     carries a 1e-4 absolute scale: Adam's update is +-lr whatever the gradient's size)."""
     import os
     if not REL_REPORT:
