@@ -45,32 +45,36 @@ template <class C> struct mix_epi_of<C, decltype((void)C::MIX_EPI)> { static con
 // belong to source A), POST_ACT (dgrad: activation whose derivative multiplies d_a).
 // FUSED = true: the body is one stage of a multi-stage workgroup (fused_small.hip): `bid` selects the image
 // group, nobody returns early (barriers of later stages follow) and the LDS region is handed in.
-template <class C, bool FUSED>
-__device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid, float4* smem) {
+// LDS carve-up of a conv3x3 workgroup: source-A tile (float4 planes), one spare slot for redirected stores, source-B tile, the layer's
+// weights in HWIO order (wave-uniform ds_reads broadcast them into VGPRs / the MFMA weight registers), the SRC_DH dzpre tile.
+template <class C>
+struct ConvLds {
     using G = Geo<C::H, C::W, C::THREADS, C::CW>;
-    constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
-    constexpr int PB = C::CB / 4;
-    constexpr int A_ELEMS = PA * G::IMGS * G::TRA * G::PWA;  // float4 slots (floats for SRC_SCALAR)
-    float4* ldsA = smem;
-    constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
-    float4* ldsB = smem + DUMP + 1;
-    constexpr int B_ELEMS = PB == 0 ? 0 : (C::UPS == 2 ? PB * G::IMGS * G::TRB * G::PWB : PB * G::IMGS);
-    // weights staged in LDS (HWIO order as in global memory): wave-uniform ds_reads broadcast them into VGPRs,
-    // so the FMAs are plain v_fma_f32 with vector operands (103 TF/s measured) instead of SGPR-operand or
-    // packed forms (52-60 TF/s measured on gfx950, tools/valu_peak.hip).
-    constexpr int W_FLOATS = 9 * C::WCI * C::WCO;
-    float* ldsW = (float*)(ldsB + B_ELEMS);
-    constexpr int DZW = G::W + 4, DZ_FLOATS = (C::SRC == SRC_DH) ? (G::TRA + 2) * DZW : 0;
-    float* ldsDz = ldsW + ((W_FLOATS + 3) / 4) * 4;     // SRC_DH: dzpre tile with a 2-pixel halo
+    static constexpr int PA = (C::SRC == SRC_SCALAR) ? 1 : (C::CA + 3) / 4;
+    static constexpr int PB = C::CB / 4;
+    static constexpr int A_ELEMS = PA * G::IMGS * G::TRA * G::PWA;  // float4 slots (floats for SRC_SCALAR)
+    static constexpr int DUMP = (C::SRC == SRC_SCALAR) ? (A_ELEMS + 3) / 4 : A_ELEMS;   // one spare slot for redirected stores
+    static constexpr int B_ELEMS = PB == 0 ? 0 : (C::UPS == 2 ? PB * G::IMGS * G::TRB * G::PWB : PB * G::IMGS);
+    static constexpr int W_FLOATS = 9 * C::WCI * C::WCO;
+    static constexpr int DZW = G::W + 4, DZ_FLOATS = (C::SRC == SRC_DH) ? (G::TRA + 2) * DZW : 0;
+};
 
-    const int tid = threadIdx.x;                 // all threads take part in the loads
+// stage 1 of a conv3x3 workgroup: the input tile(s) of tile `bid` into LDS (global loads and LDS stores of all elements, unrolled)
+template <class C>
+__device__ __forceinline__ void conv_stage_inputs(const ConvParams& P, const int bid, const int tid, float4* smem) {
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
+    using L = ConvLds<C>;
+    constexpr int PA = L::PA, PB = L::PB, DUMP = L::DUMP, W_FLOATS = L::W_FLOATS, DZW = L::DZW, DZ_FLOATS = L::DZ_FLOATS;
+    float4* const ldsA = smem;
+    float4* const ldsB = smem + L::DUMP + 1;
+    float* const ldsW = (float*)(ldsB + L::B_ELEMS);
+    [[maybe_unused]] float* const ldsDz = ldsW + ((W_FLOATS + 3) / 4) * 4;     // SRC_DH: dzpre tile with a 2-pixel halo
     const int qtid = tid % C::THREADS;           // quad handled by this thread
-    const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
+    [[maybe_unused]] const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
     const QuadPos q = quad_pos<G>(qtid, bid);
-    const int n0 = (G::IMGS == 1) ? q.n : bid * G::IMGS;
-    const int N = P.n;
-    const DropCtx dc = drop_ctx(P.drop);
-
+    [[maybe_unused]] const int n0 = (G::IMGS == 1) ? q.n : bid * G::IMGS;
+    [[maybe_unused]] const int N = P.n;
+    [[maybe_unused]] const DropCtx dc = drop_ctx(P.drop);
     // ---- stage inputs ----
     if constexpr (C::SRC == SRC_F32) {
         DropCtx dl = dc;
@@ -150,6 +154,20 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
         if constexpr (C::UPS == 2) load_b_half<G, PB>(ldsB, (const float4*)P.src_b, n0, q.row0, N, tid);
         else load_b_pix<G, PB>(ldsB, (const float4*)P.src_b, n0, N, tid);
     }
+}
+
+template <class C>
+__device__ __forceinline__ void conv_stage_weights(const ConvParams& P, const int tid, float4* smem) {
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
+    using L = ConvLds<C>;
+    constexpr int PA = L::PA, PB = L::PB, DUMP = L::DUMP, W_FLOATS = L::W_FLOATS, DZW = L::DZW, DZ_FLOATS = L::DZ_FLOATS;
+    float4* const ldsA = smem;
+    float4* const ldsB = smem + L::DUMP + 1;
+    float* const ldsW = (float*)(ldsB + L::B_ELEMS);
+    [[maybe_unused]] float* const ldsDz = ldsW + ((W_FLOATS + 3) / 4) * 4;     // SRC_DH: dzpre tile with a 2-pixel halo
+    [[maybe_unused]] const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
+    [[maybe_unused]] const int N = P.n;
+    [[maybe_unused]] const DropCtx dc = drop_ctx(P.drop);
     for_elems<(W_FLOATS + 3) / 4, G::LT>(tid, [&](int e) {
         int i = 4 * e;
         float4 v;
@@ -157,8 +175,24 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
         v.z = P.w[i + 2 < W_FLOATS ? i + 2 : 0]; v.w = P.w[i + 3 < W_FLOATS ? i + 3 : 0];
         ((float4*)ldsW)[e] = v;
     });
-    __syncthreads();
+}
 
+// stage 2: the FMA block and the epilogue of tile `bid` from the staged LDS tiles
+template <class C, bool FUSED>
+__device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid, const int tid, float4* smem) {
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
+    using L = ConvLds<C>;
+    constexpr int PA = L::PA, PB = L::PB, DUMP = L::DUMP, W_FLOATS = L::W_FLOATS, DZW = L::DZW, DZ_FLOATS = L::DZ_FLOATS;
+    float4* const ldsA = smem;
+    float4* const ldsB = smem + L::DUMP + 1;
+    float* const ldsW = (float*)(ldsB + L::B_ELEMS);
+    [[maybe_unused]] float* const ldsDz = ldsW + ((W_FLOATS + 3) / 4) * 4;     // SRC_DH: dzpre tile with a 2-pixel halo
+    const int qtid = tid % C::THREADS;           // quad handled by this thread
+    [[maybe_unused]] const int cw = tid / C::THREADS;             // wave-uniform: which output-channel chunks this wave computes
+    const QuadPos q = quad_pos<G>(qtid, bid);
+    [[maybe_unused]] const int n0 = (G::IMGS == 1) ? q.n : bid * G::IMGS;
+    [[maybe_unused]] const int N = P.n;
+    [[maybe_unused]] const DropCtx dc = drop_ctx(P.drop);
     auto wf = [&](int tap, int ci, int oc) -> float {
         if constexpr (C::WT == 0) return ldsW[(tap * C::WCI + ci) * C::WCO + oc];
         else return ldsW[((8 - tap) * C::WCI + oc) * C::WCO + ci];
@@ -459,6 +493,84 @@ __device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid,
     }
 }
 
+
+// Cfg members: see conv_compute.  FUSED = true: the body is one stage of a multi-stage workgroup: `bid` selects the image
+// group, nobody returns early (barriers of later stages follow) and the LDS region is handed in.
+template <class C, bool FUSED>
+__device__ __forceinline__ void conv3x3_body(const ConvParams& P, const int bid, float4* smem) {
+    const int tid = threadIdx.x;                 // all threads take part in the loads
+    conv_stage_inputs<C>(P, bid, tid, smem);
+    conv_stage_weights<C>(P, tid, smem);
+    __syncthreads();
+    conv_compute<C, FUSED>(P, bid, tid, smem);
+}
+
+// optional config member: static constexpr int TPW = k -> a workgroup runs k consecutive tiles (strips of an image) as a software
+// pipeline: the global loads of tile t+1 are issued into registers before the matrix instructions of tile t and written to the LDS
+// tile after them (conv_tile.h fetch_* / commit_*); weights and halo columns are staged once per workgroup.
+template <class C, class = void> struct tpw_of { static constexpr int value = 1; };
+template <class C> struct tpw_of<C, decltype((void)C::TPW)> { static constexpr int value = C::TPW; };
+
+template <class C>
+__device__ __forceinline__ void conv3x3_body_pipe(const ConvParams& P, const int bid0, float4* smem) {
+    using G = Geo<C::H, C::W, C::THREADS, C::CW>;
+    using L = ConvLds<C>;
+    constexpr int PA = L::PA, PB = L::PB, TPW = tpw_of<C>::value;
+    static_assert(G::IMGS == 1, "pipelined tiles are strips of one image");
+    static_assert(CGS_CONV_MFMA4 && C::SRC != SRC_SCALAR && C::SRC != SRC_DH && C::SRC != SRC_F32C3, "matrix-core path, split loaders");
+    static_assert(PB == 0 || C::UPS == 2, "source B at half resolution");
+    static_assert(C::EPI == EPI_DGRAD || !C::DROP, "no Dropout in the split fp32 loader");
+    float4* const ldsA = smem;
+    [[maybe_unused]] float4* const ldsB = smem + L::DUMP + 1;
+    const int tid = threadIdx.x;
+    const int N = P.n;
+    conv_stage_weights<C>(P, tid, smem);
+    zero_halo_cols<G, PA>(ldsA, tid);
+    auto pos = [&](int t, int& n0, int& row0) { const int b = bid0 + t; n0 = b / G::STRIPS; row0 = (b % G::STRIPS) * G::TH; };
+    using RA = std::conditional_t<C::SRC == SRC_F32, FetchF32<G, PA>,
+               std::conditional_t<C::SRC == SRC_U8C3, FetchU8<G>,
+               std::conditional_t<C::SRC == SRC_MIXC3, FetchMix<G>,
+               std::conditional_t<C::SRC == SRC_POOLEXP, FetchPool<G, PA, false>, FetchPool<G, PA, true>>>>>;
+    RA ra;
+    [[maybe_unused]] FetchBHalf<G, PB == 0 ? 1 : PB> rb;
+    auto fetch = [&](int t) {
+        int n0, row0;
+        pos(t, n0, row0);
+        if constexpr (C::SRC == SRC_F32) fetch_a_f32<G, PA>(ra, (const float4*)P.src_a, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_U8C3) fetch_a_u8c3<G>(ra, (const uint32_t*)P.src_a, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_MIXC3) fetch_a_mix<G>(ra, (const uint32_t*)P.mix_a, (const uint32_t*)P.mix_b, (const float4*)P.mix_z, P.mix_n_a, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_POOLEXP) fetch_poolexp<G, PA, false>(ra, (const float4*)P.src_a, P.amask_in, n0, 0, false, row0, N, tid);
+        else fetch_poolexp<G, PA, true>(ra, (const float4*)P.src_a, P.amask_in, n0, P.mix_n_a, P.mix_inject != 0, row0, N, tid);
+        if constexpr (PB > 0) fetch_b_half<G, PB>(rb, (const float4*)P.src_b, n0, row0, N, tid);
+    };
+    auto commit = [&](int t) {
+        int n0, row0;
+        pos(t, n0, row0);
+        auto idx = [](int p, int img, int r, int x) { return ldsA_idx<G, PA>(p, img, r, x + 1); };
+        if constexpr (C::SRC == SRC_F32) commit_a_f32<G, PA>(ra, ldsA, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_U8C3) commit_a_u8c3<G>(ra, ldsA, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_MIXC3) commit_a_mix<G>(ra, ldsA, P.mix_n_a, n0, row0, N, tid);
+        else if constexpr (C::SRC == SRC_POOLEXP) commit_poolexp<G, PA, false>(ra, ldsA, n0, false, row0, N, tid, idx, L::DUMP);
+        else commit_poolexp<G, PA, true>(ra, ldsA, n0, P.mix_inject != 0, row0, N, tid, idx, L::DUMP);
+        if constexpr (PB > 0) commit_b_half<G, PB>(rb, ldsB, n0, row0, N, tid);
+    };
+    fetch(0);
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        commit(t);
+        __syncthreads();
+        if (t + 1 < TPW) fetch(t + 1);
+        conv_compute<C, true>(P, bid0 + t, tid, smem);
+        if (t + 1 < TPW) __syncthreads();      // every wave is done with the tile before the next one is written
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_pipe_kernel(ConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 smem[];
+    conv3x3_body_pipe<C>(P, blockIdx.x * tpw_of<C>::value, smem);
+}
+
 template <class C>
 __global__ void __launch_bounds__(C::THREADS * C::CW) conv3x3_kernel(ConvParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
@@ -524,3 +636,13 @@ CGS_DG_CFG(DMask2, 64, 128, SRC_SCALAR, 1, 16, 1, 2, 0, 16, 8, 16, CGS_ACT_LRELU
 // masker.2 + masker.0 data gradients in one pass (SRC_DH rebuilds d(masker.0 output) in the loader)
 CGS_DG_CFG(DMaskHead, 64, 128, SRC_DH, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 2)
 
+// software-pipelined forms (conv3x3_body_pipe: a workgroup runs all strips of an image), kept where they measured faster (r4b A/B:
+// features.0 on the mixes 32.0 -> 30.8 us, features.0 + mix backward 54.1 -> 50.0, features.3 backward 30.2 -> 29.7, features.0 on the
+// frames 28.7 -> 28.4; features.3 forward, dec_model.0 forward / data gradient were neutral to slower: these kernels are bound by
+// instruction issue, their load phases already hide behind the other resident workgroups)
+#ifndef CGS_CONV_PIPE
+#define CGS_CONV_PIPE 1
+#endif
+struct FEnc0U8P : FEnc0U8 { static constexpr int TPW = 4; };
+struct FEnc0MixP : FEnc0Mix { static constexpr int TPW = 4; };
+struct DEnc1P : DEnc1 { static constexpr int TPW = 2; };

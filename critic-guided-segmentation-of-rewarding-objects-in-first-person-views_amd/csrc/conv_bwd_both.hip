@@ -15,7 +15,8 @@ __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradPar
         constexpr int SLAB = (9 * (CWG::CA + CWG::CB) + 1) * CWG::CO;
         wgrad_dispatch<CWG, SPARSE>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
     } else {
-        conv3x3_body<CDG, false>(pd, blockIdx.x - nbw, smem);
+        if constexpr (tpw_of<CDG>::value > 1) conv3x3_body_pipe<CDG>(pd, (blockIdx.x - nbw) * tpw_of<CDG>::value, smem);
+        else conv3x3_body<CDG, false>(pd, blockIdx.x - nbw, smem);
     }
 }
 
@@ -52,6 +53,8 @@ static int launch_both(WgradParams pw, const ConvParams& pd, hipStream_t st) {
     int tiles = (GW::IMGS == 1) ? pw.n * GW::STRIPS : (pw.n + GW::IMGS - 1) / GW::IMGS;
     int nbw = both_slabs<CWG>(pw.n);
     int nbd = (GD::IMGS == 1) ? pd.n * GD::STRIPS : (pd.n + GD::IMGS - 1) / GD::IMGS;
+    static_assert(tpw_of<CDG>::value == 1 || (GD::IMGS == 1 && GD::STRIPS % tpw_of<CDG>::value == 0), "pipelined strips of one image");
+    nbd /= tpw_of<CDG>::value;
     pw.ntiles = tiles;
     const size_t ld = conv_lds_bytes<CDG>();
     if constexpr (sparse_cfg<CWG>::ok) {
@@ -119,7 +122,7 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
         case 2: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc2, DEnc2>(pw, pd, st);
         case 3: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec1, DDec1>(pw, pd, st);
         case 4: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec2x, DDec2>(pw, pd, st);
-        case 5: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc1, DEnc1>(pw, pd, st);
+        case 5: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return CGS_CONV_PIPE ? launch_both<WEnc1, DEnc1P>(pw, pd, st) : launch_both<WEnc1, DEnc1>(pw, pd, st);
         case 6: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec0, DDec0>(pw, pd, st);
         case 7: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WDec3x, DDec3y>(pw, pd, st);
         case 8: if (d->drop_a.p > 0.f) return CGS_ERR_UNSUPPORTED; return launch_both<WEnc0F32, DEnc0>(pw, pd, st);
@@ -140,6 +143,7 @@ extern "C" int cgs_conv3x3_bwd_both(const cgs_conv_desc* d, const void* src_a, c
 // conv_bwd_both_kernel (bit-identical to it); dzpre equals the two-launch form up to the order of the sums.
 // ------------------------------------------------------------------------------------------------
 struct DEnc0D : DEnc0 { static constexpr bool MIX_EPI = true; static constexpr int SRC = SRC_POOLEXP_DIFF; };
+struct DEnc0DP : DEnc0D { static constexpr int TPW = 4; };
 struct MixBwdArgs {
     const uint8_t* a; const uint8_t* b; const float* z; float* dzpre;
     int n_a, inject;
@@ -157,11 +161,12 @@ __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvP
         wgrad_dispatch<CWG, SPARSE>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
         return;
     }
-    const int bid = blockIdx.x - nbw, img = bid / G::STRIPS, strip = bid % G::STRIPS;
+    const int bid = blockIdx.x - nbw;
     pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
     pd.mix_n_a = M.n_a;
-    conv3x3_body<DEnc0D, true>(pd, img * G::STRIPS + strip, smem);
+    if constexpr (CGS_CONV_PIPE) conv3x3_body_pipe<DEnc0DP>(pd, bid * DEnc0DP::TPW, smem);
+    else conv3x3_body<DEnc0D, true>(pd, bid, smem);
 }
 
 extern "C" int cgs_enc0_bwd_mix_slabs(int32_t n_mix) { return n_mix < 0 ? CGS_ERR_BADARG : both_slabs<WEnc0F32>(n_mix); }
@@ -183,7 +188,7 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     pd.src_a = dy; pd.amask_in = amask; pd.w = w; pd.n = n_mix;
     MixBwdArgs M{a, b, z, dzpre, n_a, inject ? 1 : 0, l1_scale, l2_scale, valuefak_pred};
     const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
-    const int nbd = n_a * GD::STRIPS;
+    const int nbd = CGS_CONV_PIPE ? n_a * GD::STRIPS / DEnc0DP::TPW : n_a * GD::STRIPS;
     const bool sp = wgrad_sparse_enabled() != 0;
     const size_t lw = sp ? wgrad_any_lds_bytes<WEnc0F32, true>() : wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
     const size_t lds = lw > ld ? lw : ld;                    // 41 KB (data-gradient tile): three workgroups per CU

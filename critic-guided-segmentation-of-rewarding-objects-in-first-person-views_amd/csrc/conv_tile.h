@@ -295,6 +295,210 @@ __device__ __forceinline__ void load_b_pix(float4* ldsB, const float4* __restric
     });
 }
 
+template <int N, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split loaders (software pipeline over the tiles of a persistent workgroup, conv3x3_body_pipe): fetch_* issues the global loads of a
+// tile into a REGISTER block, commit_* writes that block into the LDS tile -- the loads of tile t+1 are in flight while the matrix
+// instructions of tile t run, and only the LDS stores sit between two tiles' compute phases.  Same element maps, clamping and
+// select-to-zero as the one-piece loaders above (bit-identical tiles).  The halo columns are zeroed once per workgroup by the caller.
+// ------------------------------------------------------------------------------------------------
+template <int E, int THREADS, class F>
+__device__ __forceinline__ void for_elems_it(int tid, F f) {
+    constexpr int IT = (E + THREADS - 1) / THREADS;
+    static_for<IT>([&](auto I) {
+        constexpr int it = decltype(I)::value;
+        int e = tid + it * THREADS;
+        f(std::integral_constant<int, it>{}, e < E ? e : E - 1);
+    });
+}
+
+template <class G, int PA> struct FetchF32 { static constexpr int E = G::IMGS * G::TRA * G::W * PA, IT = (E + G::LT - 1) / G::LT; float4 v[IT]; };
+template <class G, int PA>
+__device__ __forceinline__ void fetch_a_f32(FetchF32<G, PA>& R, const float4* __restrict__ src, int n0, int row0, int N, int tid) {
+    for_elems_it<FetchF32<G, PA>::E, G::LT>(tid, [&](auto I, int e) {
+        int p = e % PA, x = (e / PA) % G::W, r = (e / (PA * G::W)) % G::TRA, img = e / (PA * G::W * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        R.v[decltype(I)::value] = src[in ? ((n * G::H + y) * G::W + x) * PA + p : 0];
+    });
+}
+template <class G, int PA>
+__device__ __forceinline__ void commit_a_f32(const FetchF32<G, PA>& R, float4* ldsA, int n0, int row0, int N, int tid) {
+    for_elems_it<FetchF32<G, PA>::E, G::LT>(tid, [&](auto I, int e) {
+        int p = e % PA, x = (e / PA) % G::W, r = (e / (PA * G::W)) % G::TRA, img = e / (PA * G::W * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        ldsA[ldsA_idx<G, PA>(p, img, r, x + 1)] = in ? R.v[decltype(I)::value] : f4zero();
+    });
+}
+
+template <class G> struct FetchU8 { static constexpr int E = G::IMGS * G::TRA * (G::W / 4), IT = (E + G::LT - 1) / G::LT; uint32_t d[IT][3]; };
+template <class G>
+__device__ __forceinline__ void fetch_a_u8c3(FetchU8<G>& R, const uint32_t* __restrict__ src, int n0, int row0, int N, int tid) {
+    constexpr int GW = G::W / 4;
+    for_elems_it<FetchU8<G>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        int gi = in ? ((n * G::H + y) * G::W + g * 4) * 3 / 4 : 0;
+        R.d[it][0] = src[gi]; R.d[it][1] = src[gi + 1]; R.d[it][2] = src[gi + 2];
+    });
+}
+template <class G>
+__device__ __forceinline__ void commit_a_u8c3(const FetchU8<G>& R, float4* ldsA, int n0, int row0, int N, int tid) {
+    constexpr int GW = G::W / 4;
+    const float s = 1.f / 255.f;
+    for_elems_it<FetchU8<G>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        uint32_t d0 = in ? R.d[it][0] : 0u, d1 = in ? R.d[it][1] : 0u, d2 = in ? R.d[it][2] : 0u;
+        float4 p0 = make_float4((d0 & 255) * s, ((d0 >> 8) & 255) * s, ((d0 >> 16) & 255) * s, 0.f);
+        float4 p1 = make_float4((d0 >> 24) * s, (d1 & 255) * s, ((d1 >> 8) & 255) * s, 0.f);
+        float4 p2 = make_float4(((d1 >> 16) & 255) * s, (d1 >> 24) * s, (d2 & 255) * s, 0.f);
+        float4 p3 = make_float4(((d2 >> 8) & 255) * s, ((d2 >> 16) & 255) * s, (d2 >> 24) * s, 0.f);
+        int base = (img * G::TRA + r) * G::PWA;
+        ldsA[base + G::pc(g * 4 + 1)] = p0;
+        ldsA[base + G::pc(g * 4 + 2)] = p1;
+        ldsA[base + G::pc(g * 4 + 3)] = p2;
+        ldsA[base + G::pc(g * 4 + 4)] = p3;
+    });
+}
+
+template <class G> struct FetchMix { static constexpr int E = G::IMGS * G::TRA * (G::W / 4), IT = (E + G::LT - 1) / G::LT; uint32_t a[IT][3], b[IT][3]; float4 z[IT]; };
+template <class G>
+__device__ __forceinline__ void fetch_a_mix(FetchMix<G>& R, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                            const float4* __restrict__ z, int n_a, int n0, int row0, int N, int tid) {
+    constexpr int GW = G::W / 4;
+    for_elems_it<FetchMix<G>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        int src_n = in ? (n >= n_a ? n - n_a : n) : 0;
+        int pg = in ? (src_n * G::H + y) * G::W / 4 + g : 0;
+        R.a[it][0] = a[3 * pg]; R.a[it][1] = a[3 * pg + 1]; R.a[it][2] = a[3 * pg + 2];
+        R.b[it][0] = b[3 * pg]; R.b[it][1] = b[3 * pg + 1]; R.b[it][2] = b[3 * pg + 2];
+        R.z[it] = z[pg];
+    });
+}
+template <class G>
+__device__ __forceinline__ void commit_a_mix(const FetchMix<G>& R, float4* ldsA, int n_a, int n0, int row0, int N, int tid) {
+    constexpr int GW = G::W / 4;
+    const float s = 1.f / 255.f;
+    for_elems_it<FetchMix<G>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int g = e % GW, r = (e / GW) % G::TRA, img = e / (GW * G::TRA);
+        int n = n0 + img, y = row0 + r - 1;
+        bool in = n < N && y >= 0 && y < G::H;
+        const bool inj = n >= n_a;
+        uint32_t a0 = R.a[it][0], a1 = R.a[it][1], a2 = R.a[it][2], b0 = R.b[it][0], b1 = R.b[it][1], b2 = R.b[it][2];
+        const float4 zz = R.z[it];
+        if (inj) { uint32_t t; t = a0; a0 = b0; b0 = t; t = a1; a1 = b1; b1 = t; t = a2; a2 = b2; b2 = t; }
+        auto mixv = [&](uint32_t da, uint32_t db, int sh, float zi) {
+            float av = ((da >> sh) & 255) * s, bv = ((db >> sh) & 255) * s;
+            return av * (1.f - zi) + zi * bv;
+        };
+        float4 p0 = make_float4(mixv(a0, b0, 0, zz.x), mixv(a0, b0, 8, zz.x), mixv(a0, b0, 16, zz.x), 0.f);
+        float4 p1 = make_float4(mixv(a0, b0, 24, zz.y), mixv(a1, b1, 0, zz.y), mixv(a1, b1, 8, zz.y), 0.f);
+        float4 p2 = make_float4(mixv(a1, b1, 16, zz.z), mixv(a1, b1, 24, zz.z), mixv(a2, b2, 0, zz.z), 0.f);
+        float4 p3 = make_float4(mixv(a2, b2, 8, zz.w), mixv(a2, b2, 16, zz.w), mixv(a2, b2, 24, zz.w), 0.f);
+        int base = (img * G::TRA + r) * G::PWA;
+        ldsA[base + G::pc(g * 4 + 1)] = in ? p0 : f4zero();
+        ldsA[base + G::pc(g * 4 + 2)] = in ? p1 : f4zero();
+        ldsA[base + G::pc(g * 4 + 3)] = in ? p2 : f4zero();
+        ldsA[base + G::pc(g * 4 + 4)] = in ? p3 : f4zero();
+    });
+}
+
+// pooled gradient + argmax nibbles (HALO = 1 data-gradient tile); DIFF: also image n0 + n_off's (subtracted when sub)
+template <class G, int PA, bool DIFF> struct FetchPool {
+    static constexpr int JR = G::RQ + 2, E = G::IMGS * JR * (G::W / 2) * PA, IT = (E + G::LT - 1) / G::LT;
+    float4 v[IT]; uint32_t nib[IT]; float4 u[DIFF ? IT : 1]; uint32_t nbj[DIFF ? IT : 1];
+};
+template <class G, int PA, bool DIFF>
+__device__ __forceinline__ void fetch_poolexp(FetchPool<G, PA, DIFF>& R, const float4* __restrict__ dp, const uint32_t* __restrict__ am,
+                                              int n0, int n_off, bool sub, int row0, int N, int tid) {
+    constexpr int HP = G::H / 2, WP = G::W / 2, JR = G::RQ + 2, AMW = (PA + 1) / 2;
+    const int pr0 = row0 / 2 - 1;
+    for_elems_it<FetchPool<G, PA, DIFF>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int p = e % PA, px = (e / PA) % WP, j = (e / (PA * WP)) % JR, img = e / (PA * WP * JR);
+        int n = n0 + img, pr = pr0 + j;
+        bool in = n < N && pr >= 0 && pr < HP;
+        int pi = in ? (n * HP + pr) * WP + px : 0;
+        R.v[it] = dp[pi * PA + p];
+        R.nib[it] = am[pi * AMW + (p >> 1)];
+        if constexpr (DIFF) {
+            int pj = (in && sub) ? ((n + n_off) * HP + pr) * WP + px : 0;
+            R.u[it] = dp[pj * PA + p];
+            R.nbj[it] = am[pj * AMW + (p >> 1)];
+        }
+    });
+}
+template <class G, int PA, bool DIFF, class IdxF>
+__device__ __forceinline__ void commit_poolexp(const FetchPool<G, PA, DIFF>& R, float4* lds, int n0, bool sub, int row0, int N, int tid,
+                                               IdxF idx, int dump) {
+    constexpr int HP = G::H / 2, WP = G::W / 2, JR = G::RQ + 2;
+    const int pr0 = row0 / 2 - 1;
+    for_elems_it<FetchPool<G, PA, DIFF>::E, G::LT>(tid, [&](auto I, int e) {
+        constexpr int it = decltype(I)::value;
+        int p = e % PA, px = (e / PA) % WP, j = (e / (PA * WP)) % JR, img = e / (PA * WP * JR);
+        int n = n0 + img, pr = pr0 + j;
+        bool in = n < N && pr >= 0 && pr < HP;
+        uint32_t nib = (R.nib[it] >> ((p & 1) * 16)) & 0xFFFFu;
+        nib = in ? nib : 0xFFFFu;
+        uint32_t nbj = 0xFFFFu;
+        if constexpr (DIFF) {
+            nbj = (R.nbj[it] >> ((p & 1) * 16)) & 0xFFFFu;
+            nbj = (in && sub) ? nbj : 0xFFFFu;
+        }
+#pragma unroll
+        for (int pos = 0; pos < 4; ++pos) {
+            int r = 2 * j + (pos >> 1) - 1;
+            bool ok = r >= 0 && r < G::TH + 2;
+            float4 a = nib_select(R.v[it], nib, pos);
+            if constexpr (DIFF) {
+                const float4 b = nib_select(R.u[it], nbj, pos);
+                a = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+            }
+            lds[ok ? idx(p, img, r, 2 * px + (pos & 1)) : dump] = a;
+        }
+    });
+}
+
+template <class G, int PB> struct FetchBHalf { static constexpr int E = G::IMGS * G::TRB * G::PWB * PB, IT = (E + G::LT - 1) / G::LT; float4 v[IT]; };
+template <class G, int PB>
+__device__ __forceinline__ void fetch_b_half(FetchBHalf<G, PB>& R, const float4* __restrict__ src, int n0, int row0, int N, int tid) {
+    const int sy0 = row0 / 2;
+    for_elems_it<FetchBHalf<G, PB>::E, G::LT>(tid, [&](auto I, int e) {
+        int p = e % PB, c = (e / PB) % G::PWB, r = (e / (PB * G::PWB)) % G::TRB, img = e / (PB * G::PWB * G::TRB);
+        int n = n0 + img, sy = sy0 + r - 1, sx = c - 1;
+        bool in = n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW;
+        R.v[decltype(I)::value] = src[in ? ((n * G::QH + sy) * G::QW + sx) * PB + p : 0];
+    });
+}
+template <class G, int PB>
+__device__ __forceinline__ void commit_b_half(const FetchBHalf<G, PB>& R, float4* ldsB, int n0, int row0, int N, int tid) {
+    const int sy0 = row0 / 2;
+    for_elems_it<FetchBHalf<G, PB>::E, G::LT>(tid, [&](auto I, int e) {
+        int p = e % PB, c = (e / PB) % G::PWB, r = (e / (PB * G::PWB)) % G::TRB, img = e / (PB * G::PWB * G::TRB);
+        int n = n0 + img, sy = sy0 + r - 1, sx = c - 1;
+        bool in = n < N && sy >= 0 && sy < G::QH && sx >= 0 && sx < G::QW;
+        ldsB[((p * G::IMGS + img) * G::TRB + r) * G::PWB + c] = in ? R.v[decltype(I)::value] : f4zero();
+    });
+}
+
 // ------------------------------------------------------------------------------------------------
 // Compute core: accumulate one float4 plane (4 input channels) of a 4x4 receptive field into the
 // 2x2 x OCB accumulator block.  WF(tap, ci, oc) returns the (wave-uniform) weight.
@@ -338,15 +542,6 @@ __device__ __forceinline__ void fma_plane(float (&acc)[4][OCB], const float4 (&p
 // is 9 registers.  An exact fp32 FMA chain in the same (tap, channel) order as fma_plane.
 // ------------------------------------------------------------------------------------------------
 typedef float frag4 __attribute__((ext_vector_type(4)));
-
-template <int N, class F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl<N>(f, std::make_integer_sequence<int, N>{});
-}
 
 // steps (tap, ci) are numbered tap * CIN + ci over ALL input channels of the layer (both sources)
 template <int OCG, int NCH, int CIN, int CI0, int NREG>
