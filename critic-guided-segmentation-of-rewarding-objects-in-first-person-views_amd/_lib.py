@@ -114,6 +114,14 @@ SIGNATURES = {
     "cgs_genbf16_pack_weights": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_genbf16_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_genbf16_gemm": (i32, [i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_genbf16_conv3x3_fwd_train": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_genbf16_pack_weights_t": (i32, [i32, i32, vp, vp, vp]),
+    "cgs_bf16_conv3x3_bwd_weight_slabs": (i32, [i32, i32, i32, i32]),
+    "cgs_bf16_conv3x3_bwd_weight": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_pool_expand": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_cat_split": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, i32, vp]),
+    "cgs_bf16_lrelu_bwd": (i32, [i64, vp, vp, f32, vp]),
+    "cgs_bf16_convert": (i32, [i64, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_convt4s2_fwd": (i32, [i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_data": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),

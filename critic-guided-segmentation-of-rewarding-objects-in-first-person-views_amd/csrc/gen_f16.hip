@@ -42,6 +42,8 @@ struct Gen16ConvParams {
     int a_u8, ca, cb, ups, n, hw, co, act, pool, th, out_f32;
     float slope;
     unsigned long long* dbg;   // debug hook (dbg_gen16_stamps): s_memtime at the stage boundaries of the first 4096 workgroups
+    uint8_t* codes;            // training (pool = 1): argmax position 0..3 of every pooled element, 4 = pooled value <= 0 (no gradient)
+    int a_f32;                 // source A is fp32 NHWC with ca channels (the replaced / injected mixes of the config-5 training step)
 };
 
 unsigned long long* g_gen16_stamps = nullptr;
@@ -58,6 +60,19 @@ __global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __
         const int k = ch * 16 + 4 * q + j;
         const int ci = k < pa4 ? (k < ca ? k : -1) : (k < cp ? ca + (k - pa4) : -1);
         out[e] = E16<BF>::cvt((ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
+    }
+}
+
+// The data gradient's operand: conv3x3(dY [co_layer channels]) with w'[tap][k = layer output channel][col = layer input channel] =
+// w[8 - tap][col][k] (flipped taps, transposed channels) -- the forward kernel then computes d cat(A, up(B)) at full resolution.
+template <bool BF>
+__global__ void __launch_bounds__(256) gen16_pack_weights_T_kernel(const float* __restrict__ w, int ci_layer, int co_layer, typename E16<BF>::T* __restrict__ out) {
+    const int cp = (co_layer + 3) & ~3, nchunk = (cp + 15) / 16, ncol = (ci_layer + 15) / 16 * 16;
+    const int total = 9 * nchunk * 4 * ncol * 4;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int j = e & 3, col = (e >> 2) % ncol, q = ((e >> 2) / ncol) & 3, ch = ((e >> 2) / (ncol * 4)) % nchunk, tap = (e >> 2) / (ncol * 4 * nchunk);
+        const int k = ch * 16 + 4 * q + j;
+        out[e] = E16<BF>::cvt((k < co_layer && col < ci_layer) ? w[((size_t)(8 - tap) * ci_layer + col) * co_layer + k] : 0.f);
     }
 }
 
@@ -130,6 +145,13 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
                                 if (k0 + 2 < P.ca) t4[2] = EL::cvt(s8[2] * sc);
                                 if (k0 + 3 < P.ca) t4[3] = EL::cvt(s8[3] * sc);
                                 v = *(const half4_t*)t4;
+                            } else if (P.a_f32) {          // fp32 NHWC, any ca (uniform branch: training of the 128x128 variant only)
+                                const float* sf = (const float*)P.a + pix * (uint32_t)P.ca + k0;
+                                half_t t4[4] = {EL::cvt(sf[0]), EL::cvt(0.f), EL::cvt(0.f), EL::cvt(0.f)};
+                                if (k0 + 1 < P.ca) t4[1] = EL::cvt(sf[1]);
+                                if (k0 + 2 < P.ca) t4[2] = EL::cvt(sf[2]);
+                                if (k0 + 3 < P.ca) t4[3] = EL::cvt(sf[3]);
+                                v = *(const half4_t*)t4;
                             } else {
                                 v = *(const half4_t*)((const half_t*)P.a + (pix * (uint32_t)P.ca + k0));       // (ca % 4 == 0)
                             }
@@ -182,10 +204,15 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
             const int q = 4 * t + kq, qy = q / QW, qx = q % QW;
             if (P.pool) {
                 float m = gen_act(acc[i][c][0] + bias, P.act, P.slope);
+                uint32_t code = 0;
 #pragma unroll
-                for (int j = 1; j < 4; ++j) m = fmaxf(m, gen_act(acc[i][c][j] + bias, P.act, P.slope));
+                for (int j = 1; j < 4; ++j) {
+                    const float vj = gen_act(acc[i][c][j] + bias, P.act, P.slope);
+                    if (vj > m) { m = vj; code = j; }          // first maximum wins, as max_pool2d
+                }
                 const size_t pp = (((size_t)img * (H / 2) + row0 / 2 + qy) * (W / 2) + qx) * P.co + col;
                 if (P.out_f32) ((float*)P.out)[pp] = m; else ((half_t*)P.out)[pp] = EL::cvt(m);
+                if (P.codes) P.codes[pp] = (uint8_t)(m > 0.f ? code : 4u);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -274,15 +301,18 @@ extern "C" int cgs_genbf16_pack_weights(int32_t ca, int32_t cb, int32_t co, cons
 template <bool BF>
 static int gen16_conv(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups, int32_t act, float slope,
                       int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16, const float* bias, void* out,
-                      cgs_stream_t stream) {
+                      cgs_stream_t stream, uint8_t* codes = nullptr) {
+    const int a_f32 = a_is_u8 == 2;                                   // a_is_u8: 0 = 16-bit, 1 = uint8, 2 = fp32 (bf16 training path)
+    a_is_u8 = a_is_u8 == 1;
     if (n < 0 || !src_a || !w16 || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
-    if (!a_is_u8 && (ca & 3)) return CGS_ERR_BADARG;                  // 16-bit sources are read 4 channels at a time
+    if (!a_is_u8 && !a_f32 && (ca & 3)) return CGS_ERR_BADARG;        // 16-bit sources are read 4 channels at a time
+    if (codes && !pool) return CGS_ERR_BADARG;
     if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
     if (!(gen_hw_ok(hw) || hw == 128)) return CGS_ERR_UNSUPPORTED;    // 128: the build-defined config-5 variant
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     Gen16ConvParams P{src_a, src_b, w16, bias, out, a_is_u8, ca, cb, cb > 0 ? ups : 1, n, hw, co, act, pool,
-                      gen_strip_rows(hw), out_is_f32, slope, g_gen16_stamps};
+                      gen_strip_rows(hw), out_is_f32, slope, g_gen16_stamps, codes, a_f32};
     const int ncb = (co + 15) / 16, strips = hw / P.th;
     const int per = ncb == 1 ? 1 : ((ncb == 2 || ncb == 4) ? 2 : 3);
     const size_t lds = (size_t)(P.th + 2) * (hw + 2) * 16 * 2;
@@ -298,13 +328,31 @@ static int gen16_conv(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co,
 extern "C" int cgs_gen16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                      int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
                                      const void* w16, const float* bias, void* out, cgs_stream_t stream) {
-    if (hw == 128) return CGS_ERR_UNSUPPORTED;          // fp16 = the reference's 64x64 model (config 4)
+    if (hw == 128 || (a_is_u8 != 0 && a_is_u8 != 1)) return CGS_ERR_UNSUPPORTED;          // fp16 = the reference's 64x64 model (config 4)
     return gen16_conv<false>(n, hw, ca, cb, co, a_is_u8, ups, act, slope, pool, out_is_f32, src_a, src_b, w16, bias, out, stream);
 }
 extern "C" int cgs_genbf16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                        int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
                                        const void* w16, const float* bias, void* out, cgs_stream_t stream) {
     return gen16_conv<true>(n, hw, ca, cb, co, a_is_u8, ups, act, slope, pool, out_is_f32, src_a, src_b, w16, bias, out, stream);
+}
+
+// training form of the bf16 convolution: a_kind 0 = bf16, 1 = uint8, 2 = fp32 source A; codes (pool = 1) = the argmax bytes the backward
+// pass re-expands the pooled gradient with (cgs_bf16_pool_expand)
+extern "C" int cgs_genbf16_conv3x3_fwd_train(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, int32_t ups,
+                                             int32_t act, float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b,
+                                             const void* w16, const float* bias, void* out, uint8_t* codes, cgs_stream_t stream) {
+    if (a_kind < 0 || a_kind > 2) return CGS_ERR_BADARG;
+    return gen16_conv<true>(n, hw, ca, cb, co, a_kind, ups, act, slope, pool, out_is_f32, src_a, src_b, w16, bias, out, stream, codes);
+}
+
+extern "C" int cgs_genbf16_pack_weights_t(int32_t ci_layer, int32_t co_layer, const float* w, void* w16, cgs_stream_t stream) {
+    if (ci_layer <= 0 || co_layer <= 0 || !w || !w16) return CGS_ERR_BADARG;
+    const int64_t total = cgs_gen16_packed_weight_halves(co_layer, 0, ci_layer);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gen16_pack_weights_T_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, ci_layer, co_layer, (__bf16*)w16);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
 }
 
 static int gen16_gemm(bool bf, int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_16, int32_t out_is_16, const void* x,

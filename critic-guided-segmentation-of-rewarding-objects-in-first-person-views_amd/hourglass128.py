@@ -3,21 +3,36 @@
 The reference cannot take 128x128 frames: its 4x4 valid convolution (/root/reference/nets.py:184) would see an 8x8 map and
 Flatten -> Linear (nets.py:189-190) shape-errors.  This module defines the smallest change that keeps every
 other layer's shape -- one extra Conv2d(8,8,3)+ReLU+MaxPool stage in front of the encoder, one extra Upsample+cat+Conv2d stage
-behind the decoder -- and runs its eval-mode forward pass (critic value + mask, the -process path) on the bf16 form of the
-shape-generic kernels (csrc/gen_f16.hip: bf16 activations and weights in HBM / LDS, fp32 accumulation on v_mfma_f32_16x16x16_bf16;
-the 4x4 valid convolution, the Linear layers and the decoder's 1x1 pointwise convolution as MFMA GEMMs).
-PARITY UNPINNED: there is no reference counterpart; tests compare against the build's own fp32 CPU restatement
-(oracle/hourglass_ref.py, hourglass128_apply) with a stated bf16 tolerance.  Not wired into main.py (the reference's CLI has no
-such size); `bench.py --config 5` measures it."""
+behind the decoder -- and runs
+
+  * infer()        the eval-mode forward pass (critic value + mask, the -process path), and
+  * phase2_step()  (round 4) the mask-training step with the loss arrangement of main.py:364-429 (critic on [B|A], mask on A,
+                   replaced / injected mixes, critic on the mixes, lfak MSE(A) + MSE(replaced, B) + MSE(injected, A) + L1 |Z|,
+                   Adam on critic + masker), Dropout off
+
+on bf16 kernels: bf16 activations and activation gradients in HBM, bf16 operand copies of the 3x3 weights, fp32 accumulation, fp32
+master weights / Adam state in ONE flat buffer (kernel layout: HWIO weights followed by their bias, k-major GEMM matrices).
+Forward and data gradients: csrc/gen_f16.hip (v_mfma_f32_16x16x16_bf16; the data gradient is the same kernel on the flipped /
+transposed operand); weight gradients: csrc/gen_bf16_train.hip (v_mfma_f32_16x16x32_bf16 over K = 32 pixels, operands through
+ds_read_b64_tr_b16); the 4x4 valid convolution, the Linear layers and the decoder's 1x1 pointwise convolution as MFMA GEMMs (bf16
+rows forward, fp32 backward: a few thousand multiply-adds per image).
+PARITY UNPINNED: there is no reference counterpart; tests compare against the build's own fp32 CPU restatement and its autograd
+(oracle/hourglass_ref.py, hourglass128_apply / hourglass128_phase2_loss) with a stated bf16 tolerance.  Not wired into main.py (the
+reference's CLI has no such size); `bench.py --config 5 [--mode train]` measures it."""
 import ctypes as C
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
 from . import _lib
+from . import generic as gen
+from . import hourglass as hg
+from . import parallel
 from .generic import _ACT, _p, _s
 
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
+ENC_HW = (128, 64, 32, 16, 8)            # pre-pool map size of the five encoder stages
+GEMM_KEYS = ("features.17", "crit.1", "crit.4")
 
 
 def _hwio(w: torch.Tensor) -> torch.Tensor:
@@ -25,63 +40,143 @@ def _hwio(w: torch.Tensor) -> torch.Tensor:
 
 
 class Hourglass128:
-    """Holds one parameter set (dicts of fp32 tensors with the key names of oracle.critic128_shapes / masker128_shapes) in the
-    kernels' layouts: bf16 operand copies of the 3x3 layers, fp32 k-major matrices for the GEMM-shaped layers."""
+    """One parameter set (dicts of fp32 tensors with the key names of oracle.critic128_shapes / masker128_shapes) as a flat fp32
+    master buffer in the kernels' layouts + the bf16 operand copies of the 3x3 layers."""
 
     def __init__(self, critic_params: Dict[str, torch.Tensor], masker_params: Dict[str, torch.Tensor], device="cuda:0", chfak: int = 1,
-                 neck: int = 32, masker_channels: int = 16):
+                 neck: int = 32, masker_channels: int = 16, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, lfak: float = 5.0,
+                 L1: float = 0.5, L2: float = 0.0, process_group=None):
         if not torch.cuda.is_available():
             raise _lib.CgsError("Hourglass128 needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = _lib.load()
-        self.dev = torch.device(device)
+        self.dev = dev = torch.device(device)
         d = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
         self.d, self.nb, self.mc = d, neck * chfak, masker_channels
-        dev = self.dev
+        nb = self.nb
+        self.lr, self.b1, self.b2, self.eps, self.lfak, self.L1, self.L2 = lr, betas[0], betas[1], eps, lfak, L1, L2
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         f = lambda t: t.detach().to(dev, torch.float32).contiguous()
-        self.w16, self.bias, self.mat = {}, {}, {}
-
-        def conv(key, P, ca, cb, co):
-            w = _hwio(f(P[key + ".weight"]))
-            nh = self.lib.cgs_gen16_packed_weight_halves(ca, cb, co)
-            w16 = torch.empty(nh, device=dev, dtype=torch.bfloat16)
-            _lib.call("cgs_genbf16_pack_weights", ca, cb, co, _p(w), _p(w16), _s())
-            self.w16[key], self.bias[key] = w16, f(P[key + ".bias"])
-
+        # ---- layout: (key, kind, shape info) in flat order; conv = [9 ci co | co], gemm = [k n | n] ----
+        self.convs = {}      # key -> (ca, cb, co)
         cin = 3
         for key, co in zip(ENC_KEYS, d):
-            conv(key, critic_params, cin, 0, co)
+            self.convs[key] = (cin, 0, co)
             cin = co
-        nb = self.nb
-        # GEMM-shaped layers, k-major [k][n]: the 4x4 valid convolution (k = (y*4+x)*c), the Linear layers, the 1x1 convolution
-        self.mat["features.17"] = f(critic_params["features.17.weight"]).permute(2, 3, 1, 0).contiguous().reshape(16 * d[4], nb)
-        self.mat["crit.1"] = f(critic_params["crit.1.weight"]).t().contiguous()
-        self.mat["crit.4"] = f(critic_params["crit.4.weight"]).t().contiguous()
-        self.mat["dec_model.5"] = f(masker_params["dec_model.5.weight"]).reshape(nb, nb).t().contiguous()
-        for k, P in (("features.17", critic_params), ("crit.1", critic_params), ("crit.4", critic_params), ("dec_model.5", masker_params)):
-            self.bias[k] = f(P[k + ".bias"])
-        conv("dec_model.4", masker_params, d[4], nb, d[4])
+        self.convs["dec_model.4"] = (d[4], nb, d[4])
         for i in (3, 2, 1, 0):
-            conv(f"dec_model.{i}", masker_params, d[i], d[i + 1], d[i])
-        conv("masker.0", masker_params, 3, d[0], masker_channels)
-        conv("masker.2", masker_params, masker_channels, 0, 1)
+            self.convs[f"dec_model.{i}"] = (d[i], d[i + 1], d[i])
+        self.convs["masker.0"] = (3, d[0], masker_channels)
+        self.convs["masker.2"] = (masker_channels, 0, 1)
+        self.gemms = {"features.17": (16 * d[4], nb), "crit.1": (nb, nb), "crit.4": (nb, 1), "dec_model.5": (nb, nb)}
+        self.critic_keys = list(ENC_KEYS) + list(GEMM_KEYS)
+        self.masker_keys = ["dec_model.5", "dec_model.4", "dec_model.3", "dec_model.2", "dec_model.1", "dec_model.0", "masker.0", "masker.2"]
+        self.off, total = {}, 0
+        for key in self.critic_keys + self.masker_keys:
+            cnt = (9 * (self.convs[key][0] + self.convs[key][1]) * self.convs[key][2] + self.convs[key][2]) if key in self.convs else \
+                  (self.gemms[key][0] * self.gemms[key][1] + self.gemms[key][1])
+            self.off[key] = (total, cnt)
+            total += (cnt + 3) // 4 * 4
+        self.total = total
+        self.flat = torch.zeros(total, device=dev)
+        self.grad, self.m, self.v = torch.zeros_like(self.flat), torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.step_t = torch.zeros(1, device=dev, dtype=torch.int64)
+        self.load_state(critic_params, masker_params)
+        self.w16, self.w16T = {}, {}
+        for key, (ca, cb, co) in self.convs.items():
+            self.w16[key] = torch.empty(self.lib.cgs_gen16_packed_weight_halves(ca, cb, co), device=dev, dtype=torch.bfloat16)
+            self.w16T[key] = torch.empty(self.lib.cgs_gen16_packed_weight_halves(co, 0, ca + cb), device=dev, dtype=torch.bfloat16)
+        self._pack_weights(transposed=False)
+        self._train = None
         torch.cuda.current_stream().synchronize()
 
-    def _conv(self, key, a, b, co, act="none", pool=False, ups=2, out_f32=False):
+    # ---- parameters -----------------------------------------------------------------------------------------------------------
+    def _wview(self, key):
+        o, cnt = self.off[key]
+        nbias = self.convs[key][2] if key in self.convs else self.gemms[key][1]
+        return self.flat[o:o + cnt - nbias], self.flat[o + cnt - nbias:o + cnt]
+
+    def load_state(self, critic_params=None, masker_params=None):
+        f = lambda t: t.detach().to(self.dev, torch.float32).contiguous()
+        with torch.no_grad():
+            for P in (critic_params, masker_params):
+                if P is None:
+                    continue
+                for key in self.critic_keys + self.masker_keys:
+                    if key + ".weight" not in P:
+                        continue
+                    w, b = self._wview(key)
+                    W = f(P[key + ".weight"])
+                    if key in self.convs:
+                        w.copy_(_hwio(W))
+                    elif key == "features.17":      # 4x4 valid convolution: k = (y*4+x)*c
+                        w.copy_(W.permute(2, 3, 1, 0).contiguous().reshape(-1))
+                    elif key == "dec_model.5":      # 1x1 convolution
+                        w.copy_(W.reshape(self.nb, self.nb).t().contiguous().reshape(-1))
+                    else:
+                        w.copy_(W.t().contiguous().reshape(-1))
+                    b.copy_(f(P[key + ".bias"]))
+        if self.pg is not None:
+            parallel.broadcast_params_(self.flat, self.pg)
+        if getattr(self, "w16", None):
+            self._pack_weights(transposed=self._train is not None)
+
+    def state_dicts(self):
+        """(critic, masker) parameter dicts in the shapes of oracle.critic128_shapes / masker128_shapes (fp32 master weights)."""
+        out = ({}, {})
+        for which, keys in enumerate((self.critic_keys, self.masker_keys)):
+            for key in keys:
+                w, b = self._wview(key)
+                if key in self.convs:
+                    ca, cb, co = self.convs[key]
+                    W = w.reshape(3, 3, ca + cb, co).permute(3, 2, 0, 1)
+                elif key == "features.17":
+                    W = w.reshape(4, 4, self.d[4], self.nb).permute(3, 2, 0, 1)
+                elif key == "dec_model.5":
+                    W = w.reshape(self.nb, self.nb).t().reshape(self.nb, self.nb, 1, 1)
+                else:
+                    k, n = self.gemms[key]
+                    W = w.reshape(k, n).t()
+                out[which][key + ".weight"], out[which][key + ".bias"] = W.contiguous().clone(), b.clone()
+        return out
+
+    def _pack_weights(self, transposed: bool):
+        for key, (ca, cb, co) in self.convs.items():
+            w, _ = self._wview(key)
+            _lib.call("cgs_genbf16_pack_weights", ca, cb, co, _p(w), _p(self.w16[key]), _s())
+            if transposed:
+                _lib.call("cgs_genbf16_pack_weights_t", ca + cb, co, _p(w), _p(self.w16T[key]), _s())
+
+    # ---- layer wrappers ---------------------------------------------------------------------------------------------------------
+    def _conv(self, key, a, b, co, act="none", pool=False, ups=2, out_f32=False, out=None, codes=None, w16=None, a_kind=None):
         n, hw, ca = a.shape[0], a.shape[1], a.shape[3]
         cb = 0 if b is None else b.shape[-1]
         oh = hw // 2 if pool else hw
-        out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
-        _lib.call("cgs_genbf16_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], 0.01, int(pool), int(out_f32),
-                  _p(a), _p(b), _p(self.w16[key]), _p(self.bias[key]), _p(out), _s())
+        if out is None:
+            out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        if a_kind is None:
+            a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+        bias = self._wview(key)[1] if w16 is None else self._zero_bias(co)
+        _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, ca, cb, co, a_kind, ups, _ACT[act], 0.01, int(pool), int(out_f32), _p(a), _p(b),
+                  _p(self.w16[key] if w16 is None else w16), _p(bias), _p(out), _p(codes), _s())
         return out
 
-    def _gemm(self, key, x, k, n_out, act="none", out_bf16=True):
+    def _zero_bias(self, co):
+        z = getattr(self, "_zb", None)
+        if z is None or z.numel() < co:
+            z = self._zb = torch.zeros(max(64, co), device=self.dev)
+        return z
+
+    def _gemm(self, key, x, k, n_out, act="none", out_bf16=True, out=None):
         m = x.shape[0]
-        out = torch.empty((m, n_out), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-        _lib.call("cgs_genbf16_gemm", m, k, n_out, _ACT[act], 0.01, int(x.dtype == torch.bfloat16), int(out_bf16), _p(x), _p(self.mat[key]),
-                  _p(self.bias[key]), _p(out), _s())
+        if out is None:
+            out = torch.empty((m, n_out), device=x.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+        w, b = self._wview(key)
+        _lib.call("cgs_genbf16_gemm", m, k, n_out, _ACT[act], 0.01, int(x.dtype == torch.bfloat16), int(out_bf16), _p(x), _p(w), _p(b),
+                  _p(out), _s())
         return out
 
+    # ---- inference (eval-mode forward) ------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def infer(self, x_u8: torch.Tensor):
         """x_u8: NHWC uint8 [n,128,128,3] on the device.  Returns (pred [n] fp32, Z [n,128,128] fp32)."""
@@ -102,6 +197,215 @@ class Hourglass128:
         hm = self._conv("masker.0", x_u8, o, self.mc, act="lrelu")
         Z = self._conv("masker.2", hm, None, 1, act="sigmoid", out_f32=True).reshape(n, 128, 128)
         return pred, Z
+
+    # ---- training (round 4) ---------------------------------------------------------------------------------------------------------
+    class _Train:
+        """Buffers of a phase-2 step for n A-images (+ n B-images): everything preallocated, the step is a static launch sequence."""
+
+        def __init__(self, net: "Hourglass128", n: int):
+            dev, d, nb = net.dev, net.d, net.nb
+            bf = lambda *s: torch.empty(s, device=dev, dtype=torch.bfloat16)
+            f32 = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+            u8 = lambda *s: torch.empty(s, device=dev, dtype=torch.uint8)
+            self.n = n
+            n4 = 4 * n
+            self.ab = u8(2 * n, 128, 128, 3)              # [B | A]
+            self.y = f32(n)
+            self.mixed, self.dmixed = f32(2 * n, 128, 128, 3), f32(2 * n, 128, 128, 3)
+            # critic activations for the 4n slots [B | A | replaced | injected]
+            self.e = [bf(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
+            self.codes = [u8(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
+            self.e4f = f32(n4, 16 * d[4])
+            self.e5, self.h1, self.pred = f32(n4, nb), f32(n4, nb), f32(n4)
+            # masker
+            self.o5 = bf(n, nb)
+            self.o = [bf(n, 64, 64, d[0]), bf(n, 32, 32, d[1]), bf(n, 16, 16, d[2]), bf(n, 8, 8, d[3]), bf(n, 4, 4, d[4])]   # o0 .. o4
+            self.hm, self.Z = bf(n, 128, 128, net.mc), f32(n, 128, 128)
+            self.nzpart = net.lib.cgs_mix_fwd_partials(n, 16384)
+            self.zsum, self.losses, self.dpred = f32(2 * self.nzpart), torch.zeros(8, device=dev), f32(n4)
+            self.dzpre = f32(n, 128, 128)
+            self.ws: Dict[str, torch.Tensor] = {}
+            self.gws = gen.Workspace()
+            self.plan_a = self.plan_b = None
+
+        def buf(self, name, shape, dtype=torch.bfloat16, dev=None):
+            t = self.ws.get(name)
+            if t is None:
+                t = self.ws[name] = torch.empty(shape, device=dev, dtype=dtype)
+            return t
+
+    def _critic_forward(self, T, src, lo: int, hi: int):
+        """Critic on slots [lo, hi): src = the frames / mixes of those slots (uint8 or fp32 NHWC)."""
+        n, d, nb = hi - lo, self.d, self.nb
+        x = src
+        for i, (key, co) in enumerate(zip(ENC_KEYS, d)):
+            x = self._conv(key, x, None, co, act="relu", pool=True, out=T.e[i][lo:hi], codes=T.codes[i][lo:hi])
+        e4 = T.e[4][lo:hi].reshape(n, 16 * d[4])
+        _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 1, _p(e4), _p(T.e4f[lo:hi]), _s())      # fp32 copy for the head's weight gradient
+        self._gemm("features.17", e4, 16 * d[4], nb, act="relu", out_bf16=False, out=T.e5[lo:hi])
+        self._gemm("crit.1", T.e5[lo:hi], nb, nb, act="relu", out_bf16=False, out=T.h1[lo:hi])
+        self._gemm("crit.4", T.h1[lo:hi], nb, 1, act="sigmoid", out_bf16=False, out=T.pred[lo:hi])
+
+    def _masker_forward(self, T, A):
+        n, d, nb = T.n, self.d, self.nb
+        ea = [t[n:2 * n] for t in T.e]
+        self._gemm("dec_model.5", T.e5[n:2 * n], nb, nb, out=T.o5)
+        self._conv("dec_model.4", ea[4], T.o5.view(n, 1, 1, nb), d[4], ups=4, out=T.o[4])
+        for i in (3, 2, 1, 0):
+            self._conv(f"dec_model.{i}", ea[i], T.o[i + 1], d[i], out=T.o[i])
+        self._conv("masker.0", A, T.o[0], self.mc, act="lrelu", out=T.hm)
+        self._conv("masker.2", T.hm, None, 1, act="sigmoid", out_f32=True, out=T.Z.view(n, 128, 128, 1))
+
+    def _wgrad(self, T, plan, key, tag, n, hw, a, b, ups, dy, dyc=None):
+        ca, cb, co = self.convs[key]
+        nsl = self.lib.cgs_bf16_conv3x3_bwd_weight_slabs(n, hw, ca, cb)
+        cnt = 9 * (ca + cb) * co + co
+        slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
+        a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+        _lib.call("cgs_bf16_conv3x3_bwd_weight", n, hw, ca, cb, co, dyc if dyc is not None else co, a_kind, ups, _p(a), _p(b), _p(dy), _p(slab), _s())
+        plan.add(slab, nsl, cnt, self.off[key][0])
+
+    def _dgrad(self, T, key, dy, name, out_f32=False, dy_channels=None):
+        """d cat(A, up(B)) [n,hw,hw,ca+cb] of layer `key` from dy [n,hw,hw,co (padded to dy_channels)]."""
+        ca, cb, co = self.convs[key]
+        n, hw = dy.shape[0], dy.shape[1]
+        out = T.buf(name, (n, hw, hw, ca + cb), torch.float32 if out_f32 else torch.bfloat16, self.dev)
+        _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, dy_channels if dy_channels is not None else co, 0, ca + cb, 0, 1, _lib.ACT_NONE, 0.01, 0,
+                  int(out_f32), _p(dy), None, _p(self.w16T[key]), _p(self._zero_bias(ca + cb)), _p(out), None, _s())
+        return out
+
+    def _gemm_bwd(self, T, plan, key, tag, x, g, need_dx=True):
+        """y = x [n,k] . W [k,m] + b: registers dW / db slabs (split over the batch), returns d x = g . W^T [n,k] (fp32)."""
+        k, m = self.gemms[key]
+        n = x.shape[0]
+        w, _ = self._wview(key)
+        o = self.off[key][0]
+        gen.gemm_ex_batch(plan, T.gws, f"{key}_{tag}_w", o, k, n, m, x, 1, k, g, m, 1, self.dev)                  # x^T . g
+        ones = T.ws.get("ones")
+        if ones is None:
+            ones = T.ws["ones"] = torch.ones(max(4 * T.n, 64), device=self.dev)
+        gen.gemm_ex_batch(plan, T.gws, f"{key}_{tag}_b", o + k * m, 1, n, m, ones, 0, 1, g, m, 1, self.dev)       # column sums
+        if not need_dx:
+            return None
+        dx = T.buf(f"dx_{key}_{tag}", (n, k), torch.float32, self.dev)
+        gen.gemm_ex(n, m, k, g, m, 1, w, 1, m, dx)                                                                # g . W^T
+        return dx
+
+    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None):
+        """Backward of the critic on slots [lo, hi) from T.dpred; skips = [dskip_0..4] gradients arriving at the embeds from the
+        decoder (bf16), d_e5_add fp32 [n,nb]; want_dx: fp32 [n,128,128,3] output for the image gradient."""
+        n, d, nb = hi - lo, self.d, self.nb
+        dz = T.buf(f"dz_{tag}", (n, 1), torch.float32, self.dev)
+        dz.copy_(T.dpred[lo:hi].reshape(n, 1))
+        gen.grad_fix(dz, T.pred[lo:hi].reshape(n, 1), act="sigmoid")
+        dh1 = self._gemm_bwd(T, plan, "crit.4", tag, T.h1[lo:hi], dz)
+        gen.grad_fix(dh1, T.h1[lo:hi], act="relu")
+        de5 = self._gemm_bwd(T, plan, "crit.1", tag, T.e5[lo:hi], dh1)
+        gen.grad_fix(de5, T.e5[lo:hi], act="relu", addend=d_e5_add)
+        de4f = self._gemm_bwd(T, plan, "features.17", tag, T.e4f[lo:hi], de5)
+        dp = T.buf(f"dp4_{tag}", (n, 4, 4, d[4]), torch.bfloat16, self.dev)
+        _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 0, _p(de4f), _p(dp), _s())
+        for i in (4, 3, 2, 1, 0):
+            key, hw, co = ENC_KEYS[i], ENC_HW[i], d[i]
+            dyf = T.buf(f"dyf{i}_{tag}", (n, hw, hw, co), torch.bfloat16, self.dev)
+            _lib.call("cgs_bf16_pool_expand", n, hw // 2, co, _p(dp), _p(skips[i]) if skips is not None else None, _p(T.codes[i][lo:hi]), _p(dyf), _s())
+            a = src if i == 0 else T.e[i - 1][lo:hi]
+            self._wgrad(T, plan, key, tag, n, hw, a, None, 2, dyf)
+            if i > 0:
+                dp = self._dgrad(T, key, dyf, f"de{i - 1}_{tag}")
+            elif want_dx is not None:
+                ca = 3
+                _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, co, 0, ca, 0, 1, _lib.ACT_NONE, 0.01, 0, 1, _p(dyf), None, _p(self.w16T[key]),
+                          _p(self._zero_bias(ca)), _p(want_dx), None, _s())
+
+    def _masker_backward(self, T, plan, A):
+        n, d, nb = T.n, self.d, self.nb
+        ea = [t[n:2 * n] for t in T.e]
+        dz4 = T.buf("dz4", (n, 128, 128, 4), torch.bfloat16, self.dev)
+        _lib.call("cgs_bf16_convert", n * 16384, 1, 4, 0, _p(T.dzpre), _p(dz4), _s())
+        self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, dz4, dyc=4)
+        dh = self._dgrad(T, "masker.2", dz4, "dhm", dy_channels=4)
+        _lib.call("cgs_bf16_lrelu_bwd", dh.numel(), _p(dh), _p(T.hm), 0.01, _s())
+        self._wgrad(T, plan, "masker.0", "m", n, 128, A, T.o[0], 2, dh)
+        dcat = self._dgrad(T, "masker.0", dh, "dcat_m0")
+        do = T.buf("do0", (n, 64, 64, d[0]), torch.bfloat16, self.dev)
+        _lib.call("cgs_bf16_cat_split", n, 128, 3, d[0], 2, _p(dcat), None, _p(do), 0, _s())
+        skips = [None] * 5
+        for i in (0, 1, 2, 3):
+            key, hw = f"dec_model.{i}", 64 >> i
+            self._wgrad(T, plan, key, "m", n, hw, ea[i], T.o[i + 1], 2, do)
+            dcat = self._dgrad(T, key, do, f"dcat_d{i}")
+            skips[i] = T.buf(f"dskip{i}", (n, hw, hw, d[i]), torch.bfloat16, self.dev)
+            do = T.buf(f"do{i + 1}", (n, hw // 2, hw // 2, d[i + 1]), torch.bfloat16, self.dev)
+            _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(do), 0, _s())
+        self._wgrad(T, plan, "dec_model.4", "m", n, 4, ea[4], T.o5, 4, do)
+        dcat = self._dgrad(T, "dec_model.4", do, "dcat_d4")
+        skips[4] = T.buf("dskip4", (n, 4, 4, d[4]), torch.bfloat16, self.dev)
+        do5 = T.buf("do5", (n, nb), torch.float32, self.dev)
+        _lib.call("cgs_bf16_cat_split", n, 4, d[4], nb, 4, _p(dcat), _p(skips[4]), _p(do5), 1, _s())
+        de5 = self._gemm_bwd(T, plan, "dec_model.5", "m", T.e5[n:2 * n], do5)
+        return skips, de5
+
+    def _phase2_body(self, T):
+        n = T.n
+        A, B = T.ab[n:], T.ab[:n]
+        self._critic_forward(T, T.ab, 0, 2 * n)
+        self._masker_forward(T, A)
+        _lib.call("cgs_mix_fwd", n, 16384, _p(A), _p(B), _p(T.Z), 1, _p(T.mixed), _p(T.zsum), _s())
+        self._critic_forward(T, T.mixed, 2 * n, 4 * n)
+        nz = n * 16384
+        _lib.call("cgs_phase2_losses", n, _p(T.pred), _p(T.y), _p(T.zsum), T.nzpart, self.lfak, self.L1, self.L2, 1 | 2, nz, _p(T.losses),
+                  _p(T.dpred), _s())
+        first = T.plan_a is None
+        pa, pb = hg.SlabPlan(), hg.SlabPlan()
+        self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
+        _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
+        skips, de5 = self._masker_backward(T, pa, A)
+        self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips)
+        if first:
+            T.plan_a, T.plan_b = pa.build(self.grad), pb.build(self.grad, accumulate=True)
+        T.plan_a.run(None)
+        T.plan_b.run(self.step_t)        # ticks the step counter
+        if self.pg is not None and self.world > 1:
+            parallel.allreduce_sum_(self.grad, self.pg)
+        _lib.call("cgs_adam_flat", self.total, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), _p(self.step_t), self.lr, self.b1, self.b2,
+                  self.eps, 1.0 / self.world, _s())
+        self._pack_weights(transposed=True)
+
+    def phase2_step(self, A_u8: Optional[torch.Tensor] = None, B_u8: Optional[torch.Tensor] = None, Y: Optional[torch.Tensor] = None,
+                    use_graph: bool = True):
+        """One optimiser step (loss arrangement of main.py:364-429, Dropout off) on n A-frames / n B-frames (uint8 NHWC [n,128,128,3])
+        and targets Y [n]; omitted inputs reuse the resident batch.  Returns the device tensor losses[8] = (critic, replace, inject,
+        l1, l2, total, 0, 0)."""
+        if self._train is None:
+            if A_u8 is None:
+                raise _lib.CgsError("the first phase2_step needs the batch")
+            self._train = Hourglass128._Train(self, A_u8.shape[0])
+            self._pack_weights(transposed=True)
+            self._graph = None
+        T = self._train
+        n = T.n
+        for t, dst in ((A_u8, T.ab[n:]), (B_u8, T.ab[:n])):
+            if t is not None:
+                if t.dtype != torch.uint8 or tuple(t.shape) != (n, 128, 128, 3):
+                    raise _lib.CgsError(f"phase2_step reads uint8 frames [{n},128,128,3]")
+                dst.copy_(t, non_blocking=True)
+        if Y is not None:
+            T.y.copy_(Y.to(torch.float32), non_blocking=True)
+        if self._graph is None:
+            self._phase2_body(T)                 # eager: allocations + reduction tables
+            self._graph = "eager"
+            if use_graph and (self.pg is None or self.world == 1):
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._phase2_body(T)
+                self._graph = g
+        elif self._graph == "eager":
+            self._phase2_body(T)
+        else:
+            self._graph.replay()
+        return T.losses
 
     # fp32 algorithmic traffic / FLOPs per image (layer-granular model of SURVEY.md section 8d, applied to this variant)
     @staticmethod

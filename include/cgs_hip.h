@@ -474,6 +474,32 @@ int cgs_genbf16_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32
                             const float* bias, void* out, cgs_stream_t stream);
 int cgs_genbf16_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_bf16, int32_t out_is_bf16, const void* x,
                      const float* w, const float* bias, void* out, cgs_stream_t stream);
+
+/* ---- bf16 TRAINING of the build-defined 128x128 variant (BASELINE config 5; hourglass128.py; csrc/gen_bf16_train.hip) -------------------
+ * No reference counterpart (the reference's 4x4 valid convolution nets.py:184 cannot take 128x128 frames): parity unpinned.
+ * cgs_genbf16_conv3x3_fwd_train: cgs_genbf16_conv3x3_fwd with source A bf16 (a_kind 0), uint8 (1) or fp32 (2: the replaced / injected
+ *   mixes) and, for pooled layers, codes [n,hw/2,hw/2,co] = the argmax position 0..3 of every pooled element (4: value <= 0).
+ * cgs_genbf16_pack_weights_t: the data gradient's operand -- cgs_genbf16_conv3x3_fwd(ca = co_layer, cb = 0, co = ci_layer) on it computes
+ *   d cat(A, up(B)) [n,hw,hw,ci_layer] from dY [n,hw,hw,co_layer] (packed size cgs_gen16_packed_weight_halves(co_layer, 0, ci_layer)).
+ * cgs_bf16_conv3x3_bwd_weight: slab [cgs_bf16_conv3x3_bwd_weight_slabs(n,hw,ca,cb)][9 (ca+cb) co + co] = per-workgroup partial
+ *   (dW in HWIO order | db) of conv3x3(cat(A, up_ups(B))) from dY [n,hw,hw,dy_channels] (bf16; columns >= co zero padding), on
+ *   v_mfma_f32_16x16x32_bf16 with K = 32 pixels (operands through ds_read_b64_tr_b16); summed by cgs_reduce_slabs.
+ * cgs_bf16_pool_expand: out [n,2hp,2hp,c] = (dp [n,hp,hp,c] (+ addend)) at the argmax position, 0 elsewhere (backward of ReLU + MaxPool2d(2)).
+ * cgs_bf16_cat_split: d cat [n,hw,hw,ca+cb] -> dskip [n,hw,hw,ca] (may be NULL) and dlow [n,hw/ups,hw/ups,cb] (cell sums; fp32 when low_is_f32).
+ * cgs_bf16_lrelu_bwd: d *= LeakyReLU'(h) in place.  cgs_bf16_convert: rows x c_src -> rows x c_dst (zero pad), fp32 -> bf16 or back.      */
+int cgs_genbf16_conv3x3_fwd_train(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, int32_t ups, int32_t act,
+                                  float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16,
+                                  const float* bias, void* out, uint8_t* codes, cgs_stream_t stream);
+int cgs_genbf16_pack_weights_t(int32_t ci_layer, int32_t co_layer, const float* w_hwio, void* w16, cgs_stream_t stream);
+int cgs_bf16_conv3x3_bwd_weight_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb);
+int cgs_bf16_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t dy_channels, int32_t a_kind, int32_t ups,
+                                const void* src_a, const void* src_b, const void* dy, float* slab, cgs_stream_t stream);
+int cgs_bf16_pool_expand(int32_t n, int32_t hp, int32_t c, const void* dp, const void* addend, const uint8_t* codes, void* out,
+                         cgs_stream_t stream);
+int cgs_bf16_cat_split(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t ups, const void* dcat, void* dskip, void* dlow,
+                       int32_t low_is_f32, cgs_stream_t stream);
+int cgs_bf16_lrelu_bwd(int64_t count, void* d, const void* h, float slope, cgs_stream_t stream);
+int cgs_bf16_convert(int64_t rows, int32_t c_src, int32_t c_dst, int32_t to_f32, const void* src, void* dst, cgs_stream_t stream);
 int cgs_gen_convt4s2_fwd(int32_t n, int32_t h, int32_t ca, int32_t cb, int32_t co, int32_t act, float slope,
                          const float* a, const float* b, const float* w, const float* bias, float* out,
                          cgs_stream_t stream);

@@ -445,18 +445,43 @@ def masker128_shapes(chfak: int = 1, neck: int = 32, masker_channels: int = 16):
             ("masker.2.weight", (1, masker_channels, 3, 3)), ("masker.2.bias", (1,))]
 
 
-def hourglass128_apply(Pc: Params, Pm: Params, X: torch.Tensor):
-    """Eval-mode critic value and mask of the 128x128 variant.  X: NCHW fp32 [n,3,128,128] in [0,1]."""
+def critic128_apply(Pc: Params, X: torch.Tensor):
+    """Critic of the 128x128 variant: (pred [n,1], [e0..e4, e5])."""
     h, emb = X, []
     for key in ENC128_KEYS:
         h = F.max_pool2d(F.relu(F.conv2d(h, Pc[key + ".weight"], Pc[key + ".bias"], padding=1)), 2)
         emb.append(h)
     e5 = F.relu(F.conv2d(h, Pc["features.17.weight"], Pc["features.17.bias"]))
     hid = F.relu(F.linear(e5.flatten(1), Pc["crit.1.weight"], Pc["crit.1.bias"]))
-    pred = torch.sigmoid(F.linear(hid, Pc["crit.4.weight"], Pc["crit.4.bias"]))
+    return torch.sigmoid(F.linear(hid, Pc["crit.4.weight"], Pc["crit.4.bias"])), emb + [e5]
+
+
+def masker128_apply(Pm: Params, X: torch.Tensor, emb):
+    e5 = emb[5]
     o = F.conv2d(e5, Pm["dec_model.5.weight"], Pm["dec_model.5.bias"])
     o = F.conv2d(torch.cat((emb[4], _up2(_up2(o))), 1), Pm["dec_model.4.weight"], Pm["dec_model.4.bias"], padding=1)
     for i in (3, 2, 1, 0):
         o = F.conv2d(torch.cat((emb[i], _up2(o)), 1), Pm[f"dec_model.{i}.weight"], Pm[f"dec_model.{i}.bias"], padding=1)
     hm = F.leaky_relu(F.conv2d(torch.cat((X, _up2(o)), 1), Pm["masker.0.weight"], Pm["masker.0.bias"], padding=1), 0.01)
-    return pred, torch.sigmoid(F.conv2d(hm, Pm["masker.2.weight"], Pm["masker.2.bias"], padding=1))
+    return torch.sigmoid(F.conv2d(hm, Pm["masker.2.weight"], Pm["masker.2.bias"], padding=1))
+
+
+def hourglass128_phase2_loss(Pc: Params, Pm: Params, A: torch.Tensor, B: torch.Tensor, Y: torch.Tensor, lfak: float = 5, L1: float = 0.5):
+    """The phase-2 objective of main.py:364-429 (live critic, inject, staticnorm, Dropout off) on the 128x128 variant: the
+    self-consistency check of Hourglass128.phase2_step (parity unpinned).  A, B: NCHW fp32 [n,3,128,128].  Returns (total, parts, Z, pred)."""
+    pred, emb = critic128_apply(Pc, A)
+    negpred = critic128_apply(Pc, B)[0].squeeze().detach()
+    pred = pred.squeeze()
+    parts = {"critic": F.mse_loss(pred, Y)}
+    Z = masker128_apply(Pm, A, emb)
+    rv = critic128_apply(Pc, A * (1 - Z) + Z * B)[0].squeeze()
+    iv = critic128_apply(Pc, B * (1 - Z) + Z * A)[0].squeeze()
+    parts["replace"], parts["inject"] = F.mse_loss(rv, negpred), F.mse_loss(iv, pred.detach())
+    parts["norm"] = L1 * F.l1_loss(Z, torch.zeros_like(Z))
+    return lfak * parts["critic"] + parts["replace"] + parts["inject"] + parts["norm"], parts, Z, pred
+
+
+def hourglass128_apply(Pc: Params, Pm: Params, X: torch.Tensor):
+    """Eval-mode critic value and mask of the 128x128 variant.  X: NCHW fp32 [n,3,128,128] in [0,1]."""
+    pred, emb = critic128_apply(Pc, X)
+    return pred, masker128_apply(Pm, X, emb)
