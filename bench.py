@@ -71,8 +71,8 @@ def parse():
                          "round-3 form); default = the collective is captured into the step graph when the RCCL trial capture succeeds")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--config", type=int, default=0,
-                    help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart), eval-mode "
-                         "forward on the bf16 kernels, batch 256")
+                    help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart) on the bf16 "
+                         "kernels, batch 256: --mode train = the phase-2 training step, --mode infer = the eval-mode forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--prime-s", type=float, default=0.4,
@@ -289,21 +289,46 @@ def generic_mode(args, dev, rank):
 
 
 def config5_mode(args, dev):
-    """BASELINE config 5 (side line): 128x128x3 frames, batch 256, bf16 storage / fp32 accumulate, the build-defined six-stage variant."""
+    """BASELINE config 5 (side line): 128x128x3 frames, batch 256, bf16 storage / fp32 accumulate, the build-defined six-stage variant.
+    --mode train: the phase-2 training step (Hourglass128.phase2_step); otherwise the eval-mode forward."""
     from cgs_amd import hourglass128
     from oracle import hourglass_ref as orc          # only for the seeded stand-in weights (shape tables + RandomState draw)
     n = 256 if args.batch == 512 else args.batch
     net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev)
     X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    train = args.mode == "train"
+    if train:
+        B = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
+        Y = torch.rand(n, generator=torch.Generator().manual_seed(2)).to(dev)
+        net.phase2_step(X, B, Y)
+        run = lambda: net.phase2_step()
+    else:
+        run = lambda: net.infer(X)
     for _ in range(max(args.warmup, 3)):
-        net.infer(X)
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        net.infer(X)
+        run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     el, flops = hourglass128.Hourglass128.model_cost()
+    if train:
+        # layer-granular model as SURVEY 8(d) builds it for the 64x64 step: 4 critic forwards + the mask forward, 3 critic backward + the mask
+        # backward passes at ~2x a forward's elements / FLOPs each (data + weight gradient)
+        elc, flc = hourglass128.Hourglass128.critic_cost()
+        el_step, fl_step = 4 * elc + (el - elc) + 2 * (3 * elc + (el - elc)), 4 * flc + (flops - flc) + 2 * (3 * flc + (flops - flc))
+        ach = 2.0 * el_step * n / dt / 1e9
+        print(json.dumps({"metric": "Hourglass-128 (build-defined) train images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                          "dtype": "bf16 (f32 accumulate, f32 master weights)", "data": "synthetic",
+                          "config": {"workload": "BASELINE config 5 as a training step: phase-2 step (4 critic fwd, 3 critic bwd, mask fwd + bwd, mix, losses, "
+                                                 "Adam) of the six-stage 128x128 variant (no reference counterpart, parity unpinned), bf16 activations / "
+                                                 "gradients, weight gradients on v_mfma_f32_16x16x32_bf16", "batch": n, "final_total_loss": float(net._train.losses[5])},
+                          "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                                       "algorithmic_elements_per_image": el_step, "flops_per_image": fl_step,
+                                       "bf16_TFLOPs": fl_step * n / dt / 1e12}}), flush=True)
+        return
     ach = 2.0 * el * n / dt / 1e9          # bf16: 2 bytes per element of the layer-granular traffic model
     print(json.dumps({"metric": "Hourglass-128 (build-defined) inference images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,

@@ -17,7 +17,7 @@ int mask_train_partials(int n);
 int mask_train_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0, const float* w2,
                       const float* b2, float* h, float* z, float* zpart, const float* w0_pack, hipStream_t st);
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
-                          const float* w2, const float* b2, float* z, hipStream_t st);
+                          const float* w2, const float* b2, float* z, hipStream_t st, int o0_f16);
 // (round 2's opt-in two-pixels-per-MFMA-row form of features.0 / features.3 -- measured slower -- lives in tools/experiments/pconv.hip,
 //  outside the product library; the 3x3 layers now run on v_mfma_f32_4x4x1 inside conv3x3_body)
 static constexpr bool use_mconv() { return true; }      // the layers with a matrix-core implicit-GEMM kernel always use it
@@ -181,5 +181,13 @@ extern "C" int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, c
                                       const float* b_m0, const float* w_m2, const float* b_m2, float* z, cgs_stream_t stream) {
     if (n < 0 || !x || !o0 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !z) return CGS_ERR_BADARG;
     if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
-    return mask_infer_f16_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream);
+    return mask_infer_f16_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream, 0);
+}
+
+// the same with o0 stored as fp16 NHWC (cgs_f16_dec0_fwd's output): the mask head of the fused fp16 inference path
+extern "C" int cgs_mask_infer_fwd_f16o(int32_t n, int32_t src_a, const void* x, const void* o0_f16, const float* w_m0,
+                                       const float* b_m0, const float* w_m2, const float* b_m2, float* z, cgs_stream_t stream) {
+    if (n < 0 || !x || !o0_f16 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !z) return CGS_ERR_BADARG;
+    if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
+    return mask_infer_f16_launch(n, src_a, x, (const float*)o0_f16, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream, 1);
 }

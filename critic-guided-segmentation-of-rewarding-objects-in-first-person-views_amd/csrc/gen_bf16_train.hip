@@ -68,29 +68,35 @@ __global__ void __launch_bounds__(256) bf16_wgrad_kernel(WgParams P) {
     for (int t = blockIdx.x; t < P.ntiles; t += P.nblocks) {
         const int img0 = TI == 1 ? t / strips : t * TI, row0 = TI == 1 ? (t % strips) * TH : 0;
         // ---- X tile: the virtual cat(A, up(B)) with a one-pixel zero halo, channel quads beyond the layer's zero ----
+        // (row by row: the only divisions left are by the compile-time quad count)
         constexpr int NQ = CIP / 4;
-        for (int e = tid; e < TI * PH * PW * NQ; e += 256) {
-            const int g = e % NQ, pix = e / NQ, xx = pix % PW, rr = (pix / PW) % PH, ii = pix / (PW * PH);
-            const int img = img0 + ii, y = row0 + rr - 1, x = xx - 1, k0 = 4 * g;
-            short4_t v = short4_t{0, 0, 0, 0};
-            if (img < P.n && y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
-                if (k0 < pa4) {
-                    const size_t pg = ((size_t)img * H + y) * W + x;
-                    if (P.a_kind == 0) {
-                        v = *(const short4_t*)((const uint16_t*)P.a + pg * P.ca + k0);
+        for (int row = 0; row < TI * PH; ++row) {
+            const int ii = TI == 1 ? 0 : row / PH, rr = TI == 1 ? row : row - ii * PH;
+            const int img = img0 + ii, y = row0 + rr - 1;
+            const bool rowok = img < P.n && y >= 0 && y < H;
+            const size_t arow = ((size_t)img * H + y) * W, brow = ((size_t)img * HB + (y >> ush)) * WB;
+            uint16_t* const xrow = xt + (size_t)row * PW * CIP;
+            for (int e = tid; e < PW * NQ; e += 256) {
+                const int g = e % NQ, xx = e / NQ, x = xx - 1, k0 = 4 * g;
+                short4_t v = short4_t{0, 0, 0, 0};
+                if (rowok && x >= 0 && x < W && k0 < cp) {
+                    if (k0 < pa4) {
+                        const size_t pg = arow + x;
+                        if (P.a_kind == 0) {
+                            v = *(const short4_t*)((const uint16_t*)P.a + pg * P.ca + k0);
+                        } else {
+                            float f[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int c = 0; c < 4; ++c)
+                                if (k0 + c < P.ca)
+                                    f[c] = P.a_kind == 1 ? (float)((const uint8_t*)P.a)[pg * P.ca + k0 + c] * (1.f / 255.f) : ((const float*)P.a)[pg * P.ca + k0 + c];
+                            v = short4_t{(short)f2bf(f[0]), (short)f2bf(f[1]), (short)f2bf(f[2]), (short)f2bf(f[3])};
+                        }
                     } else {
-                        float f[4] = {0.f, 0.f, 0.f, 0.f};
-                        for (int c = 0; c < 4; ++c)
-                            if (k0 + c < P.ca)
-                                f[c] = P.a_kind == 1 ? (float)((const uint8_t*)P.a)[pg * P.ca + k0 + c] * (1.f / 255.f) : ((const float*)P.a)[pg * P.ca + k0 + c];
-                        v = short4_t{(short)f2bf(f[0]), (short)f2bf(f[1]), (short)f2bf(f[2]), (short)f2bf(f[3])};
+                        v = *(const short4_t*)(P.b + (brow + (x >> ush)) * P.cb + (k0 - pa4));
                     }
-                } else {
-                    const size_t pb = ((size_t)img * HB + (y >> ush)) * WB + (x >> ush);
-                    v = *(const short4_t*)(P.b + pb * P.cb + (k0 - pa4));
                 }
+                *(short4_t*)(xrow + (size_t)xx * CIP + k0) = v;
             }
-            *(short4_t*)(xt + (size_t)pix * CIP + k0) = v;
         }
         // ---- dY tile: [pixel][16 output channels] ----
         for (int e = tid; e < TP * 4; e += 256) {
@@ -208,8 +214,20 @@ __global__ void __launch_bounds__(256) bf16_cat_split_kernel(const uint16_t* __r
 
 // d [i] *= h[i] > 0 ? 1 : slope   (LeakyReLU', from the saved OUTPUT: its sign is the pre-activation's)
 __global__ void __launch_bounds__(256) bf16_lrelu_bwd_kernel(uint16_t* __restrict__ d, const uint16_t* __restrict__ h, int64_t count, float slope) {
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256)
+    const int64_t quads = count / 4;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < quads; e += (int64_t)gridDim.x * 256) {
+        short4_t dv = ((const short4_t*)d)[e];
+        const short4_t hv = ((const short4_t*)h)[e];
+        if (!(bf2f((uint16_t)hv.x) > 0.f)) dv.x = (short)f2bf(bf2f((uint16_t)dv.x) * slope);
+        if (!(bf2f((uint16_t)hv.y) > 0.f)) dv.y = (short)f2bf(bf2f((uint16_t)dv.y) * slope);
+        if (!(bf2f((uint16_t)hv.z) > 0.f)) dv.z = (short)f2bf(bf2f((uint16_t)dv.z) * slope);
+        if (!(bf2f((uint16_t)hv.w) > 0.f)) dv.w = (short)f2bf(bf2f((uint16_t)dv.w) * slope);
+        ((short4_t*)d)[e] = dv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) {
+        const int64_t e = 4 * quads + threadIdx.x;
         if (!(bf2f(h[e]) > 0.f)) d[e] = f2bf(bf2f(d[e]) * slope);
+    }
 }
 
 // rows of c_src channels -> rows of c_dst channels (zero padded / truncated); dir 0: fp32 -> bf16, 1: bf16 -> fp32
@@ -292,7 +310,7 @@ extern "C" int cgs_bf16_cat_split(int32_t n, int32_t hw, int32_t ca, int32_t cb,
 extern "C" int cgs_bf16_lrelu_bwd(int64_t count, void* d, const void* h, float slope, cgs_stream_t stream) {
     if (count < 0 || !d || !h) return CGS_ERR_BADARG;
     if (count == 0) return CGS_OK;
-    const int64_t blocks = (count + 255) / 256;
+    const int64_t blocks = (count / 4 + 255) / 256 + 1;
     hipLaunchKernelGGL(bf16_lrelu_bwd_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream,
                        (uint16_t*)d, (const uint16_t*)h, count, slope);
     CGS_HIP_CHECK_LAUNCH();

@@ -1,0 +1,187 @@
+// fp16 convolutions of the FUSED inference path (BASELINE config 4: "-process inference-only mask path, batch 2048, fp16 conv
+// kernels"; main.py:1130-1151, nets.py:170-176, 516-517): features.0 (uint8 frames -> e0), features.3 (e0 -> e1) and dec_model.0
+// (cat(e0, up(o1)) -> o0) with fp16 activations in HBM / LDS, fp16 weights, fp32 accumulation on v_mfma_f32_16x16x32_f16 -- gfx950's
+// K = 32 form: one instruction covers 8 / 4 / 2 taps of a 4- / 8- / 16-channel input, so a 3x3 layer is 2 / 3 / 5 instructions per
+// 16 pixels and the matrix time is negligible; the kernels are built for the memory side: one workgroup stages a whole 32x32 image
+// (or a 16-row strip of a 64x64 frame) once as an NHWC fp16 tile whose pixel is ONE 8- / 16- / 32-byte LDS read per lane and tap
+// group, every global access is a full 16-byte lane access, the weights live in registers.
+// Workgroups are persistent over the strips (weights -> registers once per workgroup).  Pooled layers issue the instruction as
+// D[pixel][output channel] with a tile = four 2x2 pool windows (tile pixel 4 w + pos): a lane's four accumulators are ONE window, so
+// ReLU + MaxPool2d(2) is three in-lane maxima + bias; the plain layer (dec_model.0) issues D[output channel][pixel]: four consecutive
+// channels of the lane's pixel = one 8-byte store.
+// The 16x16-and-smaller layers stay on the fp32 tail kernels (0.3 % of the path's bytes): features.3 therefore writes e1 in fp32.
+// OPT-IN precision (engine.infer(fp16=True) at chfak 1): never used by training or by the parity-gated fp32 paths.
+#include "tail_common.h"
+
+namespace {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 half4h_t __attribute__((ext_vector_type(4)));
+
+struct HConvParams {
+    const void* a;          // uint8 frames [n,HW,HW,3] (U8) or fp16 NHWC [n,HW,HW,CA]
+    const float* b;         // fp32 NHWC [n,HW/2,HW/2,CB] (nearest-upsampled second source) or NULL
+    const float* w;         // HWIO fp32 [9][CA_real + CB][8]
+    const float* bias;      // [8]
+    void* out;              // pooled [n,HW/2,HW/2,8] or [n,HW,HW,8]; fp16 or fp32
+    int n;
+    int nstrips;            // n * (HW / TH): the workgroups are persistent over them (weights -> registers once)
+};
+
+// HW: map size; CA: channels of source A in the LDS pixel (4 = uint8 rgb0, 8 = fp16); CB: channels of the upsampled fp32 source (0 / 8);
+// TH: rows per workgroup; POOL: ReLU + MaxPool2d(2) epilogue (else plain bias); OUT_F32: fp32 output
+template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32>
+__global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
+    constexpr int CIN = CA + CB, TPM = 32 / CIN, NM = (9 + TPM - 1) / TPM;      // taps per instruction, instructions per tile
+    constexpr int PW = HW + 2, PH = TH + 2, STRIPS = HW / TH, CA_REAL = CA == 4 ? 3 : CA;
+    constexpr int NT = TH * HW / 16;                                            // 16-pixel tiles per workgroup
+    static_assert(CIN == 4 || CIN == 8 || CIN == 16, "pixel = 8 / 16 / 32 bytes");
+    extern __shared__ __attribute__((aligned(16))) float4 hsm[];
+    _Float16* const tile = (_Float16*)hsm;                                     // [PH][PW][CIN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+
+    // ---- weights -> registers: A operand of instruction g, lane (m = l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN ----
+    half8_t wa[NM];
+#pragma unroll
+    for (int g = 0; g < NM; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
+            const int cr = c < CA ? c : CA_REAL + (c - CA);                      // channel of the layer's HWIO weights
+            const bool ok = tap < 9 && l15 < 8 && (c < CA ? c < CA_REAL : true);
+            wa[g][j] = (_Float16)(ok ? P.w[((tap < 9 ? tap : 0) * (CA_REAL + CB) + (ok ? cr : 0)) * 8 + (l15 & 7)] : 0.f);
+        }
+    float br[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) br[r] = P.bias[(4 * kq + r) & 7];
+    const float bl = P.bias[l15 & 7];
+
+    for (int e = tid; e < PH * 2 * (CIN / 4); e += 256) {                       // halo columns: zero for every strip
+        const int q = e % (CIN / 4), side = (e / (CIN / 4)) & 1, r = e / (2 * (CIN / 4));
+        *(half4h_t*)(tile + ((size_t)r * PW + (side ? PW - 1 : 0)) * CIN + 4 * q) = half4h_t{0, 0, 0, 0};
+    }
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+    const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
+    // ---- stage the tile (zero halo rows) ----
+    if constexpr (CA == 4) {                // uint8 frames: 4 pixels = 12 bytes = 3 dwords per thread-item
+        constexpr int GW = HW / 4;
+        const uint32_t* src = (const uint32_t*)P.a;
+        for (int e = tid; e < PH * GW; e += 256) {
+            const int g = e % GW, r = e / GW, y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+            uint32_t d0 = src[gi], d1 = src[gi + 1], d2 = src[gi + 2];
+            if (!in) { d0 = 0; d1 = 0; d2 = 0; }
+            const float s = 1.f / 255.f;
+            half4h_t p0 = {(_Float16)((d0 & 255) * s), (_Float16)(((d0 >> 8) & 255) * s), (_Float16)(((d0 >> 16) & 255) * s), (_Float16)0.f};
+            half4h_t p1 = {(_Float16)((d0 >> 24) * s), (_Float16)((d1 & 255) * s), (_Float16)(((d1 >> 8) & 255) * s), (_Float16)0.f};
+            half4h_t p2 = {(_Float16)(((d1 >> 16) & 255) * s), (_Float16)((d1 >> 24) * s), (_Float16)((d2 & 255) * s), (_Float16)0.f};
+            half4h_t p3 = {(_Float16)(((d2 >> 8) & 255) * s), (_Float16)(((d2 >> 16) & 255) * s), (_Float16)((d2 >> 24) * s), (_Float16)0.f};
+            half4h_t* dst = (half4h_t*)(tile + ((size_t)r * PW + 1 + 4 * g) * 4);
+            dst[0] = p0; dst[1] = p1; dst[2] = p2; dst[3] = p3;
+        }
+    } else {
+        const half8_t* src = (const half8_t*)P.a;                              // 8 fp16 channels = one 16-byte access
+        for (int e = tid; e < PH * HW; e += 256) {
+            const int x = e % HW, r = e / HW, y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            half8_t v = src[in ? ((size_t)img * HW + y) * HW + x : 0];
+            if (!in) v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            *(half8_t*)(tile + ((size_t)r * PW + 1 + x) * CIN) = v;
+            if constexpr (CB > 0) {         // the nearest-upsampled fp32 source, converted: channels CA .. CA + 7 of the pixel
+                const float4* sb = (const float4*)P.b;
+                const size_t pb = in ? (((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1)) * 2 : 0;
+                float4 u0 = sb[pb], u1 = sb[pb + 1];
+                if (!in) { u0 = f4zero(); u1 = f4zero(); }
+                const half8_t hb = {(_Float16)u0.x, (_Float16)u0.y, (_Float16)u0.z, (_Float16)u0.w, (_Float16)u1.x, (_Float16)u1.y, (_Float16)u1.z, (_Float16)u1.w};
+                *(half8_t*)(tile + ((size_t)r * PW + 1 + x) * CIN + CA) = hb;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
+#pragma unroll 2
+    for (int t = wave; t < NT; t += 4) {
+        int y, x;                           // strip-local pixel of this lane
+        if constexpr (POOL) {
+            constexpr int TPR = HW / 8;     // tiles per row pair
+            const int wy = t / TPR, tx = t % TPR, win = l15 >> 2, pos = l15 & 3;
+            y = 2 * wy + (pos >> 1); x = 8 * tx + 2 * win + (pos & 1);
+        } else {
+            constexpr int TPR = HW / 16;
+            y = t / TPR; x = 16 * (t % TPR) + l15;
+        }
+        const _Float16* pix = tile + ((size_t)y * PW + x) * CIN;                // tap (0,0) of the lane's 3x3 window
+        frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            half8_t b;
+            if constexpr (CIN == 4) {       // two taps per lane: 2 x 8 bytes
+                int t0 = g * 8 + 2 * kq, t1 = t0 + 1;
+                t0 = t0 < 9 ? t0 : 8; t1 = t1 < 9 ? t1 : 8;
+                const half4h_t lo = *(const half4h_t*)(pix + ((t0 / 3) * PW + t0 % 3) * 4), hi = *(const half4h_t*)(pix + ((t1 / 3) * PW + t1 % 3) * 4);
+                b = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else if constexpr (CIN == 8) {
+                int tp = g * 4 + kq;
+                tp = tp < 9 ? tp : 8;
+                b = *(const half8_t*)(pix + ((tp / 3) * PW + tp % 3) * 8);
+            } else {
+                int tp = g * 2 + (kq >> 1);
+                tp = tp < 9 ? tp : 8;
+                b = *(const half8_t*)(pix + ((tp / 3) * PW + tp % 3) * 16 + 8 * (kq & 1));
+            }
+            // pooled layers: D[pixel = 4 kq + r][oc = l15] -- a lane's four accumulators are ONE pool window (in-lane maximum);
+            // plain layers: D[oc = 4 kq + r][pixel = l15] -- four consecutive channels of the lane's pixel (one vector store)
+            if constexpr (POOL) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, wa[g], acc, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g], b, acc, 0, 0, 0);
+        }
+        if constexpr (POOL) {
+            // ReLU(max(window) + bias) == max over the window of ReLU(. + bias); lane (kq, l15 < 8): window kq of the tile, channel l15
+            constexpr int TPR = HW / 8;
+            const int wy = t / TPR, tx = t % TPR;
+            const float m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bl, 0.f);
+            if (l15 < 8) {
+                const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * 8) + l15;
+                if constexpr (OUT_F32) ((float*)P.out)[o] = m;
+                else ((_Float16*)P.out)[o] = (_Float16)m;
+            }
+        } else if (kq < 2) {
+            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * 8) + 4 * kq;
+            if constexpr (OUT_F32) *(float4*)((float*)P.out + o) = make_float4(acc[0] + br[0], acc[1] + br[1], acc[2] + br[2], acc[3] + br[3]);
+            else *(half4h_t*)((_Float16*)P.out + o) = half4h_t{(_Float16)(acc[0] + br[0]), (_Float16)(acc[1] + br[1]), (_Float16)(acc[2] + br[2]), (_Float16)(acc[3] + br[3])};
+        }
+    }
+    __syncthreads();            // every wave is done with the tile before the next strip is staged
+    }
+}
+
+template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32>
+int hconv_launch(const HConvParams& P, hipStream_t st) {
+    if (P.n <= 0) return CGS_OK;
+    const size_t lds = (size_t)(TH + 2) * (HW + 2) * (CA + CB) * 2;
+    HConvParams Q = P;
+    Q.nstrips = P.n * (HW / TH);
+    const int blocks = Q.nstrips < 1024 ? Q.nstrips : 1024;      // persistent: 4 workgroups per CU
+    hipLaunchKernelGGL((hconv_kernel<HW, CA, CB, TH, POOL, OUT_F32>), dim3(blocks), dim3(256), lds, st, Q);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+}  // namespace
+
+extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
+    if (n < 0 || !x_u8 || !w_hwio || !bias || !e0_f16) return CGS_ERR_BADARG;
+    return hconv_launch<64, 4, 0, 16, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0}, (hipStream_t)stream);
+}
+
+extern "C" int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream) {
+    if (n < 0 || !e0_f16 || !w_hwio || !bias || !e1_f32) return CGS_ERR_BADARG;
+    return hconv_launch<32, 8, 0, 32, true, true>(HConvParams{e0_f16, nullptr, w_hwio, bias, e1_f32, n, 0}, (hipStream_t)stream);
+}
+
+extern "C" int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f32, const float* w_hwio, const float* bias, void* o0_f16,
+                                cgs_stream_t stream) {
+    if (n < 0 || !e0_f16 || !o1_f32 || !w_hwio || !bias || !o0_f16) return CGS_ERR_BADARG;
+    return hconv_launch<32, 8, 8, 32, false, false>(HConvParams{e0_f16, o1_f32, w_hwio, bias, o0_f16, n, 0}, (hipStream_t)stream);
+}

@@ -297,6 +297,7 @@ struct MaskInferParams {
     // training form (TRAIN = true): h (the masker.0 output the backward pass needs) is stored once from the LDS tile, and every
     // tile leaves (sum |z|, sum z^2) for the L1 / L2 mask losses (main.py:421-429) at zpart[2 * tile]
     float* h_out; float* zpart;
+    int o0_f16;      // mask_infer_f16_kernel only: o0 is fp16 NHWC (the fused fp16 inference path, hconv.hip) instead of fp32
 };
 
 struct MaskInferGeo {
@@ -480,8 +481,14 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
 // ------------------------------------------------------------------------------------------------
 // fp16-operand variant of the inference mask head (BASELINE config 4: "-process inference-only, fp16 conv kernels"):
 // the masker.0 GEMM runs on v_mfma_f32_16x16x16_f16 (fp16 image / o0 / weight operands, fp32 accumulate): K = 16 per
-// instruction, 5 instead of 17 MFMAs per 16 pixels, each 4x shorter than an fp32 MFMA.  masker.2 stays fp32 on the
-// fp32 h tile.  OPT-IN only (engine.infer(..., fp16_mask_head=True)); the result differs from the fp32 path by ~1e-3
+// instruction, 5 instead of 17 MFMAs per 16 pixels, each 4x shorter than an fp32 MFMA.
+// (round 4) masker.2 (16 -> 1 channels) no longer walks a 16-channel h tile in LDS (144 fp32 FMAs and 36 16-byte LDS reads per
+// pixel: half of the kernel's 210 us at batch 2048).  The instruction is issued as D[oc][pixel] (weights = A operand), so a lane's
+// four accumulators are four consecutive CHANNELS of one pixel -- exactly the B-operand layout of another 16x16x16 MFMA: after bias +
+// LeakyReLU + the fp16 conversion they feed P[tap][pixel] = sum_c w2[tap][c] h[pixel][c] (A = masker.2's weights, 9 of 16 rows used)
+// straight from registers.  h never reaches LDS; the nine per-tap planes P_t do (fp32, 9 floats per pixel), and
+// Z = sigmoid(b2 + sum_t P_t[y + ky - 1][x + kx - 1]) is nine conflict-free dword reads and adds per pixel.
+// OPT-IN only (engine.infer(..., fp16_mask_head=True) / fp16=True); the result differs from the fp32 path by ~1e-3
 // absolute in Z (tests/test_gpu_kernels.py), so it is never used for training or for the parity-gated paths.
 // K layout of one instruction = 4 lanes-groups (kq) x 4 halves: image: kq = tap (4m + kq), halves = (r, g, b, 0);
 // o0: kq = (fold column b = kq>>1, channel group kq&1), instruction m = fold row a.
@@ -489,20 +496,20 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
 template <int SRC>
-__global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams P) {
+__global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams P) {
     using G = MaskInferGeo;
     constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, LR = G::LR, LC = G::LC, HPS = G::HPS;
     constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     _Float16* ximg = (_Float16*)smem;                      // [IR][IC][4]  (r, g, b, 0)
     _Float16* xo = ximg + IR * IC * 4;                     // [LR][LC][8]
-    float* hs = (float*)(xo + LR * LC * 8);                // [HR][IC][HPS] fp32
+    float* pl = (float*)(xo + LR * LC * 8);                // [9 taps][HR][IC] fp32: P_t of rows row0-1 .. row0+8, columns -1 .. 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int hf = wave & 1, par = wave >> 1;
     const int py = (par + 1) & 1;
 
-    // ---- masker.0 weights -> fp16 registers (B operand: k = 4*kq + c, n = l15 = oc) ----
+    // ---- masker.0 weights -> fp16 registers (the A operand: m = l15 = oc, k = 4*kq + c) ----
     half4_t wimg[3], wo[2][2];         // image: instruction m covers taps 4m..4m+3;  o0: [px][a = m]
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
@@ -529,10 +536,17 @@ __global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams 
                     }
                 wo[px][a][c] = (_Float16)v;
             }
-    const float bias0 = P.b0[l15], bias2 = P.b2[0];
-    for (int e = tid; e < HR * 2 * 16; e += 256) {
-        int ch = e & 15, side = (e >> 4) & 1, r = e >> 5;
-        hs[(r * IC + (side ? IC - 1 : 0)) * HPS + ch] = 0.f;
+    const float bias2 = P.b2[0];
+    float b0r[4];
+    half4_t w2a;                       // masker.2 as the A operand of the P instruction: m = l15 = tap (9 of 16 rows), k = 4*kq + c = channel
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        b0r[c] = P.b0[4 * kq + c];
+        w2a[c] = (_Float16)(l15 < 9 ? P.w2[(l15 < 9 ? l15 : 0) * 16 + 4 * kq + c] : 0.f);
+    }
+    for (int e = tid; e < 9 * HR * 2; e += 256) {        // the two halo columns of every plane row: zero for every tile
+        const int side = e & 1, r = e >> 1;
+        pl[r * IC + (side ? IC - 1 : 0)] = 0.f;
     }
     // per-lane tap offsets of the three image instructions (halves): tap t = 4m + kq (t > 8: any valid address, zero weight)
     int toff[3];
@@ -566,10 +580,15 @@ __global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams 
             int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
             int ly = row0 / 2 + pr - 2, lx = pc - 1;
             bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            float4 v = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
-            v = in ? v : f4zero();
+            const int oi = in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0;
             half4_t hv;
-            hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+            if (P.o0_f16) {            // (uniform branch)
+                hv = ((const half4_t*)P.o0)[oi];
+            } else {
+                const float4 v = ((const float4*)P.o0)[oi];
+                hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+            }
+            if (!in) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
             *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
         });
         __syncthreads();
@@ -579,22 +598,27 @@ __global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams 
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             const int jj = t >> 1, px = t & 1;
-            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};                         // D[oc = 4 kq + r][pixel = l15]
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const half4_t a = *(const half4_t*)(ximg + ibase + (2 * jj * IC + px) * 4 + toff[m]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, wimg[m], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wimg[m], a, acc, 0, 0, 0);
             }
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2) {
                 const half4_t a = *(const half4_t*)(xo + obase + ((jj + a2 + 1) * LC + px) * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a, wo[px][a2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wo[px][a2], a, acc, 0, 0, 0);
             }
             const int j = par + 2 * jj, y = row0 - 1 + j;
-            const float keep = (y >= 0 && y < H) ? 1.f : 0.f;
-            float* hrow = hs + (j * IC + 1 + 2 * (16 * hf + 4 * kq) + px) * HPS + l15;
+            const float keep = (y >= 0 && y < H) ? 1.f : 0.f;              // rows outside the image: masker.2 pads h with zeros
+            half4_t hv;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) hrow[2 * i * HPS] = keep * act_fwd<CGS_ACT_LRELU>(acc[i] + bias0);
+            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(keep * act_fwd<CGS_ACT_LRELU>(acc[r] + b0r[r]));
+            const frag4 pt = __builtin_amdgcn_mfma_f32_16x16x16f16(w2a, hv, frag4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // P[tap = 4 kq + r][pixel]
+            float* prow = pl + j * IC + 1 + 2 * (16 * hf + l15) + px;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (4 * kq + r < 9) prow[(4 * kq + r) * HR * IC] = pt[r];
         }
         __syncthreads();
         {
@@ -602,20 +626,9 @@ __global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams 
 #pragma unroll
             for (int rep = 0; rep < 2; ++rep) {
                 const int yl = yl0 + 4 * rep;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                float zpre = bias2;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float4* hp = (const float4*)(hs + ((yl + t / 3) * IC + x + t % 3) * HPS);
-                    const auto* wp = cgs_to_const(P.w2) + t * 16;
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float4 hv = hp[c4];
-                        a0 = fmaf(hv.x, wp[4 * c4], a0); a1 = fmaf(hv.y, wp[4 * c4 + 1], a1);
-                        a2 = fmaf(hv.z, wp[4 * c4 + 2], a2); a3 = fmaf(hv.w, wp[4 * c4 + 3], a3);
-                    }
-                    if (t % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-                }
-                const float zpre = ((a0 + a1) + (a2 + a3)) + bias2;
+                for (int t = 0; t < 9; ++t) zpre += pl[(t * HR + yl + t / 3) * IC + x + t % 3];
                 P.z[(size_t)(n0 * H + row0 + yl) * W + x] = 1.f / (1.f + expf(-zpre));
             }
         }
@@ -624,12 +637,13 @@ __global__ void __launch_bounds__(256, 2) mask_infer_f16_kernel(MaskInferParams 
 }
 
 static constexpr size_t kMaskInferF16Lds =
-    (size_t)MaskInferGeo::IR * MaskInferGeo::IC * 4 * 2 + (size_t)MaskInferGeo::LR * MaskInferGeo::LC * 8 * 2 + (size_t)MaskInferGeo::HS * 4;
+    (size_t)MaskInferGeo::IR * MaskInferGeo::IC * 4 * 2 + (size_t)MaskInferGeo::LR * MaskInferGeo::LC * 8 * 2 +
+    (size_t)9 * MaskInferGeo::HR * MaskInferGeo::IC * 4;
 
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
-                          const float* w2, const float* b2, float* z, hipStream_t st) {
+                          const float* w2, const float* b2, float* z, hipStream_t st, int o0_f16) {
     if (n <= 0) return CGS_OK;
-    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr};
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr, o0_f16};
     int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
     if (img_kind == CGS_SRC_U8)
         hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_U8>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);

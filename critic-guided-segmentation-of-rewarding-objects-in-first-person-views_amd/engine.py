@@ -493,17 +493,55 @@ class HourglassEngine:
         pred, Z, _ = gen.infer_f16(self.fc, self.lc, self.fm if want_mask else None, self.lm, X, chfak, neck, w16, embeds_from=emb)
         return pred, Z
 
+    def _infer_f16_fused(self, X: torch.Tensor, want_mask: bool):
+        """BASELINE config 4 on the FUSED path (round 4): features.0 / features.3 / dec_model.0 on the fp16 convolutions of
+        csrc/hconv.hip (fp16 activations in HBM, v_mfma_f32_16x16x32_f16), the mask head on the fp16 one-kernel form reading the fp16
+        o0, the 16x16-and-smaller layers on the fp32 tail kernels.  uint8 frames, eval mode, one critic."""
+        b, dev = X.shape[0], X.device
+        ws = getattr(self, "_f16ws", None)
+        if ws is None or ws["b"] != b:
+            f16 = lambda *s: torch.empty(s, device=dev, dtype=torch.float16)
+            f32 = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+            ws = self._f16ws = dict(b=b, e0=f16(b, 32, 32, 8), e1=f32(b, 16, 16, 8), e2=f32(b, 8, 8, 8), am2=torch.empty((b, 8, 8, 1), device=dev, dtype=torch.int32),
+                                    e3=f32(b, 4, 4, 16), am3=torch.empty((b, 4, 4, 2), device=dev, dtype=torch.int32), e4=f32(b, 32), h1=f32(b, 32),
+                                    o4=f32(b, 32), o3=f32(b, 4, 4, 16), o2=f32(b, 8, 8, 8), o1=f32(b, 16, 16, 8), o0=f16(b, 32, 32, 8))
+        pred = torch.empty(b, device=dev, dtype=torch.float32)
+        cp, mp = self.fc.data_ptr(), self.fm.data_ptr()
+        wc = lambda k: C.c_void_p(cp + 4 * self.lc.off(k))
+        wm = lambda k: C.c_void_p(mp + 4 * self.lm.off(k))
+        _lib.call("cgs_f16_enc0_fwd", b, _P(X), wc("features.0.weight"), wc("features.0.bias"), _P(ws["e0"]), _S())
+        _lib.call("cgs_f16_enc1_fwd", b, _P(ws["e0"]), wc("features.3.weight"), wc("features.3.bias"), _P(ws["e1"]), _S())
+        tw = hg.tail_enc_weights(self.fc, self.lc, (mp + 4 * self.lm.off("dec_model.4.weight"), mp + 4 * self.lm.off("dec_model.4.bias")))
+        nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
+        _lib.call("cgs_tail_enc_fwd", b, C.byref(tw), _P(ws["e1"]), _P(ws["e2"]), _P(ws["am2"]), _P(ws["e3"]), _P(ws["am3"]), _P(ws["e4"]),
+                  _P(ws["h1"]), _P(pred), _P(ws["o4"]) if want_mask else None, nd, nd, nd, _S())
+        if not want_mask:
+            return pred, None
+        td = hg.tail_dec_weights(self.fm, self.lm)
+        _lib.call("cgs_tail_dec_fwd", b, C.byref(td), _P(ws["e1"]), _P(ws["e2"]), _P(ws["e3"]), _P(ws["o4"]), _P(ws["o3"]), _P(ws["o2"]), _P(ws["o1"]), _S())
+        _lib.call("cgs_f16_dec0_fwd", b, _P(ws["e0"]), _P(ws["o1"]), wm("dec_model.0.weight"), wm("dec_model.0.bias"), _P(ws["o0"]), _S())
+        Z = torch.empty((b, 64, 64), device=dev, dtype=torch.float32)
+        _lib.call("cgs_mask_infer_fwd_f16o", b, _lib.SRC_U8, _P(X), _P(ws["o0"]), wm("masker.0.weight"), wm("masker.0.bias"), wm("masker.2.weight"),
+                  wm("masker.2.bias"), _P(Z), _S())
+        return pred, Z
+
     @torch.no_grad()
-    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False, fp16: bool = False):
+    def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False, fp16: bool = False,
+              fp16_layerwise: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
         Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM.
-        fp16 (opt-in, uint8 frames, eval mode): fp16 activations and weights in every layer, fp32 accumulation (~1e-3 abs in Z).
+        fp16 (opt-in, uint8 frames, eval mode): BASELINE config 4 -- the fused fp16 path (fp16 activations / weights in the 64x64 and 32x32
+        convolutions and the mask head, fp32 accumulation, the 16x16-and-smaller tail in fp32); fp16_layerwise=True: the shape-generic
+        chain with fp16 activations in EVERY layer (what chfak != 1 runs).
         train_mode (-noevalmode, main.py:1109-1118): Dropout stays active, a fresh mask per call.
         With a second critic (-separate, main.py:1140-1142) the masker's inputs come from it."""
         hg._chk_img(X, 0, "infer input")
         if fp16:
             if train_mode or fp16_mask_head:
                 raise _lib.CgsError("fp16 inference is an eval-mode path of its own (no Dropout, no fp16_mask_head)")
+            # chfak 1, uint8 frames, one critic: the fused fp16 path (round 4); fp16_layerwise keeps the shape-generic layer-by-layer chain
+            if type(self) is HourglassEngine and not self.separate and X.dtype == torch.uint8 and not fp16_layerwise:
+                return self._infer_f16_fused(X.contiguous(), want_mask)
             return self._infer_f16(X, want_mask, 1, 32)
         b = X.shape[0]
         drop = hg.NO_DROP

@@ -407,6 +407,17 @@ class Hourglass128:
             self._graph.replay()
         return T.losses
 
+    @staticmethod
+    def critic_cost(chfak: int = 1, neck: int = 32):
+        """(elements, FLOPs) per image of the critic's forward pass alone (same model as model_cost)."""
+        d, nb = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak], neck * chfak
+        el, mac, cin, hw = 0, 0, 3, 128
+        for co in d:
+            el += hw * hw * (cin + co); mac += hw * hw * 9 * cin * co
+            cin, hw = co, hw // 2
+        el += 16 * d[4] + nb + 2 * nb + nb + 1; mac += 16 * d[4] * nb + nb * nb + nb
+        return el, 2 * mac
+
     # fp32 algorithmic traffic / FLOPs per image (layer-granular model of SURVEY.md section 8d, applied to this variant)
     @staticmethod
     def model_cost(chfak: int = 1, neck: int = 32, mc: int = 16):

@@ -149,6 +149,19 @@ int cgs_mask_infer_fwd_f16(int32_t n, int32_t src_a, const void* x, const float*
                            const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
                            cgs_stream_t stream);
 
+/* ---- fused fp16 inference path (BASELINE config 4; csrc/hconv.hip): the three 64x64 / 32x32 convolutions of the eval-mode forward
+ * (nets.py:170-176, 516-517) with fp16 activations / weights and fp32 accumulation on v_mfma_f32_16x16x32_f16.  cgs_f16_enc0_fwd:
+ * uint8 frames [n,64,64,3] -> e0 fp16 [n,32,32,8] (conv + ReLU + MaxPool2d(2)); cgs_f16_enc1_fwd: e0 -> e1 fp32 [n,16,16,8] (the
+ * 16x16-and-smaller layers stay on the fp32 tail kernels); cgs_f16_dec0_fwd: cat(e0, nearest-up(o1 fp32 [n,16,16,8])) -> o0 fp16
+ * [n,32,32,8]; cgs_mask_infer_fwd_f16o: cgs_mask_infer_fwd_f16 reading that fp16 o0.  Weights / bias: the layer's HWIO fp32 parameters.
+ * Opt-in precision (engine.infer(fp16=True)); never used by training.                                                              */
+int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream);
+int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream);
+int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f32, const float* w_hwio, const float* bias, void* o0_f16,
+                     cgs_stream_t stream);
+int cgs_mask_infer_fwd_f16o(int32_t n, int32_t src_a, const void* x, const void* o0_f16, const float* w_m0_hwio, const float* b_m0,
+                            const float* w_m2_hwio, const float* b_m2, float* z, cgs_stream_t stream);
+
 /* ---- the 16x16-and-smaller layers, image by image inside one workgroup ("tail" kernels, csrc/tail.hip) ------------
  * Replace, for one critic pass / the decoder, the per-layer launches of features.6, features.10 (nets.py:176-183), the
  * critic head features.14 + crit.1 + crit.4 (nets.py:184-194) and dec_model.4/.3/.2/.1 (nets.py:501-513): every

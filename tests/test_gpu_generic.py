@@ -187,8 +187,9 @@ def test_fp16_inference_error_distribution_vs_fp32_oracle(g1, chfak, neck, n):
 
 
 def test_config4_batch2048_fp16_inference_vs_fp32_oracle(g1):
-    """BASELINE config 4 AT ITS STATED SIZE: the -process inference path on 2048 frames with fp16 conv kernels, both forms -- every
-    layer fp16 (engine.infer(fp16=True), csrc/gen_f16.hip) and fp16 operands in the masker.0 GEMM only (fp16_mask_head=True) --
+    """BASELINE config 4 AT ITS STATED SIZE: the -process inference path on 2048 frames with fp16 conv kernels, three forms -- the
+    fused fp16 path (engine.infer(fp16=True), round 4: csrc/hconv.hip + the fp16 mask head), every layer fp16 layer by layer
+    (fp16_layerwise=True, csrc/gen_f16.hip) and fp16 operands in the mask head only (fp16_mask_head=True) --
     against the fp32 CPU oracle on the same frames.  The bounds are ~3x the measured distribution on the G1 weights (printed), so
     a regression of the kernels' precision by a factor of a few fails here."""
     from cgs_amd import engine
@@ -210,8 +211,9 @@ def test_config4_batch2048_fp16_inference_vs_fp32_oracle(g1):
     p32, z32 = e.infer(xd)
     rel_close(z32.cpu().numpy(), rz, "fp32 Z at batch 2048")
     rel_close(p32.cpu().numpy(), rp, "fp32 pred at batch 2048")
-    for name, kw, zmax, zmean, pmax in (("all layers fp16", dict(fp16=True), 1e-4, 1.5e-5, 4e-5),
-                                        ("fp16 masker.0 operands", dict(fp16_mask_head=True), 8e-5, 1e-5, 1e-6)):
+    for name, kw, zmax, zmean, pmax in (("fused fp16 path (hconv + fp16 mask head)", dict(fp16=True), 2e-4, 3e-5, 6e-5),
+                                        ("all layers fp16, layer by layer", dict(fp16=True, fp16_layerwise=True), 1e-4, 1.5e-5, 4e-5),
+                                        ("fp16 mask-head operands", dict(fp16_mask_head=True), 1.2e-4, 1.5e-5, 1e-6)):
         pred, Z = e.infer(xd, **kw)
         dz = np.abs(Z.cpu().numpy().astype(np.float64) - rz)
         dp = np.abs(pred.cpu().numpy().astype(np.float64) - rp)
@@ -280,3 +282,55 @@ def test_config5_128x128_bf16_forward_vs_build_restatement(n):
     assert dz.max() < 6e-4 and dz.mean() < 1e-4
     assert dp.max() < 1e-4
     assert Z.shape == (n, 128, 128) and pred.shape == (n,)
+
+
+def test_fused_fp16_convolutions_vs_float64_conv_on_fp16_operands(g1):
+    """The three fp16 convolutions of the fused inference path (csrc/hconv.hip, v_mfma_f32_16x16x32_f16) one by one against float64
+    conv2d on the SAME fp16-rounded inputs and weights: only the fp32 accumulation order and the output rounding differ
+    (fp16 outputs: 2^-11 relative; the fp32 output of features.3: 1e-5 of the tensor's maximum)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from cgs_amd import _lib
+    pc, pm = g1
+    dev = torch.device("cuda:0")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    h = lambda t: t.to(torch.float16).double()
+    n = 5
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8))
+    x[1, 10:30, 5:50] = 77                      # a flat patch
+    hwio = lambda w: w.permute(2, 3, 1, 0).contiguous().to(dev)
+    # features.0
+    w0, b0 = pc["features.0.weight"], pc["features.0.bias"]
+    w0g, b0g, xg = hwio(w0), b0.to(dev), x.to(dev)
+    e0 = torch.empty((n, 32, 32, 8), device=dev, dtype=torch.float16)
+    _lib.call("cgs_f16_enc0_fwd", n, P(xg), P(w0g), P(b0g), P(e0), S())
+    ref0 = F.max_pool2d(F.relu(F.conv2d(h(x.double().permute(0, 3, 1, 2) / 255.0), h(w0), b0.double(), padding=1)), 2).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    err = (e0.double().cpu() - ref0).abs().max().item() / ref0.abs().max().item()
+    print(f"features.0 fp16: max err / max = {err:.2e}")
+    assert err < 1e-3
+    # features.3 on that e0 (fp32 output)
+    w1, b1 = pc["features.3.weight"], pc["features.3.bias"]
+    w1g, b1g = hwio(w1), b1.to(dev)
+    e1 = torch.empty((n, 16, 16, 8), device=dev, dtype=torch.float32)
+    _lib.call("cgs_f16_enc1_fwd", n, P(e0), P(w1g), P(b1g), P(e1), S())
+    e0c = e0.double().cpu().permute(0, 3, 1, 2)
+    ref1 = F.max_pool2d(F.relu(F.conv2d(e0c, h(w1), b1.double(), padding=1)), 2).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    err = (e1.double().cpu() - ref1).abs().max().item() / ref1.abs().max().item()
+    print(f"features.3 fp16 operands, fp32 out: max err / max = {err:.2e}")
+    assert err < 1e-5
+    # dec_model.0 on cat(e0, up(o1)): linear, fp16 output
+    wd, bd = pm["dec_model.0.weight"], pm["dec_model.0.bias"]
+    wdg, bdg = hwio(wd), bd.to(dev)
+    o1 = torch.from_numpy(rs.randn(n, 16, 16, 8).astype(np.float32)).to(dev)
+    o0 = torch.empty((n, 32, 32, 8), device=dev, dtype=torch.float16)
+    _lib.call("cgs_f16_dec0_fwd", n, P(e0), P(o1), P(wdg), P(bdg), P(o0), S())
+    cat = torch.cat((e0c, F.interpolate(h(o1.cpu()).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")), 1)
+    refd = F.conv2d(cat, h(wd), bd.double(), padding=1).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    err = (o0.double().cpu() - refd).abs().max().item() / refd.abs().max().item()
+    print(f"dec_model.0 fp16: max err / max = {err:.2e}")
+    assert err < 1e-3

@@ -14,7 +14,8 @@ python bench.py --chfak 5 --mode infer --fp16 --steps 20 --warmup 3 > $out/bench
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 > $out/bench_infer2048.json 2>/dev/null || exit 1
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16-mask-head > $out/bench_infer2048_f16head.json 2>/dev/null || exit 1
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16 > $out/bench_infer2048_f16all.json 2>/dev/null || exit 1
-python bench.py --config 5 > $out/bench_config5.json 2>/dev/null || exit 1
+python bench.py --config 5 --mode infer > $out/bench_config5.json 2>/dev/null || exit 1
+python bench.py --config 5 --mode train --steps 50 --warmup 5 > $out/bench_config5_train.json 2>/dev/null || exit 1
 python bench.py --mode cli-train > $out/bench_cli_train.json 2>/dev/null || exit 1
 python bench.py --mode phase1 > $out/bench_phase1.json 2>/dev/null || exit 1
 tools/prof.sh final/prof || exit 1

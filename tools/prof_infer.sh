@@ -1,0 +1,7 @@
+#!/bin/bash
+# usage (GPU box): tools/prof_infer.sh NAME [bench args]  -> kernel stats of bench.py --mode infer --batch 2048 under gpurun_out/NAME
+name=$1; shift
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/$name -o runc -- python3 $root/bench.py --mode infer --batch 2048 --steps 20 --warmup 5 "$@" > $root/gpurun_out/$name.log 2>&1
+cd $root && python tools/kernel_stats.py gpurun_out/$name 25 12
