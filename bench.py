@@ -33,19 +33,34 @@ ALGO_BYTES_PER_IMAGE = 4.841e6      # SURVEY.md section 8(d), fp32, chfak 1 (1 2
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the HIP sources + the C ABI header: ties a committed counter summary to the kernels it measured."""
+    import glob
+    import hashlib
+    pkg = os.path.join(REPO, "critic-guided-segmentation-of-rewarding-objects-in-first-person-views_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(pkg, "*.hip")) + glob.glob(os.path.join(pkg, "*.h")) + [os.path.join(REPO, "include", "cgs_hip.h")]):
+        with open(f, "rb") as fp:
+            h.update(os.path.basename(f).encode() + b"\0" + fp.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(n):
-    """HBM bytes per step from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes,
-    FETCH_SIZE doubled for the 16-B/lane streaming kernels per the gfx950 rule; tools/sq_counters.sh + .py).  None when no
-    summary exists for this batch size: counters cannot be collected from inside the timed run."""
-    for name in ("r03_g_traffic.json", "r03_f_traffic.json", "r03_e_traffic.json", "r03_d_traffic.json", "r02_traffic.json"):      # the newest summary of the shipped kernels first
+    """(HBM bytes per step, source) from the newest committed PMC summary for this batch size (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled for the 16-B/lane streaming kernels per the gfx950 rule; tools/sq_counters.sh + .py +
+    traffic_from_counters.py).  Counters cannot be collected from inside the timed run: the summary carries the hash of the kernel sources
+    it was measured on, and `source` says whether that is THIS build.  (None, None) when no summary exists."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_traffic.json")), reverse=True):      # the newest summary first
         try:
-            with open(os.path.join(REPO, "profiles", name)) as fp:
+            with open(path) as fp:
                 t = json.load(fp)
             if t.get("n_images") == n:
-                return t["traffic_bytes_per_step"]
+                return t["traffic_bytes_per_step"], {"file": "profiles/" + os.path.basename(path), "csrc_sha16": t.get("csrc_sha16"),
+                                                     "measured_on_this_build": t.get("csrc_sha16") == csrc_sha16()}
         except (OSError, ValueError, KeyError):
             continue
-    return None
+    return None, None
 
 
 def parse():
@@ -495,6 +510,7 @@ def main():
         ms_step = wall * 1e3 / args.steps
         launch_ms = dev_ms / args.steps
         achieved = ALGO_BYTES_PER_IMAGE * n / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(n)
         out = {
             "metric": f"Hourglass+critic train images/sec, 64x64x3 batch={n}",
             "value": n * world * args.steps / wall,
@@ -519,11 +535,11 @@ def main():
             # achieved / frac: ALGORITHMIC bytes of SURVEY 8(d)'s layer-granular model per second (the contract's definition), not
             # bytes that crossed the HBM pins: the fused step moves fewer (traffic), see measured_hbm_GBs and fp32_TFLOPs
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(n),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one phase-2 step = one HIP-graph launch",
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_IMAGE * n,
                          "launch_ms": launch_ms,
-                         "measured_hbm_GBs": (measured_traffic(n) / (launch_ms * 1e-3) / 1e9) if measured_traffic(n) else None,
+                         "measured_hbm_GBs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
                          "fp32_TFLOPs": 86.75e6 * n / (launch_ms * 1e-3) / 1e12, "fp32_frac_of_157TF": 86.75e6 * n / (launch_ms * 1e-3) / 157.3e12},
             "final_losses": dict(zip(("critic", "replace", "inject", "l1", "l2", "total"), losses[:6])),
         }

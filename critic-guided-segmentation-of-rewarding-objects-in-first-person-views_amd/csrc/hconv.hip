@@ -13,6 +13,13 @@
 // OPT-IN precision (engine.infer(fp16=True) at chfak 1): never used by training or by the parity-gated fp32 paths.
 #include "tail_common.h"
 
+#ifndef HCONV_ENC0_TH
+#define HCONV_ENC0_TH 32          // rows of a 64x64 frame per features.0 workgroup (16 / 32 / 64 within 1 %: r4 A/B)
+#endif
+#ifndef HCONV_BLOCKS
+#define HCONV_BLOCKS 1024         // persistent workgroups per launch
+#endif
+
 namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -162,7 +169,7 @@ int hconv_launch(const HConvParams& P, hipStream_t st) {
     const size_t lds = (size_t)(TH + 2) * (HW + 2) * (CA + CB) * 2;
     HConvParams Q = P;
     Q.nstrips = P.n * (HW / TH);
-    const int blocks = Q.nstrips < 1024 ? Q.nstrips : 1024;      // persistent: 4 workgroups per CU
+    const int blocks = Q.nstrips < HCONV_BLOCKS ? Q.nstrips : HCONV_BLOCKS;      // persistent workgroups
     hipLaunchKernelGGL((hconv_kernel<HW, CA, CB, TH, POOL, OUT_F32>), dim3(blocks), dim3(256), lds, st, Q);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
@@ -172,7 +179,7 @@ int hconv_launch(const HConvParams& P, hipStream_t st) {
 
 extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
     if (n < 0 || !x_u8 || !w_hwio || !bias || !e0_f16) return CGS_ERR_BADARG;
-    return hconv_launch<64, 4, 0, 16, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0}, (hipStream_t)stream);
+    return hconv_launch<64, 4, 0, HCONV_ENC0_TH, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream) {

@@ -374,6 +374,14 @@ class Workspace(dict):
             t = self[name] = torch.zeros(tuple(shape), device=dev, dtype=dtype)
         return t
 
+    def ones(self, n: int, dev) -> torch.Tensor:
+        """A vector of n ones, filled once (it used to be re-filled by a torch kernel in every step)."""
+        name = f"ones_{n}"
+        t = self.get(name)
+        if t is None or t.numel() != max(n, 1):
+            t = self[name] = torch.ones(max(n, 1), device=dev, dtype=torch.float32)
+        return t
+
 
 def _flip(ws: Workspace, flat: torch.Tensor, lay: Layout, key: str, ci: int, co: int) -> int:
     """The layer's HWIO weight pointer: _bwd_data packs it (taps reversed, channels transposed) for the data-gradient pass."""
@@ -453,8 +461,7 @@ def critic_backward_weights(grad: torch.Tensor, goff: int, lay: Layout, chfak: i
     gp = grad.data_ptr() + 4 * goff
     dst = lambda k: gp + 4 * lay.off(k)
     d, nb = dims(chfak, neck)
-    ones = ws.buf(f"ones_{n}", (max(n, 1),), x.device)
-    ones.fill_(1.0)
+    ones = ws.ones(n, x.device)
     h1 = s["h1d"] if training else s["h1"]
     e3 = s["e3d"] if training else s["e3"]
     e2 = s["e2d"] if training else s["e2"]
@@ -532,8 +539,7 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
     # dec_model.4: o4 = e4 W + b (1x1 convolution on the 1x1 map)
     d_o4 = d_o.view(n, nb)
     gp = grad.data_ptr() + 4 * goff
-    ones = ws.buf(f"ones_{n}", (max(n, 1),), dev)
-    ones.fill_(1.0)
+    ones = ws.ones(n, dev)
     gemm_ex_batch(plan, ws, "dec4w", goff + lay.off("dec_model.4.weight"), nb, n, nb, embeds[4], 1, nb, d_o4, nb, 1, dev)
     gemm_ex_batch(plan, ws, "dec4b", goff + lay.off("dec_model.4.bias"), 1, n, nb, ones, 0, 1, d_o4, nb, 1, dev)
     if need_embed_grads:
