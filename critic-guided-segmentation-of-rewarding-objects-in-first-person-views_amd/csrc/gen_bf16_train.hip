@@ -68,35 +68,35 @@ __global__ void __launch_bounds__(256) bf16_wgrad_kernel(WgParams P) {
     for (int t = blockIdx.x; t < P.ntiles; t += P.nblocks) {
         const int img0 = TI == 1 ? t / strips : t * TI, row0 = TI == 1 ? (t % strips) * TH : 0;
         // ---- X tile: the virtual cat(A, up(B)) with a one-pixel zero halo, channel quads beyond the layer's zero ----
-        // (row by row: the only divisions left are by the compile-time quad count)
+        // (flat over (tile pixel, channel quad): divisions by the run-time tile width through an exact float reciprocal -- a half-integer
+        //  over PW is never within 0.5 / PW of an integer, far outside the rounding error at these magnitudes; the row-by-row form
+        //  measured slower: 520 items per 128-pixel row leave most of the third round idle)
         constexpr int NQ = CIP / 4;
-        for (int row = 0; row < TI * PH; ++row) {
-            const int ii = TI == 1 ? 0 : row / PH, rr = TI == 1 ? row : row - ii * PH;
-            const int img = img0 + ii, y = row0 + rr - 1;
-            const bool rowok = img < P.n && y >= 0 && y < H;
-            const size_t arow = ((size_t)img * H + y) * W, brow = ((size_t)img * HB + (y >> ush)) * WB;
-            uint16_t* const xrow = xt + (size_t)row * PW * CIP;
-            for (int e = tid; e < PW * NQ; e += 256) {
-                const int g = e % NQ, xx = e / NQ, x = xx - 1, k0 = 4 * g;
-                short4_t v = short4_t{0, 0, 0, 0};
-                if (rowok && x >= 0 && x < W && k0 < cp) {
-                    if (k0 < pa4) {
-                        const size_t pg = arow + x;
-                        if (P.a_kind == 0) {
-                            v = *(const short4_t*)((const uint16_t*)P.a + pg * P.ca + k0);
-                        } else {
-                            float f[4] = {0.f, 0.f, 0.f, 0.f};
-                            for (int c = 0; c < 4; ++c)
-                                if (k0 + c < P.ca)
-                                    f[c] = P.a_kind == 1 ? (float)((const uint8_t*)P.a)[pg * P.ca + k0 + c] * (1.f / 255.f) : ((const float*)P.a)[pg * P.ca + k0 + c];
-                            v = short4_t{(short)f2bf(f[0]), (short)f2bf(f[1]), (short)f2bf(f[2]), (short)f2bf(f[3])};
-                        }
+        const float inv_pw = 1.f / (float)PW, inv_ph = 1.f / (float)PH;
+        for (int e = tid; e < TI * PH * PW * NQ; e += 256) {
+            const int g = e % NQ, pix = e / NQ;
+            const int prow = (int)(((float)pix + 0.5f) * inv_pw), xx = pix - prow * PW;
+            const int ii = TI == 1 ? 0 : (int)(((float)prow + 0.5f) * inv_ph), rr = prow - ii * PH;
+            const int img = img0 + ii, y = row0 + rr - 1, x = xx - 1, k0 = 4 * g;
+            short4_t v = short4_t{0, 0, 0, 0};
+            if (img < P.n && y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
+                if (k0 < pa4) {
+                    const size_t pg = ((size_t)img * H + y) * W + x;
+                    if (P.a_kind == 0) {
+                        v = *(const short4_t*)((const uint16_t*)P.a + pg * P.ca + k0);
                     } else {
-                        v = *(const short4_t*)(P.b + (brow + (x >> ush)) * P.cb + (k0 - pa4));
+                        float f[4] = {0.f, 0.f, 0.f, 0.f};
+                        for (int c = 0; c < 4; ++c)
+                            if (k0 + c < P.ca)
+                                f[c] = P.a_kind == 1 ? (float)((const uint8_t*)P.a)[pg * P.ca + k0 + c] * (1.f / 255.f) : ((const float*)P.a)[pg * P.ca + k0 + c];
+                        v = short4_t{(short)f2bf(f[0]), (short)f2bf(f[1]), (short)f2bf(f[2]), (short)f2bf(f[3])};
                     }
+                } else {
+                    const size_t pb = ((size_t)img * HB + (y >> ush)) * WB + (x >> ush);
+                    v = *(const short4_t*)(P.b + pb * P.cb + (k0 - pa4));
                 }
-                *(short4_t*)(xrow + (size_t)xx * CIP + k0) = v;
             }
+            *(short4_t*)(xt + (size_t)pix * CIP + k0) = v;
         }
         // ---- dY tile: [pixel][16 output channels] ----
         for (int e = tid; e < TP * 4; e += 256) {

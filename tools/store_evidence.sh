@@ -16,6 +16,6 @@ sed -i "s#gpurun_out/final/sq_counters.csv#profiles/${t}_sq_counters.csv#" profi
 cp $f/prof_chfak5/runc_kernel_stats.csv profiles/${t}_generic_chfak5_kernel_stats.csv
 cp $f/prof_infer_f16/runc_kernel_stats.csv profiles/${t}_infer2048_fp16_kernel_stats.csv
 cp $f/prof_config5_train/runc_kernel_stats.csv profiles/${t}_config5_train_kernel_stats.csv 2>/dev/null || cp $f/prof_config5_train/*/runc_kernel_stats.csv profiles/${t}_config5_train_kernel_stats.csv
-cat $f/bench_chfak5_train.json $f/bench_chfak5_infer.json $f/bench_chfak5_infer_f16.json > profiles/${t}_generic_chfak5_bench.json
-cat $f/bench_infer2048.json $f/bench_infer2048_f16head.json $f/bench_infer2048_f16.json $f/bench_config5.json $f/bench_config5_train.json $f/bench_cli_train.json $f/bench_phase1.json $f/bench_force_pg.json $f/bench_force_pg_eager.json > profiles/${t}_side_benches.json
+grep -h "^{" $f/bench_chfak5_train.json $f/bench_chfak5_infer.json $f/bench_chfak5_infer_f16.json > profiles/${t}_generic_chfak5_bench.json
+grep -h "^{" $f/bench_infer2048.json $f/bench_infer2048_f16head.json $f/bench_infer2048_f16.json $f/bench_config5.json $f/bench_config5_train.json $f/bench_cli_train.json $f/bench_phase1.json $f/bench_force_pg.json $f/bench_force_pg_eager.json > profiles/${t}_side_benches.json
 echo stored
