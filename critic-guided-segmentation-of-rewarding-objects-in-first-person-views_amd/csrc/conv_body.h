@@ -35,6 +35,10 @@ struct ConvParams {
 
 enum { EPI_POOL = 0, EPI_PLAIN = 1, EPI_DGRAD = 2 };
 
+// optional second destination of a pooled epilogue: an NHWC LDS tile of the workgroup's image (pixel (y, x) at base + (y + 1) pitch + (x + 1) ps):
+// the fused features.3 + encoder-tail kernel (tail.hip) hands the pooled map to the next layers without a trip through memory
+struct PoolLds { float* base; int pitch, ps; };
+
 // optional config member: static constexpr bool MIX_EPI = true -> the data gradient w.r.t. source A stays in registers and
 // the epilogue writes the mix backward's d(pre-sigmoid mask) instead (conv_bwd_both.hip: features.0 + mix backward)
 template <class C, class = void> struct mix_epi_of { static constexpr bool value = false; };
@@ -179,7 +183,7 @@ __device__ __forceinline__ void conv_stage_weights(const ConvParams& P, const in
 
 // stage 2: the FMA block and the epilogue of tile `bid` from the staged LDS tiles
 template <class C, bool FUSED>
-__device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid, const int tid, float4* smem) {
+__device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid, const int tid, float4* smem, const PoolLds pool_lds = PoolLds{nullptr, 0, 0}) {
     using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     using L = ConvLds<C>;
     constexpr int PA = L::PA, PB = L::PB, DUMP = L::DUMP, W_FLOATS = L::W_FLOATS, DZW = L::DZW, DZ_FLOATS = L::DZ_FLOATS;
@@ -338,6 +342,12 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
 #pragma unroll
                 for (int i = 0; i < C::OCB / 4; ++i)
                     o4[i] = make_float4(pooled[4 * i], pooled[4 * i + 1], pooled[4 * i + 2], pooled[4 * i + 3]);
+                if (pool_lds.base) {
+                    float4* l4 = (float4*)(pool_lds.base + ((y0 >> 1) + 1) * pool_lds.pitch + (q.qx + 1) * pool_lds.ps + oc0);
+#pragma unroll
+                    for (int i = 0; i < C::OCB / 4; ++i)
+                        l4[i] = make_float4(pooled[4 * i], pooled[4 * i + 1], pooled[4 * i + 2], pooled[4 * i + 3]);
+                }
                 if (P.amask_out) {
                     if constexpr (C::OCB % 8 == 0) {
 #pragma unroll
@@ -512,7 +522,7 @@ template <class C, class = void> struct tpw_of { static constexpr int value = 1;
 template <class C> struct tpw_of<C, decltype((void)C::TPW)> { static constexpr int value = C::TPW; };
 
 template <class C>
-__device__ __forceinline__ void conv3x3_body_pipe(const ConvParams& P, const int bid0, float4* smem) {
+__device__ __forceinline__ void conv3x3_body_pipe(const ConvParams& P, const int bid0, float4* smem, const PoolLds pool_lds = PoolLds{nullptr, 0, 0}) {
     using G = Geo<C::H, C::W, C::THREADS, C::CW>;
     using L = ConvLds<C>;
     constexpr int PA = L::PA, PB = L::PB, TPW = tpw_of<C>::value;
@@ -560,7 +570,7 @@ __device__ __forceinline__ void conv3x3_body_pipe(const ConvParams& P, const int
         commit(t);
         __syncthreads();
         if (t + 1 < TPW) fetch(t + 1);
-        conv_compute<C, true>(P, bid0 + t, tid, smem);
+        conv_compute<C, true>(P, bid0 + t, tid, smem, pool_lds);
         if (t + 1 < TPW) __syncthreads();      // every wave is done with the tile before the next one is written
     }
 }
@@ -646,3 +656,4 @@ CGS_DG_CFG(DMaskHead, 64, 128, SRC_DH, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 
 struct FEnc0U8P : FEnc0U8 { static constexpr int TPW = 4; };
 struct FEnc0MixP : FEnc0Mix { static constexpr int TPW = 4; };
 struct DEnc1P : DEnc1 { static constexpr int TPW = 2; };
+struct FEnc1P : FEnc1 { static constexpr int TPW = 2; };      // used by the fused features.3 + encoder-tail kernel (tail.hip)

@@ -19,6 +19,7 @@
 #include "tail4.h"
 #include "head_wgrad.h"
 #include "wgrad_dec0.h"
+#include "conv_body.h"
 
 namespace {
 
@@ -78,7 +79,13 @@ struct TailEncFwdParams {
 using X1P = TileP<16, 16, 8, 8, 148>;     // e1
 using X2P = TileP<8, 8, 8, 8, 84>;        // dropout(e2)
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P) {
+// FUSED (round 4): the workgroup first runs features.3 of ITS image (conv3x3_body_pipe<FEnc1P>: both 16-row strips, software-pipelined;
+// e1 + argmax nibbles go to memory for the backward pass and the decoder as before) with the pooled epilogue also writing the x1 tile,
+// then the tail stages: no e1 round trip, no launch boundary, and the tail's prologue (kernel arguments, Dropout counters, LDS zeroing,
+// cold instruction fetch: 38 % of the stand-alone kernel's life by the stamps) runs while the convolution's loads are in flight.
+template <bool FUSED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P, ConvParams PC) {
+    extern __shared__ __attribute__((aligned(16))) float4 conv_smem[];       // FUSED: the convolution's tiles + weights
     __shared__ __attribute__((aligned(16))) float x1[X1P::FLOATS];
     __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
     __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
@@ -89,13 +96,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // the first image's loads and the Dropout step counters are requested before anything else: they fly during the set-up below
     int img = blockIdx.x;
     float4 pe[2] = {f4zero(), f4zero()};
-    if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
+    if constexpr (!FUSED) {
+        if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
+    }
     const DropCtx d2 = drop_ctx(P.drop_e2, P.w.b6), d3 = drop_ctx(P.drop_e3, P.w.b6), dh = drop_ctx(P.drop_h1, P.w.b6);
 
     // ---- once per workgroup: halos -> 0, conv weights -> registers (features.6: both channel groups; features.10: this wave's
     //      four output channels), head weights -> registers ----
     tilep_zero<X1P>(x1, tid);
     tilep_zero<X2P>(x2, tid);
+    if constexpr (FUSED) {
+        // features.3 of image blockIdx.x (strips 2 b, 2 b + 1); its first barrier separates the zeroing above from the epilogue's tile writes.
+        // The tail's weight registers are loaded AFTER it: held across the convolution they would push the kernel past 128 registers.
+        conv3x3_body_pipe<FEnc1P>(PC, 2 * (int)blockIdx.x, conv_smem, PoolLds{x1, X1P::PITCH, X1P::PS});
+    }
     if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
     float wr6[2][5], wr10[1][5];
     fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
@@ -115,16 +129,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 
     for (; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
-        // ---- e1 -> tile interior (512 float4), then the next image's loads ----
+        // ---- e1 -> tile interior (512 float4), then the next image's loads (FUSED: the convolution's epilogue filled the tile) ----
+        if constexpr (!FUSED) {
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
-            *(float4*)(x1 + X1P::at(y, x) + 4 * p) = pe[it];
-        }
-        __syncthreads();
-        if (img + P.nblocks < P.n) {
-            pe[0] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid];
-            pe[1] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid + 256];
+            for (int it = 0; it < 2; ++it) {
+                const int e = tid + 256 * it, p = e & 1, x = (e >> 1) & 15, y = e >> 5;
+                *(float4*)(x1 + X1P::at(y, x) + 4 * p) = pe[it];
+            }
+            __syncthreads();
+            if (img + P.nblocks < P.n) {
+                pe[0] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid];
+                pe[1] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid + 256];
+            }
         }
         TAIL_STAMP(2);
         // ---- features.6 + ReLU + pool: this wave's 64 pixels, all 8 channels ----
@@ -258,7 +274,25 @@ extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const 
     if (n == 0) return CGS_OK;
     TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
     const int blocks = P.nblocks;
-    hipLaunchKernelGGL(tail_enc_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(tail_enc_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// features.3 (conv 8 -> 8 at 32x32 + ReLU + MaxPool2d(2), nets.py:173-175) AND the encoder tail in one launch, one workgroup per image:
+// e0 [n,32,32,8] -> e1 [n,16,16,8] + am1 (to memory, as cgs_conv3x3_fwd writes them) -> everything cgs_tail_enc_fwd produces.
+extern "C" int cgs_enc1_tail_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e0, const float* w3, const float* b3, float* e1,
+                                 uint32_t* am1, float* e2, uint32_t* am2, float* e3, uint32_t* am3, float* e4, float* h1, float* pred, float* o4,
+                                 cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e0 || !w3 || !b3 || !e1 || !am1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->b6 || !w->w10 || !w->b10 || !w->w14 || !w->b14 || !w->wl1 || !w->bl1 || !w->wl2 || !w->bl2) return CGS_ERR_BADARG;
+    if (o4 && (!w->wpw || !w->bpw)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, n, g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
+    ConvParams PC{};
+    PC.src_a = e0; PC.w = w3; PC.bias = b3; PC.out = e1; PC.amask_out = am1; PC.n = n;
+    const size_t lds = conv_lds_bytes<FEnc1P>();
+    hipLaunchKernelGGL(tail_enc_fwd_kernel<true>, dim3(n), dim3(256), lds, (hipStream_t)stream, P, PC);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -29,6 +29,8 @@ MASK_TRAIN_FUSED = True
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
 TAIL_FWD = True
 TAIL_BWD = True
+# features.3 and the encoder tail as ONE launch, one workgroup per image (csrc/tail.hip: tail_enc_fwd_kernel<true>, round 4)
+ENC1_TAIL_FUSED = True
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
@@ -218,8 +220,9 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
         am = o.get(f"am{i}")
         if am is None:
             am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
-        if TAIL_FWD and i >= 2:
-            continue        # features.6 / features.10 / head: one tail kernel below
+        if TAIL_FWD and (i >= 2 or (i == 1 and ENC1_TAIL_FUSED)):
+            src = e
+            continue        # features.6 / features.10 / head (and, fused, features.3): one tail kernel below
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         if mixin and i == 0:
             d.src_a = _lib.SRC_MIX
@@ -233,6 +236,13 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     if TAIL_FWD:
         pwp = (pw[0], pw[1]) if pw else None
         tw = tail_enc_weights(flat, lay, (pwp[0].value, pwp[1].value) if pwp else None)
+        if ENC1_TAIL_FUSED:
+            k3 = ENC_LAYERS[1][0]
+            _lib.call("cgs_enc1_tail_fwd", n, C.byref(tw), _p(o["e0"]), C.c_void_p(flat.data_ptr() + 4 * lay.off(k3 + ".weight")),
+                      C.c_void_p(flat.data_ptr() + 4 * lay.off(k3 + ".bias")), _p(o["e1"]), _p(o["am1"]), _p(o["e2"]), _p(o["am2"]), _p(o["e3"]),
+                      _p(o["am3"]), _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _p(pw[2]) if pw else None, drop.desc(DROP_SITE_E2, True, 128),
+                      drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
+            return o
         _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(o["e1"]), _p(o["e2"]), _p(o["am2"]), _p(o["e3"]), _p(o["am3"]),
                   _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _p(pw[2]) if pw else None, drop.desc(DROP_SITE_E2, True, 128),
                   drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())

@@ -187,6 +187,12 @@ typedef struct {
 int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
                      uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_dropout drop_e2,
                      cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+/* features.3 (cgs_conv3x3_fwd of the 8 -> 8 layer at 32x32: e0 [n,32,32,8] -> e1 [n,16,16,8] + am1, nets.py:173-175) and cgs_tail_enc_fwd in ONE
+ * launch, one workgroup per image (round 4): e1 / am1 are written for the backward pass and the decoder as before, the tail stages read
+ * the pooled map from the workgroup's LDS tile.  w3 / b3: features.3's HWIO weights and bias.                                          */
+int cgs_enc1_tail_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e0, const float* w3, const float* b3, float* e1,
+                      uint32_t* am1, float* e2, uint32_t* am2, float* e3, uint32_t* am3, float* e4, float* h1, float* pred, float* o4,
+                      cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
 int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
 /* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
