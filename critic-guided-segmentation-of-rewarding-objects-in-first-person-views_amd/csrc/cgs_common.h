@@ -113,3 +113,11 @@ __device__ __forceinline__ float act_fwd(float v) {
         hipError_t e__ = hipGetLastError();            \
         if (e__ != hipSuccess) return (int)e__;        \
     } while (0)
+
+// In-kernel s_memtime stamps (tools/*_stamps.py) exist only in a debug build (tools/build_variant.py stamps -DCGS_DEBUG_STAMPS): in the
+// product library the stamp pointer is a compile-time NULL, the stamping code folds away and the dbg_* hooks are not exported.
+#ifdef CGS_DEBUG_STAMPS
+#define CGS_STAMP_PTR(p) (p)
+#else
+#define CGS_STAMP_PTR(p) ((unsigned long long*)nullptr)
+#endif

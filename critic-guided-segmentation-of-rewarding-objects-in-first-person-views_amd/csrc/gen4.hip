@@ -39,7 +39,7 @@ struct Gen4Params {
     unsigned long long* dbg;                            // debug: per-workgroup phase stamps (tools/gen4_stamps.py), NULL in the product path
 };
 unsigned long long* g_gen4_stamps = nullptr;
-#define G4_STAMP(k) do { if (P.dbg && tid == 0 && blockIdx.x < 4096) P.dbg[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G4_STAMP(k) do { if (CGS_STAMP_PTR(P.dbg) && tid == 0 && blockIdx.x < 4096) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 // ---- weights as register images: wp[((chunk * 9 + tap) * ngp + g) * 64 + 4 * cin + i] = w[tap][channel cin of the chunk][4 g + i],
 // ngp = passes x groups per pass (gen4_groups), zero for the groups past the layer's last ----
@@ -382,7 +382,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
 }
 
 }  // namespace
+#ifdef CGS_DEBUG_STAMPS
 extern "C" int dbg_gen4_stamps(unsigned long long* stamps) { g_gen4_stamps = stamps; return CGS_OK; }
+#endif
 
 // ---- launchers (gen.hip's C entry points call these) ----
 struct Gen4Launch {

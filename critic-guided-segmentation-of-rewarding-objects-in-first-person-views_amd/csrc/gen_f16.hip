@@ -47,7 +47,7 @@ struct Gen16ConvParams {
 };
 
 unsigned long long* g_gen16_stamps = nullptr;
-#define G16_STAMP(k) do { if (P.dbg && tid == 0 && blockIdx.x < 4096) P.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G16_STAMP(k) do { if (CGS_STAMP_PTR(P.dbg) && tid == 0 && blockIdx.x < 4096) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ int g16_pa4(const Gen16ConvParams& P) { return (P.ca + 3) & ~3; }
 
@@ -274,7 +274,9 @@ __global__ void __launch_bounds__(64) gen16_gemm_kernel(Gen16GemmParams P) {
 
 }  // namespace
 
+#ifdef CGS_DEBUG_STAMPS
 extern "C" int dbg_gen16_stamps(unsigned long long* p) { g_gen16_stamps = p; return CGS_OK; }
+#endif
 
 extern "C" int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;

@@ -34,8 +34,10 @@ constexpr int kWinPitch = 33;
 unsigned long long* g_maskfwd_stamps = nullptr;
 }
 
-#define MF_STAMP(k) do { if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MF_STAMP(k) do { if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#ifdef CGS_DEBUG_STAMPS
 extern "C" int dbg_maskfwd_stamps(unsigned long long* stamps) { g_maskfwd_stamps = stamps; return CGS_OK; }
+#endif
 
 template <int SRC>     // SRC_U8C3 / SRC_F32C3
 __global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {

@@ -55,10 +55,12 @@ unsigned long long* g_tail_stamps = nullptr;     // debug: per-workgroup stage t
 
 // Debug hook (not part of the product path): when set, thread 0 of every tail workgroup records s_memtime at its stage
 // boundaries of its FIRST image into stamps[(kernel * 2048 + block) * 16 + stage].
+#ifdef CGS_DEBUG_STAMPS
 extern "C" int dbg_tail_stamps(unsigned long long* stamps) { g_tail_stamps = stamps; return CGS_OK; }
+#endif
 #define TAIL_STAMP(k)                                                                                     \
     do {                                                                                                  \
-        if (P.dbg && tid == 0 && img == (int)blockIdx.x) P.dbg[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+        if (CGS_STAMP_PTR(P.dbg) && tid == 0 && img == (int)blockIdx.x) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 
 // ------------------------------------------------------------------------------------------------
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
     __shared__ float red[8][32], es[32], hs[32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int o = tid & 31, kg = tid >> 5;
     // the first image's loads and the Dropout step counters are requested before anything else: they fly during the set-up below
     int img = blockIdx.x;
@@ -110,11 +112,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // The tail's weight registers are loaded AFTER it: held across the convolution they would push the kernel past 128 registers.
         conv3x3_body_pipe<FEnc1P>(PC, 2 * (int)blockIdx.x, conv_smem, PoolLds{x1, X1P::PITCH, X1P::PS});
     }
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
     float wr6[2][5], wr10[1][5];
     fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
     fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
     float w1r[4], wpr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -124,7 +126,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     const cgs_cptr b6c = cgs_to_const(P.w.b6), b10c = cgs_to_const(P.w.b10);
     const float b14 = P.w.b14[o], bl1 = P.w.bl1[o], wl2 = P.w.wl2[o], bl2 = P.w.bl2[0], bpw = P.o4 ? P.w.bpw[o] : 0.f;
     const PxPos pa = px16(wave, lane), pb = px8(lane);
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();
     __syncthreads();
 
     for (; img < P.n; img += P.nblocks) {
@@ -262,7 +264,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         __syncthreads();
         TAIL_STAMP(11);
     }
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
 extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (wave == 0) mask0_pack_weights(P.m0_w, P.m0_pack, lane);
         return;
     }
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15, kq = lane >> 4;
     // the first image's loads are requested before the set-up (and the next image's as soon as the tiles are filled)
     int img = blockIdx.x;
@@ -468,7 +470,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
         TAIL_STAMP(6);
     }
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
 extern "C" int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
@@ -543,7 +545,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     float* dz4s = lds_all + ODZ4;
     static_assert(OEND >= 4 * 5 * 256, "reduction scratch fits the tile area");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5, half = lane & 32;
     const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
@@ -740,7 +742,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const size_t b = blockIdx.x;
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
     wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
 extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }
@@ -839,7 +841,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* dy1 = sm + L::D1; float* dy2 = sm + L::D2; float* dy3 = sm + L::D3;
     float* w1s = sm + L::W1; float* w2s = sm + L::W2; float* red = sm + L::RED;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15;
 
     // (the once-per-workgroup LDS set-up -- zero halos, dec_model.1 / .2 weights -- runs inside the first iteration, behind the
@@ -1006,7 +1008,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (tid < 8 && P.slab1) P.slab1[b * kTailSlabD1 + 1152 + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     if (P.slab2) wg2.store(P.slab2 + b * kTailSlabD2, wave, lane);
     if (P.slab3) wg3.store(P.slab3 + b * kTailSlabD3, wave, lane);
-    if (P.dbg && tid == 0) P.dbg[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
 extern "C" int cgs_tail_dec_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }

@@ -1,3 +1,4 @@
+# needs the debug build of the library: python tools/build_variant.py stamps -DCGS_DEBUG_STAMPS ; CGS_LIB_PATH=<pkg>/libcgs_hip_stamps.so (the product library exports no dbg_* hooks)
 """Stage timing of the fp16 conv kernel (debug hook dbg_gen16_stamps): python tools/gen16_stamps.py"""
 import ctypes as C, os, sys
 import numpy as np, torch

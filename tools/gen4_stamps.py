@@ -1,3 +1,4 @@
+# needs the debug build of the library: python tools/build_variant.py stamps -DCGS_DEBUG_STAMPS ; CGS_LIB_PATH=<pkg>/libcgs_hip_stamps.so (the product library exports no dbg_* hooks)
 """Phase timing of gen4_conv3x3_kernel (debug hook dbg_gen4_stamps): mean s_memtime deltas between the phase boundaries of the
 first 4096 workgroups for one layer shape.  Usage (GPU box): python tools/gen4_stamps.py [hw ca cb co n [u8] [pool]]"""
 import ctypes as C

@@ -1,3 +1,4 @@
+# needs the debug build of the library: python tools/build_variant.py stamps -DCGS_DEBUG_STAMPS ; CGS_LIB_PATH=<pkg>/libcgs_hip_stamps.so (the product library exports no dbg_* hooks)
 """Phase time stamps (s_memtime, thread 0 of every workgroup) of the one-kernel mask head forward: tools/maskfwd_stamps.py [n]"""
 import ctypes as C, os, sys, torch
 import numpy as np

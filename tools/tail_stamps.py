@@ -1,3 +1,4 @@
+# needs the debug build of the library: python tools/build_variant.py stamps -DCGS_DEBUG_STAMPS ; CGS_LIB_PATH=<pkg>/libcgs_hip_stamps.so (the product library exports no dbg_* hooks)
 """Stage timing of the tail kernels (debug hook dbg_tail_stamps): mean s_memtime deltas between the stage boundaries of
 every workgroup's first image, per kernel.  Usage (GPU box): python tools/tail_stamps.py [batch]"""
 import ctypes as C
@@ -22,6 +23,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = torch.zeros(4 * 2048 * 16, dtype=torch.int64, device=dev)
 lib = _lib.load()
+if not hasattr(lib, "dbg_tail_stamps"):
+    raise SystemExit("stamps need the debug build: python tools/build_variant.py stamps -DCGS_DEBUG_STAMPS, then CGS_LIB_PATH=<pkg>/libcgs_hip_stamps.so")
 lib.dbg_tail_stamps.argtypes = [C.c_void_p]
 lib.dbg_tail_stamps(C.c_void_p(buf.data_ptr()))
 eng.phase2_step()
