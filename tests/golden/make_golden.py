@@ -24,6 +24,7 @@ Fixtures (all float32 unless noted):
   g7_dropout.npz         phase-2 step with dropout 0.3 and the recorded keep-masks
   g8_unet_convt.npz      legacy Unet(upsample=False) (ConvTranspose2d decoder, LeakyReLU(0.2)): weights, mask, u0, critic value
   g8_unet_train.npz      the same class, one training step: loss = MSE(mask, target) + MSE(critic, target), all 24 parameter gradients
+  g6_process.npz         (make_golden_g6.py) the PNG outputs of the reference's own `main.py -process` CLI run end to end
 """
 import json
 import os

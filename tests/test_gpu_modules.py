@@ -221,6 +221,48 @@ def test_cli_train_then_process(tmp_path):
     assert (np.isnan(got2[1]) and np.isnan(want_sal)) or abs(got2[1] - want_sal) <= 5e-3, (got2, want_sal)
 
 
+def test_cli_process_matches_the_reference_cli_capture(tmp_path, golden, g1):
+    """`main.py -process` of THIS build against G6 = the PNG files the reference's own `main.py -process` wrote for the same frames and
+    G1 weights (tests/golden/make_golden_g6.py): identical file names for the three command lines, raw masks within one uint8 step of
+    the reference's (the HIP fp32 mask differs from the CPU one by ~1e-6, (Z * 255).astype(uint8) truncates), thresholded masks equal
+    except where Z is within 1e-5 of the threshold, the frame column of the concatenated strips exact."""
+    import json
+    from PIL import Image
+    pc, pm = g1
+    g = golden("g6_process.npz")
+    X, names = g["frames"], [str(s) for s in g["names"]]
+    listing = json.loads(str(g["listing_json"]))
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "src"))
+    for nm, x in zip(names, X):
+        Image.fromarray(x).save(os.path.join(root, "src", nm + ".png"))
+    cnames = [str(s) for s in g["checkpoint_names"]]
+    os.makedirs(os.path.join(root, "m", "saves"))
+    torch.save(pc, os.path.join(root, cnames[0]))
+    torch.save(pm, os.path.join(root, cnames[1]))
+    runs = {"default": [], "concat": ["-concatenated"], "thr052": ["--binarymaskthreshold", "0.52"]}
+    _, Zref = orc.infer_masks(pc, pm, X / 255.0)
+    for tag, extra in runs.items():
+        r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-process", "--model", "m", "--source-imgs", "src",
+                            "--mask-output-imgs", "out_" + tag] + extra, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert sorted(os.listdir(os.path.join(root, "out_" + tag))) == listing[tag], tag
+        thr = 0.52 if tag == "thr052" else 0.5
+        for i, f in enumerate(listing[tag]):
+            got = np.array(Image.open(os.path.join(root, "out_" + tag, f))).astype(int)
+            ref = g[f"{tag}/{f}"].astype(int)
+            assert got.shape == ref.shape
+            if f.endswith("raw-mask.png"):
+                assert np.abs(got - ref).max() <= 1 and (got != ref).mean() < 2e-3, f
+            elif f.endswith("thresholded-mask.png"):
+                nm = f[:-len("-thresholded-mask.png")]
+                near = np.abs(Zref[names.index(nm), 0] - thr) < 1e-5
+                assert not ((got[..., 0] != ref[..., 0]) & ~near).any(), f
+            else:       # frame | raw mask | thresholded mask
+                np.testing.assert_array_equal(got[:, :64], ref[:, :64])
+                assert np.abs(got[:, 64:128] - ref[:, 64:128]).max() <= 1
+
+
 DP_WORKER = r"""
 import os, sys
 sys.path.insert(0, {repo!r})

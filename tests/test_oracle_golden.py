@@ -249,3 +249,31 @@ def test_oracle_unet_restatement_matches_reference_capture(golden):
     np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(u0.numpy(), g["u0"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(c.numpy(), g["critic"], rtol=1e-5, atol=1e-6)
+
+
+def test_g6_process_writer_matches_the_reference_cli(golden, g1):
+    """G6: the reference's OWN `main.py -process` was run end to end in the build container
+    (tests/golden/make_golden_g6.py) and its PNG outputs captured.  The oracle's hand restatement of the post-processing
+    (infer_masks + postprocess_masks, main.py:1130-1223) reproduces every file bit for bit: raw masks, thresholded masks at 0.5 and
+    0.52, the -concatenated strips; the file names keep everything before the LAST dot of the source name; the checkpoint names are
+    the ones the reference's Handler computed for the default flags (main.py:86-104)."""
+    import json
+    pc, pm = g1
+    g = golden("g6_process.npz")
+    X, names = g["frames"], [str(s) for s in g["names"]]
+    listing = json.loads(str(g["listing_json"]))
+    _, M = orc.infer_masks(pc, pm, X / 255.0)
+    for tag, thr in (("default", 0.5), ("thr052", 0.52)):
+        hard, stack = orc.postprocess_masks(X / 255.0, M, thr)
+        assert listing[tag] == sorted(f"{nm}-{c}.png" for nm in names for c in ("raw-mask", "thresholded-mask"))
+        for i, nm in enumerate(names):
+            np.testing.assert_array_equal(g[f"{tag}/{nm}-raw-mask.png"], stack[i, 1])
+            np.testing.assert_array_equal(g[f"{tag}/{nm}-thresholded-mask.png"], stack[i, 2])
+    hard, stack = orc.postprocess_masks(X / 255.0, M, 0.5)
+    assert listing["concat"] == sorted(f"{nm}_with_mask.png" for nm in names)
+    for i, nm in enumerate(names):
+        np.testing.assert_array_equal(g[f"concat/{nm}_with_mask.png"], np.concatenate(list(stack[i]), axis=-2))
+    # checkpoint naming contract, pinned by the reference's Handler itself
+    from cgs_amd import cli, handler
+    cn, mn = handler.checkpoint_names(cli.parse_args(["--model", "m"]))
+    assert [f"m/saves/critic-{cn}.pt", f"m/saves/masker-{mn}.pt"] == [str(s) for s in g["checkpoint_names"]]
