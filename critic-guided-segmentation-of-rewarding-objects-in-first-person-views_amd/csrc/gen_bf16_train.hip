@@ -68,11 +68,27 @@ __global__ void __launch_bounds__(256) bf16_wgrad_kernel(WgParams P) {
     for (int t = blockIdx.x; t < P.ntiles; t += P.nblocks) {
         const int img0 = TI == 1 ? t / strips : t * TI, row0 = TI == 1 ? (t % strips) * TH : 0;
         // ---- X tile: the virtual cat(A, up(B)) with a one-pixel zero halo, channel quads beyond the layer's zero ----
-        // (flat over (tile pixel, channel quad): divisions by the run-time tile width through an exact float reciprocal -- a half-integer
+        // (flat over (tile pixel, channel chunk): divisions by the run-time tile width through an exact float reciprocal -- a half-integer
         //  over PW is never within 0.5 / PW of an integer, far outside the rounding error at these magnitudes; the row-by-row form
         //  measured slower: 520 items per 128-pixel row leave most of the third round idle)
-        constexpr int NQ = CIP / 4;
         const float inv_pw = 1.f / (float)PW, inv_ph = 1.f / (float)PH;
+        if (P.a_kind == 0 && !(P.ca & 7) && !(P.cb & 7)) {
+            // bf16 sources in 8-channel chunks: one 16-byte load and one 16-byte LDS store per item
+            constexpr int NO = CIP / 8;
+            for (int e = tid; e < TI * PH * PW * NO; e += 256) {
+                const int g = e % NO, pix = e / NO;
+                const int prow = (int)(((float)pix + 0.5f) * inv_pw), xx = pix - prow * PW;
+                const int ii = TI == 1 ? 0 : (int)(((float)prow + 0.5f) * inv_ph), rr = prow - ii * PH;
+                const int img = img0 + ii, y = row0 + rr - 1, x = xx - 1, k0 = 8 * g;
+                short8_t v = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (img < P.n && y >= 0 && y < H && x >= 0 && x < W && k0 < cp) {
+                    if (k0 < pa4) v = *(const short8_t*)((const uint16_t*)P.a + (((size_t)img * H + y) * W + x) * P.ca + k0);
+                    else v = *(const short8_t*)(P.b + (((size_t)img * HB + (y >> ush)) * WB + (x >> ush)) * P.cb + (k0 - pa4));
+                }
+                *(short8_t*)(xt + (size_t)pix * CIP + k0) = v;
+            }
+        } else {
+        constexpr int NQ = CIP / 4;
         for (int e = tid; e < TI * PH * PW * NQ; e += 256) {
             const int g = e % NQ, pix = e / NQ;
             const int prow = (int)(((float)pix + 0.5f) * inv_pw), xx = pix - prow * PW;
@@ -98,13 +114,24 @@ __global__ void __launch_bounds__(256) bf16_wgrad_kernel(WgParams P) {
             }
             *(short4_t*)(xt + (size_t)pix * CIP + k0) = v;
         }
+        }
         // ---- dY tile: [pixel][16 output channels] ----
-        for (int e = tid; e < TP * 4; e += 256) {
-            const int g = e & 3, pl = e >> 2, ii = pl >> lgTW, rem = pl & (TH * W - 1), y = rem >> lgW, x = rem & (W - 1);
-            const int img = img0 + ii;
-            short4_t v = short4_t{0, 0, 0, 0};
-            if (img < P.n && 4 * g < P.dyc) v = *(const short4_t*)(P.dy + (((size_t)img * H + row0 + y) * W + x) * P.dyc + 4 * g);
-            *(short4_t*)(dt + (size_t)pl * 16 + 4 * g) = v;
+        if (!(P.dyc & 7)) {                 // 8-channel chunks: 16-byte accesses
+            for (int e = tid; e < TP * 2; e += 256) {
+                const int g = e & 1, pl = e >> 1, ii = pl >> lgTW, rem = pl & (TH * W - 1), y = rem >> lgW, x = rem & (W - 1);
+                const int img = img0 + ii;
+                short8_t v = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (img < P.n && 8 * g < P.dyc) v = *(const short8_t*)(P.dy + (((size_t)img * H + row0 + y) * W + x) * P.dyc + 8 * g);
+                *(short8_t*)(dt + (size_t)pl * 16 + 8 * g) = v;
+            }
+        } else {
+            for (int e = tid; e < TP * 4; e += 256) {
+                const int g = e & 3, pl = e >> 2, ii = pl >> lgTW, rem = pl & (TH * W - 1), y = rem >> lgW, x = rem & (W - 1);
+                const int img = img0 + ii;
+                short4_t v = short4_t{0, 0, 0, 0};
+                if (img < P.n && 4 * g < P.dyc) v = *(const short4_t*)(P.dy + (((size_t)img * H + row0 + y) * W + x) * P.dyc + 4 * g);
+                *(short4_t*)(dt + (size_t)pl * 16 + 4 * g) = v;
+            }
         }
         __syncthreads();
         // ---- K blocks of 32 pixels: lane group kq supplies pixels 8 kq .. 8 kq + 7 (two transposed 4-pixel reads) ----
@@ -246,7 +273,7 @@ WgGeom wg_geom(int n, int hw, int ca, int cb) {
     WgGeom g{};
     const int cp = ((ca + 3) & ~3) + cb;
     g.nci = (cp + 15) / 16;
-    if (hw >= 32) { g.ti = 1; g.th = 512 / hw; }
+    if (hw >= 32) { g.ti = 1; g.th = (g.nci == 1 ? 1024 : 512) / hw; }      // 1024-pixel tiles (less halo re-staging) while the tile fits
     else if (hw == 16) { g.ti = 2; g.th = 16; }
     else if (hw == 8) { g.ti = 8; g.th = 8; }
     else { g.ti = 16; g.th = 4; }

@@ -263,6 +263,40 @@ def test_cli_process_matches_the_reference_cli_capture(tmp_path, golden, g1):
                 assert np.abs(got[:, 64:128] - ref[:, 64:128]).max() <= 1
 
 
+def test_cli_process_fp16_path_against_the_reference_capture(tmp_path, golden, g1):
+    """`main.py -process -fp16` (this build's own switch: the fused fp16 inference path of BASELINE config 4) on the G6 frames: the same
+    files as the reference's CLI, raw masks within 2 uint8 steps (|dZ| of the fp16 path is ~4e-5), thresholded masks equal except where
+    the fp32 mask is within 2e-4 of the threshold."""
+    import json
+    from PIL import Image
+    pc, pm = g1
+    g = golden("g6_process.npz")
+    X, names = g["frames"], [str(s) for s in g["names"]]
+    listing = json.loads(str(g["listing_json"]))
+    root = str(tmp_path)
+    os.makedirs(os.path.join(root, "src"))
+    for nm, x in zip(names, X):
+        Image.fromarray(x).save(os.path.join(root, "src", nm + ".png"))
+    cnames = [str(s) for s in g["checkpoint_names"]]
+    os.makedirs(os.path.join(root, "m", "saves"))
+    torch.save(pc, os.path.join(root, cnames[0]))
+    torch.save(pm, os.path.join(root, cnames[1]))
+    r = subprocess.run([sys.executable, os.path.join(REPO, "main.py"), "-process", "-fp16", "--model", "m", "--source-imgs", "src",
+                        "--mask-output-imgs", "out"], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert sorted(os.listdir(os.path.join(root, "out"))) == listing["default"]
+    _, Zref = orc.infer_masks(pc, pm, X / 255.0)
+    for f in listing["default"]:
+        got = np.array(Image.open(os.path.join(root, "out", f))).astype(int)
+        ref = g[f"default/{f}"].astype(int)
+        if f.endswith("raw-mask.png"):
+            assert np.abs(got - ref).max() <= 2, f
+        else:
+            nm = f[:-len("-thresholded-mask.png")]
+            near = np.abs(Zref[names.index(nm), 0] - 0.5) < 2e-4
+            assert not ((got[..., 0] != ref[..., 0]) & ~near).any(), f
+
+
 DP_WORKER = r"""
 import os, sys
 sys.path.insert(0, {repo!r})
