@@ -121,3 +121,13 @@ __device__ __forceinline__ float act_fwd(float v) {
 #else
 #define CGS_STAMP_PTR(p) ((unsigned long long*)nullptr)
 #endif
+
+// Phase staggering (round 4; used by the fused features.3 + encoder-tail kernel -- in every other kernel of the step it measured neutral to
+// +1 us, r4p): the workgroups of such a launch are all resident at once and walk through the same sequence of
+// issue-bound and latency-bound phases in lockstep; delaying every other co-resident workgroup by a few microseconds at its start lets
+// the latency-bound phases of one half run under the matrix instructions of the other.  Workgroups 256 apart share a CU (8 XCDs x 32
+// CUs, round-robin dispatch), hence bit 8.  s_sleep SLEEP = SLEEP x 64 cycles.
+template <int BIT, int SLEEP>
+__device__ __forceinline__ void cgs_stagger() {
+    if ((blockIdx.x >> BIT) & 1) __builtin_amdgcn_s_sleep(SLEEP);
+}
