@@ -1,25 +1,29 @@
 // fp16 inference family (BASELINE.json config 4: "-process inference-only mask path ... fp16 conv kernels"): every layer of
 // NewCritic.forward / UnetDecoder.forward (nets.py:197-212, 494-523; main.py:1130-1151) with fp16 activations in HBM and LDS, fp16
-// weights, fp32 accumulation on v_mfma_f32_16x16x16_f16 (K = 16 per instruction: one MFMA per tap and 16-channel chunk), for any
+// weights, fp32 accumulation on v_mfma_f32_16x16x32_f16 (round 4: gfx950's K = 32 form -- one instruction per PAIR of taps and 16-channel
+// chunk, five per chunk instead of nine), for any
 // channel factor (runtime channel counts, like gen.hip).  An opt-in precision mode: the fp32 path stays the default everywhere.
 //
-//   gen16_pack_weights : HWIO fp32 [9][ci][co] -> fp16 [tap][chunk][quad][padded co][4]: the B operand of a lane (4 consecutive
-//                        input channels of one output channel) is one 8-byte load, a wave's loads are contiguous.
+//   gen16_pack_weights : HWIO fp32 [9][ci][co] -> fp16 [tap pair][chunk][kq][padded co][8]: the B operand of a lane (8 consecutive
+//                        input channels of one output channel at one of the pair's taps) is one 16-byte load, a wave's loads are contiguous.
 //   gen16_conv3x3      : conv3x3(cat(A, nearest-up(B))) + bias + act (+ MaxPool2d(2)); A uint8 (frames, /255 fused) or fp16 NHWC,
 //                        B fp16 NHWC; output fp16 NHWC, or fp32 for the mask layer.  LDS tile [rows][cols][4 quads of 4 halves]
-//                        with the quad index XOR-swizzled by the row parity: the 8-byte A-operand reads of a wave's two pixel
-//                        rows land in different bank halves.
+//                        with the quad index XOR-swizzled by the row parity: the 16-byte A-operand reads (two adjacent quads) of a
+//                        wave's two pixel rows land in different bank halves.
 //   gen16_gemm         : Linear layers / the 4x4 valid convolution / the 1x1 convolution on fp16 or fp32 rows, fp32 weights.
 #include "gen_common.h"
 
 namespace {
 
 // 16-bit element types: IEEE half (config 4) and bfloat16 (config 5: the build-defined 128x128 variant, hourglass128.py).  Both are
-// stored as raw 16-bit words; E16<BF> converts and picks the MFMA (v_mfma_f32_16x16x16_f16 / v_mfma_f32_16x16x16_bf16: K = 16 keeps the
-// 16-channel chunk of this family -- gfx950's K = 32 bf16 form would be half padding at the 8- and 16-channel layers of chfak 1).
+// stored as raw 16-bit words; E16<BF> converts and picks the MFMA (v_mfma_f32_16x16x32_f16 / _bf16 for the convolutions: K = 32 = two taps
+// of a 16-channel chunk; the K = 16 forms remain for other users of E16).
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half_t;
 typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8v_t __attribute__((ext_vector_type(8)));
+typedef short short8v_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8v_t __attribute__((ext_vector_type(8)));
 template <bool BF> struct E16;
 template <> struct E16<false> {
     using T = half_t; using V4 = half4_t;
@@ -27,6 +31,8 @@ template <> struct E16<false> {
     __device__ static __forceinline__ float up(T v) { return (float)v; }
     __device__ static __forceinline__ V4 zero() { return V4{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f}; }
     __device__ static __forceinline__ frag4 mfma(V4 a, V4 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+    using V8 = half8v_t;           // gfx950's K = 32 form: 8 elements per lane
+    __device__ static __forceinline__ frag4 mfma32(V8 a, V8 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct E16<true> {
     using T = __bf16; using V4 = short4_t;
@@ -34,6 +40,10 @@ template <> struct E16<true> {
     __device__ static __forceinline__ float up(T v) { return (float)v; }
     __device__ static __forceinline__ V4 zero() { return V4{0, 0, 0, 0}; }
     __device__ static __forceinline__ frag4 mfma(V4 a, V4 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+    using V8 = short8v_t;
+    __device__ static __forceinline__ frag4 mfma32(V8 a, V8 b, frag4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8v_t, a), __builtin_bit_cast(bf16x8v_t, b), c, 0, 0, 0);
+    }
 };
 
 struct Gen16ConvParams {
@@ -51,15 +61,18 @@ unsigned long long* g_gen16_stamps = nullptr;
 
 __device__ __forceinline__ int g16_pa4(const Gen16ConvParams& P) { return (P.ca + 3) & ~3; }
 
+// Operand layout of the K = 32 instruction (round 4: v_mfma_f32_16x16x32_{f16,bf16}; the K = 16 form spent nine instructions and nine
+// 8-byte LDS reads per 16 pixels and 16-channel chunk, this one five and five 16-byte reads): [tap pair tp][chunk][kq][padded co][8],
+// lane group kq = tap 2 tp + (kq >> 1), channels 8 (kq & 1) .. + 7 of the 16-channel chunk (the tenth tap is zero).
 template <bool BF>
 __global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __restrict__ w, int ca, int cb, int co, typename E16<BF>::T* __restrict__ out) {
     const int pa4 = (ca + 3) & ~3, cp = pa4 + cb, nchunk = (cp + 15) / 16, ncol = (co + 15) / 16 * 16, ci_total = ca + cb;
-    const int total = 9 * nchunk * 4 * ncol * 4;
+    const int total = 5 * nchunk * 4 * ncol * 8;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int j = e & 3, col = (e >> 2) % ncol, q = ((e >> 2) / ncol) & 3, ch = ((e >> 2) / (ncol * 4)) % nchunk, tap = (e >> 2) / (ncol * 4 * nchunk);
-        const int k = ch * 16 + 4 * q + j;
+        const int j = e & 7, col = (e >> 3) % ncol, kq = ((e >> 3) / ncol) & 3, ch = ((e >> 3) / (ncol * 4)) % nchunk, tp = (e >> 3) / (ncol * 4 * nchunk);
+        const int tap = 2 * tp + (kq >> 1), k = ch * 16 + 8 * (kq & 1) + j;
         const int ci = k < pa4 ? (k < ca ? k : -1) : (k < cp ? ca + (k - pa4) : -1);
-        out[e] = E16<BF>::cvt((ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
+        out[e] = E16<BF>::cvt((tap < 9 && ci >= 0 && col < co) ? w[((size_t)tap * ci_total + ci) * co + col] : 0.f);
     }
 }
 
@@ -68,11 +81,11 @@ __global__ void __launch_bounds__(256) gen16_pack_weights_kernel(const float* __
 template <bool BF>
 __global__ void __launch_bounds__(256) gen16_pack_weights_T_kernel(const float* __restrict__ w, int ci_layer, int co_layer, typename E16<BF>::T* __restrict__ out) {
     const int cp = (co_layer + 3) & ~3, nchunk = (cp + 15) / 16, ncol = (ci_layer + 15) / 16 * 16;
-    const int total = 9 * nchunk * 4 * ncol * 4;
+    const int total = 5 * nchunk * 4 * ncol * 8;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int j = e & 3, col = (e >> 2) % ncol, q = ((e >> 2) / ncol) & 3, ch = ((e >> 2) / (ncol * 4)) % nchunk, tap = (e >> 2) / (ncol * 4 * nchunk);
-        const int k = ch * 16 + 4 * q + j;
-        out[e] = E16<BF>::cvt((k < co_layer && col < ci_layer) ? w[((size_t)(8 - tap) * ci_layer + col) * co_layer + k] : 0.f);
+        const int j = e & 7, col = (e >> 3) % ncol, kq = ((e >> 3) / ncol) & 3, ch = ((e >> 3) / (ncol * 4)) % nchunk, tp = (e >> 3) / (ncol * 4 * nchunk);
+        const int tap = 2 * tp + (kq >> 1), k = ch * 16 + 8 * (kq & 1) + j;
+        out[e] = E16<BF>::cvt((tap < 9 && k < co_layer && col < ci_layer) ? w[((size_t)(8 - tap) * ci_layer + col) * co_layer + k] : 0.f);
     }
 }
 
@@ -109,7 +122,8 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
         apix[i] = y * PW + x;
         apar[i] = y & 1;
     }
-    const half_t* wl = (const half_t*)P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 4;      // + ((tap * nchunk + ch) * 4) * ncol * 4
+    using half8_t = typename EL::V8;
+    const half_t* wl = (const half_t*)P.w16 + ((size_t)kq * ncol + cg * NCB * 16 + l15) * 8;      // + ((tp * nchunk + ch) * 4) * ncol * 8
 
     for (int e = tid; e < (TH + 2) * 2 * 4; e += 256) {      // the two halo columns: zero for every chunk, written once
         const int g = e & 3, side = (e >> 2) & 1, r = e >> 3;
@@ -170,20 +184,25 @@ __global__ void __launch_bounds__(256) gen16_conv3x3_kernel(Gen16ConvParams P) {
         __syncthreads();
         G16_STAMP(2);
 #pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tp = 0; tp < 5; ++tp) {              // tap pairs: lane group kq takes tap 2 tp + (kq >> 1) (the tenth tap: zero weights)
+            int tap = 2 * tp + (kq >> 1);
+            tap = tap < 9 ? tap : 8;
             const int ty = tap / 3, toff = ty * PW + tap % 3;
-            half4_t b[NCB];
-            const half_t* wp = wl + (size_t)((tap * nchunk + ch) * 4) * ncol * 4;
+            half8_t b[NCB];
+            const half_t* wp = wl + (size_t)((tp * nchunk + ch) * 4) * ncol * 8;
 #pragma unroll
-            for (int c = 0; c < NCB; ++c)
-                b[c] = (cg * NCB * 16 + 16 * c + l15 < ncol) ? *(const half4_t*)(wp + 64 * c) : EL::zero();
+            for (int c = 0; c < NCB; ++c) {
+                b[c] = *(const half8_t*)(wp + 128 * c);
+                if (!(cg * NCB * 16 + 16 * c + l15 < ncol)) b[c] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            }
 #pragma unroll
             for (int i = 0; i < G16_MAX_TPW; ++i) {
                 if (wave + 4 * i < ntiles) {
-                    const int qpos = kq ^ (((apar[i] + ty) & 1) << 1);
-                    const half4_t a = *(const half4_t*)(tile + ((size_t)(apix[i] + toff) * 4 + qpos) * 4);
+                    // channels 8 (kq & 1) .. + 7 = quads 2 (kq & 1), + 1; the row-parity swizzle (quad ^ 2 par) moves the pair as a whole
+                    const int opos = (kq & 1) ^ ((apar[i] + ty) & 1);
+                    const half8_t a = *(const half8_t*)(tile + ((size_t)(apix[i] + toff) * 4 + 2 * opos) * 4);
 #pragma unroll
-                    for (int c = 0; c < NCB; ++c) acc[i][c] = EL::mfma(a, b[c], acc[i][c]);
+                    for (int c = 0; c < NCB; ++c) acc[i][c] = EL::mfma32(a, b[c], acc[i][c]);
                 }
             }
         }
@@ -281,7 +300,7 @@ extern "C" int dbg_gen16_stamps(unsigned long long* p) { g_gen16_stamps = p; ret
 extern "C" int64_t cgs_gen16_packed_weight_halves(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
     const int cp = ((ca + 3) & ~3) + cb;
-    return (int64_t)9 * ((cp + 15) / 16) * 4 * ((co + 15) / 16 * 16) * 4;
+    return (int64_t)5 * ((cp + 15) / 16) * 4 * ((co + 15) / 16 * 16) * 8;
 }
 
 static int gen16_pack(bool bf, int32_t ca, int32_t cb, int32_t co, const float* w, void* w16, cgs_stream_t stream) {
