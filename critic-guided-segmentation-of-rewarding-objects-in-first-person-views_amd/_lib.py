@@ -40,6 +40,10 @@ class TailDecWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("w3", "b3", "w2", "b2", "w1", "b1")]
 
 
+class Pack16Job(C.Structure):        # = cgs_gen16_pack_job (include/cgs_hip.h)
+    _fields_ = [("w", C.c_void_p), ("out", C.c_void_p), ("ca", i32), ("cb", i32), ("co", i32), ("transposed", i32)]
+
+
 class ReduceJob(C.Structure):
     _fields_ = [("slab", C.c_void_p), ("dst", C.c_void_p), ("nslab", i32), ("stride", i32), ("count", i32),
                 ("accumulate", i32)]
@@ -121,6 +125,7 @@ SIGNATURES = {
     "cgs_genbf16_gemm": (i32, [i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_genbf16_conv3x3_fwd_train": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_genbf16_pack_weights_t": (i32, [i32, i32, vp, vp, vp]),
+    "cgs_genbf16_pack_batch": (i32, [vp, i32, vp]),
     "cgs_bf16_conv3x3_bwd_weight_slabs": (i32, [i32, i32, i32, i32]),
     "cgs_bf16_conv3x3_bwd_weight": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_bf16_pool_expand": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),

@@ -376,6 +376,41 @@ extern "C" int cgs_genbf16_pack_weights_t(int32_t ci_layer, int32_t co_layer, co
     return CGS_OK;
 }
 
+// every layer's operands of a training step in ONE launch (the 128x128 variant repacks its bf16 copies after each Adam step: ~30 small
+// launches before): jobs = DEVICE array; transposed = the data gradient's operand (ca = the layer's input channels, co = its outputs)
+template <bool BF>
+__global__ void __launch_bounds__(256) gen16_pack_batch_kernel(const cgs_gen16_pack_job* __restrict__ jobs) {
+    const cgs_gen16_pack_job J = jobs[blockIdx.y];
+    typename E16<BF>::T* out = (typename E16<BF>::T*)J.out;
+    if (!J.transposed) {
+        const int pa4 = (J.ca + 3) & ~3, cp = pa4 + J.cb, nchunk = (cp + 15) / 16, ncol = (J.co + 15) / 16 * 16, ci_total = J.ca + J.cb;
+        const int total = 5 * nchunk * 4 * ncol * 8;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int j = e & 7, col = (e >> 3) % ncol, kq = ((e >> 3) / ncol) & 3, ch = ((e >> 3) / (ncol * 4)) % nchunk, tp = (e >> 3) / (ncol * 4 * nchunk);
+            const int tap = 2 * tp + (kq >> 1), k = ch * 16 + 8 * (kq & 1) + j;
+            const int ci = k < pa4 ? (k < J.ca ? k : -1) : (k < cp ? J.ca + (k - pa4) : -1);
+            out[e] = E16<BF>::cvt((tap < 9 && ci >= 0 && col < J.co) ? J.w[((size_t)tap * ci_total + ci) * J.co + col] : 0.f);
+        }
+    } else {
+        const int ci_layer = J.ca + J.cb, co_layer = J.co;
+        const int cp = (co_layer + 3) & ~3, nchunk = (cp + 15) / 16, ncol = (ci_layer + 15) / 16 * 16;
+        const int total = 5 * nchunk * 4 * ncol * 8;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int j = e & 7, col = (e >> 3) % ncol, kq = ((e >> 3) / ncol) & 3, ch = ((e >> 3) / (ncol * 4)) % nchunk, tp = (e >> 3) / (ncol * 4 * nchunk);
+            const int tap = 2 * tp + (kq >> 1), k = ch * 16 + 8 * (kq & 1) + j;
+            out[e] = E16<BF>::cvt((tap < 9 && k < co_layer && col < ci_layer) ? J.w[((size_t)(8 - tap) * ci_layer + col) * co_layer + k] : 0.f);
+        }
+    }
+}
+
+extern "C" int cgs_genbf16_pack_batch(const cgs_gen16_pack_job* jobs, int32_t njobs, cgs_stream_t stream) {
+    if (!jobs || njobs < 0) return CGS_ERR_BADARG;
+    if (njobs == 0) return CGS_OK;
+    hipLaunchKernelGGL(gen16_pack_batch_kernel<true>, dim3(16, njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
 static int gen16_gemm(bool bf, int32_t m, int32_t k, int32_t n, int32_t act, float slope, int32_t x_is_16, int32_t out_is_16, const void* x,
                       const float* w, const float* bias, void* out, cgs_stream_t stream) {
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;

@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // every other co-resident workgroup starts ~4 us late: its neighbours' latency-bound tail stages then run under its matrix
         // instructions instead of all four workgroups of a CU moving through the phases in lockstep (r4 A/B, five runs each:
         // 0.590-0.593 ms/step against 0.596-0.607 without; the un-staggered step is bimodal)
-        cgs_stagger<8, 127>();
+        cgs_stagger<8, 127>();      // (sweep r4: 64 x 64 cycles is too short -- the step stays bimodal --, 190 / 254 and bit 9 measure the same)
         // features.3 of image blockIdx.x (strips 2 b, 2 b + 1); its first barrier separates the zeroing above from the epilogue's tile writes.
         // The tail's weight registers are loaded AFTER it: held across the convolution they would push the kernel past 128 registers.
         conv3x3_body_pipe<FEnc1P>(PC, 2 * (int)blockIdx.x, conv_smem, PoolLds{x1, X1P::PITCH, X1P::PS});

@@ -141,11 +141,20 @@ class Hourglass128:
         return out
 
     def _pack_weights(self, transposed: bool):
-        for key, (ca, cb, co) in self.convs.items():
-            w, _ = self._wview(key)
-            _lib.call("cgs_genbf16_pack_weights", ca, cb, co, _p(w), _p(self.w16[key]), _s())
-            if transposed:
-                _lib.call("cgs_genbf16_pack_weights_t", ca + cb, co, _p(w), _p(self.w16T[key]), _s())
+        """bf16 operand copies of every 3x3 layer from the fp32 master weights: ONE launch (a device job table, built once)."""
+        key = bool(transposed)
+        tabs = self.__dict__.setdefault("_pack_tables", {})
+        if key not in tabs:
+            jobs = []
+            for k, (ca, cb, co) in self.convs.items():
+                w, _ = self._wview(k)
+                jobs.append(_lib.Pack16Job(w.data_ptr(), self.w16[k].data_ptr(), ca, cb, co, 0))
+                if transposed:
+                    jobs.append(_lib.Pack16Job(w.data_ptr(), self.w16T[k].data_ptr(), ca, cb, co, 1))
+            arr = (_lib.Pack16Job * len(jobs))(*jobs)
+            tabs[key] = (torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.dev), len(jobs))
+        tab, n = tabs[key]
+        _lib.call("cgs_genbf16_pack_batch", _p(tab), n, _s())
 
     # ---- layer wrappers ---------------------------------------------------------------------------------------------------------
     def _conv(self, key, a, b, co, act="none", pool=False, ups=2, out_f32=False, out=None, codes=None, w16=None, a_kind=None):

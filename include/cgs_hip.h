@@ -510,6 +510,14 @@ int cgs_genbf16_conv3x3_fwd_train(int32_t n, int32_t hw, int32_t ca, int32_t cb,
                                   float slope, int32_t pool, int32_t out_is_f32, const void* src_a, const void* src_b, const void* w16,
                                   const float* bias, void* out, uint8_t* codes, cgs_stream_t stream);
 int cgs_genbf16_pack_weights_t(int32_t ci_layer, int32_t co_layer, const float* w_hwio, void* w16, cgs_stream_t stream);
+/* All bf16 operand copies of a step in one launch: jobs = DEVICE array of njobs entries; transposed = 0: cgs_genbf16_pack_weights(ca, cb, co),
+ * 1: cgs_genbf16_pack_weights_t(ca + cb, co) of the layer whose HWIO weights are w.                                                       */
+typedef struct cgs_gen16_pack_job {
+    const float* w;
+    void* out;
+    int32_t ca, cb, co, transposed;
+} cgs_gen16_pack_job;
+int cgs_genbf16_pack_batch(const cgs_gen16_pack_job* jobs, int32_t njobs, cgs_stream_t stream);
 int cgs_bf16_conv3x3_bwd_weight_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb);
 int cgs_bf16_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t dy_channels, int32_t a_kind, int32_t ups,
                                 const void* src_a, const void* src_b, const void* dy, float* slab, cgs_stream_t stream);
