@@ -77,6 +77,8 @@ SIGNATURES = {
     "cgs_reduce_adam": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, vp, vp, vp, i32, f32, f32, f32, i32, i64, vp, vp]),
     "cgs_tail_dec_bwd_slabs": (i32, [i32]),
     "cgs_tail_dec_bwd": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 14 + [vp]),
+    "cgs_dec0_tail_dec_bwd": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 17 + [vp]),
+    "cgs_tail_dec_fwd_dec0": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 13 + [vp]),
     "cgs_conv3x3_bwd_weight_slabs": (i32, [C.POINTER(ConvDesc)]),
     "cgs_conv3x3_bwd_weight": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),
     "cgs_conv3x3_bwd_both_slabs": (i32, [C.POINTER(ConvDesc)]),

@@ -656,4 +656,6 @@ CGS_DG_CFG(DMaskHead, 64, 128, SRC_DH, 16, 11, 16, 2, 3, 8, 4, 3, CGS_ACT_NONE, 
 struct FEnc0U8P : FEnc0U8 { static constexpr int TPW = 4; };
 struct FEnc0MixP : FEnc0Mix { static constexpr int TPW = 4; };
 struct DEnc1P : DEnc1 { static constexpr int TPW = 2; };
-struct FEnc1P : FEnc1 { static constexpr int TPW = 2; };      // used by the fused features.3 + encoder-tail kernel (tail.hip)
+struct FEnc1P : FEnc1 { static constexpr int TPW = 2; };
+struct DDec0P : DDec0 { static constexpr int TPW = 2; };
+struct FDec0P : FDec0 { static constexpr int TPW = 2; };      // used by the fused decoder-tail forward + dec_model.0 kernel (tail.hip)      // used by the fused dec_model.0 data gradient + decoder-tail backward kernel (tail.hip)      // used by the fused features.3 + encoder-tail kernel (tail.hip)

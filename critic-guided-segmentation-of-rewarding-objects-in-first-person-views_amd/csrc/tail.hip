@@ -354,7 +354,11 @@ __device__ __forceinline__ void mask0_pack_weights(const float* __restrict__ w0,
 
 using T1F = TileP<16, 16, 16, 16, 292>;     // cat(e1, up(o2)) of the forward decoder tail (2-way conflicts on the b128 reads accepted)
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P) {
+// FUSED (round 4): one workgroup per image; after the tail stages (o1 written) the same workgroup runs dec_model.0 of ITS image
+// (conv3x3_body_pipe<FDec0P>: cat(e0, up(o1)) -> o0), every other co-resident workgroup ~4 us late (cgs_stagger).
+template <bool FUSED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P, ConvParams PC) {
+    extern __shared__ __attribute__((aligned(16))) float4 dec_conv_smem[];     // FUSED: dec_model.0's tiles + weights
     __shared__ __attribute__((aligned(16))) float t1[T1F::FLOATS];
     __shared__ __attribute__((aligned(16))) float t2[T8x24::FLOATS];
     __shared__ __attribute__((aligned(16))) float t3[T4x48::FLOATS];
@@ -365,6 +369,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (wave == 0) mask0_pack_weights(P.m0_w, P.m0_pack, lane);
         return;
     }
+    if constexpr (FUSED) cgs_stagger<8, 127>();
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15, kq = lane >> 4;
     // the first image's loads are requested before the set-up (and the next image's as soon as the tiles are filled)
@@ -474,6 +479,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
         TAIL_STAMP(6);
     }
+    if constexpr (FUSED) {          // o1 of image blockIdx.x is in memory (the loop's last barrier): dec_model.0 of that image, both strips
+        conv3x3_body_pipe<FDec0P>(PC, 2 * (int)blockIdx.x, dec_conv_smem);
+    }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
@@ -486,7 +494,28 @@ extern "C" int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, c
     TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr,
                        w_m0, m0_pack};
     const int blocks = tail_blocks(n, tail_fwd_cap());
-    hipLaunchKernelGGL(tail_dec_fwd_kernel, dim3(blocks + (m0_pack ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(tail_dec_fwd_kernel<false>, dim3(blocks + (m0_pack ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// cgs_tail_dec_fwd_pack AND dec_model.0 (cgs_conv3x3_fwd of the 16 -> 8 layer at 32x32: cat(e0 [n,32,32,8], nearest-up(o1)) -> o0
+// [n,32,32,8], linear; nets.py:516-517) in one launch, one workgroup per image (n <= 1024, else CGS_ERR_UNSUPPORTED).
+extern "C" int cgs_tail_dec_fwd_dec0(int32_t n, const cgs_tail_dec_weights* w, const float* e0, const float* e1, const float* e2, const float* e3,
+                                     const float* o4, float* o3, float* o2, float* o1, const float* w0, const float* b0, float* o0,
+                                     const float* w_m0, float* m0_pack, cgs_stream_t stream) {
+    if (n < 0 || !w || !e0 || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1 || !w0 || !b0 || !o0 || (m0_pack && !w_m0)) return CGS_ERR_BADARG;
+    if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    if (n > tail_fwd_cap()) return CGS_ERR_UNSUPPORTED;
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, n, g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr, w_m0, m0_pack};
+    ConvParams PC{};
+    PC.src_a = e0; PC.src_b = o1; PC.w = w0; PC.bias = b0; PC.out = o0; PC.n = n;
+    const size_t lds = conv_lds_bytes<FDec0P>();
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_fwd_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(conv_lds_bytes<FDec0P>()));
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(tail_dec_fwd_kernel<true>, dim3(n + (m0_pack ? 1 : 0)), dim3(256), lds, (hipStream_t)stream, P, PC);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -837,9 +866,19 @@ struct TailDecBwdLds {
     static constexpr size_t BYTES = (size_t)FLOATS * 4;
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_dec_bwd_kernel(TailDecBwdParams P) {
+// FUSED (round 4): one workgroup per image first runs dec_model.0's data gradient of ITS image (conv3x3_body_pipe<DDec0P>: the skip
+// gradient d e0 and the cell-summed d o1 go to memory as cgs_conv3x3_bwd_data writes them; the tile region of this kernel is its
+// scratch), then the tail stages read that d o1 back (same workgroup: visible after the barrier).  Every other co-resident workgroup
+// starts ~4 us late, so the latency-bound chains of one half run under the matrix instructions of the other (cgs_stagger).
+template <bool FUSED>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_dec_bwd_kernel(TailDecBwdParams P, ConvParams PC) {
     using L = TailDecBwdLds;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    if constexpr (FUSED) {
+        cgs_stagger<8, 127>();
+        conv3x3_body_pipe<DDec0P>(PC, 2 * (int)blockIdx.x, smem4);
+        __syncthreads();            // d o1 of this image is in memory; the convolution's tiles are dead
+    }
     float* sm = (float*)smem4;
     float* t1 = sm + L::T1; float* t2 = sm + L::T2; float* t3 = sm + L::T3;
     float* dy1 = sm + L::D1; float* dy2 = sm + L::D2; float* dy3 = sm + L::D3;
@@ -1023,11 +1062,35 @@ extern "C" int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const 
     if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !do1 || !dE1 || !dE2 || !dE3 || !d_o4) return CGS_ERR_BADARG;
     if (!w->w3 || !w->w2 || !w->w1) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel),
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel<false>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
     if (attr != hipSuccess) return (int)attr;
     TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
-    hipLaunchKernelGGL(tail_dec_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(tail_dec_bwd_kernel<false>, dim3(tail_blocks(n, tail_bwd_cap())), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P, ConvParams{});
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// dec_model.0's data gradient (cgs_conv3x3_bwd_data of the 16 -> 8 layer at 32x32: dy = d o0 [n,32,32,8] -> d e0 [n,32,32,8] and the
+// cell-summed d o1 [n,16,16,8]) AND cgs_tail_dec_bwd in one launch, one workgroup per image (n <= cgs_tail_dec_bwd_slabs' cap: the
+// tail's slabs are one row per image).  w0: dec_model.0's HWIO weights.  CGS_ERR_UNSUPPORTED for larger n (the caller launches the two).
+extern "C" int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0, float* dE0, const float* e1,
+                                     const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1,
+                                     float* dE1, float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1,
+                                     cgs_stream_t stream) {
+    if (n < 0 || !w || !dy_o0 || !w0 || !dE0 || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !do1 || !dE1 || !dE2 || !dE3 || !d_o4) return CGS_ERR_BADARG;
+    if (!w->w3 || !w->w2 || !w->w1) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    if (n > tail_bwd_cap()) return CGS_ERR_UNSUPPORTED;
+    static_assert(TailDecBwdLds::BYTES >= 26 * 1024, "the convolution's tiles fit the tail's LDS block");
+    if (conv_lds_bytes<DDec0P>() > TailDecBwdLds::BYTES) return CGS_ERR_UNSUPPORTED;
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel<true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, n, g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
+    ConvParams PC{};
+    PC.src_a = dy_o0; PC.w = w0; PC.out = dE0; PC.out2 = do1; PC.n = n;
+    hipLaunchKernelGGL(tail_dec_bwd_kernel<true>, dim3(n), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P, PC);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -31,6 +31,10 @@ TAIL_FWD = True
 TAIL_BWD = True
 # features.3 and the encoder tail as ONE launch, one workgroup per image (csrc/tail.hip: tail_enc_fwd_kernel<true>, round 4)
 ENC1_TAIL_FUSED = True
+# dec_model.0's data gradient and the decoder tail's backward as ONE launch, one workgroup per image (tail_dec_bwd_kernel<true>, round 4)
+DEC0_TAIL_BWD_FUSED = True
+# the decoder tail's forward and dec_model.0 as ONE launch, one workgroup per image (tail_dec_fwd_kernel<true>, round 4)
+DEC_TAIL_DEC0_FUSED = True
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
@@ -472,11 +476,21 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             m0pack = o.get("m0pack")
             if m0pack is None:
                 m0pack = o["m0pack"] = torch.empty(40 * 64, device=dev, dtype=torch.float32)
-        _lib.call("cgs_tail_dec_fwd_pack", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
-                  _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack), _stream())
-        prev = o["o1"]
+        dec0_done = False
+        if DEC_TAIL_DEC0_FUSED and n <= 1024:
+            if o.get("o0") is None:
+                o["o0"] = torch.empty((n, 32, 32, 8), device=dev, dtype=torch.float32)
+            _lib.call("cgs_tail_dec_fwd_dec0", n, C.byref(tw), _p(embeds[0]), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
+                      _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("dec_model.0.weight")),
+                      C.c_void_p(fp + 4 * lay.off("dec_model.0.bias")), _p(o["o0"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack),
+                      _stream())
+            dec0_done = True
+        else:
+            _lib.call("cgs_tail_dec_fwd_pack", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
+                      _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack), _stream())
+        prev = o["o0"] if dec0_done else o["o1"]
     for name, sa, (key, hw, ca, cb, co, ups, act, pool, _s) in zip(names, srcs_a, DEC_LAYERS):
-        if TAIL_FWD and name in ("o3", "o2", "o1"):
+        if TAIL_FWD and (name in ("o3", "o2", "o1") or (name == "o0" and dec0_done)):
             continue
         if name == "hm" and not keep_hm and MASK_INFER_FUSED:
             if o.get("Z") is None:
@@ -546,6 +560,7 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
     dy = dzpre
     fused_head_do0 = None
     head_done = False    # masker.2 AND masker.0 fully handled by the mask-head kernel
+    fuse_dec0 = None
     u8_or_f32_needs_da = False   # the image never needs a gradient on this path
     for li in (5, 4, 3, 2, 1, 0):
         if li == 4 and head_done:
@@ -559,9 +574,15 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
                 d_embeds[ei] = buf(f"dE{ei}", shp)
             do4 = buf("do4", (n, 32))
             tw = tail_dec_weights(flat, lay)
-            _lib.call("cgs_tail_dec_bwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(saved["o4"]),
-                      _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
-                      _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
+            if fuse_dec0 is not None:      # dec_model.0's data gradient rides in front, one workgroup per image
+                dy_o0, w0ptr, de0 = fuse_dec0
+                _lib.call("cgs_dec0_tail_dec_bwd", n, C.byref(tw), _p(dy_o0), w0ptr, _p(de0), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]),
+                          _p(saved["o4"]), _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
+                          _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
+            else:
+                _lib.call("cgs_tail_dec_bwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(saved["o4"]),
+                          _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
+                          _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
             for k, c in cnts.items():
                 plan.add(sl[k], nsl, c, lay.off(f"dec_model.{k}.weight"))
             dy = do4
@@ -639,7 +660,10 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
             de = buf(f"dE{ei}", (n, hw, hw, ca))
             shape_b = (n, 32) if ups == 4 else (n, hw // 2, hw // 2, cb)
             db = buf(f"do{ei + 1}", shape_b)
-            _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, None, _lib.ACT_NONE, None, 0, _p(de), _p(db), _stream())
+            if li == 3 and TAIL_BWD and DEC0_TAIL_BWD_FUSED and n <= lib.cgs_tail_dec_bwd_slabs(n) and lib.cgs_tail_dec_bwd_slabs(n) == n:
+                fuse_dec0 = (dy, wptr, de)      # launched together with the decoder tail's backward below
+            else:
+                _lib.call("cgs_conv3x3_bwd_data", C.byref(d), _p(dy), None, wptr, None, _lib.ACT_NONE, None, 0, _p(de), _p(db), _stream())
             d_embeds[ei] = de
             dy = db
     # bottleneck 1x1 conv: dy = d o4 [n,32]

@@ -246,6 +246,17 @@ int cgs_tail_dec_bwd_slabs(int32_t n);
 int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
                      float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, cgs_stream_t stream);
+/* dec_model.0's data gradient (cgs_conv3x3_bwd_data of the 16 -> 8 layer at 32x32: dy_o0 [n,32,32,8] -> dE0 [n,32,32,8] = the skip
+ * gradient at e0, do1 [n,16,16,8] = the cell-summed gradient at o1) and cgs_tail_dec_bwd (which consumes that do1) in ONE launch, one
+ * workgroup per image (round 4).  n <= cgs_tail_dec_bwd_slabs(n) (one slab row per image), else CGS_ERR_UNSUPPORTED.               */
+int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0_hwio, float* dE0, const float* e1,
+                          const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1, float* dE1,
+                          float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, cgs_stream_t stream);
+/* cgs_tail_dec_fwd_pack and dec_model.0's forward (cgs_conv3x3_fwd of the 16 -> 8 layer at 32x32: cat(e0, nearest-up(o1)) -> o0, linear;
+ * nets.py:516-517) in ONE launch, one workgroup per image (round 4; n <= 1024, else CGS_ERR_UNSUPPORTED).                              */
+int cgs_tail_dec_fwd_dec0(int32_t n, const cgs_tail_dec_weights* w, const float* e0, const float* e1, const float* e2, const float* e3,
+                          const float* o4, float* o3, float* o2, float* o1, const float* w0_hwio, const float* b0, float* o0,
+                          const float* w_m0, float* m0_pack, cgs_stream_t stream);
 
 /* ---- convolution backward, weights --------------------------------------------------
  * Replaces convolution_backward(weight, bias).  Each workgroup writes one partial "slab"
