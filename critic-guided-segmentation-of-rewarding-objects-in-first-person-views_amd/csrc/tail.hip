@@ -85,8 +85,11 @@ using X2P = TileP<8, 8, 8, 8, 84>;        // dropout(e2)
 // e1 + argmax nibbles go to memory for the backward pass and the decoder as before) with the pooled epilogue also writing the x1 tile,
 // then the tail stages: no e1 round trip, no launch boundary, and the tail's prologue (kernel arguments, Dropout counters, LDS zeroing,
 // cold instruction fetch: 38 % of the stand-alone kernel's life by the stamps) runs while the convolution's loads are in flight.
-template <bool FUSED>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P, ConvParams PC) {
+// ENC0 (with FUSED): 1 / 2 = features.0 of the image as well (uint8 frames / the virtual replaced | injected mixes: four 16-row strips,
+// conv3x3_body_pipe<FEnc0U8P / FEnc0MixP>; e0 + am0 to memory as before, features.3 reads that e0 back): the whole critic forward of an
+// image in one workgroup.
+template <bool FUSED, int ENC0 = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P, ConvParams PC, ConvParams PC0) {
     extern __shared__ __attribute__((aligned(16))) float4 conv_smem[];       // FUSED: the convolution's tiles + weights
     __shared__ __attribute__((aligned(16))) float x1[X1P::FLOATS];
     __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
@@ -112,6 +115,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // instructions instead of all four workgroups of a CU moving through the phases in lockstep (r4 A/B, five runs each:
         // 0.590-0.593 ms/step against 0.596-0.607 without; the un-staggered step is bimodal)
         cgs_stagger<8, 127>();      // (sweep r4: 64 x 64 cycles is too short -- the step stays bimodal --, 190 / 254 and bit 9 measure the same)
+        if constexpr (ENC0 == 1) { conv3x3_body_pipe<FEnc0U8P>(PC0, 4 * (int)blockIdx.x, conv_smem); __syncthreads(); }
+        if constexpr (ENC0 == 2) { conv3x3_body_pipe<FEnc0MixP>(PC0, 4 * (int)blockIdx.x, conv_smem); __syncthreads(); }
         // features.3 of image blockIdx.x (strips 2 b, 2 b + 1); its first barrier separates the zeroing above from the epilogue's tile writes.
         // The tail's weight registers are loaded AFTER it: held across the convolution they would push the kernel past 128 registers.
         conv3x3_body_pipe<FEnc1P>(PC, 2 * (int)blockIdx.x, conv_smem, PoolLds{x1, X1P::PITCH, X1P::PS});
@@ -280,7 +285,7 @@ extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const 
     if (n == 0) return CGS_OK;
     TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
     const int blocks = P.nblocks;
-    hipLaunchKernelGGL(tail_enc_fwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
+    hipLaunchKernelGGL((tail_enc_fwd_kernel<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, ConvParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -298,7 +303,38 @@ extern "C" int cgs_enc1_tail_fwd(int32_t n, const cgs_tail_enc_weights* w, const
     ConvParams PC{};
     PC.src_a = e0; PC.w = w3; PC.bias = b3; PC.out = e1; PC.amask_out = am1; PC.n = n;
     const size_t lds = conv_lds_bytes<FEnc1P>();
-    hipLaunchKernelGGL(tail_enc_fwd_kernel<true>, dim3(n), dim3(256), lds, (hipStream_t)stream, P, PC);
+    hipLaunchKernelGGL((tail_enc_fwd_kernel<true, 0>), dim3(n), dim3(256), lds, (hipStream_t)stream, P, PC, ConvParams{});
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// The WHOLE critic forward of an image in one workgroup: features.0 (cgs_conv3x3_fwd of the 3 -> 8 layer at 64x64 on uint8 frames, or -- x_is_mix --
+// on the virtual replaced | injected mixes of a cgs_mix_src) -> e0 + am0, then everything cgs_enc1_tail_fwd does.  w0 / b0: features.0's
+// HWIO weights and bias.
+extern "C" int cgs_critic_fwd_fused(int32_t n, const cgs_tail_enc_weights* w, const void* x, int32_t x_is_mix, const float* w0, const float* b0,
+                                    float* e0, uint32_t* am0, const float* w3, const float* b3, float* e1, uint32_t* am1, float* e2, uint32_t* am2,
+                                    float* e3, uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_dropout drop_e2,
+                                    cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream) {
+    if (n < 0 || !w || !x || !w0 || !b0 || !e0 || !am0 || !w3 || !b3 || !e1 || !am1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->b6 || !w->w10 || !w->b10 || !w->w14 || !w->b14 || !w->wl1 || !w->bl1 || !w->wl2 || !w->bl2) return CGS_ERR_BADARG;
+    if (o4 && (!w->wpw || !w->bpw)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, n, g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
+    ConvParams PC{}, PC0{};
+    PC.src_a = e0; PC.w = w3; PC.bias = b3; PC.out = e1; PC.amask_out = am1; PC.n = n;
+    PC0.w = w0; PC0.bias = b0; PC0.out = e0; PC0.amask_out = am0; PC0.n = n;
+    size_t lds = conv_lds_bytes<FEnc1P>();
+    if (x_is_mix) {
+        const cgs_mix_src* m = (const cgs_mix_src*)x;        // HOST struct
+        if (!m->a || !m->b || !m->z || m->n_a <= 0 || n > 2 * m->n_a) return CGS_ERR_BADARG;
+        PC0.mix_a = m->a; PC0.mix_b = m->b; PC0.mix_z = m->z; PC0.mix_n_a = m->n_a;
+        if (conv_lds_bytes<FEnc0MixP>() > lds) lds = conv_lds_bytes<FEnc0MixP>();
+        hipLaunchKernelGGL((tail_enc_fwd_kernel<true, 2>), dim3(n), dim3(256), lds, (hipStream_t)stream, P, PC, PC0);
+    } else {
+        PC0.src_a = x;
+        if (conv_lds_bytes<FEnc0U8P>() > lds) lds = conv_lds_bytes<FEnc0U8P>();
+        hipLaunchKernelGGL((tail_enc_fwd_kernel<true, 1>), dim3(n), dim3(256), lds, (hipStream_t)stream, P, PC, PC0);
+    }
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -31,6 +31,8 @@ TAIL_FWD = True
 TAIL_BWD = True
 # features.3 and the encoder tail as ONE launch, one workgroup per image (csrc/tail.hip: tail_enc_fwd_kernel<true>, round 4)
 ENC1_TAIL_FUSED = True
+# ... and features.0 in front of it: the whole critic forward of an image in one workgroup (uint8 frames and virtual mixes)
+CRITIC_FWD_FUSED = True
 # dec_model.0's data gradient and the decoder tail's backward as ONE launch, one workgroup per image (tail_dec_bwd_kernel<true>, round 4)
 DEC0_TAIL_BWD_FUSED = True
 # the decoder tail's forward and dec_model.0 as ONE launch, one workgroup per image (tail_dec_fwd_kernel<true>, round 4)
@@ -217,6 +219,7 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     dev = x.device
     o = out if out is not None else {}
     src = x
+    whole = TAIL_FWD and ENC1_TAIL_FUSED and CRITIC_FWD_FUSED and (mixin or u8)      # the whole forward in one launch (not for fp32 frames)
     for i, (key, hw, ca, cb, co, ups, act, pool, site) in enumerate(ENC_LAYERS):
         e = o.get(f"e{i}")
         if e is None:
@@ -224,9 +227,9 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
         am = o.get(f"am{i}")
         if am is None:
             am = o[f"am{i}"] = torch.empty((n, hw // 2, hw // 2, co // 8), device=dev, dtype=torch.int32)
-        if TAIL_FWD and (i >= 2 or (i == 1 and ENC1_TAIL_FUSED)):
+        if TAIL_FWD and (i >= 2 or (i == 1 and ENC1_TAIL_FUSED) or (i == 0 and whole)):
             src = e
-            continue        # features.6 / features.10 / head (and, fused, features.3): one tail kernel below
+            continue        # features.6 / features.10 / head (and, fused, features.3 / features.0): one tail kernel below
         d = conv_desc(n, hw, ca, cb, co, u8 and i == 0, ups, act, pool, drop.desc(DROP_SITE_E2, site is not None, 128))
         if mixin and i == 0:
             d.src_a = _lib.SRC_MIX
@@ -240,6 +243,14 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     if TAIL_FWD:
         pwp = (pw[0], pw[1]) if pw else None
         tw = tail_enc_weights(flat, lay, (pwp[0].value, pwp[1].value) if pwp else None)
+        if whole:
+            k0, k3 = ENC_LAYERS[0][0], ENC_LAYERS[1][0]
+            wp_ = lambda k: C.c_void_p(flat.data_ptr() + 4 * lay.off(k))
+            _lib.call("cgs_critic_fwd_fused", n, C.byref(tw), x.ptr() if mixin else _p(x), int(mixin), wp_(k0 + ".weight"), wp_(k0 + ".bias"),
+                      _p(o["e0"]), _p(o["am0"]), wp_(k3 + ".weight"), wp_(k3 + ".bias"), _p(o["e1"]), _p(o["am1"]), _p(o["e2"]), _p(o["am2"]),
+                      _p(o["e3"]), _p(o["am3"]), _p(o["e4"]), _p(o["h1"]), _p(o["pred"]), _p(pw[2]) if pw else None,
+                      drop.desc(DROP_SITE_E2, True, 128), drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8), _stream())
+            return o
         if ENC1_TAIL_FUSED:
             k3 = ENC_LAYERS[1][0]
             _lib.call("cgs_enc1_tail_fwd", n, C.byref(tw), _p(o["e0"]), C.c_void_p(flat.data_ptr() + 4 * lay.off(k3 + ".weight")),

@@ -193,6 +193,12 @@ int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, 
 int cgs_enc1_tail_fwd(int32_t n, const cgs_tail_enc_weights* w, const float* e0, const float* w3, const float* b3, float* e1,
                       uint32_t* am1, float* e2, uint32_t* am2, float* e3, uint32_t* am3, float* e4, float* h1, float* pred, float* o4,
                       cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1, cgs_stream_t stream);
+/* The whole critic forward (nets.py:170-194) of an image in one workgroup (round 4): features.0 on uint8 frames x [n,64,64,3] or -- x_is_mix --
+ * on the virtual mixes (x = the cgs_mix_src descriptor, as cgs_conv3x3_fwd with CGS_SRC_MIX) -> e0 [n,32,32,8] + am0, then cgs_enc1_tail_fwd.           */
+int cgs_critic_fwd_fused(int32_t n, const cgs_tail_enc_weights* w, const void* x, int32_t x_is_mix, const float* w0, const float* b0,
+                         float* e0, uint32_t* am0, const float* w3, const float* b3, float* e1, uint32_t* am1, float* e2, uint32_t* am2,
+                         float* e3, uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_dropout drop_e2, cgs_dropout drop_e3,
+                         cgs_dropout drop_h1, cgs_stream_t stream);
 int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
 /* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
