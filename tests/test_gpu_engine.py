@@ -297,3 +297,40 @@ def test_ragged_batch_sizes_vs_oracle(g1, n):
     g1c = e1.lc.unflatten(e1.gc)
     for k, v in r1["grads"].items():
         rel_close(g1c[k].cpu().numpy(), v.numpy(), f"phase-1 grad {k} (n={n})")
+
+
+def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, monkeypatch):
+    """Round 4: the whole critic forward of an image in one workgroup (cgs_critic_fwd_fused), decoder tail + dec_model.0
+    (cgs_tail_dec_fwd_dec0) and dec_model.0's data gradient + decoder tail backward (cgs_dec0_tail_dec_bwd) run the same kernel bodies in
+    the same order as the separate launches (cgs_conv3x3_fwd x2 + cgs_tail_enc_fwd, cgs_tail_dec_fwd_pack + cgs_conv3x3_fwd,
+    cgs_conv3x3_bwd_data + cgs_tail_dec_bwd): two dropout-0.3 training steps and an inference give bitwise equal losses, parameters,
+    Adam moments, critic values and masks with the fusions switched off one by one and all together (this also keeps the un-fused entry
+    points exercised)."""
+    from cgs_amd import engine, hourglass as hg
+    pc, pm = g1
+    dev = torch.device("cuda:0")
+    rs = np.random.RandomState(21)
+    n = 37
+    A = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    B = torch.from_numpy(rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)).to(dev)
+    Y = torch.from_numpy(rs.rand(n).astype(np.float32)).to(dev)
+
+    def run():
+        e = engine.HourglassEngine(n, device=dev, dropout=0.3, use_graph=False)
+        e.load_state(pc, pm)
+        for _ in range(2):
+            e.phase2_step(A, B, Y)
+        pred, Z = e.infer(A)
+        torch.cuda.synchronize()
+        return [t.clone() for t in (e.losses, e.flat, e.m, e.v, pred, Z)]
+
+    base = run()
+    flags = ("CRITIC_FWD_FUSED", "ENC1_TAIL_FUSED", "DEC_TAIL_DEC0_FUSED", "DEC0_TAIL_BWD_FUSED")
+    for off in [(f,) for f in flags] + [flags]:
+        for f in off:
+            monkeypatch.setattr(hg, f, False)
+        got = run()
+        for f in off:
+            monkeypatch.setattr(hg, f, True)
+        for a, b, what in zip(got, base, ("losses", "parameters", "m", "v", "pred", "Z")):
+            assert torch.equal(a, b), f"{what} differ with {off} switched off"
