@@ -24,6 +24,23 @@ namespace {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4h_t __attribute__((ext_vector_type(4)));
+typedef short bshort8_t __attribute__((ext_vector_type(8)));
+typedef short bshort4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bbf16x8_t __attribute__((ext_vector_type(8)));
+
+// 16-bit element of the tile / operands: IEEE half (config 4) or bfloat16 (config 5: the 128x128 variant's features.0)
+struct ElF16 {
+    using V8 = half8_t; using V4 = half4h_t; using S = _Float16;
+    __device__ static __forceinline__ S cvt(float f) { return (_Float16)f; }
+    __device__ static __forceinline__ frag4 mfma(V8 a, V8 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+struct ElBF16 {
+    using V8 = bshort8_t; using V4 = bshort4_t; using S = short;
+    __device__ static __forceinline__ S cvt(float f) { return (short)__builtin_bit_cast(unsigned short, (__bf16)f); }
+    __device__ static __forceinline__ frag4 mfma(V8 a, V8 b, frag4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bbf16x8_t, a), __builtin_bit_cast(bbf16x8_t, b), c, 0, 0, 0);
+    }
+};
 
 struct HConvParams {
     const void* a;          // uint8 frames [n,HW,HW,3] (U8) or fp16 NHWC [n,HW,HW,CA]
@@ -33,18 +50,24 @@ struct HConvParams {
     void* out;              // pooled [n,HW/2,HW/2,8] or [n,HW,HW,8]; fp16 or fp32
     int n;
     int nstrips;            // n * (HW / TH): the workgroups are persistent over them (weights -> registers once)
+    int a_f32;              // CA == 4: source A is fp32 NHWC [n,HW,HW,3] (the replaced / injected mixes of config 5) instead of uint8
+    uint8_t* codes;         // pooled layers, training: argmax position 0..3 of every pooled element (4: value <= 0), or NULL
 };
 
 // HW: map size; CA: channels of source A in the LDS pixel (4 = uint8 rgb0, 8 = fp16); CB: channels of the upsampled fp32 source (0 / 8);
 // TH: rows per workgroup; POOL: ReLU + MaxPool2d(2) epilogue (else plain bias); OUT_F32: fp32 output
-template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32>
+template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32, class EL = ElF16>
 __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
+    using half8_t = typename EL::V8;
+    using half4h_t = typename EL::V4;
+    using h16_t = typename EL::S;             // (the names below say "half": either 16-bit type)
+#define HCVT(x) EL::cvt(x)
     constexpr int CIN = CA + CB, TPM = 32 / CIN, NM = (9 + TPM - 1) / TPM;      // taps per instruction, instructions per tile
     constexpr int PW = HW + 2, PH = TH + 2, STRIPS = HW / TH, CA_REAL = CA == 4 ? 3 : CA;
     constexpr int NT = TH * HW / 16;                                            // 16-pixel tiles per workgroup
     static_assert(CIN == 4 || CIN == 8 || CIN == 16, "pixel = 8 / 16 / 32 bytes");
     extern __shared__ __attribute__((aligned(16))) float4 hsm[];
-    _Float16* const tile = (_Float16*)hsm;                                     // [PH][PW][CIN]
+    h16_t* const tile = (h16_t*)hsm;                                     // [PH][PW][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
 
     // ---- weights -> registers: A operand of instruction g, lane (m = l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN ----
@@ -56,7 +79,7 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
             const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
             const int cr = c < CA ? c : CA_REAL + (c - CA);                      // channel of the layer's HWIO weights
             const bool ok = tap < 9 && l15 < 8 && (c < CA ? c < CA_REAL : true);
-            wa[g][j] = (_Float16)(ok ? P.w[((tap < 9 ? tap : 0) * (CA_REAL + CB) + (ok ? cr : 0)) * 8 + (l15 & 7)] : 0.f);
+            wa[g][j] = HCVT(ok ? P.w[((tap < 9 ? tap : 0) * (CA_REAL + CB) + (ok ? cr : 0)) * 8 + (l15 & 7)] : 0.f);
         }
     float br[4];
 #pragma unroll
@@ -77,14 +100,25 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
             const int g = e % GW, r = e / GW, y = row0 + r - 1;
             const bool in = y >= 0 && y < HW;
             const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+            half4h_t* dst = (half4h_t*)(tile + ((size_t)r * PW + 1 + 4 * g) * 4);
+            if (P.a_f32) {              // (uniform branch) fp32 NHWC frames: 4 pixels = 12 floats = 3 float4
+                const float4* sf = (const float4*)P.a;
+                const size_t fi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+                float4 f0 = sf[fi], f1 = sf[fi + 1], f2 = sf[fi + 2];
+                if (!in) { f0 = f4zero(); f1 = f4zero(); f2 = f4zero(); }
+                dst[0] = half4h_t{HCVT(f0.x), HCVT(f0.y), HCVT(f0.z), HCVT(0.f)};
+                dst[1] = half4h_t{HCVT(f0.w), HCVT(f1.x), HCVT(f1.y), HCVT(0.f)};
+                dst[2] = half4h_t{HCVT(f1.z), HCVT(f1.w), HCVT(f2.x), HCVT(0.f)};
+                dst[3] = half4h_t{HCVT(f2.y), HCVT(f2.z), HCVT(f2.w), HCVT(0.f)};
+                continue;
+            }
             uint32_t d0 = src[gi], d1 = src[gi + 1], d2 = src[gi + 2];
             if (!in) { d0 = 0; d1 = 0; d2 = 0; }
             const float s = 1.f / 255.f;
-            half4h_t p0 = {(_Float16)((d0 & 255) * s), (_Float16)(((d0 >> 8) & 255) * s), (_Float16)(((d0 >> 16) & 255) * s), (_Float16)0.f};
-            half4h_t p1 = {(_Float16)((d0 >> 24) * s), (_Float16)((d1 & 255) * s), (_Float16)(((d1 >> 8) & 255) * s), (_Float16)0.f};
-            half4h_t p2 = {(_Float16)(((d1 >> 16) & 255) * s), (_Float16)((d1 >> 24) * s), (_Float16)((d2 & 255) * s), (_Float16)0.f};
-            half4h_t p3 = {(_Float16)(((d2 >> 8) & 255) * s), (_Float16)(((d2 >> 16) & 255) * s), (_Float16)((d2 >> 24) * s), (_Float16)0.f};
-            half4h_t* dst = (half4h_t*)(tile + ((size_t)r * PW + 1 + 4 * g) * 4);
+            half4h_t p0 = {HCVT((d0 & 255) * s), HCVT(((d0 >> 8) & 255) * s), HCVT(((d0 >> 16) & 255) * s), HCVT(0.f)};
+            half4h_t p1 = {HCVT((d0 >> 24) * s), HCVT((d1 & 255) * s), HCVT(((d1 >> 8) & 255) * s), HCVT(0.f)};
+            half4h_t p2 = {HCVT(((d1 >> 16) & 255) * s), HCVT((d1 >> 24) * s), HCVT((d2 & 255) * s), HCVT(0.f)};
+            half4h_t p3 = {HCVT(((d2 >> 8) & 255) * s), HCVT(((d2 >> 16) & 255) * s), HCVT((d2 >> 24) * s), HCVT(0.f)};
             dst[0] = p0; dst[1] = p1; dst[2] = p2; dst[3] = p3;
         }
     } else {
@@ -100,7 +134,7 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
                 const size_t pb = in ? (((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1)) * 2 : 0;
                 float4 u0 = sb[pb], u1 = sb[pb + 1];
                 if (!in) { u0 = f4zero(); u1 = f4zero(); }
-                const half8_t hb = {(_Float16)u0.x, (_Float16)u0.y, (_Float16)u0.z, (_Float16)u0.w, (_Float16)u1.x, (_Float16)u1.y, (_Float16)u1.z, (_Float16)u1.w};
+                const half8_t hb = {HCVT(u0.x), HCVT(u0.y), HCVT(u0.z), HCVT(u0.w), HCVT(u1.x), HCVT(u1.y), HCVT(u1.z), HCVT(u1.w)};
                 *(half8_t*)(tile + ((size_t)r * PW + 1 + x) * CIN + CA) = hb;
             }
         }
@@ -119,7 +153,7 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
             constexpr int TPR = HW / 16;
             y = t / TPR; x = 16 * (t % TPR) + l15;
         }
-        const _Float16* pix = tile + ((size_t)y * PW + x) * CIN;                // tap (0,0) of the lane's 3x3 window
+        const h16_t* pix = tile + ((size_t)y * PW + x) * CIN;                // tap (0,0) of the lane's 3x3 window
         frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
@@ -140,8 +174,8 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
             }
             // pooled layers: D[pixel = 4 kq + r][oc = l15] -- a lane's four accumulators are ONE pool window (in-lane maximum);
             // plain layers: D[oc = 4 kq + r][pixel = l15] -- four consecutive channels of the lane's pixel (one vector store)
-            if constexpr (POOL) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, wa[g], acc, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g], b, acc, 0, 0, 0);
+            if constexpr (POOL) acc = EL::mfma(b, wa[g], acc);
+            else acc = EL::mfma(wa[g], b, acc);
         }
         if constexpr (POOL) {
             // ReLU(max(window) + bias) == max over the window of ReLU(. + bias); lane (kq, l15 < 8): window kq of the tile, channel l15
@@ -151,26 +185,35 @@ __global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
             if (l15 < 8) {
                 const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * 8) + l15;
                 if constexpr (OUT_F32) ((float*)P.out)[o] = m;
-                else ((_Float16*)P.out)[o] = (_Float16)m;
+                else ((h16_t*)P.out)[o] = HCVT(m);
+                if (P.codes) {          // first maximum wins (max_pool2d); 4 = the pooled value is not positive: no gradient
+                    uint32_t code = 0;
+                    float mm = acc[0] + bl;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) if (acc[j] + bl > mm) { mm = acc[j] + bl; code = j; }
+                    P.codes[o] = (uint8_t)(m > 0.f ? code : 4u);
+                }
             }
         } else if (kq < 2) {
             const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * 8) + 4 * kq;
             if constexpr (OUT_F32) *(float4*)((float*)P.out + o) = make_float4(acc[0] + br[0], acc[1] + br[1], acc[2] + br[2], acc[3] + br[3]);
-            else *(half4h_t*)((_Float16*)P.out + o) = half4h_t{(_Float16)(acc[0] + br[0]), (_Float16)(acc[1] + br[1]), (_Float16)(acc[2] + br[2]), (_Float16)(acc[3] + br[3])};
+            else *(half4h_t*)((h16_t*)P.out + o) = half4h_t{HCVT(acc[0] + br[0]), HCVT(acc[1] + br[1]), HCVT(acc[2] + br[2]), HCVT(acc[3] + br[3])};
         }
     }
     __syncthreads();            // every wave is done with the tile before the next strip is staged
     }
 }
 
-template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32>
+#undef HCVT
+
+template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32, class EL = ElF16>
 int hconv_launch(const HConvParams& P, hipStream_t st) {
     if (P.n <= 0) return CGS_OK;
     const size_t lds = (size_t)(TH + 2) * (HW + 2) * (CA + CB) * 2;
     HConvParams Q = P;
     Q.nstrips = P.n * (HW / TH);
     const int blocks = Q.nstrips < HCONV_BLOCKS ? Q.nstrips : HCONV_BLOCKS;      // persistent workgroups
-    hipLaunchKernelGGL((hconv_kernel<HW, CA, CB, TH, POOL, OUT_F32>), dim3(blocks), dim3(256), lds, st, Q);
+    hipLaunchKernelGGL((hconv_kernel<HW, CA, CB, TH, POOL, OUT_F32, EL>), dim3(blocks), dim3(256), lds, st, Q);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -179,16 +222,25 @@ int hconv_launch(const HConvParams& P, hipStream_t st) {
 
 extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
     if (n < 0 || !x_u8 || !w_hwio || !bias || !e0_f16) return CGS_ERR_BADARG;
-    return hconv_launch<64, 4, 0, HCONV_ENC0_TH, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0}, (hipStream_t)stream);
+    return hconv_launch<64, 4, 0, HCONV_ENC0_TH, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0, 0, nullptr}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream) {
     if (n < 0 || !e0_f16 || !w_hwio || !bias || !e1_f32) return CGS_ERR_BADARG;
-    return hconv_launch<32, 8, 0, 32, true, true>(HConvParams{e0_f16, nullptr, w_hwio, bias, e1_f32, n, 0}, (hipStream_t)stream);
+    return hconv_launch<32, 8, 0, 32, true, true>(HConvParams{e0_f16, nullptr, w_hwio, bias, e1_f32, n, 0, 0, nullptr}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f32, const float* w_hwio, const float* bias, void* o0_f16,
                                 cgs_stream_t stream) {
     if (n < 0 || !e0_f16 || !o1_f32 || !w_hwio || !bias || !o0_f16) return CGS_ERR_BADARG;
-    return hconv_launch<32, 8, 8, 32, false, false>(HConvParams{e0_f16, o1_f32, w_hwio, bias, o0_f16, n, 0}, (hipStream_t)stream);
+    return hconv_launch<32, 8, 8, 32, false, false>(HConvParams{e0_f16, o1_f32, w_hwio, bias, o0_f16, n, 0, 0, nullptr}, (hipStream_t)stream);
+}
+
+// config 5 (the build-defined 128x128 variant, hourglass128.py): features.0 (3 -> 8 at 128x128 + ReLU + MaxPool2d(2)) with bf16 output
+// [n,64,64,8] on v_mfma_f32_16x16x32_bf16; x: uint8 frames (x_is_f32 = 0) or fp32 frames [n,128,128,3] (the replaced / injected mixes);
+// codes (optional, training): the argmax bytes cgs_bf16_pool_expand consumes.
+extern "C" int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16,
+                                 uint8_t* codes, cgs_stream_t stream) {
+    if (n < 0 || !x || !w_hwio || !bias || !e0_bf16) return CGS_ERR_BADARG;
+    return hconv_launch<128, 4, 0, 16, true, false, ElBF16>(HConvParams{x, nullptr, w_hwio, bias, e0_bf16, n, 0, x_is_f32 ? 1 : 0, codes}, (hipStream_t)stream);
 }

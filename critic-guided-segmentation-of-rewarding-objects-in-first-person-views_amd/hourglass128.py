@@ -30,6 +30,7 @@ from . import hourglass as hg
 from . import parallel
 from .generic import _ACT, _p, _s
 
+ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False: the generic bf16 convolution; r4 A/B)
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
 ENC_HW = (128, 64, 32, 16, 8)            # pre-pool map size of the five encoder stages
 GEMM_KEYS = ("features.17", "crit.1", "crit.4")
@@ -165,6 +166,12 @@ class Hourglass128:
             out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
         if a_kind is None:
             a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+        if ENC0_DIRECT and key == "features.0" and w16 is None and (ca, cb, co, hw) == (3, 0, 8, 128) and pool and act == "relu" \
+                and not out_f32 and a_kind in (1, 2):
+            # chfak 1: the whole-strip kernel of the fp16 inference path in bfloat16 (csrc/hconv.hip), weights from the fp32 master copy
+            w, bias = self._wview(key)
+            _lib.call("cgs_bf16_enc0_fwd", n, _p(a), int(a_kind == 2), _p(w), _p(bias), _p(out), _p(codes), _s())
+            return out
         bias = self._wview(key)[1] if w16 is None else self._zero_bias(co)
         _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, ca, cb, co, a_kind, ups, _ACT[act], 0.01, int(pool), int(out_f32), _p(a), _p(b),
                   _p(self.w16[key] if w16 is None else w16), _p(bias), _p(out), _p(codes), _s())

@@ -161,6 +161,11 @@ int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f32, const f
                      cgs_stream_t stream);
 int cgs_mask_infer_fwd_f16o(int32_t n, int32_t src_a, const void* x, const void* o0_f16, const float* w_m0_hwio, const float* b_m0,
                             const float* w_m2_hwio, const float* b_m2, float* z, cgs_stream_t stream);
+/* config 5 (build-defined 128x128 variant, hourglass128.py; chfak 1): features.0 on the same kernel in bfloat16 -- x: uint8 frames
+ * (x_is_f32 = 0) or fp32 frames [n,128,128,3] (the replaced / injected mixes, main.py:642-670) -> e0 bf16 [n,64,64,8]; codes (optional):
+ * the MaxPool2d argmax bytes [n,64,64,8] of the training forward (cgs_bf16_pool_expand reads them).                                    */
+int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16, uint8_t* codes,
+                      cgs_stream_t stream);
 
 /* ---- the 16x16-and-smaller layers, image by image inside one workgroup ("tail" kernels, csrc/tail.hip) ------------
  * Replace, for one critic pass / the decoder, the per-layer launches of features.6, features.10 (nets.py:176-183), the

@@ -175,6 +175,48 @@ def test_bf16_forward_codes_pool_expand_cat_split_lrelu_convert():
     assert torch.equal(dst.cpu(), ref4.to(torch.bfloat16)) and torch.equal(back.cpu(), ref4.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("src", ["u8", "f32"])
+def test_bf16_enc0_whole_strip_kernel_vs_float64_conv(src):
+    """cgs_bf16_enc0_fwd (features.0 of config 5 on the whole-strip kernel, csrc/hconv.hip) vs the float64 convolution of the same
+    bf16-rounded operands: pooled output within one bf16 rounding, argmax bytes == max_pool2d's indices; n = 9 is ragged against
+    the persistent grid's strip loop."""
+    from cgs_amd import _lib
+    _lib.load()
+    n, hw = 9, 128
+    g = torch.Generator().manual_seed(128)
+    if src == "u8":
+        x = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, generator=g)
+        x[0, :16, :16] = 77               # a flat patch: exact ties, the first maximum wins
+        xr = bf(x.double() / 255.0)
+    else:
+        x = torch.rand((n, hw, hw, 3), generator=g)
+        x[0, :16, :16] = 0.25
+        xr = bf(x.double())
+    w = torch.randn((8, 3, 3, 3), generator=g) * 0.3
+    b = torch.randn(8, generator=g) * 0.1
+    b[0] = 0.5                            # a channel whose flat patch is positive, so the tie rule is exercised
+    w_g, x_g, b_g = w.permute(2, 3, 1, 0).contiguous().cuda(), x.cuda(), b.cuda()
+    out = torch.full((n, hw // 2, hw // 2, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    codes = torch.full((n, hw // 2, hw // 2, 8), 99, device="cuda", dtype=torch.uint8)
+    _lib.call("cgs_bf16_enc0_fwd", n, P(x_g), int(src == "f32"), P(w_g), P(b_g), P(out), P(codes), S())
+    torch.cuda.synchronize()
+    pre = F.relu(F.conv2d(xr.permute(0, 3, 1, 2), bf(w), b.double(), padding=1))
+    pooled, idx = F.max_pool2d(pre, 2, return_indices=True)
+    pooled = pooled.permute(0, 2, 3, 1)
+    ref_code = (((idx // hw) % 2) * 2 + (idx % hw) % 2).permute(0, 2, 3, 1)
+    ref_code = torch.where(pooled > 0, ref_code, torch.full_like(ref_code, 4))
+    got_code = codes.cpu().long()
+    agree = (got_code == ref_code).double().mean().item()
+    assert agree > 0.999 and torch.equal(got_code[0, 1:7, 1:7], ref_code[0, 1:7, 1:7]), agree
+    err = (out.double().cpu() - pooled).abs().max().item()
+    assert err <= 2.0 ** -8 * pooled.abs().max().item(), err       # half a bf16 ulp of the largest value (+ fp32 summation order)
+    # and without the codes pointer (the inference form): same output
+    out2 = torch.empty_like(out)
+    _lib.call("cgs_bf16_enc0_fwd", n, P(x_g), int(src == "f32"), P(w_g), P(b_g), P(out2), None, S())
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
 def _grad_dicts(net):
     """The flat gradient buffer of Hourglass128 as (critic, masker) dicts in the oracle's shapes."""
     saved = net.flat.clone()
