@@ -1,0 +1,250 @@
+// Weight + bias gradient of the LARGE-MAP 3x3 layers of BASELINE config 5 (the build-defined 128x128 Hourglass, hourglass128.py, chfak 1):
+// features.0 (3 -> 8 at 128x128), masker.0 (3 + 8 -> 16 at 128x128), masker.2 (16 -> 1 at 128x128), features.3 (8 -> 8 at 64x64) and
+// dec_model.0 (8 + 8 -> 8 at 64x64) -- 86 % of the weight-gradient time of the step on the shape-generic bf16_wgrad_kernel
+// (gen_bf16_train.hip: run-time shapes, 2 workgroups per CU, taps dealt to the waves so every wave re-reads dY).  Same arithmetic
+// (bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16 with K = 32 pixels through ds_read_b64_tr_b16), built like hconv.hip:
+//   * compile-time shapes, workgroups persistent over row strips of one image, 3-4 workgroups per CU (one stages while another multiplies);
+//   * the X tile is NHWC with a pixel of 8 / 16 / 32 bytes (4 / 8 / 16 channels): a transposing read's four column groups are four
+//     (tap, channel quad) pairs, so a 16-row block holds 4 / 2 / 1 taps: 3 / 5 / 9 matrix instructions per 32 pixels instead of 9 / 9 / 9;
+//   * the dY strip is contiguous in memory: staged by a flat 16-byte copy; a single-channel dY (masker.2: d Z fp32) is read from its
+//     fp32 source and needs no transposing read (8 consecutive pixels = one 16-byte LDS read);
+//   * the waves split the strip's 32-pixel blocks (every wave holds all row blocks), one cross-wave sum per workgroup at the end,
+//     one slab row per workgroup -> cgs_reduce_slabs (fixed order: bitwise reproducible).
+// No reference counterpart (the reference cannot run 128x128 frames): parity unpinned, see hourglass128.py.
+#include "tail_common.h"
+
+namespace {
+
+typedef short hs4_t __attribute__((ext_vector_type(4)));
+typedef short hs8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 hbf8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) hs4_t lds_hs4_t;
+
+__device__ __forceinline__ short hbf(float f) { return (short)__builtin_bit_cast(unsigned short, (__bf16)f); }      // round to nearest even
+__device__ __forceinline__ hs4_t tr4(const uint16_t* addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_hs4_t*)addr); }
+__device__ __forceinline__ hbf8_t pk8(hs4_t a, hs4_t b) {
+    const hs8_t s = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return __builtin_bit_cast(hbf8_t, s);
+}
+
+struct HWgParams {
+    const void* a;          // CA == 4: uint8 or fp32 frames [n,HW,HW,3]; else bf16 NHWC [n,HW,HW,CA]
+    const uint16_t* b;      // CB == 8: bf16 [n,HW/2,HW/2,8], nearest-upsampled; else NULL
+    const void* dy;         // CO > 1: bf16 [n,HW,HW,CO]; CO == 1: fp32 [n,HW,HW]
+    float* slab;            // [blocks][9 (CA_real + CB) CO + CO]
+    int n, nstrips, a_f32;
+};
+
+// HW: map size; CA: channels of source A in the LDS pixel (4 = rgb0 from uint8 / fp32 frames; 8 / 16 = bf16); CB: 0 / 8 (upsampled bf16
+// source); CO: output channels (1, 8, 16); TH: rows per strip
+template <int HW, int CA, int CB, int CO, int TH>
+__global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
+    constexpr int CIN = CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16);             // channels of the LDS pixel
+    constexpr int TPB = 16 / CIN, NB = (9 + TPB - 1) / TPB;                     // taps per 16-row block, row blocks
+    constexpr int CA_REAL = CA == 4 ? 3 : CA, CI = CA_REAL + CB;
+    constexpr int PW = HW + 2, PH = TH + 2, STRIPS = HW / TH, CPR = HW / 32, NCH = TH * CPR;
+    constexpr int XT = (PH * PW * CIN + 7) & ~7;                                // elements of the X tile (16-byte multiple)
+    static_assert(CO == 1 || CO == 8 || CO == 16, "dY pixel = 2 / 16 / 32 bytes");
+    static_assert(CA == 4 || (CA & 7) == 0, "bf16 sources in 16-byte chunks");
+    extern __shared__ __attribute__((aligned(16))) float4 hsm[];
+    uint16_t* const xt = (uint16_t*)hsm;                                        // [PH][PW][CIN]
+    uint16_t* const dt = xt + XT;                                               // [TH * HW][CO]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4, q = l15 >> 2, p = l15 & 3;
+
+    // this lane's part of a transposing read of row block b: tap 4 b + p (CIN 4), 2 b + (p >> 1) + channels 4 (p & 1) (CIN 8), b + channels 4 p
+    int aoff[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        int t = CIN == 4 ? 4 * b + p : (CIN == 8 ? 2 * b + (p >> 1) : b);
+        t = t < 9 ? t : 8;                                                      // rows of taps >= 9: duplicates, dropped at the end
+        aoff[b] = ((t / 3) * PW + t % 3) * CIN + (CIN == 4 ? 0 : (CIN == 8 ? 4 * (p & 1) : 4 * p));
+    }
+    frag4 acc[NB], accb = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = frag4{0.f, 0.f, 0.f, 0.f};
+    const short one = (short)0x3F80;                                            // bf16 1.0: bias gradient = column sums of dY
+    const hbf8_t ones = __builtin_bit_cast(hbf8_t, hs8_t{one, one, one, one, one, one, one, one});
+
+    for (int e = tid; e < XT / 8; e += 256) ((float4*)xt)[e] = f4zero();        // halo columns + padding channels: zero for every strip
+
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+        const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
+        // ---- X tile ----
+        if constexpr (CA == 4) {            // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item
+            constexpr int GW = HW / 4;
+#pragma unroll 2
+            for (int e = tid; e < PH * GW; e += 256) {
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                const bool in = y >= 0 && y < HW;
+                const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+                float f[12];
+                if (P.a_f32) {
+                    const float4* sf = (const float4*)P.a;
+                    const float4 f0 = sf[gi], f1 = sf[gi + 1], f2 = sf[gi + 2];
+                    f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
+                    f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
+                } else {
+                    const uint32_t* su = (const uint32_t*)P.a;
+                    const uint32_t d[3] = {su[gi], su[gi + 1], su[gi + 2]};
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const hs4_t v = in ? hs4_t{hbf(f[3 * j]), hbf(f[3 * j + 1]), hbf(f[3 * j + 2]), 0} : hs4_t{0, 0, 0, 0};
+                    *(hs4_t*)(xt + ((size_t)r * PW + 1 + 4 * g + j) * CIN) = v;
+                }
+            }
+        } else {
+            constexpr int NG = CA / 8;
+            const hs8_t* src = (const hs8_t*)P.a;
+#pragma unroll 2
+            for (int e = tid; e < PH * HW * NG; e += 256) {
+                const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
+                const bool in = y >= 0 && y < HW;
+                hs8_t v = src[in ? (((size_t)img * HW + y) * HW + x) * NG + g : 0];
+                if (!in) v = hs8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                *(hs8_t*)(xt + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = v;
+            }
+        }
+        if constexpr (CB == 8) {            // the nearest-upsampled source: channels CA .. CA + 7 of the pixel
+            const hs8_t* sb = (const hs8_t*)P.b;
+#pragma unroll 2
+            for (int e = tid; e < PH * HW; e += 256) {
+                const int x = e % HW, r = e / HW, y = row0 + r - 1;
+                const bool in = y >= 0 && y < HW;
+                hs8_t v = sb[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1) : 0];
+                if (!in) v = hs8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                uint16_t* d = xt + ((size_t)r * PW + 1 + x) * CIN + CA;       // 8-byte aligned (CA = 4) or 16
+                *(hs4_t*)d = hs4_t{v[0], v[1], v[2], v[3]};
+                *(hs4_t*)(d + 4) = hs4_t{v[4], v[5], v[6], v[7]};
+            }
+        }
+        // ---- dY strip: contiguous in memory ----
+        if constexpr (CO == 1) {
+            const float4* sd = (const float4*)((const float*)P.dy + ((size_t)img * HW + row0) * HW);
+            for (int e = tid; e < TH * HW / 4; e += 256) {
+                const float4 v = sd[e];
+                *(hs4_t*)(dt + 4 * e) = hs4_t{hbf(v.x), hbf(v.y), hbf(v.z), hbf(v.w)};
+            }
+        } else {
+            const float4* sd = (const float4*)((const uint16_t*)P.dy + ((size_t)img * HW + row0) * HW * CO);
+#pragma unroll 2
+            for (int e = tid; e < TH * HW * CO / 8; e += 256) ((float4*)dt)[e] = sd[e];
+        }
+        __syncthreads();
+        // ---- 32-pixel blocks of the strip (x0 .. x0 + 31 of row y): lane group kq supplies pixels 8 kq .. + 7 (two transposing reads) ----
+        for (int c = wave; c < NCH; c += 4) {
+            const int y = c / CPR, x0 = (c % CPR) * 32;
+            hbf8_t B;
+            if constexpr (CO == 1) {
+                B = __builtin_bit_cast(hbf8_t, *(const hs8_t*)(dt + c * 32 + 8 * kq));          // every column the same: column 0 is used
+            } else {
+                const uint16_t* db = dt + (size_t)(c * 32 + 8 * kq + q) * CO + (CO == 8 ? 4 * (p & 1) : 4 * p);
+                B = pk8(tr4(db), tr4(db + 4 * CO));
+            }
+            accb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, B, accb, 0, 0, 0);
+            const uint16_t* ab = xt + (size_t)(y * PW + x0 + 8 * kq + q) * CIN;
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pk8(tr4(ab + aoff[b]), tr4(ab + aoff[b] + 4 * CIN)), B, acc[b], 0, 0, 0);
+        }
+        __syncthreads();            // every wave is done with the tiles before the next strip is staged
+    }
+
+    // ---- cross-wave sum, slab row [9][CI][CO] + [CO]: D[m = 4 kq + r][n = l15]: m = row of the block, n = output channel ----
+    float* const red = (float*)hsm;                                             // [4 waves][NB + 1][64 lanes] float4
+#pragma unroll
+    for (int b = 0; b < NB; ++b) *(frag4*)(red + (((size_t)wave * (NB + 1) + b) * 64 + lane) * 4) = acc[b];
+    *(frag4*)(red + (((size_t)wave * (NB + 1) + NB) * 64 + lane) * 4) = accb;
+    __syncthreads();
+    float* const sl = P.slab + (size_t)blockIdx.x * (9 * CI * CO + CO);
+    for (int e = tid; e < (NB + 1) * 256; e += 256) {
+        const int b = e >> 8, ln = (e >> 2) & 63, r = e & 3, n = ln & 15, g = ln >> 4;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) s += red[(((size_t)w * (NB + 1) + b) * 64 + ln) * 4 + r];
+        if (n >= CO) continue;
+        if (b == NB) {
+            if (g == 0 && r == 0) sl[9 * CI * CO + n] = s;
+            continue;
+        }
+        const int tap = CIN == 4 ? 4 * b + g : (CIN == 8 ? 2 * b + (g >> 1) : b);
+        const int ch = CIN == 4 ? r : (CIN == 8 ? 4 * (g & 1) + r : 4 * g + r);  // channel of the LDS pixel
+        const int ci = ch < CA ? (ch < CA_REAL ? ch : -1) : (ch < CA + CB ? CA_REAL + (ch - CA) : -1);
+        if (tap < 9 && ci >= 0) sl[(tap * CI + ci) * CO + n] = s;
+    }
+}
+
+template <int HW, int CA, int CB, int CO, int TH>
+struct HWg {
+    static constexpr int CIN = CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16), TPB = 16 / CIN, NB = (9 + TPB - 1) / TPB;
+    static constexpr size_t tiles = (size_t)(((TH + 2) * (HW + 2) * CIN + 7) & ~7) * 2 + (size_t)TH * HW * CO * 2;
+    static constexpr size_t red = (size_t)4 * (NB + 1) * 64 * 16;
+    static constexpr size_t lds = tiles > red ? tiles : red;
+    static int blocks(int n) {
+        const int per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
+        const int nstrips = n * (HW / TH), cap = 256 * per_cu;
+        return nstrips < cap ? nstrips : cap;
+    }
+    static int launch(HWgParams P, hipStream_t st) {
+        P.nstrips = P.n * (HW / TH);
+        auto k = hwgrad_kernel<HW, CA, CB, CO, TH>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(k, dim3(blocks(P.n)), dim3(256), lds, st, P);
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
+};
+
+using HWgEnc0 = HWg<128, 4, 0, 8, 8>;        // features.0
+using HWgMask0 = HWg<128, 4, 8, 16, 4>;      // masker.0
+using HWgMask2 = HWg<128, 16, 0, 1, 4>;      // masker.2
+using HWgEnc1 = HWg<64, 8, 0, 8, 16>;        // features.3
+using HWgDec0 = HWg<64, 8, 8, 8, 8>;         // dec_model.0
+
+int hwg_which(int hw, int ca, int cb, int co) {
+    if (hw == 128 && ca == 3 && cb == 0 && co == 8) return 1;
+    if (hw == 128 && ca == 3 && cb == 8 && co == 16) return 2;
+    if (hw == 128 && ca == 16 && cb == 0 && co == 1) return 3;
+    if (hw == 64 && ca == 8 && cb == 0 && co == 8) return 4;
+    if (hw == 64 && ca == 8 && cb == 8 && co == 8) return 5;
+    return 0;
+}
+
+}  // namespace
+
+// Slab rows cgs_bf16_hwgrad writes for this shape (0: the shape is not one of the dedicated ones -> cgs_bf16_conv3x3_bwd_weight).
+extern "C" int cgs_bf16_hwgrad_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co) {
+    if (n < 0) return CGS_ERR_BADARG;
+    switch (hwg_which(hw, ca, cb, co)) {
+        case 1: return HWgEnc0::blocks(n);
+        case 2: return HWgMask0::blocks(n);
+        case 3: return HWgMask2::blocks(n);
+        case 4: return HWgEnc1::blocks(n);
+        case 5: return HWgDec0::blocks(n);
+    }
+    return 0;
+}
+
+// dW / db slabs of conv3x3(cat(A, nearest-up2(B))): a_kind 0 = bf16 [n,hw,hw,ca], 1 = uint8, 2 = fp32 frames [n,hw,hw,3];
+// dy: bf16 [n,hw,hw,co] (co > 1) or fp32 [n,hw,hw] (co == 1); slab [cgs_bf16_hwgrad_slabs][9 (ca + cb) co + co].
+extern "C" int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, const void* src_a, const void* src_b,
+                               const void* dy, float* slab, cgs_stream_t stream) {
+    const int which = hwg_which(hw, ca, cb, co);
+    if (n < 0 || !src_a || !dy || !slab || (cb > 0 && !src_b) || a_kind < 0 || a_kind > 2) return CGS_ERR_BADARG;
+    if (!which) return CGS_ERR_UNSUPPORTED;
+    if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;                     // frames are uint8 / fp32, activations bf16
+    if (n == 0) return CGS_OK;
+    const HWgParams P{src_a, (const uint16_t*)src_b, dy, slab, n, 0, a_kind == 2 ? 1 : 0};
+    switch (which) {
+        case 1: return HWgEnc0::launch(P, (hipStream_t)stream);
+        case 2: return HWgMask0::launch(P, (hipStream_t)stream);
+        case 3: return HWgMask2::launch(P, (hipStream_t)stream);
+        case 4: return HWgEnc1::launch(P, (hipStream_t)stream);
+        default: return HWgDec0::launch(P, (hipStream_t)stream);
+    }
+}

@@ -30,6 +30,7 @@ from . import hourglass as hg
 from . import parallel
 from .generic import _ACT, _p, _s
 
+HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
 ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False: the generic bf16 convolution; r4 A/B)
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
 ENC_HW = (128, 64, 32, 16, 8)            # pre-pool map size of the five encoder stages
@@ -272,12 +273,19 @@ class Hourglass128:
         self._conv("masker.0", A, T.o[0], self.mc, act="lrelu", out=T.hm)
         self._conv("masker.2", T.hm, None, 1, act="sigmoid", out_f32=True, out=T.Z.view(n, 128, 128, 1))
 
-    def _wgrad(self, T, plan, key, tag, n, hw, a, b, ups, dy, dyc=None):
+    def _wgrad(self, T, plan, key, tag, n, hw, a, b, ups, dy, dyc=None, dy_f32=None):
+        """dW / db slabs of layer `key`; dy_f32: the fp32 single-channel gradient the dedicated kernel reads instead of the padded bf16 dy."""
         ca, cb, co = self.convs[key]
-        nsl = self.lib.cgs_bf16_conv3x3_bwd_weight_slabs(n, hw, ca, cb)
         cnt = 9 * (ca + cb) * co + co
-        slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
         a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+        nsl = self.lib.cgs_bf16_hwgrad_slabs(n, hw, ca, cb, co) if HWGRAD and (cb == 0 or ups == 2) and (co > 1 or dy_f32 is not None) else 0
+        if nsl > 0:          # the large-map layers of chfak 1: csrc/hwgrad.hip
+            slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
+            _lib.call("cgs_bf16_hwgrad", n, hw, ca, cb, co, a_kind, _p(a), _p(b), _p(dy_f32 if co == 1 else dy), _p(slab), _s())
+            plan.add(slab, nsl, cnt, self.off[key][0])
+            return
+        nsl = self.lib.cgs_bf16_conv3x3_bwd_weight_slabs(n, hw, ca, cb)
+        slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
         _lib.call("cgs_bf16_conv3x3_bwd_weight", n, hw, ca, cb, co, dyc if dyc is not None else co, a_kind, ups, _p(a), _p(b), _p(dy), _p(slab), _s())
         plan.add(slab, nsl, cnt, self.off[key][0])
 
@@ -339,7 +347,7 @@ class Hourglass128:
         ea = [t[n:2 * n] for t in T.e]
         dz4 = T.buf("dz4", (n, 128, 128, 4), torch.bfloat16, self.dev)
         _lib.call("cgs_bf16_convert", n * 16384, 1, 4, 0, _p(T.dzpre), _p(dz4), _s())
-        self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, dz4, dyc=4)
+        self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, dz4, dyc=4, dy_f32=T.dzpre)
         dh = self._dgrad(T, "masker.2", dz4, "dhm", dy_channels=4)
         _lib.call("cgs_bf16_lrelu_bwd", dh.numel(), _p(dh), _p(T.hm), 0.01, _s())
         self._wgrad(T, plan, "masker.0", "m", n, 128, A, T.o[0], 2, dh)

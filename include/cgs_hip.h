@@ -166,6 +166,13 @@ int cgs_mask_infer_fwd_f16o(int32_t n, int32_t src_a, const void* x, const void*
  * the MaxPool2d argmax bytes [n,64,64,8] of the training forward (cgs_bf16_pool_expand reads them).                                    */
 int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16, uint8_t* codes,
                       cgs_stream_t stream);
+/* Weight + bias gradient of the large-map layers of config 5 at chfak 1 (csrc/hwgrad.hip; same arithmetic as cgs_bf16_conv3x3_bwd_weight):
+ * (hw, ca, cb, co) = (128,3,0,8) features.0, (128,3,8,16) masker.0, (128,16,0,1) masker.2, (64,8,0,8) features.3, (64,8,8,8) dec_model.0.
+ * cgs_bf16_hwgrad_slabs: slab rows written for n images (0: not a dedicated shape).  a_kind: 0 bf16 [n,hw,hw,ca], 1 uint8 / 2 fp32 frames
+ * [n,hw,hw,3]; src_b bf16 [n,hw/2,hw/2,cb] (nearest-upsampled x2); dy bf16 [n,hw,hw,co], or fp32 [n,hw,hw] when co == 1.              */
+int cgs_bf16_hwgrad_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co);
+int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, const void* src_a, const void* src_b,
+                    const void* dy, float* slab, cgs_stream_t stream);
 
 /* ---- the 16x16-and-smaller layers, image by image inside one workgroup ("tail" kernels, csrc/tail.hip) ------------
  * Replace, for one critic pass / the decoder, the per-layer launches of features.6, features.10 (nets.py:176-183), the

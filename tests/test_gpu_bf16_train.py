@@ -76,6 +76,56 @@ def test_bf16_weight_gradient_vs_float64_autograd(shape):
     assert err < 2e-5
 
 
+HWG_SHAPES = [  # (n, hw, ca, cb, co, a_kind): the dedicated large-map shapes (csrc/hwgrad.hip); n ragged against the persistent grid
+    (3, 128, 3, 0, 8, 1), (5, 128, 3, 0, 8, 2), (3, 128, 3, 8, 16, 1), (3, 128, 16, 0, 1, 0), (7, 64, 8, 0, 8, 0), (5, 64, 8, 8, 8, 0),
+    (300, 64, 8, 0, 8, 0)]
+
+
+@pytest.mark.parametrize("shape", HWG_SHAPES)
+def test_bf16_large_map_weight_gradient_vs_float64_autograd(shape):
+    """cgs_bf16_hwgrad (the dedicated kernels of the 128x128 / 64x64 layers) vs float64 autograd on the same bf16-rounded operands:
+    every slab element written, relative error of the sums <= 2e-5 of the tensor's maximum (n = 300 at 64x64: more strips than
+    persistent workgroups, every workgroup walks several)."""
+    from cgs_amd import _lib
+    n, hw, ca, cb, co, a_kind = shape
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(hw * 7 + ca + 31 * cb)
+    if a_kind == 1:
+        a_dev = torch.randint(0, 256, (n, hw, hw, ca), dtype=torch.uint8, generator=g)
+        a_ref = bf(a_dev.double() / 255.0)
+    elif a_kind == 2:
+        a_dev = torch.rand((n, hw, hw, ca), generator=g)
+        a_ref = bf(a_dev.double())
+    else:
+        a_dev = torch.randn((n, hw, hw, ca), generator=g).to(torch.bfloat16)
+        a_ref = a_dev.double()
+    b_dev = torch.randn((n, hw // 2, hw // 2, cb), generator=g).to(torch.bfloat16) if cb else None
+    if co == 1:
+        dy_dev = torch.randn((n, hw, hw), generator=g) * 0.1            # fp32 single-channel gradient, rounded to bf16 by the loader
+        dy_ref = bf(dy_dev.double()).reshape(n, 1, hw, hw)
+    else:
+        dy_dev = (torch.randn((n, hw, hw, co), generator=g) * 0.1).to(torch.bfloat16)
+        dy_ref = dy_dev.double().permute(0, 3, 1, 2)
+    x = cat_up(a_ref.permute(0, 3, 1, 2), b_dev.double().permute(0, 3, 1, 2) if cb else None, 2)
+    w = torch.zeros((co, ca + cb, 3, 3), dtype=torch.float64, requires_grad=True)
+    bias = torch.zeros(co, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(x, w, bias, padding=1) * dy_ref).sum().backward()
+    nsl = lib.cgs_bf16_hwgrad_slabs(n, hw, ca, cb, co)
+    assert nsl > 0
+    cnt = 9 * (ca + cb) * co + co
+    slab = torch.full((nsl, cnt), float("nan"), device="cuda")
+    a_g, b_g, dy_g = a_dev.cuda(), (b_dev.cuda() if cb else None), dy_dev.cuda()
+    _lib.call("cgs_bf16_hwgrad", n, hw, ca, cb, co, a_kind, P(a_g), P(b_g), P(dy_g), P(slab), S())
+    torch.cuda.synchronize()
+    assert torch.isfinite(slab).all(), "a slab element was not written"
+    got = slab.double().sum(0).cpu()
+    ref = torch.cat((w.grad.permute(2, 3, 1, 0).reshape(-1), bias.grad))
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"{shape}: max err / max |ref| = {err:.2e}")
+    assert err < 2e-5
+    assert lib.cgs_bf16_hwgrad_slabs(n, 32, ca, cb, co) == 0            # not a dedicated shape: the caller takes the generic kernel
+
+
 @pytest.mark.parametrize("shape", [(2, 128, 3, 8, 16), (3, 64, 8, 8, 8), (4, 8, 8, 0, 16), (3, 128, 16, 0, 1), (5, 4, 16, 32, 16)])
 def test_bf16_data_gradient_is_forward_kernel_on_transposed_pack(shape):
     """d cat(A, up(B)) = conv3x3(dY) with flipped / transposed weights (cgs_genbf16_pack_weights_t + the forward kernel) vs float64
