@@ -60,6 +60,11 @@ SIGNATURES = {
     "cgs_f16_enc1_fwd": (i32, [i32, vp, vp, vp, vp, vp]),
     "cgs_f16_dec0_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "cgs_bf16_enc0_fwd": (i32, [i32, vp, i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_mask0_fwd": (i32, [i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_bf16_mask2_fwd": (i32, [i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_enc0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
+    "cgs_bf16_mask2_bwd_data": (i32, [i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_mask0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
     "cgs_bf16_hwgrad_slabs": (i32, [i32, i32, i32, i32, i32]),
     "cgs_bf16_hwgrad": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_mask_train_fwd_partials": (i32, [i32]),

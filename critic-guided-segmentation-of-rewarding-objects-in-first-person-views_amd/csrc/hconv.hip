@@ -218,6 +218,257 @@ int hconv_launch(const HConvParams& P, hipStream_t st) {
     return CGS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Config 5 (the build-defined 128x128 variant, hourglass128.py, chfak 1): the large-map layers of the TRAINING step in bfloat16 on the
+// same plan -- whole-strip NHWC tile, weights in registers (converted from the fp32 master copy, flipped + transposed for a data
+// gradient), persistent workgroups -- with the epilogues the step needs fused: ReLU + MaxPool2d(2) + argmax bytes, bias + LeakyReLU /
+// Sigmoid, the 2x2 cell sum of a nearest-upsampled source's gradient (replaces cgs_bf16_cat_split), the LeakyReLU' factor of the layer
+// below (replaces cgs_bf16_lrelu_bwd).  Replaces gen16_conv3x3_kernel (run-time shapes, 16-pixel staging items) on these layers.
+struct H5Params {
+    const void* a;          // CA == 4: uint8 / fp32 frames [n,HW,HW,3]; CA == 1: fp32 [n,HW,HW]; else bf16 NHWC [n,HW,HW,CA]
+    const uint16_t* b;      // CB == 8: bf16 [n,HW/2,HW/2,8], nearest-upsampled; else NULL
+    const float* w;         // the layer's HWIO fp32 weights [9][CIL][COL]
+    const float* bias;      // [CO] or NULL
+    void* out;
+    uint8_t* codes;         // EPI_POOLMAX: argmax bytes or NULL
+    const uint16_t* hm;     // EPI_LRELU_BWD: the layer's own output of the forward pass, bf16 [n,HW,HW,CO]
+    int n, nstrips, a_f32;
+};
+
+enum { EPI_PLAIN = 0, EPI_POOLMAX = 1, EPI_POOLSUM = 2, EPI_LRELU_BWD = 3 };
+
+// CA: LDS channels of source A (4 = rgb0 frames, 1 = fp32 single channel, 8 / 16 = bf16); CB: 0 / 8; CO: output channels of the kernel;
+// CIL, COL: the LAYER's input / output channels (weight strides); DGRAD: the kernel computes the data gradient of the layer with respect to
+// its input channels O0 .. O0 + CO - 1 (source = dY with COL channels); EPI / ACT: epilogue; OUT_F32: fp32 output (else bf16)
+template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_>
+struct H5Cfg {
+    static constexpr int HW = HW_, TH = TH_, CA = CA_, CB = CB_, CO = CO_, CIL = CIL_, COL = COL_, O0 = O0_, EPI = EPI_, ACT = ACT_;
+    static constexpr bool DGRAD = DGRAD_, OUT_F32 = OUT_F32_, POOL = EPI_ == EPI_POOLMAX || EPI_ == EPI_POOLSUM;
+    static constexpr int CIN = CA + CB <= 1 ? 1 : (CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16));
+    static constexpr int TPM = 32 / CIN, NM = (9 + TPM - 1) / TPM, CA_REAL = CA == 4 ? 3 : CA;
+    static constexpr int PW = HW + 2, PH = TH + 2;
+    static constexpr size_t lds = (size_t)((PH * PW * CIN + 7) & ~7) * 2;
+};
+
+template <class C>
+__global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
+    using EL = ElBF16;
+    using v8 = EL::V8; using v4 = EL::V4;
+    constexpr int HW = C::HW, TH = C::TH, CA = C::CA, CB = C::CB, CO = C::CO, CIN = C::CIN, TPM = C::TPM, NM = C::NM, PW = C::PW, PH = C::PH;
+    constexpr int STRIPS = HW / TH, NT = TH * HW / 16, XT = (PH * PW * CIN + 7) & ~7;
+    extern __shared__ __attribute__((aligned(16))) float4 hsm[];
+    short* const tile = (short*)hsm;                                            // [PH][PW][CIN]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+
+    // ---- weights -> registers: lane (row l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN, LDS channel k % CIN ----
+    v8 wa[NM];
+#pragma unroll
+    for (int g = 0; g < NM; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
+            int idx = -1;
+            if (tap < 9 && l15 < CO) {
+                if constexpr (C::DGRAD) {       // d x[ci = O0 + oc] = sum over (tap', co) of dY[p + off(tap')][co] W[8 - tap'][ci][co]
+                    if (c < C::COL) idx = ((8 - tap) * C::CIL + C::O0 + l15) * C::COL + c;
+                } else {
+                    const int cr = c < CA ? (c < C::CA_REAL ? c : -1) : (c < CA + CB ? C::CA_REAL + (c - CA) : -1);
+                    if (cr >= 0) idx = (tap * C::CIL + cr) * C::COL + l15;
+                }
+            }
+            wa[g][j] = EL::cvt(idx >= 0 ? P.w[idx] : 0.f);
+        }
+    float br[4] = {0.f, 0.f, 0.f, 0.f};
+    float bl = 0.f;
+    if (P.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) br[r] = 4 * kq + r < CO ? P.bias[4 * kq + r] : 0.f;
+        bl = l15 < CO ? P.bias[l15] : 0.f;
+    }
+    int toff1[8];                               // CIN == 1: this lane's eight taps (8 kq + j, clamped: the weights of taps >= 9 are zero)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int t = 8 * kq + j;
+        t = t < 9 ? t : 8;
+        toff1[j] = (t / 3) * PW + t % 3;
+    }
+
+    for (int e = tid; e < XT / 8; e += 256) ((float4*)tile)[e] = f4zero();       // halo columns + padding channels: zero for every strip
+    __syncthreads();
+
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+    const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
+    // ---- stage the tile (zero halo rows) ----
+    if constexpr (CA == 4) {                    // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item
+        constexpr int GW = HW / 4;
+#pragma unroll 2
+        for (int e = tid; e < PH * GW; e += 256) {
+            const int g = e % GW, r = e / GW, y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+            float f[12];
+            if (P.a_f32) {
+                const float4* sf = (const float4*)P.a;
+                const float4 f0 = sf[gi], f1 = sf[gi + 1], f2 = sf[gi + 2];
+                f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
+                f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
+            } else {
+                const uint32_t* su = (const uint32_t*)P.a;
+                const uint32_t d[3] = {su[gi], su[gi + 1], su[gi + 2]};
+#pragma unroll
+                for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const v4 v = in ? v4{EL::cvt(f[3 * j]), EL::cvt(f[3 * j + 1]), EL::cvt(f[3 * j + 2]), 0} : v4{0, 0, 0, 0};
+                *(v4*)(tile + ((size_t)r * PW + 1 + 4 * g + j) * CIN) = v;
+            }
+        }
+    } else if constexpr (CA == 1) {             // fp32 single channel: 4 pixels per item (the tile row starts 2 bytes after an 8-byte boundary)
+        constexpr int GW = HW / 4;
+        for (int e = tid; e < PH * GW; e += 256) {
+            const int g = e % GW, r = e / GW, y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            float4 v = ((const float4*)P.a)[in ? (((size_t)img * HW + y) * HW) / 4 + g : 0];
+            if (!in) v = f4zero();
+            short* d = tile + (size_t)r * PW + 1 + 4 * g;
+            d[0] = EL::cvt(v.x); d[1] = EL::cvt(v.y); d[2] = EL::cvt(v.z); d[3] = EL::cvt(v.w);
+        }
+    } else {
+        constexpr int NG = CA / 8;
+        const v8* src = (const v8*)P.a;
+#pragma unroll 2
+        for (int e = tid; e < PH * HW * NG; e += 256) {
+            const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            v8 v = src[in ? (((size_t)img * HW + y) * HW + x) * NG + g : 0];
+            if (!in) v = v8{0, 0, 0, 0, 0, 0, 0, 0};
+            *(v8*)(tile + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = v;
+        }
+    }
+    if constexpr (CB == 8) {                    // the nearest-upsampled bf16 source: channels CA .. CA + 7 of the pixel
+        const v8* sb = (const v8*)P.b;
+#pragma unroll 2
+        for (int e = tid; e < PH * HW; e += 256) {
+            const int x = e % HW, r = e / HW, y = row0 + r - 1;
+            const bool in = y >= 0 && y < HW;
+            v8 v = sb[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1) : 0];
+            if (!in) v = v8{0, 0, 0, 0, 0, 0, 0, 0};
+            short* d = tile + ((size_t)r * PW + 1 + x) * CIN + CA;             // 8-byte aligned (CA = 4) or 16
+            *(v4*)d = v4{v[0], v[1], v[2], v[3]};
+            *(v4*)(d + 4) = v4{v[4], v[5], v[6], v[7]};
+        }
+    }
+    __syncthreads();
+
+    // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
+#pragma unroll 2
+    for (int t = wave; t < NT; t += 4) {
+        int y, x;                               // strip-local pixel of this lane
+        if constexpr (C::POOL) {
+            constexpr int TPR = HW / 8;
+            const int wy = t / TPR, tx = t % TPR, win = l15 >> 2, pos = l15 & 3;
+            y = 2 * wy + (pos >> 1); x = 8 * tx + 2 * win + (pos & 1);
+        } else {
+            constexpr int TPR = HW / 16;
+            y = t / TPR; x = 16 * (t % TPR) + l15;
+        }
+        const short* pix = tile + ((size_t)y * PW + x) * CIN;                   // tap (0,0) of the lane's 3x3 window
+        frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < NM; ++g) {
+            v8 b;
+            if constexpr (CIN == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) b[j] = pix[toff1[j]];
+            } else if constexpr (CIN == 4) {
+                int t0 = g * 8 + 2 * kq, t1 = t0 + 1;
+                t0 = t0 < 9 ? t0 : 8; t1 = t1 < 9 ? t1 : 8;
+                const v4 lo = *(const v4*)(pix + ((t0 / 3) * PW + t0 % 3) * 4), hi = *(const v4*)(pix + ((t1 / 3) * PW + t1 % 3) * 4);
+                b = v8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            } else if constexpr (CIN == 8) {
+                int tp = g * 4 + kq;
+                tp = tp < 9 ? tp : 8;
+                b = *(const v8*)(pix + ((tp / 3) * PW + tp % 3) * 8);
+            } else {
+                int tp = g * 2 + (kq >> 1);
+                tp = tp < 9 ? tp : 8;
+                b = *(const v8*)(pix + ((tp / 3) * PW + tp % 3) * 16 + 8 * (kq & 1));
+            }
+            if constexpr (C::POOL) acc = EL::mfma(b, wa[g], acc);               // D[pixel = 4 kq + r][oc = l15]: a lane's four values = one 2x2 window
+            else acc = EL::mfma(wa[g], b, acc);                                 // D[oc = 4 kq + r][pixel = l15]
+        }
+        if constexpr (C::POOL) {
+            constexpr int TPR = HW / 8;
+            const int wy = t / TPR, tx = t % TPR;
+            if (l15 < CO) {
+                const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * CO) + l15;
+                float m;
+                if constexpr (C::EPI == EPI_POOLSUM) m = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                else m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bl, 0.f);
+                if constexpr (C::OUT_F32) ((float*)P.out)[o] = m;
+                else ((short*)P.out)[o] = EL::cvt(m);
+                if constexpr (C::EPI == EPI_POOLMAX) {
+                    if (P.codes) {              // first maximum wins (max_pool2d); 4 = the pooled value is not positive: no gradient
+                        uint32_t code = 0;
+                        float mm = acc[0] + bl;
+#pragma unroll
+                        for (int j = 1; j < 4; ++j) if (acc[j] + bl > mm) { mm = acc[j] + bl; code = j; }
+                        P.codes[o] = (uint8_t)(m > 0.f ? code : 4u);
+                    }
+                }
+            }
+        } else if (4 * kq < CO) {
+            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * CO) + 4 * kq;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[r] + br[r];
+                if constexpr (C::ACT == CGS_ACT_LRELU) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
+                if constexpr (C::ACT == CGS_ACT_SIGMOID) v[r] = 1.f / (1.f + __expf(-v[r]));
+                if constexpr (C::ACT == CGS_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (C::EPI == EPI_LRELU_BWD) {                             // x LeakyReLU'(h): h = the layer's forward output (bf16: sign is exact)
+                const v4 h = *(const v4*)((const short*)P.hm + o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = h[r] > 0 ? v[r] : 0.01f * v[r];
+            }
+            if constexpr (CO % 4 == 0) {
+                if constexpr (C::OUT_F32) *(float4*)((float*)P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+                else *(v4*)((short*)P.out + o) = v4{EL::cvt(v[0]), EL::cvt(v[1]), EL::cvt(v[2]), EL::cvt(v[3])};
+            } else {
+#pragma unroll
+                for (int r = 0; r < CO; ++r) {
+                    if constexpr (C::OUT_F32) ((float*)P.out)[o + r] = v[r];
+                    else ((short*)P.out)[o + r] = EL::cvt(v[r]);
+                }
+            }
+        }
+    }
+    __syncthreads();            // every wave is done with the tile before the next strip is staged
+    }
+}
+
+template <class C>
+int h5_launch(H5Params P, hipStream_t st) {
+    if (P.n <= 0) return CGS_OK;
+    P.nstrips = P.n * (C::HW / C::TH);
+    // persistent workgroups: as many as stay resident (LDS; at most 4 per CU), then as few as walk the same number of strips each
+    const int per_cu = (int)((160 * 1024) / C::lds) < 4 ? (int)((160 * 1024) / C::lds) : 4, cap = 256 * per_cu;
+    const int rounds = (P.nstrips + cap - 1) / cap, blocks = (P.nstrips + rounds - 1) / rounds;
+    hipLaunchKernelGGL((h5conv_kernel<C>), dim3(blocks), dim3(256), C::lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+//                      HW   TH  CA CB  CO CIL COL O0 DGRAD  EPI            ACT              OUT_F32
+using H5Mask0F = H5Cfg<128,  8,  4, 8, 16, 11, 16, 0, false, EPI_PLAIN,     CGS_ACT_LRELU,   false>;   // masker.0 forward
+using H5Mask2F = H5Cfg<128,  8, 16, 0,  1, 16,  1, 0, false, EPI_PLAIN,     CGS_ACT_SIGMOID, true>;    // masker.2 forward
+using H5Enc0D  = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    true>;    // features.0: image gradient
+using H5Mask2D = H5Cfg<128, 16,  1, 0, 16, 16,  1, 0, true,  EPI_LRELU_BWD, CGS_ACT_NONE,    false>;   // masker.2: d hm (x LeakyReLU')
+using H5Mask0D = H5Cfg<128,  8, 16, 0,  8, 11, 16, 3, true,  EPI_POOLSUM,   CGS_ACT_NONE,    false>;   // masker.0: d o0 (2x2 cell sums)
+
 }  // namespace
 
 extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
@@ -243,4 +494,33 @@ extern "C" int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, con
                                  uint8_t* codes, cgs_stream_t stream) {
     if (n < 0 || !x || !w_hwio || !bias || !e0_bf16) return CGS_ERR_BADARG;
     return hconv_launch<128, 4, 0, 16, true, false, ElBF16>(HConvParams{x, nullptr, w_hwio, bias, e0_bf16, n, 0, x_is_f32 ? 1 : 0, codes}, (hipStream_t)stream);
+}
+
+// ---- config 5, the 128x128 layers of the training step (h5conv_kernel above); weights / bias: the layer's fp32 HWIO master parameters ----
+// masker.0 forward: LeakyReLU(conv3x3(cat(frames uint8 [n,128,128,3] / 255, nearest-up2(o0 bf16 [n,64,64,8])))) -> hm bf16 [n,128,128,16]
+extern "C" int cgs_bf16_mask0_fwd(int32_t n, const uint8_t* x_u8, const void* o0_bf16, const float* w_hwio, const float* bias, void* hm_bf16,
+                                  cgs_stream_t stream) {
+    if (n < 0 || !x_u8 || !o0_bf16 || !w_hwio || !bias || !hm_bf16) return CGS_ERR_BADARG;
+    return h5_launch<H5Mask0F>(H5Params{x_u8, (const uint16_t*)o0_bf16, w_hwio, bias, hm_bf16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+}
+// masker.2 forward: Sigmoid(conv3x3(hm)) -> Z fp32 [n,128,128]
+extern "C" int cgs_bf16_mask2_fwd(int32_t n, const void* hm_bf16, const float* w_hwio, const float* bias, float* z, cgs_stream_t stream) {
+    if (n < 0 || !hm_bf16 || !w_hwio || !bias || !z) return CGS_ERR_BADARG;
+    return h5_launch<H5Mask2F>(H5Params{hm_bf16, nullptr, w_hwio, bias, z, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+}
+// features.0 data gradient: dy bf16 [n,128,128,8] (the re-expanded pooled gradient) -> d frames fp32 [n,128,128,3]
+extern "C" int cgs_bf16_enc0_bwd_data(int32_t n, const void* dy_bf16, const float* w_hwio, float* dx, cgs_stream_t stream) {
+    if (n < 0 || !dy_bf16 || !w_hwio || !dx) return CGS_ERR_BADARG;
+    return h5_launch<H5Enc0D>(H5Params{dy_bf16, nullptr, w_hwio, nullptr, dx, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+}
+// masker.2 data gradient through masker.0's LeakyReLU: dz fp32 [n,128,128] (pre-Sigmoid gradient), hm bf16 [n,128,128,16] -> d (masker.0
+// pre-activation) bf16 [n,128,128,16]
+extern "C" int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream) {
+    if (n < 0 || !dz || !hm_bf16 || !w_hwio || !dhm_bf16) return CGS_ERR_BADARG;
+    return h5_launch<H5Mask2D>(H5Params{dz, nullptr, w_hwio, nullptr, dhm_bf16, nullptr, (const uint16_t*)hm_bf16, n, 0, 0}, (hipStream_t)stream);
+}
+// masker.0 data gradient with respect to the upsampled source: dhm bf16 [n,128,128,16] -> d o0 bf16 [n,64,64,8] (summed over each 2x2 cell)
+extern "C" int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream) {
+    if (n < 0 || !dhm_bf16 || !w_hwio || !do0_bf16) return CGS_ERR_BADARG;
+    return h5_launch<H5Mask0D>(H5Params{dhm_bf16, nullptr, w_hwio, nullptr, do0_bf16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }

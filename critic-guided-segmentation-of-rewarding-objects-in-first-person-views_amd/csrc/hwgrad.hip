@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
     const hbf8_t ones = __builtin_bit_cast(hbf8_t, hs8_t{one, one, one, one, one, one, one, one});
 
     for (int e = tid; e < XT / 8; e += 256) ((float4*)xt)[e] = f4zero();        // halo columns + padding channels: zero for every strip
+    __syncthreads();                                                            // (before other threads stage the same addresses)
 
     for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
         const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
@@ -184,8 +185,10 @@ struct HWg {
     static constexpr size_t lds = tiles > red ? tiles : red;
     static int blocks(int n) {
         const int per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
-        const int nstrips = n * (HW / TH), cap = 256 * per_cu;
-        return nstrips < cap ? nstrips : cap;
+        const int nstrips = n * (HW / TH), cap = 256 * per_cu;          // as many as stay resident, then as few as walk the same
+        if (nstrips <= 0) return 0;                                     // number of strips each
+        const int rounds = (nstrips + cap - 1) / cap;
+        return (nstrips + rounds - 1) / rounds;
     }
     static int launch(HWgParams P, hipStream_t st) {
         P.nstrips = P.n * (HW / TH);

@@ -30,6 +30,7 @@ from . import hourglass as hg
 from . import parallel
 from .generic import _ACT, _p, _s
 
+H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
 HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
 ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False: the generic bf16 convolution; r4 A/B)
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
@@ -54,6 +55,7 @@ class Hourglass128:
         self.dev = dev = torch.device(device)
         d = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
         self.d, self.nb, self.mc = d, neck * chfak, masker_channels
+        self.h5 = chfak == 1 and masker_channels == 16       # the dedicated 128x128 kernels are compiled for these channel counts
         nb = self.nb
         self.lr, self.b1, self.b2, self.eps, self.lfak, self.L1, self.L2 = lr, betas[0], betas[1], eps, lfak, L1, L2
         self.pg = process_group
@@ -178,6 +180,13 @@ class Hourglass128:
                   _p(self.w16[key] if w16 is None else w16), _p(bias), _p(out), _p(codes), _s())
         return out
 
+    def _mask_head_fwd(self, n, x_u8, o0, hm, Z):
+        """masker.0 + masker.2 of chfak 1 on the whole-strip kernels (weights straight from the fp32 master copy)."""
+        w0, b0 = self._wview("masker.0")
+        w2, b2 = self._wview("masker.2")
+        _lib.call("cgs_bf16_mask0_fwd", n, _p(x_u8), _p(o0), _p(w0), _p(b0), _p(hm), _s())
+        _lib.call("cgs_bf16_mask2_fwd", n, _p(hm), _p(w2), _p(b2), _p(Z), _s())
+
     def _zero_bias(self, co):
         z = getattr(self, "_zb", None)
         if z is None or z.numel() < co:
@@ -211,8 +220,13 @@ class Hourglass128:
         o = self._conv("dec_model.4", e[4], o.view(n, 1, 1, nb), d[4], ups=4)
         for i in (3, 2, 1, 0):
             o = self._conv(f"dec_model.{i}", e[i], o, d[i])
-        hm = self._conv("masker.0", x_u8, o, self.mc, act="lrelu")
-        Z = self._conv("masker.2", hm, None, 1, act="sigmoid", out_f32=True).reshape(n, 128, 128)
+        if H5CONV and self.h5:
+            hm = torch.empty((n, 128, 128, 16), device=self.dev, dtype=torch.bfloat16)
+            Z = torch.empty((n, 128, 128), device=self.dev)
+            self._mask_head_fwd(n, x_u8, o, hm, Z)
+        else:
+            hm = self._conv("masker.0", x_u8, o, self.mc, act="lrelu")
+            Z = self._conv("masker.2", hm, None, 1, act="sigmoid", out_f32=True).reshape(n, 128, 128)
         return pred, Z
 
     # ---- training (round 4) ---------------------------------------------------------------------------------------------------------
@@ -270,6 +284,9 @@ class Hourglass128:
         self._conv("dec_model.4", ea[4], T.o5.view(n, 1, 1, nb), d[4], ups=4, out=T.o[4])
         for i in (3, 2, 1, 0):
             self._conv(f"dec_model.{i}", ea[i], T.o[i + 1], d[i], out=T.o[i])
+        if H5CONV and self.h5:
+            self._mask_head_fwd(n, A, T.o[0], T.hm, T.Z)
+            return
         self._conv("masker.0", A, T.o[0], self.mc, act="lrelu", out=T.hm)
         self._conv("masker.2", T.hm, None, 1, act="sigmoid", out_f32=True, out=T.Z.view(n, 128, 128, 1))
 
@@ -337,6 +354,8 @@ class Hourglass128:
             self._wgrad(T, plan, key, tag, n, hw, a, None, 2, dyf)
             if i > 0:
                 dp = self._dgrad(T, key, dyf, f"de{i - 1}_{tag}")
+            elif want_dx is not None and H5CONV and self.h5:
+                _lib.call("cgs_bf16_enc0_bwd_data", n, _p(dyf), _p(self._wview(key)[0]), _p(want_dx), _s())
             elif want_dx is not None:
                 ca = 3
                 _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, co, 0, ca, 0, 1, _lib.ACT_NONE, 0.01, 0, 1, _p(dyf), None, _p(self.w16T[key]),
@@ -345,15 +364,22 @@ class Hourglass128:
     def _masker_backward(self, T, plan, A):
         n, d, nb = T.n, self.d, self.nb
         ea = [t[n:2 * n] for t in T.e]
-        dz4 = T.buf("dz4", (n, 128, 128, 4), torch.bfloat16, self.dev)
-        _lib.call("cgs_bf16_convert", n * 16384, 1, 4, 0, _p(T.dzpre), _p(dz4), _s())
-        self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, dz4, dyc=4, dy_f32=T.dzpre)
-        dh = self._dgrad(T, "masker.2", dz4, "dhm", dy_channels=4)
-        _lib.call("cgs_bf16_lrelu_bwd", dh.numel(), _p(dh), _p(T.hm), 0.01, _s())
-        self._wgrad(T, plan, "masker.0", "m", n, 128, A, T.o[0], 2, dh)
-        dcat = self._dgrad(T, "masker.0", dh, "dcat_m0")
         do = T.buf("do0", (n, 64, 64, d[0]), torch.bfloat16, self.dev)
-        _lib.call("cgs_bf16_cat_split", n, 128, 3, d[0], 2, _p(dcat), None, _p(do), 0, _s())
+        if H5CONV and HWGRAD and self.h5:        # fp32 dz read directly; LeakyReLU' and the 2x2 cell sums in the data gradients' epilogues
+            self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, None, dy_f32=T.dzpre)
+            dh = T.buf("dhm", (n, 128, 128, 16), torch.bfloat16, self.dev)
+            _lib.call("cgs_bf16_mask2_bwd_data", n, _p(T.dzpre), _p(T.hm), _p(self._wview("masker.2")[0]), _p(dh), _s())
+            self._wgrad(T, plan, "masker.0", "m", n, 128, A, T.o[0], 2, dh)
+            _lib.call("cgs_bf16_mask0_bwd_data", n, _p(dh), _p(self._wview("masker.0")[0]), _p(do), _s())
+        else:
+            dz4 = T.buf("dz4", (n, 128, 128, 4), torch.bfloat16, self.dev)
+            _lib.call("cgs_bf16_convert", n * 16384, 1, 4, 0, _p(T.dzpre), _p(dz4), _s())
+            self._wgrad(T, plan, "masker.2", "m", n, 128, T.hm, None, 2, dz4, dyc=4, dy_f32=T.dzpre)
+            dh = self._dgrad(T, "masker.2", dz4, "dhm", dy_channels=4)
+            _lib.call("cgs_bf16_lrelu_bwd", dh.numel(), _p(dh), _p(T.hm), 0.01, _s())
+            self._wgrad(T, plan, "masker.0", "m", n, 128, A, T.o[0], 2, dh)
+            dcat = self._dgrad(T, "masker.0", dh, "dcat_m0")
+            _lib.call("cgs_bf16_cat_split", n, 128, 3, d[0], 2, _p(dcat), None, _p(do), 0, _s())
         skips = [None] * 5
         for i in (0, 1, 2, 3):
             key, hw = f"dec_model.{i}", 64 >> i

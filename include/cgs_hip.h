@@ -166,6 +166,19 @@ int cgs_mask_infer_fwd_f16o(int32_t n, int32_t src_a, const void* x, const void*
  * the MaxPool2d argmax bytes [n,64,64,8] of the training forward (cgs_bf16_pool_expand reads them).                                    */
 int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16, uint8_t* codes,
                       cgs_stream_t stream);
+/* The 128x128 layers of config 5's training step at chfak 1 on the whole-strip kernel in bfloat16 (csrc/hconv.hip, h5conv_kernel), with the
+ * step's element-wise neighbours fused; w_hwio / bias = the layer's fp32 master parameters [9][ci][co] / [co]:
+ *   cgs_bf16_mask0_fwd      hm bf16 [n,128,128,16] = LeakyReLU(conv3x3(cat(frames uint8 / 255, nearest-up2(o0 bf16 [n,64,64,8]))))
+ *   cgs_bf16_mask2_fwd      Z fp32 [n,128,128]     = Sigmoid(conv3x3(hm))
+ *   cgs_bf16_enc0_bwd_data  d frames fp32 [n,128,128,3] from d features.0 bf16 [n,128,128,8]
+ *   cgs_bf16_mask2_bwd_data d (masker.0 pre-activation) bf16 [n,128,128,16] = conv3x3^T(dz fp32 [n,128,128]) x LeakyReLU'(hm)
+ *   cgs_bf16_mask0_bwd_data d o0 bf16 [n,64,64,8] = 2x2 cell sums of conv3x3^T(dhm) over the upsampled source's channels             */
+int cgs_bf16_mask0_fwd(int32_t n, const uint8_t* x_u8, const void* o0_bf16, const float* w_hwio, const float* bias, void* hm_bf16,
+                       cgs_stream_t stream);
+int cgs_bf16_mask2_fwd(int32_t n, const void* hm_bf16, const float* w_hwio, const float* bias, float* z, cgs_stream_t stream);
+int cgs_bf16_enc0_bwd_data(int32_t n, const void* dy_bf16, const float* w_hwio, float* dx, cgs_stream_t stream);
+int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream);
+int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream);
 /* Weight + bias gradient of the large-map layers of config 5 at chfak 1 (csrc/hwgrad.hip; same arithmetic as cgs_bf16_conv3x3_bwd_weight):
  * (hw, ca, cb, co) = (128,3,0,8) features.0, (128,3,8,16) masker.0, (128,16,0,1) masker.2, (64,8,0,8) features.3, (64,8,8,8) dec_model.0.
  * cgs_bf16_hwgrad_slabs: slab rows written for n images (0: not a dedicated shape).  a_kind: 0 bf16 [n,hw,hw,ca], 1 uint8 / 2 fp32 frames

@@ -267,6 +267,62 @@ def test_bf16_enc0_whole_strip_kernel_vs_float64_conv(src):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("n", [3, 70])
+def test_h5conv_large_map_layers_vs_float64(n):
+    """The five 128x128 kernels of config 5's training step (h5conv_kernel, csrc/hconv.hip) vs float64 torch ops on the same bf16-rounded
+    operands: forward layers with their activations, data gradients with the fused LeakyReLU' factor / 2x2 cell sums.  bf16 outputs:
+    within half a bf16 ulp of the largest value (2^-8 relative to it); fp32 outputs: 1e-5.  n = 70: more strips than persistent
+    workgroups (every workgroup walks several)."""
+    from cgs_amd import _lib
+    _lib.load()
+    g = torch.Generator().manual_seed(500 + n)
+    hwio = lambda w: w.permute(2, 3, 1, 0).contiguous().cuda()
+    relmax = lambda got, ref: (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    # masker.0 forward
+    x = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=g)
+    o0 = torch.randn((n, 64, 64, 8), generator=g).to(torch.bfloat16)
+    w0 = torch.randn((16, 11, 3, 3), generator=g) * 0.2
+    b0 = torch.randn(16, generator=g) * 0.1
+    x_g, o0_g, w0_g, b0_g = x.cuda(), o0.cuda(), hwio(w0), b0.cuda()
+    hm_g = torch.full((n, 128, 128, 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_mask0_fwd", n, P(x_g), P(o0_g), P(w0_g), P(b0_g), P(hm_g), S())
+    cat = cat_up(bf(x.double() / 255.0).permute(0, 3, 1, 2), o0.double().permute(0, 3, 1, 2), 2)
+    ref = F.leaky_relu(F.conv2d(cat, bf(w0), b0.double(), padding=1), 0.01).permute(0, 2, 3, 1)
+    assert relmax(hm_g, ref) <= 2.0 ** -8
+    # masker.2 forward (on the kernel's own hm)
+    w2 = torch.randn((1, 16, 3, 3), generator=g) * 0.1
+    b2 = torch.randn(1, generator=g) * 0.1
+    w2_g, b2_g = hwio(w2), b2.cuda()
+    z_g = torch.full((n, 128, 128), 7.0, device="cuda")
+    _lib.call("cgs_bf16_mask2_fwd", n, P(hm_g), P(w2_g), P(b2_g), P(z_g), S())
+    hm = hm_g.cpu()
+    refz = torch.sigmoid(F.conv2d(hm.double().permute(0, 3, 1, 2), bf(w2), b2.double(), padding=1))[:, 0]
+    assert (z_g.double().cpu() - refz).abs().max().item() <= 1e-5
+    # features.0 image gradient
+    dy = (torch.randn((n, 128, 128, 8), generator=g) * 0.1).to(torch.bfloat16)
+    we = torch.randn((8, 3, 3, 3), generator=g) * 0.3
+    dy_g, we_g = dy.cuda(), hwio(we)
+    dx_g = torch.full((n, 128, 128, 3), 7.0, device="cuda")
+    _lib.call("cgs_bf16_enc0_bwd_data", n, P(dy_g), P(we_g), P(dx_g), S())
+    refdx = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), bf(we), padding=1).permute(0, 2, 3, 1)
+    assert relmax(dx_g, refdx) <= 1e-5
+    # masker.2 data gradient x LeakyReLU'(hm)
+    dz = torch.randn((n, 128, 128), generator=g) * 0.1
+    dz_g = dz.cuda()
+    dhm_g = torch.full((n, 128, 128, 16), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_mask2_bwd_data", n, P(dz_g), P(hm_g), P(w2_g), P(dhm_g), S())
+    refdh = F.conv_transpose2d(bf(dz.double()).unsqueeze(1), bf(w2), padding=1).permute(0, 2, 3, 1)
+    refdh = torch.where(hm.double() > 0, refdh, 0.01 * refdh)
+    assert relmax(dhm_g, refdh) <= 2.0 ** -8
+    # masker.0 data gradient of the upsampled source, summed over the 2x2 cells
+    do_g = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_mask0_bwd_data", n, P(dhm_g), P(w0_g), P(do_g), S())
+    torch.cuda.synchronize()
+    dcat = F.conv_transpose2d(dhm_g.cpu().double().permute(0, 3, 1, 2), bf(w0), padding=1)[:, 3:]
+    refdo = dcat.reshape(n, 8, 64, 2, 64, 2).sum((3, 5)).permute(0, 2, 3, 1)
+    assert relmax(do_g, refdo) <= 2.0 ** -8
+
+
 def _grad_dicts(net):
     """The flat gradient buffer of Hourglass128 as (critic, masker) dicts in the oracle's shapes."""
     saved = net.flat.clone()
