@@ -11,6 +11,8 @@ LIB_PATH = os.environ.get("CGS_LIB_PATH") or os.path.join(HERE, "libcgs_hip.so")
 OK, ERR_UNSUPPORTED, ERR_BADARG = 0, -1, -2
 SRC_F32, SRC_U8, SRC_MIX = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
+H5_ENC1_FWD, H5_ENC1_BWD_DATA, H5_DEC0_FWD, H5_DEC0_BWD_SKIP, H5_DEC0_BWD_LOW = 1, 2, 3, 4, 5
+H5_ENC1_BWD_DATA_POOLED = 6      # cgs_bf16_h5conv (cgs_hip.h)
 
 vp = C.c_void_p
 i32 = C.c_int32
@@ -64,9 +66,12 @@ SIGNATURES = {
     "cgs_bf16_mask2_fwd": (i32, [i32, vp, vp, vp, vp, vp]),
     "cgs_bf16_enc0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
     "cgs_bf16_mask2_bwd_data": (i32, [i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_enc0_bwd_data_pooled": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "cgs_bf16_mask0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
+    "cgs_bf16_h5conv": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_bf16_hwgrad_slabs": (i32, [i32, i32, i32, i32, i32]),
     "cgs_bf16_hwgrad": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "cgs_bf16_hwgrad_pooled": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_train_fwd_partials": (i32, [i32]),
     "cgs_mask_train_fwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_train_fwd_packed": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

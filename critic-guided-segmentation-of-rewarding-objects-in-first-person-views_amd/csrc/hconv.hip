@@ -231,7 +231,7 @@ struct H5Params {
     const float* w;         // the layer's HWIO fp32 weights [9][CIL][COL]
     const float* bias;      // [CO] or NULL
     void* out;
-    uint8_t* codes;         // EPI_POOLMAX: argmax bytes or NULL
+    uint8_t* codes;         // EPI_POOLMAX: argmax bytes or NULL (written); APOOL: the argmax bytes of source A (read)
     const uint16_t* hm;     // EPI_LRELU_BWD: the layer's own output of the forward pass, bf16 [n,HW,HW,CO]
     int n, nstrips, a_f32;
 };
@@ -241,8 +241,10 @@ enum { EPI_PLAIN = 0, EPI_POOLMAX = 1, EPI_POOLSUM = 2, EPI_LRELU_BWD = 3 };
 // CA: LDS channels of source A (4 = rgb0 frames, 1 = fp32 single channel, 8 / 16 = bf16); CB: 0 / 8; CO: output channels of the kernel;
 // CIL, COL: the LAYER's input / output channels (weight strides); DGRAD: the kernel computes the data gradient of the layer with respect to
 // its input channels O0 .. O0 + CO - 1 (source = dY with COL channels); EPI / ACT: epilogue; OUT_F32: fp32 output (else bf16)
-template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_>
+template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_, bool APOOL_ = false>
 struct H5Cfg {
+    static constexpr bool APOOL = APOOL_;   // source A = a pooled gradient re-expanded while it is staged (a = dP bf16 [n,HW/2,HW/2,CA], b = the optional
+                                            // addend of the same shape, codes = the forward pass's argmax bytes): replaces cgs_bf16_pool_expand
     static constexpr int HW = HW_, TH = TH_, CA = CA_, CB = CB_, CO = CO_, CIL = CIL_, COL = COL_, O0 = O0_, EPI = EPI_, ACT = ACT_;
     static constexpr bool DGRAD = DGRAD_, OUT_F32 = OUT_F32_, POOL = EPI_ == EPI_POOLMAX || EPI_ == EPI_POOLSUM;
     static constexpr int CIN = CA + CB <= 1 ? 1 : (CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16));
@@ -295,72 +297,145 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     }
 
     for (int e = tid; e < XT / 8; e += 256) ((float4*)tile)[e] = f4zero();       // halo columns + padding channels: zero for every strip
-    __syncthreads();
 
+    // ---- staging, split: fetch = every global load of a strip issued back to back into registers (ONE memory round trip per strip, in
+    //      flight while the previous strip multiplies), commit = conversion + LDS stores.  Items: source A = 4 frame pixels (3 dwords /
+    //      3 float4), 4 fp32 pixels or 8 bf16 channels; source B = one low-resolution pixel (8 channels) -> the two tile pixels above it.
+    constexpr int GW = HW / 4;
+    constexpr int HP = HW / 2, PR = TH / 2 + 2;                                  // APOOL: pooled rows under a strip's tile
+    constexpr int NA = C::APOOL ? (PR * HP + 255) / 256 : (CA == 4 || CA == 1 ? (PH * GW + 255) / 256 : (PH * HW * (CA / 8) + 255) / 256);
+    constexpr int NAV = CA == 4 || C::APOOL ? 3 : 1;                             // float4 registers per item
+    static_assert(!C::APOOL || (CA == 8 && CB == 0), "pooled source: 8 channels");
+    constexpr int NBI = CB == 8 ? (PH * (HW / 2) + 255) / 256 : 1;
+    float4 ra[NA][NAV];
+    float4 rb[NBI];
+    auto fetch = [&](int strip) {
+        const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            if constexpr (C::APOOL) {
+                const int xp = e % HP, rp = e / HP, yp = row0 / 2 - 1 + rp;
+                const bool in = rp < PR && yp >= 0 && yp < HP;
+                const size_t gi = in ? ((size_t)img * HP + yp) * HP + xp : 0;
+                ra[i][0] = ((const float4*)P.a)[gi];
+                ra[i][1] = P.b ? ((const float4*)P.b)[gi] : f4zero();
+                const float2 cd = ((const float2*)P.codes)[gi];
+                ra[i][2] = make_float4(cd.x, cd.y, 0.f, 0.f);
+            } else if constexpr (CA == 4) {
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
+                if (P.a_f32) {
+                    const float4* sf = (const float4*)P.a;
+                    ra[i][0] = sf[gi]; ra[i][1] = sf[gi + 1]; ra[i][2] = sf[gi + 2];
+                } else {
+                    const uint32_t* su = (const uint32_t*)P.a;
+                    ra[i][0] = make_float4(__uint_as_float(su[gi]), __uint_as_float(su[gi + 1]), __uint_as_float(su[gi + 2]), 0.f);
+                }
+            } else if constexpr (CA == 1) {
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                ra[i][0] = ((const float4*)P.a)[in ? (((size_t)img * HW + y) * HW) / 4 + g : 0];
+            } else {
+                constexpr int NG = CA / 8;
+                const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                ra[i][0] = ((const float4*)P.a)[in ? (((size_t)img * HW + y) * HW + x) * NG + g : 0];
+            }
+        }
+        if constexpr (CB == 8) {
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const int e = tid + 256 * i, xc = e % (HW / 2), r = e / (HW / 2), y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                rb[i] = ((const float4*)P.b)[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + xc : 0];
+            }
+        }
+    };
+    auto commit = [&](int strip) {
+        const int row0 = (strip % STRIPS) * TH;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            if constexpr (C::APOOL) {           // one pooled pixel -> the 2 x 2 tile pixels above it: the gradient goes where the maximum was
+                const int xp = e % HP, rp = e / HP, yp = row0 / 2 - 1 + rp;
+                if (rp >= PR) continue;
+                const bool in = yp >= 0 && yp < HP;
+                const uint32_t dw[4] = {__float_as_uint(ra[i][0].x), __float_as_uint(ra[i][0].y), __float_as_uint(ra[i][0].z), __float_as_uint(ra[i][0].w)};
+                const uint32_t aw[4] = {__float_as_uint(ra[i][1].x), __float_as_uint(ra[i][1].y), __float_as_uint(ra[i][1].z), __float_as_uint(ra[i][1].w)};
+                const uint32_t cw[2] = {__float_as_uint(ra[i][2].x), __float_as_uint(ra[i][2].y)};
+                short sv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t sh = 16 * (c & 1);
+                    sv[c] = EL::cvt(__uint_as_float(((dw[c >> 1] >> sh) & 0xffffu) << 16) + __uint_as_float(((aw[c >> 1] >> sh) & 0xffffu) << 16));
+                }
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const int r = 2 * rp - 1 + (pos >> 1);
+                    if (r < 0 || r >= PH) continue;
+                    v8 v;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = in && ((cw[c >> 2] >> (8 * (c & 3))) & 255u) == (uint32_t)pos ? sv[c] : (short)0;
+                    *(v8*)(tile + ((size_t)r * PW + 1 + 2 * xp + (pos & 1)) * CIN) = v;
+                }
+            } else if constexpr (CA == 4) {
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                if (r >= PH) continue;
+                const bool in = y >= 0 && y < HW;
+                float f[12];
+                if (P.a_f32) {
+                    const float4 f0 = ra[i][0], f1 = ra[i][1], f2 = ra[i][2];
+                    f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
+                    f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
+                } else {
+                    const uint32_t d[3] = {__float_as_uint(ra[i][0].x), __float_as_uint(ra[i][0].y), __float_as_uint(ra[i][0].z)};
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const v4 v = in ? v4{EL::cvt(f[3 * j]), EL::cvt(f[3 * j + 1]), EL::cvt(f[3 * j + 2]), 0} : v4{0, 0, 0, 0};
+                    *(v4*)(tile + ((size_t)r * PW + 1 + 4 * g + j) * CIN) = v;
+                }
+            } else if constexpr (CA == 1) {     // (the tile row starts 2 bytes after an 8-byte boundary: four 2-byte stores)
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                if (r >= PH) continue;
+                const bool in = y >= 0 && y < HW;
+                const float4 v = in ? ra[i][0] : f4zero();
+                short* d = tile + (size_t)r * PW + 1 + 4 * g;
+                d[0] = EL::cvt(v.x); d[1] = EL::cvt(v.y); d[2] = EL::cvt(v.z); d[3] = EL::cvt(v.w);
+            } else {
+                constexpr int NG = CA / 8;
+                const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
+                if (r >= PH) continue;
+                const bool in = y >= 0 && y < HW;
+                *(float4*)(tile + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = in ? ra[i][0] : f4zero();
+            }
+        }
+        if constexpr (CB == 8) {
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) {
+                const int e = tid + 256 * i, xc = e % (HW / 2), r = e / (HW / 2), y = row0 + r - 1;
+                if (r >= PH) continue;
+                const bool in = y >= 0 && y < HW;
+                const float4 v = in ? rb[i] : f4zero();
+                short* d = tile + ((size_t)r * PW + 1 + 2 * xc) * CIN + CA;    // 8-byte aligned (CA = 4) or 16
+                const float2 lo = make_float2(v.x, v.y), hi = make_float2(v.z, v.w);
+                *(float2*)d = lo; *(float2*)(d + 4) = hi;
+                *(float2*)(d + CIN) = lo; *(float2*)(d + CIN + 4) = hi;
+            }
+        }
+    };
+
+    if ((int)blockIdx.x < P.nstrips) fetch(blockIdx.x);
+    __syncthreads();                                                             // (the zeroes above, before other threads stage the same addresses)
     for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
     const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
-    // ---- stage the tile (zero halo rows) ----
-    if constexpr (CA == 4) {                    // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item
-        constexpr int GW = HW / 4;
-#pragma unroll 2
-        for (int e = tid; e < PH * GW; e += 256) {
-            const int g = e % GW, r = e / GW, y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-            float f[12];
-            if (P.a_f32) {
-                const float4* sf = (const float4*)P.a;
-                const float4 f0 = sf[gi], f1 = sf[gi + 1], f2 = sf[gi + 2];
-                f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
-                f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
-            } else {
-                const uint32_t* su = (const uint32_t*)P.a;
-                const uint32_t d[3] = {su[gi], su[gi + 1], su[gi + 2]};
-#pragma unroll
-                for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const v4 v = in ? v4{EL::cvt(f[3 * j]), EL::cvt(f[3 * j + 1]), EL::cvt(f[3 * j + 2]), 0} : v4{0, 0, 0, 0};
-                *(v4*)(tile + ((size_t)r * PW + 1 + 4 * g + j) * CIN) = v;
-            }
-        }
-    } else if constexpr (CA == 1) {             // fp32 single channel: 4 pixels per item (the tile row starts 2 bytes after an 8-byte boundary)
-        constexpr int GW = HW / 4;
-        for (int e = tid; e < PH * GW; e += 256) {
-            const int g = e % GW, r = e / GW, y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            float4 v = ((const float4*)P.a)[in ? (((size_t)img * HW + y) * HW) / 4 + g : 0];
-            if (!in) v = f4zero();
-            short* d = tile + (size_t)r * PW + 1 + 4 * g;
-            d[0] = EL::cvt(v.x); d[1] = EL::cvt(v.y); d[2] = EL::cvt(v.z); d[3] = EL::cvt(v.w);
-        }
-    } else {
-        constexpr int NG = CA / 8;
-        const v8* src = (const v8*)P.a;
-#pragma unroll 2
-        for (int e = tid; e < PH * HW * NG; e += 256) {
-            const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            v8 v = src[in ? (((size_t)img * HW + y) * HW + x) * NG + g : 0];
-            if (!in) v = v8{0, 0, 0, 0, 0, 0, 0, 0};
-            *(v8*)(tile + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = v;
-        }
-    }
-    if constexpr (CB == 8) {                    // the nearest-upsampled bf16 source: channels CA .. CA + 7 of the pixel
-        const v8* sb = (const v8*)P.b;
-#pragma unroll 2
-        for (int e = tid; e < PH * HW; e += 256) {
-            const int x = e % HW, r = e / HW, y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            v8 v = sb[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1) : 0];
-            if (!in) v = v8{0, 0, 0, 0, 0, 0, 0, 0};
-            short* d = tile + ((size_t)r * PW + 1 + x) * CIN + CA;             // 8-byte aligned (CA = 4) or 16
-            *(v4*)d = v4{v[0], v[1], v[2], v[3]};
-            *(v4*)(d + 4) = v4{v[4], v[5], v[6], v[7]};
-        }
-    }
+    commit(strip);
     __syncthreads();
+    if (strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);            // in flight while this strip multiplies
 
     // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
 #pragma unroll 2
@@ -463,11 +538,19 @@ int h5_launch(H5Params P, hipStream_t st) {
 }
 
 //                      HW   TH  CA CB  CO CIL COL O0 DGRAD  EPI            ACT              OUT_F32
+using H5Enc0F  = H5Cfg<128, 16,  4, 0,  8,  3,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    false>;   // features.0 forward (+ argmax bytes)
 using H5Mask0F = H5Cfg<128,  8,  4, 8, 16, 11, 16, 0, false, EPI_PLAIN,     CGS_ACT_LRELU,   false>;   // masker.0 forward
 using H5Mask2F = H5Cfg<128,  8, 16, 0,  1, 16,  1, 0, false, EPI_PLAIN,     CGS_ACT_SIGMOID, true>;    // masker.2 forward
 using H5Enc0D  = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    true>;    // features.0: image gradient
+using H5Enc0DP = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    true,  true>;   // ... from the pooled gradient
 using H5Mask2D = H5Cfg<128, 16,  1, 0, 16, 16,  1, 0, true,  EPI_LRELU_BWD, CGS_ACT_NONE,    false>;   // masker.2: d hm (x LeakyReLU')
 using H5Mask0D = H5Cfg<128,  8, 16, 0,  8, 11, 16, 3, true,  EPI_POOLSUM,   CGS_ACT_NONE,    false>;   // masker.0: d o0 (2x2 cell sums)
+using H5Enc1F  = H5Cfg< 64, 16,  8, 0,  8,  8,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    false>;   // features.3 forward (+ argmax bytes)
+using H5Enc1D  = H5Cfg< 64, 16,  8, 0,  8,  8,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false>;   // features.3: d e0
+using H5Enc1DP = H5Cfg< 64, 16,  8, 0,  8,  8,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false, true>;   // ... from the pooled gradient
+using H5Dec0F  = H5Cfg< 64,  8,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.0 forward
+using H5Dec0DS = H5Cfg< 64, 16,  8, 0,  8, 16,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.0: d skip (e0)
+using H5Dec0DL = H5Cfg< 64, 16,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_ACT_NONE,    false>;   // dec_model.0: d o1 (2x2 cell sums)
 
 }  // namespace
 
@@ -493,7 +576,11 @@ extern "C" int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f
 extern "C" int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16,
                                  uint8_t* codes, cgs_stream_t stream) {
     if (n < 0 || !x || !w_hwio || !bias || !e0_bf16) return CGS_ERR_BADARG;
+#ifdef CGS_ENC0_OLD
     return hconv_launch<128, 4, 0, 16, true, false, ElBF16>(HConvParams{x, nullptr, w_hwio, bias, e0_bf16, n, 0, x_is_f32 ? 1 : 0, codes}, (hipStream_t)stream);
+#else
+    return h5_launch<H5Enc0F>(H5Params{x, nullptr, w_hwio, bias, e0_bf16, codes, nullptr, n, 0, x_is_f32 ? 1 : 0}, (hipStream_t)stream);
+#endif
 }
 
 // ---- config 5, the 128x128 layers of the training step (h5conv_kernel above); weights / bias: the layer's fp32 HWIO master parameters ----
@@ -513,6 +600,13 @@ extern "C" int cgs_bf16_enc0_bwd_data(int32_t n, const void* dy_bf16, const floa
     if (n < 0 || !dy_bf16 || !w_hwio || !dx) return CGS_ERR_BADARG;
     return h5_launch<H5Enc0D>(H5Params{dy_bf16, nullptr, w_hwio, nullptr, dx, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }
+// the same from the pooled gradient: dp bf16 [n,64,64,8] (+ addend or NULL), codes = the argmax bytes of the forward pass (no re-expanded copy)
+extern "C" int cgs_bf16_enc0_bwd_data_pooled(int32_t n, const void* dp_bf16, const void* addend_bf16, const uint8_t* codes, const float* w_hwio,
+                                             float* dx, cgs_stream_t stream) {
+    if (n < 0 || !dp_bf16 || !codes || !w_hwio || !dx) return CGS_ERR_BADARG;
+    return h5_launch<H5Enc0DP>(H5Params{dp_bf16, (const uint16_t*)addend_bf16, w_hwio, nullptr, dx, const_cast<uint8_t*>(codes), nullptr, n, 0, 0},
+                               (hipStream_t)stream);
+}
 // masker.2 data gradient through masker.0's LeakyReLU: dz fp32 [n,128,128] (pre-Sigmoid gradient), hm bf16 [n,128,128,16] -> d (masker.0
 // pre-activation) bf16 [n,128,128,16]
 extern "C" int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream) {
@@ -523,4 +617,22 @@ extern "C" int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* h
 extern "C" int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream) {
     if (n < 0 || !dhm_bf16 || !w_hwio || !do0_bf16) return CGS_ERR_BADARG;
     return h5_launch<H5Mask0D>(H5Params{dhm_bf16, nullptr, w_hwio, nullptr, do0_bf16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+}
+
+// The 64x64 layers of the same step (which: CGS_H5_*, cgs_hip.h): features.3 forward (src_a bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax
+// bytes) and data gradient (dy bf16 [n,64,64,8] -> d e0), dec_model.0 forward (cat(e0, nearest-up2(o1 bf16 [n,32,32,8])) -> o0) and its two
+// data gradients (d o0 bf16 [n,64,64,8] -> the skip gradient [n,64,64,8] / the cell-summed low-resolution gradient [n,32,32,8]).
+extern "C" int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, const void* src_b, const float* w_hwio, const float* bias, void* out,
+                               uint8_t* codes, cgs_stream_t stream) {
+    if (n < 0 || !src_a || !w_hwio || !out) return CGS_ERR_BADARG;
+    const H5Params P{src_a, (const uint16_t*)src_b, w_hwio, bias, out, codes, nullptr, n, 0, 0};
+    switch (which) {
+        case CGS_H5_ENC1_FWD: return bias ? h5_launch<H5Enc1F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_ENC1_BWD_DATA: return h5_launch<H5Enc1D>(P, (hipStream_t)stream);
+        case CGS_H5_ENC1_BWD_DATA_POOLED: return codes ? h5_launch<H5Enc1DP>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_DEC0_FWD: return bias && src_b ? h5_launch<H5Dec0F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_DEC0_BWD_SKIP: return h5_launch<H5Dec0DS>(P, (hipStream_t)stream);
+        case CGS_H5_DEC0_BWD_LOW: return h5_launch<H5Dec0DL>(P, (hipStream_t)stream);
+    }
+    return CGS_ERR_UNSUPPORTED;
 }

@@ -30,14 +30,17 @@ __device__ __forceinline__ hbf8_t pk8(hs4_t a, hs4_t b) {
 struct HWgParams {
     const void* a;          // CA == 4: uint8 or fp32 frames [n,HW,HW,3]; else bf16 NHWC [n,HW,HW,CA]
     const uint16_t* b;      // CB == 8: bf16 [n,HW/2,HW/2,8], nearest-upsampled; else NULL
-    const void* dy;         // CO > 1: bf16 [n,HW,HW,CO]; CO == 1: fp32 [n,HW,HW]
+    const void* dy;         // CO > 1: bf16 [n,HW,HW,CO]; CO == 1: fp32 [n,HW,HW]; DYPOOL: the pooled gradient bf16 [n,HW/2,HW/2,8]
+    const uint16_t* dy_add; // DYPOOL: optional addend of the pooled gradient (same shape) or NULL
+    const uint8_t* codes;   // DYPOOL: argmax bytes of the forward pass [n,HW/2,HW/2,8]
     float* slab;            // [blocks][9 (CA_real + CB) CO + CO]
     int n, nstrips, a_f32;
 };
 
 // HW: map size; CA: channels of source A in the LDS pixel (4 = rgb0 from uint8 / fp32 frames; 8 / 16 = bf16); CB: 0 / 8 (upsampled bf16
 // source); CO: output channels (1, 8, 16); TH: rows per strip
-template <int HW, int CA, int CB, int CO, int TH>
+// DYPOOL: dY = a pooled gradient re-expanded while it is staged (the gradient goes where the forward maximum was): replaces cgs_bf16_pool_expand
+template <int HW, int CA, int CB, int CO, int TH, bool DYPOOL = false>
 __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
     constexpr int CIN = CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16);             // channels of the LDS pixel
     constexpr int TPB = 16 / CIN, NB = (9 + TPB - 1) / TPB;                     // taps per 16-row block, row blocks
@@ -122,7 +125,32 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
             }
         }
         // ---- dY strip: contiguous in memory ----
-        if constexpr (CO == 1) {
+        if constexpr (DYPOOL) {
+            static_assert(!DYPOOL || CO == 8, "pooled gradient: 8 channels");
+            constexpr int HP = HW / 2;
+            for (int e = tid; e < (TH / 2) * HP; e += 256) {
+                const int xp = e % HP, rp = e / HP;
+                const size_t gi = ((size_t)img * HP + row0 / 2 + rp) * HP + xp;
+                const float4 d4 = ((const float4*)P.dy)[gi], a4 = P.dy_add ? ((const float4*)P.dy_add)[gi] : f4zero();
+                const float2 c2 = ((const float2*)P.codes)[gi];
+                const uint32_t dw[4] = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
+                const uint32_t aw[4] = {__float_as_uint(a4.x), __float_as_uint(a4.y), __float_as_uint(a4.z), __float_as_uint(a4.w)};
+                const uint32_t cw[2] = {__float_as_uint(c2.x), __float_as_uint(c2.y)};
+                short sv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const uint32_t sh = 16 * (c & 1);
+                    sv[c] = hbf(__uint_as_float(((dw[c >> 1] >> sh) & 0xffffu) << 16) + __uint_as_float(((aw[c >> 1] >> sh) & 0xffffu) << 16));
+                }
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    hs8_t v;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = ((cw[c >> 2] >> (8 * (c & 3))) & 255u) == (uint32_t)pos ? sv[c] : (short)0;
+                    *(hs8_t*)(dt + ((size_t)(2 * rp + (pos >> 1)) * HW + 2 * xp + (pos & 1)) * 8) = v;
+                }
+            }
+        } else if constexpr (CO == 1) {
             const float4* sd = (const float4*)((const float*)P.dy + ((size_t)img * HW + row0) * HW);
             for (int e = tid; e < TH * HW / 4; e += 256) {
                 const float4 v = sd[e];
@@ -177,7 +205,7 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
     }
 }
 
-template <int HW, int CA, int CB, int CO, int TH>
+template <int HW, int CA, int CB, int CO, int TH, bool DYPOOL = false>
 struct HWg {
     static constexpr int CIN = CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16), TPB = 16 / CIN, NB = (9 + TPB - 1) / TPB;
     static constexpr size_t tiles = (size_t)(((TH + 2) * (HW + 2) * CIN + 7) & ~7) * 2 + (size_t)TH * HW * CO * 2;
@@ -192,7 +220,7 @@ struct HWg {
     }
     static int launch(HWgParams P, hipStream_t st) {
         P.nstrips = P.n * (HW / TH);
-        auto k = hwgrad_kernel<HW, CA, CB, CO, TH>;
+        auto k = hwgrad_kernel<HW, CA, CB, CO, TH, DYPOOL>;
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
@@ -208,6 +236,8 @@ using HWgMask0 = HWg<128, 4, 8, 16, 4>;      // masker.0
 using HWgMask2 = HWg<128, 16, 0, 1, 4>;      // masker.2
 using HWgEnc1 = HWg<64, 8, 0, 8, 16>;        // features.3
 using HWgDec0 = HWg<64, 8, 8, 8, 8>;         // dec_model.0
+using HWgEnc0P = HWg<128, 4, 0, 8, 8, true>; // features.0 / features.3 from the pooled gradient + argmax bytes
+using HWgEnc1P = HWg<64, 8, 0, 8, 16, true>;
 
 int hwg_which(int hw, int ca, int cb, int co) {
     if (hw == 128 && ca == 3 && cb == 0 && co == 8) return 1;
@@ -242,7 +272,7 @@ extern "C" int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, in
     if (!which) return CGS_ERR_UNSUPPORTED;
     if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;                     // frames are uint8 / fp32, activations bf16
     if (n == 0) return CGS_OK;
-    const HWgParams P{src_a, (const uint16_t*)src_b, dy, slab, n, 0, a_kind == 2 ? 1 : 0};
+    const HWgParams P{src_a, (const uint16_t*)src_b, dy, nullptr, nullptr, slab, n, 0, a_kind == 2 ? 1 : 0};
     switch (which) {
         case 1: return HWgEnc0::launch(P, (hipStream_t)stream);
         case 2: return HWgMask0::launch(P, (hipStream_t)stream);
@@ -250,4 +280,17 @@ extern "C" int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, in
         case 4: return HWgEnc1::launch(P, (hipStream_t)stream);
         default: return HWgDec0::launch(P, (hipStream_t)stream);
     }
+}
+
+// The same for features.0 (hw 128, ca 3) / features.3 (hw 64, ca 8) with dY given as the pooled gradient dp bf16 [n,hw/2,hw/2,8] (+ addend of
+// the same shape or NULL) and the forward pass's argmax bytes: no re-expanded copy of dY in memory.  Slab rows: cgs_bf16_hwgrad_slabs(.., co = 8).
+extern "C" int cgs_bf16_hwgrad_pooled(int32_t n, int32_t hw, int32_t ca, int32_t a_kind, const void* src_a, const void* dp, const void* addend,
+                                      const uint8_t* codes, float* slab, cgs_stream_t stream) {
+    const int which = hwg_which(hw, ca, 0, 8);
+    if (n < 0 || !src_a || !dp || !codes || !slab || a_kind < 0 || a_kind > 2) return CGS_ERR_BADARG;
+    if (which != 1 && which != 4) return CGS_ERR_UNSUPPORTED;
+    if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const HWgParams P{src_a, nullptr, dp, (const uint16_t*)addend, codes, slab, n, 0, a_kind == 2 ? 1 : 0};
+    return which == 1 ? HWgEnc0P::launch(P, (hipStream_t)stream) : HWgEnc1P::launch(P, (hipStream_t)stream);
 }

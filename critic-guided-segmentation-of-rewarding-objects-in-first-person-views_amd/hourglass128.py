@@ -31,6 +31,7 @@ from . import parallel
 from .generic import _ACT, _p, _s
 
 H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
+POOL_FUSED = True           # ... and the pooled gradients of features.0 / features.3 re-expanded inside their consumers (no cgs_bf16_pool_expand)
 HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
 ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False: the generic bf16 convolution; r4 A/B)
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
@@ -175,6 +176,14 @@ class Hourglass128:
             w, bias = self._wview(key)
             _lib.call("cgs_bf16_enc0_fwd", n, _p(a), int(a_kind == 2), _p(w), _p(bias), _p(out), _p(codes), _s())
             return out
+        if H5CONV and self.h5 and w16 is None and not out_f32 and a_kind == 0:
+            w, bias = self._wview(key)
+            if key == "features.3" and (hw, ca, cb, co) == (64, 8, 0, 8) and pool and act == "relu":
+                _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_FWD, n, _p(a), None, _p(w), _p(bias), _p(out), _p(codes), _s())
+                return out
+            if key == "dec_model.0" and (hw, ca, cb, co, ups) == (64, 8, 8, 8, 2) and not pool and act == "none":
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_FWD, n, _p(a), _p(b), _p(w), _p(bias), _p(out), None, _s())
+                return out
         bias = self._wview(key)[1] if w16 is None else self._zero_bias(co)
         _lib.call("cgs_genbf16_conv3x3_fwd_train", n, hw, ca, cb, co, a_kind, ups, _ACT[act], 0.01, int(pool), int(out_f32), _p(a), _p(b),
                   _p(self.w16[key] if w16 is None else w16), _p(bias), _p(out), _p(codes), _s())
@@ -348,11 +357,31 @@ class Hourglass128:
         _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 0, _p(de4f), _p(dp), _s())
         for i in (4, 3, 2, 1, 0):
             key, hw, co = ENC_KEYS[i], ENC_HW[i], d[i]
+            if i <= 1 and H5CONV and HWGRAD and POOL_FUSED and self.h5:
+                # the 128x128 / 64x64 levels: weight and data gradient read the pooled gradient + argmax bytes (no re-expanded copy)
+                a = src if i == 0 else T.e[i - 1][lo:hi]
+                a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+                add, cod = (_p(skips[i]) if skips is not None else None), _p(T.codes[i][lo:hi])
+                nsl, cnt = self.lib.cgs_bf16_hwgrad_slabs(n, hw, self.convs[key][0], 0, 8), 9 * self.convs[key][0] * 8 + 8
+                slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
+                _lib.call("cgs_bf16_hwgrad_pooled", n, hw, self.convs[key][0], a_kind, _p(a), _p(dp), add, cod, _p(slab), _s())
+                plan.add(slab, nsl, cnt, self.off[key][0])
+                w = self._wview(key)[0]
+                if i == 1:
+                    de0 = T.buf(f"de0_{tag}", (n, 64, 64, d[0]), torch.bfloat16, self.dev)
+                    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED, n, _p(dp), add, _p(w), None, _p(de0), cod, _s())
+                    dp = de0
+                elif want_dx is not None:
+                    _lib.call("cgs_bf16_enc0_bwd_data_pooled", n, _p(dp), add, cod, _p(w), _p(want_dx), _s())
+                continue
             dyf = T.buf(f"dyf{i}_{tag}", (n, hw, hw, co), torch.bfloat16, self.dev)
             _lib.call("cgs_bf16_pool_expand", n, hw // 2, co, _p(dp), _p(skips[i]) if skips is not None else None, _p(T.codes[i][lo:hi]), _p(dyf), _s())
             a = src if i == 0 else T.e[i - 1][lo:hi]
             self._wgrad(T, plan, key, tag, n, hw, a, None, 2, dyf)
-            if i > 0:
+            if i == 1 and H5CONV and self.h5:
+                dp = T.buf(f"de0_{tag}", (n, 64, 64, d[0]), torch.bfloat16, self.dev)
+                _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA, n, _p(dyf), None, _p(self._wview(key)[0]), None, _p(dp), None, _s())
+            elif i > 0:
                 dp = self._dgrad(T, key, dyf, f"de{i - 1}_{tag}")
             elif want_dx is not None and H5CONV and self.h5:
                 _lib.call("cgs_bf16_enc0_bwd_data", n, _p(dyf), _p(self._wview(key)[0]), _p(want_dx), _s())
@@ -384,10 +413,16 @@ class Hourglass128:
         for i in (0, 1, 2, 3):
             key, hw = f"dec_model.{i}", 64 >> i
             self._wgrad(T, plan, key, "m", n, hw, ea[i], T.o[i + 1], 2, do)
-            dcat = self._dgrad(T, key, do, f"dcat_d{i}")
             skips[i] = T.buf(f"dskip{i}", (n, hw, hw, d[i]), torch.bfloat16, self.dev)
-            do = T.buf(f"do{i + 1}", (n, hw // 2, hw // 2, d[i + 1]), torch.bfloat16, self.dev)
-            _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(do), 0, _s())
+            dlow = T.buf(f"do{i + 1}", (n, hw // 2, hw // 2, d[i + 1]), torch.bfloat16, self.dev)
+            if i == 0 and H5CONV and self.h5:        # the two halves of d cat(e0, up(o1)) straight from the whole-strip kernel
+                w = self._wview(key)[0]
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_SKIP, n, _p(do), None, _p(w), None, _p(skips[i]), None, _s())
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_LOW, n, _p(do), None, _p(w), None, _p(dlow), None, _s())
+            else:
+                dcat = self._dgrad(T, key, do, f"dcat_d{i}")
+                _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(dlow), 0, _s())
+            do = dlow
         self._wgrad(T, plan, "dec_model.4", "m", n, 4, ea[4], T.o5, 4, do)
         dcat = self._dgrad(T, "dec_model.4", do, "dcat_d4")
         skips[4] = T.buf("dskip4", (n, 4, 4, d[4]), torch.bfloat16, self.dev)

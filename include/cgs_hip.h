@@ -177,8 +177,18 @@ int cgs_bf16_mask0_fwd(int32_t n, const uint8_t* x_u8, const void* o0_bf16, cons
                        cgs_stream_t stream);
 int cgs_bf16_mask2_fwd(int32_t n, const void* hm_bf16, const float* w_hwio, const float* bias, float* z, cgs_stream_t stream);
 int cgs_bf16_enc0_bwd_data(int32_t n, const void* dy_bf16, const float* w_hwio, float* dx, cgs_stream_t stream);
+int cgs_bf16_enc0_bwd_data_pooled(int32_t n, const void* dp_bf16, const void* addend_bf16, const uint8_t* codes, const float* w_hwio, float* dx,
+                                  cgs_stream_t stream);      /* the same from dP bf16 [n,64,64,8] (+ addend) and the forward argmax bytes */
 int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream);
 int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream);
+/* The 64x64 layers of the same step: features.3 forward (src_a = e0 bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax bytes) and data gradient
+ * (src_a = dy bf16 [n,64,64,8] -> d e0); dec_model.0 forward (cat(src_a = e0, nearest-up2(src_b = o1 bf16 [n,32,32,8])) -> o0 [n,64,64,8]) and
+ * its data gradients (src_a = d o0 [n,64,64,8] -> skip gradient [n,64,64,8] / cell-summed low-resolution gradient [n,32,32,8]).  bias NULL
+ * for the data gradients.                                                                                                            */
+enum { CGS_H5_ENC1_FWD = 1, CGS_H5_ENC1_BWD_DATA = 2, CGS_H5_DEC0_FWD = 3, CGS_H5_DEC0_BWD_SKIP = 4, CGS_H5_DEC0_BWD_LOW = 5,
+       CGS_H5_ENC1_BWD_DATA_POOLED = 6 /* src_a = dP bf16 [n,32,32,8], src_b = addend or NULL, codes = the forward argmax bytes (read) */ };
+int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, const void* src_b, const float* w_hwio, const float* bias, void* out,
+                    uint8_t* codes, cgs_stream_t stream);
 /* Weight + bias gradient of the large-map layers of config 5 at chfak 1 (csrc/hwgrad.hip; same arithmetic as cgs_bf16_conv3x3_bwd_weight):
  * (hw, ca, cb, co) = (128,3,0,8) features.0, (128,3,8,16) masker.0, (128,16,0,1) masker.2, (64,8,0,8) features.3, (64,8,8,8) dec_model.0.
  * cgs_bf16_hwgrad_slabs: slab rows written for n images (0: not a dedicated shape).  a_kind: 0 bf16 [n,hw,hw,ca], 1 uint8 / 2 fp32 frames
@@ -186,6 +196,10 @@ int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio
 int cgs_bf16_hwgrad_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co);
 int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, const void* src_a, const void* src_b,
                     const void* dy, float* slab, cgs_stream_t stream);
+/* features.0 (hw 128, ca 3) / features.3 (hw 64, ca 8) with dY given as the pooled gradient dp bf16 [n,hw/2,hw/2,8] (+ addend or NULL) and the
+ * forward pass's argmax bytes (what cgs_bf16_pool_expand would re-expand); slab rows = cgs_bf16_hwgrad_slabs(n, hw, ca, 0, 8).          */
+int cgs_bf16_hwgrad_pooled(int32_t n, int32_t hw, int32_t ca, int32_t a_kind, const void* src_a, const void* dp, const void* addend,
+                           const uint8_t* codes, float* slab, cgs_stream_t stream);
 
 /* ---- the 16x16-and-smaller layers, image by image inside one workgroup ("tail" kernels, csrc/tail.hip) ------------
  * Replace, for one critic pass / the decoder, the per-layer launches of features.6, features.10 (nets.py:176-183), the

@@ -323,6 +323,95 @@ def test_h5conv_large_map_layers_vs_float64(n):
     assert relmax(do_g, refdo) <= 2.0 ** -8
 
 
+def test_h5conv_64x64_layers_vs_float64():
+    """cgs_bf16_h5conv: features.3 forward (+ argmax bytes) / data gradient and dec_model.0 forward / its two data gradients vs float64
+    torch ops on the same bf16-rounded operands (bf16 outputs: 2^-8 of the largest value); n = 150: strips > persistent workgroups."""
+    from cgs_amd import _lib
+    _lib.load()
+    n = 150
+    g = torch.Generator().manual_seed(64)
+    hwio = lambda w: w.permute(2, 3, 1, 0).contiguous().cuda()
+    relmax = lambda got, ref: (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    e0 = torch.randn((n, 64, 64, 8), generator=g).to(torch.bfloat16)
+    e0[0, :8, :8] = 0.5
+    w = torch.randn((8, 8, 3, 3), generator=g) * 0.2
+    b = torch.randn(8, generator=g) * 0.1
+    e0_g, w_g, b_g = e0.cuda(), hwio(w), b.cuda()
+    e1_g = torch.full((n, 32, 32, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    codes = torch.full((n, 32, 32, 8), 99, device="cuda", dtype=torch.uint8)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_FWD, n, P(e0_g), None, P(w_g), P(b_g), P(e1_g), P(codes), S())
+    pre = F.relu(F.conv2d(e0.double().permute(0, 3, 1, 2), bf(w), b.double(), padding=1))
+    pooled, idx = F.max_pool2d(pre, 2, return_indices=True)
+    pooled = pooled.permute(0, 2, 3, 1)
+    ref_code = (((idx // 64) % 2) * 2 + (idx % 64) % 2).permute(0, 2, 3, 1)
+    ref_code = torch.where(pooled > 0, ref_code, torch.full_like(ref_code, 4))
+    got_code = codes.cpu().long()
+    assert (got_code == ref_code).double().mean().item() > 0.999 and torch.equal(got_code[0, 1:3, 1:3], ref_code[0, 1:3, 1:3])
+    assert relmax(e1_g, pooled) <= 2.0 ** -8
+    dy = (torch.randn((n, 64, 64, 8), generator=g) * 0.1).to(torch.bfloat16)
+    dy_g = dy.cuda()
+    de0_g = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA, n, P(dy_g), None, P(w_g), None, P(de0_g), None, S())
+    assert relmax(de0_g, F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), bf(w), padding=1).permute(0, 2, 3, 1)) <= 2.0 ** -8
+    o1 = torch.randn((n, 32, 32, 8), generator=g).to(torch.bfloat16)
+    wd = torch.randn((8, 16, 3, 3), generator=g) * 0.2
+    o1_g, wd_g = o1.cuda(), hwio(wd)
+    o0_g = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_FWD, n, P(e0_g), P(o1_g), P(wd_g), P(b_g), P(o0_g), None, S())
+    cat = cat_up(e0.double().permute(0, 3, 1, 2), o1.double().permute(0, 3, 1, 2), 2)
+    assert relmax(o0_g, F.conv2d(cat, bf(wd), b.double(), padding=1).permute(0, 2, 3, 1)) <= 2.0 ** -8
+    ds_g = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    dl_g = torch.full((n, 32, 32, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_SKIP, n, P(dy_g), None, P(wd_g), None, P(ds_g), None, S())
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_LOW, n, P(dy_g), None, P(wd_g), None, P(dl_g), None, S())
+    torch.cuda.synchronize()
+    dcat = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), bf(wd), padding=1)
+    assert relmax(ds_g, dcat[:, :8].permute(0, 2, 3, 1)) <= 2.0 ** -8
+    assert relmax(dl_g, dcat[:, 8:].reshape(n, 8, 32, 2, 32, 2).sum((3, 5)).permute(0, 2, 3, 1)) <= 2.0 ** -8
+
+
+@pytest.mark.parametrize("with_addend", [False, True])
+def test_pooled_gradient_consumers_are_bit_identical_to_pool_expand_then_kernel(with_addend):
+    """cgs_bf16_hwgrad_pooled / cgs_bf16_enc0_bwd_data_pooled / CGS_H5_ENC1_BWD_DATA_POOLED re-expand the pooled gradient while they stage
+    it: same bits as cgs_bf16_pool_expand followed by the kernel on the expanded tensor (which the tests above pin to float64)."""
+    from cgs_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(99)
+    for hw, ca, a_kind, n in ((128, 3, 1, 5), (128, 3, 2, 3), (64, 8, 0, 37)):
+        hp = hw // 2
+        if a_kind == 1:
+            a = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, generator=g).cuda()
+        elif a_kind == 2:
+            a = torch.rand((n, hw, hw, 3), generator=g).cuda()
+        else:
+            a = torch.randn((n, hw, hw, 8), generator=g).to(torch.bfloat16).cuda()
+        dp = (torch.randn((n, hp, hp, 8), generator=g) * 0.1).to(torch.bfloat16).cuda()
+        add = (torch.randn((n, hp, hp, 8), generator=g) * 0.1).to(torch.bfloat16).cuda() if with_addend else None
+        codes = torch.randint(0, 5, (n, hp, hp, 8), dtype=torch.uint8, generator=g).cuda()
+        w = (torch.randn((9, ca, 8), generator=g) * 0.3).cuda()
+        dyf = torch.empty((n, hw, hw, 8), device="cuda", dtype=torch.bfloat16)
+        _lib.call("cgs_bf16_pool_expand", n, hp, 8, P(dp), P(add), P(codes), P(dyf), S())
+        nsl, cnt = lib.cgs_bf16_hwgrad_slabs(n, hw, ca, 0, 8), 9 * ca * 8 + 8
+        s1 = torch.full((nsl, cnt), float("nan"), device="cuda")
+        s2 = torch.full((nsl, cnt), float("nan"), device="cuda")
+        _lib.call("cgs_bf16_hwgrad", n, hw, ca, 0, 8, a_kind, P(a), None, P(dyf), P(s1), S())
+        _lib.call("cgs_bf16_hwgrad_pooled", n, hw, ca, a_kind, P(a), P(dp), P(add), P(codes), P(s2), S())
+        torch.cuda.synchronize()
+        assert torch.isfinite(s1).all() and torch.equal(s1, s2)
+        if hw == 128:
+            d1 = torch.full((n, 128, 128, 3), 7.0, device="cuda")
+            d2 = torch.full((n, 128, 128, 3), 8.0, device="cuda")
+            _lib.call("cgs_bf16_enc0_bwd_data", n, P(dyf), P(w), P(d1), S())
+            _lib.call("cgs_bf16_enc0_bwd_data_pooled", n, P(dp), P(add), P(codes), P(w), P(d2), S())
+        else:
+            d1 = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+            d2 = torch.full((n, 64, 64, 8), 8.0, device="cuda", dtype=torch.bfloat16)
+            _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA, n, P(dyf), None, P(w), None, P(d1), None, S())
+            _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED, n, P(dp), P(add), P(w), None, P(d2), P(codes), S())
+        torch.cuda.synchronize()
+        assert torch.equal(d1, d2)
+
+
 def _grad_dicts(net):
     """The flat gradient buffer of Hourglass128 as (critic, masker) dicts in the oracle's shapes."""
     saved = net.flat.clone()
