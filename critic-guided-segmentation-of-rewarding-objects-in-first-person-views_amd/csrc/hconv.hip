@@ -263,30 +263,41 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     short* const tile = (short*)hsm;                                            // [PH][PW][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
 
-    // ---- weights -> registers: lane (row l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN, LDS channel k % CIN ----
-    v8 wa[NM];
+    // ---- weights -> registers: lane (row l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN, LDS channel k % CIN.
+    //      PAIR (8 output channels, short K): the 16-wide output side of the instruction holds TWO pixel tiles -- tile h of a pair is
+    //      multiplied by the weight set whose rows 8 h .. 8 h + 7 are the layer's (the other rows zero) into the SAME accumulator, so every
+    //      lane of the epilogue carries a real output (the per-tile instruction count, not the matrix rate, bounds these kernels) ----
+    constexpr bool PAIR = CO == 8 && CIN <= 8;
+    constexpr int NP = PAIR ? 2 : 1;
+    const int ocl = PAIR ? (l15 & 7) : l15;
+    v8 wa[NP][NM];
+#pragma unroll
+    for (int h = 0; h < NP; ++h)
 #pragma unroll
     for (int g = 0; g < NM; ++g)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
             int idx = -1;
-            if (tap < 9 && l15 < CO) {
+            if (tap < 9 && (PAIR ? (l15 >> 3) == h : l15 < CO)) {
                 if constexpr (C::DGRAD) {       // d x[ci = O0 + oc] = sum over (tap', co) of dY[p + off(tap')][co] W[8 - tap'][ci][co]
-                    if (c < C::COL) idx = ((8 - tap) * C::CIL + C::O0 + l15) * C::COL + c;
+                    if (c < C::COL) idx = ((8 - tap) * C::CIL + C::O0 + ocl) * C::COL + c;
                 } else {
                     const int cr = c < CA ? (c < C::CA_REAL ? c : -1) : (c < CA + CB ? C::CA_REAL + (c - CA) : -1);
-                    if (cr >= 0) idx = (tap * C::CIL + cr) * C::COL + l15;
+                    if (cr >= 0) idx = (tap * C::CIL + cr) * C::COL + ocl;
                 }
             }
-            wa[g][j] = EL::cvt(idx >= 0 ? P.w[idx] : 0.f);
+            wa[h][g][j] = EL::cvt(idx >= 0 ? P.w[idx] : 0.f);
         }
     float br[4] = {0.f, 0.f, 0.f, 0.f};
     float bl = 0.f;
     if (P.bias) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) br[r] = 4 * kq + r < CO ? P.bias[4 * kq + r] : 0.f;
-        bl = l15 < CO ? P.bias[l15] : 0.f;
+        for (int r = 0; r < 4; ++r) {
+            const int ch = PAIR ? (4 * kq + r) & 7 : 4 * kq + r;
+            br[r] = ch < CO ? P.bias[ch] : 0.f;
+        }
+        bl = ocl < CO ? P.bias[ocl] : 0.f;
     }
     int toff1[8];                               // CIN == 1: this lane's eight taps (8 kq + j, clamped: the weights of taps >= 9 are zero)
 #pragma unroll
@@ -438,9 +449,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     if (strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);            // in flight while this strip multiplies
 
     // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
-#pragma unroll 2
-    for (int t = wave; t < NT; t += 4) {
-        int y, x;                               // strip-local pixel of this lane
+    auto tile_pixel = [&](int t, int& y, int& x) {      // strip-local pixel of this lane in tile t
         if constexpr (C::POOL) {
             constexpr int TPR = HW / 8;
             const int wy = t / TPR, tx = t % TPR, win = l15 >> 2, pos = l15 & 3;
@@ -449,8 +458,14 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
             constexpr int TPR = HW / 16;
             y = t / TPR; x = 16 * (t % TPR) + l15;
         }
-        const short* pix = tile + ((size_t)y * PW + x) * CIN;                   // tap (0,0) of the lane's 3x3 window
+    };
+    for (int t = NP * wave; t < NT; t += 4 * NP) {
         frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+        int y, x;
+        tile_pixel(t + h, y, x);
+        const short* pix = tile + ((size_t)y * PW + x) * CIN;                   // tap (0,0) of the lane's 3x3 window
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
             v8 b;
@@ -471,14 +486,15 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 tp = tp < 9 ? tp : 8;
                 b = *(const v8*)(pix + ((tp / 3) * PW + tp % 3) * 16 + 8 * (kq & 1));
             }
-            if constexpr (C::POOL) acc = EL::mfma(b, wa[g], acc);               // D[pixel = 4 kq + r][oc = l15]: a lane's four values = one 2x2 window
-            else acc = EL::mfma(wa[g], b, acc);                                 // D[oc = 4 kq + r][pixel = l15]
+            if constexpr (C::POOL) acc = EL::mfma(b, wa[h][g], acc);            // D[pixel = 4 kq + r][oc = l15]: a lane's four values = one 2x2 window
+            else acc = EL::mfma(wa[h][g], b, acc);                              // D[oc = 4 kq + r][pixel = l15]
+        }
         }
         if constexpr (C::POOL) {
             constexpr int TPR = HW / 8;
-            const int wy = t / TPR, tx = t % TPR;
-            if (l15 < CO) {
-                const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * CO) + l15;
+            const int te = t + (PAIR ? l15 >> 3 : 0), wy = te / TPR, tx = te % TPR;     // the tile this lane's column belongs to
+            if (PAIR || l15 < CO) {
+                const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * CO) + ocl;
                 float m;
                 if constexpr (C::EPI == EPI_POOLSUM) m = (acc[0] + acc[1]) + (acc[2] + acc[3]);
                 else m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bl, 0.f);
@@ -494,8 +510,10 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                     }
                 }
             }
-        } else if (4 * kq < CO) {
-            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * CO) + 4 * kq;
+        } else if (PAIR || 4 * kq < CO) {
+            int y, x;
+            tile_pixel(t + (PAIR ? kq >> 1 : 0), y, x);                         // the tile this lane's rows belong to
+            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * CO) + (PAIR ? 4 * (kq & 1) : 4 * kq);
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

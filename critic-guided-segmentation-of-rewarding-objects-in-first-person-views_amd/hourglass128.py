@@ -30,6 +30,7 @@ from . import hourglass as hg
 from . import parallel
 from .generic import _ACT, _p, _s
 
+TAIL = True                 # the 16x16-and-smaller layers of chfak 1 (same shapes as the 64x64 model's) on the fp32 per-image tail kernels (csrc/tail.hip)
 H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
 POOL_FUSED = True           # ... and the pooled gradients of features.0 / features.3 re-expanded inside their consumers (no cgs_bf16_pool_expand)
 HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
@@ -37,6 +38,7 @@ ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False:
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
 ENC_HW = (128, 64, 32, 16, 8)            # pre-pool map size of the five encoder stages
 GEMM_KEYS = ("features.17", "crit.1", "crit.4")
+_NODROP = _lib.Dropout(0.0, 0, 0, None, 0, 0)        # Dropout off (the tail kernels take the 64x64 model's three sites)
 
 
 def _hwio(w: torch.Tensor) -> torch.Tensor:
@@ -57,6 +59,7 @@ class Hourglass128:
         d = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak]
         self.d, self.nb, self.mc = d, neck * chfak, masker_channels
         self.h5 = chfak == 1 and masker_channels == 16       # the dedicated 128x128 kernels are compiled for these channel counts
+        self.tail = self.h5 and neck == 32                   # ... and the tail kernels for the 64x64 model's 16x16-and-smaller shapes
         nb = self.nb
         self.lr, self.b1, self.b2, self.eps, self.lfak, self.L1, self.L2 = lr, betas[0], betas[1], eps, lfak, L1, L2
         self.pg = process_group
@@ -219,15 +222,34 @@ class Hourglass128:
             raise _lib.CgsError("Hourglass128.infer reads uint8 frames [n,128,128,3] (NHWC, contiguous, on the device)")
         n, d, nb = x_u8.shape[0], self.d, self.nb
         e, src = [], x_u8
-        for key, co in zip(ENC_KEYS, d):
-            src = self._conv(key, src, None, co, act="relu", pool=True)
-            e.append(src)
-        e5 = self._gemm("features.17", e[4].reshape(n, 16 * d[4]), 16 * d[4], nb, act="relu")
-        h1 = self._gemm("crit.1", e5, nb, nb, act="relu")
-        pred = self._gemm("crit.4", h1, nb, 1, act="sigmoid", out_bf16=False).reshape(n)
-        o = self._gemm("dec_model.5", e5, nb, nb)                                  # the 1x1 pointwise convolution: an MFMA GEMM
-        o = self._conv("dec_model.4", e[4], o.view(n, 1, 1, nb), d[4], ups=4)
-        for i in (3, 2, 1, 0):
+        if TAIL and self.tail:      # the 16x16-and-smaller levels: two fp32 per-image launches (csrc/tail.hip) instead of eleven
+            f32 = lambda *sh: torch.empty(sh, device=self.dev, dtype=torch.float32)
+            i32 = lambda *sh: torch.empty(sh, device=self.dev, dtype=torch.int32)
+            for i in (0, 1):
+                src = self._conv(ENC_KEYS[i], src, None, d[i], act="relu", pool=True)
+                e.append(src)
+            e2 = self._conv("features.6", src, None, d[2], act="relu", pool=True, out_f32=True)
+            e3, am3, e4, am4, e5, h1, pred, o5 = f32(n, 8, 8, 8), i32(n, 8, 8, 1), f32(n, 4, 4, 16), i32(n, 4, 4, 2), f32(n, 32), f32(n, 32), f32(n), f32(n, 32)
+            tw = self._tail_enc_w(True)
+            _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(e2), _p(e3), _p(am3), _p(e4), _p(am4), _p(e5), _p(h1), _p(pred), _p(o5),
+                      _NODROP, _NODROP, _NODROP, _s())
+            o4, o3, o2 = f32(n, 4, 4, 16), f32(n, 8, 8, 8), f32(n, 16, 16, 8)
+            tdw = self._tail_dec_w()
+            _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(e2), _p(e3), _p(e4), _p(o5), _p(o4), _p(o3), _p(o2), _s())
+            o = torch.empty((n, 16, 16, 8), device=self.dev, dtype=torch.bfloat16)
+            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(o2), _p(o), _s())
+            lower = (1, 0)
+        else:
+            for key, co in zip(ENC_KEYS, d):
+                src = self._conv(key, src, None, co, act="relu", pool=True)
+                e.append(src)
+            e5 = self._gemm("features.17", e[4].reshape(n, 16 * d[4]), 16 * d[4], nb, act="relu")
+            h1 = self._gemm("crit.1", e5, nb, nb, act="relu")
+            pred = self._gemm("crit.4", h1, nb, 1, act="sigmoid", out_bf16=False).reshape(n)
+            o = self._gemm("dec_model.5", e5, nb, nb)                              # the 1x1 pointwise convolution: an MFMA GEMM
+            o = self._conv("dec_model.4", e[4], o.view(n, 1, 1, nb), d[4], ups=4)
+            lower = (3, 2, 1, 0)
+        for i in lower:
             o = self._conv(f"dec_model.{i}", e[i], o, d[i])
         if H5CONV and self.h5:
             hm = torch.empty((n, 128, 128, 16), device=self.dev, dtype=torch.bfloat16)
@@ -256,6 +278,11 @@ class Hourglass128:
             self.e = [bf(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
             self.codes = [u8(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
             self.e4f = f32(n4, 16 * d[4])
+            if TAIL and net.tail:       # fp32 activations of the levels the tail kernels own (their names: e1 e2 am2 e3 am3 | o4 o3 o2 o1)
+                i32 = lambda *s: torch.empty(s, device=dev, dtype=torch.int32)
+                self.t_e2, self.t_e3, self.t_am3 = f32(n4, 16, 16, 8), f32(n4, 8, 8, 8), i32(n4, 8, 8, 1)
+                self.t_e4, self.t_am4 = f32(n4, 4, 4, 16), i32(n4, 4, 4, 2)
+                self.t_o5, self.t_o4, self.t_o3, self.t_o2 = f32(2 * n, 32), f32(n, 4, 4, 16), f32(n, 8, 8, 8), f32(n, 16, 16, 8)
             self.e5, self.h1, self.pred = f32(n4, nb), f32(n4, nb), f32(n4)
             # masker
             self.o5 = bf(n, nb)
@@ -274,8 +301,35 @@ class Hourglass128:
                 t = self.ws[name] = torch.empty(shape, device=dev, dtype=dtype)
             return t
 
-    def _critic_forward(self, T, src, lo: int, hi: int):
+    # ---- the fp32 tail kernels of the 64x64 model (csrc/tail.hip) on this model's identical lower levels:
+    #      theirs features.6 / .10 / .14, dec_model.4 (1x1) / .3 / .2 / .1  =  ours features.9 / .13 / .17, dec_model.5 / .4 / .3 / .2
+    def _tail_enc_w(self, with_pw: bool):
+        w = lambda k: self._wview(k)[0].data_ptr()
+        b = lambda k: self._wview(k)[1].data_ptr()
+        return _lib.TailEncWeights(w("features.9"), b("features.9"), w("features.13"), b("features.13"), w("features.17"), b("features.17"),
+                                   w("crit.1"), b("crit.1"), w("crit.4"), b("crit.4"),
+                                   w("dec_model.5") if with_pw else None, b("dec_model.5") if with_pw else None)
+
+    def _tail_dec_w(self):
+        w = lambda k: self._wview(k)[0].data_ptr()
+        b = lambda k: self._wview(k)[1].data_ptr()
+        return _lib.TailDecWeights(w("dec_model.4"), b("dec_model.4"), w("dec_model.3"), b("dec_model.3"), w("dec_model.2"), b("dec_model.2"))
+
+    def _critic_forward_tail(self, T, src, lo: int, hi: int, want_o5: bool):
+        n, d = hi - lo, self.d
+        x = src
+        for i in (0, 1):
+            x = self._conv(ENC_KEYS[i], x, None, d[i], act="relu", pool=True, out=T.e[i][lo:hi], codes=T.codes[i][lo:hi])
+        self._conv("features.6", x, None, d[2], act="relu", pool=True, out_f32=True, out=T.t_e2[lo:hi], codes=T.codes[2][lo:hi])
+        tw = self._tail_enc_w(want_o5)
+        _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(T.t_e2[lo:hi]), _p(T.t_e3[lo:hi]), _p(T.t_am3[lo:hi]), _p(T.t_e4[lo:hi]),
+                  _p(T.t_am4[lo:hi]), _p(T.e5[lo:hi]), _p(T.h1[lo:hi]), _p(T.pred[lo:hi]), _p(T.t_o5[lo:hi]) if want_o5 else None,
+                  _NODROP, _NODROP, _NODROP, _s())
+
+    def _critic_forward(self, T, src, lo: int, hi: int, want_o5: bool = False):
         """Critic on slots [lo, hi): src = the frames / mixes of those slots (uint8 or fp32 NHWC)."""
+        if TAIL and self.tail:
+            return self._critic_forward_tail(T, src, lo, hi, want_o5)
         n, d, nb = hi - lo, self.d, self.nb
         x = src
         for i, (key, co) in enumerate(zip(ENC_KEYS, d)):
@@ -289,9 +343,17 @@ class Hourglass128:
     def _masker_forward(self, T, A):
         n, d, nb = T.n, self.d, self.nb
         ea = [t[n:2 * n] for t in T.e]
-        self._gemm("dec_model.5", T.e5[n:2 * n], nb, nb, out=T.o5)
-        self._conv("dec_model.4", ea[4], T.o5.view(n, 1, 1, nb), d[4], ups=4, out=T.o[4])
-        for i in (3, 2, 1, 0):
+        if TAIL and self.tail:      # dec_model.5 came out of the critic's tail kernel; .4 / .3 / .2 in one launch, fp32
+            tdw = self._tail_dec_w()
+            _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(T.t_e2[n:2 * n]), _p(T.t_e3[n:2 * n]), _p(T.t_e4[n:2 * n]), _p(T.t_o5[n:2 * n]),
+                      _p(T.t_o4), _p(T.t_o3), _p(T.t_o2), _s())
+            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(T.t_o2), _p(T.o[2]), _s())
+            lower = (1, 0)
+        else:
+            self._gemm("dec_model.5", T.e5[n:2 * n], nb, nb, out=T.o5)
+            self._conv("dec_model.4", ea[4], T.o5.view(n, 1, 1, nb), d[4], ups=4, out=T.o[4])
+            lower = (3, 2, 1, 0)
+        for i in lower:
             self._conv(f"dec_model.{i}", ea[i], T.o[i + 1], d[i], out=T.o[i])
         if H5CONV and self.h5:
             self._mask_head_fwd(n, A, T.o[0], T.hm, T.Z)
@@ -341,9 +403,8 @@ class Hourglass128:
         gen.gemm_ex(n, m, k, g, m, 1, w, 1, m, dx)                                                                # g . W^T
         return dx
 
-    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None):
-        """Backward of the critic on slots [lo, hi) from T.dpred; skips = [dskip_0..4] gradients arriving at the embeds from the
-        decoder (bf16), d_e5_add fp32 [n,nb]; want_dx: fp32 [n,128,128,3] output for the image gradient."""
+    def _head_backward(self, T, plan, tag, lo, hi, d_e5_add):
+        """The critic head's backward as GEMMs (the path without the tail kernels): returns d e4 (pooled, bf16)."""
         n, d, nb = hi - lo, self.d, self.nb
         dz = T.buf(f"dz_{tag}", (n, 1), torch.float32, self.dev)
         dz.copy_(T.dpred[lo:hi].reshape(n, 1))
@@ -355,7 +416,44 @@ class Hourglass128:
         de4f = self._gemm_bwd(T, plan, "features.17", tag, T.e4f[lo:hi], de5)
         dp = T.buf(f"dp4_{tag}", (n, 4, 4, d[4]), torch.bfloat16, self.dev)
         _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 0, _p(de4f), _p(dp), _s())
-        for i in (4, 3, 2, 1, 0):
+        return dp
+
+    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None, plan_pw=None):
+        """Backward of the critic on slots [lo, hi) from T.dpred; skips = [dskip_0..4] gradients arriving at the embeds from the
+        decoder (bf16), d_e5_add fp32 [n,nb]; want_dx: fp32 [n,128,128,3] output for the image gradient."""
+        n, d, nb = hi - lo, self.d, self.nb
+        if TAIL and self.tail:
+            # head + features.13 + features.9 in one launch from dpred: d e2 (fp32, the decoder's skip gradient included); skips[2..4] / d_e5_add
+            # are the fp32 tensors cgs_tail_dec_bwd left (dE1 dE2 dE3 / d_o4 in its names)
+            f32 = torch.float32
+            nsl = self.lib.cgs_tail_enc_bwd_slabs(n)
+            sl13, sl9 = T.buf(f"slab_t13_{tag}", (nsl, 1168), f32, self.dev), T.buf(f"slab_t9_{tag}", (nsl, 584), f32, self.dev)
+            hvec, de2 = T.buf(f"hvec_{tag}", (n, 384), f32, self.dev), T.buf(f"de2f_{tag}", (n, 16, 16, 8), f32, self.dev)
+            has = skips is not None
+            tw = self._tail_enc_w(has)
+            _lib.call("cgs_tail_enc_bwd", n, C.byref(tw), _p(T.t_e2[lo:hi]), _p(T.t_e3[lo:hi]), _p(T.t_am3[lo:hi]), _p(T.t_e4[lo:hi]),
+                      _p(T.t_am4[lo:hi]), _p(T.e5[lo:hi]), _p(T.h1[lo:hi]), _p(T.pred[lo:hi]), _p(T.dpred[lo:hi]), None, 0.0, 0,
+                      _p(skips[2]) if has else None, _p(skips[3]) if has else None, _p(skips[4]) if has else None,
+                      _p(d_e5_add) if has else None, n if has else 0, _p(de2), _p(hvec), _p(sl13), _p(sl9), _NODROP, _NODROP, _NODROP, _s())
+            plan.add(sl13, nsl, 1168, self.off["features.13"][0])
+            plan.add(sl9, nsl, 584, self.off["features.9"][0])
+            nh = self.lib.cgs_tail_head_wgrad_slabs(n)
+            slh = T.buf(f"slab_thead_{tag}", (nh, hg.HEAD_SLAB), f32, self.dev)
+            slpw = T.buf(f"slab_tpw_{tag}", (nh, hg.PW_SLAB), f32, self.dev) if has else None
+            _lib.call("cgs_tail_head_wgrad", n, _p(hvec), _p(T.e5[lo:hi]), _p(d_e5_add) if has else None, n if has else 0,
+                      0, None, None, None, 0, _p(slh), _p(slpw), _s())
+            plan.add(slh, nh, hg.HEAD_SLAB, self.off["features.17"][0])
+            if has:
+                (plan_pw or plan).add(slpw, nh, hg.PW_SLAB, self.off["dec_model.5"][0])      # (a masker parameter: the overwriting plan)
+            dp = T.buf(f"dp2_{tag}", (n, 16, 16, d[2]), torch.bfloat16, self.dev)
+            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(de2), _p(dp), _s())
+            levels = (2, 1, 0)
+            if has:
+                skips = [skips[0], skips[1], None, None, None]
+        else:
+            levels = (4, 3, 2, 1, 0)
+            dp = self._head_backward(T, plan, tag, lo, hi, d_e5_add)
+        for i in levels:
             key, hw, co = ENC_KEYS[i], ENC_HW[i], d[i]
             if i <= 1 and H5CONV and HWGRAD and POOL_FUSED and self.h5:
                 # the 128x128 / 64x64 levels: weight and data gradient read the pooled gradient + argmax bytes (no re-expanded copy)
@@ -410,19 +508,36 @@ class Hourglass128:
             dcat = self._dgrad(T, "masker.0", dh, "dcat_m0")
             _lib.call("cgs_bf16_cat_split", n, 128, 3, d[0], 2, _p(dcat), None, _p(do), 0, _s())
         skips = [None] * 5
-        for i in (0, 1, 2, 3):
+        tail = TAIL and self.tail
+        for i in ((0, 1) if tail else (0, 1, 2, 3)):
             key, hw = f"dec_model.{i}", 64 >> i
             self._wgrad(T, plan, key, "m", n, hw, ea[i], T.o[i + 1], 2, do)
             skips[i] = T.buf(f"dskip{i}", (n, hw, hw, d[i]), torch.bfloat16, self.dev)
-            dlow = T.buf(f"do{i + 1}", (n, hw // 2, hw // 2, d[i + 1]), torch.bfloat16, self.dev)
+            low_f32 = tail and i == 1        # the tail kernel below reads its d o (16x16) in fp32
+            dlow = T.buf(f"do{i + 1}" + ("f" if low_f32 else ""), (n, hw // 2, hw // 2, d[i + 1]), torch.float32 if low_f32 else torch.bfloat16, self.dev)
             if i == 0 and H5CONV and self.h5:        # the two halves of d cat(e0, up(o1)) straight from the whole-strip kernel
                 w = self._wview(key)[0]
                 _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_SKIP, n, _p(do), None, _p(w), None, _p(skips[i]), None, _s())
                 _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_LOW, n, _p(do), None, _p(w), None, _p(dlow), None, _s())
             else:
                 dcat = self._dgrad(T, key, do, f"dcat_d{i}")
-                _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(dlow), 0, _s())
+                _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(dlow), int(low_f32), _s())
             do = dlow
+        if tail:        # dec_model.2 / .3 / .4 backward in one launch (fp32): skip gradients at e2 / e3 / e4 and d o5
+            f32 = torch.float32
+            nsl = self.lib.cgs_tail_dec_bwd_slabs(n)
+            cnts = {"dec_model.4": 6912 + 16, "dec_model.3": 1728 + 8, "dec_model.2": 1152 + 8}
+            sl = {k: T.buf(f"slab_t_{k}", (nsl, c), f32, self.dev) for k, c in cnts.items()}
+            skips[2], skips[3], skips[4] = (T.buf("dE2f", (n, 16, 16, 8), f32, self.dev), T.buf("dE3f", (n, 8, 8, 8), f32, self.dev),
+                                            T.buf("dE4f", (n, 4, 4, 16), f32, self.dev))
+            do5 = T.buf("do5", (n, nb), f32, self.dev)
+            tdw = self._tail_dec_w()
+            _lib.call("cgs_tail_dec_bwd", n, C.byref(tdw), _p(T.t_e2[n:2 * n]), _p(T.t_e3[n:2 * n]), _p(T.t_e4[n:2 * n]), _p(T.t_o5[n:2 * n]),
+                      _p(T.t_o4), _p(T.t_o3), _p(do), _p(skips[2]), _p(skips[3]), _p(skips[4]), _p(do5),
+                      _p(sl["dec_model.4"]), _p(sl["dec_model.3"]), _p(sl["dec_model.2"]), _s())
+            for k, c in cnts.items():
+                plan.add(sl[k], nsl, c, self.off[k][0])
+            return skips, do5          # dec_model.5's backward runs in the A pass's tail kernel (cgs_tail_enc_bwd, d_o4)
         self._wgrad(T, plan, "dec_model.4", "m", n, 4, ea[4], T.o5, 4, do)
         dcat = self._dgrad(T, "dec_model.4", do, "dcat_d4")
         skips[4] = T.buf("dskip4", (n, 4, 4, d[4]), torch.bfloat16, self.dev)
@@ -434,7 +549,7 @@ class Hourglass128:
     def _phase2_body(self, T):
         n = T.n
         A, B = T.ab[n:], T.ab[:n]
-        self._critic_forward(T, T.ab, 0, 2 * n)
+        self._critic_forward(T, T.ab, 0, 2 * n, want_o5=True)
         self._masker_forward(T, A)
         _lib.call("cgs_mix_fwd", n, 16384, _p(A), _p(B), _p(T.Z), 1, _p(T.mixed), _p(T.zsum), _s())
         self._critic_forward(T, T.mixed, 2 * n, 4 * n)
@@ -446,7 +561,7 @@ class Hourglass128:
         self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
         _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
         skips, de5 = self._masker_backward(T, pa, A)
-        self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips)
+        self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips, plan_pw=pa)
         if first:
             T.plan_a, T.plan_b = pa.build(self.grad), pb.build(self.grad, accumulate=True)
         T.plan_a.run(None)
