@@ -569,6 +569,11 @@ using H5Enc1DP = H5Cfg< 64, 16,  8, 0,  8,  8,  8, 0, true,  EPI_PLAIN,     CGS_
 using H5Dec0F  = H5Cfg< 64,  8,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.0 forward
 using H5Dec0DS = H5Cfg< 64, 16,  8, 0,  8, 16,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.0: d skip (e0)
 using H5Dec0DL = H5Cfg< 64, 16,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_ACT_NONE,    false>;   // dec_model.0: d o1 (2x2 cell sums)
+using H5Enc2F  = H5Cfg< 32, 32,  8, 0,  8,  8,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    true>;    // features.6 forward -> fp32 (the tail kernels' input)
+using H5Enc2DP = H5Cfg< 32, 32,  8, 0,  8,  8,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false, true>;   // features.6: d e1 from the pooled gradient
+using H5Dec1F  = H5Cfg< 32, 16,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.1 forward
+using H5Dec1DS = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.1: d skip (e1)
+using H5Dec1DL = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_ACT_NONE,    true>;    // dec_model.1: d o2 (2x2 cell sums, fp32: the tail kernels' input)
 
 }  // namespace
 
@@ -637,7 +642,7 @@ extern "C" int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const fl
     return h5_launch<H5Mask0D>(H5Params{dhm_bf16, nullptr, w_hwio, nullptr, do0_bf16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }
 
-// The 64x64 layers of the same step (which: CGS_H5_*, cgs_hip.h): features.3 forward (src_a bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax
+// The 64x64 and 32x32 layers of the same step (which: CGS_H5_*, cgs_hip.h; the 32x32 forms: same roles one level down, see the header): features.3 forward (src_a bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax
 // bytes) and data gradient (dy bf16 [n,64,64,8] -> d e0), dec_model.0 forward (cat(e0, nearest-up2(o1 bf16 [n,32,32,8])) -> o0) and its two
 // data gradients (d o0 bf16 [n,64,64,8] -> the skip gradient [n,64,64,8] / the cell-summed low-resolution gradient [n,32,32,8]).
 extern "C" int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, const void* src_b, const float* w_hwio, const float* bias, void* out,
@@ -651,6 +656,11 @@ extern "C" int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, cons
         case CGS_H5_DEC0_FWD: return bias && src_b ? h5_launch<H5Dec0F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
         case CGS_H5_DEC0_BWD_SKIP: return h5_launch<H5Dec0DS>(P, (hipStream_t)stream);
         case CGS_H5_DEC0_BWD_LOW: return h5_launch<H5Dec0DL>(P, (hipStream_t)stream);
+        case CGS_H5_ENC2_FWD: return bias ? h5_launch<H5Enc2F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_ENC2_BWD_DATA_POOLED: return codes ? h5_launch<H5Enc2DP>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_DEC1_FWD: return bias && src_b ? h5_launch<H5Dec1F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_DEC1_BWD_SKIP: return h5_launch<H5Dec1DS>(P, (hipStream_t)stream);
+        case CGS_H5_DEC1_BWD_LOW: return h5_launch<H5Dec1DL>(P, (hipStream_t)stream);
     }
     return CGS_ERR_UNSUPPORTED;
 }

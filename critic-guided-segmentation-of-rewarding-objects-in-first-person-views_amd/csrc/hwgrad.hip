@@ -1,6 +1,6 @@
 // Weight + bias gradient of the LARGE-MAP 3x3 layers of BASELINE config 5 (the build-defined 128x128 Hourglass, hourglass128.py, chfak 1):
-// features.0 (3 -> 8 at 128x128), masker.0 (3 + 8 -> 16 at 128x128), masker.2 (16 -> 1 at 128x128), features.3 (8 -> 8 at 64x64) and
-// dec_model.0 (8 + 8 -> 8 at 64x64) -- 86 % of the weight-gradient time of the step on the shape-generic bf16_wgrad_kernel
+// features.0 (3 -> 8 at 128x128), masker.0 (3 + 8 -> 16 at 128x128), masker.2 (16 -> 1 at 128x128), features.3 (8 -> 8 at 64x64),
+// dec_model.0 (8 + 8 -> 8 at 64x64) and their 32x32 counterparts features.6 / dec_model.1 -- 86 % of the weight-gradient time of the step on the shape-generic bf16_wgrad_kernel
 // (gen_bf16_train.hip: run-time shapes, 2 workgroups per CU, taps dealt to the waves so every wave re-reads dY).  Same arithmetic
 // (bf16 operands, fp32 accumulation on v_mfma_f32_16x16x32_bf16 with K = 32 pixels through ds_read_b64_tr_b16), built like hconv.hip:
 //   * compile-time shapes, workgroups persistent over row strips of one image, 3-4 workgroups per CU (one stages while another multiplies);
@@ -238,6 +238,9 @@ using HWgEnc1 = HWg<64, 8, 0, 8, 16>;        // features.3
 using HWgDec0 = HWg<64, 8, 8, 8, 8>;         // dec_model.0
 using HWgEnc0P = HWg<128, 4, 0, 8, 8, true>; // features.0 / features.3 from the pooled gradient + argmax bytes
 using HWgEnc1P = HWg<64, 8, 0, 8, 16, true>;
+using HWgEnc2 = HWg<32, 8, 0, 8, 32>;        // features.6 / dec_model.1: one image per strip
+using HWgEnc2P = HWg<32, 8, 0, 8, 32, true>;
+using HWgDec1 = HWg<32, 8, 8, 8, 32>;
 
 int hwg_which(int hw, int ca, int cb, int co) {
     if (hw == 128 && ca == 3 && cb == 0 && co == 8) return 1;
@@ -245,6 +248,8 @@ int hwg_which(int hw, int ca, int cb, int co) {
     if (hw == 128 && ca == 16 && cb == 0 && co == 1) return 3;
     if (hw == 64 && ca == 8 && cb == 0 && co == 8) return 4;
     if (hw == 64 && ca == 8 && cb == 8 && co == 8) return 5;
+    if (hw == 32 && ca == 8 && cb == 0 && co == 8) return 6;
+    if (hw == 32 && ca == 8 && cb == 8 && co == 8) return 7;
     return 0;
 }
 
@@ -259,6 +264,8 @@ extern "C" int cgs_bf16_hwgrad_slabs(int32_t n, int32_t hw, int32_t ca, int32_t 
         case 3: return HWgMask2::blocks(n);
         case 4: return HWgEnc1::blocks(n);
         case 5: return HWgDec0::blocks(n);
+        case 6: return HWgEnc2::blocks(n);
+        case 7: return HWgDec1::blocks(n);
     }
     return 0;
 }
@@ -278,7 +285,9 @@ extern "C" int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, in
         case 2: return HWgMask0::launch(P, (hipStream_t)stream);
         case 3: return HWgMask2::launch(P, (hipStream_t)stream);
         case 4: return HWgEnc1::launch(P, (hipStream_t)stream);
-        default: return HWgDec0::launch(P, (hipStream_t)stream);
+        case 5: return HWgDec0::launch(P, (hipStream_t)stream);
+        case 6: return HWgEnc2::launch(P, (hipStream_t)stream);
+        default: return HWgDec1::launch(P, (hipStream_t)stream);
     }
 }
 
@@ -288,9 +297,9 @@ extern "C" int cgs_bf16_hwgrad_pooled(int32_t n, int32_t hw, int32_t ca, int32_t
                                       const uint8_t* codes, float* slab, cgs_stream_t stream) {
     const int which = hwg_which(hw, ca, 0, 8);
     if (n < 0 || !src_a || !dp || !codes || !slab || a_kind < 0 || a_kind > 2) return CGS_ERR_BADARG;
-    if (which != 1 && which != 4) return CGS_ERR_UNSUPPORTED;
+    if (which != 1 && which != 4 && which != 6) return CGS_ERR_UNSUPPORTED;
     if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     const HWgParams P{src_a, nullptr, dp, (const uint16_t*)addend, codes, slab, n, 0, a_kind == 2 ? 1 : 0};
-    return which == 1 ? HWgEnc0P::launch(P, (hipStream_t)stream) : HWgEnc1P::launch(P, (hipStream_t)stream);
+    return which == 1 ? HWgEnc0P::launch(P, (hipStream_t)stream) : (which == 4 ? HWgEnc1P::launch(P, (hipStream_t)stream) : HWgEnc2P::launch(P, (hipStream_t)stream));
 }

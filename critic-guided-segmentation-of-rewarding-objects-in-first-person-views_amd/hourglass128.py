@@ -179,8 +179,16 @@ class Hourglass128:
             w, bias = self._wview(key)
             _lib.call("cgs_bf16_enc0_fwd", n, _p(a), int(a_kind == 2), _p(w), _p(bias), _p(out), _p(codes), _s())
             return out
+        if H5CONV and self.h5 and w16 is None and out_f32 and a_kind == 0 and key == "features.6" and (hw, ca, cb, co) == (32, 8, 0, 8) and pool \
+                and act == "relu":       # (fp32 output: the tail kernels' input)
+            w, bias = self._wview(key)
+            _lib.call("cgs_bf16_h5conv", _lib.H5_ENC2_FWD, n, _p(a), None, _p(w), _p(bias), _p(out), _p(codes), _s())
+            return out
         if H5CONV and self.h5 and w16 is None and not out_f32 and a_kind == 0:
             w, bias = self._wview(key)
+            if key == "dec_model.1" and (hw, ca, cb, co, ups) == (32, 8, 8, 8, 2) and not pool and act == "none":
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC1_FWD, n, _p(a), _p(b), _p(w), _p(bias), _p(out), None, _s())
+                return out
             if key == "features.3" and (hw, ca, cb, co) == (64, 8, 0, 8) and pool and act == "relu":
                 _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_FWD, n, _p(a), None, _p(w), _p(bias), _p(out), _p(codes), _s())
                 return out
@@ -455,20 +463,21 @@ class Hourglass128:
             dp = self._head_backward(T, plan, tag, lo, hi, d_e5_add)
         for i in levels:
             key, hw, co = ENC_KEYS[i], ENC_HW[i], d[i]
-            if i <= 1 and H5CONV and HWGRAD and POOL_FUSED and self.h5:
-                # the 128x128 / 64x64 levels: weight and data gradient read the pooled gradient + argmax bytes (no re-expanded copy)
+            if (i <= 1 or (i == 2 and TAIL and self.tail)) and H5CONV and HWGRAD and POOL_FUSED and self.h5:
+                # the 128x128 / 64x64 (/ 32x32) levels: weight and data gradient read the pooled gradient + argmax bytes (no re-expanded copy)
                 a = src if i == 0 else T.e[i - 1][lo:hi]
                 a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
-                add, cod = (_p(skips[i]) if skips is not None else None), _p(T.codes[i][lo:hi])
+                add, cod = (_p(skips[i]) if skips is not None and skips[i] is not None else None), _p(T.codes[i][lo:hi])
                 nsl, cnt = self.lib.cgs_bf16_hwgrad_slabs(n, hw, self.convs[key][0], 0, 8), 9 * self.convs[key][0] * 8 + 8
                 slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
                 _lib.call("cgs_bf16_hwgrad_pooled", n, hw, self.convs[key][0], a_kind, _p(a), _p(dp), add, cod, _p(slab), _s())
                 plan.add(slab, nsl, cnt, self.off[key][0])
                 w = self._wview(key)[0]
-                if i == 1:
-                    de0 = T.buf(f"de0_{tag}", (n, 64, 64, d[0]), torch.bfloat16, self.dev)
-                    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED, n, _p(dp), add, _p(w), None, _p(de0), cod, _s())
-                    dp = de0
+                if i >= 1:
+                    de = T.buf(f"de{i - 1}_{tag}", (n, hw, hw, d[i - 1]), torch.bfloat16, self.dev)
+                    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED if i == 1 else _lib.H5_ENC2_BWD_DATA_POOLED, n, _p(dp), add, _p(w), None,
+                              _p(de), cod, _s())
+                    dp = de
                 elif want_dx is not None:
                     _lib.call("cgs_bf16_enc0_bwd_data_pooled", n, _p(dp), add, cod, _p(w), _p(want_dx), _s())
                 continue
@@ -515,10 +524,10 @@ class Hourglass128:
             skips[i] = T.buf(f"dskip{i}", (n, hw, hw, d[i]), torch.bfloat16, self.dev)
             low_f32 = tail and i == 1        # the tail kernel below reads its d o (16x16) in fp32
             dlow = T.buf(f"do{i + 1}" + ("f" if low_f32 else ""), (n, hw // 2, hw // 2, d[i + 1]), torch.float32 if low_f32 else torch.bfloat16, self.dev)
-            if i == 0 and H5CONV and self.h5:        # the two halves of d cat(e0, up(o1)) straight from the whole-strip kernel
+            if (i == 0 or (i == 1 and low_f32)) and H5CONV and self.h5:      # the two halves of d cat(e, up(o)) straight from the whole-strip kernel
                 w = self._wview(key)[0]
-                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_SKIP, n, _p(do), None, _p(w), None, _p(skips[i]), None, _s())
-                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_LOW, n, _p(do), None, _p(w), None, _p(dlow), None, _s())
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_SKIP if i == 0 else _lib.H5_DEC1_BWD_SKIP, n, _p(do), None, _p(w), None, _p(skips[i]), None, _s())
+                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC0_BWD_LOW if i == 0 else _lib.H5_DEC1_BWD_LOW, n, _p(do), None, _p(w), None, _p(dlow), None, _s())
             else:
                 dcat = self._dgrad(T, key, do, f"dcat_d{i}")
                 _lib.call("cgs_bf16_cat_split", n, hw, d[i], d[i + 1], 2, _p(dcat), _p(skips[i]), _p(dlow), int(low_f32), _s())

@@ -186,17 +186,22 @@ int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio
  * its data gradients (src_a = d o0 [n,64,64,8] -> skip gradient [n,64,64,8] / cell-summed low-resolution gradient [n,32,32,8]).  bias NULL
  * for the data gradients.                                                                                                            */
 enum { CGS_H5_ENC1_FWD = 1, CGS_H5_ENC1_BWD_DATA = 2, CGS_H5_DEC0_FWD = 3, CGS_H5_DEC0_BWD_SKIP = 4, CGS_H5_DEC0_BWD_LOW = 5,
-       CGS_H5_ENC1_BWD_DATA_POOLED = 6 /* src_a = dP bf16 [n,32,32,8], src_b = addend or NULL, codes = the forward argmax bytes (read) */ };
+       CGS_H5_ENC1_BWD_DATA_POOLED = 6, /* src_a = dP bf16 [n,32,32,8], src_b = addend or NULL, codes = the forward argmax bytes (read) */
+       /* the 32x32 level: features.6 forward (e1 bf16 [n,32,32,8] -> e2 FP32 [n,16,16,8] + argmax bytes: the tail kernels' input), its data
+        * gradient from the pooled gradient (as 6, one level down), dec_model.1 forward (cat(e1, nearest-up2(o2 bf16 [n,16,16,8])) -> o1) and
+        * its data gradients (skip: bf16 [n,32,32,8]; low: cell sums, FP32 [n,16,16,8])                                                  */
+       CGS_H5_ENC2_FWD = 7, CGS_H5_ENC2_BWD_DATA_POOLED = 8, CGS_H5_DEC1_FWD = 9, CGS_H5_DEC1_BWD_SKIP = 10, CGS_H5_DEC1_BWD_LOW = 11 };
 int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, const void* src_b, const float* w_hwio, const float* bias, void* out,
                     uint8_t* codes, cgs_stream_t stream);
 /* Weight + bias gradient of the large-map layers of config 5 at chfak 1 (csrc/hwgrad.hip; same arithmetic as cgs_bf16_conv3x3_bwd_weight):
- * (hw, ca, cb, co) = (128,3,0,8) features.0, (128,3,8,16) masker.0, (128,16,0,1) masker.2, (64,8,0,8) features.3, (64,8,8,8) dec_model.0.
+ * (hw, ca, cb, co) = (128,3,0,8) features.0, (128,3,8,16) masker.0, (128,16,0,1) masker.2, (64,8,0,8) features.3, (64,8,8,8) dec_model.0,
+ * (32,8,0,8) features.6, (32,8,8,8) dec_model.1.
  * cgs_bf16_hwgrad_slabs: slab rows written for n images (0: not a dedicated shape).  a_kind: 0 bf16 [n,hw,hw,ca], 1 uint8 / 2 fp32 frames
  * [n,hw,hw,3]; src_b bf16 [n,hw/2,hw/2,cb] (nearest-upsampled x2); dy bf16 [n,hw,hw,co], or fp32 [n,hw,hw] when co == 1.              */
 int cgs_bf16_hwgrad_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co);
 int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_kind, const void* src_a, const void* src_b,
                     const void* dy, float* slab, cgs_stream_t stream);
-/* features.0 (hw 128, ca 3) / features.3 (hw 64, ca 8) with dY given as the pooled gradient dp bf16 [n,hw/2,hw/2,8] (+ addend or NULL) and the
+/* features.0 (hw 128, ca 3) / features.3 (hw 64, ca 8) / features.6 (hw 32, ca 8) with dY given as the pooled gradient dp bf16 [n,hw/2,hw/2,8] (+ addend or NULL) and the
  * forward pass's argmax bytes (what cgs_bf16_pool_expand would re-expand); slab rows = cgs_bf16_hwgrad_slabs(n, hw, ca, 0, 8).          */
 int cgs_bf16_hwgrad_pooled(int32_t n, int32_t hw, int32_t ca, int32_t a_kind, const void* src_a, const void* dp, const void* addend,
                            const uint8_t* codes, float* slab, cgs_stream_t stream);

@@ -78,7 +78,7 @@ def test_bf16_weight_gradient_vs_float64_autograd(shape):
 
 HWG_SHAPES = [  # (n, hw, ca, cb, co, a_kind): the dedicated large-map shapes (csrc/hwgrad.hip); n ragged against the persistent grid
     (3, 128, 3, 0, 8, 1), (5, 128, 3, 0, 8, 2), (3, 128, 3, 8, 16, 1), (3, 128, 16, 0, 1, 0), (7, 64, 8, 0, 8, 0), (5, 64, 8, 8, 8, 0),
-    (300, 64, 8, 0, 8, 0)]
+    (300, 64, 8, 0, 8, 0), (9, 32, 8, 0, 8, 0), (1100, 32, 8, 8, 8, 0)]
 
 
 @pytest.mark.parametrize("shape", HWG_SHAPES)
@@ -123,7 +123,7 @@ def test_bf16_large_map_weight_gradient_vs_float64_autograd(shape):
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"{shape}: max err / max |ref| = {err:.2e}")
     assert err < 2e-5
-    assert lib.cgs_bf16_hwgrad_slabs(n, 32, ca, cb, co) == 0            # not a dedicated shape: the caller takes the generic kernel
+    assert lib.cgs_bf16_hwgrad_slabs(n, 16, ca, cb, co) == 0            # not a dedicated shape: the caller takes the generic kernel
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 3, 8, 16), (3, 64, 8, 8, 8), (4, 8, 8, 0, 16), (3, 128, 16, 0, 1), (5, 4, 16, 32, 16)])
@@ -377,7 +377,7 @@ def test_pooled_gradient_consumers_are_bit_identical_to_pool_expand_then_kernel(
     from cgs_amd import _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(99)
-    for hw, ca, a_kind, n in ((128, 3, 1, 5), (128, 3, 2, 3), (64, 8, 0, 37)):
+    for hw, ca, a_kind, n in ((128, 3, 1, 5), (128, 3, 2, 3), (64, 8, 0, 37), (32, 8, 0, 41)):
         hp = hw // 2
         if a_kind == 1:
             a = torch.randint(0, 256, (n, hw, hw, 3), dtype=torch.uint8, generator=g).cuda()
@@ -403,13 +403,63 @@ def test_pooled_gradient_consumers_are_bit_identical_to_pool_expand_then_kernel(
             d2 = torch.full((n, 128, 128, 3), 8.0, device="cuda")
             _lib.call("cgs_bf16_enc0_bwd_data", n, P(dyf), P(w), P(d1), S())
             _lib.call("cgs_bf16_enc0_bwd_data_pooled", n, P(dp), P(add), P(codes), P(w), P(d2), S())
-        else:
+        elif hw == 64:
             d1 = torch.full((n, 64, 64, 8), 7.0, device="cuda", dtype=torch.bfloat16)
             d2 = torch.full((n, 64, 64, 8), 8.0, device="cuda", dtype=torch.bfloat16)
             _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA, n, P(dyf), None, P(w), None, P(d1), None, S())
             _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED, n, P(dp), P(add), P(w), None, P(d2), P(codes), S())
+        else:       # 32x32: only the pooled form exists; its reference = float64 transposed convolution of the expanded gradient
+            d2 = torch.full((n, 32, 32, 8), 8.0, device="cuda", dtype=torch.bfloat16)
+            _lib.call("cgs_bf16_h5conv", _lib.H5_ENC2_BWD_DATA_POOLED, n, P(dp), P(add), P(w), None, P(d2), P(codes), S())
+            torch.cuda.synchronize()
+            wt = bf(w.cpu().reshape(3, 3, 8, 8).permute(3, 2, 0, 1).double())
+            ref = F.conv_transpose2d(dyf.cpu().double().permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
+            assert (d2.double().cpu() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()
+            d1 = d2
         torch.cuda.synchronize()
         assert torch.equal(d1, d2)
+
+
+def test_h5conv_32x32_layers_vs_float64():
+    """The 32x32 forms of cgs_bf16_h5conv (features.6 forward -> fp32 + argmax bytes, dec_model.1 forward and its two data gradients, the
+    cell-summed one in fp32) vs float64 torch ops on the same bf16-rounded operands; n = 1100: images > persistent workgroups."""
+    from cgs_amd import _lib
+    _lib.load()
+    n = 1100
+    g = torch.Generator().manual_seed(32)
+    hwio = lambda w: w.permute(2, 3, 1, 0).contiguous().cuda()
+    relmax = lambda got, ref: (got.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    e1 = torch.randn((n, 32, 32, 8), generator=g).to(torch.bfloat16)
+    w = torch.randn((8, 8, 3, 3), generator=g) * 0.2
+    b = torch.randn(8, generator=g) * 0.1
+    e1_g, w_g, b_g = e1.cuda(), hwio(w), b.cuda()
+    e2_g = torch.full((n, 16, 16, 8), 7.0, device="cuda")
+    codes = torch.full((n, 16, 16, 8), 99, device="cuda", dtype=torch.uint8)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_ENC2_FWD, n, P(e1_g), None, P(w_g), P(b_g), P(e2_g), P(codes), S())
+    pre = F.relu(F.conv2d(e1.double().permute(0, 3, 1, 2), bf(w), b.double(), padding=1))
+    pooled, idx = F.max_pool2d(pre, 2, return_indices=True)
+    pooled = pooled.permute(0, 2, 3, 1)
+    ref_code = (((idx // 32) % 2) * 2 + (idx % 32) % 2).permute(0, 2, 3, 1)
+    ref_code = torch.where(pooled > 0, ref_code, torch.full_like(ref_code, 4))
+    assert (codes.cpu().long() == ref_code).double().mean().item() > 0.999
+    assert relmax(e2_g, pooled) <= 1e-5
+    o2 = torch.randn((n, 16, 16, 8), generator=g).to(torch.bfloat16)
+    wd = torch.randn((8, 16, 3, 3), generator=g) * 0.2
+    o2_g, wd_g = o2.cuda(), hwio(wd)
+    o1_g = torch.full((n, 32, 32, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC1_FWD, n, P(e1_g), P(o2_g), P(wd_g), P(b_g), P(o1_g), None, S())
+    cat = cat_up(e1.double().permute(0, 3, 1, 2), o2.double().permute(0, 3, 1, 2), 2)
+    assert relmax(o1_g, F.conv2d(cat, bf(wd), b.double(), padding=1).permute(0, 2, 3, 1)) <= 2.0 ** -8
+    dy = (torch.randn((n, 32, 32, 8), generator=g) * 0.1).to(torch.bfloat16)
+    dy_g = dy.cuda()
+    ds_g = torch.full((n, 32, 32, 8), 7.0, device="cuda", dtype=torch.bfloat16)
+    dl_g = torch.full((n, 16, 16, 8), 7.0, device="cuda")
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC1_BWD_SKIP, n, P(dy_g), None, P(wd_g), None, P(ds_g), None, S())
+    _lib.call("cgs_bf16_h5conv", _lib.H5_DEC1_BWD_LOW, n, P(dy_g), None, P(wd_g), None, P(dl_g), None, S())
+    torch.cuda.synchronize()
+    dcat = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), bf(wd), padding=1)
+    assert relmax(ds_g, dcat[:, :8].permute(0, 2, 3, 1)) <= 2.0 ** -8
+    assert relmax(dl_g, dcat[:, 8:].reshape(n, 8, 16, 2, 16, 2).sum((3, 5)).permute(0, 2, 3, 1)) <= 1e-5
 
 
 def _grad_dicts(net):
