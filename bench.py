@@ -303,30 +303,46 @@ def generic_mode(args, dev, rank):
                                    "traffic": None, "flops_per_image": flops}}), flush=True)
 
 
-def config5_mode(args, dev):
-    """BASELINE config 5 (side line): 128x128x3 frames, batch 256, bf16 storage / fp32 accumulate, the build-defined six-stage variant.
-    --mode train: the phase-2 training step (Hourglass128.phase2_step); otherwise the eval-mode forward."""
+def config5_mode(args, dev, pg=None, world=1, rank=0):
+    """BASELINE config 5 (side line): 128x128x3 frames, batch 256 per GPU, bf16 storage / fp32 accumulate, the build-defined six-stage variant.
+    --mode train: the phase-2 training step (Hourglass128.phase2_step), data parallel under --gpus N (one replica per rank, the flat gradient
+    bucket all-reduced over RCCL inside the step's HIP graph; weak scaling); otherwise the eval-mode forward."""
     from cgs_amd import hourglass128
     from oracle import hourglass_ref as orc          # only for the seeded stand-in weights (shape tables + RandomState draw)
     n = 256 if args.batch == 512 else args.batch
-    net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev)
-    X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(0)).to(dev)
+    net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev,
+                                    process_group=pg, force_allreduce=args.force_pg, dp_graph=not args.dp_eager_allreduce)
+    X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(10 * rank)).to(dev)
     train = args.mode == "train"
     if train:
-        B = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(1)).to(dev)
-        Y = torch.rand(n, generator=torch.Generator().manual_seed(2)).to(dev)
+        B = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(10 * rank + 1)).to(dev)
+        Y = torch.rand(n, generator=torch.Generator().manual_seed(10 * rank + 2)).to(dev)
         net.phase2_step(X, B, Y)
+        if pg is not None:
+            print(f"[bench] rank {rank}: all-reduce inside the step graph: {net.dp_single_graph} ({net.dp_capture_note})", file=sys.stderr, flush=True)
         run = lambda: net.phase2_step()
     else:
         run = lambda: net.infer(X)
-    for _ in range(max(args.warmup, 3)):
+
+    def barrier():
+        if pg is not None:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):         # (a fixed count on every rank: each step issues a collective)
         run()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
-    torch.cuda.synchronize()
+    barrier()
     dt = (time.perf_counter() - t0) / args.steps
+    if pg is not None:                           # max over ranks
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
     el, flops = hourglass128.Hourglass128.model_cost()
     if train:
         # layer-granular model as SURVEY 8(d) builds it for the 64x64 step: 4 critic forwards + the mask forward, 3 critic backward + the mask
@@ -334,12 +350,14 @@ def config5_mode(args, dev):
         elc, flc = hourglass128.Hourglass128.critic_cost()
         el_step, fl_step = 4 * elc + (el - elc) + 2 * (3 * elc + (el - elc)), 4 * flc + (flops - flc) + 2 * (3 * flc + (flops - flc))
         ach = 2.0 * el_step * n / dt / 1e9
-        print(json.dumps({"metric": "Hourglass-128 (build-defined) train images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
-                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
-                          "dtype": "bf16 (f32 accumulate, f32 master weights)", "data": "synthetic",
+        print(json.dumps({"metric": "Hourglass-128 (build-defined) train images/sec, 128x128x3 batch=%d per GPU" % n, "value": world * n / dt, "unit": "images/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "dtype": "bf16 (f32 accumulate, f32 master weights)", "data": "synthetic",
                           "config": {"workload": "BASELINE config 5 as a training step: phase-2 step (4 critic fwd, 3 critic bwd, mask fwd + bwd, mix, losses, "
                                                  "Adam) of the six-stage 128x128 variant (no reference counterpart, parity unpinned), bf16 activations / "
-                                                 "gradients, weight gradients on v_mfma_f32_16x16x32_bf16", "batch": n, "final_total_loss": float(net._train.losses[5])},
+                                                 "gradients, weight gradients on v_mfma_f32_16x16x32_bf16", "batch": n, "global_batch": n * world, "parallelism": f"dp{world}",
+                                     "allreduce_in_step_graph": bool(net.dp_single_graph), "collective_backend": ("nccl" if pg is not None else None),
+                                     "final_total_loss": float(net._train.losses[5])},
                           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                        "algorithmic_elements_per_image": el_step, "flops_per_image": fl_step,
                                        "bf16_TFLOPs": fl_step * n / dt / 1e12}}), flush=True)
@@ -440,9 +458,12 @@ def main():
     from cgs_amd import engine
     n = args.batch
     if args.config == 5:
-        if world > 1:
-            raise SystemExit("--config 5 is a one-GPU side measurement")
-        return config5_mode(args, dev)
+        if world > 1 and args.mode != "train":
+            raise SystemExit("--config 5 --mode infer is a one-GPU side measurement (--mode train takes --gpus N: data parallel)")
+        r = config5_mode(args, dev, pg, world, rank)
+        if pg is not None:
+            torch.distributed.destroy_process_group()
+        return r
     if args.chfak != 1:
         if args.mode not in ("train", "infer") or world > 1:
             raise SystemExit("--chfak != 1: --mode train / infer on one GPU (a secondary measurement; the headline is chfak 1)")

@@ -438,24 +438,7 @@ class HourglassEngine:
             return False
         if getattr(self, "_capturable", None) is not None:
             return self._capturable
-        import torch.distributed as dist
-        ok = False
-        if dist.get_backend(self.pg) != "nccl":
-            self.dp_capture_note = f"backend {dist.get_backend(self.pg)} reduces through the host"
-        else:
-            try:
-                t = torch.ones(64, device=self.dev)
-                dist.all_reduce(t, group=self.pg)                  # communicator + channels set up outside the capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    dist.all_reduce(t, group=self.pg)
-                g.replay()
-                torch.cuda.synchronize()
-                ok = bool(torch.isfinite(t).all().item()) and float(t[0].item()) == float(self.world) ** 2
-                self.dp_capture_note = "trial capture + replay ok" if ok else f"trial replay gave {float(t[0].item())}, expected {self.world ** 2}"
-            except Exception as e:       # noqa: BLE001 -- any failure means: keep the collective outside the graphs
-                self.dp_capture_note = f"trial capture failed: {type(e).__name__}: {e}"
+        ok, self.dp_capture_note = parallel.collective_capturable(self.pg, self.dev)
         self._capturable = ok
         return ok
 

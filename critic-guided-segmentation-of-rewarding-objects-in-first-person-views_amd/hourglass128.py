@@ -51,7 +51,7 @@ class Hourglass128:
 
     def __init__(self, critic_params: Dict[str, torch.Tensor], masker_params: Dict[str, torch.Tensor], device="cuda:0", chfak: int = 1,
                  neck: int = 32, masker_channels: int = 16, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, lfak: float = 5.0,
-                 L1: float = 0.5, L2: float = 0.0, process_group=None):
+                 L1: float = 0.5, L2: float = 0.0, process_group=None, force_allreduce: bool = False, dp_graph: bool = True):
         if not torch.cuda.is_available():
             raise _lib.CgsError("Hourglass128 needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = _lib.load()
@@ -64,6 +64,10 @@ class Hourglass128:
         self.lr, self.b1, self.b2, self.eps, self.lfak, self.L1, self.L2 = lr, betas[0], betas[1], eps, lfak, L1, L2
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # data parallel (one replica per rank, the flat gradient bucket all-reduced before Adam; force_allreduce: also on a 1-rank group, the
+        # rehearsal of the N > 1 launch form).  dp_graph: record the collective in the step's HIP graph when RCCL allows (parallel.collective_capturable)
+        self.dp = process_group is not None and (self.world > 1 or force_allreduce)
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = dp_graph, False, None
         f = lambda t: t.detach().to(dev, torch.float32).contiguous()
         # ---- layout: (key, kind, shape info) in flat order; conv = [9 ci co | co], gemm = [k n | n] ----
         self.convs = {}      # key -> (ca, cb, co)
@@ -575,7 +579,7 @@ class Hourglass128:
             T.plan_a, T.plan_b = pa.build(self.grad), pb.build(self.grad, accumulate=True)
         T.plan_a.run(None)
         T.plan_b.run(self.step_t)        # ticks the step counter
-        if self.pg is not None and self.world > 1:
+        if self.dp:
             parallel.allreduce_sum_(self.grad, self.pg)
         _lib.call("cgs_adam_flat", self.total, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), _p(self.step_t), self.lr, self.b1, self.b2,
                   self.eps, 1.0 / self.world, _s())
@@ -604,12 +608,19 @@ class Hourglass128:
         if self._graph is None:
             self._phase2_body(T)                 # eager: allocations + reduction tables
             self._graph = "eager"
-            if use_graph and (self.pg is None or self.world == 1):
+            capturable = not self.dp
+            if use_graph and self.dp:
+                if not self.dp_graph:
+                    self.dp_capture_note = "disabled by the caller (dp_graph=False)"
+                else:
+                    capturable, self.dp_capture_note = parallel.collective_capturable(self.pg, self.dev)
+            if use_graph and capturable:        # data parallel: kernels -> all-reduce -> Adam as ONE graph launch per step
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if self.dp else {})):
                     self._phase2_body(T)
                 self._graph = g
+                self.dp_single_graph = self.dp
         elif self._graph == "eager":
             self._phase2_body(T)
         else:

@@ -71,3 +71,25 @@ def broadcast_params_(flat: torch.Tensor, group=None, src: int = 0) -> torch.Ten
         else:
             dist.broadcast(flat, src=src, group=group)
     return flat
+
+
+def collective_capturable(group, dev):
+    """(ok, note): can a gradient all-reduce on `group` be recorded into a HIP graph?  True for the RCCL backend on device memory when a
+    trial capture + replay of a small all-reduce on this very group succeeds (gloo rehearsals stage through the host)."""
+    if dist.get_backend(group) != "nccl":
+        return False, f"backend {dist.get_backend(group)} reduces through the host"
+    world = dist.get_world_size(group)
+    try:
+        t = torch.ones(64, device=dev)
+        dist.all_reduce(t, group=group)                    # communicator + channels set up outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            dist.all_reduce(t, group=group)
+        g.replay()
+        torch.cuda.synchronize()
+        ok = bool(torch.isfinite(t).all().item()) and float(t[0].item()) == float(world) ** 2
+        return ok, ("trial capture + replay ok" if ok else f"trial replay gave {float(t[0].item())}, expected {world ** 2}")
+    except Exception as e:       # noqa: BLE001 -- any failure means: keep the collective outside the graphs
+        return False, f"trial capture failed: {type(e).__name__}: {e}"
+

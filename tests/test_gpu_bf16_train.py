@@ -588,3 +588,62 @@ def test_config5_training_data_parallel_world2(tmp_path):
     d = np.abs(got - want)
     print(f"DP(2) vs single process after 2 steps: max |d param| {d.max():.2e}, mean {d.mean():.2e}")
     assert d.mean() < 5e-5 and np.quantile(d, 0.999) < 2.1e-3
+
+
+DP128_RCCL_WORKER = r"""
+import os, sys
+sys.path.insert(0, {repo!r})
+import numpy as np, torch
+import torch.distributed as dist
+import cgs_amd
+from cgs_amd import hourglass128
+from oracle import hourglass_ref as orc
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world_size=1)       # nccl == RCCL on ROCm
+pc = orc.seeded_params(orc.critic128_shapes(), 31)
+pm = orc.seeded_params(orc.masker128_shapes(), 32)
+rs = np.random.RandomState(12)
+n = 8
+A = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
+B = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
+Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
+res = {{}}
+for name, kw in (("single", dict()), ("dp_graph", dict(process_group=dist.group.WORLD, force_allreduce=True)),
+                 ("dp_eager", dict(process_group=dist.group.WORLD, force_allreduce=True, dp_graph=False))):
+    net = hourglass128.Hourglass128(pc, pm, **kw)
+    for _ in range(4):
+        net.phase2_step(A, B, Y)
+    torch.cuda.synchronize()
+    res[name] = dict(flat=net.flat.cpu().numpy(), m=net.m.cpu().numpy(), t=int(net.step_t.item()), losses=net._train.losses.cpu().numpy(),
+                     single_graph=bool(net.dp_single_graph), note=net.dp_capture_note, graphed=not isinstance(net._graph, str))
+np.save({out!r}, np.array([res], dtype=object), allow_pickle=True)
+dist.destroy_process_group()
+"""
+
+
+def test_config5_dp_launch_form_on_one_rank_rccl_group(tmp_path):
+    """Hourglass128's data-parallel launch form on a ONE-rank RCCL group: with the all-reduce recorded in the step's HIP graph (one graph
+    launch per step) and with the eager form, against the plain single-GPU step -- the same kernels in the same order plus an identity
+    all-reduce and the 1 / world = 1 scale in Adam: parameters, first moments, step counter and losses after 4 steps are bit-identical."""
+    import os, subprocess, sys
+    REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dp128_rccl.npy")
+    script = tmp_path / "dp128_rccl_worker.py"
+    script.write_text(DP128_RCCL_WORKER.format(repo=REPO, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = np.load(out, allow_pickle=True)[0]
+    base = res["single"]
+    assert base["t"] == 4 and base["graphed"]
+    print(f"all-reduce in the step graph: {res['dp_graph']['single_graph']} ({res['dp_graph']['note']})")
+    assert res["dp_graph"]["single_graph"] == res["dp_graph"]["graphed"] and not res["dp_eager"]["graphed"]
+    for name in ("dp_graph", "dp_eager"):
+        got = res[name]
+        assert got["t"] == 4
+        np.testing.assert_array_equal(got["losses"], base["losses"])
+        np.testing.assert_array_equal(got["flat"], base["flat"])
+        np.testing.assert_array_equal(got["m"], base["m"])
+
