@@ -317,7 +317,7 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
     if train:
         B = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(10 * rank + 1)).to(dev)
         Y = torch.rand(n, generator=torch.Generator().manual_seed(10 * rank + 2)).to(dev)
-        net.phase2_step(X, B, Y)
+        net.phase2_step(X, B, Y, use_graph=not args.no_graph)
         if pg is not None:
             print(f"[bench] rank {rank}: all-reduce inside the step graph: {net.dp_single_graph} ({net.dp_capture_note})", file=sys.stderr, flush=True)
         run = lambda: net.phase2_step()

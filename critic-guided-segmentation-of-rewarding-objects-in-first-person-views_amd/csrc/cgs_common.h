@@ -131,3 +131,12 @@ template <int BIT, int SLEEP>
 __device__ __forceinline__ void cgs_stagger() {
     if ((blockIdx.x >> BIT) & 1) __builtin_amdgcn_s_sleep(SLEEP);
 }
+
+// Virtual workgroup id under which XCD x (= blockIdx.x % 8: workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2) owns a
+// CONTIGUOUS range of ids: neighbouring ids -- neighbouring strips of an image, whose halo rows overlap -- then run on the same XCD at the
+// same time and the shared rows come out of that XCD's L2 instead of crossing the fabric once per XCD.  A bijection on [0, g).
+__device__ __forceinline__ int cgs_xcd_contiguous(int b, int g) {
+    const int per = g >> 3, rem = g & 7, x = b & 7;
+    return x * per + (x < rem ? x : rem) + (b >> 3);
+}
+

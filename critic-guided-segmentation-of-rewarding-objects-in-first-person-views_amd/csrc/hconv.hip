@@ -16,6 +16,18 @@
 #ifndef HCONV_ENC0_TH
 #define HCONV_ENC0_TH 32          // rows of a 64x64 frame per features.0 workgroup (16 / 32 / 64 within 1 %: r4 A/B)
 #endif
+#ifndef H5_PREFETCH
+#define H5_PREFETCH 0             // h5conv: 1 = the next strip's loads issued before the current strip's matrix loop; 0 = right before their commit
+                                  // (r4 A/B at config 5: 1.035 vs 1.048 ms per step -- the 40 more live registers cost more than the overlap returns;
+                                  // what pays is issuing a strip's loads back to back: one memory round trip per strip either way)
+#endif
+#ifndef H5_PER_CU
+#define H5_PER_CU 4               // h5conv: persistent workgroups per CU (at most; LDS may allow fewer)
+#endif
+#ifndef H5_XCD
+#define H5_XCD 1                 // h5conv: XCD-contiguous strip order (0: round-robin; r4 A/B: no difference -- the halo rows two strips share come out of
+                                  // the memory-side cache either way)
+#endif
 #ifndef HCONV_BLOCKS
 #define HCONV_BLOCKS 1024         // persistent workgroups per launch
 #endif
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     for (int e = tid; e < XT / 8; e += 256) ((float4*)tile)[e] = f4zero();       // halo columns + padding channels: zero for every strip
 
     // ---- staging, split: fetch = every global load of a strip issued back to back into registers (ONE memory round trip per strip, in
-    //      flight while the previous strip multiplies), commit = conversion + LDS stores.  Items: source A = 4 frame pixels (3 dwords /
+    //      optionally -- H5_PREFETCH -- in flight while the previous strip multiplies), commit = conversion + LDS stores.  Items: source A = 4 frame pixels (3 dwords /
     //      3 float4), 4 fp32 pixels or 8 bf16 channels; source B = one low-resolution pixel (8 channels) -> the two tile pixels above it.
     constexpr int GW = HW / 4;
     constexpr int HP = HW / 2, PR = TH / 2 + 2;                                  // APOOL: pooled rows under a strip's tile
@@ -440,13 +452,15 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
         }
     };
 
-    if ((int)blockIdx.x < P.nstrips) fetch(blockIdx.x);
+    const int vb = H5_XCD ? cgs_xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // neighbouring strips (shared halo rows) on one XCD's L2
+    if (H5_PREFETCH && vb < P.nstrips) fetch(vb);
     __syncthreads();                                                             // (the zeroes above, before other threads stage the same addresses)
-    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+    for (int strip = vb; strip < P.nstrips; strip += gridDim.x) {
     const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
+    if (!H5_PREFETCH) fetch(strip);
     commit(strip);
     __syncthreads();
-    if (strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);            // in flight while this strip multiplies
+    if (H5_PREFETCH && strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);   // in flight while this strip multiplies
 
     // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
     auto tile_pixel = [&](int t, int& y, int& x) {      // strip-local pixel of this lane in tile t
@@ -548,7 +562,7 @@ int h5_launch(H5Params P, hipStream_t st) {
     if (P.n <= 0) return CGS_OK;
     P.nstrips = P.n * (C::HW / C::TH);
     // persistent workgroups: as many as stay resident (LDS; at most 4 per CU), then as few as walk the same number of strips each
-    const int per_cu = (int)((160 * 1024) / C::lds) < 4 ? (int)((160 * 1024) / C::lds) : 4, cap = 256 * per_cu;
+    const int per_cu = (int)((160 * 1024) / C::lds) < H5_PER_CU ? (int)((160 * 1024) / C::lds) : H5_PER_CU, cap = 256 * per_cu;
     const int rounds = (P.nstrips + cap - 1) / cap, blocks = (P.nstrips + rounds - 1) / rounds;
     hipLaunchKernelGGL((h5conv_kernel<C>), dim3(blocks), dim3(256), C::lds, st, P);
     CGS_HIP_CHECK_LAUNCH();

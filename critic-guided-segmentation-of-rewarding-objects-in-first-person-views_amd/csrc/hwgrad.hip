@@ -13,6 +13,10 @@
 // No reference counterpart (the reference cannot run 128x128 frames): parity unpinned, see hourglass128.py.
 #include "tail_common.h"
 
+#ifndef HWG_XCD
+#define HWG_XCD 1                // XCD-contiguous strip order (0: round-robin; r4 A/B)
+#endif
+
 namespace {
 
 typedef short hs4_t __attribute__((ext_vector_type(4)));
@@ -71,7 +75,7 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
     for (int e = tid; e < XT / 8; e += 256) ((float4*)xt)[e] = f4zero();        // halo columns + padding channels: zero for every strip
     __syncthreads();                                                            // (before other threads stage the same addresses)
 
-    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+    for (int strip = HWG_XCD ? cgs_xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x; strip < P.nstrips; strip += gridDim.x) {   // (neighbouring strips on one XCD's L2)
         const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
         // ---- X tile ----
         if constexpr (CA == 4) {            // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item

@@ -45,7 +45,8 @@ def load(sub):
 sq1, sq2, fe, wr = load("sq1"), load("sq2"), load("fetch"), load("write")
 cols1 = ["SQ_WAVES", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU"]
 cols2 = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_WAIT_INST_LDS", "GRBM_GUI_ACTIVE"]
-STREAM16 = ("mask_head_kernel", "mask0_fwd", "FMask2", "wgrad_kernel", "wgrad_any_kernel<WDec", "wgrad_any_kernel<WMask", "conv_bwd_both", "enc0_bwd_mix", "FEnc1", "FDec", "DDec", "reduce_slabs", "reduce_adam", "tail_")
+STREAM16 = ("mask_head_kernel", "mask0_fwd", "FMask2", "wgrad_kernel", "wgrad_any_kernel<WDec", "wgrad_any_kernel<WMask", "conv_bwd_both", "enc0_bwd_mix", "FEnc1", "FDec", "DDec", "reduce_slabs", "reduce_adam", "tail_",
+            "h5conv_kernel", "hwgrad_kernel")      # (config 5: 16-byte staging loads; the uint8 frames of three of them are 3 of ~39 B / pixel)
 with open(out, "w", newline="") as fp:
     w = csv.writer(fp)
     w.writerow(["kernel", "calls_per_step", "us_per_step"] + cols1 + cols2 + ["FETCH_bytes_raw", "WRITE_bytes", "fetch_x2_applies",
