@@ -1,21 +1,21 @@
-// fp16 convolutions of the FUSED inference path (BASELINE config 4: "-process inference-only mask path, batch 2048, fp16 conv
-// kernels"; main.py:1130-1151, nets.py:170-176, 516-517): features.0 (uint8 frames -> e0), features.3 (e0 -> e1) and dec_model.0
-// (cat(e0, up(o1)) -> o0) with fp16 activations in HBM / LDS, fp16 weights, fp32 accumulation on v_mfma_f32_16x16x32_f16 -- gfx950's
-// K = 32 form: one instruction covers 8 / 4 / 2 taps of a 4- / 8- / 16-channel input, so a 3x3 layer is 2 / 3 / 5 instructions per
-// 16 pixels and the matrix time is negligible; the kernels are built for the memory side: one workgroup stages a whole 32x32 image
-// (or a 16-row strip of a 64x64 frame) once as an NHWC fp16 tile whose pixel is ONE 8- / 16- / 32-byte LDS read per lane and tap
-// group, every global access is a full 16-byte lane access, the weights live in registers.
-// Workgroups are persistent over the strips (weights -> registers once per workgroup).  Pooled layers issue the instruction as
-// D[pixel][output channel] with a tile = four 2x2 pool windows (tile pixel 4 w + pos): a lane's four accumulators are ONE window, so
-// ReLU + MaxPool2d(2) is three in-lane maxima + bias; the plain layer (dec_model.0) issues D[output channel][pixel]: four consecutive
-// channels of the lane's pixel = one 8-byte store.
-// The 16x16-and-smaller layers stay on the fp32 tail kernels (0.3 % of the path's bytes): features.3 therefore writes e1 in fp32.
-// OPT-IN precision (engine.infer(fp16=True) at chfak 1): never used by training or by the parity-gated fp32 paths.
+// Whole-strip 16-bit convolutions (h5conv_kernel): the large-map 3x3 layers of
+//   * BASELINE config 4, the FUSED fp16 inference path ("-process inference-only mask path, batch 2048, fp16 conv kernels"; main.py:1130-1151,
+//     nets.py:170-176, 516-517): features.0 (uint8 frames -> e0), features.3 (e0 -> e1) and dec_model.0 (cat(e0, up(o1)) -> o0) in IEEE half;
+//   * BASELINE config 5, the build-defined 128x128 variant (hourglass128.py, chfak 1): every forward layer and data gradient of its 128x128 /
+//     64x64 / 32x32 levels in bfloat16 (no reference counterpart: parity unpinned),
+// with 16-bit activations in HBM / LDS, 16-bit weights, fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16} -- gfx950's K = 32 form: one
+// instruction covers 8 / 4 / 2 taps of a 4- / 8- / 16-channel input, so a 3x3 layer is 2 / 3 / 5 instructions per 16 pixels and the matrix
+// time is negligible; the kernel is built for the memory side and the per-tile instruction count: compile-time shapes (H5Cfg), a workgroup
+// persistent over row strips of one image stages a strip once as an NHWC tile whose pixel is ONE 8- / 16- / 32-byte LDS read per lane and tap
+// group (every global access a full 16-byte lane access, all loads of a strip issued back to back), the weights live in registers (converted
+// from the fp32 master copy; flipped + transposed for a data gradient).  Pooled epilogues issue the instruction as D[pixel][output channel]
+// with a tile = four 2x2 pool windows (tile pixel 4 w + pos): a lane's four accumulators are ONE window, so ReLU + MaxPool2d(2) (+ its argmax
+// byte) or the 2x2 cell sum is in-lane; plain epilogues issue D[output channel][pixel]: four consecutive channels of the lane's pixel = one
+// vector store.  8-channel outputs share an accumulator between two pixel tiles (PAIR).
+// The 16x16-and-smaller layers of both configurations stay on the fp32 tail kernels (tail.hip): features.3 of config 4 and features.6 of
+// config 5 therefore write fp32.  OPT-IN precisions: never used by the fp32 training path or the parity-gated fp32 paths.
 #include "tail_common.h"
 
-#ifndef HCONV_ENC0_TH
-#define HCONV_ENC0_TH 32          // rows of a 64x64 frame per features.0 workgroup (16 / 32 / 64 within 1 %: r4 A/B)
-#endif
 #ifndef H5_PREFETCH
 #define H5_PREFETCH 0             // h5conv: 1 = the next strip's loads issued before the current strip's matrix loop; 0 = right before their commit
                                   // (r4 A/B at config 5: 1.035 vs 1.048 ms per step -- the 40 more live registers cost more than the overlap returns;
@@ -24,12 +24,12 @@
 #ifndef H5_PER_CU
 #define H5_PER_CU 4               // h5conv: persistent workgroups per CU (at most; LDS may allow fewer)
 #endif
+#ifndef H5_PAIR16
+#define H5_PAIR16 0              // h5conv: 1 = tile pairing also for 16-channel pixels with 8 outputs (20 more weight registers; r4 A/B: 0.8 % slower per config-5 step)
+#endif
 #ifndef H5_XCD
 #define H5_XCD 1                 // h5conv: XCD-contiguous strip order (0: round-robin; r4 A/B: no difference -- the halo rows two strips share come out of
                                   // the memory-side cache either way)
-#endif
-#ifndef HCONV_BLOCKS
-#define HCONV_BLOCKS 1024         // persistent workgroups per launch
 #endif
 
 namespace {
@@ -40,7 +40,7 @@ typedef short bshort8_t __attribute__((ext_vector_type(8)));
 typedef short bshort4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bbf16x8_t __attribute__((ext_vector_type(8)));
 
-// 16-bit element of the tile / operands: IEEE half (config 4) or bfloat16 (config 5: the 128x128 variant's features.0)
+// 16-bit element of the tile / operands: IEEE half (config 4) or bfloat16 (config 5)
 struct ElF16 {
     using V8 = half8_t; using V4 = half4h_t; using S = _Float16;
     __device__ static __forceinline__ S cvt(float f) { return (_Float16)f; }
@@ -54,189 +54,9 @@ struct ElBF16 {
     }
 };
 
-struct HConvParams {
-    const void* a;          // uint8 frames [n,HW,HW,3] (U8) or fp16 NHWC [n,HW,HW,CA]
-    const float* b;         // fp32 NHWC [n,HW/2,HW/2,CB] (nearest-upsampled second source) or NULL
-    const float* w;         // HWIO fp32 [9][CA_real + CB][8]
-    const float* bias;      // [8]
-    void* out;              // pooled [n,HW/2,HW/2,8] or [n,HW,HW,8]; fp16 or fp32
-    int n;
-    int nstrips;            // n * (HW / TH): the workgroups are persistent over them (weights -> registers once)
-    int a_f32;              // CA == 4: source A is fp32 NHWC [n,HW,HW,3] (the replaced / injected mixes of config 5) instead of uint8
-    uint8_t* codes;         // pooled layers, training: argmax position 0..3 of every pooled element (4: value <= 0), or NULL
-};
-
-// HW: map size; CA: channels of source A in the LDS pixel (4 = uint8 rgb0, 8 = fp16); CB: channels of the upsampled fp32 source (0 / 8);
-// TH: rows per workgroup; POOL: ReLU + MaxPool2d(2) epilogue (else plain bias); OUT_F32: fp32 output
-template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32, class EL = ElF16>
-__global__ void __launch_bounds__(256) hconv_kernel(HConvParams P) {
-    using half8_t = typename EL::V8;
-    using half4h_t = typename EL::V4;
-    using h16_t = typename EL::S;             // (the names below say "half": either 16-bit type)
-#define HCVT(x) EL::cvt(x)
-    constexpr int CIN = CA + CB, TPM = 32 / CIN, NM = (9 + TPM - 1) / TPM;      // taps per instruction, instructions per tile
-    constexpr int PW = HW + 2, PH = TH + 2, STRIPS = HW / TH, CA_REAL = CA == 4 ? 3 : CA;
-    constexpr int NT = TH * HW / 16;                                            // 16-pixel tiles per workgroup
-    static_assert(CIN == 4 || CIN == 8 || CIN == 16, "pixel = 8 / 16 / 32 bytes");
-    extern __shared__ __attribute__((aligned(16))) float4 hsm[];
-    h16_t* const tile = (h16_t*)hsm;                                     // [PH][PW][CIN]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
-
-    // ---- weights -> registers: A operand of instruction g, lane (m = l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN ----
-    half8_t wa[NM];
-#pragma unroll
-    for (int g = 0; g < NM; ++g)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
-            const int cr = c < CA ? c : CA_REAL + (c - CA);                      // channel of the layer's HWIO weights
-            const bool ok = tap < 9 && l15 < 8 && (c < CA ? c < CA_REAL : true);
-            wa[g][j] = HCVT(ok ? P.w[((tap < 9 ? tap : 0) * (CA_REAL + CB) + (ok ? cr : 0)) * 8 + (l15 & 7)] : 0.f);
-        }
-    float br[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) br[r] = P.bias[(4 * kq + r) & 7];
-    const float bl = P.bias[l15 & 7];
-
-    for (int e = tid; e < PH * 2 * (CIN / 4); e += 256) {                       // halo columns: zero for every strip
-        const int q = e % (CIN / 4), side = (e / (CIN / 4)) & 1, r = e / (2 * (CIN / 4));
-        *(half4h_t*)(tile + ((size_t)r * PW + (side ? PW - 1 : 0)) * CIN + 4 * q) = half4h_t{0, 0, 0, 0};
-    }
-    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
-    const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
-    // ---- stage the tile (zero halo rows) ----
-    if constexpr (CA == 4) {                // uint8 frames: 4 pixels = 12 bytes = 3 dwords per thread-item
-        constexpr int GW = HW / 4;
-        const uint32_t* src = (const uint32_t*)P.a;
-        for (int e = tid; e < PH * GW; e += 256) {
-            const int g = e % GW, r = e / GW, y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-            half4h_t* dst = (half4h_t*)(tile + ((size_t)r * PW + 1 + 4 * g) * 4);
-            if (P.a_f32) {              // (uniform branch) fp32 NHWC frames: 4 pixels = 12 floats = 3 float4
-                const float4* sf = (const float4*)P.a;
-                const size_t fi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-                float4 f0 = sf[fi], f1 = sf[fi + 1], f2 = sf[fi + 2];
-                if (!in) { f0 = f4zero(); f1 = f4zero(); f2 = f4zero(); }
-                dst[0] = half4h_t{HCVT(f0.x), HCVT(f0.y), HCVT(f0.z), HCVT(0.f)};
-                dst[1] = half4h_t{HCVT(f0.w), HCVT(f1.x), HCVT(f1.y), HCVT(0.f)};
-                dst[2] = half4h_t{HCVT(f1.z), HCVT(f1.w), HCVT(f2.x), HCVT(0.f)};
-                dst[3] = half4h_t{HCVT(f2.y), HCVT(f2.z), HCVT(f2.w), HCVT(0.f)};
-                continue;
-            }
-            uint32_t d0 = src[gi], d1 = src[gi + 1], d2 = src[gi + 2];
-            if (!in) { d0 = 0; d1 = 0; d2 = 0; }
-            const float s = 1.f / 255.f;
-            half4h_t p0 = {HCVT((d0 & 255) * s), HCVT(((d0 >> 8) & 255) * s), HCVT(((d0 >> 16) & 255) * s), HCVT(0.f)};
-            half4h_t p1 = {HCVT((d0 >> 24) * s), HCVT((d1 & 255) * s), HCVT(((d1 >> 8) & 255) * s), HCVT(0.f)};
-            half4h_t p2 = {HCVT(((d1 >> 16) & 255) * s), HCVT((d1 >> 24) * s), HCVT((d2 & 255) * s), HCVT(0.f)};
-            half4h_t p3 = {HCVT(((d2 >> 8) & 255) * s), HCVT(((d2 >> 16) & 255) * s), HCVT((d2 >> 24) * s), HCVT(0.f)};
-            dst[0] = p0; dst[1] = p1; dst[2] = p2; dst[3] = p3;
-        }
-    } else {
-        const half8_t* src = (const half8_t*)P.a;                              // 8 fp16 channels = one 16-byte access
-        for (int e = tid; e < PH * HW; e += 256) {
-            const int x = e % HW, r = e / HW, y = row0 + r - 1;
-            const bool in = y >= 0 && y < HW;
-            half8_t v = src[in ? ((size_t)img * HW + y) * HW + x : 0];
-            if (!in) v = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            *(half8_t*)(tile + ((size_t)r * PW + 1 + x) * CIN) = v;
-            if constexpr (CB > 0) {         // the nearest-upsampled fp32 source, converted: channels CA .. CA + 7 of the pixel
-                const float4* sb = (const float4*)P.b;
-                const size_t pb = in ? (((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1)) * 2 : 0;
-                float4 u0 = sb[pb], u1 = sb[pb + 1];
-                if (!in) { u0 = f4zero(); u1 = f4zero(); }
-                const half8_t hb = {HCVT(u0.x), HCVT(u0.y), HCVT(u0.z), HCVT(u0.w), HCVT(u1.x), HCVT(u1.y), HCVT(u1.z), HCVT(u1.w)};
-                *(half8_t*)(tile + ((size_t)r * PW + 1 + x) * CIN + CA) = hb;
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- tiles: 16 pixels = 4 pool windows adjacent in x (lane = 4 window + position), or 16 consecutive pixels of a row ----
-#pragma unroll 2
-    for (int t = wave; t < NT; t += 4) {
-        int y, x;                           // strip-local pixel of this lane
-        if constexpr (POOL) {
-            constexpr int TPR = HW / 8;     // tiles per row pair
-            const int wy = t / TPR, tx = t % TPR, win = l15 >> 2, pos = l15 & 3;
-            y = 2 * wy + (pos >> 1); x = 8 * tx + 2 * win + (pos & 1);
-        } else {
-            constexpr int TPR = HW / 16;
-            y = t / TPR; x = 16 * (t % TPR) + l15;
-        }
-        const h16_t* pix = tile + ((size_t)y * PW + x) * CIN;                // tap (0,0) of the lane's 3x3 window
-        frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < NM; ++g) {
-            half8_t b;
-            if constexpr (CIN == 4) {       // two taps per lane: 2 x 8 bytes
-                int t0 = g * 8 + 2 * kq, t1 = t0 + 1;
-                t0 = t0 < 9 ? t0 : 8; t1 = t1 < 9 ? t1 : 8;
-                const half4h_t lo = *(const half4h_t*)(pix + ((t0 / 3) * PW + t0 % 3) * 4), hi = *(const half4h_t*)(pix + ((t1 / 3) * PW + t1 % 3) * 4);
-                b = half8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            } else if constexpr (CIN == 8) {
-                int tp = g * 4 + kq;
-                tp = tp < 9 ? tp : 8;
-                b = *(const half8_t*)(pix + ((tp / 3) * PW + tp % 3) * 8);
-            } else {
-                int tp = g * 2 + (kq >> 1);
-                tp = tp < 9 ? tp : 8;
-                b = *(const half8_t*)(pix + ((tp / 3) * PW + tp % 3) * 16 + 8 * (kq & 1));
-            }
-            // pooled layers: D[pixel = 4 kq + r][oc = l15] -- a lane's four accumulators are ONE pool window (in-lane maximum);
-            // plain layers: D[oc = 4 kq + r][pixel = l15] -- four consecutive channels of the lane's pixel (one vector store)
-            if constexpr (POOL) acc = EL::mfma(b, wa[g], acc);
-            else acc = EL::mfma(wa[g], b, acc);
-        }
-        if constexpr (POOL) {
-            // ReLU(max(window) + bias) == max over the window of ReLU(. + bias); lane (kq, l15 < 8): window kq of the tile, channel l15
-            constexpr int TPR = HW / 8;
-            const int wy = t / TPR, tx = t % TPR;
-            const float m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bl, 0.f);
-            if (l15 < 8) {
-                const size_t o = ((((size_t)img * (HW / 2) + row0 / 2 + wy) * (HW / 2) + 4 * tx + kq) * 8) + l15;
-                if constexpr (OUT_F32) ((float*)P.out)[o] = m;
-                else ((h16_t*)P.out)[o] = HCVT(m);
-                if (P.codes) {          // first maximum wins (max_pool2d); 4 = the pooled value is not positive: no gradient
-                    uint32_t code = 0;
-                    float mm = acc[0] + bl;
-#pragma unroll
-                    for (int j = 1; j < 4; ++j) if (acc[j] + bl > mm) { mm = acc[j] + bl; code = j; }
-                    P.codes[o] = (uint8_t)(m > 0.f ? code : 4u);
-                }
-            }
-        } else if (kq < 2) {
-            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * 8) + 4 * kq;
-            if constexpr (OUT_F32) *(float4*)((float*)P.out + o) = make_float4(acc[0] + br[0], acc[1] + br[1], acc[2] + br[2], acc[3] + br[3]);
-            else *(half4h_t*)((h16_t*)P.out + o) = half4h_t{HCVT(acc[0] + br[0]), HCVT(acc[1] + br[1]), HCVT(acc[2] + br[2]), HCVT(acc[3] + br[3])};
-        }
-    }
-    __syncthreads();            // every wave is done with the tile before the next strip is staged
-    }
-}
-
-#undef HCVT
-
-template <int HW, int CA, int CB, int TH, bool POOL, bool OUT_F32, class EL = ElF16>
-int hconv_launch(const HConvParams& P, hipStream_t st) {
-    if (P.n <= 0) return CGS_OK;
-    const size_t lds = (size_t)(TH + 2) * (HW + 2) * (CA + CB) * 2;
-    HConvParams Q = P;
-    Q.nstrips = P.n * (HW / TH);
-    const int blocks = Q.nstrips < HCONV_BLOCKS ? Q.nstrips : HCONV_BLOCKS;      // persistent workgroups
-    hipLaunchKernelGGL((hconv_kernel<HW, CA, CB, TH, POOL, OUT_F32, EL>), dim3(blocks), dim3(256), lds, st, Q);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// Config 5 (the build-defined 128x128 variant, hourglass128.py, chfak 1): the large-map layers of the TRAINING step in bfloat16 on the
-// same plan -- whole-strip NHWC tile, weights in registers (converted from the fp32 master copy, flipped + transposed for a data
-// gradient), persistent workgroups -- with the epilogues the step needs fused: ReLU + MaxPool2d(2) + argmax bytes, bias + LeakyReLU /
-// Sigmoid, the 2x2 cell sum of a nearest-upsampled source's gradient (replaces cgs_bf16_cat_split), the LeakyReLU' factor of the layer
-// below (replaces cgs_bf16_lrelu_bwd).  Replaces gen16_conv3x3_kernel (run-time shapes, 16-pixel staging items) on these layers.
+// The epilogues the config-5 training step needs are fused: ReLU + MaxPool2d(2) + argmax bytes, bias + LeakyReLU / Sigmoid, the 2x2 cell sum of
+// a nearest-upsampled source's gradient (replaces cgs_bf16_cat_split), the LeakyReLU' factor of the layer below (replaces cgs_bf16_lrelu_bwd),
+// a pooled gradient re-expanded while it is staged (replaces cgs_bf16_pool_expand).
 struct H5Params {
     const void* a;          // CA == 4: uint8 / fp32 frames [n,HW,HW,3]; CA == 1: fp32 [n,HW,HW]; else bf16 NHWC [n,HW,HW,CA]
     const uint16_t* b;      // CB == 8: bf16 [n,HW/2,HW/2,8], nearest-upsampled; else NULL
@@ -253,8 +73,11 @@ enum { EPI_PLAIN = 0, EPI_POOLMAX = 1, EPI_POOLSUM = 2, EPI_LRELU_BWD = 3 };
 // CA: LDS channels of source A (4 = rgb0 frames, 1 = fp32 single channel, 8 / 16 = bf16); CB: 0 / 8; CO: output channels of the kernel;
 // CIL, COL: the LAYER's input / output channels (weight strides); DGRAD: the kernel computes the data gradient of the layer with respect to
 // its input channels O0 .. O0 + CO - 1 (source = dY with COL channels); EPI / ACT: epilogue; OUT_F32: fp32 output (else bf16)
-template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_, bool APOOL_ = false>
+template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_, bool APOOL_ = false,
+          class EL_ = ElBF16, bool BF32_ = false>
 struct H5Cfg {
+    using EL = EL_;                         // 16-bit element: bfloat16 (config 5) or IEEE half (config 4: the fused fp16 inference path)
+    static constexpr bool BF32 = BF32_;     // source B is fp32 [n,HW/2,HW/2,8] (config 4: o1 comes out of the fp32 tail kernel)
     static constexpr bool APOOL = APOOL_;   // source A = a pooled gradient re-expanded while it is staged (a = dP bf16 [n,HW/2,HW/2,CA], b = the optional
                                             // addend of the same shape, codes = the forward pass's argmax bytes): replaces cgs_bf16_pool_expand
     static constexpr int HW = HW_, TH = TH_, CA = CA_, CB = CB_, CO = CO_, CIL = CIL_, COL = COL_, O0 = O0_, EPI = EPI_, ACT = ACT_;
@@ -267,19 +90,19 @@ struct H5Cfg {
 
 template <class C>
 __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
-    using EL = ElBF16;
-    using v8 = EL::V8; using v4 = EL::V4;
+    using EL = typename C::EL;
+    using v8 = typename EL::V8; using v4 = typename EL::V4; using S = typename EL::S;
     constexpr int HW = C::HW, TH = C::TH, CA = C::CA, CB = C::CB, CO = C::CO, CIN = C::CIN, TPM = C::TPM, NM = C::NM, PW = C::PW, PH = C::PH;
     constexpr int STRIPS = HW / TH, NT = TH * HW / 16, XT = (PH * PW * CIN + 7) & ~7;
     extern __shared__ __attribute__((aligned(16))) float4 hsm[];
-    short* const tile = (short*)hsm;                                            // [PH][PW][CIN]
+    S* const tile = (S*)hsm;                                            // [PH][PW][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
 
     // ---- weights -> registers: lane (row l15 = output channel, kq): k = 8 kq + j, tap = g TPM + k / CIN, LDS channel k % CIN.
     //      PAIR (8 output channels, short K): the 16-wide output side of the instruction holds TWO pixel tiles -- tile h of a pair is
     //      multiplied by the weight set whose rows 8 h .. 8 h + 7 are the layer's (the other rows zero) into the SAME accumulator, so every
     //      lane of the epilogue carries a real output (the per-tile instruction count, not the matrix rate, bounds these kernels) ----
-    constexpr bool PAIR = CO == 8 && CIN <= 8;
+    constexpr bool PAIR = CO == 8 && (CIN <= 8 || H5_PAIR16);
     constexpr int NP = PAIR ? 2 : 1;
     const int ocl = PAIR ? (l15 & 7) : l15;
     v8 wa[NP][NM];
@@ -328,10 +151,10 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     constexpr int HP = HW / 2, PR = TH / 2 + 2;                                  // APOOL: pooled rows under a strip's tile
     constexpr int NA = C::APOOL ? (PR * HP + 255) / 256 : (CA == 4 || CA == 1 ? (PH * GW + 255) / 256 : (PH * HW * (CA / 8) + 255) / 256);
     constexpr int NAV = CA == 4 || C::APOOL ? 3 : 1;                             // float4 registers per item
-    static_assert(!C::APOOL || (CA == 8 && CB == 0), "pooled source: 8 channels");
+    static_assert(!C::APOOL || (CA == 8 && CB == 0 && sizeof(S) == 2 && !C::BF32), "pooled source: 8 bf16 channels");
     constexpr int NBI = CB == 8 ? (PH * (HW / 2) + 255) / 256 : 1;
     float4 ra[NA][NAV];
-    float4 rb[NBI];
+    float4 rb[NBI][C::BF32 ? 2 : 1];
     auto fetch = [&](int strip) {
         const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
 #pragma unroll
@@ -372,7 +195,9 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
             for (int i = 0; i < NBI; ++i) {
                 const int e = tid + 256 * i, xc = e % (HW / 2), r = e / (HW / 2), y = row0 + r - 1;
                 const bool in = r < PH && y >= 0 && y < HW;
-                rb[i] = ((const float4*)P.b)[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + xc : 0];
+                const size_t gi = in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + xc : 0;
+                if constexpr (C::BF32) { rb[i][0] = ((const float4*)P.b)[2 * gi]; rb[i][1] = ((const float4*)P.b)[2 * gi + 1]; }
+                else rb[i][0] = ((const float4*)P.b)[gi];
             }
         }
     };
@@ -427,7 +252,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 if (r >= PH) continue;
                 const bool in = y >= 0 && y < HW;
                 const float4 v = in ? ra[i][0] : f4zero();
-                short* d = tile + (size_t)r * PW + 1 + 4 * g;
+                S* d = tile + (size_t)r * PW + 1 + 4 * g;
                 d[0] = EL::cvt(v.x); d[1] = EL::cvt(v.y); d[2] = EL::cvt(v.z); d[3] = EL::cvt(v.w);
             } else {
                 constexpr int NG = CA / 8;
@@ -443,9 +268,16 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const int e = tid + 256 * i, xc = e % (HW / 2), r = e / (HW / 2), y = row0 + r - 1;
                 if (r >= PH) continue;
                 const bool in = y >= 0 && y < HW;
-                const float4 v = in ? rb[i] : f4zero();
-                short* d = tile + ((size_t)r * PW + 1 + 2 * xc) * CIN + CA;    // 8-byte aligned (CA = 4) or 16
-                const float2 lo = make_float2(v.x, v.y), hi = make_float2(v.z, v.w);
+                S* d = tile + ((size_t)r * PW + 1 + 2 * xc) * CIN + CA;    // 8-byte aligned (CA = 4) or 16
+                float2 lo, hi;
+                if constexpr (C::BF32) {
+                    const float4 u0 = in ? rb[i][0] : f4zero(), u1 = in ? rb[i][1] : f4zero();
+                    const v4 l4 = {EL::cvt(u0.x), EL::cvt(u0.y), EL::cvt(u0.z), EL::cvt(u0.w)}, h4 = {EL::cvt(u1.x), EL::cvt(u1.y), EL::cvt(u1.z), EL::cvt(u1.w)};
+                    lo = __builtin_bit_cast(float2, l4); hi = __builtin_bit_cast(float2, h4);
+                } else {
+                    const float4 v = in ? rb[i][0] : f4zero();
+                    lo = make_float2(v.x, v.y); hi = make_float2(v.z, v.w);
+                }
                 *(float2*)d = lo; *(float2*)(d + 4) = hi;
                 *(float2*)(d + CIN) = lo; *(float2*)(d + CIN + 4) = hi;
             }
@@ -479,7 +311,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
         for (int h = 0; h < NP; ++h) {
         int y, x;
         tile_pixel(t + h, y, x);
-        const short* pix = tile + ((size_t)y * PW + x) * CIN;                   // tap (0,0) of the lane's 3x3 window
+        const S* pix = tile + ((size_t)y * PW + x) * CIN;                   // tap (0,0) of the lane's 3x3 window
 #pragma unroll
         for (int g = 0; g < NM; ++g) {
             v8 b;
@@ -513,7 +345,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 if constexpr (C::EPI == EPI_POOLSUM) m = (acc[0] + acc[1]) + (acc[2] + acc[3]);
                 else m = fmaxf(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) + bl, 0.f);
                 if constexpr (C::OUT_F32) ((float*)P.out)[o] = m;
-                else ((short*)P.out)[o] = EL::cvt(m);
+                else ((S*)P.out)[o] = EL::cvt(m);
                 if constexpr (C::EPI == EPI_POOLMAX) {
                     if (P.codes) {              // first maximum wins (max_pool2d); 4 = the pooled value is not positive: no gradient
                         uint32_t code = 0;
@@ -537,18 +369,18 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 if constexpr (C::ACT == CGS_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (C::EPI == EPI_LRELU_BWD) {                             // x LeakyReLU'(h): h = the layer's forward output (bf16: sign is exact)
-                const v4 h = *(const v4*)((const short*)P.hm + o);
+                const v4 h = *(const v4*)((const S*)P.hm + o);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = h[r] > 0 ? v[r] : 0.01f * v[r];
             }
             if constexpr (CO % 4 == 0) {
                 if constexpr (C::OUT_F32) *(float4*)((float*)P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-                else *(v4*)((short*)P.out + o) = v4{EL::cvt(v[0]), EL::cvt(v[1]), EL::cvt(v[2]), EL::cvt(v[3])};
+                else *(v4*)((S*)P.out + o) = v4{EL::cvt(v[0]), EL::cvt(v[1]), EL::cvt(v[2]), EL::cvt(v[3])};
             } else {
 #pragma unroll
                 for (int r = 0; r < CO; ++r) {
                     if constexpr (C::OUT_F32) ((float*)P.out)[o + r] = v[r];
-                    else ((short*)P.out)[o + r] = EL::cvt(v[r]);
+                    else ((S*)P.out)[o + r] = EL::cvt(v[r]);
                 }
             }
         }
@@ -570,6 +402,9 @@ int h5_launch(H5Params P, hipStream_t st) {
 }
 
 //                      HW   TH  CA CB  CO CIL COL O0 DGRAD  EPI            ACT              OUT_F32
+using H4Enc0F  = H5Cfg< 64, 32,  4, 0,  8,  3,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    false, false, ElF16>;          // config 4 (fp16): features.0
+using H4Enc1F  = H5Cfg< 32, 32,  8, 0,  8,  8,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    true,  false, ElF16>;          // features.3 -> fp32 (tail kernels)
+using H4Dec0F  = H5Cfg< 32, 32,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false, false, ElF16, true>;    // dec_model.0 (o1 fp32)
 using H5Enc0F  = H5Cfg<128, 16,  4, 0,  8,  3,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    false>;   // features.0 forward (+ argmax bytes)
 using H5Mask0F = H5Cfg<128,  8,  4, 8, 16, 11, 16, 0, false, EPI_PLAIN,     CGS_ACT_LRELU,   false>;   // masker.0 forward
 using H5Mask2F = H5Cfg<128,  8, 16, 0,  1, 16,  1, 0, false, EPI_PLAIN,     CGS_ACT_SIGMOID, true>;    // masker.2 forward
@@ -593,18 +428,18 @@ using H5Dec1DL = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_
 
 extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
     if (n < 0 || !x_u8 || !w_hwio || !bias || !e0_f16) return CGS_ERR_BADARG;
-    return hconv_launch<64, 4, 0, HCONV_ENC0_TH, true, false>(HConvParams{x_u8, nullptr, w_hwio, bias, e0_f16, n, 0, 0, nullptr}, (hipStream_t)stream);
+    return h5_launch<H4Enc0F>(H5Params{x_u8, nullptr, w_hwio, bias, e0_f16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream) {
     if (n < 0 || !e0_f16 || !w_hwio || !bias || !e1_f32) return CGS_ERR_BADARG;
-    return hconv_launch<32, 8, 0, 32, true, true>(HConvParams{e0_f16, nullptr, w_hwio, bias, e1_f32, n, 0, 0, nullptr}, (hipStream_t)stream);
+    return h5_launch<H4Enc1F>(H5Params{e0_f16, nullptr, w_hwio, bias, e1_f32, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f32, const float* w_hwio, const float* bias, void* o0_f16,
                                 cgs_stream_t stream) {
     if (n < 0 || !e0_f16 || !o1_f32 || !w_hwio || !bias || !o0_f16) return CGS_ERR_BADARG;
-    return hconv_launch<32, 8, 8, 32, false, false>(HConvParams{e0_f16, o1_f32, w_hwio, bias, o0_f16, n, 0, 0, nullptr}, (hipStream_t)stream);
+    return h5_launch<H4Dec0F>(H5Params{e0_f16, (const uint16_t*)o1_f32, w_hwio, bias, o0_f16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
 }
 
 // config 5 (the build-defined 128x128 variant, hourglass128.py): features.0 (3 -> 8 at 128x128 + ReLU + MaxPool2d(2)) with bf16 output
@@ -613,11 +448,7 @@ extern "C" int cgs_f16_dec0_fwd(int32_t n, const void* e0_f16, const float* o1_f
 extern "C" int cgs_bf16_enc0_fwd(int32_t n, const void* x, int32_t x_is_f32, const float* w_hwio, const float* bias, void* e0_bf16,
                                  uint8_t* codes, cgs_stream_t stream) {
     if (n < 0 || !x || !w_hwio || !bias || !e0_bf16) return CGS_ERR_BADARG;
-#ifdef CGS_ENC0_OLD
-    return hconv_launch<128, 4, 0, 16, true, false, ElBF16>(HConvParams{x, nullptr, w_hwio, bias, e0_bf16, n, 0, x_is_f32 ? 1 : 0, codes}, (hipStream_t)stream);
-#else
     return h5_launch<H5Enc0F>(H5Params{x, nullptr, w_hwio, bias, e0_bf16, codes, nullptr, n, 0, x_is_f32 ? 1 : 0}, (hipStream_t)stream);
-#endif
 }
 
 // ---- config 5, the 128x128 layers of the training step (h5conv_kernel above); weights / bias: the layer's fp32 HWIO master parameters ----

@@ -24,5 +24,7 @@ tools/prof_generic.sh final/prof_chfak5 > $out/prof_chfak5.txt 2>&1 || exit 1
 tools/prof_infer.sh final/prof_infer_f16 --fp16 > $out/prof_infer_f16.txt 2>&1 || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_config5_train -o runc -- python3 $root/bench.py --config 5 --mode train --steps 10 --warmup 2 > $out/prof_config5_train.log 2>&1 ) || exit 1
 tools/sq_counters.sh final/pmc || exit 1
+tools/sq_counters.sh final/pmc_c5 --config 5 --mode train || exit 1
+python tools/sq_counters.py gpurun_out/final/pmc_c5 gpurun_out/final/sq_counters_config5.csv
 python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.csv && python tools/traffic_from_counters.py gpurun_out/final/sq_counters.csv gpurun_out/final/traffic.json 512
 tail -1 $out/bench.json | cut -c1-300

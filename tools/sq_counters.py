@@ -54,7 +54,7 @@ with open(out, "w", newline="") as fp:
     for k, a in sorted(sq1.items(), key=lambda kv: -kv[1]["us"]):
         c1, c2 = a["c"], sq2.get(k, {"c": {}})["c"]
         wc = max(c1.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-        w.writerow([k[:90], a["calls"], round(a["us"], 1)] + [int(c1.get(c, 0)) for c in cols1] + [int(c2.get(c, 0)) for c in cols2] +
+        w.writerow([k.replace("(anonymous namespace)::", "")[:150], a["calls"], round(a["us"], 1)] + [int(c1.get(c, 0)) for c in cols1] + [int(c2.get(c, 0)) for c in cols2] +
                    [int(fe.get(k, {"c": {}})["c"].get("FETCH_SIZE", 0) * 1024), int(wr.get(k, {"c": {}})["c"].get("WRITE_SIZE", 0) * 1024),
                     int(any(s in k for s in STREAM16)),
                     round(c1.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3), round(c1.get("SQ_WAIT_INST_ANY", 0) / wc, 3),

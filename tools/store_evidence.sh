@@ -12,6 +12,7 @@ cp $f/bench.json profiles/${t}_bench.json
 cp $f/bench_driver_cmd.json profiles/${t}_bench_driver_cmd.json
 cp $f/sq_counters.csv profiles/${t}_sq_counters.csv
 cp $f/traffic.json profiles/${t}_traffic.json
+cp $f/sq_counters_config5.csv profiles/${t}_config5_sq_counters.csv
 sed -i "s#gpurun_out/final/sq_counters.csv#profiles/${t}_sq_counters.csv#" profiles/${t}_traffic.json
 cp $f/prof_chfak5/runc_kernel_stats.csv profiles/${t}_generic_chfak5_kernel_stats.csv
 cp $f/prof_infer_f16/runc_kernel_stats.csv profiles/${t}_infer2048_fp16_kernel_stats.csv
