@@ -492,3 +492,71 @@ class Unet(nn.Module):
             torch.cuda.current_stream().synchronize()      # temporaries of this call (re-laid-out weights) die with it
             y = y.permute(0, 3, 1, 2)
             return (y, u.permute(0, 3, 1, 2)) if embeds else y
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    """cgs_bn_act_fwd / cgs_bn_act_bwd (csrc/bn.hip) on an NHWC fp32 view; torch only permutes layouts."""
+
+    @staticmethod
+    def forward(ctx, mod, X, weight, bias):
+        lib = _lib.load()
+        x = X.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        n, h, w, c = x.shape
+        pixels = n * h * w
+        dev = x.device
+        train = bool(mod.training or mod.running_mean is None)
+        y, stats = torch.empty_like(x), torch.empty((c, 4), device=dev)
+        ws = torch.empty(((3 * lib.cgs_bn_rows(pixels, c) + 2) * c,), device=dev)
+        rm, rv = (mod.running_mean, mod.running_var) if (mod.running_mean is not None and (mod.training or not train)) else (None, None)
+        _lib.call("cgs_bn_act_fwd", pixels, c, gen._p(x), gen._p(weight.detach()) if weight is not None else None,
+                  gen._p(bias.detach()) if bias is not None else None, float(mod.eps), gen._ACT[mod.act], float(mod.slope), int(train), gen._p(y), gen._p(stats),
+                  gen._p(ws), gen._p(rm), gen._p(rv), float(mod.momentum), gen._s())
+        if mod.training and mod.num_batches_tracked is not None:
+            mod.num_batches_tracked += 1
+        ctx.save_for_backward(x, y, stats, ws)
+        ctx.meta = (pixels, c, gen._ACT[mod.act], float(mod.slope), int(train), weight is not None, bias is not None)
+        return y.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, gY):
+        x, y, stats, ws = ctx.saved_tensors
+        pixels, c, act, slope, train, has_w, has_b = ctx.meta
+        dy = gY.to(torch.float32).permute(0, 2, 3, 1).contiguous()
+        dx, dg, db = torch.empty_like(x), torch.empty(c, device=x.device), torch.empty(c, device=x.device)
+        _lib.call("cgs_bn_act_bwd", pixels, c, gen._p(x), gen._p(y), gen._p(dy), gen._p(stats), act, slope, train, gen._p(dx), gen._p(dg), gen._p(db),
+                  gen._p(ws), gen._s())
+        return None, dx.permute(0, 3, 1, 2), (dg if has_w else None), (db if has_b else None)
+
+
+class BatchNormAct2d(nn.Module):
+    """OPTIONAL BatchNorm2d + activation epilogue on the HIP kernels of csrc/bn.hip (SURVEY section 8 row f4 "optional BN epilogue"; the
+    north_star's BatchNorm wording).  The reference has no BatchNorm anywhere, so no reference module maps to this one and nothing pins it:
+    same constructor / buffers / train-eval semantics as torch.nn.BatchNorm2d (+ ``act`` in {"none", "relu", "lrelu"}, ``slope``), tested
+    against it.  NCHW in / out like every module here; channels a multiple of 4, at most 64.  Under data parallelism the statistics stay
+    per GPU (no collective), as the north_star prescribes."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, act="none", slope=0.01):
+        super().__init__()
+        if num_features % 4 or not 4 <= num_features <= 64:
+            _unsupported(f"BatchNormAct2d({num_features}): the kernels take 4 .. 64 channels in multiples of 4")
+        if act not in ("none", "relu", "lrelu"):
+            _unsupported(f"BatchNormAct2d(act={act!r})")
+        if momentum is None:
+            _unsupported("BatchNormAct2d(momentum=None) (cumulative moving average)")
+        self.num_features, self.eps, self.momentum, self.act, self.slope = num_features, eps, momentum, act, slope
+        self.weight = nn.Parameter(torch.ones(num_features)) if affine else None
+        self.bias = nn.Parameter(torch.zeros(num_features)) if affine else None
+        if track_running_stats:
+            self.register_buffer("running_mean", torch.zeros(num_features))
+            self.register_buffer("running_var", torch.ones(num_features))
+            self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        else:
+            self.running_mean = self.running_var = self.num_batches_tracked = None
+
+    def forward(self, X):
+        if not X.is_cuda:
+            raise _lib.CgsError("BatchNormAct2d: the HIP kernels need a GPU tensor; there is no CPU fallback")
+        if X.dim() != 4 or X.shape[1] != self.num_features:
+            raise _lib.CgsError(f"BatchNormAct2d({self.num_features}): expected [N,{self.num_features},H,W], got {tuple(X.shape)}")
+        return _BatchNormActFn.apply(self, X, self.weight, self.bias)
+

@@ -607,6 +607,19 @@ int cgs_gather_f32(const float* src, const int64_t* idx, int32_t n, float* dst, 
 const char* cgs_build_arch(void);
 int cgs_abi_version(void);
 
+/* ---- optional BatchNorm2d (+ ReLU / LeakyReLU) epilogue (csrc/bn.hip) ------------------------------------------------------------------
+ * SURVEY section 8 row f4 ("an optional BN epilogue") / the north_star's BN wording.  The reference has NO BatchNorm: this op is on
+ * no parity path and nothing of the reference pins it (tests: torch.nn.BatchNorm2d + autograd in float64).  NHWC fp32 x / y / dy / dx
+ * [pixels][c], c a multiple of 4, <= 64; act: CGS_ACT_NONE / RELU / LRELU.  train != 0: batch statistics (biased variance for the normalisation,
+ * unbiased into running_var, momentum as torch); train == 0: running statistics.  stats [c][4] = mean, 1/sqrt(var+eps), scale, shift.
+ * ws: (3 cgs_bn_rows(pixels, c) + 2) * c floats.  Statistics are per GPU under data parallelism (no collective).                          */
+int cgs_bn_rows(int64_t pixels, int32_t c);
+int cgs_bn_act_fwd(int64_t pixels, int32_t c, const float* x, const float* gamma, const float* beta, float eps, int32_t act, float slope,
+                   int32_t train, float* y, float* stats, float* ws, float* running_mean, float* running_var, float momentum,
+                   cgs_stream_t stream);
+int cgs_bn_act_bwd(int64_t pixels, int32_t c, const float* x, const float* y, const float* dy, const float* stats, int32_t act, float slope,
+                   int32_t train, float* dx, float* dgamma, float* dbeta, float* ws, cgs_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
