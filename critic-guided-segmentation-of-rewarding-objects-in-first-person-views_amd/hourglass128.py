@@ -10,12 +10,16 @@ behind the decoder -- and runs
                    replaced / injected mixes, critic on the mixes, lfak MSE(A) + MSE(replaced, B) + MSE(injected, A) + L1 |Z|,
                    Adam on critic + masker), Dropout off
 
-on bf16 kernels: bf16 activations and activation gradients in HBM, bf16 operand copies of the 3x3 weights, fp32 accumulation, fp32
-master weights / Adam state in ONE flat buffer (kernel layout: HWIO weights followed by their bias, k-major GEMM matrices).
-Forward and data gradients: csrc/gen_f16.hip (v_mfma_f32_16x16x16_bf16; the data gradient is the same kernel on the flipped /
-transposed operand); weight gradients: csrc/gen_bf16_train.hip (v_mfma_f32_16x16x32_bf16 over K = 32 pixels, operands through
-ds_read_b64_tr_b16); the 4x4 valid convolution, the Linear layers and the decoder's 1x1 pointwise convolution as MFMA GEMMs (bf16
-rows forward, fp32 backward: a few thousand multiply-adds per image).
+on bf16 kernels: bf16 activations and activation gradients in HBM, fp32 accumulation, fp32 master weights / Adam state in ONE flat
+buffer (kernel layout: HWIO weights followed by their bias, k-major GEMM matrices).  At chfak 1 (the benchmarked configuration):
+  * the 128x128 / 64x64 / 32x32 levels run on compile-time-shaped whole-strip kernels -- forward and data gradients with the step's
+    element-wise neighbours fused (csrc/hconv.hip: h5conv_kernel, v_mfma_f32_16x16x32_bf16), weight gradients over K = 32 pixels through
+    ds_read_b64_tr_b16 (csrc/hwgrad.hip);
+  * the 16x16-and-smaller levels have exactly the shapes of the 64x64 model's lower levels and run on ITS fp32 per-image tail kernels
+    (csrc/tail.hip: cgs_tail_enc_fwd / _bwd, cgs_tail_dec_fwd / _bwd, cgs_tail_head_wgrad); their activations are fp32.
+Other channel counts (chfak != 1, neck != 32): the shape-generic 16-bit family (csrc/gen_f16.hip forward / data gradient = the same
+kernel on the flipped / transposed operand; csrc/gen_bf16_train.hip weight gradient and element-wise steps; the 4x4 valid convolution,
+the Linear layers and the decoder's 1x1 pointwise convolution as MFMA GEMMs).
 PARITY UNPINNED: there is no reference counterpart; tests compare against the build's own fp32 CPU restatement and its autograd
 (oracle/hourglass_ref.py, hourglass128_apply / hourglass128_phase2_loss) with a stated bf16 tolerance.  Not wired into main.py (the
 reference's CLI has no such size); `bench.py --config 5 [--mode train]` measures it."""
