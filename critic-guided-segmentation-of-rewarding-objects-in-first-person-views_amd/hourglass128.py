@@ -595,6 +595,9 @@ class Hourglass128:
         and targets Y [n]; omitted inputs reuse the resident batch.  Returns the device tensor losses[8] = (critic, replace, inject,
         l1, l2, total, 0, 0)."""
         if self._train is None:
+            if self.d[0] != 8 or self.nb > 48 or self.mc > 16:
+                raise _lib.CgsError("Hourglass128.phase2_step: the bf16 weight-gradient kernels take the chfak 1 channel counts (<= 16 output, <= 48 input "
+                                    "channels per layer); chfak != 1 runs infer() only")
             if A_u8 is None:
                 raise _lib.CgsError("the first phase2_step needs the batch")
             self._train = Hourglass128._Train(self, A_u8.shape[0])

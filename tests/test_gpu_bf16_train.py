@@ -471,28 +471,45 @@ def _grad_dicts(net):
     return out
 
 
-@pytest.mark.parametrize("n", [6, 256])
-def test_config5_training_step_vs_autograd_of_the_build_restatement(n):
+@pytest.mark.parametrize("n,chfak,generic", [(6, 1, False), (256, 1, False), (6, 1, True)])
+def test_config5_training_step_vs_autograd_of_the_build_restatement(n, chfak, generic):
     """BASELINE config 5 as a TRAINING step (batch 256 = its stated size; 6 = a ragged small case): Hourglass128.phase2_step -- bf16
     activations / gradients, fp32 accumulate, fp32 master weights -- against the fp32 CPU autograd of oracle.hourglass128_phase2_loss.
     PARITY UNPINNED (no reference counterpart).  Stated bf16 tolerance: loss parts within 2e-2 relative (+1e-4), every gradient
     tensor with cosine similarity >= 0.995 to the fp32 gradient and relative L2 error <= 0.12 (measured worst: 0.99798 / 0.064 at n = 6,
     0.99962 / 0.030 at n = 256; bf16 carries 8 significant bits and the
     mask head sums 16 k pixels per weight; a pool-argmax flip between the bf16 and fp32 forward moves a whole window's gradient),
-    parameters after the Adam step within 2.2e-3 absolute (lr = 1e-3: the update is +-lr)."""
+    parameters after the Adam step within 2.2e-3 absolute (lr = 1e-3: the update is +-lr).
+    Kernel paths: chfak 1 on its dedicated whole-strip / tail kernels (the benchmarked form); the same model with those switched off
+    (generic = True) on the shape-generic 16-bit family (chfak != 1 is an inference-only configuration: see the test below)."""
     from cgs_amd import hourglass128
-    pc = orc.seeded_params(orc.critic128_shapes(), 31)
-    pm = orc.seeded_params(orc.masker128_shapes(), 32)
+    pc = orc.seeded_params(orc.critic128_shapes(chfak), 31)
+    pm = orc.seeded_params(orc.masker128_shapes(chfak), 32)
+    flags = ("TAIL", "H5CONV", "HWGRAD", "POOL_FUSED", "ENC0_DIRECT")
+    saved_flags = {k: getattr(hourglass128, k) for k in flags}
+    if generic:
+        for k in flags:
+            setattr(hourglass128, k, False)
     rs = np.random.RandomState(n)
     A = rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)
     B = rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)
     A[: n // 2] = (A[: n // 2] * 0.4).astype(np.uint8)
     Y = rs.rand(n).astype(np.float32)
-    net = hourglass128.Hourglass128(pc, pm)
-    losses = net.phase2_step(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(Y).cuda(), use_graph=False)
-    torch.cuda.synchronize()
-    got_l = losses.cpu().tolist()
-    gc, gm = _grad_dicts(net)
+    try:
+        net = hourglass128.Hourglass128(pc, pm, chfak=chfak)
+        assert net.tail == (chfak == 1) and net.h5 == (chfak == 1)
+        losses = net.phase2_step(torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(Y).cuda(), use_graph=False)
+        torch.cuda.synchronize()
+        got_l = losses.cpu().tolist()
+        gc, gm = _grad_dicts(net)
+        # a second and third step through the HIP graph run and stay finite (same kernel path)
+        l2 = net.phase2_step(use_graph=True)
+        l3 = net.phase2_step()
+        torch.cuda.synchronize()
+        assert torch.isfinite(l2).all() and torch.isfinite(l3).all() and int(net.step_t.item()) == 3
+    finally:
+        for k, v in saved_flags.items():
+            setattr(hourglass128, k, v)
     torch.set_num_threads(16)
     Pc, Pm = orc.leafify(pc), orc.leafify(pm)
     total, parts, Z, pred = orc.hourglass128_phase2_loss(Pc, Pm, torch.from_numpy(A).permute(0, 3, 1, 2).float() / 255.0,
@@ -512,17 +529,31 @@ def test_config5_training_step_vs_autograd_of_the_build_restatement(n):
                 worst = (cos, k, rel)
             assert cos >= 0.995 and rel <= 0.12, f"{k}: cosine {cos:.4f}, relative L2 error {rel:.3f}"
     print(f"n={n}: worst gradient cosine {worst[0]:.5f} ({worst[1]}, relative L2 error {worst[2]:.3f})")
-    # the Adam step moved every parameter by at most ~lr
+    # three Adam steps moved every parameter by at most ~3 lr
     sc, sm = net.state_dicts()
     for got, ref in ((sc, pc), (sm, pm)):
         for k, t in ref.items():
-            assert (got[k].cpu() - t).abs().max().item() <= 2.2e-3, k
-    assert int(net.step_t.item()) == 1
-    # a second step through the HIP graph runs and stays finite
-    l2 = net.phase2_step(use_graph=True)
-    l3 = net.phase2_step()
+            assert (got[k].cpu() - t).abs().max().item() <= 3 * 2.2e-3, k
+
+
+def test_config5_chfak2_is_inference_only():
+    """chfak 2 of the 128x128 variant: infer() runs on the shape-generic 16-bit kernels (checked against the fp32 restatement with the bf16
+    bound of the chfak-1 inference test); phase2_step refuses with a message instead of a bad-argument error from a kernel launcher."""
+    from cgs_amd import hourglass128, _lib
+    pc = orc.seeded_params(orc.critic128_shapes(2), 31)
+    pm = orc.seeded_params(orc.masker128_shapes(2), 32)
+    rs = np.random.RandomState(5)
+    X = rs.randint(0, 256, (4, 128, 128, 3)).astype(np.uint8)
+    net = hourglass128.Hourglass128(pc, pm, chfak=2)
+    assert not net.tail and not net.h5
+    pred, Z = net.infer(torch.from_numpy(X).cuda())
     torch.cuda.synchronize()
-    assert torch.isfinite(l2).all() and torch.isfinite(l3).all() and int(net.step_t.item()) == 3
+    with torch.no_grad():
+        rp, rz = orc.hourglass128_apply(pc, pm, torch.from_numpy(X).permute(0, 3, 1, 2).float() / 255.0)
+    assert (pred.cpu() - rp.reshape(-1)).abs().max().item() < 2e-2
+    assert (Z.cpu() - rz.reshape(4, 128, 128)).abs().max().item() < 4e-2
+    with pytest.raises(_lib.CgsError, match="chfak 1"):
+        net.phase2_step(torch.from_numpy(X).cuda(), torch.from_numpy(X).cuda(), torch.rand(4).cuda())
 
 
 DP128_WORKER = r"""
