@@ -236,8 +236,14 @@ struct HWg {
 };
 
 using HWgEnc0 = HWg<128, 4, 0, 8, 8>;        // features.0
-using HWgMask0 = HWg<128, 4, 8, 16, 4>;      // masker.0
-using HWgMask2 = HWg<128, 16, 0, 1, 4>;      // masker.2
+#ifndef HWG_TH_M0
+#define HWG_TH_M0 4
+#endif
+#ifndef HWG_TH_M2
+#define HWG_TH_M2 4
+#endif
+using HWgMask0 = HWg<128, 4, 8, 16, HWG_TH_M0>;      // masker.0
+using HWgMask2 = HWg<128, 16, 0, 1, HWG_TH_M2>;      // masker.2
 using HWgEnc1 = HWg<64, 8, 0, 8, 16>;        // features.3
 using HWgDec0 = HWg<64, 8, 8, 8, 8>;         // dec_model.0
 using HWgEnc0P = HWg<128, 4, 0, 8, 8, true>; // features.0 / features.3 from the pooled gradient + argmax bytes
