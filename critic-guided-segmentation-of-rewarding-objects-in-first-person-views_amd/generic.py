@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from .spec import Layout
 
+ENC0_DEDICATED = True       # features.0 (3 -> 8 chfak channels at 64x64) of chfak 2 .. 5 on csrc/gen_enc0.hip (False: the shape-generic gen4 kernel)
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 
 
@@ -139,6 +140,10 @@ def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: in
         out = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.float32)
     if am is None and pool and want_argmax:
         am = torch.empty((n, oh, oh, co), device=a.device, dtype=torch.uint8)
+    if ENC0_DEDICATED and hw == 64 and ca == 3 and cb == 0 and pool and act == "relu" and co in (16, 24, 32, 40):
+        # features.0 at chfak 2 .. 5: the kernel of its own (csrc/gen_enc0.hip: lane = pool cell, all weights in registers)
+        _lib.call("cgs_gen_enc0_fwd", n, co, int(a.dtype == torch.uint8), _p(a), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _p(am), _s())
+        return (out, am) if want_argmax else out
     wp = pack_weights(w_ptr, ca, cb, co, a.device)
     _lib.call("cgs_gen_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], float(slope), int(pool), _p(a),
               _p(b), _p(wp), C.c_void_p(bias_ptr), _p(out), _p(am), _s())

@@ -481,6 +481,11 @@ int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njobs, cgs_str
 int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                         int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                         const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
+/* features.0 of NewCritic at chfak 2 / 3 / 4 / 5 (co = 16 / 24 / 32 / 40; nets.py:170-172) on kernels of their own (csrc/gen_enc0.hip): same
+ * tensors as cgs_gen_conv3x3_fwd(hw 64, ca 3, ReLU, pool) -- out [n,32,32,co] + argmax bytes (am may be NULL) -- from x = uint8 (x_is_u8) or
+ * fp32 frames [n,64,64,3] and the layer's HWIO weights [9][3][co] (not packed).  CGS_ERR_UNSUPPORTED for other channel counts.          */
+int cgs_gen_enc0_fwd(int32_t n, int32_t co, int32_t x_is_u8, const void* x, const float* w_hwio, const float* bias, float* out, uint8_t* am,
+                     cgs_stream_t stream);
 int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
                  const float* bias, float* out, cgs_stream_t stream);
 

@@ -187,3 +187,39 @@ def test_gen4_window_operand_gives_the_second_source_gradient_alone():
     d_b = torch.full_like(db_ref, float("nan"))
     _lib.call("cgs_gen_conv3x3_bwd_data_split", n, hw, mc, 0, c, 2, P(dy), P(wp), None, P(d_b), gen._s())
     rel_close(d_b.cpu().numpy(), db_ref.cpu().numpy(), "d o0")
+
+
+@pytest.mark.parametrize("n,co,u8", [(3, 40, True), (5, 40, False), (300, 16, True), (2, 24, False), (2, 32, True), (160, 40, True)])
+def test_gen_enc0_dedicated_forward_vs_float64(n, co, u8):
+    """cgs_gen_enc0_fwd (features.0 of chfak 2 .. 5 on its own kernel: lane = pool cell, all weights in registers) against float64 conv2d +
+    ReLU + MaxPool2d: pooled output within the suite's forward bound, argmax bytes = max_pool2d's indices (first maximum wins; bit 2 where the
+    pooled value is <= 0); n = 300 / 160: more strips than persistent workgroups."""
+    from cgs_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n * 100 + co)
+    a = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=g) if u8 else torch.rand((n, 64, 64, 3), generator=g)
+    if u8:
+        a[0, :8, :8] = 90                   # a flat patch: exact ties
+    w = torch.randn((9, 3, co), generator=g) * 0.3
+    b = torch.randn(co, generator=g) * 0.2
+    b[0] = 0.7
+    ref, idx = _ref_conv(a, None, 1, w, b, "relu", 0.0, True)
+    a_g, w_g, b_g = a.cuda(), w.cuda(), b.cuda()
+    out = torch.full((n, 32, 32, co), 7.0, device="cuda")
+    am = torch.full((n, 32, 32, co), 99, device="cuda", dtype=torch.uint8)
+    rc = lib.cgs_gen_enc0_fwd(n, co, int(u8), C.c_void_p(a_g.data_ptr()), C.c_void_p(w_g.data_ptr()), C.c_void_p(b_g.data_ptr()),
+                              C.c_void_p(out.data_ptr()), C.c_void_p(am.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    rel_close(out.cpu(), ref, f"gen_enc0 forward n={n} co={co}", rtol=1e-4, atol_scale=2e-5)
+    pos = (((idx // 64) % 2) * 2 + (idx % 64) % 2).permute(0, 2, 3, 1)
+    want = torch.where(ref > 0, pos, torch.full_like(pos, 4))
+    got = am.cpu().long()
+    live = ref > 1e-4                       # (a pooled value within rounding of zero may carry either flag)
+    assert ((got & 4) == (want & 4))[live | (ref == 0)].all()
+    agree = ((got & 3) == (want & 3))[live].double().mean().item()
+    assert agree > 0.999, agree
+    if u8:      # the flat patch: the four positions of a cell run the same FMA chain on the same values -> exact ties -> position 0
+        assert ((got & 3)[0, 1:3, 1:3][live[0, 1:3, 1:3]] == 0).all()
+    assert lib.cgs_gen_enc0_fwd(1, 8, 1, C.c_void_p(a_g.data_ptr()), C.c_void_p(w_g.data_ptr()), C.c_void_p(b_g.data_ptr()),
+                                C.c_void_p(out.data_ptr()), None, None) == _lib.ERR_UNSUPPORTED
