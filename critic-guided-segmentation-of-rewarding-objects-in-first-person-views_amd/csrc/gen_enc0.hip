@@ -60,29 +60,50 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int e = tid; e < TROWS * 2; e += 256) tile[(e >> 1) * TW + ((e & 1) ? TW - 1 : 0)] = f4zero();      // halo columns: zero for every strip
     __syncthreads();
 
-    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+    // staging, split: fetch = the strip's global loads into registers (items of 4 pixels = 12 bytes / 12 floats; 288 items: two per thread at most),
+    // issued for strip s + 1 BEFORE strip s multiplies; commit = conversion + LDS stores after the barrier that ends strip s
+    float4 rx[2][3];
+    auto fetch = [&](int strip) {
         const int img = strip >> 2, row0 = (strip & 3) * 16;
-        // ---- stage the tile: items of 4 pixels (12 bytes / 12 floats) ----
-        for (int e = tid; e < TROWS * 16; e += 256) {
-            const int g4 = e & 15, r = e >> 4, y = row0 + r - 1;
-            const bool in = y >= 0 && y < 64;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + 256 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
+            const bool in = r < TROWS && y >= 0 && y < 64;
             const size_t gi = in ? (((size_t)img * 64 + y) * 64 + g4 * 4) * 3 / 4 : 0;
-            float f[12];
             if (P.a_is_u8) {
                 const uint32_t* su = (const uint32_t*)P.a;
-                const uint32_t d[3] = {su[gi], su[gi + 1], su[gi + 2]};
+                rx[k][0] = make_float4(__uint_as_float(su[gi]), __uint_as_float(su[gi + 1]), __uint_as_float(su[gi + 2]), 0.f);
+            } else {
+                const float4* sf = (const float4*)P.a;
+                rx[k][0] = sf[gi]; rx[k][1] = sf[gi + 1]; rx[k][2] = sf[gi + 2];
+            }
+        }
+    };
+    auto commit = [&](int strip) {
+        const int row0 = (strip & 3) * 16;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e = tid + 256 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
+            if (r >= TROWS) continue;
+            const bool in = y >= 0 && y < 64;
+            float f[12];
+            if (P.a_is_u8) {
+                const uint32_t d[3] = {__float_as_uint(rx[k][0].x), __float_as_uint(rx[k][0].y), __float_as_uint(rx[k][0].z)};
 #pragma unroll
                 for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
             } else {
-                const float4* sf = (const float4*)P.a;
-                const float4 f0 = sf[gi], f1 = sf[gi + 1], f2 = sf[gi + 2];
-                f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
-                f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
+                f[0] = rx[k][0].x; f[1] = rx[k][0].y; f[2] = rx[k][0].z; f[3] = rx[k][0].w; f[4] = rx[k][1].x; f[5] = rx[k][1].y;
+                f[6] = rx[k][1].z; f[7] = rx[k][1].w; f[8] = rx[k][2].x; f[9] = rx[k][2].y; f[10] = rx[k][2].z; f[11] = rx[k][2].w;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 tile[r * TW + 1 + 4 * g4 + j] = in ? make_float4(f[3 * j], f[3 * j + 1], f[3 * j + 2], 0.f) : f4zero();
         }
+    };
+    if ((int)blockIdx.x < P.nstrips) fetch(blockIdx.x);
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+        const int img = strip >> 2, row0 = (strip & 3) * 16;
+        commit(strip);
         __syncthreads();
 
         // ---- this wave's band: rows 4 wave .. + 3 of the strip; lane = cell (cy = lane >> 5, cx = lane & 31) ----
@@ -92,6 +113,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int c = 0; c < 4; ++c) pt[r][c] = tile[(4 * wave + 2 * cy + r) * TW + 2 * cx + c];
+        if (strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);      // in flight while this strip multiplies
         ge_static_for<NPASS>([&](auto PASS) {
             constexpr int pass = decltype(PASS)::value;
             frag4 acc[4][GP];
@@ -121,12 +143,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 uint32_t word = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float v0 = fmaxf(acc[0][g][i] + ba[i], 0.f), v1 = fmaxf(acc[1][g][i] + ba[i], 0.f), v2 = fmaxf(acc[2][g][i] + ba[i], 0.f),
-                                v3 = fmaxf(acc[3][g][i] + ba[i], 0.f);
-                    const float mm = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                    const uint32_t cd = v0 == mm ? 0u : (v1 == mm ? 1u : (v2 == mm ? 2u : 3u));       // first position holding the maximum
-                    word |= (cd | (mm > 0.f ? 0u : 4u)) << (8 * i);
-                    m[i] = mm;
+                    // max over the cell of ReLU(v) = ReLU(max v); where that is positive the first position holding max v is the first one holding
+                    // the maximum of the ReLU'd values (where it is not, bit 2 says "no gradient" and the position is not read)
+                    const float v0 = acc[0][g][i] + ba[i], v1 = acc[1][g][i] + ba[i], v2 = acc[2][g][i] + ba[i], v3 = acc[3][g][i] + ba[i];
+                    const float mv = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                    const uint32_t cd = v0 == mv ? 0u : (v1 == mv ? 1u : (v2 == mv ? 2u : 3u));
+                    word |= (cd | (mv > 0.f ? 0u : 4u)) << (8 * i);
+                    m[i] = fmaxf(mv, 0.f);
                 }
                 *(float4*)(ob + lane * PITCH + 4 * (pass * GP + g)) = make_float4(m[0], m[1], m[2], m[3]);
                 cb[lane * NG + pass * GP + g] = word;
@@ -177,6 +200,189 @@ extern "C" int cgs_gen_enc0_fwd(int32_t n, int32_t co, int32_t x_is_u8, const vo
         case 24: return genc0_fwd_launch<6, 3>(P, (hipStream_t)stream);
         case 32: return genc0_fwd_launch<8, 4>(P, (hipStream_t)stream);
         case 40: return genc0_fwd_launch<10, 5>(P, (hipStream_t)stream);
+    }
+    return CGS_ERR_UNSUPPORTED;
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// features.0, weight + bias gradient: dW[(tap, c)][oc] = sum over pixels of X[pixel + tap][c] * dY[pixel][oc], with dY given as the POOLED
+// gradient d e0 [n,32,32,co] + the forward pass's argmax bytes (the gradient sits at the pixel that held the cell's maximum).
+// v_mfma_f32_4x4x1_16B_f32 WITHOUT broadcast = 16 independent 4x4 outer products: block b = pixel b of a 16-pixel step, A = four of the
+// 28 rows ((tap, c) pairs + the bias row of ones) of that pixel, B = four output channels of that pixel; the 16 blocks are 16 partial
+// sums that are added once, at the end of a workgroup's life.  7 row quads x NG column quads = 70 instructions per 16 pixels at 40 channels;
+// wave w owns the column quads w, w + 4, w + 8 (<= 21 accumulators) and walks every pixel of the strip: A is one 4-byte LDS read per row quad
+// (per-lane tap offsets precomputed), B one value + one argmax byte per column quad, selected on the fly.  The shape-generic row-block
+// kernel (gen_wgrad_rows.h) ran this layer at 14 % of the fp32 matrix peak (27 rows = 2 padded row blocks of 16x16x4 tiles, 8 waves sharing
+// one staged chunk of 3 channels).
+struct GEnc0WgParams {
+    const void* a;            // uint8 or fp32 frames [n,64,64,3]
+    const float* de;          // pooled gradient [n,32,32,co]
+    const uint8_t* am;        // argmax bytes [n,32,32,co]
+    float* slab;              // [blocks][27 co + co]
+    int n, a_is_u8, nstrips;
+};
+
+template <int NG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) genc0_wgrad_kernel(GEnc0WgParams P) {
+    constexpr int CO = 4 * NG, TW = 66, TH = 8, TROWS = TH + 2, NQW = (NG + 3) / 4;      // NQW: column quads per wave (at most)
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    float4* const tile = gsm;                                       // [TROWS][TW] float4 (r, g, b, 1): the 1 is the bias row's operand
+    float* const des = (float*)(gsm + TROWS * TW);                  // [TH / 2][32][CO] pooled gradient
+    uint8_t* const ams = (uint8_t*)(des + (TH / 2) * 32 * CO);      // [TH / 2][32][CO] argmax bytes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = lane >> 2, i = lane & 3;
+
+    // A operand of row quad rq, lane 4 b + i: row r = 4 rq + i = (tap, c) -> float offset inside the tile relative to the pixel; row 27 = the ones
+    int aoff[7];
+#pragma unroll
+    for (int rq = 0; rq < 7; ++rq) {
+        const int r = 4 * rq + i, tap = r < 27 ? r / 3 : 4, c = r < 27 ? r % 3 : 3;
+        aoff[rq] = ((tap / 3) * TW + tap % 3) * 4 + c;
+    }
+    frag4 acc[NQW][7];
+#pragma unroll
+    for (int q = 0; q < NQW; ++q)
+#pragma unroll
+        for (int rq = 0; rq < 7; ++rq) acc[q][rq] = frag4{0.f, 0.f, 0.f, 0.f};
+
+    for (int e = tid; e < TROWS * 2; e += 256) tile[(e >> 1) * TW + ((e & 1) ? TW - 1 : 0)] = f4zero();      // halo columns
+    __syncthreads();
+
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+        const int img = strip >> 3, row0 = (strip & 7) * TH;
+        // ---- staging: every global load of the strip issued back to back (ONE memory round trip per strip), then converted / stored ----
+        constexpr int NDE = (TH / 2) * 32 * CO / 4, NIT = (NDE + 255) / 256;        // float4 / uint32 items of the pooled gradient / argmax bytes
+        float4 rx[3], rd[NIT];
+        uint32_t ra[NIT];
+        const bool xitem = tid < TROWS * 16;                        // frames: items of 4 pixels, one per thread
+        const int g4 = tid & 15, xr = tid >> 4, xy = row0 + xr - 1;
+        const bool xin = xitem && xy >= 0 && xy < 64;
+        {
+            const size_t gi = xin ? (((size_t)img * 64 + xy) * 64 + g4 * 4) * 3 / 4 : 0;
+            if (P.a_is_u8) {
+                const uint32_t* su = (const uint32_t*)P.a;
+                rx[0] = make_float4(__uint_as_float(su[gi]), __uint_as_float(su[gi + 1]), __uint_as_float(su[gi + 2]), 0.f);
+            } else {
+                const float4* sf = (const float4*)P.a;
+                rx[0] = sf[gi]; rx[1] = sf[gi + 1]; rx[2] = sf[gi + 2];
+            }
+            const size_t base = ((size_t)img * 32 + row0 / 2) * 32 * CO;
+            const float4* sd = (const float4*)(P.de + base);
+            const uint32_t* sa = (const uint32_t*)(P.am + base);
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                const int e = tid + 256 * k, ee = e < NDE ? e : NDE - 1;
+                rd[k] = sd[ee]; ra[k] = sa[ee];
+            }
+        }
+        if (xitem) {
+            float f[12];
+            if (P.a_is_u8) {
+                const uint32_t d[3] = {__float_as_uint(rx[0].x), __float_as_uint(rx[0].y), __float_as_uint(rx[0].z)};
+#pragma unroll
+                for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+            } else {
+                f[0] = rx[0].x; f[1] = rx[0].y; f[2] = rx[0].z; f[3] = rx[0].w; f[4] = rx[1].x; f[5] = rx[1].y; f[6] = rx[1].z; f[7] = rx[1].w;
+                f[8] = rx[2].x; f[9] = rx[2].y; f[10] = rx[2].z; f[11] = rx[2].w;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                tile[xr * TW + 1 + 4 * g4 + j] = xin ? make_float4(f[3 * j], f[3 * j + 1], f[3 * j + 2], 1.f) : make_float4(0.f, 0.f, 0.f, 1.f);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            if (e < NDE) { ((float4*)des)[e] = rd[k]; ((uint32_t*)ams)[e] = ra[k]; }
+        }
+        __syncthreads();
+        // ---- 16-pixel steps: 16 consecutive pixels of a row; block b = pixel x0 + b ----
+#pragma unroll 2
+        for (int s = 0; s < TH * 4; ++s) {
+            const int y = s >> 2, x = (s & 3) * 16 + b;
+            const float* px = (const float*)(tile + y * TW + x);    // tap (0,0) of the pixel's 3x3 window (tile row 0 = image row row0 - 1)
+            float av[7];
+#pragma unroll
+            for (int rq = 0; rq < 7; ++rq) av[rq] = px[aoff[rq]];
+            const int cell = (y >> 1) * 32 + (x >> 1);
+            const uint32_t pos = 2 * (y & 1) + (x & 1);
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) {
+                const int cq = wave + 4 * q;                        // this wave's column quad (wave-uniform test below)
+                if (cq < NG) {
+                    const int col = cell * CO + 4 * cq + i;
+                    const float bv = ams[col] == pos ? des[col] : 0.f;
+#pragma unroll
+                    for (int rq = 0; rq < 7; ++rq) acc[q][rq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rq], bv, acc[q][rq], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- add the 16 blocks (lanes with equal lane & 3), one slab row per workgroup: D_b[r][j] -> row 4 rq + r, column 4 cq + j (j = lane & 3) ----
+    float* const sl = P.slab + (size_t)blockIdx.x * (28 * CO);
+#pragma unroll
+    for (int q = 0; q < NQW; ++q) {
+        const int cq = wave + 4 * q;
+        if (cq >= NG) continue;
+#pragma unroll
+        for (int rq = 0; rq < 7; ++rq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[q][rq][r];
+                v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                const int row = 4 * rq + r;                         // rows 0 .. 26: (tap, c); row 27: bias
+                if (lane < 4) sl[(row < 27 ? row * CO : 27 * CO) + 4 * cq + lane] = v;
+            }
+    }
+}
+
+template <int NG>
+struct GEnc0Wg {
+    static constexpr int CO = 4 * NG;
+    static constexpr size_t lds = (size_t)10 * 66 * 16 + (size_t)4 * 32 * CO * 4 + (size_t)4 * 32 * CO;
+    static int blocks(int n) {
+        const int nstrips = n * 8;
+        if (nstrips <= 0) return 0;
+        int per_cu = (int)((160 * 1024) / lds);
+        per_cu = per_cu < 3 ? per_cu : 3;
+        const int cap = 256 * per_cu, rounds = (nstrips + cap - 1) / cap;
+        return (nstrips + rounds - 1) / rounds;
+    }
+    static int launch(GEnc0WgParams P, hipStream_t st) {
+        P.nstrips = P.n * 8;
+        hipLaunchKernelGGL(genc0_wgrad_kernel<NG>, dim3(blocks(P.n)), dim3(256), lds, st, P);
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
+};
+
+}  // namespace
+
+// Slab rows cgs_gen_enc0_bwd_weight writes for n images (0: unsupported channel count).
+extern "C" int cgs_gen_enc0_bwd_weight_slabs(int32_t n, int32_t co) {
+    if (n < 0) return CGS_ERR_BADARG;
+    switch (co) {
+        case 16: return GEnc0Wg<4>::blocks(n);
+        case 24: return GEnc0Wg<6>::blocks(n);
+        case 32: return GEnc0Wg<8>::blocks(n);
+        case 40: return GEnc0Wg<10>::blocks(n);
+    }
+    return 0;
+}
+
+// dW / db slabs [rows][27 co + co] of features.0 (co = 16 / 24 / 32 / 40) from the frames x (uint8 / fp32 [n,64,64,3]), the pooled gradient
+// de [n,32,32,co] and the forward pass's argmax bytes am (same tensors as cgs_gen_conv3x3_bwd_weight(hw 64, ca 3, cb 0)).
+extern "C" int cgs_gen_enc0_bwd_weight(int32_t n, int32_t co, int32_t x_is_u8, const void* x, const float* de, const uint8_t* am, float* slab,
+                                       cgs_stream_t stream) {
+    if (n < 0 || !x || !de || !am || !slab) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const GEnc0WgParams P{x, de, am, slab, n, x_is_u8 ? 1 : 0, 0};
+    switch (co) {
+        case 16: return GEnc0Wg<4>::launch(P, (hipStream_t)stream);
+        case 24: return GEnc0Wg<6>::launch(P, (hipStream_t)stream);
+        case 32: return GEnc0Wg<8>::launch(P, (hipStream_t)stream);
+        case 40: return GEnc0Wg<10>::launch(P, (hipStream_t)stream);
     }
     return CGS_ERR_UNSUPPORTED;
 }

@@ -406,8 +406,14 @@ def _bwd_data(n, hw, co, ci, dy, am, w_ptr: int, out, addend=None):
 def _wgrad(plan, ws: Workspace, tag: str, dst_off: int, n, hw, a, b, ups, dy, am, co):
     """Weight + bias gradient of one 3x3 layer over n images: slab rows registered in `plan` for cgs_reduce_slabs."""
     ca, cb = a.shape[-1], (0 if b is None else b.shape[-1])
-    nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_slabs(n, ca, cb, co)
     cnt = 9 * (ca + cb) * co + co
+    if ENC0_DEDICATED and hw == 64 and ca == 3 and cb == 0 and co in (16, 24, 32, 40):      # features.0 at chfak 2 .. 5: csrc/gen_enc0.hip
+        nsl = _lib.load().cgs_gen_enc0_bwd_weight_slabs(n, co)
+        slab = ws.buf("slab_" + tag, (nsl, cnt), a.device)
+        _lib.call("cgs_gen_enc0_bwd_weight", n, co, int(a.dtype == torch.uint8), _p(a), _p(dy), _p(am), _p(slab), _s())
+        plan.add(slab, nsl, cnt, dst_off)
+        return
+    nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_slabs(n, ca, cb, co)
     slab = ws.buf("slab_" + tag, (nsl, cnt), a.device)
     _lib.call("cgs_gen_conv3x3_bwd_weight", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _p(a), _p(b), _p(dy), _p(am),
               _p(slab), _s())

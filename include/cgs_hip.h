@@ -486,6 +486,11 @@ int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t c
  * fp32 frames [n,64,64,3] and the layer's HWIO weights [9][3][co] (not packed).  CGS_ERR_UNSUPPORTED for other channel counts.          */
 int cgs_gen_enc0_fwd(int32_t n, int32_t co, int32_t x_is_u8, const void* x, const float* w_hwio, const float* bias, float* out, uint8_t* am,
                      cgs_stream_t stream);
+/* ... and the layer's weight + bias gradient: slab rows [cgs_gen_enc0_bwd_weight_slabs(n, co)][27 co + co] (-> cgs_reduce_slabs) from the frames,
+ * the pooled gradient de [n,32,32,co] and the forward pass's argmax bytes (the tensors of cgs_gen_conv3x3_bwd_weight(hw 64, ca 3, cb 0)).   */
+int cgs_gen_enc0_bwd_weight_slabs(int32_t n, int32_t co);
+int cgs_gen_enc0_bwd_weight(int32_t n, int32_t co, int32_t x_is_u8, const void* x, const float* de, const uint8_t* am, float* slab,
+                            cgs_stream_t stream);
 int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
                  const float* bias, float* out, cgs_stream_t stream);
 

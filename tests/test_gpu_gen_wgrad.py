@@ -134,3 +134,38 @@ def test_gemm_ex_splitk_bad_arguments():
     x = torch.zeros(16, device="cuda:0")
     p = C.c_void_p(x.data_ptr())
     assert lib.cgs_gen_gemm_ex_splitk(4, 4, 4, p, 1, 4, p, 4, 1, 0, p, None) != 0
+
+
+@pytest.mark.parametrize("n,co,u8", [(5, 40, True), (3, 40, False), (200, 16, False), (2, 24, True), (2, 32, False), (130, 40, False)])
+def test_gen_enc0_dedicated_weight_gradient_vs_float64_autograd(n, co, u8):
+    """cgs_gen_enc0_bwd_weight (features.0 of chfak 2 .. 5 on its own kernel: 4x4x1 outer products, block = pixel, pooled dY + argmax bytes
+    selected on the fly) against float64 autograd; every slab element written; same bits on a second call; n = 200 / 130: more strips than
+    persistent workgroups."""
+    from cgs_amd import _lib, generic
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77 * co + n)
+    a = torch.randint(0, 256, (n, 64, 64, 3), dtype=torch.uint8, generator=g) if u8 else torch.randn(n, 64, 64, 3, generator=g)
+    dE = torch.randn(n, 32, 32, co, generator=g)
+    am = torch.randint(0, 5, (n, 32, 32, co), dtype=torch.uint8, generator=g)
+    am = torch.where(torch.rand(am.shape, generator=g) < 0.1, am | 4, am)
+    full = torch.zeros(n, 32, 2, 32, 2, co)
+    for py in range(2):
+        for px in range(2):
+            full[:, :, py, :, px, :] = torch.where(am == 2 * py + px, dE, torch.zeros(()))
+    ref = _ref_wgrad(a, None, 1, full.view(n, 64, 64, co), co)
+    lib = _lib.load()
+    nsl = lib.cgs_gen_enc0_bwd_weight_slabs(n, co)
+    assert nsl >= 1 and lib.cgs_gen_enc0_bwd_weight_slabs(n, 8) == 0
+    cnt = 27 * co + co
+    a_d, de_d, am_d = a.to(dev), dE.to(dev), am.to(dev)
+    slab = torch.full((nsl, cnt), float("nan"), device=dev)
+    _lib.call("cgs_gen_enc0_bwd_weight", n, co, int(u8), generic._p(a_d), generic._p(de_d), generic._p(am_d), generic._p(slab), generic._s())
+    torch.cuda.synchronize()
+    got = slab.double().sum(0).cpu()
+    assert torch.isfinite(got).all(), "an element of a slab row was not written"
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6, f"weight gradient off by {err:.2e} of its maximum"
+    slab2 = torch.zeros_like(slab)
+    _lib.call("cgs_gen_enc0_bwd_weight", n, co, int(u8), generic._p(a_d), generic._p(de_d), generic._p(am_d), generic._p(slab2), generic._s())
+    torch.cuda.synchronize()
+    assert torch.equal(slab, slab2)
