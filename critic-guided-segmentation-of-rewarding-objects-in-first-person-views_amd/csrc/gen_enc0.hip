@@ -35,19 +35,26 @@ __device__ __forceinline__ void ge_static_for(F&& f) {
 
 __device__ __forceinline__ float ge_f4get(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
-// NG: output groups of 4 channels (co = 4 NG); GP: groups per pass (NG % GP == 0)
+// NG: output groups of 4 channels (co = 4 NG); GP: groups per pass (NG % GP == 0).
+// Every WAVE works on its own: it stages the 6 input rows of its 64 x 4 pixel band into a private LDS block (the halo rows are loaded twice per
+// image: 3 bytes per pixel), multiplies, pools, and copies its two pooled rows out through the same block -- no workgroup barrier anywhere in the
+// loop.  (r4 A/B: a 16-row strip per workgroup with two barriers per strip, with and without the next strip's loads in flight under the matrix
+// loop, measures the same 127 us per 1024 frames at 40 channels: the kernel is bound by instruction issue -- 1080 matrix + ~930 vector
+// instructions per 256 pixels, 0.45-0.5 of the fp32 matrix peak -- not by barriers or staging.)
 template <int NG, int GP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) genc0_fwd_kernel(GEnc0FwdParams P) {
     constexpr int CO = 4 * NG, NK = 27 * NG, NV = (NK + 15) / 16, NPASS = NG / GP;
-    constexpr int TW = 66, TROWS = 18;                      // input tile: 16 rows + halo, 64 columns + halo, float4 (r, g, b, 0) per pixel
+    constexpr int TW = 66, TROWS = 6;                       // a wave's input tile: 4 rows + halo, 64 columns + halo, float4 (r, g, b, 0) per pixel
     constexpr int PITCH = CO + 4;                           // floats per cell in the output block (pitch = 4 mod 8 quads: conflict-free b128)
+    constexpr int OBF = 64 * PITCH + 64 * NG, TF = TROWS * TW * 4;
+    constexpr int WBLK = OBF > TF ? OBF : TF;               // floats of a wave's block: values [64][PITCH] + codes [64][NG]; the tile aliases its head
     static_assert(NG % GP == 0, "passes of equal size");
     extern __shared__ __attribute__((aligned(16))) float4 gsm[];
-    float4* const tile = gsm;                               // [TROWS][TW]
-    float* const bias_s = (float*)(gsm + TROWS * TW);       // [CO]
-    float* const ob = bias_s + CO + (threadIdx.x >> 6) * (64 * PITCH + 64 * NG);      // this wave's output block: values [64][PITCH], then codes [64][NG]
-    uint32_t* const cb = (uint32_t*)(ob + 64 * PITCH);
+    float* const bias_s = (float*)gsm;                      // [CO]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* const ob = bias_s + CO + wave * WBLK;
+    uint32_t* const cb = (uint32_t*)(ob + 64 * PITCH);
+    float4* const tile = (float4*)ob;                       // [TROWS][TW]: dead once the patch is in registers
 
     // ---- weights -> registers: register v, lane 4 b + i = combination q = 16 v + b = (k-step ks = q / NG, group g = q % NG), output channel 4 g + i ----
     float wreg[NV];
@@ -57,17 +64,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         wreg[v] = q < NK ? P.w[ks * CO + 4 * g + (lane & 3)] : 0.f;
     }
     for (int e = tid; e < CO; e += 256) bias_s[e] = P.bias[e];
-    for (int e = tid; e < TROWS * 2; e += 256) tile[(e >> 1) * TW + ((e & 1) ? TW - 1 : 0)] = f4zero();      // halo columns: zero for every strip
-    __syncthreads();
+    __syncthreads();                                        // (the only workgroup barrier: the bias table)
 
-    // staging, split: fetch = the strip's global loads into registers (items of 4 pixels = 12 bytes / 12 floats; 288 items: two per thread at most),
-    // issued for strip s + 1 BEFORE strip s multiplies; commit = conversion + LDS stores after the barrier that ends strip s
+    // staging: the band's 6 rows x 16 items of 4 pixels (12 bytes / 12 floats) = 96 items, two per lane at most: fetch (all loads back to back),
+    // then commit (conversion + LDS stores)
     float4 rx[2][3];
-    auto fetch = [&](int strip) {
-        const int img = strip >> 2, row0 = (strip & 3) * 16;
+    auto fetch = [&](int band) {
+        const int img = band >> 4, row0 = (band & 15) * 4;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int e = tid + 256 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
+            const int e = lane + 64 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
             const bool in = r < TROWS && y >= 0 && y < 64;
             const size_t gi = in ? (((size_t)img * 64 + y) * 64 + g4 * 4) * 3 / 4 : 0;
             if (P.a_is_u8) {
@@ -79,11 +85,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
     };
-    auto commit = [&](int strip) {
-        const int row0 = (strip & 3) * 16;
+    auto commit = [&](int band) {
+        const int row0 = (band & 15) * 4;
+        if (lane < TROWS * 2) tile[(lane >> 1) * TW + ((lane & 1) ? TW - 1 : 0)] = f4zero();       // halo columns (the block was the output block)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int e = tid + 256 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
+            const int e = lane + 64 * k, g4 = e & 15, r = e >> 4, y = row0 + r - 1;
             if (r >= TROWS) continue;
             const bool in = y >= 0 && y < 64;
             float f[12];
@@ -100,20 +107,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 tile[r * TW + 1 + 4 * g4 + j] = in ? make_float4(f[3 * j], f[3 * j + 1], f[3 * j + 2], 0.f) : f4zero();
         }
     };
-    if ((int)blockIdx.x < P.nstrips) fetch(blockIdx.x);
-    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
-        const int img = strip >> 2, row0 = (strip & 3) * 16;
-        commit(strip);
-        __syncthreads();
-
-        // ---- this wave's band: rows 4 wave .. + 3 of the strip; lane = cell (cy = lane >> 5, cx = lane & 31) ----
+    const int nwaves = gridDim.x * 4, band0 = blockIdx.x * 4 + wave;
+    for (int band = band0; band < P.nstrips; band += nwaves) {
+        const int img = band >> 4, row0 = (band & 15) * 4;
+        fetch(band);
+        commit(band);
+        __builtin_amdgcn_wave_barrier();
+        // ---- lane = cell (cy = lane >> 5, cx = lane & 31) of the band ----
         const int cy = lane >> 5, cx = lane & 31;
         float4 pt[4][4];                                    // input patch rows 2 cy - 1 .. + 2, columns 2 cx - 1 .. + 2 (tile coordinates: + 1)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) pt[r][c] = tile[(4 * wave + 2 * cy + r) * TW + 2 * cx + c];
-        if (strip + (int)gridDim.x < P.nstrips) fetch(strip + gridDim.x);      // in flight while this strip multiplies
+            for (int c = 0; c < 4; ++c) pt[r][c] = tile[(2 * cy + r) * TW + 2 * cx + c];
+        __builtin_amdgcn_wave_barrier();                    // (every lane's patch is read before any lane writes results into the same block)
         ge_static_for<NPASS>([&](auto PASS) {
             constexpr int pass = decltype(PASS)::value;
             frag4 acc[4][GP];
@@ -155,31 +162,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 cb[lane * NG + pass * GP + g] = word;
             }
         });
-        // ---- the wave's 2 pooled rows x 32 cells x CO channels leave in full lines (same wave wrote them: no workgroup barrier) ----
+        // ---- the wave's 2 pooled rows x 32 cells x CO channels leave in full lines ----
         __builtin_amdgcn_wave_barrier();                    // (LDS operations of one wave execute in order: the reads below see the writes above)
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-            const size_t rowbase = (((size_t)img * 32 + row0 / 2 + 2 * wave + r) * 32) * CO;
+            const size_t rowbase = (((size_t)img * 32 + row0 / 2 + r) * 32) * CO;
             for (int f = lane; f < 32 * NG; f += 64) {
                 const int cell = f / NG, g = f % NG;
                 *(float4*)(P.out + rowbase + 4 * f) = *(const float4*)(ob + (r * 32 + cell) * PITCH + 4 * g);
                 if (P.am) *(uint32_t*)(P.am + rowbase + 4 * f) = cb[(r * 32 + cell) * NG + g];
             }
         }
-        __syncthreads();            // every wave is done with the tile (and its output block) before the next strip
+        __builtin_amdgcn_wave_barrier();                    // (results read out before the next band's tile overwrites the block)
     }
 }
 
 template <int NG, int GP>
 int genc0_fwd_launch(GEnc0FwdParams P, hipStream_t st) {
     constexpr int CO = 4 * NG;
-    constexpr size_t lds = (size_t)18 * 66 * 16 + (size_t)CO * 4 + 4 * ((size_t)64 * (CO + 4) + 64 * NG) * 4;
-    P.nstrips = P.n * 4;
+    constexpr size_t obf = (size_t)64 * (CO + 4) + 64 * NG, tf = (size_t)6 * 66 * 4;
+    constexpr size_t lds = (size_t)CO * 4 + 4 * (obf > tf ? obf : tf) * 4;
+    P.nstrips = P.n * 16;                                   // bands of 4 rows, one per wave and trip
     auto k = genc0_fwd_kernel<NG, GP>;
-    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return (int)attr;
-    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
-    const int cap = 256 * per_cu, rounds = (P.nstrips + cap - 1) / cap, blocks = (P.nstrips + rounds - 1) / rounds;
+    if (lds > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return (int)attr;
+    }
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;      // (226+ registers: two waves per SIMD)
+    const int cap = 256 * per_cu, wgs = (P.nstrips + 3) / 4, rounds = (wgs + cap - 1) / cap, blocks = (wgs + rounds - 1) / rounds;
     hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
