@@ -200,6 +200,8 @@ def flat_grads(sl):
     g = torch.zeros(lc.total + lm.total)
     lc.flatten(rec["grads_c"], g[:lc.total]); lm.flatten(rec["grads_m"], g[lc.total:])
     return g
+ok, note = parallel.collective_capturable(pg, torch.device("cpu"))      # gloo stages through the host: never recorded in a HIP graph
+assert ok is False and "gloo" in note, (ok, note)
 # every rank starts from rank 0's parameters
 p = torch.full((5,), float(rank)); parallel.broadcast_params_(p, pg); assert float(p.sum()) == 0.0
 g = flat_grads(parallel.shard_slice(n, rank, world))
