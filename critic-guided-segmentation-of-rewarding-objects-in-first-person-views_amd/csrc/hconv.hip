@@ -27,6 +27,10 @@
 #ifndef H5_PAIR16
 #define H5_PAIR16 0              // h5conv: 1 = tile pairing also for 16-channel pixels with 8 outputs (20 more weight registers; r4 A/B: 0.8 % slower per config-5 step)
 #endif
+#ifndef H5_QUAD
+#define H5_QUAD 0                // h5conv: 1 = three-channel outputs share an accumulator between four pixel tiles (r4 A/B: the four weight sets push the
+                                  // kernel past 128 registers -- three instead of four workgroups per CU: 81 vs 64 us for the fused mix backward)
+#endif
 #ifndef H5_XCD
 #define H5_XCD 1                 // h5conv: XCD-contiguous strip order (0: round-robin; r4 A/B: no difference -- the halo rows two strips share come out of
                                   // the memory-side cache either way)
@@ -66,16 +70,22 @@ struct H5Params {
     uint8_t* codes;         // EPI_POOLMAX: argmax bytes or NULL (written); APOOL: the argmax bytes of source A (read)
     const uint16_t* hm;     // EPI_LRELU_BWD: the layer's own output of the forward pass, bf16 [n,HW,HW,CO]
     int n, nstrips, a_f32;
+    // AMIX / EPI_MIXBWD (features.0's data gradient + the mix backward, main.py:395,406 differentiated): source = the pooled gradient of the replaced
+    // mix of image i MINUS that of its injected mix (images n + i of a / codes): d rep - d inj, which is all the mask gradient needs
+    // (mix_rep = A + Z (B - A), mix_inj = B - Z (B - A)); epilogue: out = dzpre [n,HW,HW] = (sum_c d_c (B_c - A_c) + l1s sign(Z) + 2 l2s Z) Z (1 - Z)
+    const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z;
+    float mix_l1s, mix_l2s;
 };
 
-enum { EPI_PLAIN = 0, EPI_POOLMAX = 1, EPI_POOLSUM = 2, EPI_LRELU_BWD = 3 };
+enum { EPI_PLAIN = 0, EPI_POOLMAX = 1, EPI_POOLSUM = 2, EPI_LRELU_BWD = 3, EPI_MIXBWD = 4 };
 
 // CA: LDS channels of source A (4 = rgb0 frames, 1 = fp32 single channel, 8 / 16 = bf16); CB: 0 / 8; CO: output channels of the kernel;
 // CIL, COL: the LAYER's input / output channels (weight strides); DGRAD: the kernel computes the data gradient of the layer with respect to
 // its input channels O0 .. O0 + CO - 1 (source = dY with COL channels); EPI / ACT: epilogue; OUT_F32: fp32 output (else bf16)
 template <int HW_, int TH_, int CA_, int CB_, int CO_, int CIL_, int COL_, int O0_, bool DGRAD_, int EPI_, int ACT_, bool OUT_F32_, bool APOOL_ = false,
-          class EL_ = ElBF16, bool BF32_ = false>
+          class EL_ = ElBF16, bool BF32_ = false, bool AMIX_ = false>
 struct H5Cfg {
+    static constexpr bool AMIX = AMIX_;     // APOOL with the source of image i = (pooled gradient of image i) - (that of image n + i): see H5Params.mix_*
     using EL = EL_;                         // 16-bit element: bfloat16 (config 5) or IEEE half (config 4: the fused fp16 inference path)
     static constexpr bool BF32 = BF32_;     // source B is fp32 [n,HW/2,HW/2,8] (config 4: o1 comes out of the fp32 tail kernel)
     static constexpr bool APOOL = APOOL_;   // source A = a pooled gradient re-expanded while it is staged (a = dP bf16 [n,HW/2,HW/2,CA], b = the optional
@@ -103,8 +113,9 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     //      multiplied by the weight set whose rows 8 h .. 8 h + 7 are the layer's (the other rows zero) into the SAME accumulator, so every
     //      lane of the epilogue carries a real output (the per-tile instruction count, not the matrix rate, bounds these kernels) ----
     constexpr bool PAIR = CO == 8 && (CIN <= 8 || H5_PAIR16);
-    constexpr int NP = PAIR ? 2 : 1;
-    const int ocl = PAIR ? (l15 & 7) : l15;
+    constexpr bool QUAD = CO == 3 && !C::POOL && H5_QUAD;           // three outputs: FOUR tiles per accumulator (tile h = rows 4 h .. 4 h + 2)
+    constexpr int NP = PAIR ? 2 : (QUAD ? 4 : 1);
+    const int ocl = PAIR ? (l15 & 7) : (QUAD ? (l15 & 3) : l15);
     v8 wa[NP][NM];
 #pragma unroll
     for (int h = 0; h < NP; ++h)
@@ -114,7 +125,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
         for (int j = 0; j < 8; ++j) {
             const int k = 8 * kq + j, tap = g * TPM + k / CIN, c = k % CIN;
             int idx = -1;
-            if (tap < 9 && (PAIR ? (l15 >> 3) == h : l15 < CO)) {
+            if (tap < 9 && (PAIR ? (l15 >> 3) == h : (QUAD ? (l15 >> 2) == h && ocl < CO : l15 < CO))) {
                 if constexpr (C::DGRAD) {       // d x[ci = O0 + oc] = sum over (tap', co) of dY[p + off(tap')][co] W[8 - tap'][ci][co]
                     if (c < C::COL) idx = ((8 - tap) * C::CIL + C::O0 + ocl) * C::COL + c;
                 } else {
@@ -129,7 +140,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     if (P.bias) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ch = PAIR ? (4 * kq + r) & 7 : 4 * kq + r;
+            const int ch = PAIR ? (4 * kq + r) & 7 : (QUAD ? r : 4 * kq + r);
             br[r] = ch < CO ? P.bias[ch] : 0.f;
         }
         bl = ocl < CO ? P.bias[ocl] : 0.f;
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     constexpr int GW = HW / 4;
     constexpr int HP = HW / 2, PR = TH / 2 + 2;                                  // APOOL: pooled rows under a strip's tile
     constexpr int NA = C::APOOL ? (PR * HP + 255) / 256 : (CA == 4 || CA == 1 ? (PH * GW + 255) / 256 : (PH * HW * (CA / 8) + 255) / 256);
-    constexpr int NAV = CA == 4 || C::APOOL ? 3 : 1;                             // float4 registers per item
+    constexpr int NAV = C::AMIX ? 4 : (CA == 4 || C::APOOL ? 3 : 1);               // float4 registers per item
     static_assert(!C::APOOL || (CA == 8 && CB == 0 && sizeof(S) == 2 && !C::BF32), "pooled source: 8 bf16 channels");
     constexpr int NBI = CB == 8 ? (PH * (HW / 2) + 255) / 256 : 1;
     float4 ra[NA][NAV];
@@ -165,9 +176,16 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const bool in = rp < PR && yp >= 0 && yp < HP;
                 const size_t gi = in ? ((size_t)img * HP + yp) * HP + xp : 0;
                 ra[i][0] = ((const float4*)P.a)[gi];
-                ra[i][1] = P.b ? ((const float4*)P.b)[gi] : f4zero();
                 const float2 cd = ((const float2*)P.codes)[gi];
-                ra[i][2] = make_float4(cd.x, cd.y, 0.f, 0.f);
+                if constexpr (C::AMIX) {        // the injected mix of the same A-image: n images further
+                    const size_t gj = gi + (size_t)P.n * HP * HP;
+                    ra[i][1] = ((const float4*)P.a)[gj];
+                    const float2 ce = ((const float2*)P.codes)[gj];
+                    ra[i][2] = make_float4(cd.x, cd.y, ce.x, ce.y);
+                } else {
+                    ra[i][1] = P.b ? ((const float4*)P.b)[gi] : f4zero();
+                    ra[i][2] = make_float4(cd.x, cd.y, 0.f, 0.f);
+                }
             } else if constexpr (CA == 4) {
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
                 const bool in = r < PH && y >= 0 && y < HW;
@@ -213,6 +231,30 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const uint32_t dw[4] = {__float_as_uint(ra[i][0].x), __float_as_uint(ra[i][0].y), __float_as_uint(ra[i][0].z), __float_as_uint(ra[i][0].w)};
                 const uint32_t aw[4] = {__float_as_uint(ra[i][1].x), __float_as_uint(ra[i][1].y), __float_as_uint(ra[i][1].z), __float_as_uint(ra[i][1].w)};
                 const uint32_t cw[2] = {__float_as_uint(ra[i][2].x), __float_as_uint(ra[i][2].y)};
+                if constexpr (C::AMIX) {        // (replaced - injected), each where its own maximum was: rounded to bf16 once
+                    const uint32_t ce[2] = {__float_as_uint(ra[i][2].z), __float_as_uint(ra[i][2].w)};
+                    float fr[8], fi[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const uint32_t sh = 16 * (c & 1);
+                        fr[c] = __uint_as_float(((dw[c >> 1] >> sh) & 0xffffu) << 16);
+                        fi[c] = __uint_as_float(((aw[c >> 1] >> sh) & 0xffffu) << 16);
+                    }
+#pragma unroll
+                    for (int pos = 0; pos < 4; ++pos) {
+                        const int r = 2 * rp - 1 + (pos >> 1);
+                        if (r < 0 || r >= PH) continue;
+                        v8 v;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const float a = ((cw[c >> 2] >> (8 * (c & 3))) & 255u) == (uint32_t)pos ? fr[c] : 0.f;
+                            const float b = ((ce[c >> 2] >> (8 * (c & 3))) & 255u) == (uint32_t)pos ? fi[c] : 0.f;
+                            v[c] = in ? EL::cvt(a - b) : (short)0;
+                        }
+                        *(v8*)(tile + ((size_t)r * PW + 1 + 2 * xp + (pos & 1)) * CIN) = v;
+                    }
+                    continue;
+                }
                 short sv[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -356,10 +398,10 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                     }
                 }
             }
-        } else if (PAIR || 4 * kq < CO) {
+        } else if (NP > 1 || 4 * kq < CO) {
             int y, x;
-            tile_pixel(t + (PAIR ? kq >> 1 : 0), y, x);                         // the tile this lane's rows belong to
-            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * CO) + (PAIR ? 4 * (kq & 1) : 4 * kq);
+            tile_pixel(t + (PAIR ? kq >> 1 : (QUAD ? kq : 0)), y, x);            // the tile this lane's rows belong to
+            const size_t o = ((((size_t)img * HW + row0 + y) * HW + x) * CO) + (PAIR ? 4 * (kq & 1) : (QUAD ? 0 : 4 * kq));
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -367,6 +409,19 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 if constexpr (C::ACT == CGS_ACT_LRELU) v[r] = v[r] > 0.f ? v[r] : 0.01f * v[r];
                 if constexpr (C::ACT == CGS_ACT_SIGMOID) v[r] = 1.f / (1.f + __expf(-v[r]));
                 if constexpr (C::ACT == CGS_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (C::EPI == EPI_MIXBWD) {                                // (CO = 3: the lanes kq == 0 hold the pixel's d rep - d inj)
+                const size_t pxi = ((size_t)img * HW + row0 + y) * HW + x;
+                const uint8_t* pa = P.mix_a + 3 * pxi;
+                const uint8_t* pb = P.mix_b + 3 * pxi;
+                const float zi = P.mix_z[pxi];
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) d = fmaf((float)pb[c] * (1.f / 255.f) - (float)pa[c] * (1.f / 255.f), v[c], d);
+                const float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
+                d += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;
+                ((float*)P.out)[pxi] = d * zi * (1.f - zi);
+                continue;
             }
             if constexpr (C::EPI == EPI_LRELU_BWD) {                             // x LeakyReLU'(h): h = the layer's forward output (bf16: sign is exact)
                 const v4 h = *(const v4*)((const S*)P.hm + o);
@@ -410,6 +465,7 @@ using H5Mask0F = H5Cfg<128,  8,  4, 8, 16, 11, 16, 0, false, EPI_PLAIN,     CGS_
 using H5Mask2F = H5Cfg<128,  8, 16, 0,  1, 16,  1, 0, false, EPI_PLAIN,     CGS_ACT_SIGMOID, true>;    // masker.2 forward
 using H5Enc0D  = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    true>;    // features.0: image gradient
 using H5Enc0DP = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    true,  true>;   // ... from the pooled gradient
+using H5Enc0DM = H5Cfg<128, 16,  8, 0,  3,  3,  8, 0, true,  EPI_MIXBWD,    CGS_ACT_NONE,    true,  true, ElBF16, false, true>;   // ... + the mix backward
 using H5Mask2D = H5Cfg<128, 16,  1, 0, 16, 16,  1, 0, true,  EPI_LRELU_BWD, CGS_ACT_NONE,    false>;   // masker.2: d hm (x LeakyReLU')
 using H5Mask0D = H5Cfg<128,  8, 16, 0,  8, 11, 16, 3, true,  EPI_POOLSUM,   CGS_ACT_NONE,    false>;   // masker.0: d o0 (2x2 cell sums)
 using H5Enc1F  = H5Cfg< 64, 16,  8, 0,  8,  8,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    false>;   // features.3 forward (+ argmax bytes)
@@ -474,6 +530,15 @@ extern "C" int cgs_bf16_enc0_bwd_data_pooled(int32_t n, const void* dp_bf16, con
     if (n < 0 || !dp_bf16 || !codes || !w_hwio || !dx) return CGS_ERR_BADARG;
     return h5_launch<H5Enc0DP>(H5Params{dp_bf16, (const uint16_t*)addend_bf16, w_hwio, nullptr, dx, const_cast<uint8_t*>(codes), nullptr, n, 0, 0},
                                (hipStream_t)stream);
+}
+// features.0's data gradient on the two mixes AND the mix backward (cgs_mix_bwd) in one pass over n images: dp / codes hold the 2 n mix images
+// [replaced | injected] (pooled gradient bf16 [2n,64,64,8], argmax bytes), a_u8 / b_u8 the frames [n,128,128,3], z the mask [n,128,128];
+// dzpre [n,128,128] = (sum_c (conv^T(d rep - d inj))_c (B_c - A_c) / 255 + l1s sign(Z) + 2 l2s Z) Z (1 - Z) -- no d mix tensor in memory.
+extern "C" int cgs_bf16_enc0_bwd_mix(int32_t n, const void* dp_bf16, const uint8_t* codes, const float* w_hwio, const uint8_t* a_u8, const uint8_t* b_u8,
+                                     const float* z, float l1s, float l2s, float* dzpre, cgs_stream_t stream) {
+    if (n < 0 || !dp_bf16 || !codes || !w_hwio || !a_u8 || !b_u8 || !z || !dzpre) return CGS_ERR_BADARG;
+    H5Params P{dp_bf16, nullptr, w_hwio, nullptr, dzpre, const_cast<uint8_t*>(codes), nullptr, n, 0, 0, a_u8, b_u8, z, l1s, l2s};
+    return h5_launch<H5Enc0DM>(P, (hipStream_t)stream);
 }
 // masker.2 data gradient through masker.0's LeakyReLU: dz fp32 [n,128,128] (pre-Sigmoid gradient), hm bf16 [n,128,128,16] -> d (masker.0
 // pre-activation) bf16 [n,128,128,16]

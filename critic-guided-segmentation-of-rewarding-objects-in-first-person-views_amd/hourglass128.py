@@ -36,6 +36,7 @@ from .generic import _ACT, _p, _s
 
 TAIL = True                 # the 16x16-and-smaller layers of chfak 1 (same shapes as the 64x64 model's) on the fp32 per-image tail kernels (csrc/tail.hip)
 H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
+MIX_BWD_FUSED = True        # features.0's image gradient of the two mixes + cgs_mix_bwd as one kernel (cgs_bf16_enc0_bwd_mix)
 POOL_FUSED = True           # ... and the pooled gradients of features.0 / features.3 re-expanded inside their consumers (no cgs_bf16_pool_expand)
 HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
 ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False: the generic bf16 convolution; r4 A/B)
@@ -434,7 +435,7 @@ class Hourglass128:
         _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 0, _p(de4f), _p(dp), _s())
         return dp
 
-    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None, plan_pw=None):
+    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None, plan_pw=None, mix_bwd=None):
         """Backward of the critic on slots [lo, hi) from T.dpred; skips = [dskip_0..4] gradients arriving at the embeds from the
         decoder (bf16), d_e5_add fp32 [n,nb]; want_dx: fp32 [n,128,128,3] output for the image gradient."""
         n, d, nb = hi - lo, self.d, self.nb
@@ -486,6 +487,9 @@ class Hourglass128:
                     _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_BWD_DATA_POOLED if i == 1 else _lib.H5_ENC2_BWD_DATA_POOLED, n, _p(dp), add, _p(w), None,
                               _p(de), cod, _s())
                     dp = de
+                elif mix_bwd is not None:       # the image gradient of both mixes + the mix backward in one pass: d(pre-sigmoid mask), no d mix tensor
+                    A8, B8, l1s, l2s = mix_bwd
+                    _lib.call("cgs_bf16_enc0_bwd_mix", n // 2, _p(dp), cod, _p(w), _p(A8), _p(B8), _p(T.Z), float(l1s), float(l2s), _p(T.dzpre), _s())
                 elif want_dx is not None:
                     _lib.call("cgs_bf16_enc0_bwd_data_pooled", n, _p(dp), add, cod, _p(w), _p(want_dx), _s())
                 continue
@@ -575,8 +579,11 @@ class Hourglass128:
                   _p(T.dpred), _s())
         first = T.plan_a is None
         pa, pb = hg.SlabPlan(), hg.SlabPlan()
-        self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
-        _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
+        if MIX_BWD_FUSED and H5CONV and HWGRAD and POOL_FUSED and self.h5:
+            self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz))
+        else:
+            self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
+            _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
         skips, de5 = self._masker_backward(T, pa, A)
         self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips, plan_pw=pa)
         if first:

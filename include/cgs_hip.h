@@ -179,6 +179,11 @@ int cgs_bf16_mask2_fwd(int32_t n, const void* hm_bf16, const float* w_hwio, cons
 int cgs_bf16_enc0_bwd_data(int32_t n, const void* dy_bf16, const float* w_hwio, float* dx, cgs_stream_t stream);
 int cgs_bf16_enc0_bwd_data_pooled(int32_t n, const void* dp_bf16, const void* addend_bf16, const uint8_t* codes, const float* w_hwio, float* dx,
                                   cgs_stream_t stream);      /* the same from dP bf16 [n,64,64,8] (+ addend) and the forward argmax bytes */
+/* features.0's data gradient on the two mixes AND cgs_mix_bwd in one pass over n A-images: dp / codes = the pooled gradient bf16 [2n,64,64,8] /
+ * argmax bytes of the 2 n mix images [replaced | injected], a_u8 / b_u8 the frames [n,128,128,3], z the mask [n,128,128] ->
+ * dzpre [n,128,128] (the gradient at the mask's pre-Sigmoid value, regularisers l1s / l2s as cgs_mix_bwd); no d mix tensor in memory.       */
+int cgs_bf16_enc0_bwd_mix(int32_t n, const void* dp_bf16, const uint8_t* codes, const float* w_hwio, const uint8_t* a_u8, const uint8_t* b_u8,
+                          const float* z, float l1s, float l2s, float* dzpre, cgs_stream_t stream);
 int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream);
 int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream);
 /* The 64x64 layers of the same step: features.3 forward (src_a = e0 bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax bytes) and data gradient

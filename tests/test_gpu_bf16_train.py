@@ -678,3 +678,30 @@ def test_config5_dp_launch_form_on_one_rank_rccl_group(tmp_path):
         np.testing.assert_array_equal(got["flat"], base["flat"])
         np.testing.assert_array_equal(got["m"], base["m"])
 
+
+
+def test_enc0_data_gradient_with_fused_mix_backward_vs_the_two_launches():
+    """cgs_bf16_enc0_bwd_mix (features.0's image gradient of the replaced and injected mixes + the mix backward in one pass over the difference
+    of the two pooled gradients) against cgs_bf16_enc0_bwd_data_pooled on both mixes followed by cgs_mix_bwd: same d(pre-sigmoid mask) up to the
+    bf16 rounding of (d rep - d inj) in the staged tile (the two-launch form rounds each to bf16 first) -- 2^-7 of the largest value."""
+    from cgs_amd import _lib
+    _lib.load()
+    n = 5
+    g = torch.Generator().manual_seed(41)
+    dp = (torch.randn((2 * n, 64, 64, 8), generator=g) * 0.1).to(torch.bfloat16).cuda()
+    codes = torch.randint(0, 5, (2 * n, 64, 64, 8), dtype=torch.uint8, generator=g).cuda()
+    w = (torch.randn((9, 3, 8), generator=g) * 0.3).cuda()
+    A = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=g).cuda()
+    B = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=g).cuda()
+    Z = torch.rand((n, 128, 128), generator=g).cuda()
+    l1s, l2s = 0.5 / (n * 16384), 0.25 / (n * 16384)
+    dmixed = torch.empty((2 * n, 128, 128, 3), device="cuda")
+    _lib.call("cgs_bf16_enc0_bwd_data_pooled", 2 * n, P(dp), None, P(codes), P(w), P(dmixed), S())
+    want = torch.full((n, 128, 128), 7.0, device="cuda")
+    _lib.call("cgs_mix_bwd", n, 16384, P(A), P(B), P(Z), P(dmixed), 1, l1s, l2s, P(want), S())
+    got = torch.full((n, 128, 128), 8.0, device="cuda")
+    _lib.call("cgs_bf16_enc0_bwd_mix", n, P(dp), P(codes), P(w), P(A), P(B), P(Z), l1s, l2s, P(got), S())
+    torch.cuda.synchronize()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    print(f"fused mix backward vs two launches: max |d| / max |ref| = {err:.2e}")
+    assert err <= 2.0 ** -7
