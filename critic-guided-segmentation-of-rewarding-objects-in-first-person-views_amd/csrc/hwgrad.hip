@@ -77,23 +77,77 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
 
     for (int strip = HWG_XCD ? cgs_xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x; strip < P.nstrips; strip += gridDim.x) {   // (neighbouring strips on one XCD's L2)
         const int img = strip / STRIPS, row0 = (strip % STRIPS) * TH;
-        // ---- X tile ----
-        if constexpr (CA == 4) {            // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item
-            constexpr int GW = HW / 4;
-#pragma unroll 2
-            for (int e = tid; e < PH * GW; e += 256) {
+        // ---- staging: EVERY global load of the strip is issued back to back into registers (compile-time trip counts), then converted and stored
+        //      to LDS: one memory round trip per strip instead of one per 256 items (these kernels multiply for well under a microsecond per
+        //      strip: a strip's life was its four to six dependent load rounds) ----
+        constexpr int GW = HW / 4, NGA = CA == 4 ? 1 : CA / 8, HP = HW / 2;
+        constexpr int NXI = CA == 4 ? (PH * GW + 255) / 256 : (PH * HW * NGA + 255) / 256, NXV = CA == 4 ? 3 : 1;     // source A items, float4 each
+        constexpr int NBI = CB == 8 ? (PH * HW + 255) / 256 : 1;                                                   // source B items
+        constexpr int NDI = DYPOOL ? ((TH / 2) * HP + 255) / 256 : (CO == 1 ? (TH * HW / 4 + 255) / 256 : (TH * HW * CO / 8 + 255) / 256);
+        constexpr int NDV = DYPOOL ? 3 : 1;
+        float4 rxa[NXI][NXV], rxb[NBI], rdy[NDI][NDV];
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int e = tid + 256 * k;
+            if constexpr (CA == 4) {        // frames: 4 pixels = 12 bytes (uint8) / 12 floats per item
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
-                const bool in = y >= 0 && y < HW;
+                const bool in = r < PH && y >= 0 && y < HW;
                 const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-                float f[12];
                 if (P.a_f32) {
                     const float4* sf = (const float4*)P.a;
-                    const float4 f0 = sf[gi], f1 = sf[gi + 1], f2 = sf[gi + 2];
+                    rxa[k][0] = sf[gi]; rxa[k][1] = sf[gi + 1]; rxa[k][2] = sf[gi + 2];
+                } else {
+                    const uint32_t* su = (const uint32_t*)P.a;
+                    rxa[k][0] = make_float4(__uint_as_float(su[gi]), __uint_as_float(su[gi + 1]), __uint_as_float(su[gi + 2]), 0.f);
+                }
+            } else {
+                const int g = e % NGA, x = (e / NGA) % HW, r = e / (NGA * HW), y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                rxa[k][0] = ((const float4*)P.a)[in ? (((size_t)img * HW + y) * HW + x) * NGA + g : 0];
+            }
+        }
+        if constexpr (CB == 8) {
+#pragma unroll
+            for (int k = 0; k < NBI; ++k) {
+                const int e = tid + 256 * k, x = e % HW, r = e / HW, y = row0 + r - 1;
+                const bool in = r < PH && y >= 0 && y < HW;
+                rxb[k] = ((const float4*)P.b)[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1) : 0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int e = tid + 256 * k;
+            if constexpr (DYPOOL) {
+                static_assert(!DYPOOL || CO == 8, "pooled gradient: 8 channels");
+                const int ee = e < (TH / 2) * HP ? e : 0, xp = ee % HP, rp = ee / HP;
+                const size_t gi = ((size_t)img * HP + row0 / 2 + rp) * HP + xp;
+                rdy[k][0] = ((const float4*)P.dy)[gi];
+                rdy[k][1] = P.dy_add ? ((const float4*)P.dy_add)[gi] : f4zero();
+                const float2 c2 = ((const float2*)P.codes)[gi];
+                rdy[k][2] = make_float4(c2.x, c2.y, 0.f, 0.f);
+            } else if constexpr (CO == 1) {
+                const float4* sd = (const float4*)((const float*)P.dy + ((size_t)img * HW + row0) * HW);
+                rdy[k][0] = sd[e < TH * HW / 4 ? e : 0];
+            } else {
+                const float4* sd = (const float4*)((const uint16_t*)P.dy + ((size_t)img * HW + row0) * HW * CO);
+                rdy[k][0] = sd[e < TH * HW * CO / 8 ? e : 0];
+            }
+        }
+        // ---- commit ----
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const int e = tid + 256 * k;
+            if constexpr (CA == 4) {
+                const int g = e % GW, r = e / GW, y = row0 + r - 1;
+                if (r >= PH) continue;
+                const bool in = y >= 0 && y < HW;
+                float f[12];
+                if (P.a_f32) {
+                    const float4 f0 = rxa[k][0], f1 = rxa[k][1], f2 = rxa[k][2];
                     f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
                     f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
                 } else {
-                    const uint32_t* su = (const uint32_t*)P.a;
-                    const uint32_t d[3] = {su[gi], su[gi + 1], su[gi + 2]};
+                    const uint32_t d[3] = {__float_as_uint(rxa[k][0].x), __float_as_uint(rxa[k][0].y), __float_as_uint(rxa[k][0].z)};
 #pragma unroll
                     for (int j = 0; j < 12; ++j) f[j] = (float)((d[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
                 }
@@ -102,44 +156,33 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
                     const hs4_t v = in ? hs4_t{hbf(f[3 * j]), hbf(f[3 * j + 1]), hbf(f[3 * j + 2]), 0} : hs4_t{0, 0, 0, 0};
                     *(hs4_t*)(xt + ((size_t)r * PW + 1 + 4 * g + j) * CIN) = v;
                 }
-            }
-        } else {
-            constexpr int NG = CA / 8;
-            const hs8_t* src = (const hs8_t*)P.a;
-#pragma unroll 2
-            for (int e = tid; e < PH * HW * NG; e += 256) {
-                const int g = e % NG, x = (e / NG) % HW, r = e / (NG * HW), y = row0 + r - 1;
-                const bool in = y >= 0 && y < HW;
-                hs8_t v = src[in ? (((size_t)img * HW + y) * HW + x) * NG + g : 0];
-                if (!in) v = hs8_t{0, 0, 0, 0, 0, 0, 0, 0};
-                *(hs8_t*)(xt + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = v;
+            } else {
+                const int g = e % NGA, x = (e / NGA) % HW, r = e / (NGA * HW), y = row0 + r - 1;
+                if (r >= PH) continue;
+                *(float4*)(xt + ((size_t)r * PW + 1 + x) * CIN + 8 * g) = (y >= 0 && y < HW) ? rxa[k][0] : f4zero();
             }
         }
         if constexpr (CB == 8) {            // the nearest-upsampled source: channels CA .. CA + 7 of the pixel
-            const hs8_t* sb = (const hs8_t*)P.b;
-#pragma unroll 2
-            for (int e = tid; e < PH * HW; e += 256) {
-                const int x = e % HW, r = e / HW, y = row0 + r - 1;
-                const bool in = y >= 0 && y < HW;
-                hs8_t v = sb[in ? ((size_t)img * (HW / 2) + (y >> 1)) * (HW / 2) + (x >> 1) : 0];
-                if (!in) v = hs8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NBI; ++k) {
+                const int e = tid + 256 * k, x = e % HW, r = e / HW, y = row0 + r - 1;
+                if (r >= PH) continue;
+                const float4 v = (y >= 0 && y < HW) ? rxb[k] : f4zero();
                 uint16_t* d = xt + ((size_t)r * PW + 1 + x) * CIN + CA;       // 8-byte aligned (CA = 4) or 16
-                *(hs4_t*)d = hs4_t{v[0], v[1], v[2], v[3]};
-                *(hs4_t*)(d + 4) = hs4_t{v[4], v[5], v[6], v[7]};
+                *(float2*)d = make_float2(v.x, v.y);
+                *(float2*)(d + 4) = make_float2(v.z, v.w);
             }
         }
-        // ---- dY strip: contiguous in memory ----
-        if constexpr (DYPOOL) {
-            static_assert(!DYPOOL || CO == 8, "pooled gradient: 8 channels");
-            constexpr int HP = HW / 2;
-            for (int e = tid; e < (TH / 2) * HP; e += 256) {
+#pragma unroll
+        for (int k = 0; k < NDI; ++k) {
+            const int e = tid + 256 * k;
+            if constexpr (DYPOOL) {         // one pooled pixel -> its 2 x 2 pixels: the gradient goes where the forward maximum was
+                if (e >= (TH / 2) * HP) continue;
                 const int xp = e % HP, rp = e / HP;
-                const size_t gi = ((size_t)img * HP + row0 / 2 + rp) * HP + xp;
-                const float4 d4 = ((const float4*)P.dy)[gi], a4 = P.dy_add ? ((const float4*)P.dy_add)[gi] : f4zero();
-                const float2 c2 = ((const float2*)P.codes)[gi];
+                const float4 d4 = rdy[k][0], a4 = rdy[k][1];
                 const uint32_t dw[4] = {__float_as_uint(d4.x), __float_as_uint(d4.y), __float_as_uint(d4.z), __float_as_uint(d4.w)};
                 const uint32_t aw[4] = {__float_as_uint(a4.x), __float_as_uint(a4.y), __float_as_uint(a4.z), __float_as_uint(a4.w)};
-                const uint32_t cw[2] = {__float_as_uint(c2.x), __float_as_uint(c2.y)};
+                const uint32_t cw[2] = {__float_as_uint(rdy[k][2].x), __float_as_uint(rdy[k][2].y)};
                 short sv[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -153,17 +196,14 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
                     for (int c = 0; c < 8; ++c) v[c] = ((cw[c >> 2] >> (8 * (c & 3))) & 255u) == (uint32_t)pos ? sv[c] : (short)0;
                     *(hs8_t*)(dt + ((size_t)(2 * rp + (pos >> 1)) * HW + 2 * xp + (pos & 1)) * 8) = v;
                 }
-            }
-        } else if constexpr (CO == 1) {
-            const float4* sd = (const float4*)((const float*)P.dy + ((size_t)img * HW + row0) * HW);
-            for (int e = tid; e < TH * HW / 4; e += 256) {
-                const float4 v = sd[e];
+            } else if constexpr (CO == 1) {
+                if (e >= TH * HW / 4) continue;
+                const float4 v = rdy[k][0];
                 *(hs4_t*)(dt + 4 * e) = hs4_t{hbf(v.x), hbf(v.y), hbf(v.z), hbf(v.w)};
+            } else {
+                if (e >= TH * HW * CO / 8) continue;
+                ((float4*)dt)[e] = rdy[k][0];
             }
-        } else {
-            const float4* sd = (const float4*)((const uint16_t*)P.dy + ((size_t)img * HW + row0) * HW * CO);
-#pragma unroll 2
-            for (int e = tid; e < TH * HW * CO / 8; e += 256) ((float4*)dt)[e] = sd[e];
         }
         __syncthreads();
         // ---- 32-pixel blocks of the strip (x0 .. x0 + 31 of row y): lane group kq supplies pixels 8 kq .. + 7 (two transposing reads) ----
