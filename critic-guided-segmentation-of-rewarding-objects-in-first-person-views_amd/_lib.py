@@ -69,6 +69,8 @@ SIGNATURES = {
     "cgs_bf16_mask2_bwd_data": (i32, [i32, vp, vp, vp, vp, vp]),
     "cgs_bf16_enc0_bwd_data_pooled": (i32, [i32, vp, vp, vp, vp, vp, vp]),
     "cgs_bf16_enc0_bwd_mix": (i32, [i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp]),
+    "cgs_bf16_enc0_fwd_mix": (i32, [i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_bf16_hwgrad_pooled_mix": (i32, [i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_bf16_mask0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
     "cgs_bf16_h5conv": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_enc0_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),

@@ -18,11 +18,16 @@ __global__ void __launch_bounds__(256) mix_fwd_kernel(int groups, int rep_groups
     __shared__ float red[2][4];
     float s1 = 0.f, s2 = 0.f;
     for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+        float4 zz = z[g];
+        float zv[4] = {zz.x, zz.y, zz.z, zz.w};
+        if (!mixed) {       // partial sums only: the consumers form the mixes themselves (cgs_bf16_enc0_fwd_mix / cgs_bf16_hwgrad_pooled_mix)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s1 += fabsf(zv[i]); s2 += zv[i] * zv[i]; }
+            continue;
+        }
         float av[12], bv[12];
         unpack12(a[3 * g], a[3 * g + 1], a[3 * g + 2], av);
         unpack12(b[3 * g], b[3 * g + 1], b[3 * g + 2], bv);
-        float4 zz = z[g];
-        float zv[4] = {zz.x, zz.y, zz.z, zz.w};
         float r[12], q[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
@@ -265,7 +270,7 @@ extern "C" int cgs_mix_fwd_partials(int32_t n, int32_t hw) {
 
 extern "C" int cgs_mix_fwd(int32_t n, int32_t hw, const uint8_t* a, const uint8_t* b, const float* z, int32_t inject,
                            float* mixed, float* zpart, cgs_stream_t stream) {
-    if (n < 0 || hw <= 0 || (hw & 3) || !a || !b || !z || !mixed || !zpart) return CGS_ERR_BADARG;
+    if (n < 0 || hw <= 0 || (hw & 3) || !z || !zpart || (mixed && (!a || !b))) return CGS_ERR_BADARG;      // mixed = NULL: only the partial sums of |Z|, Z^2
     int groups = n * (hw / 4);
     if (groups == 0) return CGS_OK;
     hipLaunchKernelGGL(mix_fwd_kernel, dim3(mix_blocks(groups)), dim3(256), 0, (hipStream_t)stream, groups, groups,

@@ -190,7 +190,15 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
                 const bool in = r < PH && y >= 0 && y < HW;
                 const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-                if (P.a_f32) {
+                if (P.a_f32 == 2) {             // virtual mixes (main.py:395,406): image img < n / 2 = A (1 - Z) + Z B of frame pair img, else B (1 - Z) + Z A
+                    const int half = P.n >> 1, is = img < half ? img : img - half;
+                    const size_t gs = in ? (((size_t)is * HW + y) * HW + g * 4) : 0;
+                    const uint32_t* sa = (const uint32_t*)P.mix_a + gs * 3 / 4;
+                    const uint32_t* sb = (const uint32_t*)P.mix_b + gs * 3 / 4;
+                    ra[i][0] = make_float4(__uint_as_float(sa[0]), __uint_as_float(sa[1]), __uint_as_float(sa[2]), 0.f);
+                    ra[i][1] = make_float4(__uint_as_float(sb[0]), __uint_as_float(sb[1]), __uint_as_float(sb[2]), 0.f);
+                    ra[i][2] = ((const float4*)P.mix_z)[gs / 4];
+                } else if (P.a_f32) {
                     const float4* sf = (const float4*)P.a;
                     ra[i][0] = sf[gi]; ra[i][1] = sf[gi + 1]; ra[i][2] = sf[gi + 2];
                 } else {
@@ -275,7 +283,19 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 if (r >= PH) continue;
                 const bool in = y >= 0 && y < HW;
                 float f[12];
-                if (P.a_f32) {
+                if (P.a_f32 == 2) {             // (the formula of cgs_mix_fwd: the fp32 mix it used to write, up to FMA contraction)
+                    const uint32_t da[3] = {__float_as_uint(ra[i][0].x), __float_as_uint(ra[i][0].y), __float_as_uint(ra[i][0].z)};
+                    const uint32_t db[3] = {__float_as_uint(ra[i][1].x), __float_as_uint(ra[i][1].y), __float_as_uint(ra[i][1].z)};
+                    const float zv[4] = {ra[i][2].x, ra[i][2].y, ra[i][2].z, ra[i][2].w};
+                    const bool inj = (strip / STRIPS) >= (P.n >> 1);
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        const float av = (float)((da[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                        const float bv = (float)((db[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                        const float zi = zv[j / 3];
+                        f[j] = inj ? bv * (1.f - zi) + zi * av : av * (1.f - zi) + zi * bv;
+                    }
+                } else if (P.a_f32) {
                     const float4 f0 = ra[i][0], f1 = ra[i][1], f2 = ra[i][2];
                     f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
                     f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
@@ -550,6 +570,16 @@ extern "C" int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* h
 extern "C" int cgs_bf16_mask0_bwd_data(int32_t n, const void* dhm_bf16, const float* w_hwio, void* do0_bf16, cgs_stream_t stream) {
     if (n < 0 || !dhm_bf16 || !w_hwio || !do0_bf16) return CGS_ERR_BADARG;
     return h5_launch<H5Mask0D>(H5Params{dhm_bf16, nullptr, w_hwio, nullptr, do0_bf16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+}
+
+// features.0 on the VIRTUAL mixes (main.py:395,406): the 2 n images [replaced | injected] are formed from the frame pairs (a_u8, b_u8 [n,128,128,3])
+// and the mask z [n,128,128] while the tile is staged -- the fp32 mixes are never written (cgs_mix_fwd with mixed = NULL leaves only its partial
+// sums of |Z| and Z^2).  e0 bf16 [2n,64,64,8] + argmax bytes, as cgs_bf16_enc0_fwd on the materialised mixes (up to which product of A (1 - Z) + Z B the compiler fuses into the add).
+extern "C" int cgs_bf16_enc0_fwd_mix(int32_t n, const uint8_t* a_u8, const uint8_t* b_u8, const float* z, const float* w_hwio, const float* bias,
+                                     void* e0_bf16, uint8_t* codes, cgs_stream_t stream) {
+    if (n < 0 || !a_u8 || !b_u8 || !z || !w_hwio || !bias || !e0_bf16) return CGS_ERR_BADARG;
+    H5Params P{a_u8, nullptr, w_hwio, bias, e0_bf16, codes, nullptr, 2 * n, 0, 2, a_u8, b_u8, z, 0.f, 0.f};
+    return h5_launch<H5Enc0F>(P, (hipStream_t)stream);
 }
 
 // The 64x64 and 32x32 layers of the same step (which: CGS_H5_*, cgs_hip.h; the 32x32 forms: same roles one level down, see the header): features.3 forward (src_a bf16 [n,64,64,8] -> e1 bf16 [n,32,32,8] + argmax

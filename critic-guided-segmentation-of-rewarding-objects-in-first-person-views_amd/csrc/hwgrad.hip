@@ -38,7 +38,8 @@ struct HWgParams {
     const uint16_t* dy_add; // DYPOOL: optional addend of the pooled gradient (same shape) or NULL
     const uint8_t* codes;   // DYPOOL: argmax bytes of the forward pass [n,HW/2,HW/2,8]
     float* slab;            // [blocks][9 (CA_real + CB) CO + CO]
-    int n, nstrips, a_f32;
+    int n, nstrips, a_f32;  // a_f32 == 2: source A = the virtual mixes of the frame pairs mix_a / mix_b [n / 2,HW,HW,3] with the mask mix_z [n / 2,HW,HW]
+    const uint8_t* mix_a; const uint8_t* mix_b; const float* mix_z;
 };
 
 // HW: map size; CA: channels of source A in the LDS pixel (4 = rgb0 from uint8 / fp32 frames; 8 / 16 = bf16); CB: 0 / 8 (upsampled bf16
@@ -93,7 +94,15 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
                 const bool in = r < PH && y >= 0 && y < HW;
                 const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-                if (P.a_f32) {
+                if (P.a_f32 == 2) {
+                    const int half = P.n >> 1, is = img < half ? img : img - half;
+                    const size_t gs = in ? (((size_t)is * HW + y) * HW + g * 4) : 0;
+                    const uint32_t* sa = (const uint32_t*)P.mix_a + gs * 3 / 4;
+                    const uint32_t* sb = (const uint32_t*)P.mix_b + gs * 3 / 4;
+                    rxa[k][0] = make_float4(__uint_as_float(sa[0]), __uint_as_float(sa[1]), __uint_as_float(sa[2]), 0.f);
+                    rxa[k][1] = make_float4(__uint_as_float(sb[0]), __uint_as_float(sb[1]), __uint_as_float(sb[2]), 0.f);
+                    rxa[k][2] = ((const float4*)P.mix_z)[gs / 4];
+                } else if (P.a_f32) {
                     const float4* sf = (const float4*)P.a;
                     rxa[k][0] = sf[gi]; rxa[k][1] = sf[gi + 1]; rxa[k][2] = sf[gi + 2];
                 } else {
@@ -142,7 +151,19 @@ __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
                 if (r >= PH) continue;
                 const bool in = y >= 0 && y < HW;
                 float f[12];
-                if (P.a_f32) {
+                if (P.a_f32 == 2) {         // the formula of cgs_mix_fwd
+                    const uint32_t da[3] = {__float_as_uint(rxa[k][0].x), __float_as_uint(rxa[k][0].y), __float_as_uint(rxa[k][0].z)};
+                    const uint32_t db[3] = {__float_as_uint(rxa[k][1].x), __float_as_uint(rxa[k][1].y), __float_as_uint(rxa[k][1].z)};
+                    const float zv[4] = {rxa[k][2].x, rxa[k][2].y, rxa[k][2].z, rxa[k][2].w};
+                    const bool inj = img >= (P.n >> 1);
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) {
+                        const float av = (float)((da[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                        const float bv = (float)((db[j >> 2] >> (8 * (j & 3))) & 255u) * (1.f / 255.f);
+                        const float zi = zv[j / 3];
+                        f[j] = inj ? bv * (1.f - zi) + zi * av : av * (1.f - zi) + zi * bv;
+                    }
+                } else if (P.a_f32) {
                     const float4 f0 = rxa[k][0], f1 = rxa[k][1], f2 = rxa[k][2];
                     f[0] = f0.x; f[1] = f0.y; f[2] = f0.z; f[3] = f0.w; f[4] = f1.x; f[5] = f1.y; f[6] = f1.z; f[7] = f1.w;
                     f[8] = f2.x; f[9] = f2.y; f[10] = f2.z; f[11] = f2.w;
@@ -329,7 +350,7 @@ extern "C" int cgs_bf16_hwgrad(int32_t n, int32_t hw, int32_t ca, int32_t cb, in
     if (!which) return CGS_ERR_UNSUPPORTED;
     if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;                     // frames are uint8 / fp32, activations bf16
     if (n == 0) return CGS_OK;
-    const HWgParams P{src_a, (const uint16_t*)src_b, dy, nullptr, nullptr, slab, n, 0, a_kind == 2 ? 1 : 0};
+    const HWgParams P{src_a, (const uint16_t*)src_b, dy, nullptr, nullptr, slab, n, 0, a_kind == 2 ? 1 : 0, nullptr, nullptr, nullptr};
     switch (which) {
         case 1: return HWgEnc0::launch(P, (hipStream_t)stream);
         case 2: return HWgMask0::launch(P, (hipStream_t)stream);
@@ -350,6 +371,18 @@ extern "C" int cgs_bf16_hwgrad_pooled(int32_t n, int32_t hw, int32_t ca, int32_t
     if (which != 1 && which != 4 && which != 6) return CGS_ERR_UNSUPPORTED;
     if ((ca == 3) != (a_kind != 0)) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    const HWgParams P{src_a, nullptr, dp, (const uint16_t*)addend, codes, slab, n, 0, a_kind == 2 ? 1 : 0};
+    const HWgParams P{src_a, nullptr, dp, (const uint16_t*)addend, codes, slab, n, 0, a_kind == 2 ? 1 : 0, nullptr, nullptr, nullptr};
     return which == 1 ? HWgEnc0P::launch(P, (hipStream_t)stream) : (which == 4 ? HWgEnc1P::launch(P, (hipStream_t)stream) : HWgEnc2P::launch(P, (hipStream_t)stream));
 }
+
+// features.0's weight gradient on the VIRTUAL mixes: the 2 n images [replaced | injected] formed from the frame pairs a_u8 / b_u8 [n,128,128,3] and
+// the mask z [n,128,128] while the tile is staged (see cgs_bf16_enc0_fwd_mix); dp / codes: the pooled gradient bf16 [2n,64,64,8] / argmax bytes.
+// Slab rows: cgs_bf16_hwgrad_slabs(2 n, 128, 3, 0, 8).
+extern "C" int cgs_bf16_hwgrad_pooled_mix(int32_t n, const uint8_t* a_u8, const uint8_t* b_u8, const float* z, const void* dp, const uint8_t* codes,
+                                          float* slab, cgs_stream_t stream) {
+    if (n < 0 || !a_u8 || !b_u8 || !z || !dp || !codes || !slab) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const HWgParams P{a_u8, nullptr, dp, nullptr, codes, slab, 2 * n, 0, 2, a_u8, b_u8, z};
+    return HWgEnc0P::launch(P, (hipStream_t)stream);
+}
+

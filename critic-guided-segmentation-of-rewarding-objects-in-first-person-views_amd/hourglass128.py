@@ -36,6 +36,7 @@ from .generic import _ACT, _p, _s
 
 TAIL = True                 # the 16x16-and-smaller layers of chfak 1 (same shapes as the 64x64 model's) on the fp32 per-image tail kernels (csrc/tail.hip)
 H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
+MIX_VIRTUAL = True          # the two mixes are formed inside features.0's forward / weight-gradient staging (no fp32 mix tensor, no mix kernel)
 MIX_BWD_FUSED = True        # features.0's image gradient of the two mixes + cgs_mix_bwd as one kernel (cgs_bf16_enc0_bwd_mix)
 POOL_FUSED = True           # ... and the pooled gradients of features.0 / features.3 re-expanded inside their consumers (no cgs_bf16_pool_expand)
 HWGRAD = True               # weight gradients of the 128x128 / 64x64 layers of chfak 1 on csrc/hwgrad.hip (False: the shape-generic kernel)
@@ -43,6 +44,13 @@ ENC0_DIRECT = True          # features.0 of chfak 1 on cgs_bf16_enc0_fwd (False:
 ENC_KEYS = ("features.0", "features.3", "features.6", "features.9", "features.13")
 ENC_HW = (128, 64, 32, 16, 8)            # pre-pool map size of the five encoder stages
 GEMM_KEYS = ("features.17", "crit.1", "crit.4")
+class MixSrc:
+    """The virtual mix batch [replaced | injected] of n frame pairs: features.0's kernels form it from (A, B, Z) while they stage."""
+
+    def __init__(self, A, B, Z):
+        self.A, self.B, self.Z = A, B, Z
+
+
 _NODROP = _lib.Dropout(0.0, 0, 0, None, 0, 0)        # Dropout off (the tail kernels take the 64x64 model's three sites)
 
 
@@ -336,6 +344,11 @@ class Hourglass128:
         n, d = hi - lo, self.d
         x = src
         for i in (0, 1):
+            if i == 0 and isinstance(src, MixSrc):
+                w, bias = self._wview(ENC_KEYS[0])
+                _lib.call("cgs_bf16_enc0_fwd_mix", n // 2, _p(src.A), _p(src.B), _p(src.Z), _p(w), _p(bias), _p(T.e[0][lo:hi]), _p(T.codes[0][lo:hi]), _s())
+                x = T.e[0][lo:hi]
+                continue
             x = self._conv(ENC_KEYS[i], x, None, d[i], act="relu", pool=True, out=T.e[i][lo:hi], codes=T.codes[i][lo:hi])
         self._conv("features.6", x, None, d[2], act="relu", pool=True, out_f32=True, out=T.t_e2[lo:hi], codes=T.codes[2][lo:hi])
         tw = self._tail_enc_w(want_o5)
@@ -475,11 +488,14 @@ class Hourglass128:
             if (i <= 1 or (i == 2 and TAIL and self.tail)) and H5CONV and HWGRAD and POOL_FUSED and self.h5:
                 # the 128x128 / 64x64 (/ 32x32) levels: weight and data gradient read the pooled gradient + argmax bytes (no re-expanded copy)
                 a = src if i == 0 else T.e[i - 1][lo:hi]
-                a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
                 add, cod = (_p(skips[i]) if skips is not None and skips[i] is not None else None), _p(T.codes[i][lo:hi])
                 nsl, cnt = self.lib.cgs_bf16_hwgrad_slabs(n, hw, self.convs[key][0], 0, 8), 9 * self.convs[key][0] * 8 + 8
                 slab = T.buf(f"slab_{key}_{tag}", (nsl, cnt), torch.float32, self.dev)
-                _lib.call("cgs_bf16_hwgrad_pooled", n, hw, self.convs[key][0], a_kind, _p(a), _p(dp), add, cod, _p(slab), _s())
+                if isinstance(a, MixSrc):
+                    _lib.call("cgs_bf16_hwgrad_pooled_mix", n // 2, _p(a.A), _p(a.B), _p(a.Z), _p(dp), cod, _p(slab), _s())
+                else:
+                    a_kind = 1 if a.dtype == torch.uint8 else (2 if a.dtype == torch.float32 else 0)
+                    _lib.call("cgs_bf16_hwgrad_pooled", n, hw, self.convs[key][0], a_kind, _p(a), _p(dp), add, cod, _p(slab), _s())
                 plan.add(slab, nsl, cnt, self.off[key][0])
                 w = self._wview(key)[0]
                 if i >= 1:
@@ -572,15 +588,17 @@ class Hourglass128:
         A, B = T.ab[n:], T.ab[:n]
         self._critic_forward(T, T.ab, 0, 2 * n, want_o5=True)
         self._masker_forward(T, A)
-        _lib.call("cgs_mix_fwd", n, 16384, _p(A), _p(B), _p(T.Z), 1, _p(T.mixed), _p(T.zsum), _s())
-        self._critic_forward(T, T.mixed, 2 * n, 4 * n)
+        virt = MIX_VIRTUAL and MIX_BWD_FUSED and TAIL and H5CONV and HWGRAD and POOL_FUSED and self.tail
+        mixsrc = MixSrc(A, B, T.Z) if virt else T.mixed
+        _lib.call("cgs_mix_fwd", n, 16384, _p(A), _p(B), _p(T.Z), 1, None if virt else _p(T.mixed), _p(T.zsum), _s())      # virt: only the sums of |Z|, Z^2
+        self._critic_forward(T, mixsrc, 2 * n, 4 * n)
         nz = n * 16384
         _lib.call("cgs_phase2_losses", n, _p(T.pred), _p(T.y), _p(T.zsum), T.nzpart, self.lfak, self.L1, self.L2, 1 | 2, nz, _p(T.losses),
                   _p(T.dpred), _s())
         first = T.plan_a is None
         pa, pb = hg.SlabPlan(), hg.SlabPlan()
         if MIX_BWD_FUSED and H5CONV and HWGRAD and POOL_FUSED and self.h5:
-            self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz))
+            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz))
         else:
             self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
             _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())

@@ -182,6 +182,14 @@ int cgs_bf16_enc0_bwd_data_pooled(int32_t n, const void* dp_bf16, const void* ad
 /* features.0's data gradient on the two mixes AND cgs_mix_bwd in one pass over n A-images: dp / codes = the pooled gradient bf16 [2n,64,64,8] /
  * argmax bytes of the 2 n mix images [replaced | injected], a_u8 / b_u8 the frames [n,128,128,3], z the mask [n,128,128] ->
  * dzpre [n,128,128] (the gradient at the mask's pre-Sigmoid value, regularisers l1s / l2s as cgs_mix_bwd); no d mix tensor in memory.       */
+/* features.0 forward / weight gradient on the VIRTUAL mixes (main.py:395,406): the 2 n images [replaced | injected] are formed from the frame pairs
+ * a_u8 / b_u8 [n,128,128,3] and the mask z [n,128,128] while a tile is staged (cgs_mix_fwd's formula); the fp32 mixes are
+ * never written: cgs_mix_fwd(.., mixed = NULL, zpart) then leaves only the partial sums of |Z| and Z^2 the loss needs.  Outputs as
+ * cgs_bf16_enc0_fwd / cgs_bf16_hwgrad_pooled on 2 n materialised images (slab rows: cgs_bf16_hwgrad_slabs(2 n, 128, 3, 0, 8)).                     */
+int cgs_bf16_enc0_fwd_mix(int32_t n, const uint8_t* a_u8, const uint8_t* b_u8, const float* z, const float* w_hwio, const float* bias, void* e0_bf16,
+                          uint8_t* codes, cgs_stream_t stream);
+int cgs_bf16_hwgrad_pooled_mix(int32_t n, const uint8_t* a_u8, const uint8_t* b_u8, const float* z, const void* dp, const uint8_t* codes, float* slab,
+                               cgs_stream_t stream);
 int cgs_bf16_enc0_bwd_mix(int32_t n, const void* dp_bf16, const uint8_t* codes, const float* w_hwio, const uint8_t* a_u8, const uint8_t* b_u8,
                           const float* z, float l1s, float l2s, float* dzpre, cgs_stream_t stream);
 int cgs_bf16_mask2_bwd_data(int32_t n, const float* dz, const void* hm_bf16, const float* w_hwio, void* dhm_bf16, cgs_stream_t stream);
