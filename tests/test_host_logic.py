@@ -99,6 +99,17 @@ def test_modules_fail_loudly_without_gpu_and_on_unsupported_shapes():
         nets.NewCritic(dims=[4, 4, 4, 8])
     with pytest.raises(NotImplementedError):
         nets.UnetDecoder(upsample=False)
+    # the optional BatchNorm epilogue and the 128x128 variant: same rule -- no CPU path
+    bn = nets.BatchNormAct2d(8, act="relu")
+    assert sorted(k for k, _ in bn.state_dict().items()) == ["bias", "num_batches_tracked", "running_mean", "running_var", "weight"]
+    with pytest.raises(_lib.CgsError, match="no CPU fallback"):
+        bn(torch.zeros(2, 8, 4, 4))
+    with pytest.raises(NotImplementedError):
+        nets.BatchNormAct2d(10)
+    if not torch.cuda.is_available():
+        from cgs_amd import hourglass128
+        with pytest.raises(_lib.CgsError, match="no CPU fallback"):
+            hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 1), orc.seeded_params(orc.masker128_shapes(), 2))
 
 
 def test_cli_surface_matches_reference():
