@@ -298,7 +298,7 @@ class Hourglass128:
             n4 = 4 * n
             self.ab = u8(2 * n, 128, 128, 3)              # [B | A]
             self.y = f32(n)
-            self.mixed, self.dmixed = f32(2 * n, 128, 128, 3), f32(2 * n, 128, 128, 3)
+            self.mixed = self.dmixed = None          # fp32 mixes / their gradient: only the paths without MIX_VIRTUAL / MIX_BWD_FUSED materialise them
             # critic activations for the 4n slots [B | A | replaced | injected]
             self.e = [bf(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
             self.codes = [u8(n4, hw // 2, hw // 2, co) for hw, co in zip(ENC_HW, d)]
@@ -589,6 +589,8 @@ class Hourglass128:
         self._critic_forward(T, T.ab, 0, 2 * n, want_o5=True)
         self._masker_forward(T, A)
         virt = MIX_VIRTUAL and MIX_BWD_FUSED and TAIL and H5CONV and HWGRAD and POOL_FUSED and self.tail
+        if not virt and T.mixed is None:
+            T.mixed = torch.empty((2 * n, 128, 128, 3), device=self.dev)
         mixsrc = MixSrc(A, B, T.Z) if virt else T.mixed
         _lib.call("cgs_mix_fwd", n, 16384, _p(A), _p(B), _p(T.Z), 1, None if virt else _p(T.mixed), _p(T.zsum), _s())      # virt: only the sums of |Z|, Z^2
         self._critic_forward(T, mixsrc, 2 * n, 4 * n)
@@ -600,7 +602,9 @@ class Hourglass128:
         if MIX_BWD_FUSED and H5CONV and HWGRAD and POOL_FUSED and self.h5:
             self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz))
         else:
-            self._critic_backward(T, pa, "mix", T.mixed, 2 * n, 4 * n, want_dx=T.dmixed)
+            if T.dmixed is None:
+                T.dmixed = torch.empty((2 * n, 128, 128, 3), device=self.dev)
+            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, want_dx=T.dmixed)
             _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
         skips, de5 = self._masker_backward(T, pa, A)
         self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips, plan_pw=pa)
