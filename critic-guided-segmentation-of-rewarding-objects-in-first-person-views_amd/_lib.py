@@ -74,6 +74,7 @@ SIGNATURES = {
     "cgs_bf16_mask0_bwd_data": (i32, [i32, vp, vp, vp, vp]),
     "cgs_bf16_h5conv": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_enc0_fwd": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen_enc0_bwd_data": (i32, [i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_enc0_bwd_weight_slabs": (i32, [i32, i32]),
     "cgs_gen_enc0_bwd_weight": (i32, [i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_bn_rows": (i32, [i64, i32]),

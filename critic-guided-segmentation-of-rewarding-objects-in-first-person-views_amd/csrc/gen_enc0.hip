@@ -396,3 +396,154 @@ extern "C" int cgs_gen_enc0_bwd_weight(int32_t n, int32_t co, int32_t x_is_u8, c
     }
     return CGS_ERR_UNSUPPORTED;
 }
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// features.0, data gradient (the image gradient of the two mixes): d x [n,64,64,3] = conv3x3^T(dY) with dY given as the pooled gradient d e0
+// [n,32,32,co] + argmax bytes.  Three outputs and K = 9 co: on gen4 (lane = pixel, one output group) every input element costs one LDS read per tap
+// and the layer ran at 0.20 of the matrix peak.  Here lane = one 2x2 cell of d x (four accumulator sets of ONE group: 16 registers), ALL
+// 9 co weight steps in 9 co / 16 registers (23 at 40 channels: v_mfma_f32_4x4x1 with A broadcast, rows = the three colour channels), and the
+// cell's 4x4 patch of dY is built in registers channel quad by channel quad from the 3x3 pooled cells around it (9 value + 9 argmax-word LDS
+// reads per quad and lane, each value kept where its byte says the maximum was): 144 matrix instructions per quad and 256 pixels.
+struct GEnc0DgParams {
+    const float* de;          // pooled gradient [n,32,32,co]
+    const uint8_t* am;        // argmax bytes [n,32,32,co]
+    const float* w;           // HWIO [9][3][co]
+    float* dx;                // [n,64,64,3]
+    int n, nstrips;
+};
+
+template <int NG>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) genc0_dgrad_kernel(GEnc0DgParams P) {
+    constexpr int CO = 4 * NG, NK = 9 * CO, NV = (NK + 15) / 16;
+    constexpr int CW = 34, CROWS = 10;                      // pooled tile: 8 cell rows + halo, 32 cells + halo; [CROWS][CW][CO] values, then the argmax bytes
+    extern __shared__ __attribute__((aligned(16))) float4 gsm[];
+    float* const des = (float*)gsm;
+    uint8_t* const ams = (uint8_t*)(des + CROWS * CW * CO);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // weights: step q = tap' * CO + oc of the TRANSPOSED convolution reads W[8 - tap'][c = i][oc]; register q >> 4, lanes 4 (q & 15) + i
+    float wreg[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int q = 16 * v + (lane >> 2), tp = q / CO, oc = q % CO, i = lane & 3;
+        wreg[v] = (q < NK && i < 3) ? P.w[((8 - tp) * 3 + i) * CO + oc] : 0.f;
+    }
+    // halo cells of the tile: value 0 with "no gradient" bytes, for every strip (columns 0 and CW - 1)
+    for (int e = tid; e < CROWS * 2 * CO; e += 256) {
+        const int c = e % CO, side = (e / CO) & 1, r = e / (2 * CO), cell = r * CW + (side ? CW - 1 : 0);
+        des[cell * CO + c] = 0.f; ams[cell * CO + c] = 4;
+    }
+    __syncthreads();
+
+    for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
+        const int img = strip >> 2, crow0 = (strip & 3) * 8;            // 16 pixel rows = 8 cell rows of the image
+        // ---- stage the pooled rows crow0 - 1 .. crow0 + 8: all loads first (float4 values, uint32 argmax words), then the LDS stores ----
+        constexpr int NI = CROWS * 32 * NG, NIT = (NI + 255) / 256;
+        float4 rv[NIT];
+        uint32_t ra[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k, ee = e < NI ? e : 0, g = ee % NG, cx = (ee / NG) & 31, r = ee / (32 * NG), cy = crow0 + r - 1;
+            const bool in = cy >= 0 && cy < 32;
+            const size_t gi = in ? (((size_t)img * 32 + cy) * 32 + cx) * NG + g : 0;
+            rv[k] = ((const float4*)P.de)[gi];
+            ra[k] = ((const uint32_t*)P.am)[gi];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int e = tid + 256 * k;
+            if (e >= NI) continue;
+            const int g = e % NG, cx = (e / NG) & 31, r = e / (32 * NG), cy = crow0 + r - 1;
+            const bool in = cy >= 0 && cy < 32;
+            const int cell = r * CW + 1 + cx;
+            *(float4*)(des + cell * CO + 4 * g) = in ? rv[k] : f4zero();
+            *(uint32_t*)(ams + cell * CO + 4 * g) = in ? ra[k] : 0x04040404u;
+        }
+        __syncthreads();
+        // ---- this wave's band: cell rows 2 wave, 2 wave + 1 of the strip; lane = cell (cy = lane >> 5, cx = lane & 31) ----
+        const int cy = 2 * wave + (lane >> 5), cx = lane & 31;
+        frag4 acc[4] = {frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}};
+        ge_static_for<NG>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            // the 3 x 3 pooled cells around the lane's cell, channel quad g (tile coordinates: + 1 row / column for the halo)
+            float4 cv[3][3];
+            uint32_t cw[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const int cell = (cy + a) * CW + cx + b;
+                    cv[a][b] = *(const float4*)(des + cell * CO + 4 * g);
+                    cw[a][b] = *(const uint32_t*)(ams + cell * CO + 4 * g);
+                }
+            // patch pixel (r, c), r, c = 0 .. 3 = image pixel (2 cy' - 1 + r, 2 cx' - 1 + c): cell (r + 1) >> 1, (c + 1) >> 1 of the 3 x 3, position
+            // 2 ((r + 1) & 1) + ((c + 1) & 1) inside it
+            ge_static_for<9>([&](auto T) {
+                constexpr int tp = decltype(T)::value, ky = tp / 3, kx = tp % 3;
+#pragma unroll
+                for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+                    for (int ox = 0; ox < 2; ++ox) {
+                        const int r = oy + ky, c = ox + kx, a = (r + 1) >> 1, b = (c + 1) >> 1;
+                        const uint32_t pos = 2 * ((r + 1) & 1) + ((c + 1) & 1);
+                        const float4 v4 = cv[a][b];
+                        const uint32_t w = cw[a][b];
+                        const float x0 = (w & 255u) == pos ? v4.x : 0.f, x1 = ((w >> 8) & 255u) == pos ? v4.y : 0.f,
+                                    x2 = ((w >> 16) & 255u) == pos ? v4.z : 0.f, x3 = (w >> 24) == pos ? v4.w : 0.f;
+                        constexpr int q0 = tp * CO + 4 * g;
+                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 0) >> 4], x0, acc[oy * 2 + ox], 4, (q0 + 0) & 15, 0);
+                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 1) >> 4], x1, acc[oy * 2 + ox], 4, (q0 + 1) & 15, 0);
+                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 2) >> 4], x2, acc[oy * 2 + ox], 4, (q0 + 2) & 15, 0);
+                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 3) >> 4], x3, acc[oy * 2 + ox], 4, (q0 + 3) & 15, 0);
+                    }
+            });
+        });
+        // ---- d x: the cell's 2 x 2 pixels x 3 channels; a row of the band = 64 pixels x 3 floats contiguous ----
+        const int py = 2 * (crow0 + cy), px = 2 * cx;
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) {
+            float* o = P.dx + (((size_t)img * 64 + py + oy) * 64 + px) * 3;
+            const frag4 a0 = acc[oy * 2], a1 = acc[oy * 2 + 1];
+            *(float2*)o = make_float2(a0[0], a0[1]);
+            *(float2*)(o + 2) = make_float2(a0[2], a1[0]);
+            *(float2*)(o + 4) = make_float2(a1[1], a1[2]);
+        }
+        __syncthreads();
+    }
+}
+
+template <int NG>
+int genc0_dgrad_launch(GEnc0DgParams P, hipStream_t st) {
+    constexpr int CO = 4 * NG;
+    constexpr size_t lds = (size_t)10 * 34 * CO * 4 + (size_t)10 * 34 * CO;
+    P.nstrips = P.n * 4;
+    auto k = genc0_dgrad_kernel<NG>;
+    if (lds > 64 * 1024) {
+        static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return (int)attr;
+    }
+    const int per_cu = (int)((160 * 1024) / lds) < 2 ? 1 : 2;
+    const int cap = 256 * per_cu, rounds = (P.nstrips + cap - 1) / cap, blocks = (P.nstrips + rounds - 1) / rounds;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(256), lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+}  // namespace
+
+// d x [n,64,64,3] of features.0 (co = 16 / 24 / 32 / 40) from the pooled gradient de [n,32,32,co], the forward pass's argmax bytes and the layer's
+// HWIO weights [9][3][co] (the tensors of cgs_gen_conv3x3_bwd_data(hw 64, co, ci 3, dy_argmax) with the raw weights instead of the packed operand).
+extern "C" int cgs_gen_enc0_bwd_data(int32_t n, int32_t co, const float* de, const uint8_t* am, const float* w_hwio, float* dx, cgs_stream_t stream) {
+    if (n < 0 || !de || !am || !w_hwio || !dx) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const GEnc0DgParams P{de, am, w_hwio, dx, n, 0};
+    switch (co) {
+        case 16: return genc0_dgrad_launch<4>(P, (hipStream_t)stream);
+        case 24: return genc0_dgrad_launch<6>(P, (hipStream_t)stream);
+        case 32: return genc0_dgrad_launch<8>(P, (hipStream_t)stream);
+        case 40: return genc0_dgrad_launch<10>(P, (hipStream_t)stream);
+    }
+    return CGS_ERR_UNSUPPORTED;
+}

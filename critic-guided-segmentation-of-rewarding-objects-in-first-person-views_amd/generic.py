@@ -398,6 +398,10 @@ def _bwd_data(n, hw, co, ci, dy, am, w_ptr: int, out, addend=None):
     for t in (dy, am, out, addend):
         if t is not None and not t.is_contiguous():
             raise _lib.CgsError("generic conv backward: dy / argmax / out / addend must be contiguous NHWC device tensors")
+    if ENC0_DEDICATED and hw == 64 and ci == 3 and am is not None and addend is None and co in (16, 24, 32, 40):
+        # the image gradient of features.0 at chfak 2 .. 5: csrc/gen_enc0.hip (lane = 2x2 cell of d x, all weight steps in registers)
+        _lib.call("cgs_gen_enc0_bwd_data", n, co, _p(dy), _p(am), C.c_void_p(w_ptr), _p(out), _s())
+        return
     wp = pack_weights(w_ptr, co, 0, ci, dy.device, transposed=True)
     _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, co, ci, _p(dy), _p(am), _p(wp), _p(addend),
               0 if addend is None else addend.shape[0], _p(out), _s())

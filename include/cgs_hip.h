@@ -504,6 +504,9 @@ int cgs_gen_enc0_fwd(int32_t n, int32_t co, int32_t x_is_u8, const void* x, cons
 int cgs_gen_enc0_bwd_weight_slabs(int32_t n, int32_t co);
 int cgs_gen_enc0_bwd_weight(int32_t n, int32_t co, int32_t x_is_u8, const void* x, const float* de, const uint8_t* am, float* slab,
                             cgs_stream_t stream);
+/* ... and its data gradient (the image gradient of the mixes): d x [n,64,64,3] from de, am and the layer's raw HWIO weights (the tensors of
+ * cgs_gen_conv3x3_bwd_data(hw 64, co, ci 3, dy_argmax)).                                                                                 */
+int cgs_gen_enc0_bwd_data(int32_t n, int32_t co, const float* de, const uint8_t* am, const float* w_hwio, float* dx, cgs_stream_t stream);
 int cgs_gen_gemm(int32_t m, int32_t k, int32_t n, int32_t act, float slope, const float* x, const float* w,
                  const float* bias, float* out, cgs_stream_t stream);
 

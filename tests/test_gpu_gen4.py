@@ -223,3 +223,30 @@ def test_gen_enc0_dedicated_forward_vs_float64(n, co, u8):
         assert ((got & 3)[0, 1:3, 1:3][live[0, 1:3, 1:3]] == 0).all()
     assert lib.cgs_gen_enc0_fwd(1, 8, 1, C.c_void_p(a_g.data_ptr()), C.c_void_p(w_g.data_ptr()), C.c_void_p(b_g.data_ptr()),
                                 C.c_void_p(out.data_ptr()), None, None) == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("n,co", [(3, 40), (2, 16), (2, 24), (2, 32), (150, 40)])
+def test_gen_enc0_dedicated_image_gradient_vs_float64(n, co):
+    """cgs_gen_enc0_bwd_data (features.0's data gradient at chfak 2 .. 5 on its own kernel: lane = 2x2 cell of d x, the 4x4 patch of dY rebuilt in
+    registers from the pooled gradient + argmax bytes) against float64 conv_transpose2d of the re-expanded gradient; n = 150: more strips than
+    persistent workgroups."""
+    from cgs_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5 * co + n)
+    dE = torch.randn(n, 32, 32, co, generator=g)
+    am = torch.randint(0, 5, (n, 32, 32, co), dtype=torch.uint8, generator=g)
+    am = torch.where(torch.rand(am.shape, generator=g) < 0.1, am | 4, am)
+    w = torch.randn(9, 3, co, generator=g) * 0.3
+    full = torch.zeros(n, 32, 2, 32, 2, co, dtype=torch.float64)
+    for py in range(2):
+        for px in range(2):
+            full[:, :, py, :, px, :] = torch.where(am == 2 * py + px, dE.double(), torch.zeros((), dtype=torch.float64))
+    wt = w.double().view(3, 3, 3, co).permute(3, 2, 0, 1)              # OIHW of the forward layer (O = co, I = 3)
+    ref = F.conv_transpose2d(full.view(n, 64, 64, co).permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1).float()
+    de_g, am_g, w_g = dE.cuda(), am.cuda(), w.cuda()
+    dx = torch.full((n, 64, 64, 3), 7.0, device="cuda")
+    rc = lib.cgs_gen_enc0_bwd_data(n, co, C.c_void_p(de_g.data_ptr()), C.c_void_p(am_g.data_ptr()), C.c_void_p(w_g.data_ptr()),
+                                   C.c_void_p(dx.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    rel_close(dx.cpu(), ref, f"gen_enc0 image gradient n={n} co={co}", rtol=1e-4, atol_scale=2e-5)
