@@ -480,24 +480,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             // patch pixel (r, c), r, c = 0 .. 3 = image pixel (2 cy' - 1 + r, 2 cx' - 1 + c): cell (r + 1) >> 1, (c + 1) >> 1 of the 3 x 3, position
             // 2 ((r + 1) & 1) + ((c + 1) & 1) inside it
+            // the 16 patch pixels of this quad, each kept where its argmax byte says the cell's maximum was
+            float pv[4][4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int a = (r + 1) >> 1, b = (c + 1) >> 1;
+                    const uint32_t pos = 2 * ((r + 1) & 1) + ((c + 1) & 1), w = cw[a][b];
+                    const float4 v4 = cv[a][b];
+                    pv[r][c][0] = (w & 255u) == pos ? v4.x : 0.f; pv[r][c][1] = ((w >> 8) & 255u) == pos ? v4.y : 0.f;
+                    pv[r][c][2] = ((w >> 16) & 255u) == pos ? v4.z : 0.f; pv[r][c][3] = (w >> 24) == pos ? v4.w : 0.f;
+                }
             ge_static_for<9>([&](auto T) {
-                constexpr int tp = decltype(T)::value, ky = tp / 3, kx = tp % 3;
+                constexpr int tp = decltype(T)::value, ky = tp / 3, kx = tp % 3, q0 = tp * CO + 4 * g;
+                ge_static_for<4>([&](auto J) {              // consecutive instructions go to the four different accumulators
+                    constexpr int j = decltype(J)::value;
 #pragma unroll
-                for (int oy = 0; oy < 2; ++oy)
+                    for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
-                    for (int ox = 0; ox < 2; ++ox) {
-                        const int r = oy + ky, c = ox + kx, a = (r + 1) >> 1, b = (c + 1) >> 1;
-                        const uint32_t pos = 2 * ((r + 1) & 1) + ((c + 1) & 1);
-                        const float4 v4 = cv[a][b];
-                        const uint32_t w = cw[a][b];
-                        const float x0 = (w & 255u) == pos ? v4.x : 0.f, x1 = ((w >> 8) & 255u) == pos ? v4.y : 0.f,
-                                    x2 = ((w >> 16) & 255u) == pos ? v4.z : 0.f, x3 = (w >> 24) == pos ? v4.w : 0.f;
-                        constexpr int q0 = tp * CO + 4 * g;
-                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 0) >> 4], x0, acc[oy * 2 + ox], 4, (q0 + 0) & 15, 0);
-                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 1) >> 4], x1, acc[oy * 2 + ox], 4, (q0 + 1) & 15, 0);
-                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 2) >> 4], x2, acc[oy * 2 + ox], 4, (q0 + 2) & 15, 0);
-                        acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + 3) >> 4], x3, acc[oy * 2 + ox], 4, (q0 + 3) & 15, 0);
-                    }
+                        for (int ox = 0; ox < 2; ++ox)
+                            acc[oy * 2 + ox] = __builtin_amdgcn_mfma_f32_4x4x1f32(wreg[(q0 + j) >> 4], pv[oy + ky][ox + kx][j], acc[oy * 2 + ox], 4,
+                                                                                  (q0 + j) & 15, 0);
+                });
             });
         });
         // ---- d x: the cell's 2 x 2 pixels x 3 channels; a row of the band = 64 pixels x 3 floats contiguous ----
