@@ -165,6 +165,11 @@ class Hourglass128:
                 out[which][key + ".weight"], out[which][key + ".bias"] = W.contiguous().clone(), b.clone()
         return out
 
+    def _packs_unused(self) -> bool:
+        """chfak 1 with every dedicated path on: no layer runs on the shape-generic 16-bit convolution, so its bf16 operand copies are never read
+        (the dedicated kernels convert the fp32 master weights themselves)."""
+        return bool(self.tail and TAIL and H5CONV and HWGRAD and POOL_FUSED and ENC0_DIRECT)
+
     def _pack_weights(self, transposed: bool):
         """bf16 operand copies of every 3x3 layer from the fp32 master weights: ONE launch (a device job table, built once)."""
         key = bool(transposed)
@@ -616,7 +621,8 @@ class Hourglass128:
             parallel.allreduce_sum_(self.grad, self.pg)
         _lib.call("cgs_adam_flat", self.total, _p(self.flat), _p(self.grad), _p(self.m), _p(self.v), _p(self.step_t), self.lr, self.b1, self.b2,
                   self.eps, 1.0 / self.world, _s())
-        self._pack_weights(transposed=True)
+        if not self._packs_unused():
+            self._pack_weights(transposed=True)
 
     def phase2_step(self, A_u8: Optional[torch.Tensor] = None, B_u8: Optional[torch.Tensor] = None, Y: Optional[torch.Tensor] = None,
                     use_graph: bool = True):
