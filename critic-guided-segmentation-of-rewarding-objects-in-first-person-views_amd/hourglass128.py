@@ -453,7 +453,25 @@ class Hourglass128:
         _lib.call("cgs_bf16_convert", n, 16 * d[4], 16 * d[4], 0, _p(de4f), _p(dp), _s())
         return dp
 
-    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None, plan_pw=None, mix_bwd=None):
+    def _head_wgrad(self, T, ranges, plan, plan_pw, tag):
+        """Weight gradients of features.17 / crit.1 / crit.4 (+ dec_model.5 where a range carries d o5) from the per-image vectors the tail
+        backward kernel(s) left: ONE launch for up to two image ranges (cgs_tail_head_wgrad sums them into the same slab rows)."""
+        assert 1 <= len(ranges) <= 2
+        f32 = torch.float32
+        total = sum(r[0] for r in ranges)
+        has_pw = any(r[3] is not None for r in ranges)
+        nh = self.lib.cgs_tail_head_wgrad_slabs(total)
+        slh = T.buf(f"slab_thead_{tag}", (nh, hg.HEAD_SLAB), f32, self.dev)
+        slpw = T.buf(f"slab_tpw_{tag}", (nh, hg.PW_SLAB), f32, self.dev) if has_pw else None
+        r0 = ranges[0]
+        r1 = ranges[1] if len(ranges) > 1 else (0, None, None, None, 0)
+        _lib.call("cgs_tail_head_wgrad", r0[0], _p(r0[1]), _p(r0[2]), _p(r0[3]), r0[4], r1[0], _p(r1[1]), _p(r1[2]), _p(r1[3]), r1[4],
+                  _p(slh), _p(slpw), _s())
+        plan.add(slh, nh, hg.HEAD_SLAB, self.off["features.17"][0])
+        if has_pw:
+            plan_pw.add(slpw, nh, hg.PW_SLAB, self.off["dec_model.5"][0])        # (a masker parameter: the overwriting plan)
+
+    def _critic_backward(self, T, plan, tag, src, lo, hi, d_e5_add=None, skips=None, want_dx=None, plan_pw=None, mix_bwd=None, head_sink=None):
         """Backward of the critic on slots [lo, hi) from T.dpred; skips = [dskip_0..4] gradients arriving at the embeds from the
         decoder (bf16), d_e5_add fp32 [n,nb]; want_dx: fp32 [n,128,128,3] output for the image gradient."""
         n, d, nb = hi - lo, self.d, self.nb
@@ -472,14 +490,11 @@ class Hourglass128:
                       _p(d_e5_add) if has else None, n if has else 0, _p(de2), _p(hvec), _p(sl13), _p(sl9), _NODROP, _NODROP, _NODROP, _s())
             plan.add(sl13, nsl, 1168, self.off["features.13"][0])
             plan.add(sl9, nsl, 584, self.off["features.9"][0])
-            nh = self.lib.cgs_tail_head_wgrad_slabs(n)
-            slh = T.buf(f"slab_thead_{tag}", (nh, hg.HEAD_SLAB), f32, self.dev)
-            slpw = T.buf(f"slab_tpw_{tag}", (nh, hg.PW_SLAB), f32, self.dev) if has else None
-            _lib.call("cgs_tail_head_wgrad", n, _p(hvec), _p(T.e5[lo:hi]), _p(d_e5_add) if has else None, n if has else 0,
-                      0, None, None, None, 0, _p(slh), _p(slpw), _s())
-            plan.add(slh, nh, hg.HEAD_SLAB, self.off["features.17"][0])
-            if has:
-                (plan_pw or plan).add(slpw, nh, hg.PW_SLAB, self.off["dec_model.5"][0])      # (a masker parameter: the overwriting plan)
+            rng = (n, hvec, T.e5[lo:hi], d_e5_add if has else None, n if has else 0)
+            if head_sink is not None:
+                head_sink.append(rng)        # the caller forms the head's weight gradients of all its passes in ONE launch (_head_wgrad)
+            else:
+                self._head_wgrad(T, [rng], plan, plan_pw or plan, tag)
             dp = T.buf(f"dp2_{tag}", (n, 16, 16, d[2]), torch.bfloat16, self.dev)
             _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(de2), _p(dp), _s())
             levels = (2, 1, 0)
@@ -604,15 +619,18 @@ class Hourglass128:
                   _p(T.dpred), _s())
         first = T.plan_a is None
         pa, pb = hg.SlabPlan(), hg.SlabPlan()
+        sink = [] if (TAIL and self.tail) else None      # the head's weight gradients of the mix pass and the A pass: one launch at the end
         if MIX_BWD_FUSED and H5CONV and HWGRAD and POOL_FUSED and self.h5:
-            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz))
+            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, mix_bwd=(A, B, self.L1 / nz, self.L2 / nz), head_sink=sink)
         else:
             if T.dmixed is None:
                 T.dmixed = torch.empty((2 * n, 128, 128, 3), device=self.dev)
-            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, want_dx=T.dmixed)
+            self._critic_backward(T, pa, "mix", mixsrc, 2 * n, 4 * n, want_dx=T.dmixed, head_sink=sink)
             _lib.call("cgs_mix_bwd", n, 16384, _p(A), _p(B), _p(T.Z), _p(T.dmixed), 1, self.L1 / nz, self.L2 / nz, _p(T.dzpre), _s())
         skips, de5 = self._masker_backward(T, pa, A)
-        self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips, plan_pw=pa)
+        self._critic_backward(T, pb, "a", A, n, 2 * n, d_e5_add=de5, skips=skips, plan_pw=pa, head_sink=sink)
+        if sink:
+            self._head_wgrad(T, sink, pa, pa, "both")      # both passes summed in the slab rows: the overwriting plan takes them whole
         if first:
             T.plan_a, T.plan_b = pa.build(self.grad), pb.build(self.grad, accumulate=True)
         T.plan_a.run(None)
