@@ -13,7 +13,7 @@ SRC_F32, SRC_U8, SRC_MIX = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_SIGMOID = 0, 1, 2, 3
 H5_ENC1_FWD, H5_ENC1_BWD_DATA, H5_DEC0_FWD, H5_DEC0_BWD_SKIP, H5_DEC0_BWD_LOW = 1, 2, 3, 4, 5
 H5_ENC1_BWD_DATA_POOLED = 6
-H5_ENC2_FWD, H5_ENC2_BWD_DATA_POOLED, H5_DEC1_FWD, H5_DEC1_BWD_SKIP, H5_DEC1_BWD_LOW = 7, 8, 9, 10, 11      # cgs_bf16_h5conv (cgs_hip.h)
+H5_ENC2_FWD, H5_ENC2_BWD_DATA_POOLED, H5_DEC1_FWD, H5_DEC1_BWD_SKIP, H5_DEC1_BWD_LOW, H5_DEC1_FWD_F32B = 7, 8, 9, 10, 11, 12      # cgs_bf16_h5conv (cgs_hip.h)
 
 vp = C.c_void_p
 i32 = C.c_int32

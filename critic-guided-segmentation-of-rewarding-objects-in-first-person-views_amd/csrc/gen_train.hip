@@ -240,18 +240,28 @@ __global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
     frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
     const bool rok = row < P.m, cok = col < P.n;
     const int kb = P.kper > 0 ? (int)blockIdx.y * P.kper : 0, ke = P.kper > 0 ? min(P.k, kb + P.kper) : P.k;
-    for (int k0 = kb + 32 * wave; k0 < ke; k0 += 128) {      // 8 k-steps per round: 16 independent loads in flight, then 8 MFMAs
-        float a[8], b[8];
+    // 8 k-steps per round and wave; THREE rounds' loads (48) are issued before their 24 MFMAs: the kernel's life is its dependent memory round trips
+    // (k = 1280 at chfak 5: ten per wave with one round in flight, 16 us per launch for 1.3 us of arithmetic; round 4: four)
+    for (int k0 = kb + 32 * wave; k0 < ke; k0 += 3 * 128) {
+        float a[3][8], b[3][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int k = k0 + 4 * u + kq, kc = k < ke ? k : ke - 1;
-            a[u] = xr[(size_t)kc * P.sxk];
-            b[u] = wc[(size_t)kc * P.swk];
-            a[u] = (rok && k < ke) ? a[u] : 0.f;
-            b[u] = (cok && k < ke) ? b[u] : 0.f;
-        }
+        for (int r = 0; r < 3; ++r)
+            if (k0 + 128 * r < ke) {            // (wave-uniform: short K runs one round)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    const int k = k0 + 128 * r + 4 * u + kq, kc = k < ke ? k : ke - 1;
+                    a[r][u] = xr[(size_t)kc * P.sxk];
+                    b[r][u] = wc[(size_t)kc * P.swk];
+                    a[r][u] = (rok && k < ke) ? a[r][u] : 0.f;
+                    b[r][u] = (cok && k < ke) ? b[r][u] : 0.f;
+                }
+            }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            if (k0 + 128 * r < ke) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][u], b[r][u], acc, 0, 0, 0);
+            }
     }
     if (wave > 0) {
 #pragma unroll

@@ -497,6 +497,7 @@ using H5Dec0DL = H5Cfg< 64, 16,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_
 using H5Enc2F  = H5Cfg< 32, 32,  8, 0,  8,  8,  8, 0, false, EPI_POOLMAX,   CGS_ACT_RELU,    true>;    // features.6 forward -> fp32 (the tail kernels' input)
 using H5Enc2DP = H5Cfg< 32, 32,  8, 0,  8,  8,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false, true>;   // features.6: d e1 from the pooled gradient
 using H5Dec1F  = H5Cfg< 32, 16,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.1 forward
+using H5Dec1FF = H5Cfg< 32, 16,  8, 8,  8, 16,  8, 0, false, EPI_PLAIN,     CGS_ACT_NONE,    false, false, ElBF16, true>;   // ... with o2 in fp32 (straight from the tail kernel)
 using H5Dec1DS = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 0, true,  EPI_PLAIN,     CGS_ACT_NONE,    false>;   // dec_model.1: d skip (e1)
 using H5Dec1DL = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_ACT_NONE,    true>;    // dec_model.1: d o2 (2x2 cell sums, fp32: the tail kernels' input)
 
@@ -599,6 +600,7 @@ extern "C" int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, cons
         case CGS_H5_ENC2_FWD: return bias ? h5_launch<H5Enc2F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
         case CGS_H5_ENC2_BWD_DATA_POOLED: return codes ? h5_launch<H5Enc2DP>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
         case CGS_H5_DEC1_FWD: return bias && src_b ? h5_launch<H5Dec1F>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
+        case CGS_H5_DEC1_FWD_F32B: return bias && src_b ? h5_launch<H5Dec1FF>(P, (hipStream_t)stream) : CGS_ERR_BADARG;
         case CGS_H5_DEC1_BWD_SKIP: return h5_launch<H5Dec1DS>(P, (hipStream_t)stream);
         case CGS_H5_DEC1_BWD_LOW: return h5_launch<H5Dec1DL>(P, (hipStream_t)stream);
     }

@@ -209,7 +209,8 @@ class Hourglass128:
         if H5CONV and self.h5 and w16 is None and not out_f32 and a_kind == 0:
             w, bias = self._wview(key)
             if key == "dec_model.1" and (hw, ca, cb, co, ups) == (32, 8, 8, 8, 2) and not pool and act == "none":
-                _lib.call("cgs_bf16_h5conv", _lib.H5_DEC1_FWD, n, _p(a), _p(b), _p(w), _p(bias), _p(out), None, _s())
+                which = _lib.H5_DEC1_FWD_F32B if b.dtype == torch.float32 else _lib.H5_DEC1_FWD      # fp32 o2: straight from the tail kernel
+                _lib.call("cgs_bf16_h5conv", which, n, _p(a), _p(b), _p(w), _p(bias), _p(out), None, _s())
                 return out
             if key == "features.3" and (hw, ca, cb, co) == (64, 8, 0, 8) and pool and act == "relu":
                 _lib.call("cgs_bf16_h5conv", _lib.H5_ENC1_FWD, n, _p(a), None, _p(w), _p(bias), _p(out), _p(codes), _s())
@@ -266,8 +267,11 @@ class Hourglass128:
             o4, o3, o2 = f32(n, 4, 4, 16), f32(n, 8, 8, 8), f32(n, 16, 16, 8)
             tdw = self._tail_dec_w()
             _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(e2), _p(e3), _p(e4), _p(o5), _p(o4), _p(o3), _p(o2), _s())
-            o = torch.empty((n, 16, 16, 8), device=self.dev, dtype=torch.bfloat16)
-            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(o2), _p(o), _s())
+            if H5CONV:      # dec_model.1 reads the tail kernel's fp32 o2 directly
+                o = o2
+            else:
+                o = torch.empty((n, 16, 16, 8), device=self.dev, dtype=torch.bfloat16)
+                _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(o2), _p(o), _s())
             lower = (1, 0)
         else:
             for key, co in zip(ENC_KEYS, d):
@@ -382,7 +386,7 @@ class Hourglass128:
             tdw = self._tail_dec_w()
             _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(T.t_e2[n:2 * n]), _p(T.t_e3[n:2 * n]), _p(T.t_e4[n:2 * n]), _p(T.t_o5[n:2 * n]),
                       _p(T.t_o4), _p(T.t_o3), _p(T.t_o2), _s())
-            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(T.t_o2), _p(T.o[2]), _s())
+            _lib.call("cgs_bf16_convert", n * 256, 8, 8, 0, _p(T.t_o2), _p(T.o[2]), _s())      # (bf16 o2: dec_model.1's weight gradient reads it too)
             lower = (1, 0)
         else:
             self._gemm("dec_model.5", T.e5[n:2 * n], nb, nb, out=T.o5)

@@ -203,7 +203,8 @@ enum { CGS_H5_ENC1_FWD = 1, CGS_H5_ENC1_BWD_DATA = 2, CGS_H5_DEC0_FWD = 3, CGS_H
        /* the 32x32 level: features.6 forward (e1 bf16 [n,32,32,8] -> e2 FP32 [n,16,16,8] + argmax bytes: the tail kernels' input), its data
         * gradient from the pooled gradient (as 6, one level down), dec_model.1 forward (cat(e1, nearest-up2(o2 bf16 [n,16,16,8])) -> o1) and
         * its data gradients (skip: bf16 [n,32,32,8]; low: cell sums, FP32 [n,16,16,8])                                                  */
-       CGS_H5_ENC2_FWD = 7, CGS_H5_ENC2_BWD_DATA_POOLED = 8, CGS_H5_DEC1_FWD = 9, CGS_H5_DEC1_BWD_SKIP = 10, CGS_H5_DEC1_BWD_LOW = 11 };
+       CGS_H5_ENC2_FWD = 7, CGS_H5_ENC2_BWD_DATA_POOLED = 8, CGS_H5_DEC1_FWD = 9, CGS_H5_DEC1_BWD_SKIP = 10, CGS_H5_DEC1_BWD_LOW = 11,
+       CGS_H5_DEC1_FWD_F32B = 12 /* as 9 with src_b = o2 in FP32 [n,16,16,8] (the tail kernel's output: no bf16 copy) */ };
 int cgs_bf16_h5conv(int32_t which, int32_t n, const void* src_a, const void* src_b, const float* w_hwio, const float* bias, void* out,
                     uint8_t* codes, cgs_stream_t stream);
 /* Weight + bias gradient of the large-map layers of config 5 at chfak 1 (csrc/hwgrad.hip; same arithmetic as cgs_bf16_conv3x3_bwd_weight):
