@@ -227,60 +227,99 @@ struct GenGemmExParams {
     int kper;           // > 0: split K -- blockIdx.y owns k in [y kper, (y + 1) kper) and writes its partial product to out + y m n
 };
 
-// one workgroup per 16 x 16 output tile (x K share), its 4 waves split the K rounds (summed in wave order through LDS);
-// A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn]
+// one workgroup per 32 x 16 output tile (x K share): two row blocks share every B fragment; its 4 waves split K in groups of 16 (summed
+// in wave order through LDS);  A(m,k) = x[m sxm + k sxk], B(k,n) = w[k swk + n swn].
+// A lane (l15, kq) supplies k = group + 4 kq + i to matrix step i of a group (any bijection of k shared by A and B is a valid order of
+// the sum), so an operand that is contiguous along k (AV / BV: stride 1, rows 16-byte aligned, K share a multiple of 4) is ONE 16-byte
+// load per group instead of four dwords 4 * stride apart.  Four groups' loads (up to 12 x 16 bytes per lane) are issued before their
+// 32 matrix instructions: the kernel's life is its dependent memory round trips (round 4: 16 x 16 tiles, dword loads: 35 us for the
+// 1024 x 1280 x 160 product of features.14 at chfak 5).
+template <bool V>
+__device__ __forceinline__ float4 gemm_ld4(const float* base, long stride, int k4, int kb, int ke) {      // raw: k past the share reads k = kb
+    if constexpr (V) return *(const float4*)(base + (k4 < ke ? k4 : kb));
+    else {
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = base[(size_t)(k4 + i < ke ? k4 + i : kb) * stride];
+        return make_float4(t[0], t[1], t[2], t[3]);
+    }
+}
+__device__ __forceinline__ float4 gemm_mask4(float4 v, int k4, int ke) {
+    return make_float4(k4 < ke ? v.x : 0.f, k4 + 1 < ke ? v.y : 0.f, k4 + 2 < ke ? v.z : 0.f, k4 + 3 < ke ? v.w : 0.f);
+}
+
+template <bool AV, bool BV>
 __global__ void __launch_bounds__(256) gen_gemm_ex_kernel(GenGemmExParams P) {
-    __shared__ float red[3][4][64];
+    __shared__ float red[3][2][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, kq = lane >> 4;
     const int ntn = (P.n + 15) / 16;
-    const int m0 = (blockIdx.x / ntn) * 16, n0 = (blockIdx.x % ntn) * 16;
-    const int row = m0 + l15, col = n0 + l15;
-    const float* xr = P.x + (size_t)(row < P.m ? row : 0) * P.sxm;
-    const float* wc = P.w + (size_t)(col < P.n ? col : 0) * P.swn;
-    frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};
-    const bool rok = row < P.m, cok = col < P.n;
+    const int m0 = (blockIdx.x / ntn) * 32, n0 = (blockIdx.x % ntn) * 16;
+    const int row0 = m0 + l15, row1 = row0 + 16, col = n0 + l15;
+    const float* xr0 = P.x + (size_t)(row0 < P.m ? row0 : P.m - 1) * P.sxm;
+    const float* xr1 = P.x + (size_t)(row1 < P.m ? row1 : P.m - 1) * P.sxm;
+    const float* wc = P.w + (size_t)(col < P.n ? col : P.n - 1) * P.swn;
+    frag4 acc0 = frag4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
     const int kb = P.kper > 0 ? (int)blockIdx.y * P.kper : 0, ke = P.kper > 0 ? min(P.k, kb + P.kper) : P.k;
-    // 8 k-steps per round and wave; THREE rounds' loads (48) are issued before their 24 MFMAs: the kernel's life is its dependent memory round trips
-    // (k = 1280 at chfak 5: ten per wave with one round in flight, 16 us per launch for 1.3 us of arithmetic; round 4: four)
-    for (int k0 = kb + 32 * wave; k0 < ke; k0 += 3 * 128) {
-        float a[3][8], b[3][8];
+    constexpr int U = 4;
+    for (int kg = kb + 16 * wave; kg < ke; kg += 64 * U) {
+        // (no branch and no use of a loaded value between the loads: either one makes the compiler wait for the loads issued so far)
+        float4 a0[U], a1[U], b[U];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-            if (k0 + 128 * r < ke) {            // (wave-uniform: short K runs one round)
+        for (int u = 0; u < U; ++u) {
+            const int k4 = kg + 64 * u + 4 * kq;
+            a0[u] = gemm_ld4<AV>(xr0, P.sxk, k4, kb, ke);
+            a1[u] = gemm_ld4<AV>(xr1, P.sxk, k4, kb, ke);
+            b[u] = gemm_ld4<BV>(wc, P.swk, k4, kb, ke);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int k = k0 + 128 * r + 4 * u + kq, kc = k < ke ? k : ke - 1;
-                    a[r][u] = xr[(size_t)kc * P.sxk];
-                    b[r][u] = wc[(size_t)kc * P.swk];
-                    a[r][u] = (rok && k < ke) ? a[r][u] : 0.f;
-                    b[r][u] = (cok && k < ke) ? b[r][u] : 0.f;
+        for (int u = 0; u < U; ++u)
+            if (kg + 64 * u < ke) {                // (wave-uniform)
+                const int k4 = kg + 64 * u + 4 * kq;
+                const float4 x0 = gemm_mask4(a0[u], k4, ke), x1 = gemm_mask4(a1[u], k4, ke), y = gemm_mask4(b[u], k4, ke);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(x0, i), f4get(y, i), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(x1, i), f4get(y, i), acc1, 0, 0, 0);
                 }
-            }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            if (k0 + 128 * r < ke) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][u], b[r][u], acc, 0, 0, 0);
             }
     }
     if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[wave - 1][j][lane] = acc[j];
+        for (int j = 0; j < 4; ++j) { red[wave - 1][0][j][lane] = acc0[j]; red[wave - 1][1][j][lane] = acc1[j]; }
     }
     __syncthreads();
     if (wave == 0 && col < P.n) {
         const float bias = P.bias ? P.bias[col] : 0.f;
+        float* const obase = P.out + (size_t)blockIdx.y * (P.kper > 0 ? (size_t)P.m * P.n : 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = m0 + 4 * kq + j;
-            if (r < P.m) {
-                float* o = P.out + (size_t)blockIdx.y * (P.kper > 0 ? (size_t)P.m * P.n : 0) + (size_t)r * P.n + col;
-                const float sum = ((acc[j] + red[0][j][lane]) + red[1][j][lane]) + red[2][j][lane];
-                const float v = gen_act(sum + bias, P.act, P.slope);
-                *o = P.accumulate ? *o + v : v;
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = m0 + 16 * h + 4 * kq + j;
+                if (r < P.m) {
+                    float* o = obase + (size_t)r * P.n + col;
+                    const float own = h ? acc1[j] : acc0[j];
+                    const float sum = ((own + red[0][h][j][lane]) + red[1][h][j][lane]) + red[2][h][j][lane];
+                    const float v = gen_act(sum + bias, P.act, P.slope);
+                    *o = P.accumulate ? *o + v : v;
+                }
             }
         }
     }
+}
+
+// an operand may be read 16 bytes along k: unit stride, 16-byte aligned rows, K shares that are multiples of 4
+static bool gemm_vec_ok(const float* p, long sk, long srow, int k, int kper) {
+    return sk == 1 && (srow & 3) == 0 && ((uintptr_t)p & 15) == 0 && (k & 3) == 0 && (kper & 3) == 0;
+}
+static void gemm_ex_launch(const GenGemmExParams& P, int nsplit, hipStream_t st) {
+    const dim3 grid(((P.m + 31) / 32) * ((P.n + 15) / 16), nsplit);
+    const bool av = gemm_vec_ok(P.x, P.sxk, P.sxm, P.k, P.kper), bv = gemm_vec_ok(P.w, P.swk, P.swn, P.k, P.kper);
+    if (av && bv) hipLaunchKernelGGL((gen_gemm_ex_kernel<true, true>), grid, dim3(256), 0, st, P);
+    else if (av) hipLaunchKernelGGL((gen_gemm_ex_kernel<true, false>), grid, dim3(256), 0, st, P);
+    else if (bv) hipLaunchKernelGGL((gen_gemm_ex_kernel<false, true>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((gen_gemm_ex_kernel<false, false>), grid, dim3(256), 0, st, P);
 }
 
 int ew_blocks(size_t items) { size_t b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); }
@@ -448,7 +487,7 @@ extern "C" int cgs_gen_gemm_ex(int32_t m, int32_t k, int32_t n, const float* x, 
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !out || act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
     if (m == 0) return CGS_OK;
     GenGemmExParams P{x, w, bias, out, m, k, n, act, accumulate, (long)sxm, (long)sxk, (long)swk, (long)swn, slope, 0};
-    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
+    gemm_ex_launch(P, 1, (hipStream_t)stream);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -458,7 +497,7 @@ extern "C" int cgs_gen_gemm_ex_splitk(int32_t m, int32_t k, int32_t n, const flo
     if (m < 0 || k <= 0 || n <= 0 || !x || !w || !slab || nsplit < 1 || nsplit > 65535) return CGS_ERR_BADARG;
     if (m == 0) return CGS_OK;
     GenGemmExParams P{x, w, nullptr, slab, m, k, n, CGS_ACT_NONE, 0, (long)sxm, (long)sxk, (long)swk, (long)swn, 0.f, (k + nsplit - 1) / nsplit};
-    hipLaunchKernelGGL(gen_gemm_ex_kernel, dim3(((m + 15) / 16) * ((n + 15) / 16), nsplit), dim3(256), 0, (hipStream_t)stream, P);
+    gemm_ex_launch(P, nsplit, (hipStream_t)stream);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -309,6 +309,9 @@ struct MaskInferGeo {
     static constexpr size_t LDS = (size_t)((XIMG + 3) / 4 * 4 + XO + HS + W2S) * 4;
 };
 
+#ifndef MIF_PREFETCH
+#define MIF_PREFETCH 0      // 1 = the next tile's fetch issued before this tile's arithmetic (measured equal at 4 / 2 workgroups per CU: the other workgroups already cover the round trip)
+#endif
 template <int SRC, bool TRAIN>
 __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
     using G = MaskInferGeo;
@@ -357,39 +360,83 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
         hs[(r * IC + (side ? IC - 1 : 0)) * HPS + ch] = 0.f;
     }
 
+    __builtin_amdgcn_s_waitcnt(0);     // the preloads above land HERE: a first use inside the tile loop would wait with vmcnt(0) and drain the prefetch
+    // Staging: ALL of a tile's global loads are issued back to back into registers (fetch), then written to LDS (commit): one
+    // memory round trip per tile instead of seven dependent load -> wait -> store rounds; with MIF_PREFETCH the next tile's fetch
+    // is issued before this tile's arithmetic.
+    constexpr int RI = (NIMG + 255) / 256, RO = (NLO + 255) / 256;
+    [[maybe_unused]] uint32_t ilo[RI], ihi[RI];
+    [[maybe_unused]] float if0[RI], if1[RI], if2[RI];
+    float4 of[RO];
+    auto fetch = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int e = tid + 256 * r;       // (no branch around the loads: elements past the tile read pixel 0 and are dropped in commit)
+            const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+            const bool in = e < NIMG && y >= 0 && y < H && x >= 0 && x < W;
+            const int pix = in ? (n0 * H + y) * W + x : 0;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                const int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                ilo[r] = s32[d]; ihi[r] = s32[d + 1 <= last ? d + 1 : last];
+            } else {
+                const float* sf = (const float*)P.img;
+                if0[r] = sf[pix * 3]; if1[r] = sf[pix * 3 + 1]; if2[r] = sf[pix * 3 + 2];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const int e = tid + 256 * r;
+            const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+            const bool in = e < NLO && ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            of[r] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+        }
+    };
+    auto commit = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        (void)n0;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int e = tid + 256 * r;
+            if (e < NIMG) {
+                const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+                const bool in = y >= 0 && y < H && x >= 0 && x < W;
+                float v0, v1, v2;
+                if constexpr (SRC == WSRC_U8) {
+                    const int pix = in ? (n0 * H + y) * W + x : 0;
+                    const uint64_t both = (((uint64_t)ihi[r] << 32) | ilo[r]) >> (((pix * 3) & 3) * 8);
+                    const float sc = 1.f / 255.f;
+                    v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+                } else {
+                    v0 = if0[r]; v1 = if1[r]; v2 = if2[r];
+                }
+                float* d = ximg + e * IPS;
+                d[0] = in ? v0 : 0.f; d[1] = in ? v1 : 0.f; d[2] = in ? v2 : 0.f; d[3] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const int e = tid + 256 * r;
+            if (e < NLO) {
+                const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+                const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+                const bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+                const float4 v = in ? of[r] : f4zero();
+                float2* d = (float2*)(xo + (pr * LC + pc) * LPS + 4 * half);
+                d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
+            }
+        }
+    };
+
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
         // ---- input tiles -> LDS: image rows row0-2 .. row0+9, o0 rows row0/2-2 .. row0/2+5 ----
-        for_elems<NIMG, 256>(tid, [&](int e) {
-            int r = e / IC, c = e % IC;
-            int y = row0 + r - 2, x = c - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            int pix = in ? (n0 * H + y) * W + x : 0;
-            float v0, v1, v2;
-            if constexpr (SRC == WSRC_U8) {
-                const uint32_t* s32 = (const uint32_t*)P.img;
-                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
-                uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
-                uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
-                const float sc = 1.f / 255.f;
-                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
-            } else {
-                const float* sf = (const float*)P.img;
-                v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
-            }
-            float* d = ximg + e * IPS;
-            d[0] = in ? v0 : 0.f; d[1] = in ? v1 : 0.f; d[2] = in ? v2 : 0.f; d[3] = 0.f;
-        });
-        for_elems<NLO, 256>(tid, [&](int e) {
-            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-            int ly = row0 / 2 + pr - 2, lx = pc - 1;
-            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            float4 v = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
-            v = in ? v : f4zero();
-            float2* d = (float2*)(xo + (pr * LC + pc) * LPS + 4 * half);
-            d[0] = make_float2(v.x, v.y); d[1] = make_float2(v.z, v.w);
-        });
+        if (!MIF_PREFETCH || tile == (int)blockIdx.x) fetch(tile);
+        commit(tile);
         __syncthreads();
+        if (MIF_PREFETCH && tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's arithmetic
 
         // ---- masker.0 on the matrix cores into the h tile: 5 rows x 2 column parities per wave ----
         // h row j = par + 2*jj: image tile row of tap ky = j + ky;  o0 tile row of fold a = jj + a + 1 (see derivation in
@@ -495,7 +542,7 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
-template <int SRC>
+template <int SRC, bool O16>
 __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams P) {
     using G = MaskInferGeo;
     constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, LR = G::LR, LC = G::LC, HPS = G::HPS;
@@ -553,45 +600,88 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
 #pragma unroll
     for (int m = 0; m < 3; ++m) { int t = 4 * m + kq; t = t < 9 ? t : 8; toff[m] = ((t / 3) * IC + t % 3) * 4; }
 
-    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    __builtin_amdgcn_s_waitcnt(0);     // the preloads above land HERE: a first use inside the tile loop would wait with vmcnt(0) and drain the prefetch
+    // Staging: ALL of a tile's global loads are issued back to back into registers (fetch), then converted and written to LDS
+    // (commit) -- one memory round trip per tile instead of seven dependent load -> wait -> store rounds (the ISA of the
+    // element-wise loop this replaces).  With MIF_PREFETCH the next tile's fetch is issued before this tile's arithmetic.
+    constexpr int RI = (NIMG + 255) / 256, RO = (NLO + 255) / 256;
+    uint32_t ilo[RI], ihi[RI];
+    [[maybe_unused]] float if0[RI], if1[RI], if2[RI];
+    [[maybe_unused]] half4_t oh[RO];
+    [[maybe_unused]] float4 of[RO];
+    auto fetch = [&](int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-        for_elems<NIMG, 256>(tid, [&](int e) {
-            int r = e / IC, c = e % IC;
-            int y = row0 + r - 2, x = c - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            int pix = in ? (n0 * H + y) * W + x : 0;
-            float v0, v1, v2;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int e = tid + 256 * r;       // (no branch around the loads: elements past the tile read pixel 0 and are dropped in commit)
+            const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+            const bool in = e < NIMG && y >= 0 && y < H && x >= 0 && x < W;
+            const int pix = in ? (n0 * H + y) * W + x : 0;
             if constexpr (SRC == WSRC_U8) {
                 const uint32_t* s32 = (const uint32_t*)P.img;
-                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
-                uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
-                uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
-                const float sc = 1.f / 255.f;
-                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+                const int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                ilo[r] = s32[d]; ihi[r] = s32[d + 1 <= last ? d + 1 : last];
             } else {
                 const float* sf = (const float*)P.img;
-                v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
+                if0[r] = sf[pix * 3]; if1[r] = sf[pix * 3 + 1]; if2[r] = sf[pix * 3 + 2];
             }
-            half4_t hv;
-            hv[0] = (_Float16)(in ? v0 : 0.f); hv[1] = (_Float16)(in ? v1 : 0.f); hv[2] = (_Float16)(in ? v2 : 0.f); hv[3] = (_Float16)0.f;
-            *(half4_t*)(ximg + e * 4) = hv;
-        });
-        for_elems<NLO, 256>(tid, [&](int e) {
-            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-            int ly = row0 / 2 + pr - 2, lx = pc - 1;
-            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+        }
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const int e = tid + 256 * r;
+            const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+            const bool in = e < NLO && ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
             const int oi = in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0;
-            half4_t hv;
-            if (P.o0_f16) {            // (uniform branch)
-                hv = ((const half4_t*)P.o0)[oi];
-            } else {
-                const float4 v = ((const float4*)P.o0)[oi];
-                hv[0] = (_Float16)v.x; hv[1] = (_Float16)v.y; hv[2] = (_Float16)v.z; hv[3] = (_Float16)v.w;
+            if constexpr (O16) oh[r] = ((const half4_t*)P.o0)[oi];
+            else of[r] = ((const float4*)P.o0)[oi];
+        }
+    };
+    auto commit = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        (void)n0;
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int e = tid + 256 * r;
+            if (e < NIMG) {
+                const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+                const bool in = y >= 0 && y < H && x >= 0 && x < W;
+                float v0, v1, v2;
+                if constexpr (SRC == WSRC_U8) {
+                    const int pix = in ? (n0 * H + y) * W + x : 0;
+                    const uint64_t both = (((uint64_t)ihi[r] << 32) | ilo[r]) >> (((pix * 3) & 3) * 8);
+                    const float sc = 1.f / 255.f;
+                    v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+                } else {
+                    v0 = if0[r]; v1 = if1[r]; v2 = if2[r];
+                }
+                half4_t hv;
+                hv[0] = (_Float16)(in ? v0 : 0.f); hv[1] = (_Float16)(in ? v1 : 0.f); hv[2] = (_Float16)(in ? v2 : 0.f); hv[3] = (_Float16)0.f;
+                *(half4_t*)(ximg + e * 4) = hv;
             }
-            if (!in) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-            *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
-        });
+        }
+#pragma unroll
+        for (int r = 0; r < RO; ++r) {
+            const int e = tid + 256 * r;
+            if (e < NLO) {
+                const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+                const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+                const bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+                half4_t hv;
+                if constexpr (O16) hv = oh[r];
+                else { hv[0] = (_Float16)of[r].x; hv[1] = (_Float16)of[r].y; hv[2] = (_Float16)of[r].z; hv[3] = (_Float16)of[r].w; }
+                if (!in) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
+            }
+        }
+    };
+
+    for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        if (!MIF_PREFETCH || tile == (int)blockIdx.x) fetch(tile);
+        commit(tile);
         __syncthreads();
+        if (MIF_PREFETCH && tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's arithmetic
 
         const int ibase = (par * IC + 2 * (16 * hf + l15)) * 4;            // halves; + (2*jj*IC + px)*4 + toff[m]
         const int obase = (16 * hf + l15) * 8 + 4 * kq;                    // halves; + ((jj + a + 1)*LC + px)*8
@@ -645,10 +735,11 @@ int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0,
     if (n <= 0) return CGS_OK;
     MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr, o0_f16};
     int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
-    if (img_kind == CGS_SRC_U8)
-        hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_U8>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
-    else
-        hipLaunchKernelGGL(mask_infer_f16_kernel<WSRC_F32>, dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    const bool u8 = img_kind == CGS_SRC_U8;
+    if (u8 && o0_f16) hipLaunchKernelGGL((mask_infer_f16_kernel<WSRC_U8, true>), dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    else if (u8) hipLaunchKernelGGL((mask_infer_f16_kernel<WSRC_U8, false>), dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    else if (o0_f16) hipLaunchKernelGGL((mask_infer_f16_kernel<WSRC_F32, true>), dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
+    else hipLaunchKernelGGL((mask_infer_f16_kernel<WSRC_F32, false>), dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
