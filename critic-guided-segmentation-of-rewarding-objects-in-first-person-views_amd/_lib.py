@@ -127,10 +127,12 @@ SIGNATURES = {
     "cgs_nchw_to_nhwc": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_packed_floats": (i64, [i32, i32, i32]),
+    "cgs_gen_conv_packed_floats_folded": (i64, [i32, i32, i32]),
     "cgs_gen_conv_pack_weights": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_pack_weights_window": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_pack_batch": (i32, [vp, i32, vp]),
     "cgs_gen_conv3x3_fwd": (i32, [i32, i32, i32, i32, i32, i32, i32, i32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_gen_conv3x3_fwd_folded": (i32, [i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_gemm": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp]),
     "cgs_gen_flip_weights": (i32, [i32, i32, vp, vp, vp]),
     "cgs_gen_conv3x3_bwd_data": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),

@@ -154,22 +154,30 @@ struct Gen4Launch {
     int n_addend, n, hw, co, act, pool;
     float slope;
     float* out2; int split_ca, split_ups;
+    int fold;
 };
 int gen4_conv_launch(const Gen4Launch& L, hipStream_t st);
-long gen4_packed_floats(int ca, int cb, int co);
+long gen4_packed_floats(int ca, int cb, int co, int fold);
 int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st);
 struct Gen4PackJob { const float* w; float* wp; int ca, cb, co, transposed, ci_layer, ci_off; };
 int gen4_pack_batch_launch(const Gen4PackJob* jobs, int njobs, hipStream_t st);
 
 extern "C" int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co) {
     if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
-    return gen4_packed_floats(ca, cb, co);
+    return gen4_packed_floats(ca, cb, co, 0);
+}
+
+// the FOLDED forward operand of a layer over cat(A, nearest-up_2(B)) (cgs_gen_conv_pack_weights with transposed = 2, cgs_gen_conv3x3_fwd_folded)
+extern "C" int64_t cgs_gen_conv_packed_floats_folded(int32_t ca, int32_t cb, int32_t co) {
+    if (ca <= 0 || cb <= 0 || co <= 0 || (cb & 3)) return CGS_ERR_BADARG;
+    return gen4_packed_floats(ca, cb, co, 1);
 }
 
 extern "C" int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
                                          cgs_stream_t stream) {
-    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !wp || (transposed && cb)) return CGS_ERR_BADARG;
-    return gen4_pack_launch(ca, cb, co, transposed ? 1 : 0, w, wp, co, 0, (hipStream_t)stream);
+    if (ca <= 0 || cb < 0 || co <= 0 || (cb & 3) || !w || !wp || transposed < 0 || transposed > 2) return CGS_ERR_BADARG;
+    if ((transposed == 1 && cb) || (transposed == 2 && !cb)) return CGS_ERR_BADARG;
+    return gen4_pack_launch(ca, cb, co, transposed, w, wp, co, 0, (hipStream_t)stream);
 }
 
 // The data gradient's operand for a WINDOW of the layer's input channels: w = HWIO [9][ci_layer][co_layer]; the packed operand maps dY
@@ -192,10 +200,11 @@ extern "C" int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njo
         const int nb = njobs - j0 < 64 ? njobs - j0 : 64;
         for (int j = 0; j < nb; ++j) {
             const cgs_gen_pack_job& J = jobs[j0 + j];
-            if (!J.w || !J.wp || J.ca <= 0 || J.cb < 0 || J.co <= 0 || (J.cb & 3) || (J.transposed && J.cb)) return CGS_ERR_BADARG;
-            if (J.ci_layer > 0 && (!J.transposed || J.ci_off < 0 || J.ci_off + J.co > J.ci_layer)) return CGS_ERR_BADARG;
+            if (!J.w || !J.wp || J.ca <= 0 || J.cb < 0 || J.co <= 0 || (J.cb & 3) || J.transposed < 0 || J.transposed > 2) return CGS_ERR_BADARG;
+            if ((J.transposed == 1 && J.cb) || (J.transposed == 2 && !J.cb)) return CGS_ERR_BADARG;
+            if (J.ci_layer > 0 && (J.transposed != 1 || J.ci_off < 0 || J.ci_off + J.co > J.ci_layer)) return CGS_ERR_BADARG;
             // (a whole-layer operand: the forward form reads w as [9][ca + cb][co]; the transposed one as [9][co][ca])
-            tmp[j] = Gen4PackJob{J.w, J.wp, J.ca, J.cb, J.co, J.transposed ? 1 : 0, J.ci_layer > 0 ? J.ci_layer : J.co, J.ci_layer > 0 ? J.ci_off : 0};
+            tmp[j] = Gen4PackJob{J.w, J.wp, J.ca, J.cb, J.co, J.transposed, J.ci_layer > 0 ? J.ci_layer : J.co, J.ci_layer > 0 ? J.ci_off : 0};
         }
         const int rc = gen4_pack_batch_launch(tmp, nb, (hipStream_t)stream);
         if (rc != CGS_OK) return rc;
@@ -203,17 +212,29 @@ extern "C" int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njo
     return CGS_OK;
 }
 
-extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
-                                   int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
-                                   const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
+static int gen_conv3x3_fwd(int fold, int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                           int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
+                           const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
     if (n < 0 || !src_a || !wp || !bias || !out || ca <= 0 || cb < 0 || co <= 0) return CGS_ERR_BADARG;
     if (cb > 0 && (!src_b || (cb & 3) || (ups != 1 && ups != 2 && ups != 4))) return CGS_ERR_BADARG;
     if (!gen_hw_ok(hw)) return CGS_ERR_UNSUPPORTED;
     if (act < CGS_ACT_NONE || act > CGS_ACT_SIGMOID) return CGS_ERR_BADARG;
+    if (fold && (cb <= 0 || ups != 2 || hw < 16 || pool)) return CGS_ERR_UNSUPPORTED;
     if (n == 0) return CGS_OK;
     Gen4Launch L{GenSrc{src_a, src_b, nullptr, a_is_u8 ? GEN_SRC_U8 : GEN_SRC_F32, ca, cb, cb > 0 ? ups : 1}, wp, bias, out, argmax,
-                 nullptr, 0, n, hw, co, act, pool, slope, nullptr, 0, 0};
+                 nullptr, 0, n, hw, co, act, pool, slope, nullptr, 0, 0, fold};
     return gen4_conv_launch(L, (hipStream_t)stream);
+}
+extern "C" int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
+                                   int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
+                                   const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream) {
+    return gen_conv3x3_fwd(0, n, hw, ca, cb, co, a_is_u8, ups, act, slope, pool, src_a, src_b, wp, bias, out, argmax, stream);
+}
+// the same layer with the FOLDED operand (cgs_gen_conv_pack_weights, transposed = 2): cb > 0, ups = 2, hw >= 16, pool = 0
+extern "C" int cgs_gen_conv3x3_fwd_folded(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t act,
+                                          float slope, const void* src_a, const float* src_b, const float* wp, const float* bias,
+                                          float* out, cgs_stream_t stream) {
+    return gen_conv3x3_fwd(1, n, hw, ca, cb, co, a_is_u8, 2, act, slope, 0, src_a, src_b, wp, bias, out, nullptr, stream);
 }
 
 // Data gradient of a 3x3 layer = the same convolution over the output gradient with the flipped, transposed kernel:

@@ -47,17 +47,39 @@ unsigned long long* g_gen4_stamps = nullptr;
 // gradient this is (ca = its output channels = dY's), read with the taps reversed; the operand covers the layer's input channels
 // [ci_off, ci_off + co) (the whole layer: ci_off = 0, co = ci_layer).
 struct Gen4PackParams { const float* w; float* wp; int ca, cb, co, transposed, total, ngp, ci_layer, ci_off; };
-__global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
+// transposed = 2: FOLDED forward operand of a layer over cat(A, nearest-up_2(B)) (gen4_conv3x3_kernel<NG, true>).  A pixel of row / column
+// parity (py, px) sees B only through the 2 x 2 neighbourhood (a, b) of its low-resolution cell: the 3 x 3 taps over the upsampled map
+// collapse to   Wf[py][px][a][b] = sum_{ky in K(py,a)} sum_{kx in K(px,b)} w[ky][kx],   K(0,0) = {0}, K(0,1) = {1,2}, K(1,0) = {0,1}, K(1,1) = {2}
+// (a whole folded tap is inside the map or outside it, like the taps it sums: the zero padding commutes with the fold) -- 4 instead of
+// 9 tap steps for every B channel.  Layout: A's chunks first, 9 slots each; then B's chunks, 16 slots each (slot = 4 * (2 py + px) + 2 a + b).
+__device__ __forceinline__ float gen4_pack_elem(const Gen4PackParams& P, int e) {
     const int pa4 = (P.ca + 3) & ~3, ngt = P.ngp, ci_total = P.ca + P.cb;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) {
-        const int lane = e & 63, r = e >> 6, g = r % ngt, tap = (r / ngt) % 9, ch = r / (ngt * 9);
-        const int k = ch * GEN_KC + (lane >> 2), col = 4 * g + (lane & 3);
-        const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
+    const int lane = e & 63, r = e >> 6, g = r % ngt, slot = r / ngt, cin = lane >> 2, col = 4 * g + (lane & 3);
+    if (P.transposed == 2) {
+        const int ncha = (pa4 + GEN_KC - 1) / GEN_KC;
+        if (col >= P.co) return 0.f;
+        if (slot < 9 * ncha) {
+            const int tap = slot % 9, k = (slot / 9) * GEN_KC + cin;
+            return k < P.ca ? P.w[((size_t)tap * ci_total + k) * P.co + col] : 0.f;
+        }
+        const int idx = slot - 9 * ncha, kb = (idx >> 4) * GEN_KC + cin, py = (idx >> 3) & 1, px = (idx >> 2) & 1, a = (idx >> 1) & 1, b = idx & 1;
+        if (kb >= P.cb) return 0.f;
+        const int ky0 = py ? (a ? 2 : 0) : (a ? 1 : 0), ky1 = py ? (a ? 2 : 1) : (a ? 2 : 0);
+        const int kx0 = px ? (b ? 2 : 0) : (b ? 1 : 0), kx1 = px ? (b ? 2 : 1) : (b ? 2 : 0);
         float v = 0.f;
-        if (real >= 0 && col < P.co)
-            v = P.transposed ? P.w[((size_t)(8 - tap) * P.ci_layer + P.ci_off + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
-        P.wp[e] = v;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) v += P.w[((size_t)(ky * 3 + kx) * ci_total + P.ca + kb) * P.co + col];
+        return v;
     }
+    const int tap = slot % 9, k = (slot / 9) * GEN_KC + cin;
+    const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
+    float v = 0.f;
+    if (real >= 0 && col < P.co)
+        v = P.transposed ? P.w[((size_t)(8 - tap) * P.ci_layer + P.ci_off + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
+    return v;
+}
+__global__ void __launch_bounds__(256) gen4_pack_kernel(Gen4PackParams P) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) P.wp[e] = gen4_pack_elem(P, e);
 }
 
 // every layer's operand of one training step in ONE launch (25 launches of ~4.7 us each otherwise): blockIdx.y = job
@@ -65,19 +87,14 @@ constexpr int G4_PACK_BATCH = 32;
 struct Gen4PackBatch { Gen4PackParams job[G4_PACK_BATCH]; };
 __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
     const Gen4PackParams& P = B.job[blockIdx.y];
-    const int pa4 = (P.ca + 3) & ~3, ngt = P.ngp, ci_total = P.ca + P.cb;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) {
-        const int lane = e & 63, r = e >> 6, g = r % ngt, tap = (r / ngt) % 9, ch = r / (ngt * 9);
-        const int k = ch * GEN_KC + (lane >> 2), col = 4 * g + (lane & 3);
-        const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
-        float v = 0.f;
-        if (real >= 0 && col < P.co)
-            v = P.transposed ? P.w[((size_t)(8 - tap) * P.ci_layer + P.ci_off + col) * P.ca + real] : P.w[((size_t)tap * ci_total + real) * P.co + col];
-        P.wp[e] = v;
-    }
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) P.wp[e] = gen4_pack_elem(P, e);
 }
 
-template <int NG>
+// FOLD (a layer over cat(A, nearest-up_2(B)), no pooling, no split): A's channels run as usual; B's are staged at B's OWN resolution (a
+// quarter of the elements, no upsampling in the loader) and multiplied through the folded taps (gen4_pack_elem): 4 instead of 9 tap steps per
+// channel.  The folded weights depend on the pixel's parity, the A operand of the instruction is one register for the whole wave: wave w
+// takes position w of every 2 x 2 cell of the tile (lane = cell), not 64 consecutive pixels.
+template <int NG, bool FOLD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -90,10 +107,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     const int pstride = P.rows * P.pw;
     float4* tile = g4sm;
     const G4Geo geo{P.n, P.hw, P.lw, P.imgs, P.th};
+    const int pa4 = gen_pa4(S), cp = FOLD ? pa4 : pa4 + S.cb;                              // channels of the full-resolution chunks
+    const int ncha = (cp + GEN_KC - 1) / GEN_KC, nchb = FOLD ? (S.cb + GEN_KC - 1) / GEN_KC : 0, nchunk = ncha + nchb;
+    // FOLD: B's tile = (th / 2 + 2) x (W / 2 + 2) low-resolution pixels per image part, in the same buffers (A's chunks are done by then)
+    const int pwb = (P.hw >> 1) + 2, rowsb = P.imgs * ((P.th >> 1) + 2), pstrideb = rowsb * pwb;
+    const G4Geo geob{P.n, P.hw >> 1, P.lw - 1, P.imgs, P.th >> 1};
     auto stage = [&](float4* dst, int ch, int ltid) {      // channel-planar tile: dst[(plane * rows + row) * pw + col], col 0 = left halo
-        gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+        if constexpr (FOLD) {
+            if (ch < ncha) {
+                const GenSrc SA{S.a, nullptr, nullptr, S.mode, S.ca, 0, 1};
+                gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, SA, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+            } else {
+                const GenSrc SB{S.b, nullptr, nullptr, GEN_SRC_F32, S.cb, 0, 1};
+                gen4_stage<GEN_K_F32V4, false>(G4Dst{dst, pstrideb, pwb, 1, 1}, SB, geob, 1, img0, row0 >> 1, (ch - ncha) * GEN_KC, 4, ltid);
+                // the halo columns of THIS layout (the buffer held full-resolution chunks before)
+                for (int e = ltid; e < 4 * rowsb * 2; e += 256) dst[(e >> 1) * pwb + ((e & 1) ? pwb - 1 : 0)] = f4zero();
+            }
+        } else {
+            gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+        }
     };
-    const int pa4 = gen_pa4(S), cp = pa4 + S.cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
     const int g0 = pass * NG;
 
     // this wave's weight registers: register image (chunk, tap, group g0 + g) = 64 consecutive floats; the packed buffer holds
@@ -110,11 +143,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     G4_STAMP(0);
 
     // this lane's pixel
-    const int p = wave * 64 + lane, q = p >> 2, pos = p & 3;
+    const int p = FOLD ? 4 * lane + wave : wave * 64 + lane, q = p >> 2, pos = p & 3;
     const int lqi = (lw - 1) + (P.th == 4 ? 1 : (P.th == 8 ? 2 : 3));        // log2(quads per image part) = log2((th / 2) * (hw / 2))
     const int il = q >> lqi, qi = q & ((1 << lqi) - 1), qy = qi >> (lw - 1), qx = qi & ((W >> 1) - 1);
     const int y = 2 * qy + (pos >> 1), x = 2 * qx + (pos & 1);
     const int base = (il * (P.th + 2) + y + 1) * P.pw + x + 1;
+    // FOLD: low-resolution tile slot of fold (a, b) = baseb + a * pwb + b  (tile row (y >> 1) + a + py, column (x >> 1) + b + px)
+    const int baseb = (il * ((P.th >> 1) + 2) + (y >> 1) + (pos >> 1)) * pwb + (x >> 1) + (pos & 1);
+    // first weight slot of chunk c (FOLD: a B chunk starts at this wave's parity)
+    auto ctfirst = [&](int c) { return (!FOLD || c < ncha) ? c * 9 : ncha * 9 + (c - ncha) * 16 + 4 * pos; };
 
     // zero halo columns (col 0 and col W + 1) of all four planes (of both buffers), once
     const int nbuf = P.dbuf ? 2 : 1;
@@ -149,10 +186,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
             __syncthreads();
         }
         if (ch < 3) G4_STAMP(3 + 5 * ch);
-        const int rem = cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
-        int lbase = base;
+        const bool bch = FOLD && ch >= ncha;
+        const int rem = bch ? S.cb - (ch - ncha) * GEN_KC : cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
+        int lbase = bch ? baseb : base;
         asm volatile("" : "+v"(lbase));
-        const int ct0 = ch * 9;
+        const int ct0 = ctfirst(ch);
         // The tap loop per plane count NP (compile-time: straight-line matrix code -- with the plane / channel tests as run-time
         // branches inside the loop the compiler copies all accumulators at every merge).  Padding channels (A's tail when ca is not
         // a multiple of 4) multiply zeros by zero weights.
@@ -178,29 +216,52 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
                 });
             };
             float4 xr[NP];
+            if (!bch) {
 #pragma unroll 1
-            for (int tap = 0; tap < 8; tap += 2) {
-                wload(w1, ct0 + tap + 1);
-                readx(xr, tap);
+                for (int tap = 0; tap < 8; tap += 2) {
+                    wload(w1, ct0 + tap + 1);
+                    readx(xr, tap);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(w0, xr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wload(w0, ct0 + tap + 2);
+                    readx(xr, tap + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(w1, xr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ch + 1 < nchunk) wload(w1, ctfirst(ch + 1));    // the next chunk's first slot (moved to w0 below, behind the staging)
+                readx(xr, 8);
                 __builtin_amdgcn_sched_barrier(0);
                 mac(w0, xr);
-                __builtin_amdgcn_sched_barrier(0);
-                wload(w0, ct0 + tap + 2);
-                readx(xr, tap + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mac(w1, xr);
-                __builtin_amdgcn_sched_barrier(0);
+            } else if constexpr (FOLD) {
+                // the four folds (a, b) of this wave's parity: slots ct0 .. ct0 + 3; the next chunk's first slot lands in w0 behind the last
+                auto readb = [&](float4 (&xr)[NP], int ab) {
+                    const int a0 = lbase + (ab >> 1) * pwb + (ab & 1);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * pstrideb + a0];
+                };
+#pragma unroll 1
+                for (int ab = 0; ab < 4; ab += 2) {
+                    wload(w1, ct0 + ab + 1);
+                    readb(xr, ab);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(w0, xr);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ab == 0) wload(w0, ct0 + 2);
+                    else if (ch + 1 < nchunk) wload(w0, ctfirst(ch + 1));
+                    readb(xr, ab + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mac(w1, xr);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            if (ch + 1 < nchunk) wload(w1, ct0 + 9);            // the next chunk's tap 0 (moved to w0 below, behind the staging)
-            readx(xr, 8);
-            __builtin_amdgcn_sched_barrier(0);
-            mac(w0, xr);
         };
         if (np == 4) taps(std::integral_constant<int, 4>{});
         else if (np == 3) taps(std::integral_constant<int, 3>{});
         else if (np == 2) taps(std::integral_constant<int, 2>{});
         else taps(std::integral_constant<int, 1>{});
-        if (ch + 1 < nchunk) {
+        if (!bch && ch + 1 < nchunk) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) w0[g] = w1[g];
         }
@@ -392,6 +453,7 @@ struct Gen4Launch {
     int n_addend, n, hw, co, act, pool;
     float slope;
     float* out2; int split_ca, split_ups;      // (optional: data gradient of a cat layer written as d_a / cell-summed d_b)
+    int fold;                                  // wp is the FOLDED operand (cgs_gen_conv_pack_weights, transposed = 2): cb > 0, ups = 2, hw >= 16, no pooling / split
 };
 
 // output-channel groups of 4: passes (workgroups over the same tile) x groups per pass (the kernel's NG)
@@ -402,15 +464,17 @@ static void gen4_groups(int co, int& npass, int& ng) {
     ng = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 6 ? 6 : per <= 8 ? 8 : 10;
 }
 
-long gen4_packed_floats(int ca, int cb, int co) {
+long gen4_packed_floats(int ca, int cb, int co, int fold) {
     int npass, ng;
     gen4_groups(co, npass, ng);
-    const int cp = ((ca + 3) & ~3) + cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
+    const int pa4 = (ca + 3) & ~3;
+    if (fold) return (long)(((pa4 + GEN_KC - 1) / GEN_KC) * 9 + ((cb + GEN_KC - 1) / GEN_KC) * 16) * npass * ng * 64;
+    const int cp = pa4 + cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
     return (long)nchunk * 9 * npass * ng * 64;
 }
 
 int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st) {
-    const long total = gen4_packed_floats(ca, cb, co);
+    const long total = gen4_packed_floats(ca, cb, co, transposed == 2);
     int npass, ng;
     gen4_groups(co, npass, ng);
     Gen4PackParams P{w, wp, ca, cb, co, transposed, (int)total, npass * ng, ci_layer, ci_off};
@@ -430,7 +494,7 @@ int gen4_pack_batch_launch(const Gen4PackJob* jobs, int njobs, hipStream_t st) {
             const Gen4PackJob& J = jobs[j0 + j];
             int npass, ng;
             gen4_groups(J.co, npass, ng);
-            const long total = gen4_packed_floats(J.ca, J.cb, J.co);
+            const long total = gen4_packed_floats(J.ca, J.cb, J.co, J.transposed == 2);
             B.job[j] = Gen4PackParams{J.w, J.wp, J.ca, J.cb, J.co, J.transposed, (int)total, npass * ng, J.ci_layer, J.ci_off};
             most = total > most ? total : most;
         }
@@ -485,12 +549,28 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
     const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
     const size_t budget = (size_t)(160 * 1024) / (ng > 8 ? 3 : 4) - 512;
-    P.dbuf = (cp > GEN_KC && 2 * tile_bytes <= budget) ? 1 : 0;
+    P.dbuf = ((cp > GEN_KC || L.fold) && 2 * tile_bytes <= budget) ? 1 : 0;
     size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
     const size_t epi = (size_t)256 * (4 * ng + 4) * sizeof(float);
     lds = lds > epi ? lds : epi;
     const dim3 grid(tiles * P.npass);
-#define G4_LAUNCH(NG_) hipLaunchKernelGGL(gen4_conv3x3_kernel<NG_>, grid, dim3(256), lds, st, P)
+    if (L.fold) {
+        // (the operand was packed for the layer's own pass split: gen4_groups(co) -- the few-tiles re-split above reads the same buffer)
+        if (L.src.cb <= 0 || L.src.ups != 2 || hw < 16 || L.pool || L.out2 || L.src.mode == GEN_SRC_POOLEXP) return CGS_ERR_UNSUPPORTED;
+#define G4_LAUNCH_F(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, true>), grid, dim3(256), lds, st, P)
+        switch (ng) {
+            case 1: G4_LAUNCH_F(1); break;
+            case 2: G4_LAUNCH_F(2); break;
+            case 4: G4_LAUNCH_F(4); break;
+            case 6: G4_LAUNCH_F(6); break;
+            case 8: G4_LAUNCH_F(8); break;
+            default: G4_LAUNCH_F(10); break;
+        }
+#undef G4_LAUNCH_F
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
+#define G4_LAUNCH(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, false>), grid, dim3(256), lds, st, P)
     switch (ng) {
         case 1: G4_LAUNCH(1); break;
         case 2: G4_LAUNCH(2); break;

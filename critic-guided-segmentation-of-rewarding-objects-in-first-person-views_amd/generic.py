@@ -15,6 +15,7 @@ import torch
 from . import _lib
 from .spec import Layout
 
+UPS_FOLD = True             # forward of a layer over cat(A, nearest-up_2(B)) at hw >= 16: B staged at its own resolution, its 9 taps folded to 4 per pixel parity (gen4.hip, FOLD)
 ENC0_DEDICATED = True       # features.0 (3 -> 8 chfak channels at 64x64) of chfak 2 .. 5 on csrc/gen_enc0.hip (False: the shape-generic gen4 kernel)
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 
@@ -92,7 +93,7 @@ def _pack(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool, ci_layer
         wp = plan.jobs.get(key)
         if wp is not None:
             return wp                                   # packed by the plan's launch at the start of this step
-    nfl = int(_lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
+    nfl = int(_lib.load().cgs_gen_conv_packed_floats_folded(ca, cb, co) if int(transposed) == 2 else _lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
     if nfl <= 0:
         raise _lib.CgsError(f"generic conv: no packed form for ca={ca} cb={cb} co={co}")
     if plan is not None and not plan.frozen:
@@ -111,13 +112,13 @@ def _pack(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool, ci_layer
     return wp
 
 
-def pack_weights(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool = False) -> torch.Tensor:
+def pack_weights(w_ptr: int, ca: int, cb: int, co: int, dev, transposed=False) -> torch.Tensor:
     """HWIO 3x3 weights at w_ptr -> the convolution kernel's operand form (cgs_gen_conv_pack_weights).  transposed: w_ptr is the
     [9][co][ca] weight of the layer whose DATA GRADIENT is wanted (ca = its output channels, co = its input channels).  One scratch
     tensor per (device, shape): the pack and the convolution that reads it are consecutive launches of one stream -- or, inside a
     pack_plan, the plan's buffer for this layer."""
     di = dev.index if dev.index is not None else torch.cuda.current_device()
-    return _pack(w_ptr, ca, cb, co, dev, transposed, 0, 0, (di, ca, cb, co))
+    return _pack(w_ptr, ca, cb, co, dev, transposed, 0, 0, (di, ca, cb, co, int(transposed) == 2))
 
 
 def pack_weights_window(w_ptr: int, co_layer: int, ci_layer: int, ci_off: int, ci_n: int, dev) -> torch.Tensor:
@@ -143,6 +144,11 @@ def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: in
     if ENC0_DEDICATED and hw == 64 and ca == 3 and cb == 0 and pool and act == "relu" and co in (16, 24, 32, 40):
         # features.0 at chfak 2 .. 5: the kernel of its own (csrc/gen_enc0.hip: lane = pool cell, all weights in registers)
         _lib.call("cgs_gen_enc0_fwd", n, co, int(a.dtype == torch.uint8), _p(a), C.c_void_p(w_ptr), C.c_void_p(bias_ptr), _p(out), _p(am), _s())
+        return (out, am) if want_argmax else out
+    if UPS_FOLD and cb > 0 and ups == 2 and hw >= 16 and not pool:
+        wp = pack_weights(w_ptr, ca, cb, co, a.device, transposed=2)      # (2 = the folded forward operand)
+        _lib.call("cgs_gen_conv3x3_fwd_folded", n, hw, ca, cb, co, int(a.dtype == torch.uint8), _ACT[act], float(slope), _p(a), _p(b), _p(wp),
+                  C.c_void_p(bias_ptr), _p(out), _s())
         return (out, am) if want_argmax else out
     wp = pack_weights(w_ptr, ca, cb, co, a.device)
     _lib.call("cgs_gen_conv3x3_fwd", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _ACT[act], float(slope), int(pool), _p(a),

@@ -473,10 +473,14 @@ int cgs_dropout_mask(cgs_dropout d, int64_t count, float* out, cgs_stream_t stre
  *   its input channels): wp is then the operand of cgs_gen_conv3x3_bwd_data (taps reversed, channels transposed).
  * cgs_gen_conv3x3_fwd: out = act(conv3x3(cat(A [ca], nearest-up_ups(B [cb])), wp) + bias), hw in {4,8,16,32,64}; pool = 1:
  *   MaxPool2d(2) of it, out [n,hw/2,hw/2,co] and argmax [same] = position 0..3 of the first maximum in bits 0-1 (may be NULL).
+ *   transposed = 2 + cgs_gen_conv3x3_fwd_folded: the same layer over cat(A, nearest-up_2(B)) (cb > 0, hw >= 16, no pooling) with B read at
+ *   its own resolution: a pixel of parity (py, px) sees B through the 2 x 2 cells around it, its nine taps over the upsampled map sum to four
+ *   (weights added per parity by the pack, cgs_gen_conv_packed_floats_folded floats) -- 4 / 9 of the matrix work for B's channels.
  * cgs_gen_gemm: out [m,n] = act(x [m,k] w [k,n] + bias [n] (may be NULL)).
  * cgs_gen_convt4s2_*: ConvTranspose2d(4,2,1) over cat(A, B) [n,h,h,*] -> [n,2h,2h,co]: forward (+bias, act), data gradient
  *   (dy = gradient at the PRE-activation output; da / db may be NULL), weight + bias gradient (dw [16*(ca+cb)*co], dbias [co]). */
 int64_t cgs_gen_conv_packed_floats(int32_t ca, int32_t cb, int32_t co);
+int64_t cgs_gen_conv_packed_floats_folded(int32_t ca, int32_t cb, int32_t co);
 int cgs_gen_conv_pack_weights(int32_t ca, int32_t cb, int32_t co, int32_t transposed, const float* w, float* wp,
                               cgs_stream_t stream);
 /* The data gradient's operand for a window of the layer's input channels: w = HWIO [9][ci_layer][co_layer]; wp
@@ -495,6 +499,8 @@ int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njobs, cgs_str
 int cgs_gen_conv3x3_fwd(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                         int32_t act, float slope, int32_t pool, const void* src_a, const float* src_b, const float* wp,
                         const float* bias, float* out, uint8_t* argmax, cgs_stream_t stream);
+int cgs_gen_conv3x3_fwd_folded(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t act, float slope,
+                               const void* src_a, const float* src_b, const float* wp, const float* bias, float* out, cgs_stream_t stream);
 /* features.0 of NewCritic at chfak 2 / 3 / 4 / 5 (co = 16 / 24 / 32 / 40; nets.py:170-172) on kernels of their own (csrc/gen_enc0.hip): same
  * tensors as cgs_gen_conv3x3_fwd(hw 64, ca 3, ReLU, pool) -- out [n,32,32,co] + argmax bytes (am may be NULL) -- from x = uint8 (x_is_u8) or
  * fp32 frames [n,64,64,3] and the layer's HWIO weights [9][3][co] (not packed).  CGS_ERR_UNSUPPORTED for other channel counts.          */

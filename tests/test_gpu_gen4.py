@@ -76,6 +76,40 @@ def test_gen4_forward_matches_float64_conv2d(n, hw, ca, cb, ups, co, act, pool, 
     rel_close(out.cpu().numpy(), ref.numpy(), "forward")
 
 
+@pytest.mark.parametrize("n,hw,ca,cb,co,act,u8", [
+    (3, 32, 40, 40, 40, "lrelu", False),    # dec_model.0 at chfak 5: A = 16 + 16 + 8 channels, B = 16 + 16 + 8, ten groups
+    (2, 64, 3, 40, 16, "lrelu", True),      # masker.0: uint8 frames + 40 decoder channels
+    (2, 64, 3, 24, 16, "none", False),      # fp32 frames (odd width), B = 16 + 8
+    (5, 16, 80, 80, 40, "none", False),     # one image per tile, low-resolution tile 8 x 8
+    (2, 16, 8, 4, 43, "relu", False),       # one-plane B chunk; 11 groups: two passes, scalar copy-out
+    (1, 32, 16, 16, 24, "sigmoid", False),  # six groups
+])
+def test_gen4_folded_upsample_forward(n, hw, ca, cb, co, act, u8):
+    """A layer over cat(A, nearest-up_2(B)) with B staged at its own resolution and its nine taps folded to four per pixel parity
+    (cgs_gen_conv3x3_fwd_folded; nets.py:480-489 decoder layers) == float64 conv2d over the explicit upsampled cat, and == the unfolded
+    kernel up to the rounding of the folded weight sums."""
+    from cgs_amd import generic as gen
+    rs = np.random.RandomState(hw * 100 + ca + cb + co)
+    dev = torch.device("cuda:0")
+    a = torch.from_numpy(rs.randint(0, 256, (n, hw, hw, ca)).astype(np.uint8)) if u8 else torch.from_numpy(rs.randn(n, hw, hw, ca).astype(np.float32))
+    b = torch.from_numpy(rs.randn(n, hw // 2, hw // 2, cb).astype(np.float32))
+    w = torch.from_numpy((rs.randn(9, ca + cb, co) / (3.0 * np.sqrt(ca + cb))).astype(np.float32))
+    bias = torch.from_numpy((0.1 * rs.randn(co)).astype(np.float32))
+    ref, _ = _ref_conv(a, b, 2, w, bias, act, 0.2, False)
+    wd, bd = w.to(dev), bias.to(dev)
+    outs = {}
+    saved = gen.UPS_FOLD
+    try:
+        for fold in (True, False):
+            gen.UPS_FOLD = fold
+            outs[fold] = gen.conv3x3(a.to(dev), b.to(dev), wd.data_ptr(), bd.data_ptr(), co, act=act, slope=0.2, ups=2).cpu().numpy()
+    finally:
+        gen.UPS_FOLD = saved
+    rel_close(outs[True], ref.numpy(), "folded forward")
+    rel_close(outs[False], ref.numpy(), "forward")
+    assert np.abs(outs[True] - outs[False]).max() <= 2e-5 * max(1.0, np.abs(ref.numpy()).max())
+
+
 @pytest.mark.parametrize("n,hw,ci,co,pooled", [
     (3, 64, 3, 40, True),       # the image layer's data gradient: 3 output channels (one group, scalar copy-out), pooled gradient source
     (5, 32, 40, 40, True),
