@@ -138,6 +138,8 @@ SIGNATURES = {
     "cgs_gen_conv3x3_bwd_data": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "cgs_gen_conv3x3_bwd_data_split": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_conv3x3_bwd_weight_slabs": (i32, [i32, i32, i32, i32]),
+    "cgs_gen_conv3x3_bwd_weight_folded_slabs": (i32, [i32, i32, i32, i32, i32]),
+    "cgs_gen_conv3x3_bwd_weight_folded": (i32, [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_gen_conv3x3_bwd_weight": (i32, [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_gen_cat_split": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "cgs_gen_grad_fix": (i32, [i64, vp, vp, i32, f32, vp, i64, Dropout, vp]),

@@ -143,6 +143,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) g
 }
 
 #include "gen_wgrad_rows.h"
+#include "gen_wgrad_fold.h"
 
 __global__ void __launch_bounds__(256) gen_flip_weights_kernel(const float* __restrict__ w, int ci, int co, float* __restrict__ out) {
     const int total = 9 * ci * co;
@@ -362,8 +363,9 @@ static int launch_wgrad_rows_r(int rbw, const GenWrParams& P, size_t lds, int gr
     return launch_wgrad_rows<NCOB, 7, POOLED>(P, lds, grid, st);
 }
 static int wgrad_rows(const GenWrPlan& wr, int n, int hw, int ca, int cb, int co, int a_is_u8, int ups, const void* a, const float* b,
-                      const float* dy, const uint8_t* am, float* slab, hipStream_t st) {
+                      const float* dy, const uint8_t* am, float* slab, hipStream_t st, int ci_stride = 0) {
     GenWrParams P{};
+    P.ci_stride = ci_stride;
     P.a = a; P.b = b; P.dy = dy; P.am = am; P.slab = slab;
     P.n = n; P.hw = hw; P.lw = __builtin_ctz(hw); P.ca = ca; P.cb = cb; P.ush = ups == 4 ? 2 : (ups == 2 ? 1 : 0); P.co = co;
     P.a_u8 = a_is_u8; P.nrg = wr.nrg;
@@ -431,6 +433,67 @@ extern "C" int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int
     hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+// ---- a layer over cat(A, nearest-up_2(B)): A's rows + the bias row by the row-block kernel (slab strides of the whole layer), B's rows
+//      by gen_wgrad_fold_kernel on B at its own resolution; both write the same G slab rows ----
+static bool wgrad_fold_ok(int hw, int ca, int cb, int co) {
+    return (hw == 16 || hw == 32 || hw == 64) && ca > 0 && (cb == 16 || cb == 24 || cb == 32 || cb == 40) && co > 0 && !(co & 3);
+}
+extern "C" int cgs_gen_conv3x3_bwd_weight_folded_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co) {
+    if (n < 0 || !wgrad_fold_ok(hw, ca, cb, co)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return 0;
+    const GenWrPlan wr = gen_wr_plan(n, ca, 0, co);
+    return wr.ok ? wr.G : CGS_ERR_UNSUPPORTED;
+}
+template <int RB>
+static int launch_wgrad_fold(int ncob, const GenWfParams& P, size_t lds, int grid, hipStream_t st) {
+    static hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_fold_kernel<RB, 1>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_fold_kernel<RB, 3>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr1 != hipSuccess) return (int)attr1;
+    if (attr3 != hipSuccess) return (int)attr3;
+    if (ncob == 1) hipLaunchKernelGGL((gen_wgrad_fold_kernel<RB, 1>), dim3(grid), dim3(512), lds, st, P);
+    else hipLaunchKernelGGL((gen_wgrad_fold_kernel<RB, 3>), dim3(grid), dim3(512), lds, st, P);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+extern "C" int cgs_gen_conv3x3_bwd_weight_folded(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8,
+                                                 const void* src_a, const float* src_b, const float* dy, float* slab, cgs_stream_t stream) {
+    if (n < 0 || !src_a || !src_b || !dy || !slab) return CGS_ERR_BADARG;
+    if (!wgrad_fold_ok(hw, ca, cb, co)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return CGS_OK;
+    const GenWrPlan wr = gen_wr_plan(n, ca, 0, co);
+    if (!wr.ok) return CGS_ERR_UNSUPPORTED;
+    GenWfParams P{};
+    P.b = src_b; P.dy = dy; P.slab = slab; P.n = n; P.hw = hw; P.lw = __builtin_ctz(hw); P.ca = ca; P.cb = cb; P.co = co;
+    P.G = wr.G; P.ncs = wr.ncs; P.cw = wr.cw;
+    const int h = hw / 2, ncob = wr.ncob, cwp = 16 * ncob;
+    P.ps = (cb & 31) == 16 ? cb : ((cb + 15) / 32) * 32 + 16;       // pixel stride of the B tile: 16 (mod 32) floats -> conflict-free A-operand reads
+    P.ds = wr.cw;
+    const size_t fin = (size_t)16 * cb * cwp * sizeof(float);      // the final [class][fold, ci][column] block
+    size_t lds = 0;
+    P.th = 0;
+    for (int th = hw < 32 ? hw : 32; th >= 2; th >>= 1) {
+        const int thb = th / 2 + 2, steps = (th / 2) * (h / 4);
+        const size_t buf = ((size_t)thb * (h + 2) * P.ps + (size_t)th * hw * P.ds + 64 + 3) & ~(size_t)3;
+        const bool fits = thb * h * (cb / 4) <= 4 * 512 && th * hw * (wr.cw / 4) <= 5 * 512 && !(steps & 3);
+        if (fits && 2 * buf * sizeof(float) <= 158 * 1024) { P.th = th; P.buf_floats = (int)buf; lds = 2 * buf * sizeof(float); break; }
+    }
+    if (!P.th || fin > 158 * 1024) return CGS_ERR_UNSUPPORTED;
+    if (lds < fin) lds = fin;
+    P.parts = hw / P.th; P.units = n * P.parts;
+    // A's rows and the bias row (ci_stride: the slab row is the whole layer's)
+    const int rc = wgrad_rows(wr, n, hw, ca, 0, co, a_is_u8, 1, src_a, nullptr, dy, nullptr, slab, (hipStream_t)stream, ca + cb);
+    if (rc != CGS_OK) return rc;
+    const int grid = P.G * P.ncs;
+    switch (cb) {
+        case 16: return launch_wgrad_fold<4>(ncob, P, lds, grid, (hipStream_t)stream);
+        case 24: return launch_wgrad_fold<6>(ncob, P, lds, grid, (hipStream_t)stream);
+        case 32: return launch_wgrad_fold<8>(ncob, P, lds, grid, (hipStream_t)stream);
+        default: return launch_wgrad_fold<10>(ncob, P, lds, grid, (hipStream_t)stream);
+    }
 }
 
 extern "C" int cgs_gen_flip_weights(int32_t ci, int32_t co, const float* w, float* wflip, cgs_stream_t stream) {

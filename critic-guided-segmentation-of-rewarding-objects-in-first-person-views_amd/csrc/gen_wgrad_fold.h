@@ -1,0 +1,182 @@
+// Weight gradient of the NEAREST-UPSAMPLED source of a decoder layer, folded (included by gen_train.hip inside its anonymous namespace):
+//   layer input = cat(A [ca], nearest-up_2(B [cb])) (nets.py:480-489, 501-513 under autograd); this kernel writes dW[tap][ca + ci][co] for B's channels,
+//   gen_wgrad_rows_kernel (cb = 0, the slab strides of the whole layer) writes A's rows and the bias row of the same slab rows.
+// A pixel of parity (py, px) reads up(B) only through the 2 x 2 low-resolution cells (a, b) around it, so the nine taps collapse to four folds
+// per parity class:   dWf[py][px][a][b][ci][co] = sum over the class's pixels of B[(y >> 1) + a - 1 + py][(x >> 1) + b - 1 + px][ci] dY[y][x][co],
+//                     dW[ky][kx] = sum_{py, px} dWf[py][px][a(py, ky)][b(px, kx)],   a(0, .) = {0, 1, 1}, a(1, .) = {0, 0, 1}
+// -- 4 cb instead of 9 cb GEMM rows per pixel, B staged at its OWN resolution (a quarter of the elements, no upsampling in the loader), and
+// 4 cb is a whole number of 16-row blocks for every cb % 4 == 0 (40 channels: 10 blocks per class, nothing padded).
+// v_mfma_f32_16x16x4_f32: rows = 16 (fold, ci) pairs, columns = 16 output channels, K = 4 pixels OF ONE CLASS (the same position of four
+// consecutive cells of a row).  Workgroup = 8 waves = 4 parity classes x 2 pixel phases; a wave owns all RB = cb / 4 row blocks x NCOB column
+// blocks of its class (RB reads of A + NCOB of B per RB x NCOB matrix instructions).  One workgroup per CU, persistent over a contiguous
+// range of chunks (th rows of one image); the next chunk's global loads fly during the matrix instructions of the current one.
+#pragma once
+
+struct GenWfParams {
+    const float* b; const float* dy;      // B [n,hw/2,hw/2,cb];  dY [n,hw,hw,co]
+    float* slab;                          // [G][9 * ci_total * co + co]
+    int n, hw, lw, ca, cb, co;
+    int G, ncs, cw;                       // chunk shares; output-channel slices of cw channels
+    int th, parts, units;                 // chunk = th rows of one image; parts = hw / th; units = chunks in the job
+    int ps, ds, buf_floats;               // LDS pixel strides (floats) of the B tile / the dY tile; floats per buffer
+};
+
+template <int RB, int NCOB>
+__global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
+    extern __shared__ __attribute__((aligned(16))) float4 gfsm[];
+    float* const sm = (float*)gfsm;
+    constexpr int CS = 4 * RB, Q4 = RB;                                  // B's channels; quads per pixel
+    constexpr int KB = 4, KD = 5;                                        // staged 16-byte items per thread (host: the chunk fits)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
+    const int cls = wave & 3, ph = wave >> 2, py = cls >> 1, px = cls & 1;
+    const int W = P.hw, lw = P.lw, h = W >> 1, lh = lw - 1, PWB = h + 2, th = P.th, thb = (th >> 1) + 2;
+    const int cos = blockIdx.x % P.ncs, g = blockIdx.x / P.ncs;
+    const int cs0 = cos * P.cw, cwl = min(P.cw, P.co - cs0), qd = cwl >> 2;
+    const int ps = P.ps, ds = P.ds, BUF = P.buf_floats, BTF = thb * PWB * ps;      // (the dY tile follows the B tile)
+    const int ci_total = P.ca + P.cb;
+    const int u0 = (int)((long)g * P.units / P.G), u1 = (int)((long)(g + 1) * P.units / P.G);
+
+    // ---- this lane's A-operand offsets (bytes): row m = 16 rb + l15 = (fold f = 2 a + b, ci) ----
+    int aoff[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int m = 16 * rb + l15, f = m / CS, ci = m - f * CS;
+        aoff[rb] = 4 * ((((f >> 1) + py) * PWB + (f & 1) + px + kq) * ps + ci);
+    }
+    const int boff = (py * W + px + 2 * kq) * ds + l15;                  // B operand: pixel (2 Yl + py, 2 (X0 + kq) + px), column 16 c + l15
+    frag4 acc[RB][NCOB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int c = 0; c < NCOB; ++c) acc[r][c] = frag4{0.f, 0.f, 0.f, 0.f};
+
+    // the halo columns of the B tile are zero for every chunk (both buffers); so is the slack behind a buffer's dY tile
+    for (int e = tid; e < 2 * thb * 2 * Q4; e += 512) {
+        const int q = e % Q4, side = (e / Q4) & 1, r = (e / (2 * Q4)) % thb, bf = e / (2 * Q4 * thb);
+        *(float4*)(sm + bf * BUF + (r * PWB + (side ? h + 1 : 0)) * ps + 4 * q) = f4zero();
+    }
+    if (tid < 32) {
+        *(float4*)(sm + BUF - 64 + 4 * (tid & 15) + (tid >> 4) * BUF) = f4zero();
+    }
+
+    // ---- staging: item = 16 bytes; B items (tile row r, low-resolution column, quad), dY items (tile row, column, quad) ----
+    const int NBI = thb * h * Q4, NDI = th * W * qd;
+    const uint32_t mqd = 65536u / (uint32_t)qd + 1u;                     // item / qd by a multiply (exact below 5461 items)
+    float4 st[KB + KD];
+    auto issue = [&](int u) __attribute__((always_inline)) {
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
+        const int img = u / P.parts, row0 = (u % P.parts) * th, yb0 = (row0 >> 1) - 1;
+        // (no branch around a load and no use of a loaded value before the last load is issued)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int e = ltid + 512 * k, pix = e / Q4, q = e - pix * Q4, xc = pix & (h - 1), r = pix >> lh, yb = yb0 + r;
+            const bool in = e < NBI && yb >= 0 && yb < h;
+            const uint32_t off = (uint32_t)((img * h + yb) * h + xc) * (uint32_t)P.cb + 4u * q;        // (< 2^31 floats: host)
+            st[k] = *(const float4*)(P.b + (in ? off : 0u));
+        }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int e = ltid + 512 * k, pix = (int)(((uint32_t)e * mqd) >> 16), q = e - pix * qd;
+            const bool in = e < NDI;
+            const uint32_t off = (uint32_t)((img * W + row0) * W + pix) * (uint32_t)P.co + cs0 + 4u * q;
+            st[KB + k] = *(const float4*)(P.dy + (in ? off : 0u));
+        }
+    };
+    auto store = [&](int bf, int u) __attribute__((always_inline)) {
+        int ltid = tid;
+        asm volatile("" : "+v"(ltid));
+        const int row0 = (u % P.parts) * th, yb0 = (row0 >> 1) - 1;
+        float* tb = sm + bf * BUF;
+        float* td = tb + BTF;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const int e = ltid + 512 * k, pix = e / Q4, q = e - pix * Q4, xc = pix & (h - 1), r = pix >> lh, yb = yb0 + r;
+            if (e < NBI) *(float4*)(tb + (r * PWB + 1 + xc) * ps + 4 * q) = (yb >= 0 && yb < h) ? st[k] : f4zero();
+        }
+#pragma unroll
+        for (int k = 0; k < KD; ++k) {
+            const int e = ltid + 512 * k, pix = (int)(((uint32_t)e * mqd) >> 16), q = e - pix * qd;
+            // (unconditional store: items past the tile land in the buffer's slack -- behind a branch the compiler keeps std_ in scratch memory)
+            *(float4*)(e < NDI ? td + pix * ds + 4 * q : tb + BUF - 16) = st[KB + k];
+        }
+    };
+
+    // ---- matrix loop: k-step s of a chunk = cells (Yl, X0 .. X0 + 3) of this wave's class; the phases take alternate steps ----
+    const int lgx = lh - 2, nst = ((th >> 1) << lgx) >> 1;              // cell groups per cell row (log2); steps per phase (even: host)
+    auto load_ops = [&](const float* tb, int it, float (&a)[RB], float (&b)[NCOB]) __attribute__((always_inline)) {
+        const int s = 2 * it + ph, yl = s >> lgx, x0 = (s & ((1 << lgx) - 1)) << 2;
+        const char* ap = (const char*)(tb + (yl * PWB + x0) * ps);
+        const float* bp = tb + BTF + (2 * yl * W + 2 * x0) * ds + boff;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) a[r] = *(const float*)(ap + aoff[r]);
+#pragma unroll
+        for (int c = 0; c < NCOB; ++c) b[c] = bp[16 * c];
+    };
+    auto mfmas = [&](const float (&a)[RB], const float (&b)[NCOB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int c = 0; c < NCOB; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
+    };
+
+    if (u0 < u1) { issue(u0); store(0, u0); }
+    __syncthreads();
+    for (int u = u0; u < u1; ++u) {
+        const int bf = (u - u0) & 1;
+        const bool more = u + 1 < u1;
+        if (more) issue(u + 1);
+        const float* tb = sm + bf * BUF;
+        float a0[RB], b0[NCOB], a1[RB], b1[NCOB];
+        load_ops(tb, 0, a0, b0);
+#pragma unroll 1
+        for (int it = 0; it < nst; it += 2) {
+            load_ops(tb, it + 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_ops(tb, it + 2 < nst ? it + 2 : it, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store(bf ^ 1, u + 1);
+        __syncthreads();
+    }
+
+    // ---- F[class][m = (fold, ci)][col] in LDS: phase 1 writes, phase 0 adds its own (fixed order), then every thread unfolds ----
+    constexpr int CWP = 16 * NCOB;
+    float* F = sm;
+    auto fidx = [&](int rb, int j, int c) { return ((cls * 4 * CS) + 16 * rb + 4 * kq + j) * CWP + 16 * c + l15; };
+    if (ph == 1) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < NCOB; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) F[fidx(rb, j, c)] = acc[rb][c][j];
+    }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int c = 0; c < NCOB; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int i = fidx(rb, j, c); F[i] = acc[rb][c][j] + F[i]; }
+    }
+    __syncthreads();
+    float* row = P.slab + (size_t)g * (9 * ci_total * P.co + P.co);
+    for (int e = tid; e < 9 * CS * cwl; e += 512) {
+        const int rc = e / cwl, col = e - rc * cwl;
+        const int tap = rc / CS, ci = rc - tap * CS, ky = tap / 3, kx = tap - 3 * ky;
+        float v = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {                                  // classes in the order (0,0) (0,1) (1,0) (1,1)
+            const int cy = c4 >> 1, cx = c4 & 1;
+            const int a = cy ? (ky == 2 ? 1 : 0) : (ky == 0 ? 0 : 1), b = cx ? (kx == 2 ? 1 : 0) : (kx == 0 ? 0 : 1);
+            v += F[((c4 * 4 + 2 * a + b) * CS + ci) * CWP + col];
+        }
+        row[((size_t)tap * ci_total + P.ca + ci) * P.co + cs0 + col] = v;
+    }
+}

@@ -28,6 +28,7 @@ struct GenWrParams {
     int G, nsl, ncs, cs, cw;              // chunk shares; input-channel slices of cs channels; output-channel slices of cw channels
     int imgs, th, parts, units;           // chunk = imgs images x th rows (128 .. 512 pixels); parts = hw / th; units = chunks in the job
     int buf_floats;                       // floats per LDS buffer
+    int ci_stride;                        // > 0: the slab rows are those of a layer with ci_stride input channels (this launch writes its first ca + cb)
 };
 
 template <int NCOB, int RBW, bool POOLED>
@@ -42,7 +43,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
     // (A's channels padded to whole quads, then B's; a lone A of fewer than 4 channels -- the frames -- keeps its width: 27 rows
     //  = 2 row blocks instead of 36 = 3)
     const bool narrow = P.cb == 0 && P.ca < 4;
-    const int ca4 = narrow ? P.ca : (P.ca + 3) & ~3, ci_total = P.ca + P.cb, ci_pad = ca4 + P.cb;
+    const int ca4 = narrow ? P.ca : (P.ca + 3) & ~3, ci_total = P.ci_stride > 0 ? P.ci_stride : P.ca + P.cb, ci_pad = ca4 + P.cb;
     const int ks0 = sl * P.cs, csl = min(P.cs, ci_pad - ks0);             // this workgroup's (padded) input channels [ks0, ks0 + csl)
     const int cs0 = cos * P.cw, cwl = min(P.cw, P.co - cs0);               // and output channels [cs0, cs0 + cwl)
     const int IMS = (th + 2) * PW * csl;                                   // in-tile floats per image slot

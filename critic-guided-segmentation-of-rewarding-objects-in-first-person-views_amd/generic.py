@@ -16,6 +16,7 @@ from . import _lib
 from .spec import Layout
 
 UPS_FOLD = True             # forward of a layer over cat(A, nearest-up_2(B)) at hw >= 16: B staged at its own resolution, its 9 taps folded to 4 per pixel parity (gen4.hip, FOLD)
+WGRAD_FOLD = True           # weight gradient of a layer over cat(A, nearest-up_2(B)) at hw >= 16: A's rows by the row-block kernel, B's by gen_wgrad_fold_kernel on B at its own resolution (4 folds per parity class instead of 9 taps)
 ENC0_DEDICATED = True       # features.0 (3 -> 8 chfak channels at 64x64) of chfak 2 .. 5 on csrc/gen_enc0.hip (False: the shape-generic gen4 kernel)
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 
@@ -423,6 +424,16 @@ def _wgrad(plan, ws: Workspace, tag: str, dst_off: int, n, hw, a, b, ups, dy, am
         _lib.call("cgs_gen_enc0_bwd_weight", n, co, int(a.dtype == torch.uint8), _p(a), _p(dy), _p(am), _p(slab), _s())
         plan.add(slab, nsl, cnt, dst_off)
         return
+    if WGRAD_FOLD and cb > 0 and ups == 2 and am is None and hw >= 16:
+        nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_folded_slabs(n, hw, ca, cb, co)
+        if nsl > 0:
+            slab = ws.buf("slab_" + tag, (nsl, cnt), a.device)
+            rc = _lib.load().cgs_gen_conv3x3_bwd_weight_folded(n, hw, ca, cb, co, int(a.dtype == torch.uint8), _p(a), _p(b), _p(dy), _p(slab), _s())
+            if rc == 0:
+                plan.add(slab, nsl, cnt, dst_off)
+                return
+            if rc != -1:        # (-1 = CGS_ERR_UNSUPPORTED, decided before anything is launched: the unfolded kernel below)
+                raise _lib.CgsError(f"cgs_gen_conv3x3_bwd_weight_folded failed: {rc}")
     nsl = _lib.load().cgs_gen_conv3x3_bwd_weight_slabs(n, ca, cb, co)
     slab = ws.buf("slab_" + tag, (nsl, cnt), a.device)
     _lib.call("cgs_gen_conv3x3_bwd_weight", n, hw, ca, cb, co, int(a.dtype == torch.uint8), ups, _p(a), _p(b), _p(dy), _p(am),

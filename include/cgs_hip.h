@@ -547,6 +547,13 @@ int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t 
 int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                const void* src_a, const float* src_b, const float* dy, const uint8_t* dy_argmax, float* slab,
                                cgs_stream_t stream);
+/* The same slab rows for a layer over cat(A, nearest-up_2(B)) (hw 16 / 32 / 64, cb 16 / 24 / 32 / 40, dY not pooled) with B read at its own
+ * resolution: per pixel parity the nine taps over the upsampled map are four folds of B's 2 x 2 cells -- 4 cb instead of 9 cb GEMM rows
+ * (csrc/gen_wgrad_fold.h); A's rows and the bias row come from the row-block kernel.  _slabs: rows per layer (<= 0: not supported);
+ * CGS_ERR_UNSUPPORTED is returned before anything is launched.                                                                    */
+int cgs_gen_conv3x3_bwd_weight_folded_slabs(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co);
+int cgs_gen_conv3x3_bwd_weight_folded(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, const void* src_a,
+                                      const float* src_b, const float* dy, float* slab, cgs_stream_t stream);
 int cgs_gen_cat_split(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t ups, const float* d_cat, float* d_a, float* d_b,
                       cgs_stream_t stream);
 int cgs_gen_grad_fix(int64_t count, float* d, const float* saved, int32_t act, float slope, const float* addend,

@@ -84,6 +84,60 @@ def test_wgrad_rows_vs_float64_autograd(n, hw, ca, cb, ups, co, pooled, u8):
     assert torch.equal(slab, slab2)
 
 
+@pytest.mark.parametrize("n,hw,ca,cb,co,u8", [
+    (3, 32, 40, 40, 40, False),        # dec_model.0 at chfak 5: ten row blocks per parity class x three column blocks
+    (2, 64, 3, 40, 16, True),          # masker.0: uint8 frames (A by the row-block kernel's narrow form) + 40 folded channels, one column block
+    (5, 16, 40, 40, 40, False),        # dec_model.1: one chunk per image
+    (2, 32, 16, 16, 16, False),        # chfak 2
+    (3, 16, 24, 24, 24, False),        # chfak 3
+    (2, 64, 3, 32, 16, False),         # chfak 4 masker.0 with fp32 frames
+    (700, 16, 8, 16, 8, False),        # more images than workgroups; a column block of 8
+])
+def test_wgrad_folded_upsample_vs_float64_autograd(n, hw, ca, cb, co, u8):
+    """cgs_gen_conv3x3_bwd_weight_folded (A's rows + bias by the row-block kernel, B's rows folded at B's resolution) == float64 autograd of
+    conv2d over the explicit cat(A, nearest-up_2(B)) (nets.py:480-489, 501-513); every element of every slab row written; same bits twice."""
+    from cgs_amd import _lib, generic
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(77 * hw + ca + cb + co + n)
+    a = torch.randint(0, 256, (n, hw, hw, ca), dtype=torch.uint8, generator=g) if u8 else torch.randn(n, hw, hw, ca, generator=g)
+    b = torch.randn(n, hw // 2, hw // 2, cb, generator=g)
+    dy = torch.randn(n, hw, hw, co, generator=g)
+    lib = _lib.load()
+    nsl = lib.cgs_gen_conv3x3_bwd_weight_folded_slabs(n, hw, ca, cb, co)
+    assert nsl >= 1
+    cnt = 9 * (ca + cb) * co + co
+    a_d, b_d, dy_d = a.to(dev), b.to(dev), dy.to(dev)
+    slab = torch.full((nsl, cnt), float("nan"), device=dev)
+    _lib.call("cgs_gen_conv3x3_bwd_weight_folded", n, hw, ca, cb, co, int(u8), generic._p(a_d), generic._p(b_d), generic._p(dy_d),
+              generic._p(slab), generic._s())
+    torch.cuda.synchronize()
+    got = slab.double().sum(0).cpu()
+    assert torch.isfinite(got).all(), "an element of a slab row was not written"
+    nref = min(n, 64)                                  # (float64 autograd on the CPU: the first images; the rest by linearity below)
+    if n > nref:
+        slab_h = torch.zeros_like(slab)
+        _lib.call("cgs_gen_conv3x3_bwd_weight_folded", nref, hw, ca, cb, co, int(u8), generic._p(a_d), generic._p(b_d), generic._p(dy_d),
+                  generic._p(slab_h), generic._s())
+        torch.cuda.synchronize()
+        nh = lib.cgs_gen_conv3x3_bwd_weight_folded_slabs(nref, hw, ca, cb, co)
+        got = slab_h[:nh].double().sum(0).cpu()
+        # the rest of the batch through torch on the device in float32 (coarser bound)
+        xin = torch.cat([a_d.float().permute(0, 3, 1, 2), F.interpolate(b_d.permute(0, 3, 1, 2), scale_factor=2, mode="nearest")], 1).double()
+        w = torch.zeros(co, ca + cb, 3, 3, dtype=torch.float64, device=dev, requires_grad=True)
+        bias = torch.zeros(co, dtype=torch.float64, device=dev, requires_grad=True)
+        gw, gb = torch.autograd.grad(F.conv2d(xin, w, bias, padding=1), (w, bias), dy_d.double().permute(0, 3, 1, 2))
+        full = torch.cat([gw.permute(2, 3, 1, 0).reshape(-1), gb]).cpu()
+        assert (slab.double().sum(0).cpu() - full).abs().max().item() / full.abs().max().item() < 3e-6
+    ref = _ref_wgrad(a[:nref], b[:nref], 2, dy[:nref], co)
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-6, f"weight gradient off by {err:.2e} of its maximum"
+    slab2 = torch.zeros_like(slab)
+    _lib.call("cgs_gen_conv3x3_bwd_weight_folded", n, hw, ca, cb, co, int(u8), generic._p(a_d), generic._p(b_d), generic._p(dy_d),
+              generic._p(slab2), generic._s())
+    torch.cuda.synchronize()
+    assert torch.equal(slab, slab2)
+
+
 def test_wgrad_single_channel_output_stays_on_the_16x16x4_kernel():
     """co = 1 (masker.2) has no row-block form: the slab count and the result come from gen_conv3x3_wgrad_kernel."""
     from cgs_amd import _lib, generic
