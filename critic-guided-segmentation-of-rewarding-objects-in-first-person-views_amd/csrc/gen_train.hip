@@ -446,18 +446,19 @@ extern "C" int cgs_gen_conv3x3_bwd_weight_folded_slabs(int32_t n, int32_t hw, in
     const GenWrPlan wr = gen_wr_plan(n, ca, 0, co);
     return wr.ok ? wr.G : CGS_ERR_UNSUPPORTED;
 }
-template <int RB>
-static int launch_wgrad_fold(int ncob, const GenWfParams& P, size_t lds, int grid, hipStream_t st) {
-    static hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_fold_kernel<RB, 1>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_fold_kernel<RB, 3>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr1 != hipSuccess) return (int)attr1;
-    if (attr3 != hipSuccess) return (int)attr3;
-    if (ncob == 1) hipLaunchKernelGGL((gen_wgrad_fold_kernel<RB, 1>), dim3(grid), dim3(512), lds, st, P);
-    else hipLaunchKernelGGL((gen_wgrad_fold_kernel<RB, 3>), dim3(grid), dim3(512), lds, st, P);
+template <int RB, int NCOB, bool NARROW>
+static int launch_wgrad_fold1(const GenWfParams& P, size_t lds, int grid, hipStream_t st) {
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gen_wgrad_fold_kernel<RB, NCOB, NARROW>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL((gen_wgrad_fold_kernel<RB, NCOB, NARROW>), dim3(grid), dim3(512), lds, st, P);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+template <int RB>
+static int launch_wgrad_fold(int ncob, bool narrow, const GenWfParams& P, size_t lds, int grid, hipStream_t st) {
+    if (narrow) return ncob == 1 ? launch_wgrad_fold1<RB, 1, true>(P, lds, grid, st) : launch_wgrad_fold1<RB, 3, true>(P, lds, grid, st);
+    return ncob == 1 ? launch_wgrad_fold1<RB, 1, false>(P, lds, grid, st) : launch_wgrad_fold1<RB, 3, false>(P, lds, grid, st);
 }
 extern "C" int cgs_gen_conv3x3_bwd_weight_folded(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8,
                                                  const void* src_a, const float* src_b, const float* dy, float* slab, cgs_stream_t stream) {
@@ -470,29 +471,38 @@ extern "C" int cgs_gen_conv3x3_bwd_weight_folded(int32_t n, int32_t hw, int32_t 
     P.b = src_b; P.dy = dy; P.slab = slab; P.n = n; P.hw = hw; P.lw = __builtin_ctz(hw); P.ca = ca; P.cb = cb; P.co = co;
     P.G = wr.G; P.ncs = wr.ncs; P.cw = wr.cw;
     const int h = hw / 2, ncob = wr.ncob, cwp = 16 * ncob;
-    P.ps = (cb & 31) == 16 ? cb : ((cb + 15) / 32) * 32 + 16;       // pixel stride of the B tile: 16 (mod 32) floats -> conflict-free A-operand reads
+    const bool narrow = ca <= 3;                                    // the frames: their rows and the bias row ride in the folded kernel
+    P.a = src_a; P.a_u8 = a_is_u8;
     P.ds = wr.cw;
-    const size_t fin = (size_t)16 * cb * cwp * sizeof(float);      // the final [class][fold, ci][column] block
+    // the final [class][fold, ci][column] block (+ narrow: [class][32][column] and the bias partial sums)
+    const size_t fin = ((size_t)16 * cb * cwp + (narrow ? (size_t)(4 * 32 + 32) * cwp : 0)) * sizeof(float);
     size_t lds = 0;
     P.th = 0;
-    for (int th = hw < 32 ? hw : 32; th >= 2; th >>= 1) {
-        const int thb = th / 2 + 2, steps = (th / 2) * (h / 4);
-        const size_t buf = ((size_t)thb * (h + 2) * P.ps + (size_t)th * hw * P.ds + 64 + 3) & ~(size_t)3;
-        const bool fits = thb * h * (cb / 4) <= 4 * 512 && th * hw * (wr.cw / 4) <= 5 * 512 && !(steps & 3);
-        if (fits && 2 * buf * sizeof(float) <= 158 * 1024) { P.th = th; P.buf_floats = (int)buf; lds = 2 * buf * sizeof(float); break; }
+    // pixel stride of the B tile: 16 (mod 32) floats -> conflict-free A-operand reads; the channel count itself when only that lets a larger chunk fit
+    const int ps_pad = (cb & 31) == 16 ? cb : ((cb + 15) / 32) * 32 + 16;
+    for (int th = hw < 32 ? hw : 32; th >= 2 && !P.th; th >>= 1) {
+        for (int pass = 0; pass < 2 && !P.th; ++pass) {
+            const int ps = pass == 0 ? ps_pad : cb;
+            const int thb = th / 2 + 2, steps = (th / 2) * (h / 4);
+            const size_t buf = ((size_t)thb * (h + 2) * ps + (size_t)th * hw * P.ds + 64 + (narrow ? (size_t)(th + 2) * (hw + 2) * 4 + 16 : 0) + 3) & ~(size_t)3;      // (+ 16: the staging's dummy slot behind the frame tile)
+            const bool fits = thb * h * (cb / 4) <= 4 * 512 && th * hw * (wr.cw / 4) <= 5 * 512 && !(steps & 3) && (!narrow || (th + 2) * hw <= 2 * 512);
+            if (fits && 2 * buf * sizeof(float) <= 158 * 1024) { P.th = th; P.ps = ps; P.buf_floats = (int)buf; lds = 2 * buf * sizeof(float); }
+        }
     }
     if (!P.th || fin > 158 * 1024) return CGS_ERR_UNSUPPORTED;
     if (lds < fin) lds = fin;
     P.parts = hw / P.th; P.units = n * P.parts;
-    // A's rows and the bias row (ci_stride: the slab row is the whole layer's)
-    const int rc = wgrad_rows(wr, n, hw, ca, 0, co, a_is_u8, 1, src_a, nullptr, dy, nullptr, slab, (hipStream_t)stream, ca + cb);
-    if (rc != CGS_OK) return rc;
+    if (!narrow) {
+        // A's rows and the bias row (ci_stride: the slab row is the whole layer's)
+        const int rc = wgrad_rows(wr, n, hw, ca, 0, co, a_is_u8, 1, src_a, nullptr, dy, nullptr, slab, (hipStream_t)stream, ca + cb);
+        if (rc != CGS_OK) return rc;
+    }
     const int grid = P.G * P.ncs;
     switch (cb) {
-        case 16: return launch_wgrad_fold<4>(ncob, P, lds, grid, (hipStream_t)stream);
-        case 24: return launch_wgrad_fold<6>(ncob, P, lds, grid, (hipStream_t)stream);
-        case 32: return launch_wgrad_fold<8>(ncob, P, lds, grid, (hipStream_t)stream);
-        default: return launch_wgrad_fold<10>(ncob, P, lds, grid, (hipStream_t)stream);
+        case 16: return launch_wgrad_fold<4>(ncob, narrow, P, lds, grid, (hipStream_t)stream);
+        case 24: return launch_wgrad_fold<6>(ncob, narrow, P, lds, grid, (hipStream_t)stream);
+        case 32: return launch_wgrad_fold<8>(ncob, narrow, P, lds, grid, (hipStream_t)stream);
+        default: return launch_wgrad_fold<10>(ncob, narrow, P, lds, grid, (hipStream_t)stream);
     }
 }
 

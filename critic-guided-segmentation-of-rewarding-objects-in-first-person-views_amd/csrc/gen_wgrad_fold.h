@@ -10,9 +10,12 @@
 // consecutive cells of a row).  Workgroup = 8 waves = 4 parity classes x 2 pixel phases; a wave owns all RB = cb / 4 row blocks x NCOB column
 // blocks of its class (RB reads of A + NCOB of B per RB x NCOB matrix instructions).  One workgroup per CU, persistent over a contiguous
 // range of chunks (th rows of one image); the next chunk's global loads fly during the matrix instructions of the current one.
+// NARROW (ca <= 3: masker.0's frames): A's 9 ca <= 27 rows (two more row blocks per wave, the full-resolution frame tile beside the others)
+// and the bias row (the sum of the B operand) come from this kernel too -- the row-block kernel would stage all of dY a second time for them.
 #pragma once
 
 struct GenWfParams {
+    const void* a; int a_u8;              // NARROW only: A [n,hw,hw,ca] (ca <= 3: the frames), fp32 or uint8 (/255)
     const float* b; const float* dy;      // B [n,hw/2,hw/2,cb];  dY [n,hw,hw,co]
     float* slab;                          // [G][9 * ci_total * co + co]
     int n, hw, lw, ca, cb, co;
@@ -21,18 +24,20 @@ struct GenWfParams {
     int ps, ds, buf_floats;               // LDS pixel strides (floats) of the B tile / the dY tile; floats per buffer
 };
 
-template <int RB, int NCOB>
+template <int RB, int NCOB, bool NARROW>
 __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 gfsm[];
     float* const sm = (float*)gfsm;
     constexpr int CS = 4 * RB, Q4 = RB;                                  // B's channels; quads per pixel
-    constexpr int KB = 4, KD = 5;                                        // staged 16-byte items per thread (host: the chunk fits)
+    constexpr int KB = 4, KD = 5, KA = NARROW ? 2 : 0;                   // staged 16-byte items per thread (host: the chunk fits)
+    constexpr int NAB = NARROW ? 2 : 0;                                  // A's row blocks (NARROW)
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;
     const int cls = wave & 3, ph = wave >> 2, py = cls >> 1, px = cls & 1;
     const int W = P.hw, lw = P.lw, h = W >> 1, lh = lw - 1, PWB = h + 2, th = P.th, thb = (th >> 1) + 2;
     const int cos = blockIdx.x % P.ncs, g = blockIdx.x / P.ncs;
     const int cs0 = cos * P.cw, cwl = min(P.cw, P.co - cs0), qd = cwl >> 2;
     const int ps = P.ps, ds = P.ds, BUF = P.buf_floats, BTF = thb * PWB * ps;      // (the dY tile follows the B tile)
+    const int PWA = W + 2, DTF = th * W * ds + 64;                                 // NARROW: the frame tile [(th + 2)][W + 2][4 floats] follows the dY tile and its slack
     const int ci_total = P.ca + P.cb;
     const int u0 = (int)((long)g * P.units / P.G), u1 = (int)((long)(g + 1) * P.units / P.G);
 
@@ -43,12 +48,29 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
         const int m = 16 * rb + l15, f = m / CS, ci = m - f * CS;
         aoff[rb] = 4 * ((((f >> 1) + py) * PWB + (f & 1) + px + kq) * ps + ci);
     }
+    // NARROW: A's rows m = 16 fb + l15 = (tap, c), 27 at most; rows past 9 ca read a valid address and are dropped at the end
+    [[maybe_unused]] int aoffa[NAB > 0 ? NAB : 1];
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int fb = 0; fb < NAB; ++fb) {
+            const int m = 16 * fb + l15, mm = m < 9 * P.ca ? m : 0, tap = mm / P.ca, c = mm - tap * P.ca, ky = tap / 3, kx = tap - 3 * ky;
+            aoffa[fb] = 4 * (((py + ky) * PWA + px + kx + 2 * kq) * 4 + c);
+        }
+    }
     const int boff = (py * W + px + 2 * kq) * ds + l15;                  // B operand: pixel (2 Yl + py, 2 (X0 + kq) + px), column 16 c + l15
     frag4 acc[RB][NCOB];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
         for (int c = 0; c < NCOB; ++c) acc[r][c] = frag4{0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] frag4 acca[NAB > 0 ? NAB : 1][NCOB];
+    [[maybe_unused]] float bsum[NCOB];
+#pragma unroll
+    for (int c = 0; c < NCOB; ++c) {
+        bsum[c] = 0.f;
+#pragma unroll
+        for (int r = 0; r < (NAB > 0 ? NAB : 1); ++r) acca[r][c] = frag4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // the halo columns of the B tile are zero for every chunk (both buffers); so is the slack behind a buffer's dY tile
     for (int e = tid; e < 2 * thb * 2 * Q4; e += 512) {
@@ -58,11 +80,18 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     if (tid < 32) {
         *(float4*)(sm + BUF - 64 + 4 * (tid & 15) + (tid >> 4) * BUF) = f4zero();
     }
+    if constexpr (NARROW) {
+        for (int e = tid; e < 2 * (th + 2) * 2; e += 512) {
+            const int side = e & 1, r = (e >> 1) % (th + 2), bf = e / (2 * (th + 2));
+            *(float4*)(sm + bf * BUF + BTF + DTF + (r * PWA + (side ? W + 1 : 0)) * 4) = f4zero();
+        }
+    }
 
     // ---- staging: item = 16 bytes; B items (tile row r, low-resolution column, quad), dY items (tile row, column, quad) ----
     const int NBI = thb * h * Q4, NDI = th * W * qd;
     const uint32_t mqd = 65536u / (uint32_t)qd + 1u;                     // item / qd by a multiply (exact below 5461 items)
-    float4 st[KB + KD];
+    const int NAI = (th + 2) * W;                                        // NARROW: frame-tile pixels
+    float4 st[KB + KD + KA];
     auto issue = [&](int u) __attribute__((always_inline)) {
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
@@ -82,6 +111,22 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
             const uint32_t off = (uint32_t)((img * W + row0) * W + pix) * (uint32_t)P.co + cs0 + 4u * q;
             st[KB + k] = *(const float4*)(P.dy + (in ? off : 0u));
         }
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int e = ltid + 512 * k, xa = e & (W - 1), r = e >> lw, y = row0 - 1 + r;
+                const bool in = e < NAI && y >= 0 && y < W;
+                const uint32_t off = in ? (uint32_t)((img * W + y) * W + xa) * (uint32_t)P.ca : 0u;
+                const int c1 = P.ca > 1 ? 1 : 0, c2 = P.ca > 2 ? 2 : 0;
+                if (P.a_u8) {
+                    const uint8_t* s8 = (const uint8_t*)P.a + off;
+                    st[KB + KD + k] = make_float4((float)s8[0], (float)s8[c1], (float)s8[c2], 0.f);
+                } else {
+                    const float* s32 = (const float*)P.a + off;
+                    st[KB + KD + k] = make_float4(s32[0], s32[c1], s32[c2], 0.f);
+                }
+            }
+        }
     };
     auto store = [&](int bf, int u) __attribute__((always_inline)) {
         int ltid = tid;
@@ -100,24 +145,49 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
             // (unconditional store: items past the tile land in the buffer's slack -- behind a branch the compiler keeps std_ in scratch memory)
             *(float4*)(e < NDI ? td + pix * ds + 4 * q : tb + BUF - 16) = st[KB + k];
         }
+        if constexpr (NARROW) {
+            float* ta = td + DTF;
+            const float sc = P.a_u8 ? 1.f / 255.f : 1.f;
+#pragma unroll
+            for (int k = 0; k < KA; ++k) {
+                const int e = ltid + 512 * k, xa = e & (W - 1), r = e >> lw, y = row0 - 1 + r;
+                const bool in = y >= 0 && y < W;
+                float4 v = st[KB + KD + k];
+                v = make_float4(in ? v.x * sc : 0.f, in && P.ca > 1 ? v.y * sc : 0.f, in && P.ca > 2 ? v.z * sc : 0.f, 0.f);
+                *(float4*)(e < NAI ? ta + (r * PWA + 1 + xa) * 4 : tb + BUF - 16) = v;
+            }
+        }
     };
 
     // ---- matrix loop: k-step s of a chunk = cells (Yl, X0 .. X0 + 3) of this wave's class; the phases take alternate steps ----
     const int lgx = lh - 2, nst = ((th >> 1) << lgx) >> 1;              // cell groups per cell row (log2); steps per phase (even: host)
-    auto load_ops = [&](const float* tb, int it, float (&a)[RB], float (&b)[NCOB]) __attribute__((always_inline)) {
+    auto load_ops = [&](const float* tb, int it, float (&a)[RB + NAB], float (&b)[NCOB]) __attribute__((always_inline)) {
         const int s = 2 * it + ph, yl = s >> lgx, x0 = (s & ((1 << lgx) - 1)) << 2;
         const char* ap = (const char*)(tb + (yl * PWB + x0) * ps);
         const float* bp = tb + BTF + (2 * yl * W + 2 * x0) * ds + boff;
 #pragma unroll
         for (int r = 0; r < RB; ++r) a[r] = *(const float*)(ap + aoff[r]);
+        if constexpr (NARROW) {
+            const char* aa = (const char*)(tb + BTF + DTF + (2 * yl * PWA + 2 * x0) * 4);
+#pragma unroll
+            for (int r = 0; r < NAB; ++r) a[RB + r] = *(const float*)(aa + aoffa[r]);
+        }
 #pragma unroll
         for (int c = 0; c < NCOB; ++c) b[c] = bp[16 * c];
     };
-    auto mfmas = [&](const float (&a)[RB], const float (&b)[NCOB]) __attribute__((always_inline)) {
+    auto mfmas = [&](const float (&a)[RB + NAB], const float (&b)[NCOB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int c = 0; c < NCOB; ++c) acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b[c], acc[r][c], 0, 0, 0);
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int r = 0; r < NAB; ++r)
+#pragma unroll
+                for (int c = 0; c < NCOB; ++c) acca[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[RB + r], b[c], acca[r][c], 0, 0, 0);
+#pragma unroll
+            for (int c = 0; c < NCOB; ++c) bsum[c] += b[c];
+        }
     };
 
     if (u0 < u1) { issue(u0); store(0, u0); }
@@ -127,7 +197,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
         const bool more = u + 1 < u1;
         if (more) issue(u + 1);
         const float* tb = sm + bf * BUF;
-        float a0[RB], b0[NCOB], a1[RB], b1[NCOB];
+        float a0[RB + NAB], b0[NCOB], a1[RB + NAB], b1[NCOB];
         load_ops(tb, 0, a0, b0);
 #pragma unroll 1
         for (int it = 0; it < nst; it += 2) {
@@ -147,7 +217,22 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     // ---- F[class][m = (fold, ci)][col] in LDS: phase 1 writes, phase 0 adds its own (fixed order), then every thread unfolds ----
     constexpr int CWP = 16 * NCOB;
     float* F = sm;
+    float* FA = F + 16 * CS * CWP;                       // NARROW: [class][32 rows][CWP], then the bias partial sums [8 waves][4 kq][CWP]
+    float* FB = FA + 4 * 32 * CWP;
     auto fidx = [&](int rb, int j, int c) { return ((cls * 4 * CS) + 16 * rb + 4 * kq + j) * CWP + 16 * c + l15; };
+    auto faidx = [&](int fb, int j, int c) { return (cls * 32 + 16 * fb + 4 * kq + j) * CWP + 16 * c + l15; };
+    if constexpr (NARROW) {
+#pragma unroll
+        for (int c = 0; c < NCOB; ++c) FB[(wave * 4 + kq) * CWP + 16 * c + l15] = bsum[c];
+        if (ph == 1) {
+#pragma unroll
+            for (int fb = 0; fb < NAB; ++fb)
+#pragma unroll
+                for (int c = 0; c < NCOB; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) FA[faidx(fb, j, c)] = acca[fb][c][j];
+        }
+    }
     if (ph == 1) {
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
@@ -164,6 +249,14 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
             for (int c = 0; c < NCOB; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { const int i = fidx(rb, j, c); F[i] = acc[rb][c][j] + F[i]; }
+        if constexpr (NARROW) {
+#pragma unroll
+            for (int fb = 0; fb < NAB; ++fb)
+#pragma unroll
+                for (int c = 0; c < NCOB; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const int i = faidx(fb, j, c); FA[i] = acca[fb][c][j] + FA[i]; }
+        }
     }
     __syncthreads();
     float* row = P.slab + (size_t)g * (9 * ci_total * P.co + P.co);
@@ -178,5 +271,20 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
             v += F[((c4 * 4 + 2 * a + b) * CS + ci) * CWP + col];
         }
         row[((size_t)tap * ci_total + P.ca + ci) * P.co + cs0 + col] = v;
+    }
+    if constexpr (NARROW) {
+        for (int e = tid; e < (9 * P.ca + 1) * cwl; e += 512) {
+            const int m = e / cwl, col = e - m * cwl;
+            float v = 0.f;
+            if (m < 9 * P.ca) {                        // A's rows: the four classes in order
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) v += FA[(c4 * 32 + m) * CWP + col];
+                const int tap = m / P.ca, c = m - tap * P.ca;
+                row[((size_t)tap * ci_total + c) * P.co + cs0 + col] = v;
+            } else {                                   // the bias row: 8 waves x 4 pixel lanes in order
+                for (int i = 0; i < 32; ++i) v += FB[i * CWP + col];
+                row[(size_t)9 * ci_total * P.co + cs0 + col] = v;
+            }
+        }
     }
 }
