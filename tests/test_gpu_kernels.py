@@ -673,4 +673,7 @@ def rel_kind(what):
     return "fwd"
 
 
-REL_LIMIT = {"fwd": 1e-3, "grad": 2e-3, "param": 5e-3}
+# "param": a weight after Adam steps.  The first update is lr g / (|g| + eps): ill-conditioned where |g| ~ eps, so a weight of 1 % of its tensor's maximum
+# moves with the summation ORDER of its gradient (measured worst 5.4e-3 of such a weight = 3e-6 absolute = 0.3 % of one update step, after the Linear
+# layers' GEMM changed its k order; 3.3e-3 before) -- the bound is a fraction of an update step, not a statement about the gradient (that is "grad").
+REL_LIMIT = {"fwd": 1e-3, "grad": 2e-3, "param": 1e-2}
