@@ -128,6 +128,9 @@ SIGNATURES = {
     "cgs_nhwc_to_nchw": (i32, [i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_packed_floats": (i64, [i32, i32, i32]),
     "cgs_gen_conv_packed_floats_folded": (i64, [i32, i32, i32]),
+    "cgs_gen_conv_packed_floats_up2": (i64, [i32, i32]),
+    "cgs_gen_conv_pack_weights_up2": (i32, [i32, i32, i32, i32, vp, vp, vp]),
+    "cgs_gen_conv3x3_bwd_data_up2": (i32, [i32, i32, i32, i32, vp, vp, vp, vp]),
     "cgs_gen_conv_pack_weights": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_pack_weights_window": (i32, [i32, i32, i32, i32, vp, vp, vp]),
     "cgs_gen_conv_pack_batch": (i32, [vp, i32, vp]),

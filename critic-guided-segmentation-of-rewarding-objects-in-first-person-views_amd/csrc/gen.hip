@@ -189,6 +189,29 @@ extern "C" int cgs_gen_conv_pack_weights_window(int32_t co_layer, int32_t ci_lay
     return gen4_pack_launch(co_layer, 0, ci_n, 1, w, wp, ci_layer, ci_off, (hipStream_t)stream);
 }
 
+// The data gradient towards the nearest-upsampled (x2) source of a layer, computed at the source's resolution (gen4_conv3x3_kernel<NG, 2>):
+// w = HWIO [9][ci_layer][co_layer]; the operand maps dY [n,hw,hw,co_layer] to d B [n,hw/2,hw/2,ci_n] = the gradient of input channels
+// [ci_off, ci_off + ci_n) summed over each 2 x 2 cell -- what cgs_gen_conv3x3_bwd_data_split writes to d_b, with 16 instead of 36 steps per cell.
+extern "C" int64_t cgs_gen_conv_packed_floats_up2(int32_t co_layer, int32_t ci_n) {
+    if (co_layer <= 0 || ci_n <= 0 || (co_layer & 3)) return CGS_ERR_BADARG;
+    return gen4_packed_floats(co_layer, 0, ci_n, 3);
+}
+extern "C" int cgs_gen_conv_pack_weights_up2(int32_t co_layer, int32_t ci_layer, int32_t ci_off, int32_t ci_n, const float* w, float* wp,
+                                             cgs_stream_t stream) {
+    if (co_layer <= 0 || (co_layer & 3) || ci_layer <= 0 || ci_off < 0 || ci_n <= 0 || ci_off + ci_n > ci_layer || !w || !wp) return CGS_ERR_BADARG;
+    return gen4_pack_launch(co_layer, 0, ci_n, 3, w, wp, ci_layer, ci_off, (hipStream_t)stream);
+}
+extern "C" int cgs_gen_conv3x3_bwd_data_up2(int32_t n, int32_t hw, int32_t co_layer, int32_t ci_n, const float* dy, const float* wp, float* d_b,
+                                            cgs_stream_t stream) {
+    if (n < 0 || !dy || !wp || !d_b || co_layer <= 0 || ci_n <= 0) return CGS_ERR_BADARG;
+    if ((hw != 16 && hw != 32 && hw != 64) || (co_layer & 3)) return CGS_ERR_UNSUPPORTED;
+    if (n == 0) return CGS_OK;
+    const int pbw = (co_layer + 15) / 16 * 16;
+    Gen4Launch L{GenSrc{dy, nullptr, nullptr, GEN_SRC_F32, co_layer, pbw, 1}, wp, nullptr, d_b, nullptr, nullptr, 0, n, hw / 2, ci_n, CGS_ACT_NONE, 0, 0.f,
+                 nullptr, 0, 0, 2};
+    return gen4_conv_launch(L, (hipStream_t)stream);
+}
+
 // Every 3x3 layer's operand of one step in one launch: job i packs like cgs_gen_conv_pack_weights (ci_layer = 0) or
 // cgs_gen_conv_pack_weights_window (ci_layer > 0: ca = the layer's output channels, co = the window's width).
 extern "C" int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njobs, cgs_stream_t stream) {
@@ -200,9 +223,10 @@ extern "C" int cgs_gen_conv_pack_batch(const cgs_gen_pack_job* jobs, int32_t njo
         const int nb = njobs - j0 < 64 ? njobs - j0 : 64;
         for (int j = 0; j < nb; ++j) {
             const cgs_gen_pack_job& J = jobs[j0 + j];
-            if (!J.w || !J.wp || J.ca <= 0 || J.cb < 0 || J.co <= 0 || (J.cb & 3) || J.transposed < 0 || J.transposed > 2) return CGS_ERR_BADARG;
-            if ((J.transposed == 1 && J.cb) || (J.transposed == 2 && !J.cb)) return CGS_ERR_BADARG;
-            if (J.ci_layer > 0 && (J.transposed != 1 || J.ci_off < 0 || J.ci_off + J.co > J.ci_layer)) return CGS_ERR_BADARG;
+            if (!J.w || !J.wp || J.ca <= 0 || J.cb < 0 || J.co <= 0 || (J.cb & 3) || J.transposed < 0 || J.transposed > 3) return CGS_ERR_BADARG;
+            if (((J.transposed == 1 || J.transposed == 3) && J.cb) || (J.transposed == 2 && !J.cb)) return CGS_ERR_BADARG;
+            if (J.transposed == 3 && (J.ci_layer <= 0 || (J.ca & 3))) return CGS_ERR_BADARG;      // (the up2 data-gradient operand: the window form)
+            if (J.ci_layer > 0 && ((J.transposed != 1 && J.transposed != 3) || J.ci_off < 0 || J.ci_off + J.co > J.ci_layer)) return CGS_ERR_BADARG;
             // (a whole-layer operand: the forward form reads w as [9][ca + cb][co]; the transposed one as [9][co][ca])
             tmp[j] = Gen4PackJob{J.w, J.wp, J.ca, J.cb, J.co, J.transposed, J.ci_layer > 0 ? J.ci_layer : J.co, J.ci_layer > 0 ? J.ci_off : 0};
         }

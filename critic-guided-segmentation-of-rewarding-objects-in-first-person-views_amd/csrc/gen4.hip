@@ -71,6 +71,21 @@ __device__ __forceinline__ float gen4_pack_elem(const Gen4PackParams& P, int e) 
             for (int kx = kx0; kx <= kx1; ++kx) v += P.w[((size_t)(ky * 3 + kx) * ci_total + P.ca + kb) * P.co + col];
         return v;
     }
+    if (P.transposed == 3) {
+        // the data gradient towards the nearest-upsampled source [ci_off, ci_off + co) of a layer w = HWIO [9][ci_layer][ca] (ca = dY's channels):
+        // gen4_conv3x3_kernel<NG, 2> over the space-to-depth view of dY (gen4_stage_s2d).  Chunk c lies in parity block (py, px); the cell
+        // (Y + ty, X + tx) of that block, ty = (ab >> 1) - py, reaches output cell (Y, X) through the taps ky with ((2 (Y + ty) + py) + ky - 1) >> 1 == Y:
+        // ty = -1: {2}, ty = +1: {0}, ty = 0: py ? {0, 1} : {1, 2} (columns likewise) -- 16 (block, cell) pairs instead of 4 x 9 pixel taps per cell.
+        const int pbw = (P.ca + GEN_KC - 1) / GEN_KC * GEN_KC, c = slot >> 2, ab = slot & 3, par = (c * GEN_KC) / pbw;
+        const int kk = c * GEN_KC - par * pbw + cin, py = par >> 1, px = par & 1, ty = (ab >> 1) - py, tx = (ab & 1) - px;
+        if (kk >= P.ca || col >= P.co) return 0.f;
+        const int ky0 = ty < 0 ? 2 : (ty > 0 ? 0 : (py ? 0 : 1)), ky1 = ty < 0 ? 2 : (ty > 0 ? 0 : (py ? 1 : 2));
+        const int kx0 = tx < 0 ? 2 : (tx > 0 ? 0 : (px ? 0 : 1)), kx1 = tx < 0 ? 2 : (tx > 0 ? 0 : (px ? 1 : 2));
+        float v = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) v += P.w[((size_t)(ky * 3 + kx) * P.ci_layer + P.ci_off + col) * P.ca + kk];
+        return v;
+    }
     const int tap = slot % 9, k = (slot / 9) * GEN_KC + cin;
     const int real = k < pa4 ? (k < P.ca ? k : -1) : (k - pa4 < P.cb ? P.ca + (k - pa4) : -1);
     float v = 0.f;
@@ -90,11 +105,15 @@ __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < P.total; e += gridDim.x * 256) P.wp[e] = gen4_pack_elem(P, e);
 }
 
-// FOLD (a layer over cat(A, nearest-up_2(B)), no pooling, no split): A's channels run as usual; B's are staged at B's OWN resolution (a
+// FOLD = 1 (a layer over cat(A, nearest-up_2(B)), no pooling, no split): A's channels run as usual; B's are staged at B's OWN resolution (a
 // quarter of the elements, no upsampling in the loader) and multiplied through the folded taps (gen4_pack_elem): 4 instead of 9 tap steps per
 // channel.  The folded weights depend on the pixel's parity, the A operand of the instruction is one register for the whole wave: wave w
 // takes position w of every 2 x 2 cell of the tile (lane = cell), not 64 consecutive pixels.
-template <int NG, bool FOLD>
+// FOLD = 2: the DATA gradient towards the upsampled source, computed at the source's resolution: input = the space-to-depth view of dY
+// (gen4_stage_s2d: 4 parity blocks of S.cb >= S.ca channels), output = one low-resolution cell per lane; a 16-channel chunk lies in one parity
+// block and meets 4 of the 9 cell offsets (gen4_pack_elem, transposed = 3): 16 (block, offset) steps per channel and cell where the full-resolution
+// form (9 taps per pixel, then the 2 x 2 cell sum in the epilogue) runs 36.
+template <int NG, int FOLD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,13 +126,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     const int pstride = P.rows * P.pw;
     float4* tile = g4sm;
     const G4Geo geo{P.n, P.hw, P.lw, P.imgs, P.th};
-    const int pa4 = gen_pa4(S), cp = FOLD ? pa4 : pa4 + S.cb;                              // channels of the full-resolution chunks
-    const int ncha = (cp + GEN_KC - 1) / GEN_KC, nchb = FOLD ? (S.cb + GEN_KC - 1) / GEN_KC : 0, nchunk = ncha + nchb;
+    const int pa4 = gen_pa4(S), cp = FOLD == 2 ? 0 : (FOLD ? pa4 : pa4 + S.cb);            // channels of the full-resolution chunks
+    const int ncha = (cp + GEN_KC - 1) / GEN_KC, nchb = FOLD == 2 ? (4 * S.cb) / GEN_KC : (FOLD ? (S.cb + GEN_KC - 1) / GEN_KC : 0), nchunk = ncha + nchb;
     // FOLD: B's tile = (th / 2 + 2) x (W / 2 + 2) low-resolution pixels per image part, in the same buffers (A's chunks are done by then)
     const int pwb = (P.hw >> 1) + 2, rowsb = P.imgs * ((P.th >> 1) + 2), pstrideb = rowsb * pwb;
     const G4Geo geob{P.n, P.hw >> 1, P.lw - 1, P.imgs, P.th >> 1};
     auto stage = [&](float4* dst, int ch, int ltid) {      // channel-planar tile: dst[(plane * rows + row) * pw + col], col 0 = left halo
-        if constexpr (FOLD) {
+        if constexpr (FOLD == 2) {
+            gen4_stage_s2d(G4Dst{dst, pstride, P.pw, 1, 1}, (const float*)S.a, S.ca, S.cb, geo, img0, row0, ch * GEN_KC, ltid);
+        } else if constexpr (FOLD == 1) {
             if (ch < ncha) {
                 const GenSrc SA{S.a, nullptr, nullptr, S.mode, S.ca, 0, 1};
                 gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, SA, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
@@ -143,7 +164,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     G4_STAMP(0);
 
     // this lane's pixel
-    const int p = FOLD ? 4 * lane + wave : wave * 64 + lane, q = p >> 2, pos = p & 3;
+    const int p = FOLD == 1 ? 4 * lane + wave : wave * 64 + lane, q = p >> 2, pos = p & 3;
     const int lqi = (lw - 1) + (P.th == 4 ? 1 : (P.th == 8 ? 2 : 3));        // log2(quads per image part) = log2((th / 2) * (hw / 2))
     const int il = q >> lqi, qi = q & ((1 << lqi) - 1), qy = qi >> (lw - 1), qx = qi & ((W >> 1) - 1);
     const int y = 2 * qy + (pos >> 1), x = 2 * qx + (pos & 1);
@@ -151,7 +172,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     // FOLD: low-resolution tile slot of fold (a, b) = baseb + a * pwb + b  (tile row (y >> 1) + a + py, column (x >> 1) + b + px)
     const int baseb = (il * ((P.th >> 1) + 2) + (y >> 1) + (pos >> 1)) * pwb + (x >> 1) + (pos & 1);
     // first weight slot of chunk c (FOLD: a B chunk starts at this wave's parity)
-    auto ctfirst = [&](int c) { return (!FOLD || c < ncha) ? c * 9 : ncha * 9 + (c - ncha) * 16 + 4 * pos; };
+    auto ctfirst = [&](int c) { return FOLD == 2 ? 4 * c : ((!FOLD || c < ncha) ? c * 9 : ncha * 9 + (c - ncha) * 16 + 4 * pos); };
 
     // zero halo columns (col 0 and col W + 1) of all four planes (of both buffers), once
     const int nbuf = P.dbuf ? 2 : 1;
@@ -187,8 +208,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
         }
         if (ch < 3) G4_STAMP(3 + 5 * ch);
         const bool bch = FOLD && ch >= ncha;
-        const int rem = bch ? S.cb - (ch - ncha) * GEN_KC : cp - ch * GEN_KC, np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
-        int lbase = bch ? baseb : base;
+        const int rem = FOLD == 2 ? GEN_KC : (bch ? S.cb - (ch - ncha) * GEN_KC : cp - ch * GEN_KC), np = rem >= GEN_KC ? 4 : (rem + 3) >> 2;
+        // FOLD = 2: the chunk's parity block (py, px) reads the cells at row offsets {-py, 1 - py}, column offsets {-px, 1 - px}
+        const int parc = FOLD == 2 ? (ch * GEN_KC) / S.cb : 0;
+        const int bpw = FOLD == 2 ? P.pw : pwb, bstride = FOLD == 2 ? pstride : pstrideb;
+        int lbase = FOLD == 2 ? base - (parc >> 1) * P.pw - (parc & 1) : (bch ? baseb : base);
         asm volatile("" : "+v"(lbase));
         const int ct0 = ctfirst(ch);
         // The tap loop per plane count NP (compile-time: straight-line matrix code -- with the plane / channel tests as run-time
@@ -237,9 +261,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
             } else if constexpr (FOLD) {
                 // the four folds (a, b) of this wave's parity: slots ct0 .. ct0 + 3; the next chunk's first slot lands in w0 behind the last
                 auto readb = [&](float4 (&xr)[NP], int ab) {
-                    const int a0 = lbase + (ab >> 1) * pwb + (ab & 1);
+                    const int a0 = lbase + (ab >> 1) * bpw + (ab & 1);
 #pragma unroll
-                    for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * pstrideb + a0];
+                    for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * bstride + a0];
                 };
 #pragma unroll 1
                 for (int ab = 0; ab < 4; ab += 2) {
@@ -464,17 +488,18 @@ static void gen4_groups(int co, int& npass, int& ng) {
     ng = per <= 1 ? 1 : per <= 2 ? 2 : per <= 4 ? 4 : per <= 6 ? 6 : per <= 8 ? 8 : 10;
 }
 
-long gen4_packed_floats(int ca, int cb, int co, int fold) {
+long gen4_packed_floats(int ca, int cb, int co, int fold) {      // fold = the pack mode's folded forms: 1 / 2 = forward fold, 3 = the s2d data gradient
     int npass, ng;
     gen4_groups(co, npass, ng);
     const int pa4 = (ca + 3) & ~3;
+    if (fold == 3) return (long)(4 * ((ca + GEN_KC - 1) / GEN_KC)) * 4 * npass * ng * 64;
     if (fold) return (long)(((pa4 + GEN_KC - 1) / GEN_KC) * 9 + ((cb + GEN_KC - 1) / GEN_KC) * 16) * npass * ng * 64;
     const int cp = pa4 + cb, nchunk = (cp + GEN_KC - 1) / GEN_KC;
     return (long)nchunk * 9 * npass * ng * 64;
 }
 
 int gen4_pack_launch(int ca, int cb, int co, int transposed, const float* w, float* wp, int ci_layer, int ci_off, hipStream_t st) {
-    const long total = gen4_packed_floats(ca, cb, co, transposed == 2);
+    const long total = gen4_packed_floats(ca, cb, co, transposed >= 2 ? transposed : 0);
     int npass, ng;
     gen4_groups(co, npass, ng);
     Gen4PackParams P{w, wp, ca, cb, co, transposed, (int)total, npass * ng, ci_layer, ci_off};
@@ -494,7 +519,7 @@ int gen4_pack_batch_launch(const Gen4PackJob* jobs, int njobs, hipStream_t st) {
             const Gen4PackJob& J = jobs[j0 + j];
             int npass, ng;
             gen4_groups(J.co, npass, ng);
-            const long total = gen4_packed_floats(J.ca, J.cb, J.co, J.transposed == 2);
+            const long total = gen4_packed_floats(J.ca, J.cb, J.co, J.transposed >= 2 ? J.transposed : 0);
             B.job[j] = Gen4PackParams{J.w, J.wp, J.ca, J.cb, J.co, J.transposed, (int)total, npass * ng, J.ci_layer, J.ci_off};
             most = total > most ? total : most;
         }
@@ -554,10 +579,26 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     const size_t epi = (size_t)256 * (4 * ng + 4) * sizeof(float);
     lds = lds > epi ? lds : epi;
     const dim3 grid(tiles * P.npass);
+    if (L.fold == 2) {
+        // src = the s2d view: a = dY [n, 2 hw, 2 hw, ca], cb = the parity block width (ca rounded up to 16)
+        if (L.pool || L.out2 || L.src.mode != GEN_SRC_F32 || (L.src.ca & 3) || (L.src.cb & 15) || L.src.cb < L.src.ca || hw > 32) return CGS_ERR_UNSUPPORTED;
+#define G4_LAUNCH_S(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, 2>), grid, dim3(256), lds, st, P)
+        switch (ng) {
+            case 1: G4_LAUNCH_S(1); break;
+            case 2: G4_LAUNCH_S(2); break;
+            case 4: G4_LAUNCH_S(4); break;
+            case 6: G4_LAUNCH_S(6); break;
+            case 8: G4_LAUNCH_S(8); break;
+            default: G4_LAUNCH_S(10); break;
+        }
+#undef G4_LAUNCH_S
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
     if (L.fold) {
         // (the operand was packed for the layer's own pass split: gen4_groups(co) -- the few-tiles re-split above reads the same buffer)
         if (L.src.cb <= 0 || L.src.ups != 2 || hw < 16 || L.pool || L.out2 || L.src.mode == GEN_SRC_POOLEXP) return CGS_ERR_UNSUPPORTED;
-#define G4_LAUNCH_F(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, true>), grid, dim3(256), lds, st, P)
+#define G4_LAUNCH_F(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, 1>), grid, dim3(256), lds, st, P)
         switch (ng) {
             case 1: G4_LAUNCH_F(1); break;
             case 2: G4_LAUNCH_F(2); break;
@@ -570,7 +611,7 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
         CGS_HIP_CHECK_LAUNCH();
         return CGS_OK;
     }
-#define G4_LAUNCH(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, false>), grid, dim3(256), lds, st, P)
+#define G4_LAUNCH(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, 0>), grid, dim3(256), lds, st, P)
     switch (ng) {
         case 1: G4_LAUNCH(1); break;
         case 2: G4_LAUNCH(2); break;

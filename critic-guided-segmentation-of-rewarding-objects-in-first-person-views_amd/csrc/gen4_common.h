@@ -118,6 +118,48 @@ __device__ __forceinline__ void gen4_stage(const G4Dst& D, const GenSrc& S, cons
     }
 }
 
+// Space-to-depth view of a full-resolution tensor src [n, 2H, 2W, cs] as a map at HALF resolution with 4 parity blocks of pbw >= cs channels each
+// (pbw a multiple of 16: a 16-channel chunk lies in one block): channel k = (2 py + px) * pbw + kk is src[2 y + py][2 x + px][kk] (zero for kk >= cs).
+// The loader of the data gradient towards a nearest-upsampled source (gen4_conv3x3_kernel<NG, 2>).  P = the HALF-resolution geometry.  cs % 4 == 0.
+template <int BATCH = 6>
+__device__ __forceinline__ void gen4_stage_s2d(const G4Dst& D, const float* src, int cs, int pbw, const G4Geo& P, int img0, int row0, int kbase, int tid) {
+    const int H = P.hw, W = P.hw, lw = P.lw;
+    constexpr int lp = 2;                                       // four planes: a chunk is 16 channels of one parity block
+    const int rpi = P.th + 2, rows = P.imgs * rpi;
+    const bool multi = P.imgs > 1;
+    const uint32_t mrpi = 65536u / (uint32_t)rpi + 1u;
+    const int rpr = 256 >> (lp + lw);
+    const int g = tid & 3, x = (tid >> lp) & (W - 1), rsub = tid >> (lp + lw);
+    const int k0 = kbase + 4 * g, par = k0 / pbw, kk = k0 - par * pbw, py = par >> 1, px = par & 1;
+    const bool kok = kk < cs;
+    const uint32_t offa = (uint32_t)(2 * x + px) * (uint32_t)cs + (uint32_t)(kok ? kk : 0), rs = 2u * (uint32_t)W * (uint32_t)cs;
+    float4* const dst0 = D.base + g * D.gstride + (x + D.xoff) * D.xstride;
+#pragma unroll 1
+    for (int rb = rsub; rb < rows; rb += rpr * BATCH) {
+        float4 raw[BATCH];
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            int r = rb + it * rpr;
+            r = r < rows ? r : rows - 1;
+            const int il = multi ? (int)(((uint32_t)r * mrpi) >> 16) : 0, rr = r - il * rpi;
+            const int y = row0 + rr - 1, yc = y < 0 ? 0 : (y >= H ? H - 1 : y);
+            int img = img0 + il;
+            img = img < P.n ? img : P.n - 1;
+            raw[it] = *(const float4*)(src + ((uint32_t)(img * 2 * H + 2 * yc + py) * rs + offa));
+        }
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            const int r = rb + it * rpr;
+            if (r < rows) {
+                const int il = multi ? (int)(((uint32_t)r * mrpi) >> 16) : 0, rr = r - il * rpi;
+                const int y = row0 + rr - 1;
+                const bool inb = kok && y >= 0 && y < H && img0 + il < P.n;
+                dst0[r * D.rstride] = inb ? raw[it] : f4zero();
+            }
+        }
+    }
+}
+
 template <int BATCH = 6>
 __device__ __forceinline__ void gen4_stage_any(const G4Dst& D, const GenSrc& S, const G4Geo& P, int halo, int img0, int row0, int kbase, int npmax, int tid) {
     if (S.mode == GEN_SRC_POOLEXP) return gen4_stage<GEN_K_POOLEXP, false, false, BATCH>(D, S, P, halo, img0, row0, kbase, npmax, tid);

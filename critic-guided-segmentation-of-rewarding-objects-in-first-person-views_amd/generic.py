@@ -17,6 +17,7 @@ from .spec import Layout
 
 UPS_FOLD = True             # forward of a layer over cat(A, nearest-up_2(B)) at hw >= 16: B staged at its own resolution, its 9 taps folded to 4 per pixel parity (gen4.hip, FOLD)
 WGRAD_FOLD = True           # weight gradient of a layer over cat(A, nearest-up_2(B)) at hw >= 16: A's rows by the row-block kernel, B's by gen_wgrad_fold_kernel on B at its own resolution (4 folds per parity class instead of 9 taps)
+DGRAD_UP2 = True            # data gradient towards a x2-upsampled source at the source's resolution (space-to-depth view of dY, 16 instead of 36 steps per cell; gen4.hip FOLD = 2)
 ENC0_DEDICATED = True       # features.0 (3 -> 8 chfak channels at 64x64) of chfak 2 .. 5 on csrc/gen_enc0.hip (False: the shape-generic gen4 kernel)
 _ACT = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "lrelu": _lib.ACT_LRELU, "sigmoid": _lib.ACT_SIGMOID}
 
@@ -94,7 +95,9 @@ def _pack(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool, ci_layer
         wp = plan.jobs.get(key)
         if wp is not None:
             return wp                                   # packed by the plan's launch at the start of this step
-    nfl = int(_lib.load().cgs_gen_conv_packed_floats_folded(ca, cb, co) if int(transposed) == 2 else _lib.load().cgs_gen_conv_packed_floats(ca, cb, co))
+    lib = _lib.load()
+    nfl = int(lib.cgs_gen_conv_packed_floats_up2(ca, co) if int(transposed) == 3 else
+              (lib.cgs_gen_conv_packed_floats_folded(ca, cb, co) if int(transposed) == 2 else lib.cgs_gen_conv_packed_floats(ca, cb, co)))
     if nfl <= 0:
         raise _lib.CgsError(f"generic conv: no packed form for ca={ca} cb={cb} co={co}")
     if plan is not None and not plan.frozen:
@@ -106,7 +109,9 @@ def _pack(w_ptr: int, ca: int, cb: int, co: int, dev, transposed: bool, ci_layer
         wp = _PACKED.get(scratch_key)
         if wp is None:
             wp = _PACKED[scratch_key] = torch.empty(nfl, device=dev, dtype=torch.float32)
-    if ci_layer > 0:
+    if int(transposed) == 3:
+        _lib.call("cgs_gen_conv_pack_weights_up2", ca, ci_layer, ci_off, co, C.c_void_p(w_ptr), _p(wp), _s())
+    elif ci_layer > 0:
         _lib.call("cgs_gen_conv_pack_weights_window", ca, ci_layer, ci_off, co, C.c_void_p(w_ptr), _p(wp), _s())
     else:
         _lib.call("cgs_gen_conv_pack_weights", ca, cb, co, int(transposed), C.c_void_p(w_ptr), _p(wp), _s())
@@ -126,6 +131,13 @@ def pack_weights_window(w_ptr: int, co_layer: int, ci_layer: int, ci_off: int, c
     """The data gradient's operand for input channels [ci_off, ci_off + ci_n) of a layer (cgs_gen_conv_pack_weights_window)."""
     di = dev.index if dev.index is not None else torch.cuda.current_device()
     return _pack(w_ptr, co_layer, 0, ci_n, dev, True, ci_layer, ci_off, (di, "window", co_layer, ci_layer, ci_off, ci_n))
+
+
+def pack_weights_up2(w_ptr: int, co_layer: int, ci_layer: int, ci_off: int, ci_n: int, dev) -> torch.Tensor:
+    """The operand of cgs_gen_conv3x3_bwd_data_up2: dY [co_layer channels] -> the cell-summed gradient of the x2-upsampled input channels
+    [ci_off, ci_off + ci_n) of a layer with HWIO weights [9][ci_layer][co_layer] at w_ptr."""
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    return _pack(w_ptr, co_layer, 0, ci_n, dev, 3, ci_layer, ci_off, (di, "up2", co_layer, ci_layer, ci_off, ci_n))
 
 
 def conv3x3(a: torch.Tensor, b: Optional[torch.Tensor], w_ptr: int, bias_ptr: int, co: int, act: str = "none",
@@ -541,8 +553,13 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
     # only the decoder channels of cat(X, up2(o0)) need a gradient: the operand covers input channels [3, 3 + d0) and the epilogue sums
     # the 2x2 cells (no d_cat tensor, no gradient for the image channels)
     d_o = ws.buf("d_o0", (n, 32, 32, d[0]), dev)
-    wpw = pack_weights_window(off("masker.0.weight"), mc, 3 + d[0], 3, d[0], dev)
-    rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, 64, mc, 0, d[0], 2, _p(d_hm), _p(wpw), None, _p(d_o), _s())
+    rc = _lib.ERR_UNSUPPORTED
+    if DGRAD_UP2 and mc % 4 == 0:
+        wpu = pack_weights_up2(off("masker.0.weight"), mc, 3 + d[0], 3, d[0], dev)
+        rc = _lib.load().cgs_gen_conv3x3_bwd_data_up2(n, 64, mc, d[0], _p(d_hm), _p(wpu), _p(d_o), _s())
+    if rc == _lib.ERR_UNSUPPORTED:
+        wpw = pack_weights_window(off("masker.0.weight"), mc, 3 + d[0], 3, d[0], dev)
+        rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, 64, mc, 0, d[0], 2, _p(d_hm), _p(wpw), None, _p(d_o), _s())
     if rc == _lib.ERR_UNSUPPORTED:
         dcat = ws.buf("dcat_m0", (n, 64, 64, 3 + d[0]), dev)
         _bwd_data(n, 64, mc, 3 + d[0], d_hm, None, _flip(ws, flat, lay, "masker.0", 3 + d[0], mc), dcat)
@@ -558,9 +575,19 @@ def masker_backward(flat: torch.Tensor, lay: Layout, grad: torch.Tensor, goff: i
         _wgrad(plan, ws, f"dec{i}", goff + lay.off(key + ".weight"), n, hw, embeds[i], low, ups, d_o, None, d[i])
         d_emb[i] = ws.buf(f"dEmb{i}", (n, hw, hw, ca), dev) if need_embed_grads else None
         d_low = ws.buf(f"d_o{i + 1}", (n, hw // ups, hw // ups, cb), dev)
-        # d_cat straight as (skip gradient, cell-summed low-resolution gradient) where the kernel's output passes allow it
-        wp = pack_weights(_flip(ws, flat, lay, key, ca + cb, d[i]), d[i], 0, ca + cb, dev, transposed=True)
-        rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, hw, d[i], ca, cb, ups, _p(d_o), _p(wp), _p(d_emb[i]), _p(d_low), _s())
+        rc = _lib.ERR_UNSUPPORTED
+        if DGRAD_UP2 and ups == 2 and hw >= 16 and d[i] % 4 == 0:
+            # the low-resolution gradient at its own resolution (16 instead of 36 steps per cell); the skip gradient (if anybody wants it) from
+            # the window of the skip channels alone
+            wpu = pack_weights_up2(off(key + ".weight"), d[i], ca + cb, ca, cb, dev)
+            rc = _lib.load().cgs_gen_conv3x3_bwd_data_up2(n, hw, d[i], cb, _p(d_o), _p(wpu), _p(d_low), _s())
+            if rc == 0 and d_emb[i] is not None:
+                wpa = pack_weights_window(off(key + ".weight"), d[i], ca + cb, 0, ca, dev)
+                _lib.call("cgs_gen_conv3x3_bwd_data", n, hw, d[i], ca, _p(d_o), None, _p(wpa), None, 0, _p(d_emb[i]), _s())
+        if rc == _lib.ERR_UNSUPPORTED:
+            # d_cat straight as (skip gradient, cell-summed low-resolution gradient) where the kernel's output passes allow it
+            wp = pack_weights(_flip(ws, flat, lay, key, ca + cb, d[i]), d[i], 0, ca + cb, dev, transposed=True)
+            rc = _lib.load().cgs_gen_conv3x3_bwd_data_split(n, hw, d[i], ca, cb, ups, _p(d_o), _p(wp), _p(d_emb[i]), _p(d_low), _s())
         if rc == _lib.ERR_UNSUPPORTED:
             dcat = ws.buf(f"dcat_d{i}", (n, hw, hw, ca + cb), dev)
             _bwd_data(n, hw, d[i], ca + cb, d_o, None, _flip(ws, flat, lay, key, ca + cb, d[i]), dcat)

@@ -543,6 +543,15 @@ int cgs_gen_conv3x3_bwd_data(int32_t n, int32_t hw, int32_t co, int32_t ci, cons
  * cgs_gen_conv_pack_weights_window).  CGS_ERR_UNSUPPORTED when ca is not a multiple of the kernel's output pass width.          */
 int cgs_gen_conv3x3_bwd_data_split(int32_t n, int32_t hw, int32_t co, int32_t ca, int32_t cb, int32_t ups, const float* dy,
                                    const float* wp, float* d_a, float* d_b, cgs_stream_t stream);
+/* The second output of cgs_gen_conv3x3_bwd_data_split for ups = 2 alone, computed at the source's resolution: d_b [n,hw/2,hw/2,ci_n] = the gradient of
+ * the x2-upsampled input channels [ci_off, ci_off + ci_n) of a layer (HWIO w [9][ci_layer][co_layer]) summed over each 2 x 2 cell, from dy [n,hw,hw,co_layer]
+ * read as its space-to-depth view -- 16 (parity block, cell offset) steps per channel and cell instead of 9 taps per pixel + the cell sum (36).
+ * hw 16 / 32 / 64, co_layer % 4 == 0; operand: cgs_gen_conv_pack_weights_up2 (cgs_gen_conv_packed_floats_up2(co_layer, ci_n) floats; in
+ * cgs_gen_conv_pack_batch: transposed = 3 with ca = co_layer, co = ci_n, ci_layer, ci_off).                                                     */
+int64_t cgs_gen_conv_packed_floats_up2(int32_t co_layer, int32_t ci_n);
+int cgs_gen_conv_pack_weights_up2(int32_t co_layer, int32_t ci_layer, int32_t ci_off, int32_t ci_n, const float* w, float* wp, cgs_stream_t stream);
+int cgs_gen_conv3x3_bwd_data_up2(int32_t n, int32_t hw, int32_t co_layer, int32_t ci_n, const float* dy, const float* wp, float* d_b,
+                                 cgs_stream_t stream);
 int cgs_gen_conv3x3_bwd_weight_slabs(int32_t n, int32_t ca, int32_t cb, int32_t co);
 int cgs_gen_conv3x3_bwd_weight(int32_t n, int32_t hw, int32_t ca, int32_t cb, int32_t co, int32_t a_is_u8, int32_t ups,
                                const void* src_a, const float* src_b, const float* dy, const uint8_t* dy_argmax, float* slab,

@@ -150,6 +150,38 @@ def test_gen4_data_gradient_matches_autograd(n, hw, ci, co, pooled):
     rel_close(out.cpu().numpy(), ref, "data gradient + addend")
 
 
+@pytest.mark.parametrize("n,hw,ca,cb,co", [
+    (2, 64, 3, 40, 16),        # masker.0 at chfak 5: one 16-channel chunk per parity block, ten output groups
+    (3, 32, 40, 40, 40),       # dec_model.0: parity blocks of 40 channels padded to 48 (three chunks, the last half empty)
+    (5, 16, 40, 40, 40),       # dec_model.1: low-resolution map 8 x 8, four images per tile (ragged: 5)
+    (2, 32, 16, 16, 16),       # chfak 2
+    (1, 64, 3, 24, 8),         # eight dY channels: a half-empty chunk per block; six output groups
+    (3, 32, 8, 44, 12),        # eleven output groups: two passes
+])
+def test_gen4_up2_data_gradient_vs_float64_autograd(n, hw, ca, cb, co):
+    """cgs_gen_conv3x3_bwd_data_up2: the gradient of conv3x3(cat(A, nearest-up_2(B))) w.r.t. B (nets.py:501-517 under autograd), from the
+    space-to-depth view of dY with 16 (parity block, cell offset) steps per cell, == float64 autograd through F.interpolate + conv2d, and ==
+    the 2 x 2 cell sums of the full-resolution data gradient (cgs_gen_conv3x3_bwd_data_split) up to rounding."""
+    from cgs_amd import _lib, generic as gen
+    rs = np.random.RandomState(hw + 7 * ca + 13 * cb + co)
+    dev = torch.device("cuda:0")
+    w = torch.from_numpy((rs.randn(9, ca + cb, co) / (3.0 * np.sqrt(ca + cb))).astype(np.float32))
+    dy = torch.from_numpy(rs.randn(n, hw, hw, co).astype(np.float32))
+    b = torch.zeros(n, cb, hw // 2, hw // 2, dtype=torch.float64, requires_grad=True)
+    a = torch.zeros(n, ca, hw, hw, dtype=torch.float64)
+    wt = w.double().view(3, 3, ca + cb, co).permute(3, 2, 0, 1).contiguous()
+    y = F.conv2d(torch.cat([a, F.interpolate(b, scale_factor=2, mode="nearest")], 1), wt, None, padding=1)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    ref = b.grad.permute(0, 2, 3, 1).float().numpy()
+    wd, dyd = w.to(dev), dy.to(dev)
+    out = torch.full((n, hw // 2, hw // 2, cb), float("nan"), device=dev)
+    wp = gen.pack_weights_up2(wd.data_ptr(), co, ca + cb, ca, cb, dev)
+    _lib.call("cgs_gen_conv3x3_bwd_data_up2", n, hw, co, cb, gen._p(dyd), gen._p(wp), gen._p(out), gen._s())
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    rel_close(got, ref, "d B at its own resolution")
+
+
 def test_gen4_rejects_bad_arguments():
     from cgs_amd import _lib
     lib = _lib.load()
