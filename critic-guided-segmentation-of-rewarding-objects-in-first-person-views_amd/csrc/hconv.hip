@@ -133,7 +133,10 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                     if (cr >= 0) idx = (tap * C::CIL + cr) * C::COL + ocl;
                 }
             }
-            wa[h][g][j] = EL::cvt(idx >= 0 ? P.w[idx] : 0.f);
+            // (unconditional load + select: `idx >= 0 ? P.w[idx] : 0` is a branch around the load, and every one of the 8 NM NP loads is then
+            //  waited for before the next is issued -- up to 72 dependent L1 / L2 round trips at the start of every workgroup)
+            const float wv = P.w[idx >= 0 ? idx : 0];
+            wa[h][g][j] = EL::cvt(idx >= 0 ? wv : 0.f);
         }
     float br[4] = {0.f, 0.f, 0.f, 0.f};
     float bl = 0.f;
@@ -141,9 +144,11 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ch = PAIR ? (4 * kq + r) & 7 : (QUAD ? r : 4 * kq + r);
-            br[r] = ch < CO ? P.bias[ch] : 0.f;
+            const float bv = P.bias[ch < CO ? ch : 0];
+            br[r] = ch < CO ? bv : 0.f;
         }
-        bl = ocl < CO ? P.bias[ocl] : 0.f;
+        const float bv = P.bias[ocl < CO ? ocl : 0];
+        bl = ocl < CO ? bv : 0.f;
     }
     int toff1[8];                               // CIN == 1: this lane's eight taps (8 kq + j, clamped: the weights of taps >= 9 are zero)
 #pragma unroll
