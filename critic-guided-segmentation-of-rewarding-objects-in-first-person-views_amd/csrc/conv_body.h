@@ -410,6 +410,15 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
                             b6[r] = (uint64_t)*(const uint32_t*)(P.mix_b + off) | ((uint64_t)*(const uint16_t*)(P.mix_b + off + 4) << 32);
                         }
                     }
+                    // ... and the quad's four z (+ the image's valuefak prediction) requested with them: read inside the position loop below, each
+                    // was a load -> s_waitcnt vmcnt(0) round trip of its own (nine dependent ones per strip in the ISA)
+                    [[maybe_unused]] float zq[4] = {0.f, 0.f, 0.f, 0.f};
+                    [[maybe_unused]] float vfp = 0.f;
+                    if constexpr (mix_epi_of<C>::value) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) zq[i] = P.mix_z[(size_t)(q.n * G::H + y0 + (i >> 1)) * G::W + x0 + (i & 1)];
+                        if (P.mix_vf_pred) vfp = P.mix_vf_pred[q.n];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         int y = y0 + (i >> 1), x = x0 + (i & 1);
@@ -447,10 +456,10 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
                                 const float av = (float)((a6[i >> 1] >> sh) & 255) * s255, bv = (float)((b6[i >> 1] >> sh) & 255) * s255;
                                 dsum = fmaf(bv - av, v[o], dsum);
                             }
-                            const float zi = P.mix_z[pix];
+                            const float zi = zq[i];
                             const float sg = zi > 0.f ? 1.f : (zi < 0.f ? -1.f : 0.f);
                             if (P.mix_vf_pred) {      // valuefak = 1 - pred (>= 0) weights |z| and, squared, z^2
-                                const float vf = 1.f - P.mix_vf_pred[q.n];
+                                const float vf = 1.f - vfp;
                                 dsum += P.mix_l1s * vf * sg + 2.f * P.mix_l2s * vf * vf * zi;
                             } else {                  // (the same expression as cgs_mix_bwd)
                                 dsum += P.mix_l1s * sg + 2.f * P.mix_l2s * zi;

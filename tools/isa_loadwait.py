@@ -7,7 +7,7 @@ for m in re.finditer(r'^(_Z\S+):.*\n', txt, re.M):
     name = m.group(1)
     if flt not in name:
         continue
-    i = m.end(); j = txt.find('s_endpgm', i)
+    i = m.end(); j = txt.find('.Lfunc_end', i)      # (a kernel may hold several s_endpgm: early returns)
     if j < 0:
         continue
     seq = []
