@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     const uint32_t mqd = 65536u / (uint32_t)qd + 1u;                     // item / qd by a multiply (exact below 5461 items)
     const int NAI = (th + 2) * W;                                        // NARROW: frame-tile pixels
     float4 st[KB + KD + KA];
+    [[maybe_unused]] uint8_t st8[KA > 0 ? KA : 1][3];                     // NARROW, uint8 frames: the raw bytes (converted in store(): v_cvt_f32_ubyte0 needs no mask)
     auto issue = [&](int u) __attribute__((always_inline)) {
         int ltid = tid;
         asm volatile("" : "+v"(ltid));
@@ -118,13 +119,13 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
                 const bool in = e < NAI && y >= 0 && y < W;
                 const uint32_t off = in ? (uint32_t)((img * W + y) * W + xa) * (uint32_t)P.ca : 0u;
                 const int c1 = P.ca > 1 ? 1 : 0, c2 = P.ca > 2 ? 2 : 0;
-                if (P.a_u8) {
-                    const uint8_t* s8 = (const uint8_t*)P.a + off;
-                    st[KB + KD + k] = make_float4((float)s8[0], (float)s8[c1], (float)s8[c2], 0.f);
-                } else {
-                    const float* s32 = (const float*)P.a + off;
-                    st[KB + KD + k] = make_float4(s32[0], s32[c1], s32[c2], 0.f);
-                }
+                // RAW bits only (converted in store()): a conversion here is a use of the loaded value -- the wait for it would also drain the B / dY
+                // loads issued above, and the whole prefetch with them.  Both forms are loaded (the one that is not the source's from offset 0): two
+                // exclusive branches loading into the same registers make the second one wait for everything in flight.
+                const uint8_t* s8 = (const uint8_t*)P.a + (P.a_u8 ? off : 0u);
+                const float* s32 = (const float*)P.a + (P.a_u8 ? 0u : off);
+                st[KB + KD + k] = make_float4(s32[0], s32[c1], s32[c2], 0.f);
+                st8[k][0] = s8[0]; st8[k][1] = s8[c1]; st8[k][2] = s8[c2];
             }
         }
     };
@@ -153,6 +154,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
                 const int e = ltid + 512 * k, xa = e & (W - 1), r = e >> lw, y = row0 - 1 + r;
                 const bool in = y >= 0 && y < W;
                 float4 v = st[KB + KD + k];
+                if (P.a_u8) v = make_float4((float)st8[k][0], (float)st8[k][1], (float)st8[k][2], 0.f);
                 v = make_float4(in ? v.x * sc : 0.f, in && P.ca > 1 ? v.y * sc : 0.f, in && P.ca > 2 ? v.z * sc : 0.f, 0.f);
                 *(float4*)(e < NAI ? ta + (r * PWA + 1 + xa) * 4 : tb + BUF - 16) = v;
             }
