@@ -650,12 +650,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             lde1b = ((const float4*)P.dE1)[(size_t)img * 512 + tid + 256];
         }
         uint32_t lam2 = 0;
+        int tl = tid;             // opaque per image: as loop invariants the per-thread 64-bit addresses of these guarded loads were hoisted out of the
+        asm volatile("" : "+v"(tl));      // image loop and two of them spilled -- each reload an s_waitcnt vmcnt(0) in front of the load it feeds
         if (tid < 128) {
-            le23 = ((const float4*)P.e2)[(size_t)img * 128 + tid];
-            if (P.dE2 && add) ldE2 = ((const float4*)P.dE2)[(size_t)img * 128 + tid];
-            if (tid < 64) lam2 = P.am2[(size_t)img * 64 + tid];
+            le23 = ((const float4*)P.e2)[(size_t)img * 128 + tl];
+            if (P.dE2 && add) ldE2 = ((const float4*)P.dE2)[(size_t)img * 128 + tl];
+            if (tid < 64) lam2 = P.am2[(size_t)img * 64 + tl];
         } else if (tid < 192) {
-            le23 = ((const float4*)P.e3)[(size_t)img * 64 + tid - 128];
+            le23 = ((const float4*)P.e3)[(size_t)img * 64 + tl - 128];
         }
         const uint32_t lam3 = P.am3[(size_t)img * 32 + (tid >> 3)];           // word of pooled pixel tid >> 4, channel half (tid >> 3) & 1
         const float ldE3 = (P.dE3 && add) ? P.dE3[(size_t)img * 256 + tid] : 0.f;
