@@ -45,6 +45,23 @@ struct DropCtx {
     bool on;
 };
 
+#ifndef CGS_KARG_PREFETCH
+#define CGS_KARG_PREFETCH 1
+#endif
+// One scalar load per 64-byte line of the kernel arguments, all in one batch, at the top of a kernel whose set-up reads its (several hundred bytes of)
+// arguments piecemeal: those reads are scalar loads from a segment the command processor has just written -- cold in the scalar cache -- and the compiler
+// waits for each small group before the next (SMEM returns out of order: any use is an s_waitcnt lgkmcnt(0)): ~20 dependent round trips to L2 at the start
+// of every workgroup of a launch, all workgroups in lockstep, nothing to hide them behind.  After this the set-up's loads hit the scalar cache.
+template <int BYTES>
+__device__ __forceinline__ void cgs_kernarg_prefetch() {
+    typedef __attribute__((address_space(4))) const uint32_t karg_t;
+    karg_t* ka = (karg_t*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (BYTES + 63) / 64; ++i) acc |= ka[16 * i];
+    asm volatile("" ::"s"(acc));
+}
+
 __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d) {
     DropCtx c;
     c.on = d.p > 0.f;

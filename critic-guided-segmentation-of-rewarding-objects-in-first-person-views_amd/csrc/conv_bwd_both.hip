@@ -9,6 +9,7 @@
 
 template <class CWG, class CDG, bool SPARSE>
 __global__ void __launch_bounds__(CWG::G::THREADS) conv_bwd_both_kernel(WgradParams pw, ConvParams pd, int nbw) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(WgradParams) + sizeof(ConvParams) + 8>();
     static_assert(CWG::G::THREADS == CDG::THREADS * CDG::CW, "both halves use the same workgroup size");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     if ((int)blockIdx.x < nbw) {
@@ -153,6 +154,7 @@ struct MixBwdArgs {
 
 template <class CWG, bool SPARSE>
 __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(WgradParams) + sizeof(ConvParams) + sizeof(MixBwdArgs) + 8>();
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];

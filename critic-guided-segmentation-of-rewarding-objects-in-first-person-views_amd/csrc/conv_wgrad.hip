@@ -71,6 +71,7 @@ static int launch_wgrad(WgradParams P, hipStream_t st) {
 // is a latency-bound 8 us launch of < 200 workgroups that only the step's final reduction waits for; as extra workgroups of this
 // launch it disappears behind the sparse gather (round 3: one dependent launch less on the critical path).
 __global__ void __launch_bounds__(256) wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(WgradParams) + sizeof(HeadWgradParams) + 8>();
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     if ((int)blockIdx.x < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;

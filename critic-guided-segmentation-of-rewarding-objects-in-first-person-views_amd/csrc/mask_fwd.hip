@@ -41,6 +41,7 @@ extern "C" int dbg_maskfwd_stamps(unsigned long long* stamps) { g_maskfwd_stamps
 
 template <int SRC>     // SRC_U8C3 / SRC_F32C3
 __global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(MaskFwdParams)>();
     using G = MG;
     // tiles: image strip (float4 planes, conv_tile.h layout) | o0 strip at its own resolution; after a strip's MFMAs the same
     // 32 KB are the waves' private areas for the h transposition (8 KB each)

@@ -387,6 +387,7 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
 // WG: produce slab2; W0: produce slab0 (needs img/o0); SRC: WSRC_U8 / WSRC_F32 image
 template <int TH, bool WG, bool W0, int SRC>
 __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(MHeadParams)>();
     using G = MHeadGeo<TH, W0>;
     constexpr int TRA = G::TRA, PW = G::PW, PS = G::PS;
     extern __shared__ __attribute__((aligned(16))) float4 smem[];

@@ -95,6 +95,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
     __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
     __shared__ float red[8][32], es[32], hs[32];
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncFwdParams) + 2 * sizeof(ConvParams)>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int o = tid & 31, kg = tid >> 5;
@@ -394,6 +395,7 @@ using T1F = TileP<16, 16, 16, 16, 292>;     // cat(e1, up(o2)) of the forward de
 // (conv3x3_body_pipe<FDec0P>: cat(e0, up(o1)) -> o0), every other co-resident workgroup ~4 us late (cgs_stagger).
 template <bool FUSED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P, ConvParams PC) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailDecFwdParams) + sizeof(ConvParams)>();
     extern __shared__ __attribute__((aligned(16))) float4 dec_conv_smem[];     // FUSED: dec_model.0's tiles + weights
     __shared__ __attribute__((aligned(16))) float t1[T1F::FLOATS];
     __shared__ __attribute__((aligned(16))) float t2[T8x24::FLOATS];
@@ -588,6 +590,7 @@ struct TailEncBwdParams {
 };
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams)>();
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
@@ -910,6 +913,7 @@ struct TailDecBwdLds {
 // starts ~4 us late, so the latency-bound chains of one half run under the matrix instructions of the other (cgs_stagger).
 template <bool FUSED>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_dec_bwd_kernel(TailDecBwdParams P, ConvParams PC) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailDecBwdParams) + sizeof(ConvParams)>();
     using L = TailDecBwdLds;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     if constexpr (FUSED) {
