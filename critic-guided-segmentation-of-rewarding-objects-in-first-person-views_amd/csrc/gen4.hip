@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
 // form (9 taps per pixel, then the 2 x 2 cell sum in the epilogue) runs 36.
 template <int NG, int FOLD>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(Gen4Params)>();
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const GenSrc& S = P.src;

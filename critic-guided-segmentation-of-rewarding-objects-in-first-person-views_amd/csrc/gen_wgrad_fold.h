@@ -26,6 +26,7 @@ struct GenWfParams {
 
 template <int RB, int NCOB, bool NARROW>
 __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(GenWfParams)>();
     extern __shared__ __attribute__((aligned(16))) float4 gfsm[];
     float* const sm = (float*)gfsm;
     constexpr int CS = 4 * RB, Q4 = RB;                                  // B's channels; quads per pixel

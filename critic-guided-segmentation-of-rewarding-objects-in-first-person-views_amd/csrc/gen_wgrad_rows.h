@@ -33,6 +33,7 @@ struct GenWrParams {
 
 template <int NCOB, int RBW, bool POOLED>
 __global__ void __launch_bounds__(512) gen_wgrad_rows_kernel(GenWrParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(GenWrParams)>();
     extern __shared__ __attribute__((aligned(16))) float4 gsm[];
     float* const sm = (float*)gsm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kq = lane >> 4;

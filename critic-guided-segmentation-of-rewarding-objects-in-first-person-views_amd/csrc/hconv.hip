@@ -100,6 +100,7 @@ struct H5Cfg {
 
 template <class C>
 __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(H5Params)>();
     using EL = typename C::EL;
     using v8 = typename EL::V8; using v4 = typename EL::V4; using S = typename EL::S;
     constexpr int HW = C::HW, TH = C::TH, CA = C::CA, CB = C::CB, CO = C::CO, CIN = C::CIN, TPM = C::TPM, NM = C::NM, PW = C::PW, PH = C::PH;

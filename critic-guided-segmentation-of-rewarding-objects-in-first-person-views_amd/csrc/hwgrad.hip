@@ -47,6 +47,7 @@ struct HWgParams {
 // DYPOOL: dY = a pooled gradient re-expanded while it is staged (the gradient goes where the forward maximum was): replaces cgs_bf16_pool_expand
 template <int HW, int CA, int CB, int CO, int TH, bool DYPOOL = false>
 __global__ void __launch_bounds__(256) hwgrad_kernel(HWgParams P) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(HWgParams)>();
     constexpr int CIN = CA + CB <= 4 ? 4 : (CA + CB <= 8 ? 8 : 16);             // channels of the LDS pixel
     constexpr int TPB = 16 / CIN, NB = (9 + TPB - 1) / TPB;                     // taps per 16-row block, row blocks
     constexpr int CA_REAL = CA == 4 ? 3 : CA, CI = CA_REAL + CB;
