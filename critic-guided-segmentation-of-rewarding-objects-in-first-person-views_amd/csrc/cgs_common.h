@@ -94,6 +94,33 @@ __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d, const void* sa
     return c;
 }
 
+#ifndef CGS_DROPCTX3
+#define CGS_DROPCTX3 1
+#endif
+// Three contexts at once: the three step-counter loads (each a scalar round trip to L2 -- the counter was written by the previous step's optimiser
+// kernel) are requested back to back BEFORE anything uses one of them; written as three drop_ctx calls the loads of the second and third context
+// sit behind the waits of the first one's argument reads.
+__device__ __forceinline__ void drop_ctx3(const cgs_dropout& da, const cgs_dropout& db, const cgs_dropout& dc, const void* safe,
+                                          DropCtx& ca, DropCtx& cb, DropCtx& cc) {
+    const bool ha = da.p > 0.f && da.step, hb = db.p > 0.f && db.step, hc = dc.p > 0.f && dc.step;
+    const uint64_t* pa = ha ? (const uint64_t*)da.step : (const uint64_t*)safe;
+    const uint64_t* pb = hb ? (const uint64_t*)db.step : (const uint64_t*)safe;
+    const uint64_t* pc = hc ? (const uint64_t*)dc.step : (const uint64_t*)safe;
+    const uint64_t va = *pa, vb = *pb, vc = *pc;
+    auto fill = [](DropCtx& c, const cgs_dropout& d, bool have, uint64_t v) {
+        c.on = d.p > 0.f;
+        c.p = d.p;
+        c.scale = c.on ? 1.f / (1.f - d.p) : 1.f;
+        c.site = d.site;
+        c.base = d.base;
+        c.key = make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+        const uint64_t s = have ? v : 0ull;
+        c.step_lo = (uint32_t)s;
+        c.step_hi = (uint32_t)(s >> 32);
+    };
+    fill(ca, da, ha, va); fill(cb, db, hb, vb); fill(cc, dc, hc, vc);
+}
+
 // Multipliers (0 or 1/(1-p)) for the four consecutive floats whose float4 index is idx4.
 __device__ __forceinline__ float4 drop_mult4(const DropCtx& c, uint32_t idx4) {
     uint4 r = philox4x32_10(make_uint4(idx4 + c.base, c.site, c.step_lo, c.step_hi), c.key);

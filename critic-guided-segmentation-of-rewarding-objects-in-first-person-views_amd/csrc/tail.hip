@@ -105,7 +105,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if constexpr (!FUSED) {
         if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
     }
+#if CGS_DROPCTX3
+    DropCtx d2, d3, dh;
+    drop_ctx3(P.drop_e2, P.drop_e3, P.drop_h1, P.w.b6, d2, d3, dh);
+#else
     const DropCtx d2 = drop_ctx(P.drop_e2, P.w.b6), d3 = drop_ctx(P.drop_e3, P.w.b6), dh = drop_ctx(P.drop_h1, P.w.b6);
+#endif
 
     // ---- once per workgroup: halos -> 0, conv weights -> registers (features.6: both channel groups; features.10: this wave's
     //      four output channels), head weights -> registers ----
@@ -621,7 +626,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5, half = lane & 32;
     const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
+#if CGS_DROPCTX3
+    DropCtx d2_, d3_, dh_;
+    drop_ctx3(P.drop_e2, P.drop_e3, P.drop_h1, P.w.w6, d2_, d3_, dh_);
+#else
     const DropCtx d2_ = drop_ctx(P.drop_e2, P.w.w6), d3_ = drop_ctx(P.drop_e3, P.w.w6), dh_ = drop_ctx(P.drop_h1, P.w.w6);
+#endif
     const bool has_pw = P.d_o4 != nullptr;
 
     // (the once-per-workgroup LDS set-up -- zero halos, convolution weights -- runs inside the first iteration, BEHIND the first
