@@ -399,20 +399,38 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     L.dz = L.w4p + G::W4P;             // dzpre tile with a 2-pixel halo
     const int tid = threadIdx.x;
 
-    for (int e = tid; e < G::W4P; e += 512) {
-        const int col = e & 15, oc = (e >> 4) & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
-        const int g = col >> 3, c = col & 7, v = v6 - 2 * g;      // pixel g of the pair sees window column v6 as v
-        float s = 0.f;
-        if (v >= 0 && v <= 3) {
+    // (every load of the table unconditional -- clamped index, selected afterwards -- and the loop unrolled: with `if (valid) s += P.w0[..]` each of the
+    //  4 x 12 loads per thread was a branch, a load and a wait of its own: 48 dependent round trips at the start of every workgroup, the whole launch in
+    //  lockstep behind them; the sum keeps its order, an absent term adds 0.f)
+    static_assert(G::W4P % 512 == 0 && G::W4P / 512 <= 12, "table rounds");
+    {
+        float wv[G::W4P / 512][4];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+        for (int k = 0; k < G::W4P / 512; ++k) {
+            const int e = tid + 512 * k;
+            const int col = e & 15, oc = (e >> 4) & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
+            const int g = col >> 3, c = col & 7, v = v6 - 2 * g;      // pixel g of the pair sees window column v6 as v
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    int ky = a + 2 - u, kx = b + 2 - v;
-                    if (ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2) s += P.w0[((ky * 3 + kx) * 11 + 3 + c) * 16 + oc];
-                }
+            for (int ab = 0; ab < 4; ++ab) {
+                const int ky = (ab >> 1) + 2 - u, kx = (ab & 1) + 2 - v;
+                const bool ok = v >= 0 && v <= 3 && ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2;
+                wv[k][ab] = P.w0[ok ? ((ky * 3 + kx) * 11 + 3 + c) * 16 + oc : 0];
+            }
         }
-        L.w4p[e] = s;
+#pragma unroll
+        for (int k = 0; k < G::W4P / 512; ++k) {
+            const int e = tid + 512 * k;
+            const int col = e & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
+            const int g = col >> 3, v = v6 - 2 * g;
+            float s = 0.f;
+#pragma unroll
+            for (int ab = 0; ab < 4; ++ab) {
+                const int ky = (ab >> 1) + 2 - u, kx = (ab & 1) + 2 - v;
+                const bool ok = v >= 0 && v <= 3 && ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2;
+                s += ok ? wv[k][ab] : 0.f;
+            }
+            L.w4p[e] = s;
+        }
     }
     for (int e = tid; e < 2 * TRA * 2 * 16; e += 512) {      // zero halo columns of both dH tiles (never written again)
         int ch = e & 15, side = (e >> 4) & 1, r = (e >> 5) % TRA, bufi = e / (32 * TRA);
