@@ -427,16 +427,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     } while (0)
     if (img < P.n) DEC_FWD_FETCH(img);
 
-    tilep_zero<T1F>(t1, tid);
-    tile_zero<T8x24>(t2, tid);
-    tile_zero<T4x48>(t3, tid);
-    for (int e = tid; e < 216 * 8 / 4; e += 256) ((float4*)w2s)[e] = ((const float4*)P.w.w2)[e];
+    // (every load of the set-up requested before the first LDS store: as a copy loop dec_model.2's weights were two load -> wait -> store rounds
+    //  in front of the register images' loads -- three dependent round trips per workgroup, the whole launch in lockstep)
+    const float4 w2a = ((const float4*)P.w.w2)[tid], w2b = ((const float4*)P.w.w2)[tid + 256 < 216 * 8 / 4 ? tid + 256 : 0];      // (scalars: a small array here lands in scratch)
     // dec_model.1 on v_mfma_f32_4x4x1 with lane = pixel (tail4.h): both channel groups' weights in 18 registers
     float wr1[2][9];
     fill_wreg<2, 9, 144>(wr1, lane, [&](int step, int co) { return P.w.w1[step * 8 + co]; });
+    const float b2 = P.w.b2[l15 & 7];
+    __builtin_amdgcn_sched_barrier(0);       // (the loads above stay above: the scheduler sinks them to their first use otherwise)
+    tilep_zero<T1F>(t1, tid);
+    tile_zero<T8x24>(t2, tid);
+    tile_zero<T4x48>(t3, tid);
+    ((float4*)w2s)[tid] = w2a;
+    if (tid + 256 < 216 * 8 / 4) ((float4*)w2s)[tid + 256] = w2b;
     const PxPos pa = px16(wave, lane);
     const cgs_cptr b1c = cgs_to_const(P.w.b1);
-    const float b2 = P.w.b2[l15 & 7];
     __syncthreads();
 
     for (; img < P.n; img += P.nblocks) {
