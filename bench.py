@@ -82,8 +82,12 @@ def parse():
                     help="--gpus 1 only: create a ONE-rank RCCL group and keep the data-parallel launch form (step graph -> all-reduce -> Adam): "
                          "rehearses the N > 1 code path on a 1-GPU box")
     ap.add_argument("--dp-eager-allreduce", action="store_true",
-                    help="data parallel: keep the gradient all-reduce OUTSIDE the HIP graphs (step graph -> eager all-reduce -> Adam graph, the "
-                         "round-3 form); default = the collective is captured into the step graph when the RCCL trial capture succeeds")
+                    help="data parallel: keep the gradient all-reduce OUTSIDE the HIP graphs (step graph -> eager all-reduce -> Adam graph). "
+                         "This is the default at --gpus N > 1 until an N > 1 RCCL run has exercised the captured form; on the 1-rank "
+                         "--force-pg rehearsal the default is the captured form")
+    ap.add_argument("--dp-graph-allreduce", action="store_true",
+                    help="data parallel, N > 1: record the gradient all-reduce in the step's HIP graph (one graph launch per step) when the "
+                         "trial capture + replay succeeds on EVERY rank (the decision is an all-reduced flag: parallel.collective_capturable)")
     ap.add_argument("--chfak", type=int, default=1, help="other model sizes (5 = the paper's) on the shape-generic kernels: --mode train or infer, one GPU, secondary measurement")
     ap.add_argument("--config", type=int, default=0,
                     help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart) on the bf16 "
@@ -94,6 +98,28 @@ def parse():
                     help="untimed graph replays for this many seconds right after capture (before the --warmup steps): lets the chip's "
                          "clocks settle from idle so that a short --steps/--warmup run measures the steady state; never inside the timed region")
     return ap.parse_args()
+
+
+def dp_graph_arg(args):
+    """--dp-eager-allreduce -> False, --dp-graph-allreduce -> True, neither -> None (parallel.resolve_dp_graph: graph form on a 1-rank
+    group, eager at N > 1, CGS_DP_GRAPH overrides)."""
+    if args.dp_eager_allreduce:
+        return False
+    return True if args.dp_graph_allreduce else None
+
+
+def rccl_report(dist, dev, rank, world):
+    """RCCL's own view of the job, printed by every rank on stderr and returned for the JSON line: library version, the ranks and
+    devices the communicator spans (gathered through a collective, so it is what the backend saw, not what the launcher intended)."""
+    ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    mine = torch.tensor([rank, torch.cuda.current_device(), os.getpid()], device=dev, dtype=torch.int64)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    members = [{"rank": int(t[0]), "device": int(t[1]), "pid": int(t[2])} for t in allr]
+    name = torch.cuda.get_device_name(dev)
+    print(f"[bench] rank {rank}: RCCL {ver} (torch backend 'nccl'), world {world}, device {torch.cuda.current_device()} = {name}; "
+          f"communicator members: {members}", file=sys.stderr, flush=True)
+    return {"version": ver, "members": members, "device_name": name, "nccl_debug": os.environ.get("NCCL_DEBUG")}
 
 
 def synthetic(n, rank, dev):
@@ -311,7 +337,7 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
     from oracle import hourglass_ref as orc          # only for the seeded stand-in weights (shape tables + RandomState draw)
     n = 256 if args.batch == 512 else args.batch
     net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev,
-                                    process_group=pg, force_allreduce=args.force_pg, dp_graph=not args.dp_eager_allreduce)
+                                    process_group=pg, force_allreduce=args.force_pg, dp_graph=dp_graph_arg(args))
     X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(10 * rank)).to(dev)
     train = args.mode == "train"
     if train:
@@ -444,7 +470,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    ranks_seen, backend = 1, None
+    ranks_seen, backend, rccl_view = 1, None, None
     if world > 1 or args.force_pg:     # (forced: a 1-rank RCCL group, to rehearse the N>1 code path)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -454,6 +480,7 @@ def main():
         ranks_seen, backend = dist.get_world_size(), dist.get_backend()
         if ranks_seen != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the collective backend sees {ranks_seen} ranks")
+        rccl_view = rccl_report(dist, dev, rank, world)
 
     from cgs_amd import engine
     n = args.batch
@@ -471,7 +498,7 @@ def main():
     if args.mode != "train":
         return side_mode(args, dev, world, rank)
     eng = engine.HourglassEngine(n, device=dev, dropout=args.dropout, use_graph=not args.no_graph, process_group=pg,
-                                 force_allreduce=args.force_pg, dp_graph=not args.dp_eager_allreduce)
+                                 force_allreduce=args.force_pg, dp_graph=dp_graph_arg(args))
     eng.load_state(*g1_weights())
     A, B, Y = synthetic(n, rank, dev)
     eng.phase2_step(A, B, Y)            # inputs become resident; first call = eager step + graph capture
@@ -550,6 +577,8 @@ def main():
                        "parallelism": f"dp{world}", "hip_graph": not args.no_graph, "priming_steps_untimed": primed,
                        "ranks_seen_by_collective_backend": ranks_seen, "collective_backend": backend,
                        "per_rank_ms_per_step": per_rank_ms, "allreduce_in_step_graph": bool(getattr(eng, "dp_single_graph", False)),
+                       "allreduce_launch_form_note": getattr(eng, "dp_capture_note", None) if pg is not None else None,
+                       "rccl": rccl_view,
                        "gradient_allreduce": (("one flat fp32 bucket (25 661 floats) per step, " +
                                                ("recorded in the step's HIP graph (one graph launch per step)" if eng.dp_single_graph
                                                 else f"eager between the two step graphs ({eng.dp_capture_note})")) if pg is not None else None)},

@@ -15,6 +15,7 @@ from typing import Iterable, Sequence, Tuple
 import numpy as np
 
 DATA_DIR = "runs/data/straight/"
+Y_ROWS = 7      # main.py:1296: the target array always has 7 rows (0/1 reward + up to 6 discount rows; unused rows stay zero) -- G11
 
 
 def dataset_path(envname="Treechop", datamode="trunk", datasize=100000, gammas="0.98-0.97-0.96-0.95", data_dir=DATA_DIR) -> str:
@@ -58,7 +59,9 @@ def build_dataset(episodes: Iterable[Tuple[np.ndarray, np.ndarray]], size: int, 
                   gammas: Sequence[float] = (0.98, 0.97, 0.96, 0.95)):
     """Episode list -> (X, Y, I) exactly as collect_data fills them (main.py:1293-1350), for modes "trunk" and "begin"."""
     X = np.zeros((size, 64, 64, 3), dtype=np.uint8)
-    Y = np.zeros((1 + len(gammas), size), dtype=np.float64)
+    if 1 + len(gammas) > Y_ROWS:
+        raise ValueError(f"at most {Y_ROWS - 1} discount factors fit the reference's [{Y_ROWS}, N] target array (main.py:1296)")
+    Y = np.zeros((Y_ROWS, size), dtype=np.float64)
     I = np.zeros(size, dtype=np.uint16)
     run = 0
     add = 0

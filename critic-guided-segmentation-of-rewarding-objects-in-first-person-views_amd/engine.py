@@ -35,7 +35,7 @@ class HourglassEngine:
                  inject: bool = True, live: bool = True, threshrew: float = 0.0, seed: int = 0x5EED,
                  lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
                  process_group=None, share_with: "HourglassEngine" = None, separate: bool = False, staticnorm: bool = True,
-                 force_allreduce: bool = False, dp_graph: bool = True):
+                 force_allreduce: bool = False, dp_graph: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.CgsError("HourglassEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -50,9 +50,9 @@ class HourglassEngine:
         # data parallel: the all-reduce sits between the step graph and the Adam graph.  force_allreduce keeps that
         # form for a 1-rank group too (rehearsal of the RCCL path on a 1-GPU box).
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
-        # dp_graph: record the all-reduce into the step's HIP graph when the backend allows it (RCCL); False keeps the round-3 form
-        # step graph -> eager all-reduce -> Adam graph
-        self.dp_graph, self.dp_single_graph, self.dp_capture_note = bool(dp_graph), False, None
+        # dp_graph: record the all-reduce into the step's HIP graph when the backend allows it (RCCL, decided collectively); False keeps the
+        # form step graph -> eager all-reduce -> Adam graph; None = parallel.resolve_dp_graph (graph on a 1-rank group, eager at world > 1)
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = parallel.resolve_dp_graph(dp_graph, self.world), False, None
         self.lc, self.lm = critic_layout(), masker_layout()
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         # -separate (main.py:110-111, 390): a second critic supplies the masker's skip inputs; its parameters sit behind the
@@ -434,7 +434,7 @@ class HourglassEngine:
         rehearsals stage through the host) and a trial capture + replay of a small all-reduce on this group succeeds.  The reason for
         a refusal is kept in self.dp_capture_note (bench.py prints it)."""
         if not self.dp_graph:
-            self.dp_capture_note = "disabled by the caller (dp_graph=False)"
+            self.dp_capture_note = "not requested (dp_graph False; the default at world > 1, see parallel.resolve_dp_graph)"
             return False
         if getattr(self, "_capturable", None) is not None:
             return self._capturable

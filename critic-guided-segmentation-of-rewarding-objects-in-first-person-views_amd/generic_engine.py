@@ -8,13 +8,14 @@ Per phase-2 step:  critic fwd [B|A] -> masker fwd A -> mixes (materialised, fp32
   -> critic data-gradient pass on [rep|inj] (down to the images) -> mix backward -> masker backward
   -> critic data-gradient pass on A (skip gradients added) -> ONE weight-gradient pass of the critic over [A|rep|inj]
   -> slab reduction [-> all-reduce] -> Adam."""
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
 from . import _lib
 from . import generic as gen
 from . import hourglass as hg
+from . import parallel
 from .engine import HourglassEngine, _align4
 from .spec import critic_layout, masker_layout
 
@@ -27,7 +28,7 @@ class GenericEngine(HourglassEngine):
                  L1: float = 0.5, L2: float = 0.0, inject: bool = True, live: bool = True, threshrew: float = 0.0,
                  seed: int = 0x5EED, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, use_graph: bool = True,
                  process_group=None, share_with: "GenericEngine" = None, separate: bool = False, staticnorm: bool = True,
-                 force_allreduce: bool = False):
+                 force_allreduce: bool = False, dp_graph: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.CgsError("GenericEngine needs an MI355X (HIP device); there is no CPU fallback")
         _lib.load()
@@ -41,7 +42,7 @@ class GenericEngine(HourglassEngine):
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.rank = torch.distributed.get_rank(process_group) if process_group is not None else 0
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
-        self.dp_graph, self.dp_single_graph, self.dp_capture_note = True, False, None     # see HourglassEngine
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = parallel.resolve_dp_graph(dp_graph, self.world), False, None     # see HourglassEngine
         self.lc, self.lm = critic_layout(self.chfak, self.neck), masker_layout(self.chfak, self.neck)
         self.off_c, self.off_m = 0, _align4(self.lc.total)
         self.separate, self.staticnorm = bool(separate), bool(staticnorm)

@@ -2,11 +2,14 @@
 (main.py:66-156, 158-236, 238-312, 314-575, 584-591, 1103-1223) with its inner loops replaced by the fused
 HIP engine.  Same method names, same checkpoint / dataset file naming, same output file names.
 
-Out of scope here: MineRL collection (``collect_data`` only reads an existing
-gz-pickle), CRF, videos / PNG debug grids.  ``-eval`` (section 8 f2) is carried over without CRF / videos.
+Out of scope here: CRF, videos / PNG debug grids.  ``collect_data`` reads an existing gz-pickle or, when the
+``minerl`` package is importable, builds it from MineRL episodes exactly as the reference labels them (the MineRL download / decoder
+itself is the package's; it is absent from this image).  ``-eval`` (section 8 f2) is carried over without CRF / videos.
 """
+import gzip
 import math
 import os
+import pickle
 
 import numpy as np
 import torch
@@ -56,6 +59,12 @@ class Handler:
         self.save_paths = {name: f"{self.save_path}{name}-{tag}.pt"
                            for name, tag in ((self.criticname, self.critic_args), (self.maskername, self.masker_args))}
         self._engines = {}
+        self._trace = None          # tests set a dict of lists (Handler.start_trace): per-step indices / losses of the two training loops
+
+    def start_trace(self):
+        """Keep every step's frame indices, shift and loss values of critic_pipe / segmentation_training (device clones, no host sync)."""
+        self._trace = {"p1_idx": [], "p1_loss": [], "p2_idx": [], "p2_roll": [], "p2_loss": []}
+        return self._trace
 
     # ------------------------------------------------------------------ models / checkpoints
     def reset_models(self):
@@ -91,13 +100,46 @@ class Handler:
         filepath = dataformat.dataset_path(args.envname, args.datamode, args.datasize, args.gammas, self.data_path)
         print("collecting dataset at", filepath)
         if not os.path.exists(filepath):
-            raise FileNotFoundError(
-                f"{filepath} not found. This build reads the reference's gz-pickle (X uint8 [N,64,64,3], Y float [7,N], "
-                "I uint16 [N]) but does not collect it: MineRL download/decoding is out of scope (SURVEY.md 2.3).")
+            return self._collect_fresh(filepath)
         print("loading existing dataset...")
         X, Y, I = dataformat.read_dataset(filepath)
         print("finished loading exisiting dataset")
         return X, Y, I
+
+    def _collect_fresh(self, filepath):
+        """main.py:1286-1359: no pickle yet -> read MineRL episodes through the `minerl` package (imported lazily; absent in this image,
+        where only a test stub stands in for it), label them (dataformat.build_dataset: trunk filter main.py:1325, clipped discounted
+        rewards main.py:1336-1346) and write the gz-pickle.  Like the reference, the pickle holds the rows that were filled and the
+        RETURNED arrays are the full --datasize + --testsize buffers (zero rows at the end when the episodes ran out)."""
+        args = self.args
+        try:
+            import minerl
+        except ImportError as e:
+            raise FileNotFoundError(
+                f"{filepath} not found and the `minerl` package is not installed. This build reads the reference's gz-pickle (X uint8 "
+                "[N,64,64,3], Y float [7,N], I uint16 [N]); collecting it from MineRL needs `minerl` + its data (SURVEY.md 2.3).") from e
+        root = os.getenv("MINERL_DATA_ROOT", "data/")
+        env = f"MineRL{args.envname}VectorObf-v0"
+        os.makedirs(self.data_path, exist_ok=True)
+        if not os.path.exists(f"{root}/{env}"):
+            minerl.data.download(root, experiment=env)
+        data = minerl.data.make(env, data_dir=root, num_workers=args.workers[0], worker_batch_size=args.workers[1])
+        size = args.datasize + args.testsize
+        print("collecting straight data set with", args.datasize, "+", args.testsize, "frames")
+
+        def episodes():
+            for name in data.get_trajectory_names():
+                state, _action, reward, _next, _done = zip(*data.load_data(name))
+                yield np.stack([s["pov"] for s in state]), np.array(reward)
+        X, Y, I = dataformat.build_dataset(episodes(), size, mode=args.datamode, gammas=[float(g) for g in args.gammas.split("-")])
+        rows = len(X)
+        with gzip.GzipFile(filepath, "wb") as fp:
+            pickle.dump((X, Y, I), fp)
+        Xf = np.zeros((size, 64, 64, 3), dtype=np.uint8)
+        Yf = np.zeros((dataformat.Y_ROWS, size), dtype=np.float64)
+        If = np.zeros(size, dtype=np.uint16)
+        Xf[:rows], Yf[:, :rows], If[:rows] = X, Y, I
+        return Xf, Yf, If
 
     def load_data(self, batch_size=64):
         """Train / test split (the last --testsize frames are the test set) and the --threshrew binarisation (main.py:113-128)."""
@@ -110,12 +152,15 @@ class Handler:
         self.batch_size = batch_size
 
     def _batches(self):
-        """Shuffled mini-batches of (X uint8, Y[rewidx]) like the reference's DataLoader(shuffle=True)."""
-        n = len(self.X)
-        perm = torch.randperm(n).numpy()
-        for b in range(0, n, self.batch_size):
-            idx = np.sort(perm[b:b + self.batch_size])
-            yield torch.from_numpy(self.X[idx]), torch.from_numpy(self.Y[self.args.rewidx, idx]).float()
+        """Shuffled mini-batches of (X uint8, Y[rewidx], frame indices) in the order the reference's
+        DataLoader(TensorDataset(X, Y.t(), arange), batch_size, shuffle=True) yields them (main.py:125-129): the index stream comes from
+        the same torch.utils.data.DataLoader over the frame indices, so a seeded run draws from the global torch RNG exactly as the
+        reference does (one base-seed draw per epoch, one sampler-seed draw, the permutation from the sampler's private generator) and
+        the shift draws that follow line up with the reference's (pinned by the G9 capture, tests/test_gpu_loops.py)."""
+        order = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(len(self.X))), batch_size=self.batch_size, shuffle=True)
+        for (idx_t,) in order:
+            idx = idx_t.numpy()
+            yield torch.from_numpy(self.X[idx]), torch.from_numpy(self.Y[self.args.rewidx, idx]).float(), idx
 
     def _shift_draw(self):
         """The two draws main.py:585-586 takes from the global torch RNG, as a signed roll along the width (positive = the
@@ -190,11 +235,14 @@ class Handler:
             if args.noevalmode:
                 self.critic.train()
         for epoch in range(int(mode == "test") or args.cepochs):
-            for b_idx, (X, Y) in enumerate(self._batches()):
+            for b_idx, (X, Y, idx) in enumerate(self._batches()):
                 if args.shift:
                     X = self.shift_batch(X)
                 eng = self._engine(len(X), dropout=self._p1_dropout)
                 losses = eng.phase1_step(X.contiguous().to(self.device, non_blocking=True), Y.to(self.device, non_blocking=True))
+                if self._trace is not None:      # (tests: the loop-level pin G9) no host sync: device clones
+                    self._trace["p1_idx"].append(idx.copy())
+                    self._trace["p1_loss"].append(losses[:1].clone())
                 if not b_idx % 10:
                     val = float(losses[0])       # the only host sync, every 10th batch
                     llog.append(val)
@@ -318,6 +366,10 @@ class Handler:
                 eng.gather_contrastive(self._Xpos_d, self._Xneg_d, self._ypos_d, self._yneg_d, idx_dev, shift_px=(-roll) % 64)
                 losses = eng.phase2_step()
                 steps += 1
+                if self._trace is not None:      # (tests: the loop-level pin G9)
+                    self._trace["p2_idx"].append(np.concatenate((Hidx, Lidx, Cidx)))
+                    self._trace["p2_roll"].append(roll)
+                    self._trace["p2_loss"].append(losses[:6].clone())
                 if steps == 20:                                      # throughput is reported for the steady state (after the
                     torch.cuda.synchronize()                         # eager first step and the graph capture)
                     t0, steps_t0, dt = time.perf_counter(), steps, 0.0

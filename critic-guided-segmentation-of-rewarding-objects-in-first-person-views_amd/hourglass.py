@@ -488,15 +488,20 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             if m0pack is None:
                 m0pack = o["m0pack"] = torch.empty(40 * 64, device=dev, dtype=torch.float32)
         dec0_done = False
-        if DEC_TAIL_DEC0_FUSED and n <= 1024:
+        if DEC_TAIL_DEC0_FUSED:
+            # one workgroup per image up to the library's own cap (tail_fwd_cap in csrc/tail.hip): beyond it the entry point answers
+            # CGS_ERR_UNSUPPORTED and the two-launch form below runs -- the cap is not restated here
             if o.get("o0") is None:
                 o["o0"] = torch.empty((n, 32, 32, 8), device=dev, dtype=torch.float32)
-            _lib.call("cgs_tail_dec_fwd_dec0", n, C.byref(tw), _p(embeds[0]), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
-                      _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("dec_model.0.weight")),
-                      C.c_void_p(fp + 4 * lay.off("dec_model.0.bias")), _p(o["o0"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack),
-                      _stream())
-            dec0_done = True
-        else:
+            rc = _lib.load().cgs_tail_dec_fwd_dec0(n, C.byref(tw), _p(embeds[0]), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
+                                                   _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("dec_model.0.weight")),
+                                                   C.c_void_p(fp + 4 * lay.off("dec_model.0.bias")), _p(o["o0"]),
+                                                   C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack), _stream())
+            if rc == 0:
+                dec0_done = True
+            elif rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cgs_tail_dec_fwd_dec0")
+        if not dec0_done:
             _lib.call("cgs_tail_dec_fwd_pack", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(o["o4"]),
                       _p(o["o3"]), _p(o["o2"]), _p(o["o1"]), C.c_void_p(fp + 4 * lay.off("masker.0.weight")), _p(m0pack), _stream())
         prev = o["o0"] if dec0_done else o["o1"]

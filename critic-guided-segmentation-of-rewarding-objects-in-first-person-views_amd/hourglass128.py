@@ -64,7 +64,7 @@ class Hourglass128:
 
     def __init__(self, critic_params: Dict[str, torch.Tensor], masker_params: Dict[str, torch.Tensor], device="cuda:0", chfak: int = 1,
                  neck: int = 32, masker_channels: int = 16, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, lfak: float = 5.0,
-                 L1: float = 0.5, L2: float = 0.0, process_group=None, force_allreduce: bool = False, dp_graph: bool = True):
+                 L1: float = 0.5, L2: float = 0.0, process_group=None, force_allreduce: bool = False, dp_graph: Optional[bool] = None):
         if not torch.cuda.is_available():
             raise _lib.CgsError("Hourglass128 needs an MI355X (HIP device); there is no CPU fallback")
         self.lib = _lib.load()
@@ -80,7 +80,7 @@ class Hourglass128:
         # data parallel (one replica per rank, the flat gradient bucket all-reduced before Adam; force_allreduce: also on a 1-rank group, the
         # rehearsal of the N > 1 launch form).  dp_graph: record the collective in the step's HIP graph when RCCL allows (parallel.collective_capturable)
         self.dp = process_group is not None and (self.world > 1 or force_allreduce)
-        self.dp_graph, self.dp_single_graph, self.dp_capture_note = dp_graph, False, None
+        self.dp_graph, self.dp_single_graph, self.dp_capture_note = parallel.resolve_dp_graph(dp_graph, self.world), False, None
         f = lambda t: t.detach().to(dev, torch.float32).contiguous()
         # ---- layout: (key, kind, shape info) in flat order; conv = [9 ci co | co], gemm = [k n | n] ----
         self.convs = {}      # key -> (ca, cb, co)
@@ -675,7 +675,7 @@ class Hourglass128:
             capturable = not self.dp
             if use_graph and self.dp:
                 if not self.dp_graph:
-                    self.dp_capture_note = "disabled by the caller (dp_graph=False)"
+                    self.dp_capture_note = "not requested (dp_graph False; the default at world > 1, see parallel.resolve_dp_graph)"
                 else:
                     capturable, self.dp_capture_note = parallel.collective_capturable(self.pg, self.dev)
             if use_graph and capturable:        # data parallel: kernels -> all-reduce -> Adam as ONE graph launch per step

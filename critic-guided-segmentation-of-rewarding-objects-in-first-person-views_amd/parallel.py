@@ -73,23 +73,56 @@ def broadcast_params_(flat: torch.Tensor, group=None, src: int = 0) -> torch.Ten
     return flat
 
 
+def resolve_dp_graph(dp_graph, world: int) -> bool:
+    """The default launch form of the data-parallel step.  dp_graph None = "the safe default": the all-reduce is recorded in the step's HIP
+    graph on a ONE-rank group (the rehearsal the GPU tests and `bench.py --force-pg` run) and stays OUTSIDE the graphs (step graph -> eager
+    all-reduce -> Adam graph, +~17 us per step) when world > 1, because no N > 1 RCCL run has exercised the captured form yet (there is no
+    second GPU on the build's boxes).  CGS_DP_GRAPH=1 / dp_graph=True opt in at world > 1 (the decision is then taken collectively by
+    collective_capturable); dp_graph=False forces the eager form everywhere."""
+    if dp_graph is None:
+        env = os.environ.get("CGS_DP_GRAPH")
+        if env is not None:
+            return env not in ("", "0")
+        return world <= 1
+    return bool(dp_graph)
+
+
+def _agree_all(ok: bool, group, dev) -> bool:
+    """Logical AND of a per-rank flag over the group (one eager MIN all-reduce): every rank gets the same answer."""
+    f = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
+    return bool(f.item() == 1.0)
+
+
 def collective_capturable(group, dev):
-    """(ok, note): can a gradient all-reduce on `group` be recorded into a HIP graph?  True for the RCCL backend on device memory when a
-    trial capture + replay of a small all-reduce on this very group succeeds (gloo rehearsals stage through the host)."""
+    """(ok, note): can a gradient all-reduce on `group` be recorded into a HIP graph?  The answer is COLLECTIVE -- every rank of the group
+    returns the same `ok`, so the ranks can never end up in different launch forms (one replaying a captured collective while its peer issues
+    an eager one).  Three phases, each closed by a MIN all-reduce of the per-rank flag:
+      1. an eager all-reduce (communicator + channels set up outside any capture);
+      2. CAPTURE of a trial all-reduce -- nothing is communicated while capturing, so a rank whose capture throws has no partner waiting;
+         only if every rank captured,
+      3. every rank REPLAYS its trial graph once and checks the sum.
+    False for gloo (rehearsals stage through the host).  Must be called by all ranks of the group at the same point of the program."""
     if dist.get_backend(group) != "nccl":
         return False, f"backend {dist.get_backend(group)} reduces through the host"
     world = dist.get_world_size(group)
+    t = torch.ones(64, device=dev)
+    dist.all_reduce(t, group=group)                        # (1) -- a failure here is a broken job, not a capture question: let it raise
+    torch.cuda.synchronize()
+    g, note = None, None
     try:
-        t = torch.ones(64, device=dev)
-        dist.all_reduce(t, group=group)                    # communicator + channels set up outside the capture
-        torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             dist.all_reduce(t, group=group)
-        g.replay()
-        torch.cuda.synchronize()
-        ok = bool(torch.isfinite(t).all().item()) and float(t[0].item()) == float(world) ** 2
-        return ok, ("trial capture + replay ok" if ok else f"trial replay gave {float(t[0].item())}, expected {world ** 2}")
-    except Exception as e:       # noqa: BLE001 -- any failure means: keep the collective outside the graphs
-        return False, f"trial capture failed: {type(e).__name__}: {e}"
-
+    except Exception as e:       # noqa: BLE001 -- any failure means: keep the collective outside the graphs (on EVERY rank, below)
+        g, note = None, f"trial capture failed on this rank: {type(e).__name__}: {e}"
+    if not _agree_all(g is not None, group, dev):          # (2)
+        return False, note or "trial capture failed on another rank"
+    t.fill_(float(world))
+    g.replay()
+    torch.cuda.synchronize()
+    got = float(t[0].item())
+    good = bool(torch.isfinite(t).all().item()) and got == float(world) ** 2
+    if not _agree_all(good, group, dev):                   # (3)
+        return False, (f"trial replay gave {got}, expected {world ** 2}" if not good else "trial replay gave a wrong sum on another rank")
+    return True, f"trial capture + replay ok on all {world} rank(s)"

@@ -40,8 +40,8 @@ def test_build_write_read_roundtrip(tmp_path):
         T = rs.randint(50, 120)
         eps.append((rs.randint(0, 256, (T, 64, 64, 3)).astype(np.uint8), (rs.rand(T) > 0.96).astype(np.float64)))
     X, Y, I = df.build_dataset(eps, size=300)
-    assert X.dtype == np.uint8 and Y.shape == (5, len(X)) and I.dtype == np.uint16 and len(X) <= 300
-    assert set(np.unique(Y[0])) <= {0.0, 1.0} and (Y[1:] >= Y[0]).all() and Y.max() <= 1.0
+    assert X.dtype == np.uint8 and Y.shape == (7, len(X)) and not Y[5:].any() and I.dtype == np.uint16 and len(X) <= 300
+    assert set(np.unique(Y[0])) <= {0.0, 1.0} and (Y[1:5] >= Y[0]).all() and Y.max() <= 1.0
     # after the trunk filter no kept frame (except an episode's first) follows a reward within 35 frames
     path = df.dataset_path(datasize=len(X), data_dir=str(tmp_path) + "/")
     assert path.endswith(f"Treechop-trunk-{len(X)}-[0.98-0.97-0.96-0.95].pickle")

@@ -470,6 +470,16 @@ def test_rccl_path_one_rank_rehearsal():
     base = min(single, key=lambda d: d["ms_per_step"])
     assert line["config"]["collective_backend"] == "nccl" and line["config"]["ranks_seen_by_collective_backend"] == 1
     assert np.isfinite(line["final_losses"]["total"]) and line["n_gpus"] == 1
+    # the contract's schema on the data-parallel line, and the launch form: on a 1-rank group the default records the collective in the
+    # step graph (parallel.resolve_dp_graph), after a trial capture + replay agreed on by every rank
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in line, key
+    assert line["scaling"] == "weak" and line["dtype"] == "f32" and line["roofline"]["bound"] == "hbm"
+    assert line["config"]["allreduce_in_step_graph"] is True, line["config"]["gradient_allreduce"]
+    assert "rccl" in line["config"] and line["config"]["rccl"]["version"], "bench.py --gpus N must report RCCL's view"
+    eager = run(["--force-pg", "--dp-eager-allreduce", "--steps", "5", "--warmup", "2"], env)
+    assert eager["config"]["allreduce_in_step_graph"] is False and np.isfinite(eager["final_losses"]["total"])
     extra_ms = line["ms_per_step"] - base["ms_per_step"]
     print(f"three-launch form with a 1-rank RCCL all-reduce: {line['ms_per_step']:.3f} ms vs {base['ms_per_step']:.3f} ms single graph "
           f"(+{extra_ms * 1e3:.0f} us per step)")

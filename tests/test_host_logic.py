@@ -213,6 +213,11 @@ def flat_grads(sl):
     return g
 ok, note = parallel.collective_capturable(pg, torch.device("cpu"))      # gloo stages through the host: never recorded in a HIP graph
 assert ok is False and "gloo" in note, (ok, note)
+# the launch-form decision is collective: one rank's failure makes EVERY rank fall back (ADVICE round 4: ranks must never end in different forms)
+assert parallel._agree_all(True, pg, torch.device("cpu")) is True
+assert parallel._agree_all(rank != 1, pg, torch.device("cpu")) is False
+assert parallel.resolve_dp_graph(None, world) is False and parallel.resolve_dp_graph(None, 1) is True     # eager at N > 1 until exercised
+assert parallel.resolve_dp_graph(True, world) is True and parallel.resolve_dp_graph(False, 1) is False
 # every rank starts from rank 0's parameters
 p = torch.full((5,), float(rank)); parallel.broadcast_params_(p, pg); assert float(p.sum()) == 0.0
 g = flat_grads(parallel.shard_slice(n, rank, world))
