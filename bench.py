@@ -33,6 +33,17 @@ ALGO_BYTES_PER_IMAGE = 4.841e6      # SURVEY.md section 8(d), fp32, chfak 1 (1 2
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_COLLECT = None      # the side-block child collects its lines here instead of printing them
+
+
+def emit(line: dict):
+    """One JSON line on stdout -- or, inside the side-block child, one more entry of its result list."""
+    if _COLLECT is not None:
+        _COLLECT.append(line)
+    else:
+        print(json.dumps(line), flush=True)
+
+
 def csrc_sha16():
     """sha256 (first 16 hex digits) over the HIP sources + the C ABI header: ties a committed counter summary to the kernels it measured."""
     import glob
@@ -92,7 +103,12 @@ def parse():
     ap.add_argument("--config", type=int, default=0,
                     help="5 = BASELINE config 5, a SIDE measurement: the build-defined 128x128 Hourglass (no reference counterpart) on the bf16 "
                          "kernels, batch 256: --mode train = the phase-2 training step, --mode infer = the eval-mode forward")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="headline line only: no CPU baseline and no side block (the quick form tools / tests use)")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side block (BASELINE configs 4 and 5 and the paper's model size, measured by ONE child process after the "
+                         "headline's timed region and reported under the extra key \"side\" of the same JSON line)")
+    ap.add_argument("--side-timeout", type=float, default=240.0, help="seconds the parent waits for the side-block child")
+    ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--prime-s", type=float, default=0.4,
                     help="untimed graph replays for this many seconds right after capture (before the --warmup steps): lets the chip's "
@@ -251,10 +267,18 @@ def cli_train_mode(args):
         H.segmentation_training()
     finally:
         os.chdir(cwd)
-    print(json.dumps({"metric": "main.py -train mask-training loop images/sec, 64x64x3, N=64 (reference batch)",
+    emit({"metric": "main.py -train mask-training loop images/sec, 64x64x3, N=64 (reference batch)",
                       "value": H.train_images_per_s, "unit": "images/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
                       "data": "synthetic", "config": {"workload": "Handler.segmentation_training: index draws + upload + device gather/roll + "
-                                                       "fused phase-2 step, N_A = N_B = 64, one epoch over the high-value set"}}), flush=True)
+                                                       "fused phase-2 step, N_A = N_B = 64, one epoch over the high-value set"}})
+
+
+def prime_fixed(run, seconds, nominal_ms):
+    """Untimed replays before the warm-up so that a short timed region sees settled clocks (as the headline's priming does): a FIXED count
+    seconds / nominal_ms -- never a wall-clock decision, since under data parallelism every rank must issue the same number of steps."""
+    for _ in range(int(seconds * 1e3 / nominal_ms) if seconds > 0 else 0):
+        run()
+    torch.cuda.synchronize()
 
 
 def seeded_state(layout, seed):
@@ -312,6 +336,7 @@ def generic_mode(args, dev, rank):
             return gen.masker_forward(fm, lm, A, [c[f"e{i}"] for i in range(5)], cf)["Z"]
         flops = fcf + fmf
         what = f"eval-mode critic(collect) + masker forward, chfak {cf}: shape-generic MFMA kernels"
+    prime_fixed(run, args.prime_s, 5.5 if args.mode == "train" else 1.2)
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -321,12 +346,12 @@ def generic_mode(args, dev, rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     ach = flops * n / dt / 1e12
-    print(json.dumps({"metric": f"Hourglass+critic {args.mode} images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
+    emit({"metric": f"Hourglass+critic {args.mode} images/sec, 64x64x3 batch={n}, chfak={cf} (generic kernels)", "value": n / dt,
                       "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
                       "higher_is_better": True, "dtype": "f16 (f32 accumulate)" if (args.fp16 and args.mode == "infer") else "f32",
                       "data": "synthetic", "config": {"workload": what, "batch": n},
                       "roofline": {"bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
-                                   "traffic": None, "flops_per_image": flops}}), flush=True)
+                                   "traffic": None, "flops_per_image": flops}})
 
 
 def config5_mode(args, dev, pg=None, world=1, rank=0):
@@ -334,9 +359,8 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
     --mode train: the phase-2 training step (Hourglass128.phase2_step), data parallel under --gpus N (one replica per rank, the flat gradient
     bucket all-reduced over RCCL inside the step's HIP graph; weak scaling); otherwise the eval-mode forward."""
     from cgs_amd import hourglass128
-    from oracle import hourglass_ref as orc          # only for the seeded stand-in weights (shape tables + RandomState draw)
     n = 256 if args.batch == 512 else args.batch
-    net = hourglass128.Hourglass128(orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32), device=dev,
+    net = hourglass128.Hourglass128(*hourglass128.Hourglass128.seeded_state(31), device=dev,
                                     process_group=pg, force_allreduce=args.force_pg, dp_graph=dp_graph_arg(args))
     X = torch.randint(0, 256, (n, 128, 128, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(10 * rank)).to(dev)
     train = args.mode == "train"
@@ -355,6 +379,7 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    prime_fixed(run, args.prime_s, 1.0 if train else 0.2)
     for _ in range(max(args.warmup, 3)):         # (a fixed count on every rank: each step issues a collective)
         run()
     barrier()
@@ -376,7 +401,7 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
         elc, flc = hourglass128.Hourglass128.critic_cost()
         el_step, fl_step = 4 * elc + (el - elc) + 2 * (3 * elc + (el - elc)), 4 * flc + (flops - flc) + 2 * (3 * flc + (flops - flc))
         ach = 2.0 * el_step * n / dt / 1e9
-        print(json.dumps({"metric": "Hourglass-128 (build-defined) train images/sec, 128x128x3 batch=%d per GPU" % n, "value": world * n / dt, "unit": "images/s",
+        emit({"metric": "Hourglass-128 (build-defined) train images/sec, 128x128x3 batch=%d per GPU" % n, "value": world * n / dt, "unit": "images/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                           "scaling": "weak", "dtype": "bf16 (f32 accumulate, f32 master weights)", "data": "synthetic",
                           "config": {"workload": "BASELINE config 5 as a training step: phase-2 step (4 critic fwd, 3 critic bwd, mask fwd + bwd, mix, losses, "
@@ -386,16 +411,16 @@ def config5_mode(args, dev, pg=None, world=1, rank=0):
                                      "final_total_loss": float(net._train.losses[5])},
                           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                                        "algorithmic_elements_per_image": el_step, "flops_per_image": fl_step,
-                                       "bf16_TFLOPs": fl_step * n / dt / 1e12}}), flush=True)
+                                       "bf16_TFLOPs": fl_step * n / dt / 1e12}})
         return
     ach = 2.0 * el * n / dt / 1e9          # bf16: 2 bytes per element of the layer-granular traffic model
-    print(json.dumps({"metric": "Hourglass-128 (build-defined) inference images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
+    emit({"metric": "Hourglass-128 (build-defined) inference images/sec, 128x128x3 batch=%d" % n, "value": n / dt, "unit": "images/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "dtype": "bf16 (f32 accumulate)", "data": "synthetic",
                       "config": {"workload": "BASELINE config 5: eval-mode critic + mask forward of the six-stage 128x128 variant (no reference "
                                              "counterpart, parity unpinned), bf16 activations and weights, MFMA GEMM for the 1x1 pointwise layer", "batch": n},
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                                   "algorithmic_elements_per_image": el, "flops_per_image": flops}}), flush=True)
+                                   "algorithmic_elements_per_image": el, "flops_per_image": flops}})
 
 
 def side_mode(args, dev, world, rank):
@@ -414,11 +439,16 @@ def side_mode(args, dev, world, rank):
             bytes_per_img, what = 0.563e6, ("eval-mode critic(collect)+masker forward, fp16 activations and weights in every layer, fp32 "
                                            "accumulate (BASELINE config 4; SURVEY 8d: 0.563 MB/img at fp16)")
         if args.fp16_mask_head:
-            what += "; masker.0 GEMM with fp16 operands / fp32 accumulate, everything else fp32"
+            # priced on what this path stores: the fp32 layer model WITHOUT the 16-channel mask-head intermediate (written + read = 2 x 16 x
+            # 4096 x 4 B = 0.524 MB per image in SURVEY 8d's model) -- the one-kernel mask head keeps it in LDS
+            bytes_per_img -= 2 * 16 * 4096 * 4.0
+            what += ("; masker.0 GEMM with fp16 operands / fp32 accumulate, everything else fp32; byte model = SURVEY 8d fp32 layers minus "
+                     "the mask-head intermediate the fused path never stores (0.602 MB/img)")
     else:
         eng.phase1_step(A, Y)
         run = lambda: eng.phase1_step()
         bytes_per_img, what = (67457 + 78529) * 4.0, "phase-1 critic regression step (critic fwd + bwd + Adam)"
+    prime_fixed(run, args.prime_s, 0.25 * max(1.0, n / 2048))
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -428,13 +458,105 @@ def side_mode(args, dev, world, rank):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     ach = bytes_per_img * n / dt / 1e9
-    print(json.dumps({"metric": f"Hourglass {args.mode} images/sec, 64x64x3 batch={n}", "value": n / dt, "unit": "images/s",
+    emit({"metric": f"Hourglass {args.mode} images/sec, 64x64x3 batch={n}", "value": n / dt, "unit": "images/s",
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "dtype": "f16 (f32 accumulate)" if (args.mode == "infer" and args.fp16) else
                                ("f32+f16 mask-head operands" if (args.mode == "infer" and args.fp16_mask_head) else "f32"),
                       "data": "synthetic", "config": {"workload": what, "batch": n},
                       "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                   "traffic": None}}), flush=True)
+                                   "traffic": None}})
+
+
+SIDE_RUNS = (      # (key, bench.py arguments): each is the side measurement a reader would run by hand with these flags
+    ("config4_fp16_infer_batch2048", ["--mode", "infer", "--fp16", "--batch", "2048", "--steps", "50", "--warmup", "5"]),
+    ("config5_train_batch256", ["--config", "5", "--mode", "train", "--steps", "50", "--warmup", "5"]),
+    ("config5_infer_batch256", ["--config", "5", "--mode", "infer", "--steps", "50", "--warmup", "5"]),
+    ("chfak5_train_batch512", ["--chfak", "5", "--mode", "train", "--steps", "20", "--warmup", "3"]),
+)
+
+
+def side_traffic(key):
+    """Counter traffic (bytes per launch) of a side workload from the newest committed PMC summary that names it (collected like the
+    headline's: tools/sq_counters.sh with the side run's flags, FETCH_SIZE / WRITE_SIZE in separate passes), or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_side_traffic.json")), reverse=True):
+        try:
+            with open(path) as fp:
+                t = json.load(fp)
+            if key in t:
+                return t[key]["traffic_bytes_per_step"], {"file": "profiles/" + os.path.basename(path), "csrc_sha16": t[key].get("csrc_sha16"),
+                                                          "measured_on_this_build": t[key].get("csrc_sha16") == csrc_sha16()}
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None
+
+
+def side_child_main():
+    """The side block's child process: started by the parent BEFORE anything there touched the GPU (so no process that holds a HIP
+    context forks), it imports torch, then blocks on one line of stdin until the parent's timed region is over (EOF = the parent died:
+    exit).  It then runs SIDE_RUNS one after the other in this one process and prints ONE JSON object {"side": {...}}."""
+    global _COLLECT
+    go = sys.stdin.readline()
+    if not go.strip():
+        return 3
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    side = {}
+    for key, argv in SIDE_RUNS:
+        old = sys.argv
+        sys.argv = [old[0]] + argv + ["--no-cpu-baseline"]
+        t0 = time.perf_counter()
+        try:
+            a = parse()
+            _COLLECT = []
+            if a.config == 5:
+                config5_mode(a, dev)
+            elif a.chfak != 1:
+                generic_mode(a, dev, 0)
+            else:
+                side_mode(a, dev, 1, 0)
+            line = _COLLECT[-1]
+            if line.get("roofline") is not None and line["roofline"].get("traffic") is None:
+                tr, src = side_traffic(key)
+                line["roofline"]["traffic"], line["roofline"]["traffic_source"] = tr, src
+            line["argv"] = " ".join(argv)
+            line["wall_s"] = round(time.perf_counter() - t0, 2)
+            side[key] = line
+        except Exception as e:       # noqa: BLE001 -- a failing side run must not take the others (or the headline line) with it
+            side[key] = {"error": f"{type(e).__name__}: {e}", "argv": " ".join(argv)}
+        finally:
+            _COLLECT = None
+            sys.argv = old
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    print(json.dumps({"side": side}), flush=True)
+    return 0
+
+
+def start_side_child():
+    """Popen of `python bench.py --side-child` (stdin = the go pipe, stdout = its one JSON line, stderr passed through)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--side-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                            text=True, env=env)
+
+
+def finish_side_child(child, timeout_s):
+    """Sends the go line, waits (bounded) and returns the child's {"side": ...} object -- or {"error": ...}; never raises."""
+    try:
+        out, _ = child.communicate("go\n", timeout=timeout_s)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if child.returncode != 0 or not lines:
+            return {"error": f"side child exited with code {child.returncode} and {len(lines)} JSON line(s)"}
+        return json.loads(lines[-1])["side"]
+    except subprocess.TimeoutExpired:
+        child.kill()               # (the exact process this parent started)
+        try:
+            child.communicate(timeout=10)
+        except Exception:          # noqa: BLE001
+            pass
+        return {"error": f"side child exceeded {timeout_s:.0f} s"}
+    except Exception as e:          # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def spawn_ranks(args):
@@ -458,6 +580,8 @@ def spawn_ranks(args):
 
 def main():
     args = parse()
+    if args.side_child:
+        raise SystemExit(side_child_main())
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -465,6 +589,10 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the side block's child is started HERE, before this process creates its HIP context; it idles on a pipe until the headline is done
+    headline = args.gpus == 1 and world == 1 and args.mode == "train" and args.chfak == 1 and args.config == 0 and not args.force_pg
+    # (--no-cpu-baseline = the quick form tools and tests use: headline line only, no side block either)
+    side_proc = start_side_child() if (headline and not args.no_side and not args.no_cpu_baseline and torch.cuda.device_count() > 0) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
@@ -593,9 +721,18 @@ def main():
                          "fp32_TFLOPs": 86.75e6 * n / (launch_ms * 1e-3) / 1e12, "fp32_frac_of_157TF": 86.75e6 * n / (launch_ms * 1e-3) / 157.3e12},
             "final_losses": dict(zip(("critic", "replace", "inject", "l1", "l2", "total"), losses[:6])),
         }
+        if side_proc is not None:
+            # side block: the other BASELINE configs, each measured by the child with the flags shown in its "argv" -- after the
+            # headline's timed region, before the CPU baseline takes the host cores; this process only waits
+            torch.cuda.synchronize()
+            out["side"] = finish_side_child(side_proc, args.side_timeout)
+            side_proc = None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n, args.cpu_steps, args.dropout)
         print(json.dumps(out), flush=True)
+    if side_proc is not None:           # (not reached on rank 0 of a headline run; any other path that started one closes it)
+        side_proc.stdin.close()
+        side_proc.wait()
     if pg is not None:
         torch.distributed.destroy_process_group()
 

@@ -692,6 +692,42 @@ class Hourglass128:
         return T.losses
 
     @staticmethod
+    def param_shapes(chfak: int = 1, neck: int = 32, masker_channels: int = 16):
+        """(critic, masker) parameter tables [(key, OIHW / [out, in] shape)] of the six-stage 128x128 variant, reference-style key names:
+        five 3x3 encoder stages (128 -> 4) + the 4x4 valid bottleneck convolution + the two Linear layers; six decoder layers (the 1x1
+        pointwise layer is dec_model.5) + the two mask-head layers."""
+        d, b = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak], neck * chfak
+        crit, cin = [], 3
+        for key, co in zip(ENC_KEYS, d):
+            crit += [(key + ".weight", (co, cin, 3, 3)), (key + ".bias", (co,))]
+            cin = co
+        crit += [("features.17.weight", (b, d[4], 4, 4)), ("features.17.bias", (b,)), ("crit.1.weight", (b, b)), ("crit.1.bias", (b,)),
+                 ("crit.4.weight", (1, b)), ("crit.4.bias", (1,))]
+        mask = []
+        for i in range(5):                       # dec_model.i: cat(skip e_i, upsampled lower level) -> e_i channels, 64x64 ... 4x4
+            mask += [(f"dec_model.{i}.weight", (d[i], d[i] + (d[i + 1] if i < 4 else b), 3, 3)), (f"dec_model.{i}.bias", (d[i],))]
+        mask += [("dec_model.5.weight", (b, b, 1, 1)), ("dec_model.5.bias", (b,)),
+                 ("masker.0.weight", (masker_channels, 3 + d[0], 3, 3)), ("masker.0.bias", (masker_channels,)),
+                 ("masker.2.weight", (1, masker_channels, 3, 3)), ("masker.2.bias", (1,))]
+        return crit, mask
+
+    @staticmethod
+    def seeded_state(seed: int, chfak: int = 1, neck: int = 32, masker_channels: int = 16):
+        """(critic, masker) stand-in weights for benchmarks and smoke runs: U(-1/sqrt(fan_in), +1/sqrt(fan_in)) per layer from
+        numpy RandomState(seed) / RandomState(seed + 1) (there is no checkpoint of this build-defined model)."""
+        import math
+        import numpy as np
+        out = []
+        for k, shapes in enumerate(Hourglass128.param_shapes(chfak, neck, masker_channels)):
+            rs, sd, bound = np.random.RandomState(seed + k), {}, 1.0
+            for key, shp in shapes:
+                if key.endswith(".weight"):
+                    bound = 1.0 / math.sqrt(float(np.prod(shp[1:])))
+                sd[key] = torch.from_numpy(rs.uniform(-bound, bound, size=shp).astype(np.float32))
+            out.append(sd)
+        return out[0], out[1]
+
+    @staticmethod
     def critic_cost(chfak: int = 1, neck: int = 32):
         """(elements, FLOPs) per image of the critic's forward pass alone (same model as model_cost)."""
         d, nb = [8 * chfak, 8 * chfak, 8 * chfak, 8 * chfak, 16 * chfak], neck * chfak

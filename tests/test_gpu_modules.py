@@ -488,6 +488,29 @@ def test_rccl_path_one_rank_rehearsal():
     assert extra_ms < 0.10, "the data-parallel launch form must cost at most tens of microseconds over the single-GPU step"
 
 
+def test_bench_default_line_carries_the_side_block():
+    """The driver's command (`python bench.py --gpus 1 --steps K --warmup W`) prints ONE JSON line whose extra key "side" holds the other
+    BASELINE configurations, each measured by the child process after the headline's timed region: config 4 (fp16 inference, batch 2048),
+    config 5 (128x128 bf16: training step and inference, batch 256), the paper's model size (chfak 5 training step)."""
+    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-steps", "1"],
+                       capture_output=True, text=True, env=plain, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line on stdout"
+    d = json.loads(lines[0])
+    assert d["metric"].startswith("Hourglass+critic train images/sec") and d["dtype"] == "f32" and "cpu_baseline" in d and "roofline" in d
+    side = d["side"]
+    assert "error" not in side, side
+    assert set(side) == {"config4_fp16_infer_batch2048", "config5_train_batch256", "config5_infer_batch256", "chfak5_train_batch512"}
+    for key, line in side.items():
+        assert "error" not in line, (key, line)
+        assert line["value"] > 0 and line["unit"] == "images/s" and line["steps"] >= 20 and "roofline" in line and line["argv"]
+        print(f"side {key}: {line['value'] / 1e3:.0f} k images/s, {line['ms_per_step']:.3f} ms, frac {line['roofline']['frac']:.3f} ({line['roofline']['bound']})")
+    assert side["config4_fp16_infer_batch2048"]["config"]["batch"] == 2048 and side["config4_fp16_infer_batch2048"]["dtype"].startswith("f16")
+    assert side["config5_train_batch256"]["config"]["batch"] == 256 and side["config5_train_batch256"]["dtype"].startswith("bf16")
+
+
 def test_bench_gpus_flag_starts_ranks_or_refuses():
     """`python bench.py --gpus N` without a torchrun environment starts N ranks itself (child torchrun, the parent makes no GPU
     call) or exits non-zero when fewer than N GPUs are visible -- it must never silently run on one GPU."""

@@ -243,3 +243,24 @@ def test_data_parallel_scheme_world2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DP_MAX_REL_ERR" in r.stdout
+
+
+def test_hourglass128_initialiser_matches_the_oracle_tables():
+    """bench.py --config 5 takes its stand-in weights from the product module (Hourglass128.seeded_state), not from oracle/: same key
+    names / shapes / values as the oracle's tables the GPU tests compare against."""
+    import torch
+    from cgs_amd import hourglass128 as h
+    from oracle import hourglass_ref as orc
+    crit, mask = h.Hourglass128.param_shapes()
+    assert crit == orc.critic128_shapes() and mask == orc.masker128_shapes()
+    pc, pm = h.Hourglass128.seeded_state(31)
+    oc, om = orc.seeded_params(orc.critic128_shapes(), 31), orc.seeded_params(orc.masker128_shapes(), 32)
+    assert all(torch.equal(pc[k], oc[k]) for k in oc) and all(torch.equal(pm[k], om[k]) for k in om)
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert src.count("from oracle import") == 1, "bench.py may import oracle/ only in its cpu_baseline leg"
+
+
+def test_bench_side_child_exits_when_the_parent_goes_away():
+    """The side-block child idles on its stdin pipe; EOF (the parent died before the go line) makes it exit without touching a GPU."""
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--side-child"], input="", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3 and r.stdout.strip() == ""
