@@ -29,6 +29,12 @@ CGS_DG_CFG(DDec3y, 4, 64, SRC_F32, 16, 48, 16, 4, 0, 48, 8, 16, CGS_ACT_NONE, 6)
 struct WMask0U8x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_U8, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
 struct WMask0F32x { using G = WGeo<64, 64, 4, 1, 128>; static constexpr int SRC = WSRC_F32, CA = 3, CB = 8, UPS = 2, CO = 16, DY = WDY_F32; };
 
+#ifndef CGS_CAP_W0MIX
+#define CGS_CAP_W0MIX 512
+#endif
+#ifndef CGS_CAP_W1R
+#define CGS_CAP_W1R 256
+#endif
 static constexpr int kMaxBothWgradBlocks = 256;
 static constexpr int kMaxBothWgradBlocksBig = 512;
 
@@ -41,7 +47,7 @@ static int both_slabs(int n) {
     int tiles = (GW::IMGS == 1) ? n * GW::STRIPS : (n + GW::IMGS - 1) / GW::IMGS;
     int cap = GW::H >= 32 ? kMaxBothWgradBlocksBig : kMaxBothWgradBlocks;
     if (both_sparse_ok<CWG> && wgrad_sparse_enabled()) {
-        cap = GW::H >= 64 ? 512 : 256;      // persistent sparse workgroups (swept on the step in round 3)
+        cap = GW::H >= 64 ? CGS_CAP_W0MIX : CGS_CAP_W1R;      // persistent sparse workgroups (swept on the step in round 3; A/B macros round 5)
     }
     return tiles < cap ? tiles : cap;
 }
@@ -152,18 +158,35 @@ struct MixBwdArgs {
     const float* vf_pred;
 };
 
+// (round 5) nbw1 > 0: features.3's sparse weight gradient (pw1; the role conv_bwd_both_kernel<WEnc1, ...> gave it) as nbw1 more workgroups
+// behind features.0's -- its data gradient now runs inside the tail backward launch (cgs_tail_enc_bwd_enc1), and only the step's final
+// reduction waits for this slab.
+#ifndef CGS_R1_MIX
+#define CGS_R1_MIX 1
+#endif
 template <class CWG, bool SPARSE>
-__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(WgradParams) + sizeof(ConvParams) + sizeof(MixBwdArgs) + 8>();
+__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, WgradParams pw1, int nbw1) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(ConvParams) + sizeof(MixBwdArgs) + 16>();
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");
+    static_assert(WEnc1::G::THREADS == 256, "workgroup shape");
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    if ((int)blockIdx.x < nbw) {
-        constexpr int SLAB = (9 * 3 + 1) * 8;
-        wgrad_dispatch<CWG, SPARSE>(pw, blockIdx.x, nbw, pw.ntiles, pw.slab + (size_t)blockIdx.x * SLAB, smem);
+    // block order (A/B: CGS_R1_MIX): 0 = [riders | features.0 weight gradient | data gradient], 1 = [w | riders | d], 2 = [w | d | riders]
+    const int gx = (int)gridDim.x, bx = (int)blockIdx.x;
+    const int r_lo = CGS_R1_MIX == 0 ? 0 : (CGS_R1_MIX == 1 ? nbw : gx - nbw1);
+    if (bx >= r_lo && bx < r_lo + nbw1) {
+        constexpr int SLAB1 = (9 * 8 + 1) * 8;
+        const int b1 = bx - r_lo;
+        wgrad_dispatch<WEnc1, SPARSE>(pw1, b1, nbw1, pw1.ntiles, pw1.slab + (size_t)b1 * SLAB1, smem);
         return;
     }
-    const int bid = blockIdx.x - nbw;
+    const int bm = bx - (bx >= r_lo ? nbw1 : 0);               // index among the launch's own roles
+    if (bm < nbw) {
+        constexpr int SLAB = (9 * 3 + 1) * 8;
+        wgrad_dispatch<CWG, SPARSE>(pw, bm, nbw, pw.ntiles, pw.slab + (size_t)bm * SLAB, smem);
+        return;
+    }
+    const int bid = bm - nbw;
     pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
     pd.mix_n_a = M.n_a;
@@ -173,11 +196,18 @@ __global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvP
 
 extern "C" int cgs_enc0_bwd_mix_slabs(int32_t n_mix) { return n_mix < 0 ? CGS_ERR_BADARG : both_slabs<WEnc0F32>(n_mix); }
 
-extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
-                                const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
-                                float l2_scale, const float* valuefak_pred, float* dzpre, float* slab, cgs_stream_t stream) {
+// e0_1 / dy1 / am1 / slab1 (all or none): features.3's weight gradient over the same n_mix images (cgs_conv3x3_bwd_weight of the 8 -> 8
+// layer at 32x32 with ReLU + pool: input e0_1 [n_mix,32,32,8], pooled output gradient dy1 [n_mix,16,16,8], argmax nibbles am1, slab1
+// [cgs_enc1_wgrad_rider_slabs(n_mix)][584]) as extra workgroups of this launch (round 5).
+extern "C" int cgs_enc1_wgrad_rider_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : both_slabs<WEnc1>(n); }
+
+extern "C" int cgs_enc0_bwd_mix_enc1(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
+                                     const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
+                                     float l2_scale, const float* valuefak_pred, float* dzpre, float* slab,
+                                     const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, cgs_stream_t stream) {
     if (n_a < 0 || !dy || !amask || !w || !a || !b || !z || !dzpre) return CGS_ERR_BADARG;
     if (mixed && !slab) return CGS_ERR_BADARG;           // `mixed` is only the weight gradient's input
+    if (slab1 && (!e0_1 || !dy1 || !am1)) return CGS_ERR_BADARG;
     if (n_a == 0) return CGS_OK;
     using GW = WEnc0F32::G;
     using GD = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
@@ -192,13 +222,31 @@ extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed,
     const int nbw = slab ? both_slabs<WEnc0F32>(n_mix) : 0;
     const int nbd = CGS_CONV_PIPE ? n_a * GD::STRIPS / DEnc0DP::TPW : n_a * GD::STRIPS;
     const bool sp = wgrad_sparse_enabled() != 0;
+    WgradParams pw1{};
+    int nbw1 = 0;
+    size_t lw1 = 0;
+    if (slab1) {
+        using GW1 = WEnc1::G;
+        pw1.src_a = e0_1; pw1.dy = dy1; pw1.amask = am1; pw1.slab = slab1; pw1.n = n_mix;
+        pw1.ntiles = (GW1::IMGS == 1) ? n_mix * GW1::STRIPS : (n_mix + GW1::IMGS - 1) / GW1::IMGS;
+        nbw1 = both_slabs<WEnc1>(n_mix);
+        lw1 = sp ? wgrad_any_lds_bytes<WEnc1, true>() : wgrad_lds_bytes<WEnc1>();
+    }
     const size_t lw = sp ? wgrad_any_lds_bytes<WEnc0F32, true>() : wgrad_lds_bytes<WEnc0F32>(), ld = conv_lds_bytes<DEnc0>();
-    const size_t lds = lw > ld ? lw : ld;                    // 41 KB (data-gradient tile): three workgroups per CU
-    const dim3 grid(nbw + nbd);
+    size_t lds = lw > ld ? lw : ld;                    // 41 KB (data-gradient tile): three workgroups per CU
+    if (lw1 > lds) lds = lw1;
+    const dim3 grid(nbw + nbd + nbw1);
     auto k = (mixed || !slab)       // materialised mixes (or no weight gradient at all) / mixes recomputed in the tile loader
                  ? (sp ? enc0_bwd_mix_kernel<WEnc0F32, true> : enc0_bwd_mix_kernel<WEnc0F32, false>)
                  : (sp ? enc0_bwd_mix_kernel<WEnc0Mix, true> : enc0_bwd_mix_kernel<WEnc0Mix, false>);
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw, pw1, nbw1);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+extern "C" int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
+                                const float* w, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
+                                float l2_scale, const float* valuefak_pred, float* dzpre, float* slab, cgs_stream_t stream) {
+    return cgs_enc0_bwd_mix_enc1(n_a, inject, mixed, dy, amask, w, a, b, z, l1_scale, l2_scale, valuefak_pred, dzpre, slab,
+                                 nullptr, nullptr, nullptr, nullptr, stream);
 }

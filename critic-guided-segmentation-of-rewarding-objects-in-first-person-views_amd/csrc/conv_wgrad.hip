@@ -37,11 +37,14 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_any_kernel(WgradParams P)
 
 // the sparse form is latency-bound with small tiles: more workgroups in flight than the MFMA form wants
 static constexpr int kMaxSparseBlocks = 512;
+#ifndef CGS_CAP_W0U8
+#define CGS_CAP_W0U8 1024
+#endif
 template <class C>
 static int wg_blocks_any(int n) {
     using G = typename C::G;
     if (sparse_cfg<C>::ok && wgrad_sparse_enabled()) {
-        const int cap = G::H >= 64 ? 2 * kMaxSparseBlocks : kMaxSparseBlocks;      // measured: 1024 / 512
+        const int cap = G::H >= 64 ? CGS_CAP_W0U8 : kMaxSparseBlocks;      // measured: 1024 / 512
         int t = wg_tiles<G>(n);
         return t < cap ? t : cap;
     }
@@ -70,33 +73,71 @@ static int launch_wgrad(WgradParams P, hipStream_t st) {
 // features.0's weight gradient on the uint8 frames (the A pass) and the critic head's weight gradients in ONE launch: the head GEMM
 // is a latency-bound 8 us launch of < 200 workgroups that only the step's final reduction waits for; as extra workgroups of this
 // launch it disappears behind the sparse gather (round 3: one dependent launch less on the critical path).
-__global__ void __launch_bounds__(256) wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(WgradParams) + sizeof(HeadWgradParams) + 8>();
+// (round 5) nbw1 > 0: features.3's sparse weight gradient of the same pass (P1) as nbw1 more workgroups between the two roles -- its data
+// gradient runs inside the tail backward launch (cgs_tail_enc_bwd_enc1).
+#ifndef CGS_R1_U8
+#define CGS_R1_U8 1
+#endif
+__global__ void __launch_bounds__(256) wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw, WgradParams P1, int nbw1) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(HeadWgradParams) + 16>();
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    if ((int)blockIdx.x < nbw) {
-        constexpr int SLAB = (9 * 3 + 1) * 8;
-        wgrad_dispatch<WEnc0U8, true>(P, blockIdx.x, nbw, P.ntiles, P.slab + (size_t)blockIdx.x * SLAB, smem);
-    } else {
-        tail_head_wgrad_body(H, blockIdx.x - nbw);
+    // block order (A/B: CGS_R1_U8): 0 = [riders | features.0 | head], 1 = [features.0 | riders | head], 2 = [features.0 | head | riders]
+    const int gx = (int)gridDim.x, bx = (int)blockIdx.x;
+    const int r_lo = CGS_R1_U8 == 0 ? 0 : (CGS_R1_U8 == 1 ? nbw : gx - nbw1);
+    if (bx >= r_lo && bx < r_lo + nbw1) {
+        constexpr int SLAB1 = (9 * 8 + 1) * 8;
+        const int b1 = bx - r_lo;
+        wgrad_dispatch<WEnc1, true>(P1, b1, nbw1, P1.ntiles, P1.slab + (size_t)b1 * SLAB1, smem);
+        return;
     }
+    const int bm = bx - (bx >= r_lo ? nbw1 : 0);
+    if (bm < nbw) {
+        constexpr int SLAB = (9 * 3 + 1) * 8;
+        wgrad_dispatch<WEnc0U8, true>(P, bm, nbw, P.ntiles, P.slab + (size_t)bm * SLAB, smem);
+    } else {
+        tail_head_wgrad_body(H, bm - nbw);
+    }
+}
+
+// e0_1 / dy1 / am1 / slab1 (all or none): features.3's weight gradient over n1w images ([n1w,32,32,8] input, [n1w,16,16,8] pooled output
+// gradient, argmax nibbles, slab1 [nslab1][584] with nslab1 = cgs_enc1_wgrad_rider_slabs(n1w)) as extra workgroups of this launch.
+extern "C" int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                                int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                                int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                                float* slab_head, float* slab_pw,
+                                                int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
+                                                cgs_stream_t stream) {
+    if (n <= 0 || !x_u8 || !dy || !amask || !slab) return CGS_ERR_BADARG;
+    if (n0 < 0 || n1 < 0 || n0 + n1 == 0 || !slab_head || (n0 > 0 && (!hvec0 || !e4_0)) || (n1 > 0 && (!hvec1 || !e4_1))) return CGS_ERR_BADARG;
+    if ((d_o4_0 || d_o4_1) && !slab_pw) return CGS_ERR_BADARG;
+    if (slab1 && (n1w <= 0 || !e0_1 || !dy1 || !am1 || nslab1 <= 0)) return CGS_ERR_BADARG;
+    if (slab1 && !(sparse_cfg<WEnc1>::ok && wgrad_sparse_enabled())) return CGS_ERR_UNSUPPORTED;
+    WgradParams P{};
+    P.src_a = x_u8; P.dy = dy; P.amask = amask; P.slab = slab; P.n = n;
+    P.ntiles = wg_tiles<WEnc0U8::G>(n);
+    HeadWgradParams H{{{hvec0, e4_0, d_o4_0, n0, n_o4_0}, {hvec1, e4_1, d_o4_1, n1, n_o4_1}}, slab_head, slab_pw};
+    const int nbw = wg_blocks_any<WEnc0U8>(n), nbh = (n0 + n1 + kHwIpb - 1) / kHwIpb;
+    size_t lds = wgrad_any_lds_bytes<WEnc0U8, true>();
+    WgradParams P1{};
+    int nbw1 = 0;
+    if (slab1) {
+        P1.src_a = e0_1; P1.dy = dy1; P1.amask = am1; P1.slab = slab1; P1.n = n1w;
+        P1.ntiles = wg_tiles<WEnc1::G>(n1w);
+        nbw1 = nslab1;
+        const size_t l1 = wgrad_any_lds_bytes<WEnc1, true>();
+        if (l1 > lds) lds = l1;
+    }
+    hipLaunchKernelGGL(wgrad_enc0u8_head_kernel, dim3(nbw + nbh + nbw1), dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
 }
 
 extern "C" int cgs_enc0_wgrad_u8_with_head(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
                                            int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
                                            int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
                                            float* slab_head, float* slab_pw, cgs_stream_t stream) {
-    if (n <= 0 || !x_u8 || !dy || !amask || !slab) return CGS_ERR_BADARG;
-    if (n0 < 0 || n1 < 0 || n0 + n1 == 0 || !slab_head || (n0 > 0 && (!hvec0 || !e4_0)) || (n1 > 0 && (!hvec1 || !e4_1))) return CGS_ERR_BADARG;
-    if ((d_o4_0 || d_o4_1) && !slab_pw) return CGS_ERR_BADARG;
-    WgradParams P{};
-    P.src_a = x_u8; P.dy = dy; P.amask = amask; P.slab = slab; P.n = n;
-    P.ntiles = wg_tiles<WEnc0U8::G>(n);
-    HeadWgradParams H{{{hvec0, e4_0, d_o4_0, n0, n_o4_0}, {hvec1, e4_1, d_o4_1, n1, n_o4_1}}, slab_head, slab_pw};
-    const int nbw = wg_blocks_any<WEnc0U8>(n), nbh = (n0 + n1 + kHwIpb - 1) / kHwIpb;
-    const size_t lds = wgrad_any_lds_bytes<WEnc0U8, true>();
-    hipLaunchKernelGGL(wgrad_enc0u8_head_kernel, dim3(nbw + nbh), dim3(256), lds, (hipStream_t)stream, P, H, nbw);
-    CGS_HIP_CHECK_LAUNCH();
-    return CGS_OK;
+    return cgs_enc0_wgrad_u8_with_head_enc1(n, x_u8, dy, amask, slab, n0, hvec0, e4_0, d_o4_0, n_o4_0, n1, hvec1, e4_1, d_o4_1, n_o4_1,
+                                            slab_head, slab_pw, 0, nullptr, nullptr, nullptr, nullptr, 0, stream);
 }
 
 static bool wdesc_is(const cgs_conv_desc* d, int hw, int ca, int cb, int co, int src, int ups, int pool) {

@@ -583,6 +583,10 @@ extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const 
 // left to cgs_tail_head_wgrad below, which reads the per-image vectors this kernel writes to hvec.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kTailSlab10 = 1168, kTailSlab6 = 584;
+// floats of tail_enc_bwd_kernel's one static LDS block (its tiles + weights + per-image scratch, or the dec_model.0 rider's tiles)
+static constexpr int kTailEncBwdTileFloats = T16x8::FLOATS + T8x8::FLOATS + T16x8::FLOATS + T8x16::FLOATS;
+static constexpr int kTailEncBwdOwnFloats = ((kTailEncBwdTileFloats + 3) & ~3) + 72 * 8 + 72 * 16 + 256 + 512 + 512 + 2048 + 64 + 32;
+static constexpr int kTailEncBwdLdsFloats = kTailEncBwdOwnFloats > kWD0LdsFloats ? kTailEncBwdOwnFloats : kWD0LdsFloats;
 
 struct TailEncBwdParams {
     cgs_tail_enc_weights w;
@@ -599,8 +603,14 @@ struct TailEncBwdParams {
     WDec0Params rider;      // optional: dec_model.0's weight gradient as spare workgroups of this launch (rider.slab != NULL)
 };
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams)>();
+// ENC1 (round 5): the workgroup also runs features.3's DATA gradient of its image(s) after the tail stages (conv3x3_body_pipe<DEnc1P>, the
+// body cgs_conv3x3_bwd_both launches for that layer: d e1 read back from memory inside the workgroup, argmax nibbles re-expanded in the
+// loader, the decoder's skip gradient added in the epilogue; the static LDS block is its scratch) -- one launch boundary of the step's
+// dependent chain less per critic pass.  features.3's sparse weight gradient (only the final reduction waits for it) moves into the
+// features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).
+template <bool ENC1>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P, ConvParams PC) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams) + (ENC1 ? sizeof(ConvParams) : 0)>();
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
@@ -609,6 +619,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     constexpr int OW6 = (OEND + 3) & ~3, OW10 = OW6 + 72 * 8, OXS = OW10 + 72 * 16, OM2 = OXS + 256, OD2 = OM2 + 512, OO1 = OD2 + 512,
                   OAM2 = OO1 + 2048, ODZ4 = OAM2 + 64, OALL = ODZ4 + 32;
     constexpr int LDS_ALL = OALL > kWD0LdsFloats ? OALL : kWD0LdsFloats;
+    static_assert(LDS_ALL == kTailEncBwdLdsFloats, "the launcher checks the fused convolution's scratch against this size");
     __shared__ __attribute__((aligned(16))) float lds_all[LDS_ALL];
     if ((int)blockIdx.x >= P.nblocks) {          // riders (launched only when rider.slab is given): see cgs_tail_enc_bwd_rider
         wgrad_dec0_body(P.rider, (int)blockIdx.x - P.nblocks, (int)gridDim.x - P.nblocks, lds_all);
@@ -831,6 +842,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const size_t b = blockIdx.x;
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
     wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
+    if constexpr (ENC1) {
+        // features.3's data gradient of this workgroup's images: their d e1 is in memory (stored by this workgroup, visible after the
+        // barrier), every tile and the reduction scratch above are dead
+        for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
+            __syncthreads();
+            conv3x3_body_pipe<DEnc1P>(PC, 2 * img, (float4*)lds_all);
+        }
+    }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
@@ -840,13 +859,13 @@ extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG
 // low-resolution input o1_r [n_r,16,16,8], output gradient dy_r [n_r,32,32,8], slab_r [nslab_r][1160]) as nslab_r SPARE workgroups of
 // the launch: a tail launch at N = 512 is one image per workgroup and two workgroups per CU -- a third fits (168 registers, 50 KB of
 // LDS each) and only the step's final reduction waits for that gradient.  slab_r = NULL: plain cgs_tail_enc_bwd.
-extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
-                                      const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
-                                      const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
-                                      const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
-                                      float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
-                                      int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
-                                      cgs_stream_t stream) {
+static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                               const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                               const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
+                               const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
+                               float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                               int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                               const ConvParams* enc1, cgs_stream_t stream) {
     if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
     if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
@@ -856,9 +875,41 @@ extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, 
                        hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
                        WDec0Params{e0_r, o1_r, dy_r, slab_r, n_r, n_r * kStrips}};
     const int riders = slab_r ? nslab_r : 0;
-    hipLaunchKernelGGL(tail_enc_bwd_kernel, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P);
+    if (enc1) hipLaunchKernelGGL(tail_enc_bwd_kernel<true>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, *enc1);
+    else hipLaunchKernelGGL(tail_enc_bwd_kernel<false>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                                      const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                                      const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
+                                      const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
+                                      float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                                      int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                                      cgs_stream_t stream) {
+    return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, nullptr, stream);
+}
+
+// cgs_tail_enc_bwd_rider AND features.3's data gradient (the data-gradient half of cgs_conv3x3_bwd_both for the 8 -> 8 layer at 32x32 with
+// ReLU + pool: d e1 [n,16,16,8] re-expanded by the argmax nibbles am1, weights w_enc1 (HWIO), + addend0 [n_addend,32,32,8] (the decoder's
+// skip gradient at e0, may be NULL) -> de0 [n,32,32,8]) in one launch: every workgroup continues with the convolution of the image(s)
+// whose tail it just ran (nets.py:173-194 backward; round 5).
+extern "C" int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                                     const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                                     const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1,
+                                     const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
+                                     float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                                     int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                                     const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
+                                     cgs_stream_t stream) {
+    if (!am1 || !w_enc1 || !de0 || n_addend < 0 || (n_addend > 0 && !addend0)) return CGS_ERR_BADARG;
+    if (conv_lds_bytes<DEnc1P>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
+    ConvParams pd{};
+    pd.src_a = de1; pd.amask_in = am1; pd.w = w_enc1; pd.out = de0; pd.addend = addend0; pd.n_addend = n_addend; pd.n = n;
+    return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, &pd, stream);
 }
 
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,

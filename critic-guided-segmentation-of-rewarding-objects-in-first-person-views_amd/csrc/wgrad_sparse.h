@@ -28,11 +28,22 @@ struct SpCfg {
     static_assert(PW * S * 4 <= RS, "row stride");
 };
 
+// The final reduction stages every lane's [NACC] block through LDS.  features.3 (73 rows x 256 lanes = 75 KB) does it in chunks of RCH rows
+// that fit the X tile's 19.9 KB (round 5): as a rider of another launch its dynamic LDS size is the WHOLE launch's, and 75 KB would cut
+// every role of that launch to two workgroups per CU (measured: wgrad_enc0u8_head 24.5 -> 56.8 us with the un-chunked rider).  The sums
+// and their order are unchanged.  features.0 (28 rows = 28.7 KB against an 11 KB tile) keeps the one-pass form it was tuned with.
+#ifndef CGS_SPRED_CHUNKED
+#define CGS_SPRED_CHUNKED 1
+#endif
 template <class C>
-static constexpr size_t wgrad_sparse_lds_bytes() {
-    constexpr size_t tile = (size_t)C::TRA * C::RS * 4 + 16, red = (size_t)C::NACC * 256 * 4;
-    return tile > red ? tile : red;
-}
+struct SpRed {
+    static constexpr size_t TILE = (size_t)C::TRA * C::RS * 4 + 16, FULL = (size_t)C::NACC * 256 * 4;
+    static constexpr bool CHUNKED = (CGS_SPRED_CHUNKED != 0) && (C::CA == 8) && FULL > TILE;
+    static constexpr int RCH = CHUNKED ? (int)(TILE / 1024) : C::NACC;       // rows per chunk (1 KB per row)
+    static constexpr size_t BYTES = CHUNKED ? TILE : (TILE > FULL ? TILE : FULL);
+};
+template <class C>
+static constexpr size_t wgrad_sparse_lds_bytes() { return SpRed<C>::BYTES; }
 
 // Processes tiles tile0, tile0 + tstride, ... < tend (tile = image * STRIPS + strip) and writes ONE slab [9 CA + 1][8].
 template <class C>
@@ -235,22 +246,30 @@ __device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const in
     }
 
     // ---- every lane's block through LDS, then thread (row, co) sums the 32 lanes of its output channel in a fixed order ----
-    float* red = (float*)smem;                                 // [NACC][256]
+    float* red = (float*)smem;                                 // [NACC][256], or RCH rows of it at a time (SpRed)
+    constexpr int RCH = SpRed<C>::RCH;                         // (process() ended with a barrier: the X tile is free)
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int r0 = 0; r0 < C::NACC; r0 += RCH) {
 #pragma unroll
-        for (int c = 0; c < CA; ++c) red[(t * CA + c) * 256 + tid] = acc[t][c];
-    red[9 * CA * 256 + tid] = bsum;
-    __syncthreads();
-    for (int i = tid; i < C::NACC * 8; i += 256) {
-        const int r = i >> 3, c = i & 7;
-        const float* src = red + r * 256 + c;                  // lanes c, c + 8, ...: stride 8 floats
-        float v = 0.f;
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 32; ++j) v += src[8 * j];
-        slab[i] = v;
+            for (int c = 0; c < CA; ++c) {
+                const int r = t * CA + c;                      // (compile-time after unrolling: rows outside the chunk fold away)
+                if (r >= r0 && r < r0 + RCH) red[(r - r0) * 256 + tid] = acc[t][c];
+            }
+        if (9 * CA >= r0 && 9 * CA < r0 + RCH) red[(9 * CA - r0) * 256 + tid] = bsum;
+        __syncthreads();
+        const int rows = (C::NACC - r0) < RCH ? (C::NACC - r0) : RCH;
+        for (int i = tid; i < rows * 8; i += 256) {
+            const int r = i >> 3, c = i & 7;
+            const float* src = red + r * 256 + c;              // lanes c, c + 8, ...: stride 8 floats
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) v += src[8 * j];
+            slab[r0 * 8 + i] = v;
+        }
+        __syncthreads();   // the LDS region is reused by the next chunk / a following stage
     }
-    __syncthreads();   // the LDS region may be reused by a following stage
 }
 
 // ---- which MFMA weight-gradient configurations have a sparse form (same tiles: image x strips of 8 / 16 rows) ----

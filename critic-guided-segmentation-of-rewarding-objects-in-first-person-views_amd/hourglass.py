@@ -7,6 +7,7 @@ Reference map:
   masker_forward   UnetDecoder.forward          nets.py:494-523
   *_backward       what loss.backward() does for those modules (main.py:198,462)
 """
+import os
 import ctypes as C
 from typing import Dict, List, Optional
 
@@ -37,6 +38,9 @@ CRITIC_FWD_FUSED = True
 DEC0_TAIL_BWD_FUSED = True
 # the decoder tail's forward and dec_model.0 as ONE launch, one workgroup per image (tail_dec_fwd_kernel<true>, round 4)
 DEC_TAIL_DEC0_FUSED = True
+# features.3's data gradient behind the encoder tail's backward in ONE launch (tail_enc_bwd_kernel<true>, round 5); its weight gradient then
+# rides in the features.0 backward launch of the same pass (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1)
+ENC1_TAIL_BWD_FUSED = os.environ.get("CGS_ENC1_TAIL_BWD_FUSED", "1") != "0"      # (A/B switch for tools/; the product default is on)
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
@@ -296,9 +300,15 @@ def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor
     r0 = ranges[0]
     r1 = ranges[1] if len(ranges) > 1 else (None, None, None, 0, 0, None)
     if enc0 is not None:
-        n_e, x_e, dy_e, am_e, slab_e = enc0
-        _lib.call("cgs_enc0_wgrad_u8_with_head", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4],
-                  r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw), _stream())
+        n_e, x_e, dy_e, am_e, slab_e = enc0[:5]
+        e1w = enc0[5] if len(enc0) > 5 else None          # features.3's deferred weight gradient: (n, e0, d e1, am1, slab, rows)
+        if e1w is not None:
+            _lib.call("cgs_enc0_wgrad_u8_with_head_enc1", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]),
+                      r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw),
+                      int(e1w[0]), _p(e1w[1]), _p(e1w[2]), _p(e1w[3]), _p(e1w[4]), int(e1w[5]), _stream())
+        else:
+            _lib.call("cgs_enc0_wgrad_u8_with_head", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4],
+                      r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw), _stream())
     else:
         _lib.call("cgs_tail_head_wgrad", r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]), r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4],
                   _p(sl), _p(slpw), _stream())
@@ -342,6 +352,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     side = side if side is not None else NO_SIDE
     lib = _lib.load()
     first_layer = 3
+    enc1_wgrad = None        # features.3's weight gradient, deferred into this pass's features.0 backward launch (ENC1_TAIL_BWD_FUSED)
     if TAIL_BWD and not (has_add and d_embeds[4] is not None and pw_bwd is None):
         # head + features.10 + features.6 backward in one tail kernel: d e1 (skip gradients included)
         use_pw = pw_bwd is not None and has_add
@@ -352,14 +363,30 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         d_cur = buf("de1", (n, 16, 16, 8))
         tw = tail_enc_weights(flat, lay, (pw_bwd[1].value, None) if use_pw else None)
         rd = rider if rider is not None else (0, None, None, None, None, 0)      # (n, e0, o1, dy, slab, rows): dec_model.0's weight gradient
-        _lib.call("cgs_tail_enc_bwd_rider", n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
-                  _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
-                  _p(loss[0]) if (dpred is None and loss is not None) else None, float(loss[1]) if loss is not None else 0.0,
-                  int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None,
-                  _p(d_embeds[2]) if has_add else None, _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None,
-                  n_add if has_add else 0, _p(d_cur), _p(hvec), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
-                  drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
-                  int(rd[0]), _p(rd[1]), _p(rd[2]), _p(rd[3]), _p(rd[4]), int(rd[5]), _stream())
+        targs = (n, C.byref(tw), _p(saved["e1"]), _p(saved["e2"]), _p(saved["am2"]), _p(saved["e3"]),
+                 _p(saved["am3"]), _p(saved["e4"]), _p(saved["h1"]), _p(saved["pred"]), _p(dpred),
+                 _p(loss[0]) if (dpred is None and loss is not None) else None, float(loss[1]) if loss is not None else 0.0,
+                 int(bool(loss[2])) if loss is not None else 0, _p(d_embeds[1]) if has_add else None,
+                 _p(d_embeds[2]) if has_add else None, _p(d_embeds[3]) if has_add else None, _p(pw_bwd[0]) if use_pw else None,
+                 n_add if has_add else 0, _p(d_cur), _p(hvec), _p(sl10), _p(sl6), drop.desc(DROP_SITE_E2, True, 128),
+                 drop.desc(DROP_SITE_E3, True, 64), drop.desc(DROP_SITE_H1, True, 8),
+                 int(rd[0]), _p(rd[1]), _p(rd[2]), _p(rd[3]), _p(rd[4]), int(rd[5]))
+        # features.3's data gradient in the same launch when the pass's features.0 backward launch can take its weight gradient along (the
+        # mixes' cgs_enc0_bwd_mix, or the uint8 frames' weight gradient deferred into head_wgrad) -- or when no weight gradient is needed
+        enc1_host = (mix_bwd is not None) or (u8 and head_sink is not None and dx is None)
+        fused1 = False
+        which = os.environ.get("CGS_ENC1_TAIL_BWD_WHICH", "both")       # (A/B switch for tools/: "mix" / "a" = only that pass)
+        want = which == "both" or (which == "mix") == (mix_bwd is not None)
+        if ENC1_TAIL_BWD_FUSED and want and 1 in BOTH_ENC and (enc1_host or not need_wgrad):
+            de0 = buf("de0", (n, 32, 32, 8))
+            rc = lib.cgs_tail_enc_bwd_enc1(*targs, _p(saved["am1"]), C.c_void_p(fp + 4 * lay.off("features.3.weight")),
+                                           _p(d_embeds[0]) if has_add else None, n_add if has_add else 0, _p(de0), _stream())
+            if rc == 0:
+                fused1 = True
+            elif rc != _lib.ERR_UNSUPPORTED:
+                _lib.check(rc, "cgs_tail_enc_bwd_enc1")
+        if not fused1:
+            _lib.call("cgs_tail_enc_bwd_rider", *targs, _stream())
         rider = None
         if need_wgrad:
             plan.add(sl10, nsl, 9 * 8 * 16 + 16, lay.off("features.10.weight"))
@@ -370,6 +397,13 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             else:
                 head_wgrad([rng], plan, lay, ws)
         first_layer = 1
+        if fused1:
+            if need_wgrad:
+                nsl1 = lib.cgs_enc1_wgrad_rider_slabs(n)
+                slab1 = buf("slab_enc1", (nsl1, 9 * 8 * 8 + 8))
+                enc1_wgrad = (n, saved["e0"], d_cur, saved["am1"], slab1, nsl1)
+                plan.add(slab1, nsl1, 9 * 8 * 8 + 8, lay.off("features.3.weight"))
+            d_cur, first_layer = de0, 0
     if rider is not None:
         raise _lib.CgsError("critic_backward: a deferred dec_model.0 weight gradient needs the tail backward launch to ride with")
     # ---- head: d e3 = head gradient (through dropout) + decoder skip gradient ----
@@ -404,8 +438,10 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                 nsl = lib.cgs_enc0_bwd_mix_slabs(n)
                 slab = buf("slab_enc0", (nsl, cnt))
                 plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
-            _lib.call("cgs_enc0_bwd_mix", A8.shape[0], int(bool(inj)), _p(src) if (need_wgrad and not mixin) else None, _p(d_cur),
-                      _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(vfp), _p(dzp), _p(slab), _stream())
+            e1w = enc1_wgrad if enc1_wgrad is not None else (0, None, None, None, None, 0)
+            _lib.call("cgs_enc0_bwd_mix_enc1", A8.shape[0], int(bool(inj)), _p(src) if (need_wgrad and not mixin) else None, _p(d_cur),
+                      _p(saved["am0"]), wptr, _p(A8), _p(B8), _p(Zm), float(l1s), float(l2s), _p(vfp), _p(dzp), _p(slab),
+                      _p(e1w[1]), _p(e1w[2]), _p(e1w[3]), _p(e1w[4]), _stream())
             return None
         if need_wgrad and i in BOTH_ENC and (i > 0 or (dx is not None and dx_from == 0 and not u8)):
             # both halves in one launch: slab + d e{i-1} (dropout mask and decoder skip gradient fused)
@@ -427,7 +463,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             slab = buf(f"slab_enc{i}", (nsl, cnt))
             if i == 0 and head_sink is not None and u8:
                 # features.0 on the uint8 frames: launched together with the head's weight gradients (head_wgrad below)
-                head_sink.append({"enc0": (n, src, d_cur, saved["am0"], slab)})
+                head_sink.append({"enc0": (n, src, d_cur, saved["am0"], slab, enc1_wgrad)})
+                enc1_wgrad = None
             else:
                 with side.fork():
                     _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
@@ -442,6 +479,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             dd = conv_desc(m, hw, ca, cb, co, False, ups, act, pool, _lib.Dropout(0.0, 0, 0, None))
             _lib.call("cgs_conv3x3_bwd_data", C.byref(dd), _p(d_cur[dx_from:]), _p(saved["am0"][dx_from:]), wptr, None,
                       _lib.ACT_NONE, None, 0, _p(dx), None, _stream())
+    if enc1_wgrad is not None:
+        raise _lib.CgsError("critic_backward: features.3's deferred weight gradient found no features.0 launch to ride with")
     return dx
 
 

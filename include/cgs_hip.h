@@ -296,6 +296,19 @@ int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float
                            cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                            int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                            cgs_stream_t stream);
+/* cgs_tail_enc_bwd_rider AND the data-gradient half of features.3's backward (cgs_conv3x3_bwd_both of the 8 -> 8 layer at 32x32 with ReLU +
+ * pool, nets.py:173-175 backward: d e1 re-expanded by the argmax nibbles am1 [n,16,16,1], weights w_enc1 (HWIO [3][3][8][8]), + the decoder's
+ * skip gradient addend0 [n_addend,32,32,8] (NULL: none) -> de0 [n,32,32,8]) in ONE launch (round 5): every workgroup continues with the
+ * convolution of the image(s) whose tail it just ran, so d e1 never crosses a launch boundary.  That layer's weight gradient rides in the
+ * features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).  Bit-identical to the two launches. */
+int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
+                          const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
+                          const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2,
+                          const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec, float* slab10, float* slab6,
+                          cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
+                          int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
+                          const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
+                          cgs_stream_t stream);
 int cgs_tail_head_wgrad_slabs(int32_t n_total);
 int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
                         const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
@@ -306,6 +319,16 @@ int cgs_enc0_wgrad_u8_with_head(int32_t n, const uint8_t* x_u8, const float* dy,
                                 int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
                                 int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
                                 float* slab_head, float* slab_pw, cgs_stream_t stream);
+/* The same + features.3's weight gradient over n1w images (cgs_conv3x3_bwd_weight of the 8 -> 8 layer at 32x32 with ReLU + pool: input e0_1
+ * [n1w,32,32,8], pooled output gradient dy1 [n1w,16,16,8], argmax nibbles am1, slab1 [nslab1][584], nslab1 = cgs_enc1_wgrad_rider_slabs(n1w))
+ * as nslab1 more workgroups (slab1 = NULL: none) -- the weight-gradient half that cgs_tail_enc_bwd_enc1 leaves behind (round 5).        */
+int cgs_enc1_wgrad_rider_slabs(int32_t n);
+int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                     int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                     int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                     float* slab_head, float* slab_pw,
+                                     int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
+                                     cgs_stream_t stream);
 int cgs_tail_dec_bwd_slabs(int32_t n);
 int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
@@ -377,6 +400,12 @@ int cgs_enc0_bwd_mix_slabs(int32_t n_mix);
 int cgs_enc0_bwd_mix(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
                      const float* w_hwio, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
                      float l2_scale, const float* valuefak_pred, float* dzpre, float* slab, cgs_stream_t stream);
+/* The same + features.3's weight gradient over the n_mix mixes (e0_1 [n_mix,32,32,8], dy1 [n_mix,16,16,8], am1, slab1
+ * [cgs_enc1_wgrad_rider_slabs(n_mix)][584]; all NULL: none) as extra workgroups of the launch (round 5, see cgs_tail_enc_bwd_enc1). */
+int cgs_enc0_bwd_mix_enc1(int32_t n_a, int32_t inject, const float* mixed, const float* dy, const uint32_t* amask,
+                          const float* w_hwio, const uint8_t* a, const uint8_t* b, const float* z, float l1_scale,
+                          float l2_scale, const float* valuefak_pred, float* dzpre, float* slab,
+                          const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, cgs_stream_t stream);
 /* valuefak_pred (may be NULL): -staticnorm '' of main.py:415-418 -- the regulariser terms of A-image i are weighted by
  * (1 - valuefak_pred[i]) (L1) and its square (L2); with cgs_phase2_losses / cgs_reduce_adam the same weighting of the loss
  * VALUES is selected by flag bit 8 (weights from pred[n + i], zpart holding nzpart / n partial pairs per image).        */

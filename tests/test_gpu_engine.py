@@ -301,7 +301,9 @@ def test_ragged_batch_sizes_vs_oracle(g1, n):
 
 @pytest.mark.parametrize("n", [37, 600, 1100])
 def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, monkeypatch, n):
-    """Round 4: the whole critic forward of an image in one workgroup (cgs_critic_fwd_fused), decoder tail + dec_model.0
+    """Round 5: features.3's data gradient behind the encoder tail's backward (cgs_tail_enc_bwd_enc1; its weight gradient as extra workgroups
+    of the features.0 backward launch: cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1) against cgs_tail_enc_bwd_rider +
+    cgs_conv3x3_bwd_both.  Round 4: the whole critic forward of an image in one workgroup (cgs_critic_fwd_fused), decoder tail + dec_model.0
     (cgs_tail_dec_fwd_dec0) and dec_model.0's data gradient + decoder tail backward (cgs_dec0_tail_dec_bwd) run the same kernel bodies in
     the same order as the separate launches (cgs_conv3x3_fwd x2 + cgs_tail_enc_fwd, cgs_tail_dec_fwd_pack + cgs_conv3x3_fwd,
     cgs_conv3x3_bwd_data + cgs_tail_dec_bwd): two dropout-0.3 training steps and an inference give bitwise equal losses, parameters,
@@ -327,7 +329,7 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
         return [t.clone() for t in (e.losses, e.flat, e.m, e.v, pred, Z)]
 
     base = run()
-    flags = ("CRITIC_FWD_FUSED", "ENC1_TAIL_FUSED", "DEC_TAIL_DEC0_FUSED", "DEC0_TAIL_BWD_FUSED")
+    flags = ("CRITIC_FWD_FUSED", "ENC1_TAIL_FUSED", "DEC_TAIL_DEC0_FUSED", "DEC0_TAIL_BWD_FUSED", "ENC1_TAIL_BWD_FUSED")
     for off in ([(f,) for f in flags] if n < 100 else []) + [flags]:
         for f in off:
             monkeypatch.setattr(hg, f, False)
