@@ -164,8 +164,16 @@ struct MixBwdArgs {
 #ifndef CGS_R1_MIX
 #define CGS_R1_MIX 1
 #endif
+#ifndef CGS_MIX_WAVES
+#define CGS_MIX_WAVES 0
+#endif
+#if CGS_MIX_WAVES
+#define CGS_MIX_OCC __attribute__((amdgpu_waves_per_eu(CGS_MIX_WAVES, CGS_MIX_WAVES)))
+#else
+#define CGS_MIX_OCC
+#endif
 template <class CWG, bool SPARSE>
-__global__ void __launch_bounds__(256) enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, WgradParams pw1, int nbw1) {
+__global__ void __launch_bounds__(256) CGS_MIX_OCC enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, WgradParams pw1, int nbw1) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(ConvParams) + sizeof(MixBwdArgs) + 16>();
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
     static_assert(CWG::G::THREADS == 256 && DEnc0::THREADS * DEnc0::CW == 256 && G::IMGS == 1, "workgroup shape");

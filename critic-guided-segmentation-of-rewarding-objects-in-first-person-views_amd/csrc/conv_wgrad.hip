@@ -78,7 +78,15 @@ static int launch_wgrad(WgradParams P, hipStream_t st) {
 #ifndef CGS_R1_U8
 #define CGS_R1_U8 1
 #endif
-__global__ void __launch_bounds__(256) wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw, WgradParams P1, int nbw1) {
+#ifndef CGS_U8_WAVES
+#define CGS_U8_WAVES 0
+#endif
+#if CGS_U8_WAVES
+#define CGS_U8_OCC __attribute__((amdgpu_waves_per_eu(CGS_U8_WAVES, CGS_U8_WAVES)))
+#else
+#define CGS_U8_OCC
+#endif
+__global__ void __launch_bounds__(256) CGS_U8_OCC wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw, WgradParams P1, int nbw1) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(HeadWgradParams) + 16>();
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     // block order (A/B: CGS_R1_U8): 0 = [riders | features.0 | head], 1 = [features.0 | riders | head], 2 = [features.0 | head | riders]

@@ -452,6 +452,9 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
     }
 }
 
+#ifndef CGS_REDUCE_DEEP
+#define CGS_REDUCE_DEEP 0
+#endif
 template <int SL>
 __global__ void __launch_bounds__(32 * SL) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
                                                               AdamArgs A, LossArgs L) {
@@ -484,6 +487,18 @@ __global__ void __launch_bounds__(32 * SL) reduce_adam_kernel(const cgs_reduce_j
         if (i < j.count) {
             const float* p = j.slab + i;
             int b = sl;
+#if CGS_REDUCE_DEEP
+            // (A/B round 5) 32 loads in flight per thread for the 512- and 1024-row jobs: half as many dependent memory round trips
+            for (; b + 31 * SL < j.nslab; b += 32 * SL) {
+                float t[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) t[u] = p[(size_t)(b + u * SL) * j.stride];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s[u] += t[u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s[u] += t[16 + u];
+            }
+#endif
             for (; b + 15 * SL < j.nslab; b += 16 * SL) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];

@@ -20,6 +20,7 @@
 #include "head_wgrad.h"
 #include "wgrad_dec0.h"
 #include "conv_body.h"
+#include "wgrad_sparse.h"
 
 namespace {
 
@@ -608,9 +609,12 @@ struct TailEncBwdParams {
 // loader, the decoder's skip gradient added in the epilogue; the static LDS block is its scratch) -- one launch boundary of the step's
 // dependent chain less per critic pass.  features.3's sparse weight gradient (only the final reduction waits for it) moves into the
 // features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).
+#ifndef CGS_ENC1_STAGGER
+#define CGS_ENC1_STAGGER 0
+#endif
 template <bool ENC1>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P, ConvParams PC) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams) + (ENC1 ? sizeof(ConvParams) : 0)>();
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P, ConvParams PC, WgradParams PW1) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams) + (ENC1 ? sizeof(ConvParams) + sizeof(WgradParams) : 0)>();
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
@@ -625,6 +629,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         wgrad_dec0_body(P.rider, (int)blockIdx.x - P.nblocks, (int)gridDim.x - P.nblocks, lds_all);
         return;
     }
+#if CGS_ENC1_STAGGER
+    if constexpr (ENC1) cgs_stagger<8, CGS_ENC1_STAGGER>();   // (A/B) latency-bound tail stages, then the issue-bound convolution: offset the co-resident workgroups
+#endif
     float* tiles = lds_all;                                              // after the loop: scratch of the weight-gradient reduction
     float* x1 = tiles + OX1;       // e1: X of features.6
     float* x2 = tiles + OX2;       // dropout(e2): X of features.10
@@ -843,6 +850,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
     wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
     if constexpr (ENC1) {
+        if (PW1.slab) {
+            // features.3's WEIGHT gradient of this workgroup's images, sparse form (wgrad_sparse.h: one non-zero of the pre-pool gradient
+            // per pooling window and channel), one slab row per workgroup.  As rider workgroups of the features.0 backward launches the
+            // same work cost 24 us per step (LDS-read-bound chains of 8 tiles next to LDS-bound roles, r05k); here it runs between this
+            // image's latency-bound tail stages and the other resident workgroups' convolutions.
+            __syncthreads();
+            // (opaque block index / zero: nothing of this phase can be computed -- and held in registers -- before this point)
+            int b0 = (int)blockIdx.x, tz = 0;
+            asm volatile("" : "+s"(b0));
+            asm volatile("" : "+v"(tz));
+            const int nb = P.nblocks;
+            const int nimg = b0 < P.n ? (P.n - b0 + nb - 1) / nb : 0;
+            wgrad_sparse8_body_seq(PW1, [=](int k) { return 2 * (b0 + (k >> 1) * nb) + (k & 1); }, 2 * nimg,
+                                   PW1.slab + (size_t)b0 * ((9 * 8 + 1) * 8), (float4*)lds_all, tz);
+        }
         // features.3's data gradient of this workgroup's images: their d e1 is in memory (stored by this workgroup, visible after the
         // barrier), every tile and the reduction scratch above are dead
         for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
@@ -865,7 +887,7 @@ static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const f
                                const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
                                float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                                int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
-                               const ConvParams* enc1, cgs_stream_t stream) {
+                               const ConvParams* enc1, const WgradParams* enc1w, cgs_stream_t stream) {
     if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
     if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
@@ -875,8 +897,8 @@ static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const f
                        hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
                        WDec0Params{e0_r, o1_r, dy_r, slab_r, n_r, n_r * kStrips}};
     const int riders = slab_r ? nslab_r : 0;
-    if (enc1) hipLaunchKernelGGL(tail_enc_bwd_kernel<true>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, *enc1);
-    else hipLaunchKernelGGL(tail_enc_bwd_kernel<false>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
+    if (enc1) hipLaunchKernelGGL(tail_enc_bwd_kernel<true>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, *enc1, enc1w ? *enc1w : WgradParams{});
+    else hipLaunchKernelGGL(tail_enc_bwd_kernel<false>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, WgradParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -889,7 +911,7 @@ extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, 
                                       int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                                       cgs_stream_t stream) {
     return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
-                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, nullptr, stream);
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, nullptr, nullptr, stream);
 }
 
 // cgs_tail_enc_bwd_rider AND features.3's data gradient (the data-gradient half of cgs_conv3x3_bwd_both for the 8 -> 8 layer at 32x32 with
@@ -903,13 +925,16 @@ extern "C" int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, c
                                      float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                                      int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                                      const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
-                                     cgs_stream_t stream) {
-    if (!am1 || !w_enc1 || !de0 || n_addend < 0 || (n_addend > 0 && !addend0)) return CGS_ERR_BADARG;
+                                     const float* e0, float* slab1, cgs_stream_t stream) {
+    if (!am1 || !w_enc1 || !de0 || n_addend < 0 || (n_addend > 0 && !addend0) || (slab1 && !e0)) return CGS_ERR_BADARG;
     if (conv_lds_bytes<DEnc1P>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
+    if (wgrad_sparse_lds_bytes<SpCfg<32, 8, WSRC_F32>>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
     ConvParams pd{};
     pd.src_a = de1; pd.amask_in = am1; pd.w = w_enc1; pd.out = de0; pd.addend = addend0; pd.n_addend = n_addend; pd.n = n;
+    WgradParams pw{};
+    pw.src_a = e0; pw.dy = de1; pw.amask = am1; pw.slab = slab1; pw.n = n; pw.ntiles = 2 * n;
     return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
-                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, &pd, stream);
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, &pd, &pw, stream);
 }
 
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,

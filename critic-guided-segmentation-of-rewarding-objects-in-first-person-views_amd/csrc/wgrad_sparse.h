@@ -35,6 +35,9 @@ struct SpCfg {
 #ifndef CGS_SPRED_CHUNKED
 #define CGS_SPRED_CHUNKED 1
 #endif
+#ifndef CGS_SPARSE8_LEAN
+#define CGS_SPARSE8_LEAN 1
+#endif
 template <class C>
 struct SpRed {
     static constexpr size_t TILE = (size_t)C::TRA * C::RS * 4 + 16, FULL = (size_t)C::NACC * 256 * 4;
@@ -45,10 +48,12 @@ struct SpRed {
 template <class C>
 static constexpr size_t wgrad_sparse_lds_bytes() { return SpRed<C>::BYTES; }
 
-// Processes tiles tile0, tile0 + tstride, ... < tend (tile = image * STRIPS + strip) and writes ONE slab [9 CA + 1][8].
-template <class C>
-__device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const int tile0, const int tstride, const int tend,
-                                                  float* slab, float4* smem) {
+// Processes the tiles seq(0), seq(1), ... seq(cnt - 1) (tile = image * STRIPS + strip) and writes ONE slab [9 CA + 1][8].
+// tid_bias: 0, or an OPAQUE zero when this body is one phase of a longer kernel (tail.hip) -- every address below derives from the thread
+// id, and without it the compiler computes them at the top of the kernel and keeps them in registers through the phases before.
+template <class C, class SEQ>
+__device__ __forceinline__ void wgrad_sparse_body_seq(const WgradParams& P, const SEQ seq, const int cnt, float* slab, float4* smem,
+                                                      const int tid_bias = 0) {
     constexpr int W = C::W, H = C::H, S = C::S, PW = C::PW, TH = C::TH, CA = C::CA;
     constexpr int HP = H / 2, WP = W / 2;
     float* xt = (float*)smem;                                  // [TRA] rows of RS dwords, [PW][S] float4 slots in a row
@@ -58,7 +63,7 @@ __device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const in
         q[0] = make_float2(v.x, v.y);
         q[1] = make_float2(v.z, v.w);
     };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x + tid_bias, lane = tid & 63, wave = tid >> 6;
     const int co = tid & 7, cell0 = tid >> 3;                  // pairs of this thread: cells cell0 + 32 k, k = 0..3
     const int N = P.n;
 
@@ -195,14 +200,15 @@ __device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const in
 #pragma unroll
         for (int c = 0; c < CA; ++c) acc[t][c] = 0.f;
 
-    auto process = [&](int tile, Stage& R) {
+    auto process = [&](int kt, Stage& R) {
+        const int tile = seq(kt);
         float val[4];
         uint32_t nib[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { val[k] = R.pval[k]; nib[k] = R.pnib[k]; }
         commit(tile, R);
         __syncthreads();
-        if (tile + 2 * tstride < tend) fetch(tile + 2 * tstride, R);      // the stage is free again: two tiles ahead
+        if (kt + 2 < cnt) fetch(seq(kt + 2), R);      // the stage is free again: two tiles ahead
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int cell = cell0 + 32 * k, cyl = cell / C::CPR, cx = cell % C::CPR;
@@ -234,15 +240,12 @@ __device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const in
         }
         __syncthreads();
     };
-    int tile = tile0;
-    if (tile < tend) fetch(tile, stg[0]);
-    if (tile + tstride < tend) fetch(tile + tstride, stg[1]);
-    while (tile < tend) {
-        process(tile, stg[0]);
-        tile += tstride;
-        if (tile >= tend) break;
-        process(tile, stg[1]);
-        tile += tstride;
+    if (cnt > 0) fetch(seq(0), stg[0]);
+    if (cnt > 1) fetch(seq(1), stg[1]);
+    for (int k = 0; k < cnt; k += 2) {
+        process(k, stg[0]);
+        if (k + 1 >= cnt) break;
+        process(k + 1, stg[1]);
     }
 
     // ---- every lane's block through LDS, then thread (row, co) sums the 32 lanes of its output channel in a fixed order ----
@@ -270,6 +273,134 @@ __device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const in
         }
         __syncthreads();   // the LDS region is reused by the next chunk / a following stage
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// features.3 (CA = 8, 32x32), register-lean form (round 5).  The general body above keeps a thread's whole [9][8] block (72 accumulators) and
+// two prefetch stages in registers: compiled as a ROLE of another kernel it takes 256 VGPRs (wgrad_enc0u8_head_kernel went from 60 to 256
+// registers and from five workgroups per CU to two when it hosted the role: that, not the role's own work, made it a 24 us rider).  Here a
+// (pool cell, output channel) pair is shared by TWO threads, one per half of the input channels: 36 accumulators, 9 b128 LDS reads per
+// half-pair (the same LDS traffic and multiply-adds in total), ONE tile ahead in flight (X rows raw in 5 float4, the 8 gradient values, the 8
+// argmax nibbles packed into one dword).  Thread tid: co = tid & 7, half = (tid >> 3) & 1, cell lane = tid >> 4; cells lane + 16 k, k = 0..7.
+// Reduction: rows (tap, ci) of half h come from the 128 threads of that half -> [row][16 lanes][8 co] in LDS, two chunks of <= 38 rows.
+// ------------------------------------------------------------------------------------------------
+template <class SEQ>
+__device__ __forceinline__ void wgrad_sparse8_body_seq(const WgradParams& P, const SEQ seq, const int cnt, float* slab, float4* smem,
+                                                       const int tid_bias = 0) {
+    using C = SpCfg<32, 8, WSRC_F32>;
+    constexpr int W = C::W, H = C::H, S = C::S, PW = C::PW, TH = C::TH, RS = C::RS, HP = H / 2, WP = W / 2;
+    float* xt = (float*)smem;
+    const int tid = threadIdx.x + tid_bias;
+    const int co = tid & 7, half = (tid >> 3) & 1, cl = tid >> 4;
+    auto slot_store = [&](int r, int slot, const float4& v) { *(float4*)(xt + r * RS + 4 * slot) = v; };      // RS = 276: rows 16-byte aligned
+    for (int e = tid; e < C::TRA * (PW - W) * S; e += 256) {        // zero halo columns, written once
+        const int sidx = e % S, c = (e / S) % (PW - W), r = e / (S * (PW - W));
+        slot_store(r, (c == 0 ? 0 : W + c) * S + sidx, f4zero());
+    }
+    constexpr int NF = C::TRA * W * S, ITF = (NF + 255) / 256;      // 1152 float4 per tile: 4.5 per thread
+    float4 gf[ITF];
+    float pval[8];
+    uint32_t pnibs = 0;
+    auto fetch = [&](int tile) {
+        const int n = tile / C::STRIPS, row0 = (tile % C::STRIPS) * TH, crow0 = (tile % C::STRIPS) * C::CROWS;
+        pnibs = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cell = cl + 16 * k, cy = crow0 + cell / C::CPR, cx = cell % C::CPR;
+            const int pi = (n * HP + cy) * WP + cx;
+            pval[k] = P.dy[(size_t)pi * 8 + co];
+            pnibs |= ((P.amask[pi] >> (4 * co)) & 15u) << (4 * k);
+        }
+#pragma unroll
+        for (int it = 0; it < ITF; ++it) {
+            int e = tid + 256 * it; e = e < NF ? e : NF - 1;
+            const int sidx = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
+            const bool in = y >= 0 && y < H;
+            gf[it] = ((const float4*)P.src_a)[in ? ((n * H + y) * W + x) * S + sidx : 0];
+        }
+    };
+    auto commit = [&](int tile) {
+        const int row0 = (tile % C::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < ITF; ++it) {
+            const int e = tid + 256 * it;
+            if (e < NF) {
+                const int sidx = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
+                slot_store(r, (x + 1) * S + sidx, (y >= 0 && y < H) ? gf[it] : f4zero());
+            }
+        }
+    };
+    float acc[9][4];
+    float bsum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
+    if (cnt > 0) fetch(seq(0));
+    for (int kt = 0; kt < cnt; ++kt) {
+        float val[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) val[k] = pval[k];
+        const uint32_t nibs = pnibs;
+        commit(seq(kt));
+        __syncthreads();
+        if (kt + 1 < cnt) fetch(seq(kt + 1));              // one tile ahead: its loads fly during this tile's multiply-adds
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cell = cl + 16 * k, cyl = cell / C::CPR, cx = cell % C::CPR;
+            const uint32_t nib = (nibs >> (4 * k)) & 15u;
+            const bool dead = nib > 3u;
+            const float v = dead ? 0.f : val[k];
+            const int pos = dead ? 0 : (int)nib;
+            const float* p = xt + (2 * cyl + (pos >> 1)) * RS + (2 * cx + (pos & 1)) * 4 * S + 4 * half;
+            bsum += v;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4 x = *(const float4*)(p + (t / 3) * RS + (t % 3) * 4 * S);
+                acc[t][0] = fmaf(x.x, v, acc[t][0]);
+                acc[t][1] = fmaf(x.y, v, acc[t][1]);
+                acc[t][2] = fmaf(x.z, v, acc[t][2]);
+                acc[t][3] = fmaf(x.w, v, acc[t][3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);             // one half-pair at a time: interleaving them costs 36 more registers each
+        }
+        __syncthreads();
+    }
+    // ---- reduction: row r = tap * 8 + 4 * half + c from the 128 threads of that half; [row][cell lane 0..15][co] -> sum over the lanes ----
+    float* red = (float*)smem;
+    constexpr int NROW = 73, RCH = 38;                      // 38 rows x 128 floats = 19.5 KB <= the X tile's 19.9 KB
+    static_assert((size_t)RCH * 128 * 4 <= (size_t)C::TRA * C::RS * 4, "reduction chunk fits the tile");
+#pragma unroll
+    for (int r0 = 0; r0 < NROW; r0 += RCH) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // rows of this thread: t * 8 + 4 * half + c, half = 0 / 1 -> the chunk test is per half (uniform per 8-lane group)
+                const int r = t * 8 + 4 * half + c;
+                if (r >= r0 && r < r0 + RCH) red[(r - r0) * 128 + cl * 8 + co] = acc[t][c];
+            }
+        if (half == 0 && 72 >= r0 && 72 < r0 + RCH) red[(72 - r0) * 128 + cl * 8 + co] = bsum;
+        __syncthreads();
+        const int rows = (NROW - r0) < RCH ? (NROW - r0) : RCH;
+        for (int i = tid; i < rows * 8; i += 256) {
+            const float* src = red + (i >> 3) * 128 + (i & 7);
+            float v = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v += src[8 * j];
+            slab[r0 * 8 + i] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// tiles tile0, tile0 + tstride, ... < tend
+template <class C>
+__device__ __forceinline__ void wgrad_sparse_body(const WgradParams& P, const int tile0, const int tstride, const int tend,
+                                                  float* slab, float4* smem) {
+    const int cnt = tile0 < tend ? (tend - tile0 + tstride - 1) / tstride : 0;
+    if constexpr (C::CA == 8 && C::SRC == WSRC_F32 && CGS_SPARSE8_LEAN) wgrad_sparse8_body_seq(P, [=](int k) { return tile0 + k * tstride; }, cnt, slab, smem);
+    else wgrad_sparse_body_seq<C>(P, [=](int k) { return tile0 + k * tstride; }, cnt, slab, smem);
 }
 
 // ---- which MFMA weight-gradient configurations have a sparse form (same tiles: image x strips of 8 / 16 rows) ----

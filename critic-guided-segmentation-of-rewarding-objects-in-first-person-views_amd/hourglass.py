@@ -41,6 +41,9 @@ DEC_TAIL_DEC0_FUSED = True
 # features.3's data gradient behind the encoder tail's backward in ONE launch (tail_enc_bwd_kernel<true>, round 5); its weight gradient then
 # rides in the features.0 backward launch of the same pass (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1)
 ENC1_TAIL_BWD_FUSED = os.environ.get("CGS_ENC1_TAIL_BWD_FUSED", "1") != "0"      # (A/B switch for tools/; the product default is on)
+# ... and features.3's (sparse) weight gradient inside that kernel too, per workgroup over its own images (False: as rider workgroups of the
+# features.0 backward launch, which reproduces cgs_conv3x3_bwd_both's slabs bit for bit but costs 24 us per step, r05k)
+ENC1_WGRAD_IN_TAIL = os.environ.get("CGS_ENC1_WGRAD_IN_TAIL", "1") != "0"
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
@@ -375,12 +378,14 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         # mixes' cgs_enc0_bwd_mix, or the uint8 frames' weight gradient deferred into head_wgrad) -- or when no weight gradient is needed
         enc1_host = (mix_bwd is not None) or (u8 and head_sink is not None and dx is None)
         fused1 = False
-        which = os.environ.get("CGS_ENC1_TAIL_BWD_WHICH", "both")       # (A/B switch for tools/: "mix" / "a" = only that pass)
-        want = which == "both" or (which == "mix") == (mix_bwd is not None)
-        if ENC1_TAIL_BWD_FUSED and want and 1 in BOTH_ENC and (enc1_host or not need_wgrad):
+        if ENC1_TAIL_BWD_FUSED and 1 in BOTH_ENC and (ENC1_WGRAD_IN_TAIL or enc1_host or not need_wgrad):
             de0 = buf("de0", (n, 32, 32, 8))
+            # features.3's weight gradient inside the same kernel (ENC1_WGRAD_IN_TAIL) or as riders of the features.0 backward launch
+            # (one row per tail workgroup; engine._slab_views allocates the two passes' rows adjacent under the same name)
+            slab1_in = buf("slab_enc1", (nsl, 9 * 8 * 8 + 8)) if (need_wgrad and ENC1_WGRAD_IN_TAIL) else None
             rc = lib.cgs_tail_enc_bwd_enc1(*targs, _p(saved["am1"]), C.c_void_p(fp + 4 * lay.off("features.3.weight")),
-                                           _p(d_embeds[0]) if has_add else None, n_add if has_add else 0, _p(de0), _stream())
+                                           _p(d_embeds[0]) if has_add else None, n_add if has_add else 0, _p(de0),
+                                           _p(saved["e0"]) if slab1_in is not None else None, _p(slab1_in), _stream())
             if rc == 0:
                 fused1 = True
             elif rc != _lib.ERR_UNSUPPORTED:
@@ -398,7 +403,9 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                 head_wgrad([rng], plan, lay, ws)
         first_layer = 1
         if fused1:
-            if need_wgrad:
+            if need_wgrad and slab1_in is not None:
+                plan.add(slab1_in, nsl, 9 * 8 * 8 + 8, lay.off("features.3.weight"))
+            elif need_wgrad:
                 nsl1 = lib.cgs_enc1_wgrad_rider_slabs(n)
                 slab1 = buf("slab_enc1", (nsl1, 9 * 8 * 8 + 8))
                 enc1_wgrad = (n, saved["e0"], d_cur, saved["am1"], slab1, nsl1)

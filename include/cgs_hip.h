@@ -299,8 +299,11 @@ int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float
 /* cgs_tail_enc_bwd_rider AND the data-gradient half of features.3's backward (cgs_conv3x3_bwd_both of the 8 -> 8 layer at 32x32 with ReLU +
  * pool, nets.py:173-175 backward: d e1 re-expanded by the argmax nibbles am1 [n,16,16,1], weights w_enc1 (HWIO [3][3][8][8]), + the decoder's
  * skip gradient addend0 [n_addend,32,32,8] (NULL: none) -> de0 [n,32,32,8]) in ONE launch (round 5): every workgroup continues with the
- * convolution of the image(s) whose tail it just ran, so d e1 never crosses a launch boundary.  That layer's weight gradient rides in the
- * features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).  Bit-identical to the two launches. */
+ * convolution of the image(s) whose tail it just ran, so d e1 never crosses a launch boundary.  That layer's WEIGHT gradient: slab1 != NULL
+ * (with e0 [n,32,32,8], the layer's input): formed here too, per workgroup over its own images, slab1 [cgs_tail_enc_bwd_slabs(n)][584] (the
+ * partition of the sum over the images differs from cgs_conv3x3_bwd_weight's: equal up to fp32 summation order); slab1 = NULL: left to
+ * extra workgroups of the features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1), which
+ * reproduce cgs_conv3x3_bwd_both's slabs bit for bit.  de0 is bit-identical to the two-launch form either way.                     */
 int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                           const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
                           const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2,
@@ -308,7 +311,7 @@ int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float*
                           cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                           int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                           const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
-                          cgs_stream_t stream);
+                          const float* e0, float* slab1, cgs_stream_t stream);
 int cgs_tail_head_wgrad_slabs(int32_t n_total);
 int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
                         const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,

@@ -328,6 +328,12 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
         torch.cuda.synchronize()
         return [t.clone() for t in (e.losses, e.flat, e.m, e.v, pred, Z)]
 
+    # features.3's weight gradient: formed inside the fused tail backward kernel by default (ENC1_WGRAD_IN_TAIL: one slab row per workgroup over
+    # ITS images -- a different partition of the sum over the images than the stand-alone launch's, so equal only up to fp32 summation
+    # order); with that switched off it rides as extra workgroups that reproduce the stand-alone launch's slabs bit for bit.  The bitwise
+    # comparisons therefore run in the rider form; the default form is compared with it at the end, within a summation-order tolerance.
+    default = run()
+    monkeypatch.setattr(hg, "ENC1_WGRAD_IN_TAIL", False)
     base = run()
     flags = ("CRITIC_FWD_FUSED", "ENC1_TAIL_FUSED", "DEC_TAIL_DEC0_FUSED", "DEC0_TAIL_BWD_FUSED", "ENC1_TAIL_BWD_FUSED")
     for off in ([(f,) for f in flags] if n < 100 else []) + [flags]:
@@ -338,3 +344,6 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
             monkeypatch.setattr(hg, f, True)
         for a, b, what in zip(got, base, ("losses", "parameters", "m", "v", "pred", "Z")):
             assert torch.equal(a, b), f"{what} differ with {off} switched off"
+    for a, b, what in zip(default, base, ("losses", "parameters", "m", "v", "pred", "Z")):
+        # two Adam steps: a gradient element that differs by an ulp moves its parameter by up to ~lr * 1e-3 (Adam's normalised step)
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6), f"{what}: the in-kernel weight gradient of features.3 vs its rider form: {float((a - b).abs().max())}"
