@@ -96,7 +96,7 @@ SIGNATURES = {
     "cgs_tail_enc_bwd_slabs": (i32, [i32]),
     "cgs_tail_enc_bwd": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, vp]),
     "cgs_tail_enc_bwd_rider": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, i32, vp, vp, vp, vp, i32, vp]),
-    "cgs_tail_enc_bwd_enc1": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
+    "cgs_tail_enc_bwd_enc1": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]),
     "cgs_enc1_wgrad_rider_slabs": (i32, [i32]),
     "cgs_enc0_wgrad_u8_with_head_enc1": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp]),
     "cgs_enc0_bwd_mix_enc1": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -612,9 +612,14 @@ struct TailEncBwdParams {
 #ifndef CGS_ENC1_STAGGER
 #define CGS_ENC1_STAGGER 0
 #endif
-template <bool ENC1>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P, ConvParams PC, WgradParams PW1) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams) + (ENC1 ? sizeof(ConvParams) + sizeof(WgradParams) : 0)>();
+// MODE 2 / 3 (round 5): ... and features.0's sparse WEIGHT gradient of the same images on the uint8 frames (2) / the virtual mixes (3), after
+// their d e0 has been written: the critic's whole backward pass of an image except features.0's data gradient in one workgroup; the
+// stand-alone launches then hold no weight-gradient role of this pass (cgs_enc0_bwd_mix(slab = NULL), cgs_tail_head_wgrad alone).
+template <int MODE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_enc_bwd_kernel(TailEncBwdParams P, ConvParams PC, WgradParams PW1,
+                                                                                                       WgradParams PW0) {
+    constexpr bool ENC1 = MODE >= 1;
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncBwdParams) + (ENC1 ? sizeof(ConvParams) + sizeof(WgradParams) : 0) + (MODE >= 2 ? sizeof(WgradParams) : 0)>();
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
@@ -871,6 +876,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             __syncthreads();
             conv3x3_body_pipe<DEnc1P>(PC, 2 * img, (float4*)lds_all);
         }
+        if constexpr (MODE >= 2) {
+            if (PW0.slab) {
+                // features.0's weight gradient of this workgroup's images (8 strips each) from the d e0 just written (same workgroup: visible
+                // after the barrier) and the frames / virtual mixes; one slab row per workgroup
+                __syncthreads();
+                int b0 = (int)blockIdx.x, tz = 0;
+                asm volatile("" : "+s"(b0));
+                asm volatile("" : "+v"(tz));
+                const int nb = P.nblocks;
+                const int nimg = b0 < P.n ? (P.n - b0 + nb - 1) / nb : 0;
+                using SP0 = SpCfg<64, 3, MODE == 2 ? WSRC_U8 : WSRC_MIX>;
+                wgrad_sparse_body_seq<SP0>(PW0, [=](int k) { return 8 * (b0 + (k >> 3) * nb) + (k & 7); }, 8 * nimg,
+                                           PW0.slab + (size_t)b0 * ((9 * 3 + 1) * 8), (float4*)lds_all, tz);
+            }
+        }
     }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
@@ -887,7 +907,7 @@ static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const f
                                const float* dE2, const float* dE3, const float* d_o4, int32_t n_add, float* de1, float* hvec,
                                float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                                int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
-                               const ConvParams* enc1, const WgradParams* enc1w, cgs_stream_t stream) {
+                               const ConvParams* enc1, const WgradParams* enc1w, const WgradParams* enc0w, int enc0_mix, cgs_stream_t stream) {
     if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred || !de1) return CGS_ERR_BADARG;
     if (!w->w6 || !w->w10 || !w->w14 || !w->wl1 || !w->wl2) return CGS_ERR_BADARG;
     if (d_o4 && !w->wpw) return CGS_ERR_BADARG;
@@ -897,8 +917,12 @@ static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const f
                        hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
                        WDec0Params{e0_r, o1_r, dy_r, slab_r, n_r, n_r * kStrips}};
     const int riders = slab_r ? nslab_r : 0;
-    if (enc1) hipLaunchKernelGGL(tail_enc_bwd_kernel<true>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, *enc1, enc1w ? *enc1w : WgradParams{});
-    else hipLaunchKernelGGL(tail_enc_bwd_kernel<false>, dim3(tail_blocks(n, tail_bwd_cap()) + riders), dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, WgradParams{});
+    const dim3 grid(tail_blocks(n, tail_bwd_cap()) + riders);
+    const WgradParams w1 = enc1w ? *enc1w : WgradParams{}, w0 = enc0w ? *enc0w : WgradParams{};
+    if (enc1 && enc0w && enc0_mix) hipLaunchKernelGGL(tail_enc_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, P, *enc1, w1, w0);
+    else if (enc1 && enc0w) hipLaunchKernelGGL(tail_enc_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, P, *enc1, w1, w0);
+    else if (enc1) hipLaunchKernelGGL(tail_enc_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, P, *enc1, w1, w0);
+    else hipLaunchKernelGGL(tail_enc_bwd_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, w1, w0);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -911,7 +935,7 @@ extern "C" int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, 
                                       int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                                       cgs_stream_t stream) {
     return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
-                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, nullptr, nullptr, stream);
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, nullptr, nullptr, nullptr, 0, stream);
 }
 
 // cgs_tail_enc_bwd_rider AND features.3's data gradient (the data-gradient half of cgs_conv3x3_bwd_both for the 8 -> 8 layer at 32x32 with
@@ -925,16 +949,31 @@ extern "C" int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, c
                                      float* slab10, float* slab6, cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                                      int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                                      const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
-                                     const float* e0, float* slab1, cgs_stream_t stream) {
+                                     const float* e0, float* slab1,
+                                     int32_t x_kind, const void* x, const uint32_t* am0, float* slab0, cgs_stream_t stream) {
     if (!am1 || !w_enc1 || !de0 || n_addend < 0 || (n_addend > 0 && !addend0) || (slab1 && !e0)) return CGS_ERR_BADARG;
+    if (slab0 && (!x || !am0 || (x_kind != CGS_SRC_U8 && x_kind != CGS_SRC_MIX))) return CGS_ERR_BADARG;
+    if (slab0 && wgrad_sparse_lds_bytes<SpCfg<64, 3, WSRC_U8>>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
     if (conv_lds_bytes<DEnc1P>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
     if (wgrad_sparse_lds_bytes<SpCfg<32, 8, WSRC_F32>>() > sizeof(float) * (size_t)kTailEncBwdLdsFloats) return CGS_ERR_UNSUPPORTED;
     ConvParams pd{};
     pd.src_a = de1; pd.amask_in = am1; pd.w = w_enc1; pd.out = de0; pd.addend = addend0; pd.n_addend = n_addend; pd.n = n;
     WgradParams pw{};
     pw.src_a = e0; pw.dy = de1; pw.amask = am1; pw.slab = slab1; pw.n = n; pw.ntiles = 2 * n;
+    WgradParams p0{};
+    if (slab0) {
+        p0.dy = de0; p0.amask = am0; p0.slab = slab0; p0.n = n; p0.ntiles = 8 * n;
+        if (x_kind == CGS_SRC_MIX) {
+            const cgs_mix_src* m = (const cgs_mix_src*)x;
+            if (!m->a || !m->b || !m->z || m->n_a <= 0 || (n != m->n_a && n != 2 * m->n_a)) return CGS_ERR_BADARG;
+            p0.mix_a = m->a; p0.mix_b = m->b; p0.mix_z = m->z; p0.mix_n_a = m->n_a;
+        } else {
+            p0.src_a = x;
+        }
+    }
     return tail_enc_bwd_launch(n, w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1, hvec,
-                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, &pd, &pw, stream);
+                               slab10, slab6, drop_e2, drop_e3, drop_h1, n_r, e0_r, o1_r, dy_r, slab_r, nslab_r, &pd, &pw, slab0 ? &p0 : nullptr,
+                               x_kind == CGS_SRC_MIX, stream);
 }
 
 extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,

@@ -44,6 +44,12 @@ ENC1_TAIL_BWD_FUSED = os.environ.get("CGS_ENC1_TAIL_BWD_FUSED", "1") != "0"     
 # ... and features.3's (sparse) weight gradient inside that kernel too, per workgroup over its own images (False: as rider workgroups of the
 # features.0 backward launch, which reproduces cgs_conv3x3_bwd_both's slabs bit for bit but costs 24 us per step, r05k)
 ENC1_WGRAD_IN_TAIL = os.environ.get("CGS_ENC1_WGRAD_IN_TAIL", "1") != "0"
+# ... and features.0's (sparse) weight gradient of the pass in the same kernel as well (uint8 frames / virtual mixes), after the image's d e0:
+# "A" = only the pass over A (features.0's stand-alone weight-gradient launch then holds only the head's GEMM), "mix" = only the mixes' pass
+# (cgs_enc0_bwd_mix then runs without its weight-gradient role), "both", "" = neither.  MEASURED SLOWER, default off (r05n, three interleaved
+# runs: 0.5642 ms without, 0.5649 "A", 0.5717 "mix", 0.5733 "both"): eight 8-row tiles per image lengthen the per-image chain by more than the
+# stand-alone roles cost next to features.0's data gradient.  Kept as an opt-in that the bit-identity test still exercises.
+ENC0_WGRAD_IN_TAIL = os.environ.get("CGS_ENC0_WGRAD_IN_TAIL", "")
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
@@ -279,6 +285,14 @@ def critic_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, dro
     return o
 
 
+def enc0_in_tail(mixin: bool, u8: bool, dx) -> bool:
+    """Does this critic pass form features.0's weight gradient inside its tail backward kernel (ENC0_WGRAD_IN_TAIL)?  Only the two forms the
+    training step uses: the virtual mixes, and uint8 frames without an image gradient."""
+    if mixin:
+        return ENC0_WGRAD_IN_TAIL in ("both", "mix")
+    return u8 and dx is None and ENC0_WGRAD_IN_TAIL in ("both", "A")
+
+
 def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor]):
     """Weight gradients of the critic head (+ the decoder's 1x1 conv) for the image ranges the tail backward kernel(s) left
     behind: ranges = [(hvec, e4, d_o4 or None, n, n_o4, pw_bwd or None)], at most two; one small GEMM over the images."""
@@ -355,6 +369,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
     side = side if side is not None else NO_SIDE
     lib = _lib.load()
     first_layer = 3
+    enc0_done = False        # features.0's weight gradient was formed inside the tail backward kernel (ENC0_WGRAD_IN_TAIL)
     enc1_wgrad = None        # features.3's weight gradient, deferred into this pass's features.0 backward launch (ENC1_TAIL_BWD_FUSED)
     if TAIL_BWD and not (has_add and d_embeds[4] is not None and pw_bwd is None):
         # head + features.10 + features.6 backward in one tail kernel: d e1 (skip gradients included)
@@ -383,9 +398,14 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             # features.3's weight gradient inside the same kernel (ENC1_WGRAD_IN_TAIL) or as riders of the features.0 backward launch
             # (one row per tail workgroup; engine._slab_views allocates the two passes' rows adjacent under the same name)
             slab1_in = buf("slab_enc1", (nsl, 9 * 8 * 8 + 8)) if (need_wgrad and ENC1_WGRAD_IN_TAIL) else None
+            slab0_in, xk, xp = None, 0, None
+            if need_wgrad and slab1_in is not None and enc0_in_tail(mixin, u8, dx):
+                slab0_in = buf("slab_enc0", (nsl, 9 * 3 * 8 + 8))
+                xk, xp = (_lib.SRC_MIX, x.ptr()) if mixin else (_lib.SRC_U8, _p(x))
             rc = lib.cgs_tail_enc_bwd_enc1(*targs, _p(saved["am1"]), C.c_void_p(fp + 4 * lay.off("features.3.weight")),
                                            _p(d_embeds[0]) if has_add else None, n_add if has_add else 0, _p(de0),
-                                           _p(saved["e0"]) if slab1_in is not None else None, _p(slab1_in), _stream())
+                                           _p(saved["e0"]) if slab1_in is not None else None, _p(slab1_in),
+                                           xk, xp, _p(saved["am0"]) if slab0_in is not None else None, _p(slab0_in), _stream())
             if rc == 0:
                 fused1 = True
             elif rc != _lib.ERR_UNSUPPORTED:
@@ -403,6 +423,9 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                 head_wgrad([rng], plan, lay, ws)
         first_layer = 1
         if fused1:
+            if slab0_in is not None:
+                plan.add(slab0_in, nsl, 9 * 3 * 8 + 8, lay.off("features.0.weight"))
+                enc0_done = True
             if need_wgrad and slab1_in is not None:
                 plan.add(slab1_in, nsl, 9 * 8 * 8 + 8, lay.off("features.3.weight"))
             elif need_wgrad:
@@ -441,7 +464,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             A8, B8, Zm, inj, l1s, l2s, dzp = mix_bwd[:7]
             vfp = mix_bwd[7] if len(mix_bwd) > 7 else None      # -staticnorm '': pred of A, the regulariser's per-image weight
             slab = None
-            if need_wgrad:
+            if need_wgrad and not enc0_done:
                 nsl = lib.cgs_enc0_bwd_mix_slabs(n)
                 slab = buf("slab_enc0", (nsl, cnt))
                 plan.add(slab, nsl, cnt, lay.off(key + ".weight"))
@@ -466,7 +489,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         nsl = lib.cgs_conv3x3_bwd_weight_slabs(C.byref(d))
         if nsl < 0:
             _lib.check(nsl, "cgs_conv3x3_bwd_weight_slabs")
-        if need_wgrad:
+        if need_wgrad and not (i == 0 and enc0_done):
             slab = buf(f"slab_enc{i}", (nsl, cnt))
             if i == 0 and head_sink is not None and u8:
                 # features.0 on the uint8 frames: launched together with the head's weight gradients (head_wgrad below)

@@ -303,7 +303,11 @@ int cgs_tail_enc_bwd_rider(int32_t n, const cgs_tail_enc_weights* w, const float
  * (with e0 [n,32,32,8], the layer's input): formed here too, per workgroup over its own images, slab1 [cgs_tail_enc_bwd_slabs(n)][584] (the
  * partition of the sum over the images differs from cgs_conv3x3_bwd_weight's: equal up to fp32 summation order); slab1 = NULL: left to
  * extra workgroups of the features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1), which
- * reproduce cgs_conv3x3_bwd_both's slabs bit for bit.  de0 is bit-identical to the two-launch form either way.                     */
+ * reproduce cgs_conv3x3_bwd_both's slabs bit for bit.  de0 is bit-identical to the two-launch form either way.
+ * slab0 != NULL: features.0's weight gradient of the same images as well (cgs_conv3x3_bwd_weight of the 3 -> 8 layer at 64x64 with ReLU + pool,
+ * nets.py:170-172 backward), from de0, the argmax nibbles am0 [n,32,32,1] and the layer's input x: x_kind = CGS_SRC_U8 (x = uint8 frames
+ * [n,64,64,3]) or CGS_SRC_MIX (x = the cgs_mix_src descriptor, n = n_a or 2 n_a); slab0 [cgs_tail_enc_bwd_slabs(n)][224], one row per
+ * workgroup over its own images (equal to the stand-alone launch up to fp32 summation order).                                        */
 int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float* e1, const float* e2, const uint32_t* am2,
                           const float* e3, const uint32_t* am3, const float* e4, const float* h1, const float* pred,
                           const float* dpred, const float* target, float loss_scale, int32_t bce, const float* dE1, const float* dE2,
@@ -311,7 +315,8 @@ int cgs_tail_enc_bwd_enc1(int32_t n, const cgs_tail_enc_weights* w, const float*
                           cgs_dropout drop_e2, cgs_dropout drop_e3, cgs_dropout drop_h1,
                           int32_t n_r, const float* e0_r, const float* o1_r, const float* dy_r, float* slab_r, int32_t nslab_r,
                           const uint32_t* am1, const float* w_enc1, const float* addend0, int32_t n_addend, float* de0,
-                          const float* e0, float* slab1, cgs_stream_t stream);
+                          const float* e0, float* slab1,
+                          int32_t x_kind, const void* x, const uint32_t* am0, float* slab0, cgs_stream_t stream);
 int cgs_tail_head_wgrad_slabs(int32_t n_total);
 int cgs_tail_head_wgrad(int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0, int32_t n1,
                         const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1, float* slab_head,
