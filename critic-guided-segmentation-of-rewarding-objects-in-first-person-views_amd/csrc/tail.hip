@@ -48,7 +48,14 @@ __device__ __forceinline__ float drop1(const DropCtx& dc, uint32_t i) {
 
 int tail_blocks(int n, int cap) { return n < cap ? n : cap; }
 int tail_fwd_cap() { return 1024; }      // persistent workgroups: swept on the step (round 2)
-int tail_bwd_cap() { return 512; }
+int tail_bwd_cap() { return 512; }       // decoder tail backward
+// encoder tail backward: 768 = three workgroups per CU (its 168 registers / 51 KB of LDS allow exactly that).  Round 5, with features.3's
+// data and weight gradients inside the kernel: the mixes' pass (1024 images at N = 512) on 768 workgroups -- 256 of them take two images --
+// measures 0.5577 ms per step against 0.5633 with 512 x 2 images, 0.5657 at 640, 0.5687 at 1024 (r05r / r05s, three interleaved runs each)
+#ifndef CGS_TAIL_ENC_BWD_CAP
+#define CGS_TAIL_ENC_BWD_CAP 768
+#endif
+int tail_enc_bwd_cap() { return CGS_TAIL_ENC_BWD_CAP; }
 
 unsigned long long* g_tail_stamps = nullptr;     // debug: per-workgroup stage time stamps (tools/tail_stamps.py)
 
@@ -610,7 +617,7 @@ struct TailEncBwdParams {
 // dependent chain less per critic pass.  features.3's sparse weight gradient (only the final reduction waits for it) moves into the
 // features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).
 #ifndef CGS_ENC1_STAGGER
-#define CGS_ENC1_STAGGER 0
+#define CGS_ENC1_STAGGER 64
 #endif
 // MODE 2 / 3 (round 5): ... and features.0's sparse WEIGHT gradient of the same images on the uint8 frames (2) / the virtual mixes (3), after
 // their d e0 has been written: the critic's whole backward pass of an image except features.0's data gradient in one workgroup; the
@@ -895,7 +902,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
-extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_bwd_cap()); }
+extern "C" int cgs_tail_enc_bwd_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : tail_blocks(n, tail_enc_bwd_cap()); }
 
 // cgs_tail_enc_bwd with dec_model.0's weight gradient (cgs_conv3x3_bwd_weight of that layer: n_r images, skip input e0_r [n_r,32,32,8],
 // low-resolution input o1_r [n_r,16,16,8], output gradient dy_r [n_r,32,32,8], slab_r [nslab_r][1160]) as nslab_r SPARE workgroups of
@@ -914,10 +921,10 @@ static int tail_enc_bwd_launch(int32_t n, const cgs_tail_enc_weights* w, const f
     if (slab_r && (n_r <= 0 || !e0_r || !o1_r || !dy_r || nslab_r <= 0 || nslab_r > n_r * kStrips)) return CGS_ERR_BADARG;
     if (n == 0) return slab_r ? CGS_ERR_BADARG : CGS_OK;
     TailEncBwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, dpred, target, loss_scale, bce, dE1, dE2, dE3, d_o4, n_add, de1,
-                       hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
+                       hvec, slab10, slab6, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_enc_bwd_cap()), g_tail_stamps ? g_tail_stamps + 2 * 2048 * 16 : nullptr,
                        WDec0Params{e0_r, o1_r, dy_r, slab_r, n_r, n_r * kStrips}};
     const int riders = slab_r ? nslab_r : 0;
-    const dim3 grid(tail_blocks(n, tail_bwd_cap()) + riders);
+    const dim3 grid(tail_blocks(n, tail_enc_bwd_cap()) + riders);
     const WgradParams w1 = enc1w ? *enc1w : WgradParams{}, w0 = enc0w ? *enc0w : WgradParams{};
     if (enc1 && enc0w && enc0_mix) hipLaunchKernelGGL(tail_enc_bwd_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, P, *enc1, w1, w0);
     else if (enc1 && enc0w) hipLaunchKernelGGL(tail_enc_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, P, *enc1, w1, w0);
