@@ -476,8 +476,8 @@ def test_config5_training_step_vs_autograd_of_the_build_restatement(n, chfak, ge
     """BASELINE config 5 as a TRAINING step (batch 256 = its stated size; 6 = a ragged small case): Hourglass128.phase2_step -- bf16
     activations / gradients, fp32 accumulate, fp32 master weights -- against the fp32 CPU autograd of oracle.hourglass128_phase2_loss.
     PARITY UNPINNED (no reference counterpart).  Stated bf16 tolerance: loss parts within 2e-2 relative (+1e-4), every gradient
-    tensor with cosine similarity >= 0.995 to the fp32 gradient and relative L2 error <= 0.12 (measured worst: 0.99798 / 0.064 at n = 6,
-    0.99962 / 0.030 at n = 256; bf16 carries 8 significant bits and the
+    tensor with cosine similarity >= 0.999 to the fp32 gradient and relative L2 error <= 0.06 at n = 256 (>= 0.995 / <= 0.12 at n = 6: twice
+    the measured worst, 0.99962 / 0.030 at n = 256 and 0.99798 / 0.064 at n = 6; bf16 carries 8 significant bits and the
     mask head sums 16 k pixels per weight; a pool-argmax flip between the bf16 and fp32 forward moves a whole window's gradient),
     parameters after the Adam step within 2.2e-3 absolute (lr = 1e-3: the update is +-lr).
     Kernel paths: chfak 1 on its dedicated whole-strip / tail kernels (the benchmarked form); the same model with those switched off
@@ -520,6 +520,8 @@ def test_config5_training_step_vs_autograd_of_the_build_restatement(n, chfak, ge
     for a, b in zip(got_l[:6], want_l):
         assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (got_l, want_l)
     worst = (1.0, "", 0.0)
+    # bounds = 2x what is measured (round-4 review): n = 256 (the stated batch): 0.99962 / 0.030 -> 0.999 / 0.06; n = 6: 0.99798 / 0.064 -> 0.995 / 0.12
+    cos_min, rel_max = (0.999, 0.06) if n >= 256 else (0.995, 0.12)
     for got, ref in ((gc, Pc), (gm, Pm)):
         for k, t in ref.items():
             g, r = got[k].double().cpu().reshape(-1), t.grad.double().reshape(-1)
@@ -527,7 +529,7 @@ def test_config5_training_step_vs_autograd_of_the_build_restatement(n, chfak, ge
             rel = float((g - r).norm() / (r.norm() + 1e-30))
             if cos < worst[0]:
                 worst = (cos, k, rel)
-            assert cos >= 0.995 and rel <= 0.12, f"{k}: cosine {cos:.4f}, relative L2 error {rel:.3f}"
+            assert cos >= cos_min and rel <= rel_max, f"{k}: cosine {cos:.4f}, relative L2 error {rel:.3f} (bounds {cos_min} / {rel_max})"
     print(f"n={n}: worst gradient cosine {worst[0]:.5f} ({worst[1]}, relative L2 error {worst[2]:.3f})")
     # three Adam steps moved every parameter by at most ~3 lr
     sc, sm = net.state_dicts()
@@ -569,7 +571,7 @@ rank, _, world = parallel.env_world()
 pc = orc.seeded_params(orc.critic128_shapes(), 31)
 pm = orc.seeded_params(orc.masker128_shapes(), 32)
 rs = np.random.RandomState(12)
-n = 8
+n = {n}
 A = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 B = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
@@ -634,7 +636,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0), rank=0, world
 pc = orc.seeded_params(orc.critic128_shapes(), 31)
 pm = orc.seeded_params(orc.masker128_shapes(), 32)
 rs = np.random.RandomState(12)
-n = 8
+n = {n}
 A = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 B = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
@@ -652,15 +654,16 @@ dist.destroy_process_group()
 """
 
 
-def test_config5_dp_launch_form_on_one_rank_rccl_group(tmp_path):
-    """Hourglass128's data-parallel launch form on a ONE-rank RCCL group: with the all-reduce recorded in the step's HIP graph (one graph
+@pytest.mark.parametrize("n", [8, 256])
+def test_config5_dp_launch_form_on_one_rank_rccl_group(tmp_path, n):
+    """(n = 256: config 5's stated batch.)  Hourglass128's data-parallel launch form on a ONE-rank RCCL group: with the all-reduce recorded in the step's HIP graph (one graph
     launch per step) and with the eager form, against the plain single-GPU step -- the same kernels in the same order plus an identity
     all-reduce and the 1 / world = 1 scale in Adam: parameters, first moments, step counter and losses after 4 steps are bit-identical."""
     import os, subprocess, sys
     REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = str(tmp_path / "dp128_rccl.npy")
     script = tmp_path / "dp128_rccl_worker.py"
-    script.write_text(DP128_RCCL_WORKER.format(repo=REPO, out=out))
+    script.write_text(DP128_RCCL_WORKER.format(repo=REPO, out=out, n=n))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)

@@ -26,5 +26,5 @@ python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.cs
 # counter traffic of the side workloads (FETCH_SIZE / WRITE_SIZE passes only)
 tools/side_pmc.sh final/pmc_c4 --mode infer --fp16 --batch 2048 && python tools/side_traffic.py gpurun_out/final/pmc_c4 mask_infer config4_fp16_infer_batch2048 $out/side_traffic.json
 tools/side_pmc.sh final/pmc_c5t --config 5 --mode train && python tools/side_traffic.py gpurun_out/final/pmc_c5t adam_kernel config5_train_batch256 $out/side_traffic.json
-tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "h5conv_kernel<H4Mask2" config5_infer_batch256 $out/side_traffic.json
+tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "tail_dec_fwd_kernel<false>" config5_infer_batch256 $out/side_traffic.json
 tail -1 $out/bench.json | cut -c1-300
