@@ -40,7 +40,7 @@ extern "C" int dbg_maskfwd_stamps(unsigned long long* stamps) { g_maskfwd_stamps
 #endif
 
 template <int SRC>     // SRC_U8C3 / SRC_F32C3
-__global__ void __launch_bounds__(256, 2) mask_fwd_kernel(MaskFwdParams P) {
+__global__ void __launch_bounds__(256, SRC == SRC_U8C3 ? 2 : 1) mask_fwd_kernel(MaskFwdParams P) {     // (fp32 frames: 9 more staging registers per pixel group than uint8 -- at two workgroups per SIMD they spilled 16 VGPRs)
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(MaskFwdParams)>();
     using G = MG;
     // tiles: image strip (float4 planes, conv_tile.h layout) | o0 strip at its own resolution; after a strip's MFMAs the same

@@ -48,6 +48,11 @@ __device__ __forceinline__ float drop1(const DropCtx& dc, uint32_t i) {
 
 int tail_blocks(int n, int cap) { return n < cap ? n : cap; }
 int tail_fwd_cap() { return 1024; }      // persistent workgroups: swept on the step (round 2)
+// the stand-alone decoder tail forward (inference at large batches: 84 registers / 48.6 KB of LDS = three workgroups per CU)
+#ifndef CGS_TAIL_DEC_FWD_CAP
+#define CGS_TAIL_DEC_FWD_CAP 768
+#endif
+int tail_dec_fwd_cap() { return CGS_TAIL_DEC_FWD_CAP; }
 int tail_bwd_cap() { return 512; }       // decoder tail backward
 // encoder tail backward: 768 = three workgroups per CU (its 168 registers / 51 KB of LDS allow exactly that).  Round 5, with features.3's
 // data and weight gradients inside the kernel: the mixes' pass (1024 images at N = 512) on 768 workgroups -- 256 of them take two images --
@@ -547,9 +552,9 @@ extern "C" int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, c
     if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1 || (m0_pack && !w_m0)) return CGS_ERR_BADARG;
     if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
-    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr,
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, tail_blocks(n, tail_dec_fwd_cap()), g_tail_stamps ? g_tail_stamps + 1 * 2048 * 16 : nullptr,
                        w_m0, m0_pack};
-    const int blocks = tail_blocks(n, tail_fwd_cap());
+    const int blocks = tail_blocks(n, tail_dec_fwd_cap());
     hipLaunchKernelGGL(tail_dec_fwd_kernel<false>, dim3(blocks + (m0_pack ? 1 : 0)), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
@@ -618,6 +623,9 @@ struct TailEncBwdParams {
 // features.0 backward launch that follows (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1).
 #ifndef CGS_ENC1_STAGGER
 #define CGS_ENC1_STAGGER 64
+#endif
+#ifndef CGS_ENC1_WGRAD_STAGES
+#define CGS_ENC1_WGRAD_STAGES 1
 #endif
 // MODE 2 / 3 (round 5): ... and features.0's sparse WEIGHT gradient of the same images on the uint8 frames (2) / the virtual mixes (3), after
 // their d e0 has been written: the critic's whole backward pass of an image except features.0's data gradient in one workgroup; the
@@ -861,27 +869,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const size_t b = blockIdx.x;
     wg10.reduce_store(P.slab10 ? P.slab10 + b * kTailSlab10 : nullptr, tiles, wave, lane, tid);
     wg6.reduce_store(P.slab6 ? P.slab6 + b * kTailSlab6 : nullptr, tiles, wave, lane, tid);
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 6] = __builtin_amdgcn_s_memtime();
     if constexpr (ENC1) {
+        // features.3's data gradient of this workgroup's images: their d e1 is in memory (stored by this workgroup, visible after the
+        // barrier), every tile and the reduction scratch above are dead
+        auto enc1_dgrad = [&]() {
+            for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
+                __syncthreads();
+                conv3x3_body_pipe<DEnc1P>(PC, 2 * img, (float4*)lds_all);
+            }
+            if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 7] = __builtin_amdgcn_s_memtime();
+        };
         if (PW1.slab) {
             // features.3's WEIGHT gradient of this workgroup's images, sparse form (wgrad_sparse.h: one non-zero of the pre-pool gradient
             // per pooling window and channel), one slab row per workgroup.  As rider workgroups of the features.0 backward launches the
-            // same work cost 24 us per step (LDS-read-bound chains of 8 tiles next to LDS-bound roles, r05k); here it runs between this
-            // image's latency-bound tail stages and the other resident workgroups' convolutions.
-            __syncthreads();
+            // same work cost 24 us per step (r05k).  Here its first tile's global loads (e0 rows, d e1, argmax words) are issued, THEN the
+            // data gradient runs (the `between` stage: its 108 registers + the 29 of a prefetch stage fit the kernel's 168), then the
+            // tiles are multiplied: by the stamps the phase waited ~2 us per tile for its loads when nothing ran in between.
             // (opaque block index / zero: nothing of this phase can be computed -- and held in registers -- before this point)
             int b0 = (int)blockIdx.x, tz = 0;
             asm volatile("" : "+s"(b0));
             asm volatile("" : "+v"(tz));
             const int nb = P.nblocks;
             const int nimg = b0 < P.n ? (P.n - b0 + nb - 1) / nb : 0;
-            wgrad_sparse8_body_seq(PW1, [=](int k) { return 2 * (b0 + (k >> 1) * nb) + (k & 1); }, 2 * nimg,
-                                   PW1.slab + (size_t)b0 * ((9 * 8 + 1) * 8), (float4*)lds_all, tz);
-        }
-        // features.3's data gradient of this workgroup's images: their d e1 is in memory (stored by this workgroup, visible after the
-        // barrier), every tile and the reduction scratch above are dead
-        for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
-            __syncthreads();
-            conv3x3_body_pipe<DEnc1P>(PC, 2 * img, (float4*)lds_all);
+            wgrad_sparse8_body_seq<CGS_ENC1_WGRAD_STAGES>(
+                PW1, [=](int k) { return 2 * (b0 + (k >> 1) * nb) + (k & 1); }, 2 * nimg, PW1.slab + (size_t)b0 * ((9 * 8 + 1) * 8),
+                (float4*)lds_all, tz, [&]() { enc1_dgrad(); __syncthreads(); });
+        } else {
+            enc1_dgrad();
         }
         if constexpr (MODE >= 2) {
             if (PW0.slab) {

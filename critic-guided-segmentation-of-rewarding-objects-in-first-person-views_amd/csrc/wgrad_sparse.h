@@ -38,6 +38,9 @@ struct SpCfg {
 #ifndef CGS_SPARSE8_LEAN
 #define CGS_SPARSE8_LEAN 1
 #endif
+#ifndef CGS_SP8_GROUP
+#define CGS_SP8_GROUP 1
+#endif
 template <class C>
 struct SpRed {
     static constexpr size_t TILE = (size_t)C::TRA * C::RS * 4 + 16, FULL = (size_t)C::NACC * 256 * 4;
@@ -284,49 +287,50 @@ __device__ __forceinline__ void wgrad_sparse_body_seq(const WgradParams& P, cons
 // argmax nibbles packed into one dword).  Thread tid: co = tid & 7, half = (tid >> 3) & 1, cell lane = tid >> 4; cells lane + 16 k, k = 0..7.
 // Reduction: rows (tap, ci) of half h come from the 128 threads of that half -> [row][16 lanes][8 co] in LDS, two chunks of <= 38 rows.
 // ------------------------------------------------------------------------------------------------
-template <class SEQ>
+struct SpNoBetween { __device__ __forceinline__ void operator()() const {} };
+
+// NSTG = prefetch stages (tiles in flight): 1 as a role of another launch (130 VGPRs), 2 inside the tail backward kernel, where a workgroup
+// has only 2 - 4 tiles and the FIRST tiles' load latency is what it waits for.  `between` runs after the first NSTG tiles' global loads have
+// been issued and before anything of this body touches LDS (the caller's own LDS epilogue hides the loads' round trip); it must end with
+// the LDS region free and the workgroup synchronised.
+template <int NSTG = 1, class SEQ, class BETWEEN = SpNoBetween>
 __device__ __forceinline__ void wgrad_sparse8_body_seq(const WgradParams& P, const SEQ seq, const int cnt, float* slab, float4* smem,
-                                                       const int tid_bias = 0) {
+                                                       const int tid_bias = 0, const BETWEEN between = BETWEEN{}) {
     using C = SpCfg<32, 8, WSRC_F32>;
     constexpr int W = C::W, H = C::H, S = C::S, PW = C::PW, TH = C::TH, RS = C::RS, HP = H / 2, WP = W / 2;
     float* xt = (float*)smem;
     const int tid = threadIdx.x + tid_bias;
     const int co = tid & 7, half = (tid >> 3) & 1, cl = tid >> 4;
     auto slot_store = [&](int r, int slot, const float4& v) { *(float4*)(xt + r * RS + 4 * slot) = v; };      // RS = 276: rows 16-byte aligned
-    for (int e = tid; e < C::TRA * (PW - W) * S; e += 256) {        // zero halo columns, written once
-        const int sidx = e % S, c = (e / S) % (PW - W), r = e / (S * (PW - W));
-        slot_store(r, (c == 0 ? 0 : W + c) * S + sidx, f4zero());
-    }
     constexpr int NF = C::TRA * W * S, ITF = (NF + 255) / 256;      // 1152 float4 per tile: 4.5 per thread
-    float4 gf[ITF];
-    float pval[8];
-    uint32_t pnibs = 0;
-    auto fetch = [&](int tile) {
+    struct Stage { float4 gf[ITF]; float pval[8]; uint32_t pnibs; };
+    Stage stg[NSTG];
+    auto fetch = [&](int tile, Stage& R) {
         const int n = tile / C::STRIPS, row0 = (tile % C::STRIPS) * TH, crow0 = (tile % C::STRIPS) * C::CROWS;
-        pnibs = 0;
+        R.pnibs = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int cell = cl + 16 * k, cy = crow0 + cell / C::CPR, cx = cell % C::CPR;
             const int pi = (n * HP + cy) * WP + cx;
-            pval[k] = P.dy[(size_t)pi * 8 + co];
-            pnibs |= ((P.amask[pi] >> (4 * co)) & 15u) << (4 * k);
+            R.pval[k] = P.dy[(size_t)pi * 8 + co];
+            R.pnibs |= ((P.amask[pi] >> (4 * co)) & 15u) << (4 * k);
         }
 #pragma unroll
         for (int it = 0; it < ITF; ++it) {
             int e = tid + 256 * it; e = e < NF ? e : NF - 1;
             const int sidx = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
             const bool in = y >= 0 && y < H;
-            gf[it] = ((const float4*)P.src_a)[in ? ((n * H + y) * W + x) * S + sidx : 0];
+            R.gf[it] = ((const float4*)P.src_a)[in ? ((n * H + y) * W + x) * S + sidx : 0];
         }
     };
-    auto commit = [&](int tile) {
+    auto commit = [&](int tile, const Stage& R) {
         const int row0 = (tile % C::STRIPS) * TH;
 #pragma unroll
         for (int it = 0; it < ITF; ++it) {
             const int e = tid + 256 * it;
             if (e < NF) {
                 const int sidx = e % S, x = (e / S) % W, r = e / (S * W), y = row0 + r - 1;
-                slot_store(r, (x + 1) * S + sidx, (y >= 0 && y < H) ? gf[it] : f4zero());
+                slot_store(r, (x + 1) * S + sidx, (y >= 0 && y < H) ? R.gf[it] : f4zero());
             }
         }
     };
@@ -336,15 +340,22 @@ __device__ __forceinline__ void wgrad_sparse8_body_seq(const WgradParams& P, con
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[t][c] = 0.f;
-    if (cnt > 0) fetch(seq(0));
-    for (int kt = 0; kt < cnt; ++kt) {
+#pragma unroll
+    for (int sg = 0; sg < NSTG; ++sg)
+        if (sg < cnt) fetch(seq(sg), stg[sg]);
+    between();
+    for (int e = tid; e < C::TRA * (PW - W) * S; e += 256) {        // zero halo columns, written once
+        const int sidx = e % S, c = (e / S) % (PW - W), r = e / (S * (PW - W));
+        slot_store(r, (c == 0 ? 0 : W + c) * S + sidx, f4zero());
+    }
+    auto process = [&](int kt, Stage& R) {
         float val[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) val[k] = pval[k];
-        const uint32_t nibs = pnibs;
-        commit(seq(kt));
+        for (int k = 0; k < 8; ++k) val[k] = R.pval[k];
+        const uint32_t nibs = R.pnibs;
+        commit(seq(kt), R);
         __syncthreads();
-        if (kt + 1 < cnt) fetch(seq(kt + 1));              // one tile ahead: its loads fly during this tile's multiply-adds
+        if (kt + NSTG < cnt) fetch(seq(kt + NSTG), R);      // the stage is free again: NSTG tiles ahead, in flight during the multiply-adds
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int cell = cl + 16 * k, cyl = cell / C::CPR, cx = cell % C::CPR;
@@ -362,9 +373,15 @@ __device__ __forceinline__ void wgrad_sparse8_body_seq(const WgradParams& P, con
                 acc[t][2] = fmaf(x.z, v, acc[t][2]);
                 acc[t][3] = fmaf(x.w, v, acc[t][3]);
             }
-            __builtin_amdgcn_sched_barrier(0);             // one half-pair at a time: interleaving them costs 36 more registers each
+            if ((k % CGS_SP8_GROUP) == CGS_SP8_GROUP - 1)
+                __builtin_amdgcn_sched_barrier(0);         // CGS_SP8_GROUP half-pairs at a time: each one interleaved costs 36 more registers
         }
         __syncthreads();
+    };
+    for (int kt = 0; kt < cnt; kt += NSTG) {
+#pragma unroll
+        for (int sg = 0; sg < NSTG; ++sg)
+            if (kt + sg < cnt) process(kt + sg, stg[sg]);
     }
     // ---- reduction: row r = tap * 8 + 4 * half + c from the 128 threads of that half; [row][cell lane 0..15][co] -> sum over the lanes ----
     float* red = (float*)smem;

@@ -571,7 +571,7 @@ rank, _, world = parallel.env_world()
 pc = orc.seeded_params(orc.critic128_shapes(), 31)
 pm = orc.seeded_params(orc.masker128_shapes(), 32)
 rs = np.random.RandomState(12)
-n = {n}
+n = 8
 A = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 B = torch.from_numpy(rs.randint(0, 256, (n, 128, 128, 3)).astype(np.uint8)).cuda()
 Y = torch.from_numpy(rs.rand(n).astype(np.float32)).cuda()
