@@ -100,6 +100,34 @@ __device__ __forceinline__ DropCtx drop_ctx(const cgs_dropout& d, const void* sa
 // Three contexts at once: the three step-counter loads (each a scalar round trip to L2 -- the counter was written by the previous step's optimiser
 // kernel) are requested back to back BEFORE anything uses one of them; written as three drop_ctx calls the loads of the second and third context
 // sit behind the waits of the first one's argument reads.
+// The same in two halves: the three step counters REQUESTED (raw values) / the contexts FILLED from them.  A kernel whose first image's
+// global loads follow calls _load before them and _fill after: the counters' round trip then flies together with the image's loads instead
+// of in front of them (tail_enc_bwd: global_load x 3 -> s_waitcnt vmcnt(0) stood at the top of every workgroup, 2.3 us before its first
+// image load by the stage stamps; round 5).
+__device__ __forceinline__ void drop_ctx3_load(const cgs_dropout& da, const cgs_dropout& db, const cgs_dropout& dc, const void* safe,
+                                               uint64_t& va, uint64_t& vb, uint64_t& vc) {
+    const bool ha = da.p > 0.f && da.step, hb = db.p > 0.f && db.step, hc = dc.p > 0.f && dc.step;
+    va = *(ha ? (const uint64_t*)da.step : (const uint64_t*)safe);
+    vb = *(hb ? (const uint64_t*)db.step : (const uint64_t*)safe);
+    vc = *(hc ? (const uint64_t*)dc.step : (const uint64_t*)safe);
+}
+__device__ __forceinline__ void drop_ctx3_fill(const cgs_dropout& da, const cgs_dropout& db, const cgs_dropout& dc, uint64_t va, uint64_t vb,
+                                               uint64_t vc, DropCtx& ca, DropCtx& cb, DropCtx& cc) {
+    auto fill = [](DropCtx& c, const cgs_dropout& d, uint64_t v) {
+        const bool have = d.p > 0.f && d.step;
+        c.on = d.p > 0.f;
+        c.p = d.p;
+        c.scale = c.on ? 1.f / (1.f - d.p) : 1.f;
+        c.site = d.site;
+        c.base = d.base;
+        c.key = make_uint2((uint32_t)d.seed, (uint32_t)(d.seed >> 32));
+        const uint64_t s = have ? v : 0ull;
+        c.step_lo = (uint32_t)s;
+        c.step_hi = (uint32_t)(s >> 32);
+    };
+    fill(ca, da, va); fill(cb, db, vb); fill(cc, dc, vc);
+}
+
 __device__ __forceinline__ void drop_ctx3(const cgs_dropout& da, const cgs_dropout& db, const cgs_dropout& dc, const void* safe,
                                           DropCtx& ca, DropCtx& cb, DropCtx& cc) {
     const bool ha = da.p > 0.f && da.step, hb = db.p > 0.f && db.step, hc = dc.p > 0.f && dc.step;

@@ -624,6 +624,9 @@ struct TailEncBwdParams {
 #ifndef CGS_ENC1_STAGGER
 #define CGS_ENC1_STAGGER 64
 #endif
+#ifndef CGS_DROPCTX_SPLIT
+#define CGS_DROPCTX_SPLIT 0      // (r05x A/B: 0.5570 ms either way; the split form spills 9 more SGPRs)
+#endif
 #ifndef CGS_ENC1_WGRAD_STAGES
 #define CGS_ENC1_WGRAD_STAGES 1
 #endif
@@ -669,11 +672,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const int l15 = lane & 15;
     const int o = tid & 31, kg = tid >> 5, half = lane & 32;
     const int hk = tid >> 3, part = tid & 7;          // d e4 mapping: row k = hk, columns 4*part .. +3
-#if CGS_DROPCTX3
-    DropCtx d2_, d3_, dh_;
-    drop_ctx3(P.drop_e2, P.drop_e3, P.drop_h1, P.w.w6, d2_, d3_, dh_);
-#else
-    const DropCtx d2_ = drop_ctx(P.drop_e2, P.w.w6), d3_ = drop_ctx(P.drop_e3, P.w.w6), dh_ = drop_ctx(P.drop_h1, P.w.w6);
+    // the three Dropout step counters are REQUESTED here and consumed after the first image's loads have been issued (drop_ctx3_fill below)
+    DropCtx d2_{}, d3_{}, dh_{};
+    uint64_t sv2, sv3, svh;
+    drop_ctx3_load(P.drop_e2, P.drop_e3, P.drop_h1, P.w.w6, sv2, sv3, svh);
+#if !CGS_DROPCTX_SPLIT
+    drop_ctx3_fill(P.drop_e2, P.drop_e3, P.drop_h1, sv2, sv3, svh, d2_, d3_, dh_);      // (A/B: the round-4 placement)
 #endif
     const bool has_pw = P.d_o4 != nullptr;
 
@@ -693,9 +697,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         int lz = 0;
         asm volatile("" : "+v"(lz));
         const int lane_i = lane + lz;
-        // (same for the Philox round keys: 3 contexts x 20 loop-invariant scalars otherwise live across the loop -> SGPR spills)
-        DropCtx d2 = d2_, d3 = d3_, dh = dh_;
-        asm volatile("" : "+s"(d2.key.x), "+s"(d2.key.y), "+s"(d3.key.x), "+s"(d3.key.y), "+s"(dh.key.x), "+s"(dh.key.y));
         // ---- every global load of this image, back to back ----
         // (scalars, not arrays: an array the optimiser fails to fully unroll becomes a per-thread LDS array indexed by the flat
         //  work-item id, which needs the workgroup size from the dispatch packet -- a ~10 us load from host-visible memory)
@@ -730,6 +731,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         const float4 w1v = *(const float4*)(P.w.wl1 + hk * 32 + 4 * part);
         const float4 wpv = has_pw ? *(const float4*)(P.w.wpw + hk * 32 + 4 * part) : f4zero();
         const float wl2 = P.w.wl2[o];
+#if CGS_DROPCTX_SPLIT
+        if (img == (int)blockIdx.x) drop_ctx3_fill(P.drop_e2, P.drop_e3, P.drop_h1, sv2, sv3, svh, d2_, d3_, dh_);
+#endif
+        // (the Philox round keys: 3 contexts x 20 loop-invariant scalars otherwise live across the loop -> SGPR spills)
+        DropCtx d2 = d2_, d3 = d3_, dh = dh_;
+        asm volatile("" : "+s"(d2.key.x), "+s"(d2.key.y), "+s"(d3.key.x), "+s"(d3.key.y), "+s"(dh.key.x), "+s"(dh.key.y));
         if (img == (int)blockIdx.x) {        // first image of this workgroup (uniform): the set-up, with the loads above in flight
             const int ts = tid + lz;         // (opaque: the set-up's addresses must not become loop invariants held in registers)
             tile_zero<T16x8>(x1, ts);
