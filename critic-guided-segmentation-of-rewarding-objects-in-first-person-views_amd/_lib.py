@@ -107,6 +107,9 @@ SIGNATURES = {
     "cgs_tail_dec_bwd_slabs": (i32, [i32]),
     "cgs_tail_dec_bwd": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 14 + [vp]),
     "cgs_dec0_tail_dec_bwd": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 17 + [vp]),
+    "cgs_dec0_tail_dec_bwd_do3": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 18 + [vp]),
+    "cgs_dec3_wgrad_rider_slabs": (i32, [i32]),
+    "cgs_enc0_wgrad_u8_with_head_riders": (i32, [i32, vp, vp, vp, vp, i32, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]),
     "cgs_tail_dec_fwd_dec0": (i32, [i32, C.POINTER(TailDecWeights)] + [vp] * 13 + [vp]),
     "cgs_conv3x3_bwd_weight_slabs": (i32, [C.POINTER(ConvDesc)]),
     "cgs_conv3x3_bwd_weight": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp]),

@@ -172,7 +172,7 @@ struct MixBwdArgs {
 #else
 #define CGS_MIX_OCC
 #endif
-template <class CWG, bool SPARSE>
+template <class CWG, bool SPARSE, bool R1>       // R1: the instance that carries the features.3 rider role (a role's registers are the whole launch's)
 __global__ void __launch_bounds__(256) CGS_MIX_OCC enc0_bwd_mix_kernel(WgradParams pw, ConvParams pd, MixBwdArgs M, int nbw, WgradParams pw1, int nbw1) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(ConvParams) + sizeof(MixBwdArgs) + 16>();
     using G = Geo<DEnc0::H, DEnc0::W, DEnc0::THREADS, DEnc0::CW>;
@@ -182,13 +182,15 @@ __global__ void __launch_bounds__(256) CGS_MIX_OCC enc0_bwd_mix_kernel(WgradPara
     // block order (A/B: CGS_R1_MIX): 0 = [riders | features.0 weight gradient | data gradient], 1 = [w | riders | d], 2 = [w | d | riders]
     const int gx = (int)gridDim.x, bx = (int)blockIdx.x;
     const int r_lo = CGS_R1_MIX == 0 ? 0 : (CGS_R1_MIX == 1 ? nbw : gx - nbw1);
-    if (bx >= r_lo && bx < r_lo + nbw1) {
-        constexpr int SLAB1 = (9 * 8 + 1) * 8;
-        const int b1 = bx - r_lo;
-        wgrad_dispatch<WEnc1, SPARSE>(pw1, b1, nbw1, pw1.ntiles, pw1.slab + (size_t)b1 * SLAB1, smem);
-        return;
+    if constexpr (R1) {
+        if (bx >= r_lo && bx < r_lo + nbw1) {
+            constexpr int SLAB1 = (9 * 8 + 1) * 8;
+            const int b1 = bx - r_lo;
+            wgrad_dispatch<WEnc1, SPARSE>(pw1, b1, nbw1, pw1.ntiles, pw1.slab + (size_t)b1 * SLAB1, smem);
+            return;
+        }
     }
-    const int bm = bx - (bx >= r_lo ? nbw1 : 0);               // index among the launch's own roles
+    const int bm = bx - ((R1 && bx >= r_lo) ? nbw1 : 0);       // index among the launch's own roles
     if (bm < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;
         wgrad_dispatch<CWG, SPARSE>(pw, bm, nbw, pw.ntiles, pw.slab + (size_t)bm * SLAB, smem);
@@ -244,9 +246,12 @@ extern "C" int cgs_enc0_bwd_mix_enc1(int32_t n_a, int32_t inject, const float* m
     size_t lds = lw > ld ? lw : ld;                    // 41 KB (data-gradient tile): three workgroups per CU
     if (lw1 > lds) lds = lw1;
     const dim3 grid(nbw + nbd + nbw1);
+    const bool r1 = nbw1 > 0;
     auto k = (mixed || !slab)       // materialised mixes (or no weight gradient at all) / mixes recomputed in the tile loader
-                 ? (sp ? enc0_bwd_mix_kernel<WEnc0F32, true> : enc0_bwd_mix_kernel<WEnc0F32, false>)
-                 : (sp ? enc0_bwd_mix_kernel<WEnc0Mix, true> : enc0_bwd_mix_kernel<WEnc0Mix, false>);
+                 ? (sp ? (r1 ? enc0_bwd_mix_kernel<WEnc0F32, true, true> : enc0_bwd_mix_kernel<WEnc0F32, true, false>)
+                       : (r1 ? enc0_bwd_mix_kernel<WEnc0F32, false, true> : enc0_bwd_mix_kernel<WEnc0F32, false, false>))
+                 : (sp ? (r1 ? enc0_bwd_mix_kernel<WEnc0Mix, true, true> : enc0_bwd_mix_kernel<WEnc0Mix, true, false>)
+                       : (r1 ? enc0_bwd_mix_kernel<WEnc0Mix, false, true> : enc0_bwd_mix_kernel<WEnc0Mix, false, false>));
     hipLaunchKernelGGL(k, grid, dim3(256), lds, (hipStream_t)stream, pw, pd, M, nbw, pw1, nbw1);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;

@@ -13,6 +13,7 @@
 // Lanes (r = lane&15, pixel = lane>>4) then read consecutive floats: bank-conflict free.
 #include "wgrad_sparse.h"
 #include "head_wgrad.h"
+#include "wgrad_dec3.h"
 
 // dec_model.0 (16 -> 8 channels at 32x32): outer products on v_mfma_f32_4x4x1 (wgrad_dec0.hip)
 int wgrad_dec0_slabs(int n);
@@ -78,27 +79,42 @@ static int launch_wgrad(WgradParams P, hipStream_t st) {
 #ifndef CGS_R1_U8
 #define CGS_R1_U8 1
 #endif
+// four waves per SIMD = 128 registers: what the kernel's own two roles need (114 + 4); without the cap the compiler parks the dec_model.3 rider's
+// 28 accumulators in AGPRs ON TOP of them and the launch drops to three workgroups per CU (-Rpass-analysis=kernel-resource-usage)
 #ifndef CGS_U8_WAVES
-#define CGS_U8_WAVES 0
+#define CGS_U8_WAVES 4
 #endif
 #if CGS_U8_WAVES
 #define CGS_U8_OCC __attribute__((amdgpu_waves_per_eu(CGS_U8_WAVES, CGS_U8_WAVES)))
 #else
 #define CGS_U8_OCC
 #endif
-__global__ void __launch_bounds__(256) CGS_U8_OCC wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw, WgradParams P1, int nbw1) {
-    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(HeadWgradParams) + 16>();
+// (round 5) nb3 > 0: dec_model.3's weight gradient as a GEMM over the images (wgrad_dec3.h) in the launch's LAST nb3 workgroups.
+// R1 / R3: which rider roles this instance carries -- a role's registers are the whole launch's (the general features.3 body took this
+// kernel from 114 to 256 VGPRs), so a launch without a rider runs the instance without its code.
+template <bool R1, bool R3>
+__global__ void __launch_bounds__(256) CGS_U8_OCC wgrad_enc0u8_head_kernel(WgradParams P, HeadWgradParams H, int nbw, WgradParams P1, int nbw1,
+                                                                           Dec3WgParams D3, int nb3) {
+    if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<2 * sizeof(WgradParams) + sizeof(HeadWgradParams) + sizeof(Dec3WgParams) + 24>();
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    // block order (A/B: CGS_R1_U8): 0 = [riders | features.0 | head], 1 = [features.0 | riders | head], 2 = [features.0 | head | riders]
-    const int gx = (int)gridDim.x, bx = (int)blockIdx.x;
-    const int r_lo = CGS_R1_U8 == 0 ? 0 : (CGS_R1_U8 == 1 ? nbw : gx - nbw1);
-    if (bx >= r_lo && bx < r_lo + nbw1) {
-        constexpr int SLAB1 = (9 * 8 + 1) * 8;
-        const int b1 = bx - r_lo;
-        wgrad_dispatch<WEnc1, true>(P1, b1, nbw1, P1.ntiles, P1.slab + (size_t)b1 * SLAB1, smem);
-        return;
+    if constexpr (R3) {
+        if ((int)blockIdx.x >= (int)gridDim.x - nb3) {
+            dec3_wgrad_body(D3, (int)blockIdx.x - ((int)gridDim.x - nb3), nb3, (float*)smem);
+            return;
+        }
     }
-    const int bm = bx - (bx >= r_lo ? nbw1 : 0);
+    // block order (A/B: CGS_R1_U8): 0 = [riders | features.0 | head], 1 = [features.0 | riders | head], 2 = [features.0 | head | riders]
+    const int gx = (int)gridDim.x - nb3, bx = (int)blockIdx.x;
+    const int r_lo = CGS_R1_U8 == 0 ? 0 : (CGS_R1_U8 == 1 ? nbw : gx - nbw1);
+    if constexpr (R1) {
+        if (bx >= r_lo && bx < r_lo + nbw1) {
+            constexpr int SLAB1 = (9 * 8 + 1) * 8;
+            const int b1 = bx - r_lo;
+            wgrad_dispatch<WEnc1, true>(P1, b1, nbw1, P1.ntiles, P1.slab + (size_t)b1 * SLAB1, smem);
+            return;
+        }
+    }
+    const int bm = bx - ((R1 && bx >= r_lo) ? nbw1 : 0);
     if (bm < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;
         wgrad_dispatch<WEnc0U8, true>(P, bm, nbw, P.ntiles, P.slab + (size_t)bm * SLAB, smem);
@@ -109,12 +125,18 @@ __global__ void __launch_bounds__(256) CGS_U8_OCC wgrad_enc0u8_head_kernel(Wgrad
 
 // e0_1 / dy1 / am1 / slab1 (all or none): features.3's weight gradient over n1w images ([n1w,32,32,8] input, [n1w,16,16,8] pooled output
 // gradient, argmax nibbles, slab1 [nslab1][584] with nslab1 = cgs_enc1_wgrad_rider_slabs(n1w)) as extra workgroups of this launch.
-extern "C" int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
-                                                int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
-                                                int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
-                                                float* slab_head, float* slab_pw,
-                                                int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
-                                                cgs_stream_t stream) {
+extern "C" int cgs_dec3_wgrad_rider_slabs(int32_t n) { return n < 0 ? CGS_ERR_BADARG : (n < 64 ? n : 64); }
+
+// ... + dec_model.3's weight gradient over n3 images (e3 [n3,4,4,16], o4 [n3,32], d o3 [n3,4,4,16] as cgs_dec0_tail_dec_bwd_do3 leaves it;
+// slab3 [cgs_dec3_wgrad_rider_slabs(n3)][6928]; slab3 = NULL: none) as the launch's last workgroups (round 5).
+extern "C" int cgs_enc0_wgrad_u8_with_head_riders(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                                  int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                                  int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                                  float* slab_head, float* slab_pw,
+                                                  int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
+                                                  int32_t n3, const float* e3, const float* o4, const float* do3, float* slab3,
+                                                  cgs_stream_t stream) {
+    if (slab3 && (n3 <= 0 || !e3 || !o4 || !do3)) return CGS_ERR_BADARG;
     if (n <= 0 || !x_u8 || !dy || !amask || !slab) return CGS_ERR_BADARG;
     if (n0 < 0 || n1 < 0 || n0 + n1 == 0 || !slab_head || (n0 > 0 && (!hvec0 || !e4_0)) || (n1 > 0 && (!hvec1 || !e4_1))) return CGS_ERR_BADARG;
     if ((d_o4_0 || d_o4_1) && !slab_pw) return CGS_ERR_BADARG;
@@ -135,9 +157,26 @@ extern "C" int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, 
         const size_t l1 = wgrad_any_lds_bytes<WEnc1, true>();
         if (l1 > lds) lds = l1;
     }
-    hipLaunchKernelGGL(wgrad_enc0u8_head_kernel, dim3(nbw + nbh + nbw1), dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1);
+    Dec3WgParams D3{e3, o4, do3, slab3, n3};
+    const int nb3 = slab3 ? cgs_dec3_wgrad_rider_slabs(n3) : 0;
+    if (nb3 > 0 && sizeof(float) * (size_t)kWD3LdsFloats > lds) lds = sizeof(float) * (size_t)kWD3LdsFloats;
+    const dim3 grid(nbw + nbh + nbw1 + nb3);
+    if (nbw1 > 0 && nb3 > 0) hipLaunchKernelGGL((wgrad_enc0u8_head_kernel<true, true>), grid, dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1, D3, nb3);
+    else if (nbw1 > 0) hipLaunchKernelGGL((wgrad_enc0u8_head_kernel<true, false>), grid, dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1, D3, nb3);
+    else if (nb3 > 0) hipLaunchKernelGGL((wgrad_enc0u8_head_kernel<false, true>), grid, dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1, D3, nb3);
+    else hipLaunchKernelGGL((wgrad_enc0u8_head_kernel<false, false>), grid, dim3(256), lds, (hipStream_t)stream, P, H, nbw, P1, nbw1, D3, nb3);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+extern "C" int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                                int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                                int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                                float* slab_head, float* slab_pw,
+                                                int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
+                                                cgs_stream_t stream) {
+    return cgs_enc0_wgrad_u8_with_head_riders(n, x_u8, dy, amask, slab, n0, hvec0, e4_0, d_o4_0, n_o4_0, n1, hvec1, e4_1, d_o4_1, n_o4_1,
+                                              slab_head, slab_pw, n1w, e0_1, dy1, am1, slab1, nslab1, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int cgs_enc0_wgrad_u8_with_head(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,

@@ -1055,6 +1055,7 @@ struct TailDecBwdParams {
     int n;
     int nblocks;
     unsigned long long* dbg;
+    float* do3;           // W3 = false: d o3 [n,4,4,16] for the dec_model.3 weight-gradient riders
 };
 
 using T1Q = TileP<16, 16, 16, 16, 304>;   // cat(e1, up(o2)): only the weight gradient's dword reads (2 taps x 4 channel groups on 32 banks)
@@ -1070,7 +1071,9 @@ struct TailDecBwdLds {
 // gradient d e0 and the cell-summed d o1 go to memory as cgs_conv3x3_bwd_data writes them; the tile region of this kernel is its
 // scratch), then the tail stages read that d o1 back (same workgroup: visible after the barrier).  Every other co-resident workgroup
 // starts ~4 us late, so the latency-bound chains of one half run under the matrix instructions of the other (cgs_stagger).
-template <bool FUSED>
+// W3 = false (round 5): dec_model.3's weight gradient is NOT formed here -- d o3 [n,4,4,16] goes to P.do3 and a few rider workgroups of a later launch
+// form it as a GEMM over the images (wgrad_dec3.h): 64 slab rows of 27.7 KB instead of one per image.
+template <bool FUSED, bool W3 = true>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) tail_dec_bwd_kernel(TailDecBwdParams P, ConvParams PC) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailDecBwdParams) + sizeof(ConvParams)>();
     using L = TailDecBwdLds;
@@ -1196,9 +1199,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             wave, lane_i);
         __syncthreads();
         TAIL_STAMP(4);
+        if constexpr (!W3) {
+            if (tid < 64) {
+                const int p4 = tid & 3, x = (tid >> 2) & 3, y = tid >> 4;
+                ((float4*)P.do3)[(size_t)img * 64 + tid] = *(const float4*)(dy3 + T4x16::at(y, x) + 4 * p4);
+            }
+        }
         // ---- dec_model.3: weight gradient on the matrix cores; data gradient on the vector ALU (48 input channels x 4 quads:
         //      thread = (ci, quad), weights read in their natural [tap][ci][co] order, 16 contiguous floats per (tap, ci)) ----
-        wg3.accumulate(t3, dy3, lane_i);
+        if constexpr (W3) wg3.accumulate(t3, dy3, lane_i);
         if (tid < 192) {
             const int ci = tid % 48, q = tid / 48, qy = q >> 1, qx = q & 1;
             float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1251,7 +1260,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     if (tid < 8 && P.slab1) P.slab1[b * kTailSlabD1 + 1152 + tid] = (red[tid * 4] + red[tid * 4 + 1]) + (red[tid * 4 + 2] + red[tid * 4 + 3]);
     if (P.slab2) wg2.store(P.slab2 + b * kTailSlabD2, wave, lane);
-    if (P.slab3) wg3.store(P.slab3 + b * kTailSlabD3, wave, lane);
+    if constexpr (W3) { if (P.slab3) wg3.store(P.slab3 + b * kTailSlabD3, wave, lane); }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 15] = __builtin_amdgcn_s_memtime();
 }
 
@@ -1275,11 +1284,14 @@ extern "C" int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const 
 // dec_model.0's data gradient (cgs_conv3x3_bwd_data of the 16 -> 8 layer at 32x32: dy = d o0 [n,32,32,8] -> d e0 [n,32,32,8] and the
 // cell-summed d o1 [n,16,16,8]) AND cgs_tail_dec_bwd in one launch, one workgroup per image (n <= cgs_tail_dec_bwd_slabs' cap: the
 // tail's slabs are one row per image).  w0: dec_model.0's HWIO weights.  CGS_ERR_UNSUPPORTED for larger n (the caller launches the two).
-extern "C" int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0, float* dE0, const float* e1,
-                                     const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1,
-                                     float* dE1, float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1,
-                                     cgs_stream_t stream) {
+// do3 != NULL (round 5; then slab3 must be NULL): dec_model.3's weight gradient is left to the riders of cgs_enc0_wgrad_u8_with_head_riders --
+// this launch writes d o3 [n,4,4,16] for them instead of one 27.7 KB slab row per image.
+extern "C" int cgs_dec0_tail_dec_bwd_do3(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0, float* dE0, const float* e1,
+                                         const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1,
+                                         float* dE1, float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1,
+                                         float* do3, cgs_stream_t stream) {
     if (n < 0 || !w || !dy_o0 || !w0 || !dE0 || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !do1 || !dE1 || !dE2 || !dE3 || !d_o4) return CGS_ERR_BADARG;
+    if (do3 && slab3) return CGS_ERR_BADARG;
     if (!w->w3 || !w->w2 || !w->w1) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     if (n > tail_bwd_cap()) return CGS_ERR_UNSUPPORTED;
@@ -1288,10 +1300,21 @@ extern "C" int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, c
     static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel<true>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
     if (attr != hipSuccess) return (int)attr;
-    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, n, g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr};
+    static hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_dec_bwd_kernel<true, false>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)TailDecBwdLds::BYTES);
+    if (attr3 != hipSuccess) return (int)attr3;
+    TailDecBwdParams P{*w, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, n, n, g_tail_stamps ? g_tail_stamps + 3 * 2048 * 16 : nullptr, do3};
     ConvParams PC{};
     PC.src_a = dy_o0; PC.w = w0; PC.out = dE0; PC.out2 = do1; PC.n = n;
-    hipLaunchKernelGGL(tail_dec_bwd_kernel<true>, dim3(n), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P, PC);
+    if (do3) hipLaunchKernelGGL((tail_dec_bwd_kernel<true, false>), dim3(n), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P, PC);
+    else hipLaunchKernelGGL((tail_dec_bwd_kernel<true, true>), dim3(n), dim3(256), TailDecBwdLds::BYTES, (hipStream_t)stream, P, PC);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+extern "C" int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0, float* dE0, const float* e1,
+                                     const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1,
+                                     float* dE1, float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1,
+                                     cgs_stream_t stream) {
+    return cgs_dec0_tail_dec_bwd_do3(n, w, dy_o0, w0, dE0, e1, e2, e3, o4, o3, o2, do1, dE1, dE2, dE3, d_o4, slab3, slab2, slab1, nullptr, stream);
 }

@@ -284,7 +284,8 @@ class HourglassEngine:
         defer = [] if (self.live and not self.separate and hg.TAIL_BWD) else None
         d_emb = hg.masker_backward(self.fm, self.lm, A, embeds, n, self.mbuf, self.dzpre, pm, ws=self._ws["mb"], side=self.side,
                                    pw_in_head=self.live or self.separate, defer_dec0=defer)
-        rider = defer[0] if defer else None
+        rider = next((d for d in (defer or []) if not isinstance(d, dict)), None)            # dec_model.0's weight gradient (tail launch riders)
+        dec3 = next((d["dec3"] for d in (defer or []) if isinstance(d, dict)), None)          # dec_model.3's (features.0 launch riders)
         ps = hg.SlabPlan()
         if self.separate:
             # the skip gradients (and the bottleneck's) go into the SECOND critic; its own head sees no loss (dpred = 0)
@@ -299,7 +300,7 @@ class HourglassEngine:
             d_o4, d_emb[4] = d_emb[4], None
             hg.critic_backward(self.fc, self.lc, A, n, sa, None if ft else self.dpred[n:2 * n], pc, drop.shifted(n), d_embeds=d_emb,
                                n_add=n, ws=self._ws["cb_a"], side=self.side, loss=loss_a, head_sink=sink_c,
-                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")), rider=rider)
+                               pw_bwd=(d_o4, pw[0], pm, self.lm.off("dec_model.4.weight")), rider=rider, dec3_rider=dec3)
         if sink_c:
             hg.head_wgrad(sink_c, pc, self.lc, self._ws["cb_a"])
         self.side.join()

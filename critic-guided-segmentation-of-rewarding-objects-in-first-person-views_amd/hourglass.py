@@ -53,6 +53,11 @@ ENC0_WGRAD_IN_TAIL = os.environ.get("CGS_ENC0_WGRAD_IN_TAIL", "")
 # dec_model.0's weight gradient as spare workgroups of the last critic pass's tail backward launch (live critic; csrc/tail.hip)
 DEC0_WGRAD_RIDER = True
 DEC0_RIDERS = 256
+# dec_model.3's weight gradient as a GEMM over the images in <= 64 rider workgroups of the A pass's features.0 weight-gradient launch instead of
+# one 27.7 KB slab row per image inside the decoder tail's backward (round 5; equal up to fp32 summation order).  MEASURED SLOWER, default off
+# (r05z: 0.5581 ms with, 0.5508 without): the decoder backward gets 3.7 us shorter and the final reduction reads 12 MB less, but the riders'
+# 8-image chains lengthen the step's last weight-gradient launch by more.  Kept as an opt-in that the bit-identity test still exercises.
+DEC3_WGRAD_RIDER = os.environ.get("CGS_DEC3_WGRAD_RIDER", "0") != "0"
 _both = "c3,c2,c1,c0,d3,d2,d1"   # measured: d0 and m0 do not gain
 BOTH_ENC = {int(t[1]) for t in _both.split(",") if t.startswith("c")} if BWD_BOTH else set()
 BOTH_DEC = {t for t in _both.split(",") if t[0] in "dm"} if BWD_BOTH else set()
@@ -319,7 +324,14 @@ def head_wgrad(ranges, plan: "SlabPlan", lay: Layout, ws: Dict[str, torch.Tensor
     if enc0 is not None:
         n_e, x_e, dy_e, am_e, slab_e = enc0[:5]
         e1w = enc0[5] if len(enc0) > 5 else None          # features.3's deferred weight gradient: (n, e0, d e1, am1, slab, rows)
-        if e1w is not None:
+        d3 = enc0[6] if len(enc0) > 6 else None           # dec_model.3's deferred weight gradient: (n, e3, o4, d o3, slab)
+        if d3 is not None:
+            w1 = e1w if e1w is not None else (0, None, None, None, None, 0)
+            _lib.call("cgs_enc0_wgrad_u8_with_head_riders", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]),
+                      r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw),
+                      int(w1[0]), _p(w1[1]), _p(w1[2]), _p(w1[3]), _p(w1[4]), int(w1[5]),
+                      int(d3[0]), _p(d3[1]), _p(d3[2]), _p(d3[3]), _p(d3[4]), _stream())
+        elif e1w is not None:
             _lib.call("cgs_enc0_wgrad_u8_with_head_enc1", n_e, _p(x_e), _p(dy_e), _p(am_e), _p(slab_e), r0[3], _p(r0[0]), _p(r0[1]), _p(r0[2]),
                       r0[4], r1[3], _p(r1[0]), _p(r1[1]), _p(r1[2]), r1[4], _p(sl), _p(slpw),
                       int(e1w[0]), _p(e1w[1]), _p(e1w[2]), _p(e1w[3]), _p(e1w[4]), int(e1w[5]), _stream())
@@ -339,7 +351,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                     d_embeds: Optional[List[torch.Tensor]] = None, n_add: int = 0,
                     dx: Optional[torch.Tensor] = None, dx_from: int = 0,
                     ws: Optional[Dict[str, torch.Tensor]] = None, side: "SideStream" = None,
-                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None, head_sink=None, rider=None) -> Optional[torch.Tensor]:
+                    need_wgrad: bool = True, pw_bwd=None, mix_bwd=None, loss=None, head_sink=None, rider=None,
+                    dec3_rider=None) -> Optional[torch.Tensor]:
     """Backward of critic_forward for images [0,n).  pw_bwd = (d_o4 [n_add,32], w_pw_ptr, plan_pw, dst_off): the decoder
     bottleneck's backward (dec_model.4) runs inside the head kernel; its slab is registered in plan_pw at dst_off.
     mix_bwd = (A_u8, B_u8, Z, inject, l1_scale, l2_scale, dzpre): x are the replaced|injected mixes of n_a = len(A) images;
@@ -493,8 +506,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
             slab = buf(f"slab_enc{i}", (nsl, cnt))
             if i == 0 and head_sink is not None and u8:
                 # features.0 on the uint8 frames: launched together with the head's weight gradients (head_wgrad below)
-                head_sink.append({"enc0": (n, src, d_cur, saved["am0"], slab, enc1_wgrad)})
-                enc1_wgrad = None
+                head_sink.append({"enc0": (n, src, d_cur, saved["am0"], slab, enc1_wgrad, dec3_rider)})
+                enc1_wgrad, dec3_rider = None, None
             else:
                 with side.fork():
                     _lib.call("cgs_conv3x3_bwd_weight", C.byref(d), _p(src), None, _p(d_cur), _p(saved[f"am{i}"]), _p(slab), _stream())
@@ -511,6 +524,8 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
                       _lib.ACT_NONE, None, 0, _p(dx), None, _stream())
     if enc1_wgrad is not None:
         raise _lib.CgsError("critic_backward: features.3's deferred weight gradient found no features.0 launch to ride with")
+    if dec3_rider is not None:
+        raise _lib.CgsError("critic_backward: dec_model.3's deferred weight gradient found no features.0 launch to ride with")
     return dx
 
 
@@ -659,17 +674,25 @@ def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Li
                 d_embeds[ei] = buf(f"dE{ei}", shp)
             do4 = buf("do4", (n, 32))
             tw = tail_dec_weights(flat, lay)
+            dec3_rider = (fuse_dec0 is not None and defer_dec0 is not None and DEC3_WGRAD_RIDER and u8 and not enc0_in_tail(False, True, None))
+            nsl_k = {1: nsl, 2: nsl, 3: nsl}
+            if dec3_rider:      # the layer's slab rows come from the riders: allocate their (few) rows instead of one per image
+                nsl_k[3] = lib.cgs_dec3_wgrad_rider_slabs(n)
+                sl[3] = buf("slab_dec0_rider", (nsl_k[3], cnts[3]))
             if fuse_dec0 is not None:      # dec_model.0's data gradient rides in front, one workgroup per image
                 dy_o0, w0ptr, de0 = fuse_dec0
-                _lib.call("cgs_dec0_tail_dec_bwd", n, C.byref(tw), _p(dy_o0), w0ptr, _p(de0), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]),
+                do3 = buf("do3", (n, 4, 4, 16)) if dec3_rider else None
+                _lib.call("cgs_dec0_tail_dec_bwd_do3", n, C.byref(tw), _p(dy_o0), w0ptr, _p(de0), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]),
                           _p(saved["o4"]), _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
-                          _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
+                          None if dec3_rider else _p(sl[3]), _p(sl[2]), _p(sl[1]), _p(do3), _stream())
+                if dec3_rider:
+                    defer_dec0.append({"dec3": (n, embeds[3], saved["o4"], do3, sl[3])})
             else:
                 _lib.call("cgs_tail_dec_bwd", n, C.byref(tw), _p(embeds[1]), _p(embeds[2]), _p(embeds[3]), _p(saved["o4"]),
                           _p(saved["o3"]), _p(saved["o2"]), _p(dy), _p(d_embeds[1]), _p(d_embeds[2]), _p(d_embeds[3]), _p(do4),
                           _p(sl[3]), _p(sl[2]), _p(sl[1]), _stream())
             for k, c in cnts.items():
-                plan.add(sl[k], nsl, c, lay.off(f"dec_model.{k}.weight"))
+                plan.add(sl[k], nsl_k[k], c, lay.off(f"dec_model.{k}.weight"))
             dy = do4
             break
         key, hw, ca, cb, co, ups, act, pool, _s = DEC_LAYERS[li]

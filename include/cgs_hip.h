@@ -337,6 +337,16 @@ int cgs_enc0_wgrad_u8_with_head_enc1(int32_t n, const uint8_t* x_u8, const float
                                      float* slab_head, float* slab_pw,
                                      int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
                                      cgs_stream_t stream);
+/* ... + dec_model.3's weight gradient (cgs_conv3x3_bwd_weight of the 48 -> 16 layer at 4x4 over cat(e3, Upsample(x4)(o4)), nets.py:483,503-505) over
+ * n3 images as a GEMM over the images in the launch's last workgroups (round 5): e3 [n3,4,4,16], o4 [n3,32], do3 [n3,4,4,16] = the gradient at that
+ * layer's output as cgs_dec0_tail_dec_bwd_do3 leaves it; slab3 [cgs_dec3_wgrad_rider_slabs(n3)][6928]; slab3 = NULL: none.                        */
+int cgs_dec3_wgrad_rider_slabs(int32_t n);
+int cgs_enc0_wgrad_u8_with_head_riders(int32_t n, const uint8_t* x_u8, const float* dy, const uint32_t* amask, float* slab,
+                                       int32_t n0, const float* hvec0, const float* e4_0, const float* d_o4_0, int32_t n_o4_0,
+                                       int32_t n1, const float* hvec1, const float* e4_1, const float* d_o4_1, int32_t n_o4_1,
+                                       float* slab_head, float* slab_pw,
+                                       int32_t n1w, const float* e0_1, const float* dy1, const uint32_t* am1, float* slab1, int32_t nslab1,
+                                       int32_t n3, const float* e3, const float* o4, const float* do3, float* slab3, cgs_stream_t stream);
 int cgs_tail_dec_bwd_slabs(int32_t n);
 int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, const float* o3, const float* o2, const float* do1, float* dE1, float* dE2,
@@ -347,6 +357,12 @@ int cgs_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, 
 int cgs_dec0_tail_dec_bwd(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0_hwio, float* dE0, const float* e1,
                           const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1, float* dE1,
                           float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, cgs_stream_t stream);
+/* The same; do3 != NULL (then slab3 = NULL): dec_model.3's weight gradient is NOT formed here -- d o3 [n,4,4,16] is written for the rider workgroups
+ * of cgs_enc0_wgrad_u8_with_head_riders (64 slab rows for the layer instead of one per image; equal up to fp32 summation order; round 5).         */
+int cgs_dec0_tail_dec_bwd_do3(int32_t n, const cgs_tail_dec_weights* w, const float* dy_o0, const float* w0, float* dE0, const float* e1,
+                              const float* e2, const float* e3, const float* o4, const float* o3, const float* o2, float* do1,
+                              float* dE1, float* dE2, float* dE3, float* d_o4, float* slab3, float* slab2, float* slab1, float* do3,
+                              cgs_stream_t stream);
 /* cgs_tail_dec_fwd_pack and dec_model.0's forward (cgs_conv3x3_fwd of the 16 -> 8 layer at 32x32: cat(e0, nearest-up(o1)) -> o0, linear;
  * nets.py:516-517) in ONE launch, one workgroup per image (round 4; n <= 1024, else CGS_ERR_UNSUPPORTED).                              */
 int cgs_tail_dec_fwd_dec0(int32_t n, const cgs_tail_dec_weights* w, const float* e0, const float* e1, const float* e2, const float* e3,

@@ -335,6 +335,7 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
     default = run()
     monkeypatch.setattr(hg, "ENC1_WGRAD_IN_TAIL", False)
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "")        # (features.0's weight gradient in the same kernel: likewise a per-workgroup partition)
+    monkeypatch.setattr(hg, "DEC3_WGRAD_RIDER", False)       # (dec_model.3's weight gradient as a GEMM over the images in 64 rider workgroups: likewise)
     base = run()
     flags = ("CRITIC_FWD_FUSED", "ENC1_TAIL_FUSED", "DEC_TAIL_DEC0_FUSED", "DEC0_TAIL_BWD_FUSED", "ENC1_TAIL_BWD_FUSED")
     for off in ([(f,) for f in flags] if n < 100 else []) + [flags]:
@@ -346,6 +347,7 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
         for a, b, what in zip(got, base, ("losses", "parameters", "m", "v", "pred", "Z")):
             assert torch.equal(a, b), f"{what} differ with {off} switched off"
     monkeypatch.setattr(hg, "ENC1_WGRAD_IN_TAIL", True)
+    monkeypatch.setattr(hg, "DEC3_WGRAD_RIDER", True)
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "both")    # the measured-slower opt-in: features.0's weight gradient in the tail kernel too
     opt_in = run()
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "")
@@ -353,4 +355,4 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
         for a, b, what in zip(got, base, ("losses", "parameters", "m", "v", "pred", "Z")):
             # two Adam steps: a gradient element that differs by an ulp moves its parameter by up to ~lr * 1e-3 (Adam's normalised step)
             assert torch.allclose(a, b, rtol=2e-4, atol=2e-6), \
-                f"{what}: the in-kernel weight gradients of features.3 / features.0 vs the stand-alone forms: {float((a - b).abs().max())}"
+                f"{what}: the in-kernel weight gradients of features.3 / features.0 and dec_model.3's rider GEMM vs the stand-alone forms: {float((a - b).abs().max())}"
