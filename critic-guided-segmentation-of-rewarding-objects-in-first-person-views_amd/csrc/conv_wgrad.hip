@@ -119,7 +119,7 @@ __global__ void __launch_bounds__(256) CGS_U8_OCC wgrad_enc0u8_head_kernel(Wgrad
         constexpr int SLAB = (9 * 3 + 1) * 8;
         wgrad_dispatch<WEnc0U8, true>(P, bm, nbw, P.ntiles, P.slab + (size_t)bm * SLAB, smem);
     } else {
-        tail_head_wgrad_body(H, bm - nbw);
+        tail_head_wgrad_body(H, bm - nbw, (float*)smem);
     }
 }
 
@@ -148,6 +148,7 @@ extern "C" int cgs_enc0_wgrad_u8_with_head_riders(int32_t n, const uint8_t* x_u8
     HeadWgradParams H{{{hvec0, e4_0, d_o4_0, n0, n_o4_0}, {hvec1, e4_1, d_o4_1, n1, n_o4_1}}, slab_head, slab_pw};
     const int nbw = wg_blocks_any<WEnc0U8>(n), nbh = (n0 + n1 + kHwIpb - 1) / kHwIpb;
     size_t lds = wgrad_any_lds_bytes<WEnc0U8, true>();
+    if (sizeof(float) * (size_t)kHwLdsFloats > lds) lds = sizeof(float) * (size_t)kHwLdsFloats;
     WgradParams P1{};
     int nbw1 = 0;
     if (slab1) {

@@ -10,10 +10,18 @@ struct HeadWgradRange { const float* hvec; const float* e4; const float* d_o4; i
 struct HeadWgradParams { HeadWgradRange r[2]; float* slab_head; float* slab_pw; };
 static constexpr int kHwIpb = 8;      // images per workgroup (8: 192 workgroups at 1536 images; 16 left most CUs idle)
 
-__device__ __forceinline__ void tail_head_wgrad_body(const HeadWgradParams& P, const int bid) {
-    __shared__ __attribute__((aligned(16))) float xs[kHwIpb][260];      // +4: conflict-free column reads
-    __shared__ __attribute__((aligned(16))) float dz4[kHwIpb][32], dh1[kHwIpb][32], qv[kHwIpb][32], e4s[kHwIpb][36], do4[kHwIpb][32];
-    __shared__ float dz2s[kHwIpb];
+// LDS of the body, carved from a caller-supplied block (round 5): as STATIC arrays inside a launch that also carries a role with dynamic LDS the
+// two add up for every workgroup -- wgrad_enc0u8_head_kernel ran at 13.6 + 28.7 KB = three workgroups per CU instead of five.
+static constexpr int kHwLdsFloats = kHwIpb * (260 + 32 + 32 + 32 + 36 + 32) + kHwIpb + 8;
+
+__device__ __forceinline__ void tail_head_wgrad_body(const HeadWgradParams& P, const int bid, float* lds) {
+    float (*xs)[260] = (float (*)[260])lds;                              // +4: conflict-free column reads
+    float (*dz4)[32] = (float (*)[32])(lds + kHwIpb * 260);
+    float (*dh1)[32] = (float (*)[32])(lds + kHwIpb * (260 + 32));
+    float (*qv)[32] = (float (*)[32])(lds + kHwIpb * (260 + 64));
+    float (*e4s)[36] = (float (*)[36])(lds + kHwIpb * (260 + 96));
+    float (*do4)[32] = (float (*)[32])(lds + kHwIpb * (260 + 96 + 36));
+    float* dz2s = lds + kHwIpb * (260 + 96 + 36 + 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int total = P.r[0].n + P.r[1].n, img0 = bid * kHwIpb;
     // ---- this workgroup's images -> LDS (zeros beyond the end) ----

@@ -1022,7 +1022,10 @@ extern "C" int cgs_tail_enc_bwd(int32_t n, const cgs_tail_enc_weights* w, const 
 // from the vectors tail_enc_bwd left in hvec.  16 images per workgroup; slab_head [8192 | 32 | 1024 | 32 | 32 | 1], slab_pw [1024 | 32].
 // (Inside tail_enc_bwd these sums cost 40 accumulator registers per thread and one 37 KB slab per workgroup and pass.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) { tail_head_wgrad_body(P, blockIdx.x); }
+__global__ void __launch_bounds__(256) tail_head_wgrad_kernel(HeadWgradParams P) {
+    __shared__ __attribute__((aligned(16))) float lds[kHwLdsFloats];
+    tail_head_wgrad_body(P, blockIdx.x, lds);
+}
 
 extern "C" int cgs_tail_head_wgrad_slabs(int32_t n_total) { return n_total < 0 ? CGS_ERR_BADARG : (n_total + kHwIpb - 1) / kHwIpb; }
 
