@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(C::G::THREADS) wgrad_any_kernel(WgradParams P)
 // the sparse form is latency-bound with small tiles: more workgroups in flight than the MFMA form wants
 static constexpr int kMaxSparseBlocks = 512;
 #ifndef CGS_CAP_W0U8
-#define CGS_CAP_W0U8 1024
+#define CGS_CAP_W0U8 896      // (round 5, next to the head's 192 workgroups at four per CU: 0.5483 ms; 1024: 0.5499, 832: 0.5494 -- r05af)
 #endif
 template <class C>
 static int wg_blocks_any(int n) {
