@@ -309,6 +309,9 @@ struct MaskInferGeo {
     static constexpr size_t LDS = (size_t)((XIMG + 3) / 4 * 4 + XO + HS + W2S) * 4;
 };
 
+#ifndef MIF16_PREFETCH
+#define MIF16_PREFETCH 0    // mask_infer_f16_kernel's own switch (A/B round 5)
+#endif
 #ifndef MIF_PREFETCH
 #define MIF_PREFETCH 0      // 1 = the next tile's fetch issued before this tile's arithmetic (measured equal at 4 / 2 workgroups per CU: the other workgroups already cover the round trip)
 #endif
@@ -541,28 +544,41 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
 // o0: kq = (fold column b = kq>>1, channel group kq&1), instruction m = fold row a.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// (round 5) The kernel was VALU-issue bound (SQ counters, profiles/r05_d_c4_sq.txt: 535 VALU instructions per wave and tile, 0.8 of
+// the SIMDs' issue slots), a third of them the per-PIXEL staging of the uint8 frame.  Fast forms, taken when the operands allow:
+//  * uint8 frame: a thread takes FOUR pixels = 12 bytes = three dwords (a 64-pixel row is 48 dwords, so groups never straddle rows;
+//    the tile's two halo columns are the conv's zero padding for every tile and are zeroed once).  byte -> fp16 without a conversion:
+//    v_perm_b32 places the byte under the exponent byte 0x3C (= 1 + b/1024, exact), one packed subtract of 1 leaves b/1024; the
+//    1024/255 goes into masker.0's image weights.  18 VALU per four pixels instead of 4 x 40.
+//  * fp16 o0: one 16-byte load / LDS store per low-res pixel (32 interior columns x 8 rows = one per thread).
+//  * bias as the accumulator's initial value; LeakyReLU on packed fp16; the nine tap planes stored without branches (taps 9..15 of the
+//    P instruction go to a tenth, never-read plane); rows of h outside the image zeroed after the loop by the wave that wrote them.
 template <int SRC, bool O16>
 __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams P) {
     using G = MaskInferGeo;
-    constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, LR = G::LR, LC = G::LC, HPS = G::HPS;
+    constexpr int H = G::H, W = G::W, TH = G::TH, HR = G::HR, IR = G::IR, IC = G::IC, LR = G::LR, LC = G::LC;
     constexpr int NIMG = IR * IC, NLO = LR * LC * 2;
+    constexpr bool IMG4 = SRC == WSRC_U8;                  // four-pixel staging of the uint8 frame
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
-    _Float16* ximg = (_Float16*)smem;                      // [IR][IC][4]  (r, g, b, 0)
-    _Float16* xo = ximg + IR * IC * 4;                     // [LR][LC][8]
-    float* pl = (float*)(xo + LR * LC * 8);                // [9 taps][HR][IC] fp32: P_t of rows row0-1 .. row0+8, columns -1 .. 64
+    _Float16* xo = (_Float16*)smem;                        // [LR][LC][8]  (first: 16-byte aligned pixels)
+    _Float16* ximg = xo + LR * LC * 8;                     // [IR][IC][4]  (r, g, b, 0)
+    float* pl = (float*)(ximg + IR * IC * 4);              // [9 taps + 1][HR][IC] fp32: P_t of rows row0-1 .. row0+8, columns -1 .. 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     const int hf = wave & 1, par = wave >> 1;
     const int py = (par + 1) & 1;
 
     // ---- masker.0 weights -> fp16 registers (the A operand: m = l15 = oc, k = 4*kq + c) ----
+    const float wscale = IMG4 ? 1024.f / 255.f : 1.f;
     half4_t wimg[3], wo[2][2];         // image: instruction m covers taps 4m..4m+3;  o0: [px][a = m]
 #pragma unroll
     for (int m = 0; m < 3; ++m) {
         const int t = 4 * m + kq;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wimg[m][c] = (_Float16)((t < 9 && c < 3) ? P.w0[((t < 9 ? t : 0) * 11 + (c < 3 ? c : 0)) * 16 + l15] : 0.f);
+        for (int c = 0; c < 4; ++c)
+            wimg[m][c] = (_Float16)((t < 9 && c < 3) ? wscale * P.w0[((t < 9 ? t : 0) * 11 + (c < 3 ? c : 0)) * 16 + l15] : 0.f);
     }
 #pragma unroll
     for (int px = 0; px < 2; ++px)
@@ -586,14 +602,25 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
     const float bias2 = P.b2[0];
     float b0r[4];
     half4_t w2a;                       // masker.2 as the A operand of the P instruction: m = l15 = tap (9 of 16 rows), k = 4*kq + c = channel
+    int poff[4];                       // plane of this lane's P rows 4 kq + r (taps 9 .. 15: the spare plane)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         b0r[c] = P.b0[4 * kq + c];
         w2a[c] = (_Float16)(l15 < 9 ? P.w2[(l15 < 9 ? l15 : 0) * 16 + 4 * kq + c] : 0.f);
+        poff[c] = (4 * kq + c < 9 ? 4 * kq + c : 9) * HR * IC;
     }
     for (int e = tid; e < 9 * HR * 2; e += 256) {        // the two halo columns of every plane row: zero for every tile
         const int side = e & 1, r = e >> 1;
         pl[r * IC + (side ? IC - 1 : 0)] = 0.f;
+    }
+    if constexpr (IMG4) {                                // ... and of the image tile (columns -1 and 64 are the conv's padding)
+        if (tid < IR * 2) *(uint2*)(ximg + ((tid >> 1) * IC + ((tid & 1) ? IC - 1 : 0)) * 4) = make_uint2(0u, 0u);
+    }
+    if constexpr (O16) {
+        if (tid >= 64 && tid < 64 + LR * 2) {
+            const int e = tid - 64;
+            *(uint4*)(xo + ((e >> 1) * LC + ((e & 1) ? LC - 1 : 0)) * 8) = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     // per-lane tap offsets of the three image instructions (halves): tap t = 4m + kq (t > 8: any valid address, zero weight)
     int toff[3];
@@ -602,93 +629,114 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
 
     __builtin_amdgcn_s_waitcnt(0);     // the preloads above land HERE: a first use inside the tile loop would wait with vmcnt(0) and drain the prefetch
     // Staging: ALL of a tile's global loads are issued back to back into registers (fetch), then converted and written to LDS
-    // (commit) -- one memory round trip per tile instead of seven dependent load -> wait -> store rounds (the ISA of the
-    // element-wise loop this replaces).  With MIF_PREFETCH the next tile's fetch is issued before this tile's arithmetic.
+    // (commit) -- one memory round trip per tile.  With MIF_PREFETCH the next tile's fetch is issued before this tile's arithmetic.
     constexpr int RI = (NIMG + 255) / 256, RO = (NLO + 255) / 256;
-    uint32_t ilo[RI], ihi[RI];
+    [[maybe_unused]] uint32_t d0 = 0, d1 = 0, d2 = 0;      // IMG4: this thread's four pixels
+    [[maybe_unused]] uint4 ov = make_uint4(0u, 0u, 0u, 0u);  // O16 : this thread's low-res pixel
     [[maybe_unused]] float if0[RI], if1[RI], if2[RI];
-    [[maybe_unused]] half4_t oh[RO];
     [[maybe_unused]] float4 of[RO];
+    const int rr4 = tid >> 4, g4 = tid & 15;               // IMG4: tile row 0 .. 11 (tid < 192), pixel group
+    const int pr8 = tid >> 5, lx8 = tid & 31;              // O16 : tile row 0 .. 7, low-res column
     auto fetch = [&](int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        if constexpr (IMG4) {
+            const int y = row0 + rr4 - 2;
+            const bool in = tid < IR * 16 && y >= 0 && y < H;
+            const uint32_t* p = (const uint32_t*)P.img + ((size_t)(n0 * H + (in ? y : 0)) * (W * 3 / 4) + 3 * g4);
+            d0 = p[0]; d1 = p[1]; d2 = p[2];
+        } else {
 #pragma unroll
-        for (int r = 0; r < RI; ++r) {
-            const int e = tid + 256 * r;       // (no branch around the loads: elements past the tile read pixel 0 and are dropped in commit)
-            const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
-            const bool in = e < NIMG && y >= 0 && y < H && x >= 0 && x < W;
-            const int pix = in ? (n0 * H + y) * W + x : 0;
-            if constexpr (SRC == WSRC_U8) {
-                const uint32_t* s32 = (const uint32_t*)P.img;
-                const int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
-                ilo[r] = s32[d]; ihi[r] = s32[d + 1 <= last ? d + 1 : last];
-            } else {
+            for (int r = 0; r < RI; ++r) {
+                const int e = tid + 256 * r;       // (no branch around the loads: elements past the tile read pixel 0 and are dropped in commit)
+                const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+                const bool in = e < NIMG && y >= 0 && y < H && x >= 0 && x < W;
+                const int pix = in ? (n0 * H + y) * W + x : 0;
                 const float* sf = (const float*)P.img;
                 if0[r] = sf[pix * 3]; if1[r] = sf[pix * 3 + 1]; if2[r] = sf[pix * 3 + 2];
             }
         }
+        if constexpr (O16) {
+            const int ly = row0 / 2 + pr8 - 2;
+            const bool in = ly >= 0 && ly < H / 2;
+            ov = ((const uint4*)P.o0)[(size_t)(n0 * (H / 2) + (in ? ly : 0)) * (W / 2) + lx8];
+        } else {
 #pragma unroll
-        for (int r = 0; r < RO; ++r) {
-            const int e = tid + 256 * r;
-            const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-            const int ly = row0 / 2 + pr - 2, lx = pc - 1;
-            const bool in = e < NLO && ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            const int oi = in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0;
-            if constexpr (O16) oh[r] = ((const half4_t*)P.o0)[oi];
-            else of[r] = ((const float4*)P.o0)[oi];
+            for (int r = 0; r < RO; ++r) {
+                const int e = tid + 256 * r;
+                const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+                const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+                const bool in = e < NLO && ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+                of[r] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+            }
         }
     };
     auto commit = [&](int tile) {
-        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-        (void)n0;
+        const int row0 = (tile % G::STRIPS) * TH;
+        if constexpr (IMG4) {
+            if (tid < IR * 16) {
+                const int y = row0 + rr4 - 2;
+                const bool in = y >= 0 && y < H;
+                const uint32_t e0 = in ? d0 : 0u, e1 = in ? d1 : 0u, e2 = in ? d2 : 0u;      // rows outside the image: zero bytes -> 0.0
+                const uint32_t q1 = __builtin_amdgcn_alignbyte(e1, e0, 3), q2 = __builtin_amdgcn_alignbyte(e2, e1, 2);
+                constexpr uint32_t K = 0x3C3C3C3Cu;       // selectors 0 .. 3: bytes of the pixel dword; 4: 0x3C; 0x0c: 0x00
+                auto cv = [&](uint32_t q, uint32_t sel_rg, uint32_t sel_b) {
+                    const half2_t rg = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(K, q, sel_rg)) - half2_t{(_Float16)1.f, (_Float16)1.f};
+                    const half2_t b0 = __builtin_bit_cast(half2_t, __builtin_amdgcn_perm(K, q, sel_b)) - half2_t{(_Float16)1.f, (_Float16)0.f};
+                    return make_uint2(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, b0));
+                };
+                uint2* d = (uint2*)(ximg + (rr4 * IC + 1 + 4 * g4) * 4);
+                d[0] = cv(e0, 0x04010400u, 0x0c0c0402u);
+                d[1] = cv(q1, 0x04010400u, 0x0c0c0402u);
+                d[2] = cv(q2, 0x04010400u, 0x0c0c0402u);
+                d[3] = cv(e2, 0x04020401u, 0x0c0c0403u);
+            }
+        } else {
 #pragma unroll
-        for (int r = 0; r < RI; ++r) {
-            const int e = tid + 256 * r;
-            if (e < NIMG) {
-                const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
-                const bool in = y >= 0 && y < H && x >= 0 && x < W;
-                float v0, v1, v2;
-                if constexpr (SRC == WSRC_U8) {
-                    const int pix = in ? (n0 * H + y) * W + x : 0;
-                    const uint64_t both = (((uint64_t)ihi[r] << 32) | ilo[r]) >> (((pix * 3) & 3) * 8);
-                    const float sc = 1.f / 255.f;
-                    v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
-                } else {
-                    v0 = if0[r]; v1 = if1[r]; v2 = if2[r];
+            for (int r = 0; r < RI; ++r) {
+                const int e = tid + 256 * r;
+                if (e < NIMG) {
+                    const int rr = e / IC, c = e % IC, y = row0 + rr - 2, x = c - 1;
+                    const bool in = y >= 0 && y < H && x >= 0 && x < W;
+                    half4_t hv;
+                    hv[0] = (_Float16)(in ? if0[r] : 0.f); hv[1] = (_Float16)(in ? if1[r] : 0.f); hv[2] = (_Float16)(in ? if2[r] : 0.f); hv[3] = (_Float16)0.f;
+                    *(half4_t*)(ximg + e * 4) = hv;
                 }
-                half4_t hv;
-                hv[0] = (_Float16)(in ? v0 : 0.f); hv[1] = (_Float16)(in ? v1 : 0.f); hv[2] = (_Float16)(in ? v2 : 0.f); hv[3] = (_Float16)0.f;
-                *(half4_t*)(ximg + e * 4) = hv;
             }
         }
+        if constexpr (O16) {
+            const int ly = row0 / 2 + pr8 - 2;
+            const bool in = ly >= 0 && ly < H / 2;
+            *(uint4*)(xo + (pr8 * LC + 1 + lx8) * 8) = in ? ov : make_uint4(0u, 0u, 0u, 0u);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RO; ++r) {
-            const int e = tid + 256 * r;
-            if (e < NLO) {
-                const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-                const int ly = row0 / 2 + pr - 2, lx = pc - 1;
-                const bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-                half4_t hv;
-                if constexpr (O16) hv = oh[r];
-                else { hv[0] = (_Float16)of[r].x; hv[1] = (_Float16)of[r].y; hv[2] = (_Float16)of[r].z; hv[3] = (_Float16)of[r].w; }
-                if (!in) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
+            for (int r = 0; r < RO; ++r) {
+                const int e = tid + 256 * r;
+                if (e < NLO) {
+                    const int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+                    const int ly = row0 / 2 + pr - 2, lx = pc - 1;
+                    const bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+                    half4_t hv;
+                    hv[0] = (_Float16)of[r].x; hv[1] = (_Float16)of[r].y; hv[2] = (_Float16)of[r].z; hv[3] = (_Float16)of[r].w;
+                    if (!in) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    *(half4_t*)(xo + ((pr * LC + pc) * 8 + 4 * half)) = hv;
+                }
             }
         }
     };
 
     for (int tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-        if (!MIF_PREFETCH || tile == (int)blockIdx.x) fetch(tile);
+        if (!MIF16_PREFETCH || tile == (int)blockIdx.x) fetch(tile);
         commit(tile);
         __syncthreads();
-        if (MIF_PREFETCH && tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's arithmetic
+        if (MIF16_PREFETCH && tile + (int)gridDim.x < P.ntiles) fetch(tile + gridDim.x);      // in flight under this tile's arithmetic
 
         const int ibase = (par * IC + 2 * (16 * hf + l15)) * 4;            // halves; + (2*jj*IC + px)*4 + toff[m]
         const int obase = (16 * hf + l15) * 8 + 4 * kq;                    // halves; + ((jj + a + 1)*LC + px)*8
 #pragma unroll
         for (int t = 0; t < 10; ++t) {
             const int jj = t >> 1, px = t & 1;
-            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f};                         // D[oc = 4 kq + r][pixel = l15]
+            frag4 acc = frag4{b0r[0], b0r[1], b0r[2], b0r[3]};             // D[oc = 4 kq + r][pixel = l15], from the bias
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const half4_t a = *(const half4_t*)(ximg + ibase + (2 * jj * IC + px) * 4 + toff[m]);
@@ -699,16 +747,17 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
                 const half4_t a = *(const half4_t*)(xo + obase + ((jj + a2 + 1) * LC + px) * 8);
                 acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wo[px][a2], a, acc, 0, 0, 0);
             }
-            const int j = par + 2 * jj, y = row0 - 1 + j;
-            const float keep = (y >= 0 && y < H) ? 1.f : 0.f;              // rows outside the image: masker.2 pads h with zeros
-            half4_t hv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hv[r] = (_Float16)(keep * act_fwd<CGS_ACT_LRELU>(acc[r] + b0r[r]));
+            half4_t hv = __builtin_convertvector(acc, half4_t);
+            hv = __builtin_elementwise_max(hv, hv * (_Float16)0.01f);      // LeakyReLU on the packed halves
             const frag4 pt = __builtin_amdgcn_mfma_f32_16x16x16f16(w2a, hv, frag4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);      // P[tap = 4 kq + r][pixel]
-            float* prow = pl + j * IC + 1 + 2 * (16 * hf + l15) + px;
+            float* prow = pl + (par + 2 * jj) * IC + 1 + 2 * (16 * hf + l15) + px;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (4 * kq + r < 9) prow[(4 * kq + r) * HR * IC] = pt[r];
+            for (int r = 0; r < 4; ++r) prow[poff[r]] = pt[r];
+        }
+        // rows of h outside the image are masker.2's ZERO padding: this wave wrote them (j = 0: par 0; j = 9: par 1), it clears them
+        if ((row0 == 0 && par == 0) || (row0 == H - TH && par == 1)) {
+            const int j = par ? HR - 1 : 0;
+            for (int e = lane; e < 9 * 32; e += 64) pl[((e >> 5) * HR + j) * IC + 1 + 32 * hf + (e & 31)] = 0.f;
         }
         __syncthreads();
         {
@@ -719,7 +768,7 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
                 float zpre = bias2;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) zpre += pl[(t * HR + yl + t / 3) * IC + x + t % 3];
-                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = 1.f / (1.f + expf(-zpre));
+                P.z[(size_t)(n0 * H + row0 + yl) * W + x] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504f * zpre));
             }
         }
         __syncthreads();
@@ -728,7 +777,7 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
 
 static constexpr size_t kMaskInferF16Lds =
     (size_t)MaskInferGeo::IR * MaskInferGeo::IC * 4 * 2 + (size_t)MaskInferGeo::LR * MaskInferGeo::LC * 8 * 2 +
-    (size_t)9 * MaskInferGeo::HR * MaskInferGeo::IC * 4;
+    (size_t)10 * MaskInferGeo::HR * MaskInferGeo::IC * 4;
 
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st, int o0_f16) {
