@@ -4,6 +4,9 @@
 #include "conv_tile.h"
 
 // 1: the FMA block of every 3x3 kernel runs on the matrix cores (mfma_plane, conv_tile.h); 0: on the vector ALU (fma_plane)
+#ifndef CGS_POOL_EPI_MAX3
+#define CGS_POOL_EPI_MAX3 0      // (r05 A/B: 14 % fewer VALU instructions in tail_enc_fwd, step 0.5533 vs 0.5507 ms -- the per-image chains are latency-, not issue-bound)
+#endif
 #ifndef CGS_CONV_MFMA4
 #define CGS_CONV_MFMA4 1
 #endif
@@ -322,19 +325,47 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
             uint32_t nib[(C::OCB + 7) / 8];
 #pragma unroll
             for (int i = 0; i < (C::OCB + 7) / 8; ++i) nib[i] = 0;
+            if constexpr (C::ACT == CGS_ACT_RELU && CGS_POOL_EPI_MAX3) {
+                // max over the window FIRST (ReLU is monotone: max_i relu(s_i) = relu(max_i s_i)), the argmax from equality with it:
+                // the first position whose pre-activation equals a POSITIVE maximum is the first maximum of the activations (what the
+                // running `v > m` scan below picks); a window whose maximum is <= 0 is 0xF either way.  ~14 instead of 21 VALU
+                // instructions per channel -- the forward tail kernels are instruction-issue bound (round 5, tools/isa_lines.py).
+                typedef float f2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int o = 0; o < C::OCB; ++o) {
-                float b = cgs_to_const(P.bias)[oc0 + o];
-                float m = act_fwd<C::ACT>(acc[0][o] + b);
-                uint32_t idx = 0;
+                for (int o2 = C::OCB - 2; o2 >= 0; o2 -= 2) {
+                    const f2_t b2 = {cgs_to_const(P.bias)[oc0 + o2], cgs_to_const(P.bias)[oc0 + o2 + 1]};
+                    f2_t s[4];
 #pragma unroll
-                for (int i = 1; i < 4; ++i) {
-                    float v = act_fwd<C::ACT>(acc[i][o] + b);
-                    if (v > m) { m = v; idx = i; }
+                    for (int i = 0; i < 4; ++i) s[i] = f2_t{acc[i][o2], acc[i][o2 + 1]} + b2;
+#pragma unroll
+                    for (int h = 1; h >= 0; --h) {
+                        const int o = o2 + h;
+                        const float mr = fmaxf(fmaxf(s[0][h], s[1][h]), fmaxf(s[2][h], s[3][h]));
+                        pooled[o] = fmaxf(mr, 0.f);
+                        uint32_t idx = s[2][h] == mr ? 2u : 3u;
+                        idx = s[1][h] == mr ? 1u : idx;
+                        idx = s[0][h] == mr ? 0u : idx;
+                        if (!(mr > 0.f)) idx = 15u;
+                        // channels from the top down: channel o ends at bits 4 (o % 8) ..  (as an instruction: left to the compiler the shift is
+                        // folded into the selects' constants -- 0x20000000, 0x30000000, ... -- which it then has to keep moving into registers)
+                        asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(nib[o / 8]) : "v"(nib[o / 8]), "v"(idx));
+                    }
                 }
-                if (!(m > 0.f)) idx = 15u;
-                pooled[o] = m;
-                nib[o / 8] |= idx << (4 * (o % 8));
+            } else {
+#pragma unroll
+                for (int o = 0; o < C::OCB; ++o) {
+                    float b = cgs_to_const(P.bias)[oc0 + o];
+                    float m = act_fwd<C::ACT>(acc[0][o] + b);
+                    uint32_t idx = 0;
+#pragma unroll
+                    for (int i = 1; i < 4; ++i) {
+                        float v = act_fwd<C::ACT>(acc[i][o] + b);
+                        if (v > m) { m = v; idx = i; }
+                    }
+                    if (!(m > 0.f)) idx = 15u;
+                    pooled[o] = m;
+                    nib[o / 8] |= idx << (4 * (o % 8));
+                }
             }
             if (live) {
                 int pi = (q.n * HP + (y0 >> 1)) * WP + q.qx;
@@ -452,8 +483,14 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
                             float dsum = 0.f;
 #pragma unroll
                             for (int o = 0; o < 3; ++o) {
-                                const int sh = 8 * (3 * (i & 1) + o);
-                                const float av = (float)((a6[i >> 1] >> sh) & 255) * s255, bv = (float)((b6[i >> 1] >> sh) & 255) * s255;
+                                // byte k of the row's six, from the 32-bit halves: `(float)((a6 >> sh) & 255)` on the 64-bit value is a 64-bit
+                                // integer -> float conversion (shift pair, leading-zero count, ldexp: 30 instructions per byte, a fifth of this
+                                // kernel's vector instructions; round 5, tools/isa_lines.py) where one v_cvt_f32_ubyteN does it.  Same values.
+                                const int kb = 3 * (i & 1) + o;
+                                const uint32_t aw = kb < 4 ? (uint32_t)a6[i >> 1] : (uint32_t)(a6[i >> 1] >> 32);
+                                const uint32_t bw = kb < 4 ? (uint32_t)b6[i >> 1] : (uint32_t)(b6[i >> 1] >> 32);
+                                const int sh = 8 * (kb & 3);
+                                const float av = (float)((aw >> sh) & 255u) * s255, bv = (float)((bw >> sh) & 255u) * s255;
                                 dsum = fmaf(bv - av, v[o], dsum);
                             }
                             const float zi = zq[i];

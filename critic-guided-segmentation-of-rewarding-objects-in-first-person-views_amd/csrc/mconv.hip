@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(C::G::THREADS) mconv_kernel(MConvParams P) {
                     uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
                     uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
                     const float sc = 1.f / 255.f;
-                    v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+                    const uint32_t b3 = (uint32_t)both;      // (32-bit conversions)
+                    v = make_float4((b3 & 255u) * sc, ((b3 >> 8) & 255u) * sc, ((b3 >> 16) & 255u) * sc, 0.f);
                 } else {
                     const float* sf = (const float*)P.src_a;
                     v = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
@@ -217,7 +218,8 @@ __global__ void __launch_bounds__(256) mask0_fwd_kernel(Mask0FwdParams P) {
                 uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
                 uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
                 const float sc = 1.f / 255.f;
-                v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+                const uint32_t b3 = (uint32_t)both;      // (32-bit conversions)
+                    v0 = (b3 & 255u) * sc; v1 = ((b3 >> 8) & 255u) * sc; v2 = ((b3 >> 16) & 255u) * sc;
             } else {
                 const float* sf = (const float*)P.img;
                 v0 = sf[pix * 3]; v1 = sf[pix * 3 + 1]; v2 = sf[pix * 3 + 2];
@@ -411,7 +413,8 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
                     const int pix = in ? (n0 * H + y) * W + x : 0;
                     const uint64_t both = (((uint64_t)ihi[r] << 32) | ilo[r]) >> (((pix * 3) & 3) * 8);
                     const float sc = 1.f / 255.f;
-                    v0 = (both & 255) * sc; v1 = ((both >> 8) & 255) * sc; v2 = ((both >> 16) & 255) * sc;
+                    const uint32_t b3 = (uint32_t)both;      // (32-bit conversions)
+                    v0 = (b3 & 255u) * sc; v1 = ((b3 >> 8) & 255u) * sc; v2 = ((b3 >> 16) & 255u) * sc;
                 } else {
                     v0 = if0[r]; v1 = if1[r]; v2 = if2[r];
                 }

@@ -133,7 +133,8 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
                     uint32_t lo = s32[d], hi = s32[d + 1 <= last ? d + 1 : last];
                     uint64_t both = (((uint64_t)hi << 32) | lo) >> ((off & 3) * 8);
                     const float sc = 1.f / 255.f;
-                    ra[it] = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+                    const uint32_t b3 = (uint32_t)both;      // (32-bit: a uint64_t -> float conversion is ~30 instructions, v_cvt_f32_ubyteN one)
+                    ra[it] = make_float4((b3 & 255u) * sc, ((b3 >> 8) & 255u) * sc, ((b3 >> 16) & 255u) * sc, 0.f);
                 } else {
                     const float* sf = (const float*)P.src_a;
                     ra[it] = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
@@ -197,7 +198,7 @@ __device__ __forceinline__ void wgrad_body(const WgradParams& P, const int tile0
                     float m[3];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        float av = ((a6 >> (8 * c)) & 255) * sc, bv = ((b6 >> (8 * c)) & 255) * sc;
+                        float av = (((uint32_t)a6 >> (8 * c)) & 255u) * sc, bv = (((uint32_t)b6 >> (8 * c)) & 255u) * sc;      // (32-bit conversions)
                         m[c] = av * (1.f - zi) + zi * bv;
                     }
                     v = make_float4(m[0], m[1], m[2], 0.f);
