@@ -38,6 +38,9 @@ struct MHeadParams {
     int n, ntiles;
 };
 
+#ifndef MH_WACC_PK
+#define MH_WACC_PK 1
+#endif
 template <int TH, bool W0>
 struct MHeadGeo {
     static constexpr int H = 64, W = 64, TRA = TH + 2, PW = W + 2, PS = 17, DZW = W + 4, DZR = TH + 4, STRIPS = H / TH;
@@ -69,13 +72,28 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
     auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };   // clamped: prefetches past the end re-read
 
     float w2r[9][4];
-    float wacc[9][4], bacc = 0.f;      // masker.2 weight-gradient partials of this thread (plane pl)
+    // masker.2 weight-gradient partials of this thread (plane pl).  MH_WACC_PK: held as register PAIRS and pinned as pairs, so that their FMAs are
+    // v_pk_fma_f32 (the per-scalar pins below left them as 288 v_fmac_f32 per tile; round 5)
+#if MH_WACC_PK
+    typedef float mh_f2 __attribute__((ext_vector_type(2)));
+    mh_f2 wacc[9][2];
+#else
+    float wacc[9][4];
+#endif
+    float bacc = 0.f;
     float4 hvs[IT];
     float dzr[DIT];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { w2r[t][c] = P.w2[t * 16 + 4 * pl + c]; wacc[t][c] = 0.f; }
+        for (int c = 0; c < 4; ++c) {
+            w2r[t][c] = P.w2[t * 16 + 4 * pl + c];
+#if MH_WACC_PK
+            wacc[t][c >> 1][c & 1] = 0.f;
+#else
+            wacc[t][c] = 0.f;
+#endif
+        }
 
     // loads = address arithmetic + the load only; masking happens where the value is consumed (a select here would
     // wait for the load)
@@ -141,10 +159,16 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
                         a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
                         a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
                         if (WG && it != 0 && it != IT - 1) {     // items 0 and IT-1 are the halo rows: never owned
+#if MH_WACC_PK
+                            const mh_f2 dd = {d, d};
+                            wacc[ky * 3 + kx][0] = __builtin_elementwise_fma(dd, mh_f2{hw_.x, hw_.y}, wacc[ky * 3 + kx][0]);
+                            wacc[ky * 3 + kx][1] = __builtin_elementwise_fma(dd, mh_f2{hw_.z, hw_.w}, wacc[ky * 3 + kx][1]);
+#else
                             wacc[ky * 3 + kx][0] = fmaf(d, hw_.x, wacc[ky * 3 + kx][0]);
                             wacc[ky * 3 + kx][1] = fmaf(d, hw_.y, wacc[ky * 3 + kx][1]);
                             wacc[ky * 3 + kx][2] = fmaf(d, hw_.z, wacc[ky * 3 + kx][2]);
                             wacc[ky * 3 + kx][3] = fmaf(d, hw_.w, wacc[ky * 3 + kx][3]);
+#endif
                         }
                     }
                 static_assert(IT == TH + 2, "one item per tile row: item index == row index");
@@ -155,7 +179,11 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 #pragma unroll
                     for (int t = 0; t < 9; ++t)
 #pragma unroll
+#if MH_WACC_PK
+                        for (int c = 0; c < 2; ++c) asm volatile("" : "+v"(wacc[t][c]));
+#else
                         for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(wacc[t][c]));
+#endif
                 }
                 float4 v = make_float4(a0 * (hv.x > 0.f ? 1.f : 0.01f), a1 * (hv.y > 0.f ? 1.f : 0.01f),
                                        a2 * (hv.z > 0.f ? 1.f : 0.01f), a3 * (hv.w > 0.f ? 1.f : 0.01f));
@@ -178,7 +206,11 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+#if MH_WACC_PK
+                float v = wacc[t][c >> 1][c & 1];
+#else
                 float v = wacc[t][c];
+#endif
                 v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
                 if (lane < 4) red2[(wave * 4 + lane) * 37 + t * 4 + c] = v;
             }
