@@ -69,6 +69,8 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
     static_assert((TRA * W * 4) % 256 == 0, "whole iterations: no element is visited twice");
     const int lane = btid & 63, wave = btid >> 6;
     const int pl = btid & 3;           // the 4-channel plane of dH this thread builds
+    static_assert(4 * W == 256, "one tile row per 256-thread item");
+    const int bx = btid >> 2, bx4 = btid;      // this thread's pixel column (every item) and its float4 index within a row (= 4 bx + pl)
     auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };   // clamped: prefetches past the end re-read
 
     float w2r[9][4];
@@ -101,10 +103,11 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            int e = btid + it * 256;
-            int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
-            bool in = y >= 0 && y < H;
-            hvs[it] = ((const float4*)P.h)[in ? ((n0 * H + y) * W + x) * 4 + pl : 0];
+            // item `it` is tile row `it` (256 threads = 64 pixels x 4 planes = one row): the row test is uniform, the thread's part of the
+            // address (bx4) the same for every item -- written so, the selects and the per-item index arithmetic are scalar (round 5)
+            const int y = row0 + it - 1;
+            const bool in = y >= 0 && y < H;
+            hvs[it] = ((const float4*)P.h)[(in ? (n0 * H + y) * W * 4 : 0) + bx4];
         }
     };
     auto load_dz = [&](int tile) {
@@ -143,12 +146,12 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             load_dz(tile_of(i + 1));      // in flight during the rebuild
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
-                const int e = btid + it * 256;
-                const int x = (e >> 2) % W, r = e / (4 * W), y = row0 + r - 1;
-                const bool in = y >= 0 && y < H;
-                const int gi = in ? ((n0 * H + y) * W + x) * 4 + pl : 0;
+                const int r = it;
+                const int x = bx, y = row0 + it - 1;
+                const bool in = (it >= 1 && it <= TH) || (y >= 0 && y < H);      // interior rows of a strip are always inside the image
+                const int gi = (in ? (n0 * H + y) * W * 4 : 0) + bx4;
                 const float4 hv = hvs[it];
-                const bool own = in && r >= 1 && r <= TH;   // rows owned by this strip (halo rows: the neighbours')
+                const bool own = it >= 1 && it <= TH;       // rows owned by this strip (halo rows: the neighbours')
                 const float4 hw_ = own ? hv : f4zero();
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
