@@ -4,8 +4,12 @@
 #include "conv_tile.h"
 
 // 1: the FMA block of every 3x3 kernel runs on the matrix cores (mfma_plane, conv_tile.h); 0: on the vector ALU (fma_plane)
+#ifndef CGS_WHATIF_NO_POOL_EPI
+#define CGS_WHATIF_NO_POOL_EPI 0
+#endif
 #ifndef CGS_POOL_EPI_MAX3
-#define CGS_POOL_EPI_MAX3 0      // (r05 A/B: 14 % fewer VALU instructions in tail_enc_fwd, step 0.5533 vs 0.5507 ms -- the per-image chains are latency-, not issue-bound)
+#define CGS_POOL_EPI_MAX3 2      // 0 = the running `v > m` scan; 2 = maximum first, argmax from equality (r05 A/B: -2.7 us per step); 1 = the same with the nibble
+                                 // packing as inline-asm v_lshl_or_b32 (+2.2 us: fewer instructions, slower -- the asm statements pin the schedule); 3 = opaque idx
 #endif
 #ifndef CGS_CONV_MFMA4
 #define CGS_CONV_MFMA4 1
@@ -325,6 +329,12 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
             uint32_t nib[(C::OCB + 7) / 8];
 #pragma unroll
             for (int i = 0; i < (C::OCB + 7) / 8; ++i) nib[i] = 0;
+#if CGS_WHATIF_NO_POOL_EPI      // (experiment only: wrong results) how much of the kernel is the pooled epilogue's arithmetic?
+            if constexpr (true) {
+#pragma unroll
+                for (int o = 0; o < C::OCB; ++o) pooled[o] = (acc[0][o] + acc[1][o]) + (acc[2][o] + acc[3][o]);
+            } else
+#endif
             if constexpr (C::ACT == CGS_ACT_RELU && CGS_POOL_EPI_MAX3) {
                 // max over the window FIRST (ReLU is monotone: max_i relu(s_i) = relu(max_i s_i)), the argmax from equality with it:
                 // the first position whose pre-activation equals a POSITIVE maximum is the first maximum of the activations (what the
@@ -348,7 +358,9 @@ __device__ __forceinline__ void conv_compute(const ConvParams& P, const int bid,
                         if (!(mr > 0.f)) idx = 15u;
                         // channels from the top down: channel o ends at bits 4 (o % 8) ..  (as an instruction: left to the compiler the shift is
                         // folded into the selects' constants -- 0x20000000, 0x30000000, ... -- which it then has to keep moving into registers)
-                        asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(nib[o / 8]) : "v"(nib[o / 8]), "v"(idx));
+                        if constexpr (CGS_POOL_EPI_MAX3 == 1) asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(nib[o / 8]) : "v"(nib[o / 8]), "v"(idx));
+                        else if constexpr (CGS_POOL_EPI_MAX3 == 3) { asm("" : "+v"(idx)); nib[o / 8] = (nib[o / 8] << 4) | idx; }
+                        else nib[o / 8] = (nib[o / 8] << 4) | idx;
                     }
                 }
             } else {

@@ -38,6 +38,9 @@ struct MHeadParams {
     int n, ntiles;
 };
 
+#ifndef MH_CVT32
+#define MH_CVT32 0
+#endif
 #ifndef MH_WACC_PK
 #define MH_WACC_PK 1
 #endif
@@ -298,7 +301,12 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                 const float sc = 1.f / 255.f;
                 // (kept on the 64-bit value: with 32-bit conversions -- v_cvt_f32_ubyteN, ~30 instructions fewer per pixel -- the kernel measured
                 //  0.9 us SLOWER, r05 A/B; the matrix waves' phase 1 runs under the builder waves' arithmetic, its length is not on the tile's path)
+#if MH_CVT32
+                const uint32_t b3 = (uint32_t)both;
+                v = make_float4((b3 & 255u) * sc, ((b3 >> 8) & 255u) * sc, ((b3 >> 16) & 255u) * sc, 0.f);
+#else
                 v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
+#endif
             }
             v.w = 0.f;
             ((float4*)L.ximg)[e] = in ? v : f4zero();
