@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     __shared__ __attribute__((aligned(16))) float x1[X1P::FLOATS];
     __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
     __shared__ __attribute__((aligned(16))) float xs[256];               // dropout(e3), flat NHWC
-    __shared__ float red[8][32], es[32], hs[32];
+    __shared__ __attribute__((aligned(16))) float red[8][32];          // (also: the 64 float4 Dropout multipliers of e3 between stages 3 and 4)
+    __shared__ float es[32], hs[32];                                    // hs: the 32 Dropout multipliers of h1 (stage 3 -> stage 10)
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailEncFwdParams) + 2 * sizeof(ConvParams)>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
@@ -198,10 +199,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int j = 0; j < 32; ++j) w4r[j] = P.w.w14[(kg * 32 + j) * 32 + o];
         __syncthreads();
         TAIL_STAMP(3);
-        if (d2.on && tid < 128) {       // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
-            const int q = tid >> 1, p = tid & 1;
-            float4* v = (float4*)(x2 + X2P::at(q >> 3, q & 7) + 4 * p);
-            *v = *v * drop_mult4(d2, (uint32_t)(img * 128 + tid));
+        // The image's three sets of Dropout multipliers, ONE Philox evaluation per wave and all at the same time (round 5; they were three in a row on
+        // wave 0 -- e2's here, e3's in the next stage's epilogue on 16 lanes of every wave, h1's at the head): waves 0 / 1 = e2's 128 float4
+        // (applied in place), wave 2 = e3's 64 float4 -> red, wave 3 = h1's 32 -> hs.  Same counters, same values.
+        if (tid < 128) {                // Dropout on features.10's input (the stored e2 stays undropped: it is the skip)
+            if (d2.on) {
+                const int q = tid >> 1, p = tid & 1;
+                float4* v = (float4*)(x2 + X2P::at(q >> 3, q & 7) + 4 * p);
+                *v = *v * drop_mult4(d2, (uint32_t)(img * 128 + tid));
+            }
+        } else if (tid < 192) {
+            if (d3.on) ((float4*)red)[tid - 128] = drop_mult4(d3, (uint32_t)(img * 64 + tid - 128));     // float4 index (img * 16 + q) * 4 + wave'
+        } else if (tid < 224) {
+            if (dh.on) hs[tid - 192] = drop1(dh, (uint32_t)(img * 32 + tid - 192));
         }
         __syncthreads();
         TAIL_STAMP(4);
@@ -221,7 +231,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const float4 mv = make_float4(m[0], m[1], m[2], m[3]);
                 const uint32_t i4 = (uint32_t)((img * 16 + pb.q) * 4 + wave);      // float4 index of channels 4w .. 4w+3 of pooled pixel q
                 ((float4*)P.e3)[i4] = mv;
-                ((float4*)xs)[pb.q * 4 + wave] = d3.on ? mv * drop_mult4(d3, i4) : mv;
+                ((float4*)xs)[pb.q * 4 + wave] = d3.on ? mv * ((const float4*)red)[pb.q * 4 + wave] : mv;
                 ((uint16_t*)P.am3)[(size_t)i4] = (uint16_t)half;                    // nibbles of channels 4w .. 4w+3: 16-bit quarter of the pixel's two words
             }
         }
@@ -283,7 +293,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     P.o4[(size_t)img * 32 + o] = s;
                 }
                 // ---- Dropout -> crit.4 (32 -> 1) -> Sigmoid ----
-                float t = h * drop1(dh, (uint32_t)(img * 32 + o)) * wl2;
+                float t = h * (dh.on ? hs[o] : 1.f) * wl2;
 #pragma unroll
                 for (int m = 16; m >= 1; m >>= 1) t += __shfl_xor(t, m, 64);
                 if (o == 0) P.pred[img] = 1.f / (1.f + expf(-(t + bl2)));
