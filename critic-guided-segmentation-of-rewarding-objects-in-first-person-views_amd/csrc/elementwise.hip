@@ -455,22 +455,25 @@ __device__ __forceinline__ void phase2_loss_values(const LossArgs& L) {
 #ifndef CGS_REDUCE_DEEP
 #define CGS_REDUCE_DEEP 0
 #endif
-template <int SL>
-__global__ void __launch_bounds__(32 * SL) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
+#ifndef CGS_REDUCE_COLS
+#define CGS_REDUCE_COLS 32      // columns per workgroup (64: a wave reads 256 contiguous bytes of a slab row instead of two rows' 128; A/B round 5)
+#endif
+template <int SL, int COLS = CGS_REDUCE_COLS>
+__global__ void __launch_bounds__(COLS * SL) reduce_adam_kernel(const cgs_reduce_job* __restrict__ jobs, int njobs, uint64_t* step,
                                                               AdamArgs A, LossArgs L) {
-    __shared__ float red[SL][33];
+    __shared__ float red[SL][COLS + 1];
     __shared__ float bc[2];                  // Adam's bias corrections for t = s + 1 (once per workgroup)
     const bool loss_row = (int)blockIdx.y == njobs;
     int row_blocks = 1;                      // workgroups of this grid row that have work (and therefore read *step)
     cgs_reduce_job j{};
     if (!loss_row) {
         j = jobs[blockIdx.y];
-        row_blocks = (j.count + 31) / 32;
+        row_blocks = (j.count + COLS - 1) / COLS;
     }
     if ((int)blockIdx.x >= row_blocks) return;          // nothing to do: never reads the counter, not part of the ticket
     const uint64_t s_old = *step;
     if (loss_row) {
-        if (L.n > 0) phase2_loss_values<32 * SL>(L);
+        if (L.n > 0) phase2_loss_values<COLS * SL>(L);
     } else {
         if (threadIdx.x == 0) {
             // 1 - b^t = -expm1(t ln b): no cancellation at small t, and no double-precision pow (its registers halve the
@@ -479,8 +482,8 @@ __global__ void __launch_bounds__(32 * SL) reduce_adam_kernel(const cgs_reduce_j
             bc[0] = -expm1f(t * logf(A.b1));
             bc[1] = sqrtf(-expm1f(t * logf(A.b2)));
         }
-        const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-        const int i = blockIdx.x * 32 + col;
+        const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+        const int i = blockIdx.x * COLS + col;
         float s[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) s[u] = 0.f;
@@ -558,7 +561,7 @@ extern "C" int cgs_reduce_adam(const cgs_reduce_job* jobs, int32_t njobs, int32_
     // 16 slab lanes x 32 columns per workgroup: the ~800 working workgroups of a phase-2 step are all resident at once
     // (1024-thread workgroups needed 1.6 rounds of the chip's 2 x 256 slots)
     constexpr int SL = 16;
-    hipLaunchKernelGGL(reduce_adam_kernel<SL>, dim3((max_count + 31) / 32, njobs + 1), dim3(32 * SL), 0, (hipStream_t)stream, jobs, njobs,
+    hipLaunchKernelGGL(reduce_adam_kernel<SL>, dim3((max_count + CGS_REDUCE_COLS - 1) / CGS_REDUCE_COLS, njobs + 1), dim3(CGS_REDUCE_COLS * SL), 0, (hipStream_t)stream, jobs, njobs,
                        step, A, L);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;

@@ -38,6 +38,9 @@ struct MHeadParams {
     int n, ntiles;
 };
 
+#ifndef MH_IMG4
+#define MH_IMG4 0      // (r05 A/B: ~100 fewer vector instructions per tile on the matrix waves, step +1 us -- like MH_CVT32; only the builder waves' count is on the tile's path)
+#endif
 #ifndef MH_CVT32
 #define MH_CVT32 0
 #endif
@@ -243,6 +246,12 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     // weight gradient accumulators: image rows + bias (2 row blocks), folded o0 rows per parity (py, px) (2 row blocks each)
     frag4 accA[2], accB[2][2][2];
     float4 ra[W0 ? ITA : 1], rb[W0 ? ITB : 1];
+    // MH_IMG4 (uint8 frames): a thread stages FOUR pixels = three dwords of one tile row (a row is 48 dwords: groups never straddle rows) -- 160
+    // threads, one item, no per-pixel 64-bit shifts (round 5; the tile's halo columns are the conv's zero padding for every tile: zeroed once)
+    constexpr bool IMG4 = MH_IMG4 && SRC == WSRC_U8 && W0;
+    [[maybe_unused]] uint32_t ru[3] = {0u, 0u, 0u};
+    static_assert(TRA * 16 <= 256, "one item of four-pixel groups");
+    [[maybe_unused]] const int rr4 = mtid >> 4, g4 = mtid & 15;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         accA[q] = frag4{0.f, 0.f, 0.f, 0.f};
@@ -262,6 +271,12 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     // later: anything that touches the loaded value here would stall the wave on global memory
     auto fetch_x = [&](int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        if constexpr (IMG4) {
+            const int y = row0 + rr4 - 1;
+            const bool in = mtid < TRA * 16 && y >= 0 && y < H;
+            const uint32_t* s32 = (const uint32_t*)P.img + ((size_t)(n0 * H + (in ? y : 0)) * (W * 3 / 4) + 3 * g4);
+            ru[0] = s32[0]; ru[1] = s32[1]; ru[2] = s32[2];
+        } else
 #pragma unroll
         for (int it = 0; it < ITA; ++it) {
             int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
@@ -289,6 +304,19 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     };
     auto commit_x = [&](int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        if constexpr (IMG4) {
+            if (mtid < TRA * 16) {
+                const int y = row0 + rr4 - 1;
+                const bool in = y >= 0 && y < H;
+                const uint32_t d0 = in ? ru[0] : 0u, d1 = in ? ru[1] : 0u, d2 = in ? ru[2] : 0u;      // rows outside the image: 0 * (1/255) = 0
+                const float sc = 1.f / 255.f;
+                float4* d = (float4*)L.ximg + rr4 * PW + 1 + 4 * g4;
+                d[0] = make_float4((d0 & 255u) * sc, ((d0 >> 8) & 255u) * sc, ((d0 >> 16) & 255u) * sc, 0.f);
+                d[1] = make_float4((d0 >> 24) * sc, (d1 & 255u) * sc, ((d1 >> 8) & 255u) * sc, 0.f);
+                d[2] = make_float4(((d1 >> 16) & 255u) * sc, (d1 >> 24) * sc, (d2 & 255u) * sc, 0.f);
+                d[3] = make_float4(((d2 >> 8) & 255u) * sc, ((d2 >> 16) & 255u) * sc, (d2 >> 24) * sc, 0.f);
+            }
+        } else
 #pragma unroll
         for (int it = 0; it < ITA; ++it) {
             int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
@@ -321,6 +349,9 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
         }
     };
 
+    if constexpr (IMG4) {
+        if (mtid < TRA * 2) ((float4*)L.ximg)[(mtid >> 1) * PW + ((mtid & 1) ? PW - 1 : 0)] = f4zero();
+    }
     for (int i = 0; i <= T; ++i) {
         if constexpr (W0) {
             if (i > 0) commit_x(tile_of(i - 1));
