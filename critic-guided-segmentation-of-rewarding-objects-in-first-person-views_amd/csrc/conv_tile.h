@@ -310,13 +310,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // instructions of tile t run, and only the LDS stores sit between two tiles' compute phases.  Same element maps, clamping and
 // select-to-zero as the one-piece loaders above (bit-identical tiles).  The halo columns are zeroed once per workgroup by the caller.
 // ------------------------------------------------------------------------------------------------
+#ifndef CGS_ELEMS_GUARD
+#define CGS_ELEMS_GUARD 1
+#endif
 template <int E, int THREADS, class F>
 __device__ __forceinline__ void for_elems_it(int tid, F f) {
     constexpr int IT = (E + THREADS - 1) / THREADS;
     static_for<IT>([&](auto I) {
         constexpr int it = decltype(I)::value;
         int e = tid + it * THREADS;
+#if CGS_ELEMS_GUARD
+        // the partial last round (features.0's strips: 288 groups = one full round + 32 threads) is skipped by the waves that have no element in it --
+        // run with clamped indices by every wave it was half of the staging instructions of three waves in four (round 5)
+        if constexpr ((it + 1) * THREADS <= E) f(std::integral_constant<int, it>{}, e);
+        else if (e < E) f(std::integral_constant<int, it>{}, e);
+#else
         f(std::integral_constant<int, it>{}, e < E ? e : E - 1);
+#endif
     });
 }
 
