@@ -1,10 +1,22 @@
 #!/bin/bash
-# usage (GPU box): tools/final_evidence.sh   -> everything the round's profiles/ files are made from, under gpurun_out/final/
+# usage (GPU box): tools/final_evidence.sh TAG   -> everything the round's profiles/ files are made from, under gpurun_out/final/
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
+tag=r05_${1:-x}
 mkdir -p $out
 cd $root
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { tail -5 $out/smoke.log; exit 1; }
+tools/sq_counters.sh final/pmc || exit 1
+python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.csv && python tools/traffic_from_counters.py gpurun_out/final/sq_counters.csv gpurun_out/final/traffic.json 512
+# counter traffic of the side workloads (FETCH_SIZE / WRITE_SIZE passes only)
+tools/side_pmc.sh final/pmc_c4 --mode infer --fp16 --batch 2048 && python tools/side_traffic.py gpurun_out/final/pmc_c4 mask_infer config4_fp16_infer_batch2048 $out/side_traffic.json
+tools/side_pmc.sh final/pmc_c5t --config 5 --mode train && python tools/side_traffic.py gpurun_out/final/pmc_c5t adam_kernel config5_train_batch256 $out/side_traffic.json
+tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "tail_dec_fwd_kernel<false>" config5_infer_batch256 $out/side_traffic.json
+# the counter summaries go into THIS copy's profiles/ before the bench lines are taken: bench.py reads the newest profiles/r*_traffic.json and says whether
+# its source hash is the build's (tools/store_evidence.sh stores the same files in the build container afterwards)
+cp $out/traffic.json profiles/${tag}_traffic.json && sed -i "s#gpurun_out/final/sq_counters.csv#profiles/${tag}_sq_counters.csv#" profiles/${tag}_traffic.json
+cp $out/sq_counters.csv profiles/${tag}_sq_counters.csv
+cp $out/side_traffic.json profiles/${tag}_side_traffic.json
 # the default line (200 steps) and the driver's command, both with the side block and the CPU baseline
 python bench.py > $out/bench.json 2> $out/bench.err || exit 1
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2>/dev/null || exit 1
@@ -21,10 +33,4 @@ tools/prof.sh final/prof || exit 1
 tools/prof_generic.sh final/prof_chfak5 > $out/prof_chfak5.txt 2>&1 || exit 1
 tools/prof_infer.sh final/prof_infer_f16 --fp16 > $out/prof_infer_f16.txt 2>&1 || exit 1
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_config5_train -o runc -- python3 $root/bench.py --config 5 --mode train --steps 10 --warmup 2 --prime-s 0 > $out/prof_config5_train.log 2>&1 ) || exit 1
-tools/sq_counters.sh final/pmc || exit 1
-python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.csv && python tools/traffic_from_counters.py gpurun_out/final/sq_counters.csv gpurun_out/final/traffic.json 512
-# counter traffic of the side workloads (FETCH_SIZE / WRITE_SIZE passes only)
-tools/side_pmc.sh final/pmc_c4 --mode infer --fp16 --batch 2048 && python tools/side_traffic.py gpurun_out/final/pmc_c4 mask_infer config4_fp16_infer_batch2048 $out/side_traffic.json
-tools/side_pmc.sh final/pmc_c5t --config 5 --mode train && python tools/side_traffic.py gpurun_out/final/pmc_c5t adam_kernel config5_train_batch256 $out/side_traffic.json
-tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "tail_dec_fwd_kernel<false>" config5_infer_batch256 $out/side_traffic.json
 tail -1 $out/bench.json | cut -c1-300
