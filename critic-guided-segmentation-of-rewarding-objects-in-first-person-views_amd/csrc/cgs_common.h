@@ -201,9 +201,13 @@ __device__ __forceinline__ float act_fwd(float v) {
 // issue-bound and latency-bound phases in lockstep; delaying every other co-resident workgroup by a few microseconds at its start lets
 // the latency-bound phases of one half run under the matrix instructions of the other.  Workgroups 256 apart share a CU (8 XCDs x 32
 // CUs, round-robin dispatch), hence bit 8.  s_sleep SLEEP = SLEEP x 64 cycles.
+// ASSUMES the MI355X SPX partition (one device = 8 XCDs x 32 CUs = 256 CUs, workgroups dealt round-robin): in CPX / DPX modes or on another SKU the
+// workgroups bit BIT separates do not share a CU and the sleep would be plain added latency -- so it only happens in launches of MORE than 2^BIT
+// workgroups (a smaller launch has no second co-resident workgroup per CU to offset), and never changes results.  cgs_xcd_contiguous below makes the
+// same assumption (8 XCDs); under a different dispatch it is merely a different, still bijective, order.
 template <int BIT, int SLEEP>
 __device__ __forceinline__ void cgs_stagger() {
-    if ((blockIdx.x >> BIT) & 1) __builtin_amdgcn_s_sleep(SLEEP);
+    if (gridDim.x > (1u << BIT) && ((blockIdx.x >> BIT) & 1)) __builtin_amdgcn_s_sleep(SLEEP);
 }
 
 // Virtual workgroup id under which XCD x (= blockIdx.x % 8: workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2) owns a

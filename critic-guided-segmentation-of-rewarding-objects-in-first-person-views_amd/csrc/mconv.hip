@@ -299,7 +299,7 @@ struct MaskInferParams {
     // training form (TRAIN = true): h (the masker.0 output the backward pass needs) is stored once from the LDS tile, and every
     // tile leaves (sum |z|, sum z^2) for the L1 / L2 mask losses (main.py:421-429) at zpart[2 * tile]
     float* h_out; float* zpart;
-    int o0_f16;      // mask_infer_f16_kernel only: o0 is fp16 NHWC (the fused fp16 inference path, hconv.hip) instead of fp32
+    // (mask_infer_f16_kernel: whether o0 is fp16 NHWC -- the fused fp16 inference path, hconv.hip -- is the kernel's template parameter O16)
 };
 
 struct MaskInferGeo {
@@ -785,7 +785,7 @@ static constexpr size_t kMaskInferF16Lds =
 int mask_infer_f16_launch(int n, int img_kind, const void* img, const float* o0, const float* w0, const float* b0,
                           const float* w2, const float* b2, float* z, hipStream_t st, int o0_f16) {
     if (n <= 0) return CGS_OK;
-    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr, o0_f16};
+    MaskInferParams P{img, o0, w0, b0, w2, b2, z, n, n * MaskInferGeo::STRIPS, nullptr, nullptr};
     int blocks = P.ntiles < 1024 ? P.ntiles : 1024;
     const bool u8 = img_kind == CGS_SRC_U8;
     if (u8 && o0_f16) hipLaunchKernelGGL((mask_infer_f16_kernel<WSRC_U8, true>), dim3(blocks), dim3(256), kMaskInferF16Lds, st, P);

@@ -515,7 +515,10 @@ class HourglassEngine:
     def infer(self, X: torch.Tensor, want_mask: bool = True, fp16_mask_head: bool = False, train_mode: bool = False, fp16: bool = False,
               fp16_layerwise: bool = False):
         """Eval-mode critic (+ masker).  X: NHWC uint8 or fp32 [b,64,64,3] on the device.
-        Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): fp16 operands for the masker.0 GEMM.
+        Returns (pred [b], Z [b,64,64] or None).  fp16_mask_head (opt-in): the mask head on fp16 MFMA operands -- the masker.0 GEMM
+        (uint8 frames: bytes scaled by 1/1024 exactly, 1024/255 in the weights), its output h rounded to fp16 after a packed-fp16 LeakyReLU, and masker.2's
+        tap products; fp32 accumulation, fp32 sums of the tap planes, sigmoid via v_exp / v_rcp.  Z differs from the fp32 path by < 2e-3 absolute
+        (tests/test_gpu_kernels.py: max 2e-3, mean 3e-4 bounds; measured on the G1 weights ~3e-5 max).
         fp16 (opt-in, uint8 frames, eval mode): BASELINE config 4 -- the fused fp16 path (fp16 activations / weights in the 64x64 and 32x32
         convolutions and the mask head, fp32 accumulation, the 16x16-and-smaller tail in fp32); fp16_layerwise=True: the shape-generic
         chain with fp16 activations in EVERY layer (what chfak != 1 runs).

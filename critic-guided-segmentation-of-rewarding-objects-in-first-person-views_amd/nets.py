@@ -558,5 +558,7 @@ class BatchNormAct2d(nn.Module):
             raise _lib.CgsError("BatchNormAct2d: the HIP kernels need a GPU tensor; there is no CPU fallback")
         if X.dim() != 4 or X.shape[1] != self.num_features:
             raise _lib.CgsError(f"BatchNormAct2d({self.num_features}): expected [N,{self.num_features},H,W], got {tuple(X.shape)}")
+        if X.dtype != torch.float32:      # the kernels compute and return fp32: a silent dtype change downstream is worse than an error
+            raise _lib.CgsError(f"BatchNormAct2d: fp32 input only (got {X.dtype}); cast explicitly")
         return _BatchNormActFn.apply(self, X, self.weight, self.bias)
 

@@ -88,3 +88,12 @@ def test_batchnorm_act_eval_mode_and_determinism():
     assert torch.equal(a, b)
     with pytest.raises(Exception):
         nets.BatchNormAct2d(10)
+
+
+def test_non_fp32_input_is_rejected_loudly():
+    """The kernels compute and return fp32: a half / bfloat16 input would silently change dtype downstream -- it is an error."""
+    from cgs_amd import _lib, nets
+    m = nets.BatchNormAct2d(8).cuda()
+    for dt in (torch.float16, torch.bfloat16, torch.float64):
+        with pytest.raises(_lib.CgsError):
+            m(torch.zeros(2, 8, 4, 4, device="cuda", dtype=dt))
