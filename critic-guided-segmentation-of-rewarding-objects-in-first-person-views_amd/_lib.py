@@ -57,6 +57,8 @@ SIGNATURES = {
     "cgs_conv3x3_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "cgs_conv3x3_bwd_data": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, i32, vp, i32, vp, vp, vp]),
     "cgs_mask_infer_fwd": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_mask_infer_fwd_packed": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "cgs_mask_infer_fwd_tile": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_infer_fwd_f16": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_mask_infer_fwd_f16o": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_f16_enc0_fwd": (i32, [i32, vp, vp, vp, vp, vp]),

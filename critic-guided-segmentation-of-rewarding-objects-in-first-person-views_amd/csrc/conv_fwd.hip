@@ -3,6 +3,7 @@
 //             UnetDecoder.dec / masker convs with fused Upsample + cat + activation     nets.py:480-521
 //   backward: the same core with transposed/flipped weights; pool/ReLU gradient re-expansion in the
 //             loader; dropout, LeakyReLU', skip-gradient add and upsample-backward sums in the epilogue.
+#include <cstdlib>
 #include "conv_body.h"
 
 // layers routed to the MFMA implicit-GEMM kernels (mconv.hip); CGS_MCONV=0 keeps them on the VALU kernels (A/B)
@@ -154,11 +155,32 @@ extern "C" int cgs_mask_head_bwd(int32_t n, int32_t src_a, const void* x, const 
     return launch_conv<DMaskHead>(P, (hipStream_t)stream);
 }
 
+extern "C" int cgs_mask_infer_fwd_packed(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                         const float* w_m2, const float* b_m2, float* z, const float* w_m0_pack, cgs_stream_t stream);
 extern "C" int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
                                   const float* w_m2, const float* b_m2, float* z, cgs_stream_t stream) {
+    return cgs_mask_infer_fwd_packed(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, nullptr, stream);
+}
+
+extern "C" int cgs_mask_infer_fwd_packed(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                         const float* w_m2, const float* b_m2, float* z, const float* w_m0_pack, cgs_stream_t stream) {
     if (n < 0 || !x || !o0 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !z) return CGS_ERR_BADARG;
     if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
     if (!use_mconv()) return CGS_ERR_UNSUPPORTED;     // VALU build: the caller runs masker.0 and masker.2 as two convolutions
+    // (round 5) the TRAINING forward's kernel with nothing stored but Z: masker.2 on the matrix cores from registers instead of 144 multiply-adds and 36
+    // 16-byte LDS reads per pixel on an h tile -- 2048 frames: 317 -> see DESIGN 8.8 us; Z is then bit-identical to the training forward's.
+    // CGS_MASK_INFER_KERNEL=tile selects the tile kernel (mask_infer_kernel) again.
+    static const bool tile = [] { const char* e = getenv("CGS_MASK_INFER_KERNEL"); return e && e[0] == 't'; }();
+    if (!tile) return mask_train_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, nullptr, z, nullptr, w_m0_pack, (hipStream_t)stream);
+    return mask_infer_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream);
+}
+
+// the tile kernel (mask_infer_kernel: masker.0 into an LDS tile, masker.2 + sigmoid on that tile), whatever the environment says
+extern "C" int cgs_mask_infer_fwd_tile(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0, const float* b_m0,
+                                       const float* w_m2, const float* b_m2, float* z, cgs_stream_t stream) {
+    if (n < 0 || !x || !o0 || !w_m0 || !b_m0 || !w_m2 || !b_m2 || !z) return CGS_ERR_BADARG;
+    if (src_a != CGS_SRC_U8 && src_a != CGS_SRC_F32) return CGS_ERR_BADARG;
+    if (!use_mconv()) return CGS_ERR_UNSUPPORTED;
     return mask_infer_launch(n, src_a, x, o0, w_m0, b_m0, w_m2, b_m2, z, (hipStream_t)stream);
 }
 

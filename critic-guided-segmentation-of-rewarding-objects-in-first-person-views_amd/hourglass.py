@@ -566,8 +566,9 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
                 o[nm] = torch.empty(shp, device=dev, dtype=torch.float32)
         tw = tail_dec_weights(flat, lay)
         m0pack = None
-        if keep_hm and MASK_TRAIN_FUSED and zpart is not None:
-            # the mask head forward's weight registers, built once by a spare workgroup of this launch (the mask head follows two launches later)
+        if (keep_hm and MASK_TRAIN_FUSED and zpart is not None) or (not keep_hm and MASK_INFER_FUSED and not fp16_mask_head):
+            # the mask head forward's weight registers, built once by a spare workgroup of this launch (the mask head follows two launches later;
+            # inference runs the same kernel, storing nothing but Z)
             m0pack = o.get("m0pack")
             if m0pack is None:
                 m0pack = o["m0pack"] = torch.empty(40 * 64, device=dev, dtype=torch.float32)
@@ -595,10 +596,13 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
         if name == "hm" and not keep_hm and MASK_INFER_FUSED:
             if o.get("Z") is None:
                 o["Z"] = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
-            fn = _lib.load().cgs_mask_infer_fwd_f16 if fp16_mask_head else _lib.load().cgs_mask_infer_fwd
-            rc = fn(n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
-                    C.c_void_p(fp + 4 * lay.off("masker.0.weight")), C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
-                    C.c_void_p(fp + 4 * lay.off("masker.2.weight")), C.c_void_p(fp + 4 * lay.off("masker.2.bias")), _p(o["Z"]), _stream())
+            margs = (n, _lib.SRC_U8 if u8 else _lib.SRC_F32, _p(x), _p(prev),
+                     C.c_void_p(fp + 4 * lay.off("masker.0.weight")), C.c_void_p(fp + 4 * lay.off("masker.0.bias")),
+                     C.c_void_p(fp + 4 * lay.off("masker.2.weight")), C.c_void_p(fp + 4 * lay.off("masker.2.bias")), _p(o["Z"]))
+            if fp16_mask_head:
+                rc = _lib.load().cgs_mask_infer_fwd_f16(*margs, _stream())
+            else:
+                rc = _lib.load().cgs_mask_infer_fwd_packed(*margs, _p(o.get("m0pack")) if TAIL_FWD else None, _stream())
             if rc == 0:
                 return o
             if rc != _lib.ERR_UNSUPPORTED:

@@ -121,12 +121,20 @@ int cgs_mask_head_bwd(int32_t n, int32_t src_a, const void* x, const float* o0, 
 
 /* ---- mask head forward for inference (nets.py:488-491 in eval mode) in one pass -----------------------
  * z [n,64,64] = sigmoid(conv3x3(LeakyReLU(conv3x3(cat(x, up(o0)); w_m0, b_m0)); w_m2, b_m2)) without ever storing the
- * 16-channel intermediate (it is needed only by the backward pass): masker.0 on the matrix cores into an LDS tile,
- * masker.2 + sigmoid on that tile.  x [n,64,64,3] of kind src_a (CGS_SRC_U8 / CGS_SRC_F32), o0 [n,32,32,8].
- * Returns CGS_ERR_UNSUPPORTED in the VALU fallback build (use two cgs_conv3x3_fwd calls).                       */
+ * 16-channel intermediate (it is needed only by the backward pass).  x [n,64,64,3] of kind src_a (CGS_SRC_U8 / CGS_SRC_F32), o0 [n,32,32,8].
+ * Since round 5 this is the training forward's kernel (cgs_mask_train_fwd) storing nothing but z: masker.0 and masker.2 on the
+ * matrix cores from registers; z is bit-identical to the training forward's.  (cgs_mask_infer_fwd_tile, or CGS_MASK_INFER_KERNEL=tile in the
+ * environment: the earlier tile kernel -- masker.0 into an LDS tile, masker.2 + sigmoid on that tile.)  cgs_mask_infer_fwd_packed: the same with
+ * masker.0's per-lane weight registers w_m0_pack [40][64] as cgs_tail_dec_fwd_pack / cgs_tail_dec_fwd_dec0 build them (NULL: gathered
+ * per workgroup).  Returns CGS_ERR_UNSUPPORTED in the VALU fallback build (use two cgs_conv3x3_fwd calls).          */
 int cgs_mask_infer_fwd(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
                        const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z,
                        cgs_stream_t stream);
+int cgs_mask_infer_fwd_packed(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
+                       const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z, const float* w_m0_pack,
+                       cgs_stream_t stream);
+int cgs_mask_infer_fwd_tile(int32_t n, int32_t src_a, const void* x, const float* o0, const float* w_m0_hwio,
+                            const float* b_m0, const float* w_m2_hwio, const float* b_m2, float* z, cgs_stream_t stream);
 
 /* Training form of the same pass (nets.py:488-491 in train mode; replaces masker.0's and masker.2's separate forwards): also
  * stores h [n,64,64,16] = LeakyReLU(masker.0) ONCE from the on-chip tile (the backward pass needs it) and leaves, per tile,

@@ -539,8 +539,24 @@ def test_fused_inference_mask_head_matches_oracle_and_two_kernel_form(ctx, n, u8
     assert "hm" not in m1 and "hm" in m2
     rel_close(m1["Z"].cpu().numpy(), Z[:, 0].numpy(), "Z (fused inference)")
     np.testing.assert_allclose(m1["Z"].cpu().numpy(), m2["Z"].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    # round 5: the one-kernel form IS the training forward's kernel storing nothing but Z -- bit-identical to cgs_mask_train_fwd's Z; the earlier
+    # tile kernel (cgs_mask_infer_fwd_tile) computes the same mask in another summation order
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    off = lambda k: C.c_void_p(fm.data_ptr() + 4 * lm.off(k))
+    wargs = (off("masker.0.weight"), off("masker.0.bias"), off("masker.2.weight"), off("masker.2.bias"))
+    src = _lib.SRC_U8 if u8 else _lib.SRC_F32
+    h_t = torch.empty((n, 64, 64, 16), device=dev); z_t = torch.empty((n, 64, 64), device=dev); zp = torch.empty(2 * n, device=dev)
+    assert lib.cgs_mask_train_fwd(n, src, P(xin), P(m2["o0"]), *wargs, P(h_t), P(z_t), P(zp), st) == 0
+    z_tile = torch.empty((n, 64, 64), device=dev)
+    assert lib.cgs_mask_infer_fwd_tile(n, src, P(xin), P(m2["o0"]), *wargs, P(z_tile), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(m1["Z"], z_t)
+    np.testing.assert_allclose(z_tile.cpu().numpy(), m1["Z"].cpu().numpy(), rtol=2e-5, atol=2e-6)
+    rel_close(z_tile.cpu().numpy(), Z[:, 0].numpy(), "Z (tile kernel)")
     p = C.c_void_p(xin.data_ptr())
-    assert lib.cgs_mask_infer_fwd(n, 7, p, p, p, p, p, p, p, C.c_void_p(torch.cuda.current_stream().cuda_stream)) < 0
+    assert lib.cgs_mask_infer_fwd(n, 7, p, p, p, p, p, p, p, st) < 0
+    assert lib.cgs_mask_infer_fwd_tile(n, 7, p, p, p, p, p, p, p, st) < 0
 
 
 def test_fp16_operand_inference_mask_head_within_1e3_abs(ctx):
