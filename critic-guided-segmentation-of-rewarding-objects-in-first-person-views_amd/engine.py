@@ -177,7 +177,7 @@ class HourglassEngine:
                 d = hg.conv_desc(n, hw, ca, cb, co, False, ups, act, pool, nd)
                 # mirrors critic_backward: features.0 shares a launch with its data gradient only in the first pass
                 # (fp32 mixes, image gradient wanted); the second pass reads uint8 frames and needs no image gradient
-                in_tail1 = hg.ENC1_TAIL_BWD_FUSED and hg.ENC1_WGRAD_IN_TAIL and 1 in hg.BOTH_ENC
+                in_tail1 = hg.enc1_tail_bwd_fused(n) and hg.ENC1_WGRAD_IN_TAIL and 1 in hg.BOTH_ENC
                 # features.3 / features.0: weight gradients formed inside the tail backward kernel (first pass = the mixes, second = A's frames)
                 if tail and (i >= 2 or (i == 1 and in_tail1) or (i == 0 and in_tail1 and tag == "p2" and hg.enc0_in_tail(first, not first, None))):
                     return lib.cgs_tail_enc_bwd_slabs(n)

@@ -27,6 +27,9 @@ ENC0_MIX_FUSED = True   # features.0 backward + mix backward in one launch
 MASK_HEAD_FUSED = True   # masker.2+masker.0 data gradients in one pass
 # training forward: masker.0 + masker.2 in one kernel on v_mfma_f32_4x4x1 (csrc/mask_fwd.hip, round 3: 68 us vs 60 + 38 us)
 MASK_TRAIN_FUSED = True
+# ... from this many images on: the one-kernel form is one workgroup per image (two per CU), the two-launch form splits an image into strips -- on a
+# 256-CU device the step is faster WITHOUT it at the reference's own batch (r05, tools/ab_flags_n.py: N = 64: -14 us of 257, 128: -5, 192: +9, 256: +14)
+MASK_TRAIN_FUSED_MIN_N = int(os.environ.get("CGS_MASK_TRAIN_FUSED_MIN_N", "160"))
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
 TAIL_FWD = True
 TAIL_BWD = True
@@ -41,6 +44,16 @@ DEC_TAIL_DEC0_FUSED = True
 # features.3's data gradient behind the encoder tail's backward in ONE launch (tail_enc_bwd_kernel<true>, round 5); its weight gradient then
 # rides in the features.0 backward launch of the same pass (cgs_enc0_bwd_mix_enc1 / cgs_enc0_wgrad_u8_with_head_enc1)
 ENC1_TAIL_BWD_FUSED = os.environ.get("CGS_ENC1_TAIL_BWD_FUSED", "1") != "0"      # (A/B switch for tools/; the product default is on)
+# ... for passes of this many images or more (same measurement: N = 64: -11 us, 128: -5, 192: -3, 256: +1 without it)
+ENC1_TAIL_BWD_FUSED_MIN_N = int(os.environ.get("CGS_ENC1_TAIL_BWD_FUSED_MIN_N", "224"))
+
+
+def mask_train_fused(n: int) -> bool:
+    return MASK_TRAIN_FUSED and n >= MASK_TRAIN_FUSED_MIN_N
+
+
+def enc1_tail_bwd_fused(n: int) -> bool:
+    return ENC1_TAIL_BWD_FUSED and n >= ENC1_TAIL_BWD_FUSED_MIN_N
 # ... and features.3's (sparse) weight gradient inside that kernel too, per workgroup over its own images (False: as rider workgroups of the
 # features.0 backward launch, which reproduces cgs_conv3x3_bwd_both's slabs bit for bit but costs 24 us per step, r05k)
 ENC1_WGRAD_IN_TAIL = os.environ.get("CGS_ENC1_WGRAD_IN_TAIL", "1") != "0"
@@ -406,7 +419,7 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         # mixes' cgs_enc0_bwd_mix, or the uint8 frames' weight gradient deferred into head_wgrad) -- or when no weight gradient is needed
         enc1_host = (mix_bwd is not None) or (u8 and head_sink is not None and dx is None)
         fused1 = False
-        if ENC1_TAIL_BWD_FUSED and 1 in BOTH_ENC and (ENC1_WGRAD_IN_TAIL or enc1_host or not need_wgrad):
+        if enc1_tail_bwd_fused(n) and 1 in BOTH_ENC and (ENC1_WGRAD_IN_TAIL or enc1_host or not need_wgrad):
             de0 = buf("de0", (n, 32, 32, 8))
             # features.3's weight gradient inside the same kernel (ENC1_WGRAD_IN_TAIL) or as riders of the features.0 backward launch
             # (one row per tail workgroup; engine._slab_views allocates the two passes' rows adjacent under the same name)
@@ -566,7 +579,7 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
                 o[nm] = torch.empty(shp, device=dev, dtype=torch.float32)
         tw = tail_dec_weights(flat, lay)
         m0pack = None
-        if (keep_hm and MASK_TRAIN_FUSED and zpart is not None) or (not keep_hm and MASK_INFER_FUSED and not fp16_mask_head):
+        if (keep_hm and mask_train_fused(n) and zpart is not None) or (not keep_hm and MASK_INFER_FUSED and not fp16_mask_head):
             # the mask head forward's weight registers, built once by a spare workgroup of this launch (the mask head follows two launches later;
             # inference runs the same kernel, storing nothing but Z)
             m0pack = o.get("m0pack")
@@ -608,7 +621,7 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
             if rc != _lib.ERR_UNSUPPORTED:
                 _lib.check(rc, "cgs_mask_infer_fwd")
             # unsupported in this build: fall through to the two-kernel form
-        if name == "hm" and keep_hm and MASK_TRAIN_FUSED and zpart is not None:
+        if name == "hm" and keep_hm and mask_train_fused(n) and zpart is not None:
             # training: masker.0 and masker.2 in one kernel -- h is stored once and never re-read for Z
             for k, shp in (("hm", (n, 64, 64, 16)), ("Z", (n, 64, 64))):
                 if o.get(k) is None:
@@ -632,7 +645,7 @@ def masker_forward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: Lis
 
 def zpart_count(n: int) -> int:
     """Number of (sum |z|, sum z^2) partial pairs the training mask layer writes for n images."""
-    return _lib.load().cgs_mask_train_fwd_partials(n) if MASK_TRAIN_FUSED else 4 * n
+    return _lib.load().cgs_mask_train_fwd_partials(n) if mask_train_fused(n) else 4 * n
 
 
 def masker_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, embeds: List[torch.Tensor], n: int,

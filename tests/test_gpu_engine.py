@@ -332,6 +332,10 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
     # ITS images -- a different partition of the sum over the images than the stand-alone launch's, so equal only up to fp32 summation
     # order); with that switched off it rides as extra workgroups that reproduce the stand-alone launch's slabs bit for bit.  The bitwise
     # comparisons therefore run in the rider form; the default form is compared with it at the end, within a summation-order tolerance.
+    # (the per-image forms are used from a batch size on -- hourglass.MASK_TRAIN_FUSED_MIN_N / ENC1_TAIL_BWD_FUSED_MIN_N --: here at every n)
+    small_batch = run() if n < 100 else None                 # the small-batch forms a batch of 37 runs by default (compared at the end)
+    monkeypatch.setattr(hg, "MASK_TRAIN_FUSED_MIN_N", 0)
+    monkeypatch.setattr(hg, "ENC1_TAIL_BWD_FUSED_MIN_N", 0)
     default = run()
     monkeypatch.setattr(hg, "ENC1_WGRAD_IN_TAIL", False)
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "")        # (features.0's weight gradient in the same kernel: likewise a per-workgroup partition)
@@ -351,6 +355,13 @@ def test_per_image_fusions_are_bit_identical_to_the_launches_they_replace(g1, mo
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "both")    # the measured-slower opt-in: features.0's weight gradient in the tail kernel too
     opt_in = run()
     monkeypatch.setattr(hg, "ENC0_WGRAD_IN_TAIL", "")
+    if small_batch is not None:
+        # below the thresholds: the mask head forward as two launches (Z equal to ~2e-5 relative: another summation order) and features.3's backward
+        # as launches of its own -- the same step within that tolerance
+        for a, b, what in zip(small_batch, base, ("losses", "parameters", "m", "v", "pred", "Z")):
+            d = float((a - b).abs().max())
+            print(f"small-batch forms vs per-image forms, {what}: max |diff| {d:.3e}")
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), f"{what}: small-batch launch forms vs the per-image forms: {d}"
     for got in (default, opt_in):
         for a, b, what in zip(got, base, ("losses", "parameters", "m", "v", "pred", "Z")):
             # two Adam steps: a gradient element that differs by an ulp moves its parameter by up to ~lr * 1e-3 (Adam's normalised step)

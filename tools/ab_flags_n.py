@@ -1,5 +1,5 @@
 """In-process A/B of boolean switches of cgs_amd.hourglass at a batch size: python tools/ab_flags_n.py N FLAG [FLAG ...]
-One engine with every switch at its default, one per FLAG with that switch off (HIP graph, dropout 0.3); timed alternately, three rounds."""
+One engine with every switch at its default, one per FLAG (A+B = both) with that switch off (HIP graph, dropout 0.3); timed alternately, three rounds."""
 import os
 import sys
 import time
@@ -14,7 +14,8 @@ from cgs_amd import engine, hourglass as hg  # noqa: E402
 n, names = int(sys.argv[1]), sys.argv[2:]
 dev = torch.device("cuda:0")
 A, B, Y = bench.synthetic(n, 0, dev)
-defaults = {k: getattr(hg, k) for k in names}
+flat = [f for k in names for f in k.split("+")]
+defaults = {k: getattr(hg, k) for k in flat}
 
 
 def make():
@@ -27,9 +28,11 @@ def make():
 
 engs = {"default": make()}
 for k in names:
-    setattr(hg, k, False)
+    for f in k.split("+"):
+        setattr(hg, f, False)
     engs["no " + k] = make()
-    setattr(hg, k, defaults[k])
+    for f in k.split("+"):
+        setattr(hg, f, defaults[f])
 torch.cuda.synchronize()
 
 
