@@ -9,6 +9,7 @@ Per phase-2 step (N = images in A = images in B):
 Data parallelism: one process per GPU, each with its own N images; the only exchange is one all-reduce
 of the flat gradient buffer (25 661 floats) between the slab reduction and Adam.
 """
+import os
 import ctypes as C
 from typing import Dict, Optional
 
@@ -25,6 +26,9 @@ _S = hg._stream
 
 def _align4(x):
     return (x + 3) // 4 * 4
+
+
+PHASE1_FUSED_TAIL = os.environ.get("CGS_PHASE1_FUSED_TAIL", "1") != "0"      # (A/B switch: phase 1 with phase 2's fused step tail)
 
 
 class HourglassEngine:
@@ -362,17 +366,29 @@ class HourglassEngine:
         _lib.call("cgs_phase1_loss", n, _P(self.cbuf["pred"]), _P(self.y), int(self.bce), _P(self.losses), _P(self.dpred), _S())
         first = "p1" not in self._plans
         pc = hg.SlabPlan()
+        # (round 5) as phase 2 does: the head's weight gradients in the features.0 weight-gradient launch, reduction + Adam in one launch on one GPU
+        sink = [] if (hg.TAIL_BWD and PHASE1_FUSED_TAIL) else None
         hg.critic_backward(self.fc, self.lc, X, n, self._cview(0, n), self.dpred[:n], pc, self.drop.shifted(0), ws=self._ws["p1"],
-                           side=self.side)
+                           side=self.side, head_sink=sink)
+        if sink:
+            hg.head_wgrad(sink, pc, self.lc, self._ws["p1"])
         self.side.join()
         if first:
             full = hg.SlabPlan()
             for slab, nsl, cnt, off in pc.jobs:
                 full.jobs.append((slab, nsl, cnt, self.off_c + off))
             self._plans["p1"] = full.build(self.grad)
-        self._plans["p1"].run(self.step_t)
+        if self._p1_fused_adam():
+            self._plans["p1"].run_adam(self.step_t, self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self._ticket)
+        else:
+            self._plans["p1"].run(self.step_t)
+
+    def _p1_fused_adam(self):
+        return self.fused_tail and not self.dp and PHASE1_FUSED_TAIL
 
     def _adam_p1(self):
+        if self._p1_fused_adam():
+            return          # phase 1 on one GPU: Adam ran inside cgs_reduce_adam (the critic's parameters are exactly the reduced elements)
         _lib.call("cgs_adam_flat", self.lc.total, _P(self.flat), _P(self.grad), _P(self.m), _P(self.v), _P(self.step_t),
                   self.lr, self.b1, self.b2, self.eps, 1.0 / self.world, _S())
 
