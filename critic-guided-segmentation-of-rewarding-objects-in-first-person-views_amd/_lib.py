@@ -180,6 +180,7 @@ SIGNATURES = {
     "cgs_gen_convt4s2_bwd_weight": (i32, [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "cgs_gather_roll_u8": (i32, [vp, vp, i32, i32, vp, vp]),
     "cgs_gather_f32": (i32, [vp, vp, i32, vp, vp]),
+    "cgs_gather_contrastive": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "cgs_dropout_mask": (i32, [Dropout, i64, vp, vp]),
     "cgs_build_arch": (C.c_char_p, []),
     "cgs_abi_version": (i32, []),

@@ -398,6 +398,35 @@ __global__ void __launch_bounds__(256) gather_f32_kernel(const float* __restrict
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// The whole batch assembly of a phase-2 step (main.py:344-356) in ONE launch (round 5; it was three cgs_gather_roll_u8 and two cgs_gather_f32
+// launches per step of the N = 64 loop): workgroup b < n writes A[b] = roll(b < h ? Xpos[idx[b]] : Xneg[idx[b]]), n <= b < 2n writes
+// B[b - n] = Xneg[idx[b]] (not rolled), workgroup 2n gathers the n targets of A.
+__global__ void __launch_bounds__(256) gather_contrastive_kernel(const uint8_t* __restrict__ xpos, const uint8_t* __restrict__ xneg,
+                                                                 const float* __restrict__ ypos, const float* __restrict__ yneg,
+                                                                 const int64_t* __restrict__ idx, int n, int h, int shift,
+                                                                 uint32_t* __restrict__ a, uint32_t* __restrict__ bdst, float* __restrict__ y) {
+    const int b = blockIdx.x;
+    if (b == 2 * n) {
+        for (int i = threadIdx.x; i < n; i += 256) y[i] = i < h ? ypos[idx[i]] : yneg[idx[i]];
+        return;
+    }
+    const uint8_t* s = (b < h ? xpos : xneg) + (size_t)idx[b] * 12288;
+    uint32_t* d = b < n ? a + (size_t)b * 3072 : bdst + (size_t)(b - n) * 3072;
+    const int sb = b < n ? 3 * shift : 0;
+    for (int w = threadIdx.x; w < 3072; w += 256) {
+        const int yy = w / 48, b0 = (w % 48) * 4;
+        const uint8_t* row = s + yy * 192;
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int bb = b0 + k + sb;
+            bb = bb >= 192 ? bb - 192 : bb;
+            v |= (uint32_t)row[bb] << (8 * k);
+        }
+        d[w] = v;
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Single-GPU step tail in ONE launch: slab reduction -> gradient -> Adam update of the same element (the value never leaves
@@ -572,6 +601,16 @@ extern "C" int cgs_gather_roll_u8(const uint8_t* src, const int64_t* idx, int32_
     if (!src || !idx || !dst || n < 0 || shift_px < 0 || shift_px >= 64) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     hipLaunchKernelGGL(gather_roll_u8_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, src, idx, shift_px, (uint32_t*)dst);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+extern "C" int cgs_gather_contrastive(const uint8_t* xpos, const uint8_t* xneg, const float* ypos, const float* yneg, const int64_t* idx,
+                                      int32_t n, int32_t h, int32_t shift_px, uint8_t* a, uint8_t* b, float* y, cgs_stream_t stream) {
+    if (!xpos || !xneg || !ypos || !yneg || !idx || !a || !b || !y || n < 0 || h < 0 || h > n || shift_px < 0 || shift_px >= 64) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    hipLaunchKernelGGL(gather_contrastive_kernel, dim3(2 * n + 1), dim3(256), 0, (hipStream_t)stream, xpos, xneg, ypos, yneg, idx, n, h, shift_px,
+                       (uint32_t*)a, (uint32_t*)b, y);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

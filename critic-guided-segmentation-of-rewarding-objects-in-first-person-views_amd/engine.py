@@ -28,6 +28,7 @@ def _align4(x):
     return (x + 3) // 4 * 4
 
 
+GATHER_ONE_LAUNCH = os.environ.get("CGS_GATHER_ONE_LAUNCH", "1") != "0"
 PHASE1_FUSED_TAIL = os.environ.get("CGS_PHASE1_FUSED_TAIL", "1") != "0"      # (A/B switch: phase 1 with phase 2's fused step tail)
 
 
@@ -350,6 +351,10 @@ class HourglassEngine:
         n, h = self.n, self.n // 2
         A, B = self.ab[n:], self.ab[:n]
         ip = idx.data_ptr()
+        if GATHER_ONE_LAUNCH:       # (round 5) one launch instead of five
+            _lib.call("cgs_gather_contrastive", _P(Xpos), _P(Xneg), _P(ypos), _P(yneg), _P(idx), n, h, int(shift_px) % 64, _P(A), _P(B),
+                      _P(self.y), _S())
+            return
         g = lambda src, off, cnt, sh, dst: _lib.call("cgs_gather_roll_u8", _P(src), C.c_void_p(ip + 8 * off), cnt, int(sh) % 64,
                                                      C.c_void_p(dst), _S())
         g(Xpos, 0, h, shift_px, A.data_ptr())

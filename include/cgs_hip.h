@@ -713,6 +713,11 @@ int cgs_gen_convt4s2_bwd_weight(int32_t n, int32_t h, int32_t ca, int32_t cb, in
 int cgs_gather_roll_u8(const uint8_t* src, const int64_t* idx, int32_t n, int32_t shift_px, uint8_t* dst,
                        cgs_stream_t stream);
 int cgs_gather_f32(const float* src, const int64_t* idx, int32_t n, float* dst, cgs_stream_t stream);
+/* The contrastive batch assembly of a phase-2 step in one launch (main.py:344-356 + shift_batch main.py:584-591): a [n,64,64,3] =
+ * [xpos[idx[0..h)] | xneg[idx[h..n)]] rolled along the width by shift_px pixels (0 <= shift_px < 64), b [n,64,64,3] = xneg[idx[n..2n)] (not
+ * rolled), y [n] = [ypos[idx[0..h)] | yneg[idx[h..n)]].  Equal to three cgs_gather_roll_u8 and two cgs_gather_f32 calls.                 */
+int cgs_gather_contrastive(const uint8_t* xpos, const uint8_t* xneg, const float* ypos, const float* yneg, const int64_t* idx, int32_t n,
+                           int32_t h, int32_t shift_px, uint8_t* a, uint8_t* b, float* y, cgs_stream_t stream);
 
 const char* cgs_build_arch(void);
 int cgs_abi_version(void);

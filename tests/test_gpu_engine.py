@@ -96,9 +96,12 @@ def test_phase2_separate_critic_matches_reference_capture(golden, g1, tag, live)
         rel_close(e.critic_state()[k].cpu().numpy(), v, f"critic {k} after step 3", rtol=1e-3, atol_scale=1e-4)
 
 
-def test_device_batch_assembly_matches_host_gather_and_roll():
-    """cgs_gather_roll_u8 / cgs_gather_f32 (main.py:344-356 + shift_batch 584-591 on the device) vs numpy fancy indexing + torch.roll."""
+@pytest.mark.parametrize("one_launch", [True, False])
+def test_device_batch_assembly_matches_host_gather_and_roll(monkeypatch, one_launch):
+    """cgs_gather_contrastive (one launch, round 5) and cgs_gather_roll_u8 / cgs_gather_f32 (five) -- main.py:344-356 + shift_batch 584-591 on the
+    device -- vs numpy fancy indexing + torch.roll."""
     from cgs_amd import engine
+    monkeypatch.setattr(engine, "GATHER_ONE_LAUNCH", one_launch)
     dev = torch.device("cuda:0")
     rs = np.random.RandomState(3)
     Xpos = rs.randint(0, 256, (50, 64, 64, 3)).astype(np.uint8)
