@@ -207,7 +207,9 @@ __device__ __forceinline__ float act_fwd(float v) {
 // same assumption (8 XCDs); under a different dispatch it is merely a different, still bijective, order.
 template <int BIT, int SLEEP>
 __device__ __forceinline__ void cgs_stagger() {
-    if (gridDim.x > (1u << BIT) && ((blockIdx.x >> BIT) & 1)) __builtin_amdgcn_s_sleep(SLEEP);
+    if constexpr (SLEEP > 0) {
+        if (gridDim.x > (1u << BIT) && ((blockIdx.x >> BIT) & 1)) __builtin_amdgcn_s_sleep(SLEEP);
+    }
 }
 
 // Virtual workgroup id under which XCD x (= blockIdx.x % 8: workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2) owns a

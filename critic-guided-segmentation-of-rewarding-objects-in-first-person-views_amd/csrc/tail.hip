@@ -79,6 +79,20 @@ extern "C" int dbg_tail_stamps(unsigned long long* stamps) { g_tail_stamps = sta
 // ------------------------------------------------------------------------------------------------
 // encoder tail + critic head, forward
 // ------------------------------------------------------------------------------------------------
+// s_sleep units (x 64 cycles) of the phase stagger in the fused critic forward, the fused decoder forward and the fused decoder backward (cgs_stagger;
+// 0 = none).  Round 4 shipped 127 in all three (-5 us then); after round 5's instruction-level passes the same A/B reads the other way.
+#ifndef CGS_TAIL_STAGGER
+#define CGS_TAIL_STAGGER 0
+#endif
+#ifndef CGS_STAGGER_ENC_FWD
+#define CGS_STAGGER_ENC_FWD CGS_TAIL_STAGGER
+#endif
+#ifndef CGS_STAGGER_DEC_FWD
+#define CGS_STAGGER_DEC_FWD CGS_TAIL_STAGGER
+#endif
+#ifndef CGS_STAGGER_DEC_BWD
+#define CGS_STAGGER_DEC_BWD CGS_TAIL_STAGGER
+#endif
 struct TailEncFwdParams {
     cgs_tail_enc_weights w;
     const float* e1;
@@ -134,7 +148,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         // every other co-resident workgroup starts ~4 us late: its neighbours' latency-bound tail stages then run under its matrix
         // instructions instead of all four workgroups of a CU moving through the phases in lockstep (r4 A/B, five runs each:
         // 0.590-0.593 ms/step against 0.596-0.607 without; the un-staggered step is bimodal)
-        cgs_stagger<8, 127>();      // (sweep r4: 64 x 64 cycles is too short -- the step stays bimodal --, 190 / 254 and bit 9 measure the same)
+        cgs_stagger<8, CGS_STAGGER_ENC_FWD>();      // (sweep r4: 64 x 64 cycles is too short -- the step stays bimodal --, 190 / 254 and bit 9 measure the same)
         if constexpr (ENC0 == 1) { conv3x3_body_pipe<FEnc0U8P>(PC0, 4 * (int)blockIdx.x, conv_smem); __syncthreads(); }
         if constexpr (ENC0 == 2) { conv3x3_body_pipe<FEnc0MixP>(PC0, 4 * (int)blockIdx.x, conv_smem); __syncthreads(); }
         // features.3 of image blockIdx.x (strips 2 b, 2 b + 1); its first barrier separates the zeroing above from the epilogue's tile writes.
@@ -435,7 +449,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         if (wave == 0) mask0_pack_weights(P.m0_w, P.m0_pack, lane);
         return;
     }
-    if constexpr (FUSED) cgs_stagger<8, 127>();
+    if constexpr (FUSED) cgs_stagger<8, CGS_STAGGER_DEC_FWD>();
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16] = __builtin_amdgcn_s_memtime();
     const int l15 = lane & 15, kq = lane >> 4;
     // the first image's loads are requested before the set-up (and the next image's as soon as the tiles are filled)
@@ -1092,7 +1106,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     using L = TailDecBwdLds;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
     if constexpr (FUSED) {
-        cgs_stagger<8, 127>();
+        cgs_stagger<8, CGS_STAGGER_DEC_BWD>();
         conv3x3_body_pipe<DDec0P>(PC, 2 * (int)blockIdx.x, smem4);
         __syncthreads();            // d o1 of this image is in memory; the convolution's tiles are dead
     }
