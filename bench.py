@@ -109,6 +109,10 @@ def parse():
                          "headline's timed region and reported under the extra key \"side\" of the same JSON line)")
     ap.add_argument("--side-timeout", type=float, default=240.0, help="seconds the parent waits for the side-block child")
     ap.add_argument("--side-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="collective backend of --gpus N / --force-pg: nccl (= RCCL over xGMI, the product path).  gloo is a REHEARSAL form for boxes "
+                         "with fewer GPUs than ranks: ranks share the visible GPU(s) (local rank modulo device count) and the gradient bucket is "
+                         "reduced through the host -- it exercises every world > 1 branch of this script, its numbers mean nothing")
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--prime-s", type=float, default=0.4,
                     help="untimed graph replays for this many seconds right after capture (before the --warmup steps): lets the chip's "
@@ -136,6 +140,42 @@ def rccl_report(dist, dev, rank, world):
     print(f"[bench] rank {rank}: RCCL {ver} (torch backend 'nccl'), world {world}, device {torch.cuda.current_device()} = {name}; "
           f"communicator members: {members}", file=sys.stderr, flush=True)
     return {"version": ver, "members": members, "device_name": name, "nccl_debug": os.environ.get("NCCL_DEBUG")}
+
+
+def allreduce_latency(eng, pg, dev, world, graph_ok, reps=200):
+    """Bare latency of the step's ONE collective -- a sum all-reduce of the optimiser group's flat fp32 gradient bucket (25 661 floats =
+    103 KB when the critic is live) -- so that a scaling loss is attributable: median over `reps` calls of the HIP-event time around one
+    call on the launch stream, eager (includes the call's host launch gap) and as a replayed one-node HIP graph; MAX over ranks."""
+    import torch.distributed as dist
+    lo, cnt = eng._opt_range()
+    cdev = torch.device("cpu") if dist.get_backend(pg) == "gloo" else dev
+    buf = torch.zeros(cnt, device=cdev)
+    stream = torch.cuda.current_stream()
+
+    def median_us(fn):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        dist.barrier()
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record(stream); fn(); b.record(stream)
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in evs)
+        m = torch.tensor([t[len(t) // 2] * 1e3], device=cdev, dtype=torch.float64)
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        return float(m.item())
+
+    for _ in range(10):
+        dist.all_reduce(buf, group=pg)
+    out = {"bytes": cnt * 4, "reps": reps, "eager_median": median_us(lambda: dist.all_reduce(buf, group=pg)), "graph_median": None}
+    if graph_ok:
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            dist.all_reduce(buf, group=pg)
+        for _ in range(10):
+            g.replay()
+        out["graph_median"] = median_us(g.replay)
+    return out
 
 
 def synthetic(n, rank, dev):
@@ -535,7 +575,8 @@ def side_child_main():
 
 def start_side_child():
     """Popen of `python bench.py --side-child` (stdin = the go pipe, stdout = its one JSON line, stderr passed through)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # (no torchrun variables, and no profiler preload: a headline run under rocprofv3 must not hand the child the tool's environment)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LD_PRELOAD") and not k.startswith(("ROCP", "ROCPROF"))}
     return subprocess.Popen([sys.executable, os.path.abspath(__file__), "--side-child"], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
                             text=True, env=env)
 
@@ -564,7 +605,7 @@ def spawn_ranks(args):
     exit with its code.  Nothing in this parent has touched the GPU (torch.cuda.device_count() does not initialise HIP on
     this image), and the parent does not exec: it waits for the child."""
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.backend == "gloo" and have > 0):      # (the gloo rehearsal shares the visible GPUs between ranks)
         print(f"[bench] --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr, flush=True)
         return 2
     import socket
@@ -592,9 +633,12 @@ def main():
     # the side block's child is started HERE, before this process creates its HIP context; it idles on a pipe until the headline is done
     headline = args.gpus == 1 and world == 1 and args.mode == "train" and args.chfak == 1 and args.config == 0 and not args.force_pg
     # (--no-cpu-baseline = the quick form tools and tests use: headline line only, no side block either)
-    side_proc = start_side_child() if (headline and not args.no_side and not args.no_cpu_baseline and torch.cuda.device_count() > 0) else None
+    # (no torch.cuda call before the fork: /dev/kfd says whether a GPU node exists; the child reports a missing GPU itself)
+    side_proc = start_side_child() if (headline and not args.no_side and not args.no_cpu_baseline and os.path.exists("/dev/kfd")) else None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "gloo":         # rehearsal: ranks share the visible GPU(s)
+        local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -603,12 +647,15 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)   # nccl == RCCL on ROCm
         pg = dist.group.WORLD
         ranks_seen, backend = dist.get_world_size(), dist.get_backend()
         if ranks_seen != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the collective backend sees {ranks_seen} ranks")
-        rccl_view = rccl_report(dist, dev, rank, world)
+        rccl_view = rccl_report(dist, dev, rank, world) if backend == "nccl" else {"version": None, "members": None, "rehearsal_backend": backend}
 
     from cgs_amd import engine
     n = args.batch
@@ -645,43 +692,95 @@ def main():
     # state right after the capture step afterwards, so the warm-up and timed steps train from the G1 weights, not from a
     # state a thousand steps into fitting one fixed batch.
     snap = eng.snapshot_state()
-    barrier()
-    primed = 0
     nprime = int(-(-args.prime_s / 0.65e-3 // 50)) * 50 if args.prime_s > 0 else 0
-    while primed < nprime:
-        for _ in range(50):
-            eng.phase2_step()
-        primed += 50
-        torch.cuda.synchronize()
-    eng.restore_state(snap)
-    if pg is not None:
-        # untimed collectives on the gradient bucket itself (RCCL sets channels up lazily on the first calls of a size)
-        for _ in range(5):
-            eng._allreduce()
-        eng.grad.zero_()
-    for _ in range(args.warmup):
-        eng.phase2_step()
-    barrier()
     stream = torch.cuda.current_stream()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    for _ in range(args.steps):
-        eng.phase2_step()
-    ev1.record(stream)
-    barrier()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (graph launches go to this stream)
-    losses = eng.losses.cpu().tolist()
-    print(f"[bench] rank {rank}: {args.steps} steps in {wall:.4f}s = {wall * 1e3 / args.steps:.4f} ms/step (wall), "
-          f"{dev_ms / args.steps:.4f} ms/step (HIP events)", file=sys.stderr, flush=True)
-    per_rank_ms = [wall * 1e3 / args.steps]
-    if world > 1:
-        t = torch.zeros(world, device=dev, dtype=torch.float64)
-        t[rank] = wall
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        per_rank_ms = [float(x) * 1e3 / args.steps for x in t.tolist()]
-        wall = float(t.max().item())                      # MAX over ranks
+
+    def timed_region():
+        """prime (untimed) -> restore -> W warm-up steps -> barrier -> EXACTLY K timed steps -> barrier; returns this rank's numbers."""
+        barrier()
+        primed = 0
+        while primed < nprime:
+            for _ in range(50):
+                eng.phase2_step()
+            primed += 50
+            torch.cuda.synchronize()
+        eng.restore_state(snap)
+        if pg is not None:
+            # untimed collectives on the gradient bucket itself (RCCL sets channels up lazily on the first calls of a size)
+            for _ in range(5):
+                eng._allreduce()
+            eng.grad.zero_()
+        for _ in range(args.warmup):
+            eng.phase2_step()
+        barrier()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(stream)
+        for _ in range(args.steps):
+            eng.phase2_step()
+        ev1.record(stream)
+        barrier()
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)       # HIP events on the launch stream (graph launches go to this stream)
+        losses = eng.losses.cpu().tolist()
+        print(f"[bench] rank {rank}: {args.steps} steps in {wall:.4f}s = {wall * 1e3 / args.steps:.4f} ms/step (wall), "
+              f"{dev_ms / args.steps:.4f} ms/step (HIP events)" + (f", all-reduce in the step graph: {eng.dp_single_graph}" if pg is not None else ""),
+              file=sys.stderr, flush=True)
+        per_rank_ms = [wall * 1e3 / args.steps]
+        if world > 1:
+            t = torch.zeros(world, device=torch.device("cpu") if backend == "gloo" else dev, dtype=torch.float64)
+            t[rank] = wall
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            per_rank_ms = [float(x) * 1e3 / args.steps for x in t.tolist()]
+            wall = float(t.max().item())                      # MAX over ranks
+        return {"wall": wall, "dev_ms": dev_ms, "losses": losses, "per_rank_ms": per_rank_ms, "primed": primed}
+
+    dp_report = None
+    if pg is None:
+        res = timed_region()
+    else:
+        # Data parallel: the first N > 1 run decides everything itself (VERDICT round 5, item 6).  Unless a launch form was forced on the
+        # command line, BOTH forms of the step are timed, each with the same priming / warm-up / K steps from the same snapshot -- eager
+        # (step graph -> eager all-reduce -> Adam graph) first, then the form with the all-reduce recorded in the step's HIP graph when the
+        # collective trial (parallel.collective_capturable) succeeded on EVERY rank -- and after each timed region the replicas' parameters,
+        # Adam moments and step counter are compared bit for bit through an all-gathered 64-bit checksum.  `value` uses the faster form
+        # among those whose replicas stayed bit-identical; every decision is made from all-reduced / all-gathered quantities, so all ranks
+        # take the same branch.
+        from cgs_amd import parallel
+        forced = args.dp_eager_allreduce or args.dp_graph_allreduce
+        if forced or args.no_graph:
+            forms = ["graph" if eng.dp_single_graph else "eager"]
+            capt_ok, capt_note = bool(eng.dp_single_graph), eng.dp_capture_note
+        else:
+            capt_ok, capt_note = parallel.collective_capturable(pg, dev)
+            forms = ["eager"] + (["graph"] if capt_ok else [])
+        results = {}
+        for form in forms:
+            if not args.no_graph and not forced:
+                eng.set_dp_launch_form(form == "graph")
+            eng.restore_state(snap)
+            r = timed_region()
+            same, sums = parallel.replica_checksums([eng.flat, eng.m, eng.v, eng.step_t], pg, dev)
+            r["replicas_bit_identical"], r["replica_checksums"] = same, sums
+            results[form] = r
+        good = [f for f in forms if results[f]["replicas_bit_identical"]] or forms[:1]
+        chosen = min(good, key=lambda f: results[f]["wall"])
+        res = results[chosen]
+        lat = allreduce_latency(eng, pg, dev, world, capt_ok and not args.no_graph)
+        dp_report = {"forms_timed": {f: {"ms_per_step": results[f]["wall"] * 1e3 / args.steps, "per_rank_ms_per_step": results[f]["per_rank_ms"],
+                                         "replicas_bit_identical": results[f]["replicas_bit_identical"],
+                                         "final_total_loss_rank0": results[f]["losses"][5]} for f in forms},
+                     "value_uses_form": chosen,
+                     "choice": ("forced on the command line" if forced else
+                                "the faster of the forms whose replicas stayed bit-identical" if len(forms) > 1 else
+                                f"only the eager form was timed: {capt_note}"),
+                     "collective_capturable": capt_ok, "collective_capturable_note": capt_note,
+                     "replicas_bit_identical": res["replicas_bit_identical"],
+                     "replica_checksums_params_m_v_step": res["replica_checksums"],
+                     "allreduce_latency_us": lat}
+        if not args.no_graph and not forced:
+            eng.set_dp_launch_form(chosen == "graph")
+    wall, dev_ms, losses, per_rank_ms, primed = res["wall"], res["dev_ms"], res["losses"], res["per_rank_ms"], res["primed"]
     if rank == 0:
         ms_step = wall * 1e3 / args.steps
         launch_ms = dev_ms / args.steps
@@ -707,6 +806,8 @@ def main():
                        "per_rank_ms_per_step": per_rank_ms, "allreduce_in_step_graph": bool(getattr(eng, "dp_single_graph", False)),
                        "allreduce_launch_form_note": getattr(eng, "dp_capture_note", None) if pg is not None else None,
                        "rccl": rccl_view,
+                       "replicas_bit_identical": (dp_report["replicas_bit_identical"] if dp_report is not None else None),
+                       "dp": dp_report,
                        "gradient_allreduce": (("one flat fp32 bucket (25 661 floats) per step, " +
                                                ("recorded in the step's HIP graph (one graph launch per step)" if eng.dp_single_graph
                                                 else f"eager between the two step graphs ({eng.dp_capture_note})")) if pg is not None else None)},

@@ -109,6 +109,7 @@ class HourglassEngine:
         # launch (round 3: the data-parallel step is the single-GPU step + one launch + the collective)
         self.fused_tail = hg.TAIL_BWD
         self._graphs: Dict[str, object] = {}
+        self._forms: Dict[str, dict] = {}                    # data parallel: the captured launch forms of a step kind (set_dp_launch_form)
         # parameter version (shared by engines that share the parameters): the fp16 inference path repacks its weight copies when it moves
         self._pver = share_with._pver if share_with is not None else [0]
         self._w16 = None
@@ -140,15 +141,10 @@ class HourglassEngine:
     def adopt(self, critic_module, masker_module, sepcrit_module=None):
         """Re-homes the flat parameters of nets.NewCritic / nets.UnetDecoder into this engine's buffer, so the
         modules and the engine always see the same weights (no copies at save time)."""
-        with torch.no_grad():
-            self.fc.copy_(critic_module.flat.detach().to(self.dev))
-            self.fm.copy_(masker_module.flat.detach().to(self.dev))
-            if sepcrit_module is not None:
-                self.fs.copy_(sepcrit_module.flat.detach().to(self.dev))
-        critic_module.flat.data = self.fc
-        masker_module.flat.data = self.fm
+        critic_module._rehome(self.fc)        # values copied once; the modules' 14 per-layer Parameters then alias the engine's buffer
+        masker_module._rehome(self.fm)
         if sepcrit_module is not None:
-            sepcrit_module.flat.data = self.fs
+            sepcrit_module._rehome(self.fs)
         self._pver[0] += 1
 
     def reset_optimizer(self):
@@ -409,13 +405,42 @@ class HourglassEngine:
         return self.losses
 
     # ---- execution: eager first call (allocates workspaces, builds job tables), then HIP-graph replay ----
-    def _run(self, tag: str, body):
+    def _step_parts(self, tag: str):
+        """(all-reduce, Adam) callables of a step kind: the two launches that follow the kernels of `body` under data parallelism."""
         adam = self._adam if tag == "p2" else self._adam_p1
         if tag == "p1" and self.dp:
             def allred():
                 parallel.allreduce_sum_(self.grad[:self.lc.total], self.pg)
         else:
             allred = self._allreduce
+        return allred, adam
+
+    def _capture(self, tag: str, body, single: bool):
+        """Records the step of kind `tag` as HIP graph(s).  single (data parallel, RCCL): kernels -> all-reduce -> Adam in ONE graph;
+        otherwise one graph (kernels [+ Adam on one GPU]) and, under data parallelism, a second one for Adam with the EAGER all-reduce
+        between them.  Nothing is communicated while capturing."""
+        allred, adam = self._step_parts(tag)
+        if single:
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                body(); allred(); adam()
+            return (g1, None, False)
+        # (data parallel: thread-local capture mode -- the process group's watchdog thread polls its events while this thread captures)
+        kw = {"capture_error_mode": "thread_local"} if self.dp else {}
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, **kw):
+            body()
+            if not self.dp:
+                adam()
+        g2 = None
+        if self.dp:
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, **kw):
+                adam()
+        return (g1, g2, self.dp)
+
+    def _run(self, tag: str, body):
+        allred, adam = self._step_parts(tag)
         g = self._graphs.get(tag)
         if g is None:
             body(); allred(); adam()                       # eager warm-up: allocations + tables
@@ -424,25 +449,13 @@ class HourglassEngine:
                 return
             # the warm-up was a real step; capture the static sequence for all later steps
             torch.cuda.synchronize()
-            if self.dp and self._collective_capturable():
-                # data parallel, RCCL: the all-reduce is captured too -- the whole step (kernels -> collective -> Adam) is ONE graph launch
-                g1 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1, capture_error_mode="thread_local"):
-                    body(); allred(); adam()
-                self.dp_single_graph = True
-                self._graphs[tag] = (g1, None, False)
-                return
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                body()
-                if not self.dp:
-                    adam()
-            g2 = None
+            # data parallel, RCCL: the all-reduce is captured too when every rank can -- the whole step (kernels -> collective -> Adam)
+            # is then ONE graph launch
+            single = bool(self.dp and self._collective_capturable())
+            self._graphs[tag] = self._capture(tag, body, single)
+            self._forms[tag] = {single: self._graphs[tag]}
             if self.dp:
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
-                    adam()
-            self._graphs[tag] = (g1, g2, self.dp)
+                self.dp_single_graph = single
             return
         if g == "eager":
             body(); allred(); adam()
@@ -453,15 +466,38 @@ class HourglassEngine:
             allred()
             g2.replay()
 
+    def set_dp_launch_form(self, single: bool, tag: str = "p2"):
+        """Data parallel only, after the first step of kind `tag`: switches between the two launch forms of the step -- single = the
+        all-reduce recorded in the step's HIP graph, else step graph -> eager all-reduce -> Adam graph -- capturing the missing one
+        (no communication while capturing).  Both forms run the same kernels on the same buffers: a step is bit-identical in either
+        (test_dp_launch_form_matches_single_gpu_step).  EVERY rank of the group must make the same call at the same point of the
+        program (bench.py decides from all-reduced quantities); `single` needs parallel.collective_capturable() == True on the group."""
+        if not self.dp or self._graphs.get(tag) in (None, "eager"):
+            raise _lib.CgsError("set_dp_launch_form: a data-parallel engine with captured graphs (run one step first; use_graph=True)")
+        forms = self._forms[tag]
+        if single not in forms:
+            torch.cuda.synchronize()
+            # (the body is looked up here, not remembered: a stored bound method would tie the engine into a reference cycle, and an engine
+            #  freed by the cycle collector -- at an arbitrary later moment, e.g. inside another engine's capture -- destroys its graphs there)
+            forms[single] = self._capture(tag, self._phase2_fwd_bwd if tag == "p2" else self._phase1_fwd_bwd, single)
+        self._graphs[tag] = forms[single]
+        self.dp_single_graph = bool(single)
+        self.dp_capture_note = ("selected by set_dp_launch_form: the all-reduce is recorded in the step graph" if single else
+                                "selected by set_dp_launch_form: eager all-reduce between the step graph and the Adam graph")
+
     def _collective_capturable(self) -> bool:
         """True when the gradient all-reduce can be recorded into the step's HIP graph: the RCCL backend on device memory (gloo
         rehearsals stage through the host) and a trial capture + replay of a small all-reduce on this group succeeds.  The reason for
         a refusal is kept in self.dp_capture_note (bench.py prints it)."""
-        if not self.dp_graph:
-            self.dp_capture_note = "not requested (dp_graph False; the default at world > 1, see parallel.resolve_dp_graph)"
-            return False
         if getattr(self, "_capturable", None) is not None:
             return self._capturable
+        # the REQUEST itself (dp_graph argument / CGS_DP_GRAPH, resolved per rank) is agreed on first: a rank that skipped the collective
+        # trial below while its peer entered it would deadlock the job (ADVICE round 5)
+        if not parallel.agree_all(bool(self.dp_graph), self.pg, self.dev):
+            self.dp_capture_note = ("not requested on every rank (dp_graph False here or on a peer; the default at world > 1, see "
+                                    "parallel.resolve_dp_graph)")
+            self._capturable = False
+            return False
         ok, self.dp_capture_note = parallel.collective_capturable(self.pg, self.dev)
         self._capturable = ok
         return ok

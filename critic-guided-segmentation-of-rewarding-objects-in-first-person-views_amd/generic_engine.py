@@ -66,6 +66,7 @@ class GenericEngine(HourglassEngine):
         self._infer_step = z(1, dt=torch.int64)
         self.fused_tail = False
         self._graphs: Dict[str, object] = {}
+        self._forms: Dict[str, dict] = {}
         self._plans: Dict[str, hg.SlabPlan] = {}
         self._packplans: Dict[str, gen.PackPlan] = {}
         self._pver = share_with._pver if share_with is not None else [0]

@@ -674,8 +674,10 @@ class Hourglass128:
             self._graph = "eager"
             capturable = not self.dp
             if use_graph and self.dp:
-                if not self.dp_graph:
-                    self.dp_capture_note = "not requested (dp_graph False; the default at world > 1, see parallel.resolve_dp_graph)"
+                # the request is agreed on collectively before the collective trial (a rank that skipped it while its peer entered it would hang)
+                if not parallel.agree_all(bool(self.dp_graph), self.pg, self.dev):
+                    self.dp_capture_note = ("not requested on every rank (dp_graph False here or on a peer; the default at world > 1, see "
+                                            "parallel.resolve_dp_graph)")
                 else:
                     capturable, self.dp_capture_note = parallel.collective_capturable(self.pg, self.dev)
             if use_graph and capturable:        # data parallel: kernels -> all-reduce -> Adam as ONE graph launch per step

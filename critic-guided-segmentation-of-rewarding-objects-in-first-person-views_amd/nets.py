@@ -7,9 +7,10 @@
 return shapes, same ``state_dict`` keys / OIHW tensors (checkpoints interchange with the reference), and
 they behave as ``nn.Module`` for ``.to() / .train() / .eval() / .parameters()`` and ``torch.optim``.
 
-What differs underneath: each module owns ONE flat fp32 parameter (``.flat``) in the kernels' layout (HWIO
-conv weights, k-major linears) and its forward / backward are HIP kernels through ``libcgs_hip.so``
-(``torch.autograd.Function`` shims).  Activations are NHWC on the device; tensors handed back to the caller
+``named_parameters()`` yields the reference's 14 keyed Parameters per module (nets.py:170-194, 479-492): OIHW-shaped
+strided views of ONE flat fp32 buffer (``.flat``, a plain tensor) in the kernels' layout (HWIO conv weights, k-major
+linears); forward / backward are HIP kernels through ``libcgs_hip.so`` (``torch.autograd.Function`` shims) that read
+the flat buffer and hand the per-layer gradients back as the same views of one flat gradient.  Activations are NHWC on the device; tensors handed back to the caller
 are NCHW-shaped views with channels-last strides, so any torch op on them sees the reference's values.
 There is no CPU fallback: calling a module whose parameters are not on a HIP device raises.
 """
@@ -23,7 +24,7 @@ import torch.nn as nn
 from . import _lib
 from . import generic as gen
 from . import hourglass as hg
-from .spec import critic_layout, masker_layout
+from .spec import critic_layout, masker_layout, view_as_reference
 
 
 def _init_like_reference(layout, flat):
@@ -51,6 +52,26 @@ def _to_nhwc(X: torch.Tensor) -> torch.Tensor:
     return X.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous()
 
 
+class _Holder(nn.Module):
+    """Name-space node that carries the reference's parameter names (``features.0.weight`` ...): a group (``features``, ``crit``,
+    ``dec_model``, ``masker`` -- the reference's nn.Sequential attributes, nets.py:170-194, 479-492) or one layer of a group holding
+    its ``weight`` / ``bias`` Parameters.  No arithmetic: the owning _HipModule runs the kernels on the flat buffer those Parameters
+    alias, and it alone moves / converts them (``_apply`` here is a no-op so that .to() cannot split the aliases)."""
+
+    def __init__(self, desc=""):
+        super().__init__()
+        self._desc = desc
+
+    def extra_repr(self):
+        return self._desc
+
+    def __getitem__(self, idx):          # critic.features[3].weight, as on the reference's nn.Sequential
+        return self._modules[str(int(idx))]
+
+    def _apply(self, fn, recurse=True):
+        return self
+
+
 class _HipModule(nn.Module):
     _layout_fn = None
 
@@ -58,27 +79,107 @@ class _HipModule(nn.Module):
         self.layout = layout
         flat = torch.empty(layout.total)
         _init_like_reference(layout, flat)
-        self.flat = nn.Parameter(flat)
+        # The reference's per-layer parameters (14 keyed tensors per module; callers: main.py:178, 330-334) as nn.Parameters whose
+        # storage IS the flat kernel-layout buffer: OIHW-shaped strided views of the HWIO segments (spec.view_as_reference).  The
+        # flat buffer itself is a plain attribute -- not a parameter, not in state_dict().
+        self._flat = flat
+        pmap = OrderedDict()
+        for key, seg in layout.segs.items():
+            grp, idx, leaf = key.split(".")
+            if grp not in self._modules:
+                self.add_module(grp, _Holder())
+            g = self._modules[grp]
+            if idx not in g._modules:
+                g.add_module(idx, _Holder())
+            layer = g._modules[idx]
+            layer.register_parameter(leaf, nn.Parameter(torch.empty(0)))
+            if leaf == "weight":
+                layer._desc = f"{seg.kind}, weight {tuple(seg.ref_shape)} aliasing flat[{seg.offset}:{seg.offset + seg.count}]"
+            pmap[key] = layer._parameters[leaf]
+        self.__dict__["_pmap"] = pmap               # key -> Parameter (plain dict: the holders own the registration)
+        self.__dict__["_pstride"] = {}
+        self._rebind(flat)
         self.dropout_p = float(dropout)
         self.register_buffer("_step", torch.zeros(1, dtype=torch.int64), persistent=False)
         self._seed = int.from_bytes(os.urandom(4), "little")   # Philox key; does not touch torch's RNG stream
 
+    # ---- the flat buffer and its per-layer aliases ----
+    def _rebind(self, flat):
+        """Makes ``flat`` the module's storage: every Parameter's .data becomes a view of it (Parameter objects keep their identity, so
+        optimisers built earlier stay valid)."""
+        self._flat = flat
+        for key, v in self.layout.views(flat).items():
+            self._pmap[key].data = v
+            self._pstride[key] = v.stride()
+
+    def _sync(self):
+        """The Parameters are the truth, the flat buffer is what the kernels read.  They are the same memory unless someone replaced a
+        Parameter's storage (``p.data = t``, copy.deepcopy, pickling): such a Parameter is copied into its segment and re-aliased.
+        Returns the flat buffer."""
+        flat = self._flat
+        base = flat.data_ptr()
+        for key, seg in self.layout.segs.items():
+            p = self._pmap[key]
+            if p.device != flat.device or p.dtype != flat.dtype or p.data_ptr() != base + 4 * seg.offset or p.stride() != self._pstride[key]:
+                with torch.no_grad():
+                    v = view_as_reference(flat[seg.offset:seg.offset + seg.count], seg)
+                    v.copy_(p.detach().to(device=flat.device, dtype=flat.dtype))
+                    p.data = v
+        return flat
+
+    @property
+    def flat(self):
+        """The flat fp32 kernel-layout buffer all 14 Parameters alias (a plain tensor: not a Parameter, carries no .grad)."""
+        return self._sync()
+
+    def _rehome(self, buf):
+        """Moves the parameters into ``buf`` (a segment of an engine's buffer): values copied once, Parameters re-aliased, so module and
+        engine see the same weights from then on (engine.adopt)."""
+        with torch.no_grad():
+            buf.copy_(self._sync().to(buf.device))
+        self._rebind(buf)
+
+    def _apply(self, fn, recurse=True):
+        # .to() / .cuda() / .cpu() / .float(): the flat buffer moves as ONE tensor and the Parameters are re-aliased (the default
+        # per-parameter conversion would give each its own storage)
+        old = self._sync()
+        super()._apply(fn)                              # own buffers (_step); the holders' _apply is a no-op
+        new = fn(old)
+        if new.dtype != torch.float32:
+            raise _lib.CgsError(f"{type(self).__name__}: the HIP kernels of the module API hold fp32 parameters (got {new.dtype}); the "
+                                "fp16 / bf16 paths convert their own weight copies (engine.infer(fp16=True))")
+        grads = [(p, p.grad) for p in self._pmap.values() if p.grad is not None]
+        self._rebind(new)
+        for p, g in grads:
+            with torch.no_grad():
+                p.grad = fn(g)
+        return self
+
+    def _param_list(self):
+        return list(self._pmap.values())
+
+    def _grad_views(self, g, needs):
+        """Per-layer gradients as reference-shaped views of the flat gradient ``g`` (same strides as the Parameters: autograd takes them
+        as .grad without a copy), None where a Parameter is frozen (requires_grad_(False) on one key freezes exactly that layer)."""
+        return tuple(v if need else None for v, need in zip(self.layout.views(g).values(), needs))
+
     # ---- checkpoint contract: reference keys, reference (OIHW) tensors ----
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
         out = destination if destination is not None else OrderedDict()
-        for k, v in self.layout.unflatten(self.flat).items():
+        for k, v in self.layout.unflatten(self._sync()).items():
             out[prefix + k] = v
         return out
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         sd = {k: v for k, v in state_dict.items()}
+        flat = self._sync()
         with torch.no_grad():
-            self.layout.flatten({k: v.to(self.flat.device) for k, v in sd.items()}, self.flat.data)
+            self.layout.flatten({k: v.to(flat.device) for k, v in sd.items()}, flat)
         return torch.nn.modules.module._IncompatibleKeys([], [])
 
     def _need_device(self):
-        if not self.flat.is_cuda:
-            raise _lib.CgsError(f"{type(self).__name__}: parameters are on {self.flat.device}; the HIP kernels need "
+        if not self._flat.is_cuda:
+            raise _lib.CgsError(f"{type(self).__name__}: parameters are on {self._flat.device}; the HIP kernels need "
                                 "a GPU (call .to('cuda')).  There is no CPU fallback on this path.")
 
     def _drop_state(self):
@@ -98,13 +199,14 @@ class _GenCriticFn(torch.autograd.Function):
     """NewCritic at chfak != 1 / neck != 32 on the shape-generic kernels (generic.py): same contract as _CriticFn."""
 
     @staticmethod
-    def forward(ctx, X, flat, mod, collect):
+    def forward(ctx, X, mod, collect, *params):
         x = _to_nhwc(X)
         n = x.shape[0]
+        flat = mod._flat                   # the storage ``params`` alias (NewCritic.forward has just _sync()ed them)
         drop = mod._drop_state()
-        out = gen.critic_forward(flat.detach(), mod.layout, x, mod.chfak, mod.neck, drop=drop if drop.p > 0.0 else None)
-        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out = mod, drop, n, collect, x, out
-        ctx.save_for_backward(flat)
+        out = gen.critic_forward(flat, mod.layout, x, mod.chfak, mod.neck, drop=drop if drop.p > 0.0 else None)
+        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out, ctx.flat = mod, drop, n, collect, x, out, flat
+        ctx.save_for_backward(*params)     # version counters: an in-place update between forward and backward raises
         pred = out["pred"].view(n, 1)
         if not collect:
             return pred
@@ -112,7 +214,8 @@ class _GenCriticFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpred, *de):
-        (flat,) = ctx.saved_tensors
+        _ = ctx.saved_tensors
+        flat = ctx.flat
         mod, n, dev = ctx.mod, ctx.n, flat.device
         lay = mod.layout
         dp = torch.zeros(n, device=dev) if dpred is None else dpred.reshape(n).to(torch.float32).contiguous()
@@ -130,26 +233,28 @@ class _GenCriticFn(torch.autograd.Function):
         plan = hg.SlabPlan()
         gen.critic_backward_weights(grad, 0, lay, mod.chfak, mod.neck, ctx.out, g, ctx.x, n, plan, ws, "mod", training=training)
         plan.build(grad).run()
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), grad, None, None
+        return ((dx.permute(0, 3, 1, 2) if dx is not None else None), None, None) + mod._grad_views(grad, ctx.needs_input_grad[3:])
 
 
 class _GenMaskerFn(torch.autograd.Function):
     """UnetDecoder at chfak != 1 / neck != 32 on the shape-generic kernels: same contract as _MaskerFn."""
 
     @staticmethod
-    def forward(ctx, X, e0, e1, e2, e3, e4, flat, mod):
+    def forward(ctx, X, e0, e1, e2, e3, e4, mod, *params):
         x = _to_nhwc(X)
         n = x.shape[0]
+        flat = mod._flat
         embeds = [e.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous() for e in (e0, e1, e2, e3)]
         embeds.append(e4.detach().to(torch.float32).reshape(n, -1).contiguous())
-        m = gen.masker_forward(flat.detach(), mod.layout, x, embeds, mod.chfak, mod.neck, mod.masker_channels)
-        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m = mod, n, x, embeds, m
-        ctx.save_for_backward(flat)
+        m = gen.masker_forward(flat, mod.layout, x, embeds, mod.chfak, mod.neck, mod.masker_channels)
+        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m, ctx.flat = mod, n, x, embeds, m, flat
+        ctx.save_for_backward(*params)
         return m["Z"].view(n, 1, 64, 64)
 
     @staticmethod
     def backward(ctx, dZ):
-        (flat,) = ctx.saved_tensors
+        _ = ctx.saved_tensors
+        flat = ctx.flat
         mod, n = ctx.mod, ctx.n
         lay = mod.layout
         Z = ctx.m["Z"]
@@ -160,18 +265,19 @@ class _GenMaskerFn(torch.autograd.Function):
                                     gen.Workspace(), mod.masker_channels)
         plan.build(grad).run()
         de = [d.permute(0, 3, 1, 2) for d in d_emb[:4]] + [d_emb[4].view(n, -1, 1, 1)]
-        return (None,) + tuple(de) + (grad, None)
+        return (None,) + tuple(de) + (None,) + mod._grad_views(grad, ctx.needs_input_grad[7:])
 
 
 class _CriticFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, flat, mod, collect):
+    def forward(ctx, X, mod, collect, *params):
         x = _to_nhwc(X)
         n = x.shape[0]
+        flat = mod._flat
         drop = mod._drop_state()
-        out = hg.critic_forward(flat.detach(), mod.layout, x, n, drop)
-        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out = mod, drop, n, collect, x, out
-        ctx.save_for_backward(flat)
+        out = hg.critic_forward(flat, mod.layout, x, n, drop)
+        ctx.mod, ctx.drop, ctx.n, ctx.collect, ctx.x, ctx.out, ctx.flat = mod, drop, n, collect, x, out, flat
+        ctx.save_for_backward(*params)
         pred = out["pred"].view(n, 1)
         if not collect:
             return pred
@@ -179,7 +285,8 @@ class _CriticFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dpred, *de):
-        (flat,) = ctx.saved_tensors
+        _ = ctx.saved_tensors
+        flat = ctx.flat
         n, dev = ctx.n, flat.device
         lay = ctx.mod.layout
         dp = torch.zeros(n, device=dev) if dpred is None else dpred.reshape(n).to(torch.float32).contiguous()
@@ -196,7 +303,7 @@ class _CriticFn(torch.autograd.Function):
                            n_add=n if d_embeds is not None else 0, dx=dx, dx_from=0)
         g = torch.empty(lay.total, device=dev)
         plan.build(g).run()
-        return (dx.permute(0, 3, 1, 2) if dx is not None else None), g, None, None
+        return ((dx.permute(0, 3, 1, 2) if dx is not None else None), None, None) + ctx.mod._grad_views(g, ctx.needs_input_grad[3:])
 
 
 class NewCritic(_HipModule):
@@ -217,7 +324,8 @@ class NewCritic(_HipModule):
     def forward(self, X, collect=False):
         self._need_device()
         fn = _GenCriticFn if self._generic else _CriticFn      # chfak != 1 / neck != 32: the shape-generic kernels
-        out = fn.apply(X.to(self.flat.device), self.flat, self, bool(collect))
+        dev = self._sync().device
+        out = fn.apply(X.to(dev), self, bool(collect), *self._param_list())
         if collect:
             return out[0], list(out[1:])
         return out
@@ -225,19 +333,21 @@ class NewCritic(_HipModule):
 
 class _MaskerFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, e0, e1, e2, e3, e4, flat, mod):
+    def forward(ctx, X, e0, e1, e2, e3, e4, mod, *params):
         x = _to_nhwc(X)
         n = x.shape[0]
+        flat = mod._flat
         embeds = [e.detach().to(torch.float32).permute(0, 2, 3, 1).contiguous() for e in (e0, e1, e2, e3)]
         embeds.append(e4.detach().to(torch.float32).reshape(n, 32).contiguous())
-        m = hg.masker_forward(flat.detach(), mod.layout, x, embeds, n)
-        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m = mod, n, x, embeds, m
-        ctx.save_for_backward(flat)
+        m = hg.masker_forward(flat, mod.layout, x, embeds, n)
+        ctx.mod, ctx.n, ctx.x, ctx.embeds, ctx.m, ctx.flat = mod, n, x, embeds, m, flat
+        ctx.save_for_backward(*params)
         return m["Z"].view(n, 1, 64, 64)
 
     @staticmethod
     def backward(ctx, dZ):
-        (flat,) = ctx.saved_tensors
+        _ = ctx.saved_tensors
+        flat = ctx.flat
         n, lay = ctx.n, ctx.mod.layout
         Z = ctx.m["Z"]
         dzpre = (dZ.reshape(n, 64, 64).to(torch.float32) * Z * (1.0 - Z)).contiguous()   # sigmoid'
@@ -246,7 +356,7 @@ class _MaskerFn(torch.autograd.Function):
         g = torch.empty(lay.total, device=flat.device)
         plan.build(g).run()
         de = [d.permute(0, 3, 1, 2) for d in d_emb[:4]] + [d_emb[4].view(n, 32, 1, 1)]
-        return (None,) + tuple(de) + (g, None)
+        return (None,) + tuple(de) + (None,) + ctx.mod._grad_views(g, ctx.needs_input_grad[7:])
 
 
 class UnetDecoder(_HipModule):
@@ -268,10 +378,10 @@ class UnetDecoder(_HipModule):
 
     def forward(self, X, embeds):
         self._need_device()
-        dev = self.flat.device
+        dev = self._sync().device
         e = [t.to(dev) for t in embeds]
         fn = _GenMaskerFn if self._generic else _MaskerFn
-        return fn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self.flat, self)
+        return fn.apply(X.to(dev), e[0], e[1], e[2], e[3], e[4], self, *self._param_list())
 
 
 class _UnetFn(torch.autograd.Function):

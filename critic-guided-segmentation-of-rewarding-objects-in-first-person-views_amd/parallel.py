@@ -87,11 +87,40 @@ def resolve_dp_graph(dp_graph, world: int) -> bool:
     return bool(dp_graph)
 
 
-def _agree_all(ok: bool, group, dev) -> bool:
-    """Logical AND of a per-rank flag over the group (one eager MIN all-reduce): every rank gets the same answer."""
-    f = torch.tensor([1.0 if ok else 0.0], device=dev)
+def agree_all(ok: bool, group, dev) -> bool:
+    """Logical AND of a per-rank flag over the group (one eager MIN all-reduce; through the host for gloo): every rank gets the same
+    answer.  Must be called by all ranks of the group at the same point of the program."""
+    f = torch.tensor([1.0 if ok else 0.0], device="cpu" if dist.get_backend(group) == "gloo" else dev)
     dist.all_reduce(f, op=dist.ReduceOp.MIN, group=group)
     return bool(f.item() == 1.0)
+
+
+_agree_all = agree_all
+
+
+def checksum64(t: torch.Tensor) -> torch.Tensor:
+    """int64[2] checksum of a tensor's BITS (fp32 / int32 words, or int64): (sum of the words, position-weighted sum), wrap-around
+    int64 arithmetic -- equal on two replicas iff (up to a 2^-64 collision) every bit is equal; reorderings change the second word."""
+    t = t.detach().contiguous().reshape(-1)
+    w = (t if t.dtype == torch.int64 else t.view(torch.int32).to(torch.int64))
+    idx = torch.arange(1, w.numel() + 1, device=w.device, dtype=torch.int64)
+    return torch.stack([w.sum(), (w * idx).sum()])
+
+
+def replica_checksums(tensors, group, dev):
+    """(identical, per-rank list of hex strings): all-gathers checksum64 of each tensor of `tensors` over the group and says whether every
+    rank holds the same bits -- the data-parallel contract here is BIT-identical replicas (one all-reduced gradient, the same Adam
+    arithmetic on every rank).  One collective; all ranks must call it together."""
+    mine = torch.cat([checksum64(t) for t in tensors])
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        mine = mine.cpu()
+    else:
+        mine = mine.to(dev)
+    allc = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allc, mine, group=group)
+    rows = [[int(v) & 0xFFFFFFFFFFFFFFFF for v in c.tolist()] for c in allc]
+    return all(r == rows[0] for r in rows), ["".join(f"{v:016x}" for v in r) for r in rows]
 
 
 def collective_capturable(group, dev):

@@ -42,6 +42,24 @@ def _from_kernel(v: torch.Tensor, seg: Seg) -> torch.Tensor:
     return v.reshape(s).clone()
 
 
+def view_as_reference(v: torch.Tensor, seg: Seg) -> torch.Tensor:
+    """A reference-shaped (OIHW / [o][k]) strided VIEW of a segment of the flat kernel-layout buffer -- no copy: writes through
+    either side are seen by the other.  The per-layer ``nn.Parameter``s of nets.NewCritic / nets.UnetDecoder (and their ``.grad``s
+    over the flat gradient) are such views, so ``named_parameters()`` has the reference's keys and shapes (nets.py:170-194, 479-492)
+    while the kernels keep their one contiguous buffer."""
+    s = seg.ref_shape
+    if seg.kind in ("conv_w", "head_w4"):
+        o, i, kh, kw = s
+        return v.view(kh, kw, i, o).permute(3, 2, 0, 1)
+    if seg.kind == "linear_w":
+        o, k = s
+        return v.view(k, o).t()
+    if seg.kind == "pw_w":
+        o, i = s[0], s[1]
+        return v.view(i, o).t().unsqueeze(-1).unsqueeze(-1)
+    return v.view(s)
+
+
 class Layout:
     """Flat parameter layout of one module."""
 
@@ -71,6 +89,10 @@ class Layout:
                 if tuple(t.shape) != seg.ref_shape:
                     raise RuntimeError(f"size mismatch for {key}: checkpoint {tuple(t.shape)} vs model {seg.ref_shape}")
                 out[seg.offset:seg.offset + seg.count].copy_(_to_kernel(t.detach().to(torch.float32), seg.kind))
+
+    def views(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
+        """Reference-shaped views (no copies) of every segment of ``flat``: see view_as_reference."""
+        return OrderedDict((key, view_as_reference(flat[seg.offset:seg.offset + seg.count], seg)) for key, seg in self.segs.items())
 
     def unflatten(self, flat: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         """Flat kernel-layout buffer -> reference-format tensors (OIHW etc.), same device."""

@@ -82,13 +82,15 @@ def test_reference_style_training_loop_through_modules(golden, g1, tag, kw):
         nl = 0.5 * F.l1_loss(Z, torch.zeros_like(Z)); loss = loss + nl; parts[3] = nl.item()
         opti.zero_grad()
         loss.backward()
-        if s == 0:
-            gm = masker.layout.unflatten(masker.flat.grad)
+        if s == 0:          # per-key .grad of the 14 + 14 reference-named Parameters (nets.py:170-194, 479-492)
+            gm = {k: q.grad for k, q in masker.named_parameters()}
             for k, v in split(g, "grad/masker").items():
+                assert gm[k].shape == v.shape
                 rel_close(gm[k].cpu().numpy(), v, f"masker grad {k}")
             if live:
-                gc = critic.layout.unflatten(critic.flat.grad)
+                gc = {k: q.grad for k, q in critic.named_parameters()}
                 for k, v in split(g, "grad/critic").items():
+                    assert gc[k].shape == v.shape
                     rel_close(gc[k].cpu().numpy(), v, f"critic grad {k}")
         opti.step()
         np.testing.assert_allclose(parts, g[f"parts{s}"], rtol=1e-3, atol=1e-7)
@@ -97,6 +99,73 @@ def test_reference_style_training_loop_through_modules(golden, g1, tag, kw):
         rel_close(masker.state_dict()[k].cpu().numpy(), v, f"masker {k} after 3 steps", atol_scale=1e-4)
     for k, v in split(g, "step3/critic").items():
         rel_close(critic.state_dict()[k].cpu().numpy(), v, f"critic {k} after 3 steps", atol_scale=1e-4)
+
+
+def test_named_parameters_are_the_references_and_alias_the_flat_buffer(g1):
+    """Row b: 14 keyed Parameters per module (g1_keys.json = the reference's named_parameters), OIHW-shaped views of ONE flat buffer
+    on the device; .to() keeps the aliasing; writing through a Parameter is what the kernels read."""
+    import json
+    with open(os.path.join(REPO, "tests", "golden", "g1_keys.json")) as fp:
+        keys = json.load(fp)["chfak1"]
+    critic, masker = modules(g1)
+    for mod, name in ((critic, "critic"), (masker, "masker")):
+        assert [(k, list(q.shape)) for k, q in mod.named_parameters()] == [(k, v) for k, v in keys[name].items()]
+        flat = mod.flat
+        assert flat.is_cuda and not isinstance(flat, torch.nn.Parameter)
+        for (k, q), seg in zip(mod.named_parameters(), mod.layout.segs.values()):
+            assert q.is_cuda and q.data_ptr() == flat.data_ptr() + 4 * seg.offset and q.is_leaf and q.requires_grad
+        for k, v in g1[0 if name == "critic" else 1].items():
+            assert torch.equal(dict(mod.named_parameters())[k].detach().cpu(), v)
+    X = torch.rand(4, 3, 64, 64, device="cuda")
+    critic.eval()
+    p0 = critic(X)
+    with torch.no_grad():
+        critic.crit[4].bias += 1.0                    # the reference's attribute path (nets.py:190-194)
+    assert torch.allclose(critic(X), torch.sigmoid(torch.logit(p0) + 1.0), atol=1e-5)      # (crit.5 is a Sigmoid)
+    with torch.no_grad():
+        critic.features[0].weight.data = critic.features[0].weight.detach().clone() * 0.0      # storage replaced: re-aliased on use
+    pz = critic(X)
+    assert critic.features[0].weight.data_ptr() == critic.flat.data_ptr() and not torch.allclose(pz, torch.sigmoid(torch.logit(p0) + 1.0), atol=1e-5)
+    assert float(critic.flat[:216].abs().max()) == 0.0
+
+
+def test_freezing_one_key_freezes_exactly_that_layer(golden, g1):
+    """requires_grad_(False) on one Parameter: no .grad for it, torch.optim.Adam leaves it alone, every other layer's gradient is what
+    it was (the reference: any nn.Module parameter can be frozen by name, main.py:330-334 builds the optimiser from .parameters())."""
+    g = golden("g3_train_default.npz")
+    A, B = orc.u8_to_nchw(g["A"]).to("cuda"), orc.u8_to_nchw(g["B"]).to("cuda")
+    Y = torch.from_numpy(g["Y"]).to("cuda")
+
+    def grads(freeze):
+        critic, masker = modules(g1)
+        critic.train(); masker.train()
+        if freeze:
+            critic.features[6].weight.requires_grad_(False)
+            masker.dec_model[2].bias.requires_grad_(False)
+        opti = torch.optim.Adam([q for q in chain(critic.parameters(), masker.parameters()) if q.requires_grad])
+        pred, embeds = critic(A, collect=True)
+        Z = masker(A, embeds)
+        loss = 5 * F.mse_loss(pred.squeeze(), Y) + F.mse_loss(critic(A * (1 - Z) + Z * B).squeeze(), critic(B).squeeze().detach()) + \
+            0.5 * F.l1_loss(Z, torch.zeros_like(Z))
+        loss.backward()
+        out = {"c/" + k: (None if q.grad is None else q.grad.clone()) for k, q in critic.named_parameters()}
+        out.update({"m/" + k: (None if q.grad is None else q.grad.clone()) for k, q in masker.named_parameters()})
+        before = {"c/" + k: q.detach().clone() for k, q in critic.named_parameters()}
+        before.update({"m/" + k: q.detach().clone() for k, q in masker.named_parameters()})
+        opti.step()
+        after = {"c/" + k: q.detach().clone() for k, q in critic.named_parameters()}
+        after.update({"m/" + k: q.detach().clone() for k, q in masker.named_parameters()})
+        return out, before, after
+
+    full, _, _ = grads(False)
+    part, before, after = grads(True)
+    frozen = {"c/features.6.weight", "m/dec_model.2.bias"}
+    for k in full:
+        if k in frozen:
+            assert part[k] is None and torch.equal(before[k], after[k])
+        else:
+            assert torch.equal(part[k], full[k]), k          # the same kernels ran: bit-identical
+            assert not torch.equal(before[k], after[k]), k
 
 
 def test_layout_conversion_kernels():
@@ -425,7 +494,7 @@ def test_dp_launch_form_matches_single_gpu_step(tmp_path):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[:6000] + " ... " + r.stderr[-1500:]
     res = np.load(out, allow_pickle=True)[0]
     for live, runs in res.items():
         base = runs["single"]
@@ -444,6 +513,45 @@ def test_dp_launch_form_matches_single_gpu_step(tmp_path):
             for name in ("single", "dp_graph", "dp_eager"):
                 assert not runs[name]["m"][:nc].any() and not runs[name]["v"][:nc].any(), name
             np.testing.assert_array_equal(runs["dp_graph"]["flat"][:nc], base["flat"][:nc])
+
+
+def _check_dp_report(line, forms):
+    """Schema of the data-parallel self-validation block of a bench.py line (config.dp)."""
+    cfg = line["config"]
+    dp = cfg["dp"]
+    assert set(dp["forms_timed"]) == forms, dp["forms_timed"].keys()
+    for f, v in dp["forms_timed"].items():
+        assert v["ms_per_step"] > 0 and len(v["per_rank_ms_per_step"]) == line["n_gpus"] and v["replicas_bit_identical"] is True, (f, v)
+        assert np.isfinite(v["final_total_loss_rank0"])
+    assert dp["value_uses_form"] in forms and cfg["allreduce_in_step_graph"] is (dp["value_uses_form"] == "graph")
+    assert abs(line["ms_per_step"] - dp["forms_timed"][dp["value_uses_form"]]["ms_per_step"]) < 1e-9
+    assert line["ms_per_step"] == min(v["ms_per_step"] for v in dp["forms_timed"].values())
+    assert cfg["replicas_bit_identical"] is True and len(dp["replica_checksums_params_m_v_step"]) == line["n_gpus"]
+    assert len(set(dp["replica_checksums_params_m_v_step"])) == 1 and len(dp["replica_checksums_params_m_v_step"][0]) == 8 * 16
+    lat = dp["allreduce_latency_us"]
+    assert lat["bytes"] == 4 * 25661 and lat["reps"] == 200 and lat["eager_median"] > 0      # (11 873 + 3 pad + 13 785 floats: the flat bucket)
+    assert abs(line["value"] - 512 * line["n_gpus"] / (line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+
+
+def test_bench_world2_gloo_rehearsal_on_one_gpu():
+    """`bench.py --gpus 2 --backend gloo`: TWO ranks (started by bench.py's own child torchrun) share this box's GPU and reduce the gradient
+    bucket through the host -- every world > 1 branch of the script runs (per-rank timing gathered by a collective, max over ranks, the
+    replica checksums over two REAL replicas with different Dropout streams and different data, the all-reduce latency probe); gloo cannot
+    be recorded in a HIP graph, so only the eager form is timed and the line says why.  Numbers are meaningless (shared GPU); the schema
+    and the bit-identity of the two replicas are the point."""
+    plain = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    plain["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                        "--prime-s", "0.05", "--no-cpu-baseline"], capture_output=True, text=True, env=plain, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen_by_collective_backend"] == 2 and line["config"]["collective_backend"] == "gloo"
+    assert line["config"]["global_batch"] == 1024 and line["config"]["parallelism"] == "dp2" and len(line["config"]["per_rank_ms_per_step"]) == 2
+    _check_dp_report(line, {"eager"})
+    dp = line["config"]["dp"]
+    assert dp["collective_capturable"] is False and "gloo" in dp["collective_capturable_note"] and dp["allreduce_latency_us"]["graph_median"] is None
 
 
 def test_rccl_path_one_rank_rehearsal():
@@ -476,10 +584,23 @@ def test_rccl_path_one_rank_rehearsal():
                 "data", "config", "roofline"):
         assert key in line, key
     assert line["scaling"] == "weak" and line["dtype"] == "f32" and line["roofline"]["bound"] == "hbm"
-    assert line["config"]["allreduce_in_step_graph"] is True, line["config"]["gradient_allreduce"]
     assert "rccl" in line["config"] and line["config"]["rccl"]["version"], "bench.py --gpus N must report RCCL's view"
+    # round 6: the data-parallel run is self-validating -- BOTH launch forms timed (the collective trial succeeded on the RCCL group), the
+    # replicas' parameters / Adam moments / step counter compared through all-gathered checksums after each, `value` on the faster good one,
+    # and the bare latency of the gradient bucket's all-reduce reported in both forms
+    _check_dp_report(line, {"eager", "graph"})
+    dp = line["config"]["dp"]
+    assert dp["collective_capturable"] is True and dp["allreduce_latency_us"]["graph_median"] > 0
+    print("dp forms:", {f: round(v["ms_per_step"], 4) for f, v in dp["forms_timed"].items()}, "value uses", dp["value_uses_form"],
+          "| all-reduce of", dp["allreduce_latency_us"]["bytes"], "B: eager", round(dp["allreduce_latency_us"]["eager_median"], 1), "us, graph",
+          round(dp["allreduce_latency_us"]["graph_median"], 1), "us")
     eager = run(["--force-pg", "--dp-eager-allreduce", "--steps", "5", "--warmup", "2"], env)
     assert eager["config"]["allreduce_in_step_graph"] is False and np.isfinite(eager["final_losses"]["total"])
+    _check_dp_report(eager, {"eager"})
+    assert eager["config"]["dp"]["choice"] == "forced on the command line"
+    graph = run(["--force-pg", "--dp-graph-allreduce", "--steps", "5", "--warmup", "2"], env)
+    assert graph["config"]["allreduce_in_step_graph"] is True
+    _check_dp_report(graph, {"graph"})
     extra_ms = line["ms_per_step"] - base["ms_per_step"]
     print(f"three-launch form with a 1-rank RCCL all-reduce: {line['ms_per_step']:.3f} ms vs {base['ms_per_step']:.3f} ms single graph "
           f"(+{extra_ms * 1e3:.0f} us per step)")

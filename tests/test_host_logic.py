@@ -85,7 +85,37 @@ def test_modules_init_like_reference_and_state_dict_contract(golden, tmp_path):
         other = type(mod)()
         other.load_state_dict(torch.load(path, map_location="cpu"))
         np.testing.assert_array_equal(other.flat.detach().numpy(), mod.flat.detach().numpy())
-    assert len(list(c.parameters())) == 1 and c.flat.numel() == 11873
+    # row b: the reference's 14 keyed Parameters per module (nets.py:170-194, 479-492), views of ONE flat kernel-layout buffer
+    import copy
+    for mod, name in ((c, "critic"), (m, "masker")):
+        assert [(k, list(q.shape)) for k, q in mod.named_parameters()] == list(keys[name].items())
+        assert all(isinstance(q, torch.nn.Parameter) and q.is_leaf and q.requires_grad for q in mod.parameters())
+        assert "flat" not in dict(mod.named_parameters()) and "_flat" not in dict(mod.named_buffers())
+        assert sum(q.numel() for q in mod.parameters()) == mod.flat.numel()
+        base = mod.flat.data_ptr()
+        for q, seg in zip(mod.parameters(), mod.layout.segs.values()):
+            assert q.data_ptr() == base + 4 * seg.offset
+        for k, q in mod.named_parameters():
+            np.testing.assert_array_equal(q.detach().numpy(), g[f"{name}/{k}"])
+        # writes through a Parameter land in the flat buffer (kernel layout: HWIO), and vice versa
+        w = dict(mod.named_parameters())[next(iter(keys[name]))]
+        with torch.no_grad():
+            w[1, 2, 0, 1] = 7.5
+        seg = next(iter(mod.layout.segs.values()))
+        o, i, kh, kw = seg.ref_shape
+        assert float(mod.flat[seg.offset + ((0 * kw + 1) * i + 2) * o + 1]) == 7.5
+        # .to() moves the buffer as one tensor and keeps Parameter identity + aliasing; deepcopy / p.data = t are re-aliased on use
+        ids = [id(q) for q in mod.parameters()]
+        mod.to(torch.device("cpu")).float()
+        assert ids == [id(q) for q in mod.parameters()]
+        dup = copy.deepcopy(mod)
+        assert dup.flat.data_ptr() != mod.flat.data_ptr()
+        assert all(q.data_ptr() == dup.flat.data_ptr() + 4 * s.offset for q, s in zip(dup.parameters(), dup.layout.segs.values()))
+        np.testing.assert_array_equal(dup.flat.numpy(), mod.flat.numpy())
+        with pytest.raises(_lib.CgsError, match="fp32"):
+            copy.deepcopy(mod).half()
+    assert c.flat.numel() == 11873 and len(list(c.parameters())) == 14 and len(list(m.parameters())) == 14
+    assert [n for n, _ in c.named_children()] == ["features", "crit"] and [n for n, _ in m.named_children()] == ["dec_model", "masker"]
     assert c.training and not c.eval().training
 
 
@@ -218,6 +248,18 @@ assert parallel._agree_all(True, pg, torch.device("cpu")) is True
 assert parallel._agree_all(rank != 1, pg, torch.device("cpu")) is False
 assert parallel.resolve_dp_graph(None, world) is False and parallel.resolve_dp_graph(None, 1) is True     # eager at N > 1 until exercised
 assert parallel.resolve_dp_graph(True, world) is True and parallel.resolve_dp_graph(False, 1) is False
+# round 6: replicas are compared bit for bit through all-gathered 64-bit checksums (bench.py --gpus N: config.replicas_bit_identical)
+t = torch.arange(1000, dtype=torch.float32) * 0.37
+same, sums = parallel.replica_checksums([t, t.to(torch.int64)], pg, torch.device("cpu"))
+assert same is True and len(sums) == world and len(set(sums)) == 1 and len(sums[0]) == 4 * 16, (same, sums)
+u = t.clone()
+if rank == 1:
+    u[123] = torch.nextafter(u[123], torch.tensor(1e9))          # one ulp on one rank
+same, sums = parallel.replica_checksums([u], pg, torch.device("cpu"))
+assert same is False and sums[0] != sums[1]
+w = t.clone(); w[[3, 4]] = w[[4, 3]]                              # a reordering keeps the plain sum and moves the weighted one
+a, b = parallel.checksum64(t), parallel.checksum64(w)
+assert int(a[0]) == int(b[0]) and int(a[1]) != int(b[1])
 # every rank starts from rank 0's parameters
 p = torch.full((5,), float(rank)); parallel.broadcast_params_(p, pg); assert float(p.sum()) == 0.0
 g = flat_grads(parallel.shard_slice(n, rank, world))
