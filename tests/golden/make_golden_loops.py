@@ -87,6 +87,7 @@ class Recorders:
         self.m = refmain
         self.choice, self.rand, self.mse, self.l1, self.hist, self.iou, self.batches = [], [], [], [], [], [], []
         self._saved = []
+        self.before_mse = None       # optional observer called when F.mse_loss is entered (G12: the state before a phase-1 step)
 
     def install(self):
         m = self.m
@@ -105,6 +106,8 @@ class Recorders:
             return r
 
         def mse(a, b, *args, **kw):
+            if self.before_mse is not None:
+                self.before_mse()
             r = real_mse(a, b, *args, **kw)
             self.mse.append(float(r))
             return r
@@ -154,13 +157,48 @@ def g9(out_path):
         real_init(self, args)
         handlers.append(self)
 
+    # G12 (round 6): the reference's critic + Adam state BEFORE each phase-1 batch and the gradient each batch produced -- observers only
+    # (clones of tensors the run holds anyway), the run itself is untouched and g9_train_loop.npz regenerates byte-identically
+    p1 = {"on": False, "params": [], "m": [], "v": [], "step": [], "grads": []}
+    optis = []
+    real_adam = torch.optim.Adam
+
+    def adam_ctor(params, *a, **kw):
+        o = real_adam(params, *a, **kw)
+        optis.append(o)
+        return o
+
+    def flat_of(tensors):
+        return np.concatenate([t.detach().numpy().reshape(-1) for t in tensors]).astype(np.float32)
+
+    def before_p1_step():
+        if not p1["on"]:
+            return
+        H, opt = handlers[-1], optis[-1]
+        params = list(H.critic.parameters())
+        if p1["params"]:                 # .grad still holds the previous batch's gradient (opti.zero_grad() comes after this call)
+            p1["grads"].append(flat_of([p.grad for p in params]))
+        st = [opt.state.get(p, {}) for p in params]
+        p1["params"].append(flat_of(params))
+        p1["m"].append(flat_of([s["exp_avg"] if "exp_avg" in s else torch.zeros_like(p) for s, p in zip(st, params)]))
+        p1["v"].append(flat_of([s["exp_avg_sq"] if "exp_avg_sq" in s else torch.zeros_like(p) for s, p in zip(st, params)]))
+        steps = {int(s["step"]) for s in st if "step" in s} or {0}
+        assert len(steps) == 1
+        p1["step"].append(steps.pop())
+
     def critic_pipe(self, mode="train", test=0):
         self.critic.load_state_dict(pc)
         self.masker.load_state_dict(pm)
         self.train_loader = LoaderProxy(self.train_loader, rec.batches)
         np.random.seed(SEED_P1)
         torch.manual_seed(SEED_P1)
-        return real_cp(self, mode, test)
+        p1["on"] = True
+        try:
+            return real_cp(self, mode, test)
+        finally:
+            p1["on"] = False
+            if p1["params"] and len(p1["grads"]) < len(p1["params"]):
+                p1["grads"].append(flat_of([p.grad for p in self.critic.parameters()]))
 
     def segmentation_training(self):
         np.random.seed(SEED_P2)
@@ -209,9 +247,16 @@ def g9(out_path):
         # pass 2: the full command line
         rec = Recorders(refmain)
         handlers.clear()
+        for k in ("params", "m", "v", "step", "grads"):
+            p1[k].clear()
+        rec.before_mse = before_p1_step
         rec.install()
+        torch.optim.Adam = adam_ctor
         argv = base + ["--high-rew-thresh", repr(hi_thr), "--low-rew-thresh", repr(lo_thr)]
-        run_main(argv)
+        try:
+            run_main(argv)
+        finally:
+            torch.optim.Adam = real_adam
         rec.remove()
         H = handlers[-1]
         nb1 = len(rec.batches)
@@ -242,6 +287,16 @@ def g9(out_path):
         for k, v in H.critic.state_dict().items():
             out["critic_final/" + k] = v.detach().numpy()
         np.savez_compressed(out_path, **out)
+        # ---- G12: one row per phase-1 batch, tensors concatenated in named_parameters() order (= g1_keys.json's), reference (OIHW) layout
+        assert len(p1["params"]) == len(p1["grads"]) == nb1 and p1["step"] == list(range(nb1)), (len(p1["params"]), len(p1["grads"]), p1["step"])
+        keys = [k for k, _ in H.critic.named_parameters()]
+        last = flat_of([ck_c[k] for k in keys])          # the state after the last batch = the phase-1 checkpoint
+        np.savez_compressed(os.path.join(os.path.dirname(out_path), "g12_phase1_steps.npz"),
+                            keys_json=np.array(json.dumps(keys)), shapes_json=np.array(json.dumps([list(ck_c[k].shape) for k in keys])),
+                            params_before=np.stack(p1["params"]), adam_m_before=np.stack(p1["m"]), adam_v_before=np.stack(p1["v"]),
+                            adam_step_before=np.array(p1["step"]), grads=np.stack(p1["grads"]), params_after_last=last,
+                            loss=np.array(rec.mse[:nb1]))
+        print(f"wrote g12_phase1_steps.npz: {nb1} pre-step states of {len(last)} floats")
         print(f"wrote {os.path.basename(out_path)}: {nb1} phase-1 batches, {nsteps2} phase-2 steps, split {len(H.Xpos)} / {len(H.Xneg)}, side file {side}")
     finally:
         rec.remove()

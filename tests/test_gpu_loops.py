@@ -18,6 +18,7 @@ import pytest
 import torch
 
 import cgs_amd  # noqa: F401
+from oracle import hourglass_ref as orc      # checker only
 
 pytestmark = pytest.mark.gpu
 
@@ -100,11 +101,11 @@ def test_g9_main_train_reproduces_the_reference_run(tmp_path, monkeypatch):
     ec = max(float((ck_c[k] - torch.from_numpy(g["critic_after_p1/" + k])).abs().max()) for k in ck_c)
     print(f"G9 run A: phase-1 loss rel err: first 8 steps {e1[:8].max():.1e}, first 24 {e1[:24].max():.1e}, all 48 {e1.max():.1e}; critic after "
           f"phase 1 max abs {ec:.1e}; split {len(H.Xpos)} / {len(H.Xneg)} (reference {int(g['npos'])} / {int(g['nneg'])})")
-    # Phase 1 trains a fresh critic: Adam's normalised step turns an fp32 summation-order difference on a near-zero gradient element into a
-    # full-size update, and the trajectories drift apart by ~1.3x per step -- reproduced on the CPU alone by adding noise of 3e-7 of each
-    # gradient tensor's maximum to the oracle's replay (test_g9_phase1_trajectory_is_sensitive_to_gradient_rounding: loss 4e-2, parameters
-    # 2e-2 at step 48).  Hence tight bounds where the trajectories are still together and loose ones at the end.  Measured on MI355X:
-    # 1.2e-7 / 7.6e-5 / 8.4e-3, parameters 1.7e-2.  (Phase 2 below starts from a trained critic and stays together: 3e-5.)
+    # SMOKE bounds only -- phase 1's parity statement is test_g12_phase1_single_steps_from_the_reference_states below (each of the 48
+    # steps from the reference's own pre-step state, tight bounds).  A fresh critic's TRAJECTORY is chaotic: Adam's normalised step turns an
+    # fp32 summation-order difference on a near-zero gradient element into a full-size update and the runs drift apart by ~1.3x per step
+    # (reproduced on the CPU alone: test_g9_phase1_trajectory_is_sensitive_to_gradient_rounding).  Measured on MI355X: 1.2e-7 / 7.6e-5 /
+    # 8.4e-3, parameters 1.7e-2; the loose end bounds only catch a run that went somewhere else entirely.
     assert e1[:8].max() <= 1e-5 and e1[:24].max() <= 1e-3 and e1.max() <= 5e-2
     assert ec <= 6e-2
     assert sorted(os.listdir("m/saves")) == json.loads(str(g["listing_json"]))["saves"]                  # both checkpoint names
@@ -227,3 +228,71 @@ def test_g11_collect_data_under_a_stub_minerl_writes_the_reference_pickle(tmp_pa
         X2, Y2, I2 = H.collect_data()
         np.testing.assert_array_equal(Y2, Yp)
         os.remove(H.data_path + files[0])
+
+
+def test_g12_phase1_single_steps_from_the_reference_states():
+    """Phase 1 pinned STEP BY STEP (replaces the loose end-of-trajectory bound of run A as the parity statement for
+    row a9 at the loop level): for EACH of the 48 batches of the reference's `main.py -train` run (G9) the engine is put into the
+    reference's recorded state before that batch -- critic parameters, Adam moments, step count (G12) -- runs ONE phase1_step on the recorded
+    frames (DataLoader indices + shift draws of G9) and is compared with what the reference computed: the loss, all 14 gradients, and the
+    parameters after the step (= the recorded state before the next batch), at the G4 tolerances."""
+    from cgs_amd import engine
+    from test_gpu_kernels import rel_close
+    from test_loops_golden import g12_states, roll_from_draws
+    g9 = load("g9_train_loop.npz")
+    g, keys, unflat = g12_states()
+    X, Y, _I = li.synthetic_frames(li.DATASIZE + li.TESTSIZE, int(g9["data_seed"]))
+    dev = torch.device("cuda:0")
+    nb = len(g9["p1_batch_len"])
+    assert len(set(g9["p1_batch_len"].tolist())) == 1
+    n = int(g9["p1_batch_len"][0])
+    e = engine.HourglassEngine(n, device=dev, dropout=0.0)
+    nc = e.lc.total
+    pos, worst_loss, noise, viol = 0, 0.0, {}, []
+    NOISE_X = 8.0
+    for b in range(nb):
+        idx = g9["p1_batch_idx"][pos:pos + n]
+        pos += n
+        xb = torch.roll(torch.from_numpy(X[idx]), roll_from_draws(*g9["p1_shift_draws"][b]), dims=2).contiguous()
+        e.load_state(critic_sd=unflat(g["params_before"][b]))
+        e.lc.flatten({k: v.to(dev) for k, v in unflat(g["adam_m_before"][b]).items()}, e.m[:nc])
+        e.lc.flatten({k: v.to(dev) for k, v in unflat(g["adam_v_before"][b]).items()}, e.v[:nc])
+        e.step_t.fill_(int(g["adam_step_before"][b]))
+        loss = e.phase1_step(xb.to(dev), torch.from_numpy(Y[1, idx]).float().to(dev))
+        torch.cuda.synchronize()
+        assert int(e.step_t.item()) == b + 1
+        rl = abs(float(loss[0]) - float(g["loss"][b])) / abs(float(g["loss"][b]))
+        worst_loss = max(worst_loss, rl)
+        assert rl <= 1e-4, (b, float(loss[0]), float(g["loss"][b]))
+        got_g, want_g = e.lc.unflatten(e.gc), unflat(g["grads"][b])
+        got_p, want_p = e.critic_state(), unflat(g["params_before"][b + 1] if b + 1 < nb else g["params_after_last"])
+        # Late in the run some gradients are small sums of large cancelling terms (features.0.weight at batch 1: |g| <= 9e-5 from 262 144
+        # products per element): there fp32 summation ORDER moves the result by more than 1e-3 of it -- for the reference's own CPU kernels
+        # too.  The float64 oracle on the same state says how far the REFERENCE's fp32 gradient is from the exact one (ref_noise, per tensor);
+        # the tolerance is the G4 one plus a small multiple of that, so it collapses to the G4 tolerance wherever the reference is accurate.
+        P64 = {k: v.double().requires_grad_(True) for k, v in unflat(g["params_before"][b]).items()}
+        l64, _ = orc.phase1_loss(P64, orc.u8_to_nchw(xb.numpy()).double(), torch.from_numpy(Y[1, idx]).double())
+        l64.backward()
+        for k in keys:
+            g64 = P64[k].grad.numpy()
+            ref_noise = float(np.abs(want_g[k].numpy().astype(np.float64) - g64).max())
+            gpu_noise = float(np.abs(got_g[k].cpu().numpy().astype(np.float64) - g64).max())
+            noise[k] = max(noise.get(k, (0, 0, 0)), (gpu_noise / max(ref_noise, 1e-30), gpu_noise, ref_noise))
+            err = np.abs(got_g[k].cpu().numpy().astype(np.float64) - want_g[k].numpy())
+            tol = 1e-3 * np.abs(want_g[k].numpy()) + 2e-5 * float(want_g[k].abs().max()) + NOISE_X * ref_noise
+            if not (err <= tol).all():
+                viol.append((b, k, float(err.max() / want_g[k].abs().max()), int((err > tol).sum()), err.size, ref_noise, gpu_noise))
+                continue
+            rel_close(got_p[k].cpu().numpy(), want_p[k].numpy(), f"G12 batch {b} {k} after the step", atol_scale=1e-4)
+    # Measured on MI355X: 669 of the 672 (batch, tensor) pairs inside that tolerance; batch 25 has ONE routing difference in one image --
+    # features.6.bias off in 1 of 8 channels (8e-4 of the tensor's maximum), features.6.weight in 10 of that channel's 72 elements (2.7e-4),
+    # features.10.weight in one element (7e-5): a pre-activation / pooling candidate within fp32 rounding of its decision point falls on the
+    # other side than on the CPU (the float64 oracle sides with the reference).  Such events are admitted explicitly: at most 4 pairs, each
+    # within 1e-3 of its tensor's maximum, every one printed.
+    for v in viol:
+        print("G12 outside the elementwise tolerance: batch %d %s err/max %.2e in %d/%d elements (reference's distance from float64 %.2e, GPU's %.2e)" % v)
+    assert len(viol) <= 4 and all(v[2] <= 1e-3 for v in viol), viol
+    print("G12: worst (GPU distance from the float64 gradient) / (the reference's own), per tensor over the 48 steps:")
+    for k, (ratio, gn, rn) in noise.items():
+        print(f"   {k:22s} ratio {ratio:6.2f}  (GPU {gn:.2e}, reference {rn:.2e})")
+    print(f"G12: 48 single phase-1 steps from the reference's states: worst loss rel err {worst_loss:.1e}")

@@ -158,6 +158,62 @@ def test_g9_oracle_replays_the_reference_training_loops():
         np.testing.assert_allclose(v.detach().numpy(), g["critic_final/" + k], rtol=0, atol=5e-5, err_msg=k)          # measured 6e-6
 
 
+def g12_states():
+    """G12 (round 6): per phase-1 batch of G9's run the reference's critic parameters, Adam moments and step count BEFORE the step and the
+    gradient the step produced -- rows of concatenated tensors in named_parameters() order, reference (OIHW) layout."""
+    import json
+    g = load("g12_phase1_steps.npz")
+    keys, shapes = json.loads(str(g["keys_json"])), json.loads(str(g["shapes_json"]))
+
+    def unflat(row):
+        out, pos = {}, 0
+        for k, shp in zip(keys, shapes):
+            cnt = int(np.prod(shp))
+            out[k] = torch.from_numpy(row[pos:pos + cnt].reshape(shp).copy())
+            pos += cnt
+        assert pos == len(row)
+        return out
+    return g, keys, unflat
+
+
+def test_g12_oracle_single_steps_from_the_reference_states():
+    """Phase 1 pinned STEP BY STEP: for each of the 48 batches of G9's run the oracle starts from the reference's
+    recorded critic + Adam state, takes ONE step on the recorded batch, and reproduces the reference's loss, its gradient and its next
+    state -- tight bounds on all 48 steps, because no trajectory accumulates (compare test_g9_phase1_trajectory_is_sensitive...)."""
+    g9 = load("g9_train_loop.npz")
+    g, keys, unflat = g12_states()
+    import json
+    assert keys == list(json.load(open(os.path.join(HERE, "golden", "g1_keys.json")))["chfak1"]["critic"])
+    X, Y, _I = li.synthetic_frames(li.DATASIZE + li.TESTSIZE, int(g9["data_seed"]))
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    nb = len(g9["p1_batch_len"])
+    assert g["params_before"].shape == (nb, 11873) and g["adam_step_before"].tolist() == list(range(nb))
+    np.testing.assert_array_equal(g["loss"], g9["p1_loss"])
+    np.testing.assert_array_equal(g["params_after_last"], np.concatenate([g9["critic_after_p1/" + k].reshape(-1) for k in keys]))
+    assert not g["adam_m_before"][0].any() and not g["adam_v_before"][0].any()
+    pos, worst = 0, [0.0, 0.0, 0.0]
+    for b in range(nb):
+        n = int(g9["p1_batch_len"][b])
+        idx = g9["p1_batch_idx"][pos:pos + n]
+        pos += n
+        xb = torch.roll(torch.from_numpy(X[idx]), roll_from_draws(*g9["p1_shift_draws"][b]), dims=2)
+        Pc = orc.leafify(unflat(g["params_before"][b]))
+        opt = orc.AdamRef(list(Pc.values()))
+        opt.m, opt.v, opt.t = list(unflat(g["adam_m_before"][b]).values()), list(unflat(g["adam_v_before"][b]).values()), int(g["adam_step_before"][b])
+        loss, _ = orc.phase1_loss(Pc, orc.u8_to_nchw(xb.numpy()), torch.from_numpy(Y[1, idx]).float())
+        loss.backward()
+        grads = [t.grad for t in Pc.values()]
+        opt.step(grads)
+        want_g = unflat(g["grads"][b])
+        want_p = unflat(g["params_before"][b + 1] if b + 1 < nb else g["params_after_last"])
+        worst[0] = max(worst[0], abs(float(loss.detach()) - g["loss"][b]) / abs(g["loss"][b]))
+        for k, gr in zip(keys, grads):
+            worst[1] = max(worst[1], float((gr - want_g[k]).abs().max() / want_g[k].abs().max()))
+            worst[2] = max(worst[2], float((Pc[k].detach() - want_p[k]).abs().max()))
+    print(f"G12 oracle single steps: loss rel {worst[0]:.1e}, gradient (of each tensor's max) {worst[1]:.1e}, next parameters abs {worst[2]:.1e}")
+    assert worst[0] <= 5e-6 and worst[1] <= 1e-4 and worst[2] <= 5e-6      # measured 0 / 1.1e-5 (thread count != the reference's 1) / 1e-7
+
+
 def test_g9_phase1_trajectory_is_sensitive_to_gradient_rounding():
     """Why tests/test_gpu_loops.py bounds the END of the GPU's phase-1 trajectory loosely (loss 5e-2, parameters 6e-2) while its first steps
     agree to 1e-7: the oracle itself, replaying the reference's 48 recorded batches twice -- once as is, once with every gradient tensor
