@@ -36,16 +36,29 @@ struct MHeadParams {
     float* slab2;          // WG: masker.2 weight-gradient partials, one [145] slab per workgroup
     float* slab0;          // W0: masker.0 weight-gradient partials, one [1600] slab per workgroup
     int n, ntiles;
+    unsigned long long* dbg;   // debug build only (tools/mh_stamps.py): per workgroup, cycles summed over its tiles [builder: p1, wait1, p2, wait2 | matrix: p1, wait1, dgrad, wgrad, wait2]
 };
 
-#ifndef MH_IMG4
-#define MH_IMG4 0      // (r05 A/B: ~100 fewer vector instructions per tile on the matrix waves, step +1 us -- like MH_CVT32; only the builder waves' count is on the tile's path)
+#ifdef CGS_DEBUG_STAMPS
+#define MH_T() __builtin_amdgcn_s_memtime()
+static unsigned long long* g_mh_stamps = nullptr;
+extern "C" int dbg_mask_head_stamps(unsigned long long* stamps) { g_mh_stamps = stamps; return CGS_OK; }
+#else
+#define MH_T() 0ull
 #endif
-#ifndef MH_CVT32
-#define MH_CVT32 0
-#endif
+
+// (round 5's MH_IMG4 / MH_CVT32 staging variants of the matrix waves -- each measured +1 us -- went out with round 6's move of the staging to the builder waves)
 #ifndef MH_WACC_PK
 #define MH_WACC_PK 1
+#endif
+#ifndef MH_APK
+#define MH_APK 1       // (round 6) builder: dH's four channel sums as v_pk_fma_f32 pairs
+#endif
+#ifndef MH_INTERLEAVE
+#define MH_INTERLEAVE 1
+#endif
+#ifndef MH_DZWIN
+#define MH_DZWIN 1     // (round 6) builder: rolling 3x3 dzpre window in registers (36 instead of 100 LDS reads per tile and thread)
 #endif
 template <int TH, bool W0>
 struct MHeadGeo {
@@ -66,12 +79,13 @@ struct MHeadLds { float *xt0, *ximg, *xo, *w4p, *dz; };
 // ---------------------------------------------------------------------------------------------------------------
 // Builder waves (threads 0..255).  Per tile: [phase 1] dzpre tile -> LDS | barrier | [phase 2] rebuild dH | barrier
 // ---------------------------------------------------------------------------------------------------------------
-template <int TH, bool WG, bool W0>
+template <int TH, bool WG, bool W0, int SRC>
 __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MHeadLds& L, const int btid, const int T,
                                                   const int bid, const int grid) {
     using G = MHeadGeo<TH, W0>;
-    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, DZW = G::DZW;
+    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, DZW = G::DZW, LR = G::LR, LC = G::LC;
     constexpr int IT = TRA * W * 4 / 256, DIT = (G::DZ + 255) / 256;
+    constexpr int NPIX = TRA * PW, NLO = LR * LC * 2, ITA = (NPIX + 255) / 256, ITB = (NLO + 255) / 256;
     static_assert((TRA * W * 4) % 256 == 0, "whole iterations: no element is visited twice");
     const int lane = btid & 63, wave = btid >> 6;
     const int pl = btid & 3;           // the 4-channel plane of dH this thread builds
@@ -80,10 +94,16 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
     auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };   // clamped: prefetches past the end re-read
 
     float w2r[9][4];
+#if MH_APK
+    typedef float mh_f2 __attribute__((ext_vector_type(2)));
+    mh_f2 w2p[9][2];
+#endif
     // masker.2 weight-gradient partials of this thread (plane pl).  MH_WACC_PK: held as register PAIRS and pinned as pairs, so that their FMAs are
     // v_pk_fma_f32 (the per-scalar pins below left them as 288 v_fmac_f32 per tile; round 5)
 #if MH_WACC_PK
+#if !MH_APK
     typedef float mh_f2 __attribute__((ext_vector_type(2)));
+#endif
     mh_f2 wacc[9][2];
 #else
     float wacc[9][4];
@@ -96,6 +116,9 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             w2r[t][c] = P.w2[t * 16 + 4 * pl + c];
+#if MH_APK
+            w2p[t][c >> 1][c & 1] = w2r[t][c];
+#endif
 #if MH_WACC_PK
             wacc[t][c >> 1][c & 1] = 0.f;
 #else
@@ -105,7 +128,7 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 
     // loads = address arithmetic + the load only; masking happens where the value is consumed (a select here would
     // wait for the load)
-    auto load_h = [&](int tile) {
+    auto load_h_into = [&](float4 (&dst)[IT], int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
@@ -113,9 +136,10 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             // address (bx4) the same for every item -- written so, the selects and the per-item index arithmetic are scalar (round 5)
             const int y = row0 + it - 1;
             const bool in = y >= 0 && y < H;
-            hvs[it] = ((const float4*)P.h)[(in ? (n0 * H + y) * W * 4 : 0) + bx4];
+            dst[it] = ((const float4*)P.h)[(in ? (n0 * H + y) * W * 4 : 0) + bx4];
         }
     };
+    auto load_h = [&](int tile) { load_h_into(hvs, tile); };
     auto load_dz = [&](int tile) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
 #pragma unroll
@@ -138,18 +162,101 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             L.dz[e] = in ? dzr[it] : 0.f;
         }
     };
+
+    // (round 6) masker.0's INPUT tiles (image [r,g,b,0] and o0 at its own resolution) for the matrix waves' weight-gradient GEMM are staged by
+    // the builder waves: by the stamps (tools/mh_stamps.py) the matrix waves are the tile's critical path (11.8 k cycles of a 12.7 k tile, 7.2 k
+    // of them matrix instructions) and the fetch + commit of these tiles were 2 k of it, while the builder waves wait a third of their phase
+    // for memory.  fetch = address arithmetic + loads only (raw dwords); decoding and zero padding happen in commit, one phase later.
+    [[maybe_unused]] float4 ra[W0 ? ITA : 1], rb[W0 ? ITB : 1];
+    auto fetch_x = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = btid + it * 256; e = e < NPIX ? e : NPIX - 1;
+            int y = row0 + e / PW - 1, x = e % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            int pix = in ? (n0 * H + y) * W + x : 0;
+            if constexpr (SRC == WSRC_U8) {
+                const uint32_t* s32 = (const uint32_t*)P.img;
+                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
+                ra[it].x = __uint_as_float(s32[d]);
+                ra[it].y = __uint_as_float(s32[d + 1 <= last ? d + 1 : last]);
+            } else {
+                const float* sf = (const float*)P.img;
+                ra[it] = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            int e = btid + it * 256; e = e < NLO ? e : NLO - 1;
+            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 1, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            rb[it] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
+        }
+    };
+    auto commit_x = [&](int tile) {
+        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+#pragma unroll
+        for (int it = 0; it < ITA; ++it) {
+            int e = btid + it * 256; e = e < NPIX ? e : NPIX - 1;
+            int y = row0 + e / PW - 1, x = e % PW - 1;
+            bool in = y >= 0 && y < H && x >= 0 && x < W;
+            float4 v = ra[it];
+            if constexpr (SRC == WSRC_U8) {
+                int pix = in ? (n0 * H + y) * W + x : 0;
+                const uint32_t lo = __float_as_uint(v.x), hi = __float_as_uint(v.y);
+                const uint32_t b3 = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)((pix * 3) & 3));      // the pixel's 3 bytes start at byte (3 pix) & 3 of the dword pair
+                const float sc = 1.f / 255.f;
+                v = make_float4((float)(b3 & 255u) * sc, (float)((b3 >> 8) & 255u) * sc, (float)((b3 >> 16) & 255u) * sc, 0.f);
+            }
+            v.w = 0.f;
+            ((float4*)L.ximg)[e] = in ? v : f4zero();
+        }
+#pragma unroll
+        for (int it = 0; it < ITB; ++it) {
+            int e = btid + it * 256; e = e < NLO ? e : NLO - 1;
+            int pc = (e >> 1) % LC, pr = (e >> 1) / LC;
+            int ly = row0 / 2 + pr - 1, lx = pc - 1;
+            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
+            ((float4*)L.xo)[e] = in ? rb[it] : f4zero();       // [pr][pc][8]: e = (pr*LC + pc)*2 + half
+        }
+    };
     load_dz(tile_of(0));
     load_h(tile_of(0));
 
+    [[maybe_unused]] unsigned long long tp = MH_T(), s_p1 = 0, s_w1 = 0, s_p2 = 0, s_w2 = 0;
     for (int i = 0; i <= T; ++i) {
         store_dz(tile_of(i));
+        if constexpr (W0) {
+            if (i > 0) commit_x(tile_of(i - 1));           // read by the matrix waves' weight-gradient GEMM of tile i-1 in this iteration's phase 2
+        }
+        [[maybe_unused]] const unsigned long long ta = MH_T();
         __syncthreads();                                   // barrier 1 of tile i
+        [[maybe_unused]] const unsigned long long tb = MH_T();
         if (i < T) {
             const int tile = tile_of(i);
             const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
             float* xt = L.xt0 + (i & 1) * G::XT;
             const float* dz = L.dz;
             load_dz(tile_of(i + 1));      // in flight during the rebuild
+            if constexpr (W0) fetch_x(tile);               // committed in the next phase 1
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef MH_WHATIF_NOBUILD
+            if (P.n < 0)
+#endif
+            {
+#if MH_DZWIN
+            // (round 6) the 3x3 dzpre window of item `it` is rows it .. it+2, columns x+1 .. x+3 of the dz tile: consecutive items share two of the
+            // three rows.  All 12 x 3 values of the tile are read up front (36 LDS reads instead of 100, ONE latency instead of one per item; the
+            // compiler cannot do this itself: the dH stores between the items may alias dz).
+            float dzw[IT + 2][3];
+#pragma unroll
+            for (int rr = 0; rr < IT + 2; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) dzw[rr][cc] = dz[rr * DZW + bx + 1 + cc];
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 const int r = it;
@@ -159,14 +266,31 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
                 const float4 hv = hvs[it];
                 const bool own = it >= 1 && it <= TH;       // rows owned by this strip (halo rows: the neighbours')
                 const float4 hw_ = own ? hv : f4zero();
+#if MH_APK
+                // (round 6) the four channel sums as two register pairs: v_pk_fma_f32 (same fused arithmetic per component: same bits)
+                mh_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#else
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#endif
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
+#if MH_DZWIN
+                        float d = dzw[r + 2 - ky][2 - kx];
+#else
                         float d = dz[(r + 2 - ky) * DZW + x + 3 - kx];
+#endif
+#if MH_APK
+                        {
+                            const mh_f2 dd = {d, d};
+                            a01 = __builtin_elementwise_fma(dd, w2p[ky * 3 + kx][0], a01);
+                            a23 = __builtin_elementwise_fma(dd, w2p[ky * 3 + kx][1], a23);
+                        }
+#else
                         a0 = fmaf(d, w2r[ky * 3 + kx][0], a0); a1 = fmaf(d, w2r[ky * 3 + kx][1], a1);
                         a2 = fmaf(d, w2r[ky * 3 + kx][2], a2); a3 = fmaf(d, w2r[ky * 3 + kx][3], a3);
+#endif
                         if (WG && it != 0 && it != IT - 1) {     // items 0 and IT-1 are the halo rows: never owned
 #if MH_WACC_PK
                             const mh_f2 dd = {d, d};
@@ -180,9 +304,16 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 #endif
                         }
                     }
+#if MH_APK
+                const float a0 = a01[0], a1 = a01[1], a2 = a23[0], a3 = a23[1];
+#endif
                 static_assert(IT == TH + 2, "one item per tile row: item index == row index");
                 if (WG && it != 0 && it != IT - 1) {
+#if MH_DZWIN
+                    bacc += (own && pl == 0) ? dzw[r + 1][1] : 0.f;
+#else
                     bacc += (own && pl == 0) ? dz[(r + 1) * DZW + x + 2] : 0.f;
+#endif
                     // pin the accumulators here: otherwise their FMAs are sunk past the whole item loop and every dz / h
                     // value of all items stays live (hundreds of registers)
 #pragma unroll
@@ -202,9 +333,17 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
                 if (own && P.dh) ((float4*)P.dh)[gi] = v;
                 __builtin_amdgcn_sched_barrier(0);
             }
-            load_h(tile_of(i + 1));       // in flight until the next rebuild
+            }
+            load_h(tile_of(i + 1));       // in flight until the next rebuild (requested at the START of this rebuild into a second register set, it
+                                          // measured no faster: the rebuild does not wait for memory)
         }
+        [[maybe_unused]] const unsigned long long tc = MH_T();
         __syncthreads();                                   // barrier 2 of tile i
+        if (CGS_STAMP_PTR(P.dbg)) { const unsigned long long td = MH_T(); s_p1 += ta - tp; s_w1 += tb - ta; s_p2 += tc - tb; s_w2 += td - tc; tp = td; }
+    }
+    if (CGS_STAMP_PTR(P.dbg) && btid == 0) {
+        unsigned long long* o = CGS_STAMP_PTR(P.dbg) + (size_t)bid * 16;
+        o[0] = s_p1; o[1] = s_w1; o[2] = s_p2; o[3] = s_w2; o[4] = (unsigned long long)T;
     }
 
     if constexpr (WG) {
@@ -230,28 +369,20 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Matrix waves (threads 256..511; mtid = 0..255).  Per tile i: [phase 1] masker.0 input of tile i-1 -> LDS | barrier |
-// [phase 2] prefetch the input of tile i, data-gradient and weight-gradient GEMMs of tile i-1 | barrier
+// Matrix waves (threads 256..511; mtid = 0..255).  Per tile i: [phase 1] nothing (round 6: the builder waves stage masker.0's inputs) | barrier |
+// [phase 2] data-gradient and weight-gradient GEMMs of tile i-1 | barrier
 // ---------------------------------------------------------------------------------------------------------------
 template <int TH, bool W0, int SRC>
 __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHeadLds& L, const int mtid, const int T,
                                                  const int bid, const int grid) {
     using G = MHeadGeo<TH, W0>;
-    constexpr int H = G::H, W = G::W, TRA = G::TRA, PW = G::PW, PS = G::PS, LR = G::LR, LC = G::LC;
-    constexpr int NPIX = TRA * PW, NLO = LR * LC * 2, ITA = (NPIX + 255) / 256, ITB = (NLO + 255) / 256;
+    constexpr int PW = G::PW, PS = G::PS, LC = G::LC;
     static_assert(TH == 8, "4 matrix waves: one low-res row (data gradient) and one even + one odd row (weight gradient) each");
     const int lane = mtid & 63, mwave = mtid >> 6;
     const int l15 = lane & 15, kq = lane >> 4;
     auto tile_of = [&](int i) { return bid + (i < T ? i : T - 1) * grid; };
     // weight gradient accumulators: image rows + bias (2 row blocks), folded o0 rows per parity (py, px) (2 row blocks each)
     frag4 accA[2], accB[2][2][2];
-    float4 ra[W0 ? ITA : 1], rb[W0 ? ITB : 1];
-    // MH_IMG4 (uint8 frames): a thread stages FOUR pixels = three dwords of one tile row (a row is 48 dwords: groups never straddle rows) -- 160
-    // threads, one item, no per-pixel 64-bit shifts (round 5; the tile's halo columns are the conv's zero padding for every tile: zeroed once)
-    constexpr bool IMG4 = MH_IMG4 && SRC == WSRC_U8 && W0;
-    [[maybe_unused]] uint32_t ru[3] = {0u, 0u, 0u};
-    static_assert(TRA * 16 <= 256, "one item of four-pixel groups");
-    [[maybe_unused]] const int rr4 = mtid >> 4, g4 = mtid & 15;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         accA[q] = frag4{0.f, 0.f, 0.f, 0.f};
@@ -267,99 +398,12 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     }
     const float m1 = (16 + l15 < 27) ? 1.f : 0.f, m0 = (16 + l15 == 27) ? 1.f : 0.f;   // second row block: valid / bias / pad
 
-    // fetch = address arithmetic + loads only (raw dwords); decoding and zero padding happen in commit, one phase
-    // later: anything that touches the loaded value here would stall the wave on global memory
-    auto fetch_x = [&](int tile) {
-        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-        if constexpr (IMG4) {
-            const int y = row0 + rr4 - 1;
-            const bool in = mtid < TRA * 16 && y >= 0 && y < H;
-            const uint32_t* s32 = (const uint32_t*)P.img + ((size_t)(n0 * H + (in ? y : 0)) * (W * 3 / 4) + 3 * g4);
-            ru[0] = s32[0]; ru[1] = s32[1]; ru[2] = s32[2];
-        } else
-#pragma unroll
-        for (int it = 0; it < ITA; ++it) {
-            int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
-            int y = row0 + e / PW - 1, x = e % PW - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            int pix = in ? (n0 * H + y) * W + x : 0;
-            if constexpr (SRC == WSRC_U8) {
-                const uint32_t* s32 = (const uint32_t*)P.img;
-                int off = pix * 3, last = P.n * H * W * 3 / 4 - 1, d = off >> 2;
-                ra[it].x = __uint_as_float(s32[d]);
-                ra[it].y = __uint_as_float(s32[d + 1 <= last ? d + 1 : last]);
-            } else {
-                const float* sf = (const float*)P.img;
-                ra[it] = make_float4(sf[pix * 3], sf[pix * 3 + 1], sf[pix * 3 + 2], 0.f);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ITB; ++it) {
-            int e = mtid + it * 256; e = e < NLO ? e : NLO - 1;
-            int half = e & 1, pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-            int ly = row0 / 2 + pr - 1, lx = pc - 1;
-            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            rb[it] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
-        }
-    };
-    auto commit_x = [&](int tile) {
-        const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
-        if constexpr (IMG4) {
-            if (mtid < TRA * 16) {
-                const int y = row0 + rr4 - 1;
-                const bool in = y >= 0 && y < H;
-                const uint32_t d0 = in ? ru[0] : 0u, d1 = in ? ru[1] : 0u, d2 = in ? ru[2] : 0u;      // rows outside the image: 0 * (1/255) = 0
-                const float sc = 1.f / 255.f;
-                float4* d = (float4*)L.ximg + rr4 * PW + 1 + 4 * g4;
-                d[0] = make_float4((d0 & 255u) * sc, ((d0 >> 8) & 255u) * sc, ((d0 >> 16) & 255u) * sc, 0.f);
-                d[1] = make_float4((d0 >> 24) * sc, (d1 & 255u) * sc, ((d1 >> 8) & 255u) * sc, 0.f);
-                d[2] = make_float4(((d1 >> 16) & 255u) * sc, (d1 >> 24) * sc, (d2 & 255u) * sc, 0.f);
-                d[3] = make_float4(((d2 >> 8) & 255u) * sc, ((d2 >> 16) & 255u) * sc, (d2 >> 24) * sc, 0.f);
-            }
-        } else
-#pragma unroll
-        for (int it = 0; it < ITA; ++it) {
-            int e = mtid + it * 256; e = e < NPIX ? e : NPIX - 1;
-            int y = row0 + e / PW - 1, x = e % PW - 1;
-            bool in = y >= 0 && y < H && x >= 0 && x < W;
-            float4 v = ra[it];
-            if constexpr (SRC == WSRC_U8) {
-                int pix = in ? (n0 * H + y) * W + x : 0;
-                uint64_t both = (((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x)) >> (((pix * 3) & 3) * 8);
-                const float sc = 1.f / 255.f;
-                // (kept on the 64-bit value: with 32-bit conversions -- v_cvt_f32_ubyteN, ~30 instructions fewer per pixel -- the kernel measured
-                //  0.9 us SLOWER, r05 A/B; the matrix waves' phase 1 runs under the builder waves' arithmetic, its length is not on the tile's path)
-#if MH_CVT32
-                const uint32_t b3 = (uint32_t)both;
-                v = make_float4((b3 & 255u) * sc, ((b3 >> 8) & 255u) * sc, ((b3 >> 16) & 255u) * sc, 0.f);
-#else
-                v = make_float4((both & 255) * sc, ((both >> 8) & 255) * sc, ((both >> 16) & 255) * sc, 0.f);
-#endif
-            }
-            v.w = 0.f;
-            ((float4*)L.ximg)[e] = in ? v : f4zero();
-        }
-#pragma unroll
-        for (int it = 0; it < ITB; ++it) {
-            int e = mtid + it * 256; e = e < NLO ? e : NLO - 1;
-            int pc = (e >> 1) % LC, pr = (e >> 1) / LC;
-            int ly = row0 / 2 + pr - 1, lx = pc - 1;
-            bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            ((float4*)L.xo)[e] = in ? rb[it] : f4zero();       // [pr][pc][8]: e = (pr*LC + pc)*2 + half
-        }
-    };
-
-    if constexpr (IMG4) {
-        if (mtid < TRA * 2) ((float4*)L.ximg)[(mtid >> 1) * PW + ((mtid & 1) ? PW - 1 : 0)] = f4zero();
-    }
+    [[maybe_unused]] unsigned long long tp = MH_T(), s_p1 = 0, s_w1 = 0, s_dg = 0, s_wg = 0, s_w2 = 0, tm = 0;
     for (int i = 0; i <= T; ++i) {
-        if constexpr (W0) {
-            if (i > 0) commit_x(tile_of(i - 1));
-        }
+        // (phase 1 of the matrix waves is empty since round 6: the builder waves stage masker.0's input tiles)
+        [[maybe_unused]] const unsigned long long ta = MH_T();
         __syncthreads();                                   // barrier 1 of tile i
-        if constexpr (W0) {
-            if (i < T) fetch_x(tile_of(i));                // committed in the next phase 1
-        }
+        [[maybe_unused]] const unsigned long long tb = MH_T();
         if (i > 0) {
             const int tile = tile_of(i - 1);
             const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
@@ -368,13 +412,19 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
             // in order, so reads placed after a group's MFMAs would only start once the last of them has issued and the
             // matrix pipe would idle for a full LDS round trip per group.  A group must stay below 16 LDS instructions:
             // s_waitcnt lgkmcnt counts to 15, so "wait for the previous group only" is not expressible beyond that.
+#ifdef MH_WHATIF_NODGRAD
+            if (P.n < 0)
+#endif
             {
                 // data gradient of low-res row qyl = mwave: lane pair i = l15 covers low-res pixels 2i (columns 0-7 of the
                 // tile) and 2i+1 (columns 8-15); window = rows 2qyl-1..2qyl+2, columns 4i-1..4i+4 of dH
                 const int qyl = mwave;
                 const int abase = ((2 * qyl) * PW + 4 * l15) * PS + kq;
                 const float* wb = L.w4p + kq * 16 + l15;          // B: w4p[(pos*16 + 4*plane + kq)*16 + l15]
-                frag4 d = frag4{0.f, 0.f, 0.f, 0.f};
+                // TWO accumulation chains (even / odd k-steps, added once at the end): v_mfma_f32_16x16x4_f32 issues every 32 cycles but a
+                // dependent one only after 40 (cdna_hip_programming.md, "FP32-input MFMA"), and this role is the SIMD's only MFMA wave
+                // (round 6: 96 x 8 cycles per tile)
+                frag4 d = frag4{0.f, 0.f, 0.f, 0.f}, d1 = frag4{0.f, 0.f, 0.f, 0.f};
                 constexpr int GS = 12, NG = 96 / GS;              // 24 dwords = 12 ds_read2 per group
                 float av[2][GS], bw[2][GS];
                 auto ld = [&](int g, int buf) {
@@ -386,19 +436,44 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                     }
                 };
                 ld(0, 0);
+                __builtin_amdgcn_sched_barrier(0);        // (group 0's reads all issue before its first MFMA: they must not be dealt out between them)
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (g + 1 < NG) ld(g + 1, (g + 1) & 1);
+#if !MH_INTERLEAVE
                     __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-                    for (int j = 0; j < GS; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][j], bw[g & 1][j], d, 0, 0, 0);
+                    for (int j = 0; j < GS; j += 2) {
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][j], bw[g & 1][j], d, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g & 1][j + 1], bw[g & 1][j + 1], d1, 0, 0, 0);
+                    }
+#if MH_INTERLEAVE
+                    // (round 6) the next group's operand reads are issued BETWEEN this group's MFMAs (one LDS instruction per matrix instruction:
+                    // a matrix instruction keeps the pipe busy for 32 cycles, the wave is free to issue meanwhile) instead of in front of them,
+                    // where their issue time was a gap in the matrix pipe once per group
+                    if (g + 1 < NG) {
+#pragma unroll
+                        for (int j = 0; j < GS; ++j) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        }
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, GS, 0);
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                d += d1;
                 // D[row = pair 4kq + j][col = l15 = 8*(pixel of the pair) + channel]: 16 contiguous floats per pair
                 float* o = P.d_o0 + ((size_t)(n0 * 32 + row0 / 2 + qyl) * 32 + 2 * (4 * kq)) * 8 + l15;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j * 16] = d[j];
             }
+            if (CGS_STAMP_PTR(P.dbg)) tm = MH_T();
+#ifdef MH_WHATIF_NOWGRAD
+            if (P.n < 0)
+#endif
             if constexpr (W0) {
                 // weight gradient: this wave's rows 2*mwave (py = 0) and 2*mwave + 1 (py = 1); a k-step = 4 same-parity
                 // pixels x = 2*(4s + kq) + px of one row.  Chunk = (py, px, two k-steps): 5 ds_read2 + 8 MFMAs.
@@ -441,7 +516,17 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                 }
             }
         }
+        [[maybe_unused]] const unsigned long long tc = MH_T();
         __syncthreads();                                   // barrier 2 of tile i
+        if (CGS_STAMP_PTR(P.dbg)) {
+            const unsigned long long td = MH_T();
+            s_p1 += ta - tp; s_w1 += tb - ta; s_w2 += td - tc; tp = td;
+            if (i > 0) { s_dg += tm - tb; s_wg += tc - tm; } else s_dg += tc - tb;
+        }
+    }
+    if (CGS_STAMP_PTR(P.dbg) && mtid == 0) {
+        unsigned long long* o = CGS_STAMP_PTR(P.dbg) + (size_t)bid * 16 + 8;
+        o[0] = s_p1; o[1] = s_w1; o[2] = s_dg; o[3] = s_wg; o[4] = s_w2;
     }
 
     if constexpr (W0) {
@@ -474,6 +559,7 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     L.w4p = L.xo + G::XO;              // pair-folded weights [u 0..3][v6 0..5][oc][8*g + c]
     L.dz = L.w4p + G::W4P;             // dzpre tile with a 2-pixel halo
     const int tid = threadIdx.x;
+    [[maybe_unused]] const unsigned long long t_start = MH_T();
 
     // (every load of the table unconditional -- clamped index, selected afterwards -- and the loop unrolled: with `if (valid) s += P.w0[..]` each of the
     //  4 x 12 loads per thread was a branch, a load and a wait of its own: 48 dependent round trips at the start of every workgroup, the whole launch in
@@ -516,10 +602,12 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
 
     const int grid = gridDim.x, bid = blockIdx.x;
     const int T = (P.ntiles - bid + grid - 1) / grid;      // tiles of this workgroup: bid, bid+grid, ...
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) { CGS_STAMP_PTR(P.dbg)[(size_t)bid * 16 + 5] = t_start; CGS_STAMP_PTR(P.dbg)[(size_t)bid * 16 + 6] = MH_T(); }
     // SCALAR role branch: whole waves take one side, both sides execute 2*(T+1) workgroup barriers
-    if (__builtin_amdgcn_readfirstlane(tid) < 256) mask_head_builder<TH, WG, W0>(P, L, tid, T, bid, grid);
+    if (__builtin_amdgcn_readfirstlane(tid) < 256) mask_head_builder<TH, WG, W0, SRC>(P, L, tid, T, bid, grid);
     else mask_head_matrix<TH, W0, SRC>(P, L, tid - 256, T, bid, grid);
     __syncthreads();
+    [[maybe_unused]] const unsigned long long t_after_roles = MH_T();
 
     // ---------------- weight-gradient partials: one slab per workgroup ----------------
     if constexpr (W0) {
@@ -560,6 +648,7 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
             P.slab2[(size_t)blockIdx.x * 145 + tid] = v;
         }
     }
+    if (CGS_STAMP_PTR(P.dbg) && tid == 0) { CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 7] = MH_T(); CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 13] = t_after_roles; }
 }
 
 // one workgroup per CU (LDS), persistent over its tiles
@@ -583,7 +672,10 @@ static int launch_mask_head(MHeadParams P, hipStream_t st) {
 int mask_head_launch(int n, int img_kind, const void* img, const float* o0, const float* dzpre, const float* h,
                      const float* w2, const float* w0, float* dh, float* d_o0, float* slab2, float* slab0, hipStream_t st) {
     if (n <= 0) return CGS_OK;
-    MHeadParams P{dzpre, h, w2, w0, img, o0, dh, d_o0, slab2, slab0, n, 0};
+    MHeadParams P{dzpre, h, w2, w0, img, o0, dh, d_o0, slab2, slab0, n, 0, nullptr};
+#ifdef CGS_DEBUG_STAMPS
+    P.dbg = g_mh_stamps;
+#endif
     if (slab0) {
         if (!slab2 || !img || !o0) return CGS_ERR_BADARG;
         return img_kind == CGS_SRC_U8 ? launch_mask_head<true, true, WSRC_U8>(P, st) : launch_mask_head<true, true, WSRC_F32>(P, st);

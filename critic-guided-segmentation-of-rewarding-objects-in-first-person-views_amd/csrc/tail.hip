@@ -620,8 +620,15 @@ extern "C" int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const 
 // left to cgs_tail_head_wgrad below, which reads the per-image vectors this kernel writes to hvec.
 // ------------------------------------------------------------------------------------------------
 static constexpr int kTailSlab10 = 1168, kTailSlab6 = 584;
+// (round 6) the two pre-pool gradient tiles are read by the DATA gradients as 16-byte channel planes with lane = pixel (conv_px, tail4.h, as the
+// forward kernel reads x1 / x2): padded slots / pitches instead of the dword reads of conv_tiles, which were 4-way (8-channel tile: 32 lanes on 8
+// banks) and 8-way (16-channel tile: 4 banks) bank-conflicted.  DY3P: 16-float slots, pitch / 4 = 41 = 9 (mod 16): the 16 lanes a ds_read_b128
+// serves together ({0-3, 12-15, 20-27}: quads 0, 3, 5, 6 = rows 0-1 columns {0,1,6,7} + rows 2-3 columns {2..5} of the 8-wide map) fall on
+// slot groups {0,4,8,12} + 9 * row: 16 different ones.
+using DY2P = TileP<16, 16, 8, 8, 148>;    // d(features.6 pre-pool)
+using DY3P = TileP<8, 8, 16, 16, 164>;    // d(features.10 pre-pool)
 // floats of tail_enc_bwd_kernel's one static LDS block (its tiles + weights + per-image scratch, or the dec_model.0 rider's tiles)
-static constexpr int kTailEncBwdTileFloats = T16x8::FLOATS + T8x8::FLOATS + T16x8::FLOATS + T8x16::FLOATS;
+static constexpr int kTailEncBwdTileFloats = T16x8::FLOATS + T8x8::FLOATS + DY2P::FLOATS + DY3P::FLOATS;
 static constexpr int kTailEncBwdOwnFloats = ((kTailEncBwdTileFloats + 3) & ~3) + 72 * 8 + 72 * 16 + 256 + 512 + 512 + 2048 + 64 + 32;
 static constexpr int kTailEncBwdLdsFloats = kTailEncBwdOwnFloats > kWD0LdsFloats ? kTailEncBwdOwnFloats : kWD0LdsFloats;
 
@@ -665,7 +672,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     // The chain of one image is latency-bound, so: every global load of an image is issued at the top of its iteration (one
     // memory latency instead of one per stage), the head runs redundantly in all waves on shuffles (no single-wave sections),
     // four barriers per image.
-    constexpr int OX1 = 0, OX2 = OX1 + T16x8::FLOATS, ODY2 = OX2 + T8x8::FLOATS, ODY3 = ODY2 + T16x8::FLOATS, OEND = ODY3 + T8x16::FLOATS;
+    constexpr int OX1 = 0, OX2 = OX1 + T16x8::FLOATS, ODY2 = OX2 + T8x8::FLOATS, ODY3 = ODY2 + DY2P::FLOATS, OEND = ODY3 + DY3P::FLOATS;
+    static_assert(OX2 % 4 == 0 && ODY2 % 4 == 0 && ODY3 % 4 == 0, "16-byte aligned tiles");
     // one LDS block, carved by hand: the rider workgroups below (dec_model.0's weight gradient) use the same bytes their own way
     constexpr int OW6 = (OEND + 3) & ~3, OW10 = OW6 + 72 * 8, OXS = OW10 + 72 * 16, OM2 = OXS + 256, OD2 = OM2 + 512, OO1 = OD2 + 512,
                   OAM2 = OO1 + 2048, ODZ4 = OAM2 + 64, OALL = ODZ4 + 32;
@@ -707,8 +715,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     // (the once-per-workgroup LDS set-up -- zero halos, convolution weights -- runs inside the first iteration, BEHIND the first
     //  image's global loads: the set-up then costs no memory latency of its own)
-    WgradAccK<T8x8, T8x16, 16> wg10;
-    WgradAccK<T16x8, T16x8, 8> wg6;
+    WgradAccK<T8x8, DY3P, 16> wg10;
+    WgradAccK<T16x8, DY2P, 8> wg6;
     wg10.init(lane);
     wg6.init(lane);
 
@@ -765,8 +773,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             const int ts = tid + lz;         // (opaque: the set-up's addresses must not become loop invariants held in registers)
             tile_zero<T16x8>(x1, ts);
             tile_zero<T8x8>(x2, ts);
-            tile_zero<T16x8>(dy2, ts);
-            tile_zero<T8x16>(dy3, ts);
+            tilep_zero<DY2P>(dy2, ts);
+            tilep_zero<DY3P>(dy3, ts);
             TAIL_STAMP(12);
             for (int e = ts; e < 72 * 8 / 4; e += 256) ((float4*)w6s)[e] = ((const float4*)P.w.w6)[e];
             for (int e = ts; e < 72 * 16 / 4; e += 256) ((float4*)w10s)[e] = ((const float4*)P.w.w10)[e];
@@ -852,47 +860,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
             const uint32_t nib = (lam3 >> (4 * (c & 7))) & 15u;
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos)
-                dy3[T8x16::at(2 * qy + (pos >> 1), 2 * qx + (pos & 1)) + c] = (nib == (uint32_t)pos) ? r : 0.f;
+                dy3[DY3P::at(2 * qy + (pos >> 1), 2 * qx + (pos & 1)) + c] = (nib == (uint32_t)pos) ? r : 0.f;
         }
         __syncthreads();
         TAIL_STAMP(3);
-        // ---- features.10: weight gradient; data gradient -> Dropout mask, + skip gradient, re-expansion for features.6 ----
-        wg10.accumulate(x2, dy3, wave, lane_i);
-        conv_tiles<T8x16, 0, 16, 1>(
-            dy3, [&](int tap, int c, int) { return w10s[((8 - tap) * 8 + (l15 & 7)) * 16 + c]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                if (l15 < 8) {
-                    const int qy = q >> 2, qx = q & 3;
+        // ---- features.10: weight gradient (waves 2, 3) NEXT TO the data gradient (waves 0, 1: four of e2's eight channels each, lane = pixel
+        //      of the 8x8 map, v_mfma_f32_4x4x1 on 16-byte planes of dy3) -> Dropout mask, + skip gradient, re-expansion through features.6's
+        //      argmax nibbles into dy2 (four 16-byte stores per lane) ----
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        if (wv >= 2) {
+            wg10.template accumulate<2>(x2, dy3, wv - 2, lane_i);
+        } else {
+            float wd10[1][9];           // W^T of this wave's four channels: step = (tap, co), re-read from LDS per image
+            fill_wreg<1, 9, 144>(wd10, lane_i, [&](int step, int ci) { return w10s[((step >> 4) * 8 + 4 * wv + ci) * 16 + (step & 15)]; });
+            frag4 a[1] = {frag4{0.f, 0.f, 0.f, 0.f}};
+            const PxPos pb = px8(lane_i);
+            conv_px<DY3P, 0, 16, 16, 0, 1, 9, true, true>(a, dy3, pb.y, pb.x, wd10);
+            const int pp = pb.y * 8 + pb.x;                     // pixel of the 8x8 map = pooled pixel of features.6
+            const float4 mk4 = *(const float4*)(m2s + pp * 8 + 4 * wv), sk4 = *(const float4*)(d2s + pp * 8 + 4 * wv);
+            const float4 r = make_float4(a[0][0] * mk4.x + sk4.x, a[0][1] * mk4.y + sk4.y, a[0][2] * mk4.z + sk4.z, a[0][3] * mk4.w + sk4.w);
+            const uint32_t nib16 = (am2s[pp] >> (16 * wv)) & 0xFFFFu;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int py = 2 * qy + (j >> 1), px = 2 * qx + (j & 1), pp = py * 8 + px;   // pixel of the 8x8 map = pooled pixel of features.6
-                        const float r = acc[0][j] * m2s[pp * 8 + l15] + d2s[pp * 8 + l15];
-                        const uint32_t nib = (am2s[pp] >> (4 * l15)) & 15u;
-#pragma unroll
-                        for (int pos = 0; pos < 4; ++pos)
-                            dy2[T16x8::at(2 * py + (pos >> 1), 2 * px + (pos & 1)) + l15] = (nib == (uint32_t)pos) ? r : 0.f;
-                    }
-                }
-            },
-            wave, lane_i);
+            for (int pos = 0; pos < 4; ++pos)
+                *(float4*)(dy2 + DY2P::at(2 * pb.y + (pos >> 1), 2 * pb.x + (pos & 1)) + 4 * wv) = nib_select4(r, nib16, (uint32_t)pos);
+        }
         __syncthreads();
         TAIL_STAMP(4);
-        // ---- features.6: weight gradient; data gradient -> d e1 ----
+        // ---- features.6: data gradient (lane = pixel, this wave's 64 pixels x 8 channels) + skip gradient -> d e1 straight to memory;
+        //      then the weight gradient ----
+        {
+            float wd6[2][5];
+            fill_wreg<2, 5, 72>(wd6, lane_i, [&](int step, int ci) { return w6s[((step >> 3) * 8 + ci) * 8 + (step & 7)]; });
+            frag4 a[2] = {frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}};
+            const PxPos pa = px16(wave, lane_i);
+            conv_px<DY2P, 0, 8, 8, 0, 2, 5, true>(a, dy2, pa.y, pa.x, wd6);
+            const int pix = pa.y * 16 + pa.x;
+            const float4 s0 = ((const float4*)o1s)[pix * 2], s1 = ((const float4*)o1s)[pix * 2 + 1];      // the skip gradient parked at commit
+            float4* out = (float4*)P.de1 + (size_t)img * 512 + pix * 2;
+            out[0] = make_float4(s0.x + a[0][0], s0.y + a[0][1], s0.z + a[0][2], s0.w + a[0][3]);
+            out[1] = make_float4(s1.x + a[1][0], s1.y + a[1][1], s1.z + a[1][2], s1.w + a[1][3]);
+        }
         wg6.accumulate(x1, dy2, wave, lane_i);
-        conv_tiles<T16x8, 0, 8, 1>(
-            dy2, [&](int tap, int c, int) { return w6s[((8 - tap) * 8 + (l15 & 7)) * 8 + c]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                if (l15 < 8) {
-                    const int qy = q >> 3, qx = q & 7;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o1s[((2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] += acc[0][j];
-                }
-            },
-            wave, lane_i);
         __syncthreads();
         TAIL_STAMP(5);
-        ((float4*)P.de1)[(size_t)img * 512 + tid] = ((const float4*)o1s)[tid];
-        ((float4*)P.de1)[(size_t)img * 512 + tid + 256] = ((const float4*)o1s)[tid + 256];
     }
 
     // ---- one slab per layer for this workgroup ----

@@ -198,16 +198,19 @@ struct WgradAccK {
         }
     }
 
+    // NW: the pixel steps are dealt to NW waves (wave = 0 .. NW-1 of them); the others may do something else meanwhile
+    template <int NW = 4>
     __device__ __forceinline__ void accumulate(const float* xt, const float* dyt, int wave, int lane) {
+        static_assert(NSTEP % NW == 0, "steps split over the waves");
         const int l15 = lane & 15, kq = lane >> 4;
         const int co = l15 % CO;
-        constexpr int PERW = NSTEP / 4, BATCH = PERW % 4 == 0 ? 4 : (PERW % 2 == 0 ? 2 : 1);     // see WgradAcc::accumulate
+        constexpr int PERW = NSTEP / NW, BATCH = PERW % 4 == 0 ? 4 : (PERW % 2 == 0 ? 2 : 1);     // see WgradAcc::accumulate
 #pragma unroll 1
         for (int k0 = 0; k0 < PERW; k0 += BATCH) {
             float a[BATCH][NRB], b[BATCH];
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
-                const int p = 4 * (wave + 4 * (k0 + u)) + kq, y = p / TX::W, x = p % TX::W;
+                const int p = 4 * (wave + NW * (k0 + u)) + kq, y = p / TX::W, x = p % TX::W;
                 const int pa = (y * TX::PW + x) * TX::PCI;
                 b[u] = dyt[TY::at(y, x) + co];
 #pragma unroll

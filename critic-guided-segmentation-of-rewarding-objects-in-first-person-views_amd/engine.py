@@ -379,6 +379,14 @@ class HourglassEngine:
             for slab, nsl, cnt, off in pc.jobs:
                 full.jobs.append((slab, nsl, cnt, self.off_c + off))
             self._plans["p1"] = full.build(self.grad)
+            if self._p1_fused_adam():
+                # the fused reduction + Adam launch updates exactly the elements its jobs cover: that must be the whole critic
+                cover = torch.zeros(self.lc.total, dtype=torch.bool)
+                for _slab, _nsl, cnt, off in full.jobs:
+                    cover[off - self.off_c:off - self.off_c + cnt] = True
+                if not bool(cover.all()):
+                    raise _lib.CgsError(f"phase 1: the slab jobs cover {int(cover.sum())} of the critic's {self.lc.total} parameters; the "
+                                        "fused reduce + Adam launch would leave the rest without an update")
         if self._p1_fused_adam():
             self._plans["p1"].run_adam(self.step_t, self.flat, self.grad, self.m, self.v, self.lr, self.b1, self.b2, self.eps, self._ticket)
         else:

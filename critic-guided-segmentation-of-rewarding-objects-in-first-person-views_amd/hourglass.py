@@ -29,6 +29,9 @@ MASK_HEAD_FUSED = True   # masker.2+masker.0 data gradients in one pass
 MASK_TRAIN_FUSED = True
 # ... from this many images on: the one-kernel form is one workgroup per image (two per CU), the two-launch form splits an image into strips -- on a
 # 256-CU device the step is faster WITHOUT it at the reference's own batch (r05, tools/ab_flags_n.py: N = 64: -14 us of 257, 128: -5, 192: +9, 256: +14)
+# (this threshold, ENC1_TAIL_BWD_FUSED_MIN_N below, the 768-workgroup caps of the tail kernels and cgs_stagger were all measured on ONE device
+#  shape: MI355X in SPX mode, 8 XCDs x 32 CUs = 256 CUs; on another partitioning they are only a starting point.  The small-batch forms the
+#  reference's N = 64 takes are pinned by the reference's own run: tests/test_gpu_loops.py G9 (34 phase-2 steps) and G12 (48 phase-1 steps).)
 MASK_TRAIN_FUSED_MIN_N = int(os.environ.get("CGS_MASK_TRAIN_FUSED_MIN_N", "160"))
 # the 16x16-and-smaller layers image by image in one workgroup (csrc/tail.hip) instead of one launch per layer
 TAIL_FWD = True
@@ -389,6 +392,14 @@ def critic_backward(flat: torch.Tensor, lay: Layout, x: torch.Tensor, n: int, sa
         t = ws.get(name)
         if t is None:
             t = ws[name] = torch.empty(shape, device=dev, dtype=dtype)
+        # a cached workspace (e.g. the slab rows engine._slab_views sized for the launch form it expected) must hold what THIS call
+        # writes: a different launch form asking for more rows than were allocated would write out of bounds
+        want = 1
+        for d in shape:
+            want *= int(d)
+        if t.numel() < want or t.dtype != dtype:
+            raise _lib.CgsError(f"workspace '{name}': cached {tuple(t.shape)} {t.dtype} cannot hold the requested {tuple(shape)} {dtype} "
+                                "(the launch form changed after the workspace was sized)")
         return t
 
     has_add = d_embeds is not None and n_add > 0
