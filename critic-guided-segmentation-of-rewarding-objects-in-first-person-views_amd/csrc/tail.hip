@@ -30,7 +30,8 @@ using T8x16 = Tile<8, 8, 16>;       // d(features.10 pre-pool)
 using T16x16 = Tile<16, 16, 16>;    // cat(e1, up(o2))
 using T8x24 = Tile<8, 8, 24>;       // cat(e2, up(o3))
 using T4x48 = Tile<4, 4, 48>;       // cat(e3, up4(o4))
-using T4x16 = Tile<4, 4, 16>;       // do3
+using T4x16 = Tile<4, 4, 20>;       // do3 (16 channels in 20-float pixel slots: the dword reads of dec_model.3's data gradient -- 16 pixels x 2 channels per
+                                    // 32 lanes -- fall on 16 banks instead of 4; round 6)
 
 // gradient of conv+ReLU+pool re-expanded to one position of the 2x2 window: nibble == pos ? v : 0 (0xF = ReLU dead)
 __device__ __forceinline__ float4 nib_select4(const float4& v, uint32_t nib16, uint32_t pos) {
@@ -1115,6 +1116,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailDecBwdParams) + sizeof(ConvParams)>();
     using L = TailDecBwdLds;
     extern __shared__ __attribute__((aligned(16))) float4 smem4[];
+    if (CGS_STAMP_PTR(P.dbg) && threadIdx.x == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memtime();      // kernel entry
+    // B operand of dec_model.3's data gradient for this wave's 16 input channels: B[k = (tap, co)][col = ci] = w3[(8 - tap)][ci][co] (flipped taps);
+    // requested FIRST: the 36 loads land while the convolution below runs
+    const int wv3 = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    float w3b[36];
+    if (wv3 < 3) {
+        const float* wp = P.w.w3 + (size_t)(16 * wv3 + ((int)threadIdx.x & 15)) * 16 + (((int)threadIdx.x & 63) >> 4);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int sx = 0; sx < 4; ++sx) w3b[tap * 4 + sx] = wp[(size_t)(8 - tap) * 48 * 16 + 4 * sx];
+    }
     if constexpr (FUSED) {
         cgs_stagger<8, CGS_STAGGER_DEC_BWD>();
         conv3x3_body_pipe<DDec0P>(PC, 2 * (int)blockIdx.x, smem4);
@@ -1139,7 +1152,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     WgradAcc<T8x24, T8x8, 8, 4> wg2;
     WgradAcc<T4x48, T4x16, 16, 7> wg3;
     wg2.init(wave, lane); wg3.init(wave, lane);
-
     for (int img = blockIdx.x; img < P.n; img += P.nblocks) {
         TAIL_STAMP(1);
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
@@ -1245,38 +1257,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         // ---- dec_model.3: weight gradient on the matrix cores; data gradient on the vector ALU (48 input channels x 4 quads:
         //      thread = (ci, quad), weights read in their natural [tap][ci][co] order, 16 contiguous floats per (tap, ci)) ----
         if constexpr (W3) wg3.accumulate(t3, dy3, lane_i);
-        if (tid < 192) {
-            const int ci = tid % 48, q = tid / 48, qy = q >> 1, qx = q & 1;
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            // (the weights of tap t+1 are requested before tap t is multiplied: one L2 round trip instead of nine in a row)
-            const float4* wr0 = (const float4*)(P.w.w3 + ((size_t)8 * 48 + ci) * 16);
-            float4 wn[4] = {wr0[0], wr0[1], wr0[2], wr0[3]};
-#pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
-                const float4 wv[4] = {wn[0], wn[1], wn[2], wn[3]};
-                if (tap < 8) {
-                    const float4* wr = (const float4*)(P.w.w3 + ((size_t)(7 - tap) * 48 + ci) * 16);
+        // (round 6) dec_model.3's data gradient on the matrix cores (it was 576 multiply-adds per thread on the vector ALU behind nine dependent L2
+        // round trips for the weights: 16.5 k of the kernel's 105 k cycles by the stamps).  GEMM: M = the 16 pixels of the 4x4 map (four 2x2 quads),
+        // N = 48 input channels = one 16-column block per wave (waves 0, 1, 2), K = 9 taps x 16 channels of d o3; the B operand (W^T, flipped taps) sits
+        // in 36 registers per lane, loaded once per workgroup in front of the image loop.
+        if (wv3 < 3) {
+            const int q = l15 >> 2, y = 2 * (q >> 1) + ((l15 >> 1) & 1), x = 2 * (q & 1) + (l15 & 1);
+            const int kq = lane_i >> 4;
+            const float* ap = dy3 + (y * T4x16::PW + x) * T4x16::PCI + kq;        // tap (0,0) = pixel (y-1, x-1) = halo coordinates (y, x)
+            frag4 acc = frag4{0.f, 0.f, 0.f, 0.f}, acc1 = frag4{0.f, 0.f, 0.f, 0.f};      // two chains: a dependent 16x16x4 issues after 40 cycles, not 32
+            float av[36];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) wn[k] = wr[k];
-                }
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int y = 2 * qy + (j >> 1) + tap / 3 - 1, x = 2 * qx + (j & 1) + tap % 3 - 1;   // -1 .. 4: inside the halo tile
-                    const float4* dp = (const float4*)(dy3 + T4x16::at(y, x));
+                for (int sx = 0; sx < 4; ++sx) av[tap * 4 + sx] = ap[((tap / 3) * T4x16::PW + tap % 3) * T4x16::PCI + 4 * sx];
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const float4 dv = dp[c4];
-                        a[j] = fmaf(dv.x, wv[c4].x, a[j]); a[j] = fmaf(dv.y, wv[c4].y, a[j]);
-                        a[j] = fmaf(dv.z, wv[c4].z, a[j]); a[j] = fmaf(dv.w, wv[c4].w, a[j]);
-                    }
-                }
+            for (int k = 0; k < 36; k += 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k], w3b[k], acc, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k + 1], w3b[k + 1], acc1, 0, 0, 0);
             }
-            if (ci < 16) {
+            acc += acc1;
+            // D[row = pixel 4 kq + j = (quad kq, position j)][col = l15 = channel 16 wv3 + l15]
+            if (wv3 == 0) {          // channels 0..15: the skip gradient d e3
+                const int qy = kq >> 1, qx = kq & 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    P.dE3[((size_t)img * 16 + (2 * qy + (j >> 1)) * 4 + 2 * qx + (j & 1)) * 16 + ci] = a[j];
-            } else {
-                red[q * 32 + ci - 16] = (a[0] + a[1]) + (a[2] + a[3]);
+                    P.dE3[((size_t)img * 16 + (2 * qy + (j >> 1)) * 4 + 2 * qx + (j & 1)) * 16 + l15] = acc[j];
+            } else {                  // channels 16..47: the upsampled o4 -- summed over the 4x4 map (per quad here, over the quads below)
+                red[kq * 32 + 16 * (wv3 - 1) + l15] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
             }
         }
         __syncthreads();

@@ -42,4 +42,8 @@ for k, name in enumerate(("enc_fwd (last call: mixes)", "dec_fwd", "enc_bwd (las
     d = np.diff(s[:, cols], axis=1)
     print(f"{name}: {live.sum()} workgroups, stamps {cols}")
     print("   mean ticks per stage:", np.round(d.mean(0), 0).tolist(), " total", round(float((s[:, cols[-1]] - s[:, cols[0]]).mean())))
-    print("   kernel span (first start .. last end):", float(s[:, cols[-1]].max() - s[:, cols[0]].min()))
+    print("   span (first workgroup's first stamp .. last workgroup's last stamp):", float(s[:, cols[-1]].max() - s[:, cols[0]].min()))
+    if (s[:, 14] != 0).all() and 14 not in cols[1:-1]:
+        print("   kernel entry (stamp 14) -> first stage stamp: mean", round(float((s[:, cols[1] if cols[0] == 14 else cols[0]] - s[:, 14]).mean())),
+              " entry -> end: mean", round(float((s[:, 15] - s[:, 14]).mean())), " max", float((s[:, 15] - s[:, 14]).max()),
+              " launch span", float(s[:, 15].max() - s[:, 14].min()))
