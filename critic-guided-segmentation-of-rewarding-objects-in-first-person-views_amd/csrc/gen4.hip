@@ -113,8 +113,15 @@ __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
 // (gen4_stage_s2d: 4 parity blocks of S.cb >= S.ca channels), output = one low-resolution cell per lane; a 16-channel chunk lies in one parity
 // block and meets 4 of the 9 cell offsets (gen4_pack_elem, transposed = 3): 16 (block, offset) steps per channel and cell where the full-resolution
 // form (9 taps per pixel, then the 2 x 2 cell sum in the epilogue) runs 36.
+// workgroups (= waves per SIMD) a CU is meant to hold: NG >= 8 (32 / 40 accumulator registers) and the narrower instances
+#ifndef G4_WPE_BIG
+#define G4_WPE_BIG 3
+#endif
+#ifndef G4_WPE_SMALL
+#define G4_WPE_SMALL 4
+#endif
 template <int NG, int FOLD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? 3 : 4, NG >= 8 ? 3 : 4))) gen4_conv3x3_kernel(Gen4Params P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL, NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL))) gen4_conv3x3_kernel(Gen4Params P) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(Gen4Params)>();
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -574,7 +581,7 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling included: the cells' maxima are taken by the copy-out threads)
     const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
     const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
-    const size_t budget = (size_t)(160 * 1024) / (ng > 8 ? 3 : 4) - 512;
+    const size_t budget = (size_t)(160 * 1024) / (ng >= 8 ? G4_WPE_BIG : G4_WPE_SMALL) - 512;
     P.dbuf = ((cp > GEN_KC || L.fold) && 2 * tile_bytes <= budget) ? 1 : 0;
     size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
     const size_t epi = (size_t)256 * (4 * ng + 4) * sizeof(float);

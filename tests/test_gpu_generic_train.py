@@ -4,6 +4,8 @@ reference capture at chfak = 2 (tests/golden/g3_train_chfak2.npz) and against th
 frozen critic, -separate, chfak = 5)."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -238,6 +240,83 @@ def test_generic_phase2_with_dropout_vs_oracle(chfak, neck, n, kw):
     l2b = e2.phase2_step().clone()
     assert torch.equal(l2a, l2b)
     assert torch.equal(e.flat, e2.flat)
+
+
+def _pool_pick_flips(e, pc, n_lo, n_hi, x_in):
+    """Pooled cells of the critic's four 3x3 layers (slots n_lo:n_hi of the engine's buffers) where the kernels' argmax byte differs from
+    the argmax of a FLOAT64 convolution of the layer's own (fp32, device-computed) input: per layer (count, largest relative gap between the
+    two candidates of such a cell).  A cell whose two largest candidates agree to ~1e-7 relative is decided by fp32 rounding; taking the other
+    candidate moves dy of that cell to a neighbouring pixel -- a discrete change of the gradients below it that no summation order removes."""
+    out = []
+    srcs = [x_in, e.cbuf["e0"][n_lo:n_hi], e.cbuf["e1"][n_lo:n_hi], (e.cbuf["e2d"] if "e2d" in e.cbuf else e.cbuf["e2"])[n_lo:n_hi]]
+    for li, key in enumerate(("features.0", "features.3", "features.6", "features.10")):
+        x = srcs[li].cpu().double().permute(0, 3, 1, 2)
+        y = F.conv2d(x, pc[key + ".weight"].double(), pc[key + ".bias"].double(), padding=1)     # (pre-ReLU: max(relu) = relu(max))
+        N, Cc, H, W = y.shape
+        cells = y.reshape(N, Cc, H // 2, 2, W // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(N, Cc, H // 2, W // 2, 4)
+        srt = cells.sort(-1, descending=True).values
+        top, idx = cells.max(-1)
+        gap = (srt[..., 0] - srt[..., 1]) / srt[..., 0].abs().clamp_min(1e-30)
+        am = e.cbuf[f"am{li}"][n_lo:n_hi].cpu().permute(0, 3, 1, 2).long()
+        assert not ((top > 1e-4) & (am >= 4)).any() and not ((top < -1e-4) & (am < 4)).any(), \
+            f"{key}: ReLU gate of the pooled cells differs from float64"
+        mism = (top > 0) & (am < 4) & (am != idx)
+        out.append((int(mism.sum()), float(gap[mism].max()) if mism.any() else 0.0))
+    return out
+
+
+def test_generic_phase2_chfak5_batch128_vs_float64_oracle():
+    """The paper's model size (chfak 5, main.py:1510 / docs/index.html:151) at a batch its batch-tiled kernels really tile (n = 128: the wgrad-rows /
+    split-K / fold kernels take several images per workgroup), Dropout 0.3, ONE phase-2 step on the shape-generic
+    engine against the oracle in FLOAT64 fed the keep-masks the kernels drew (as test_gpu_engine.py::test_phase2_with_dropout_vs_oracle_masks
+    does for chfak 1 at N = 512: at 0.5 M pixels per weight the CPU's own fp32 summation is no longer a checker): losses, all 28 gradients,
+    the parameters after the step.
+
+    Of the 20 M max-pooled cells of features.0 / features.3 in this step a handful (measured: 1 + 3, gpurun_out/r06_diag_c5_flips.txt) have
+    their two largest candidates within 1e-7 .. 1e-6 relative: fp32 and float64 pick different pixels there (_pool_pick_flips shows every
+    such cell and asserts the gap is rounding-sized).  One moved dy changes 9 x ci weight-gradient elements of that layer (and, through
+    the data gradient, the layers below) by |dy| |dx| -- up to 1e-3 of the tensor's maximum here, against 1e-6 everywhere else.  The
+    weight gradients at and below a layer with such a cell are therefore checked with an absolute term of 2e-3 of the maximum, all others
+    (and every tensor when no cell flips) at the usual 2e-5."""
+    chfak, neck, n = 5, 32, 128
+    rs = np.random.RandomState(11)
+    dev = torch.device("cuda:0")
+    A = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    B = rs.randint(0, 256, (n, 64, 64, 3)).astype(np.uint8)
+    Y = rs.rand(n).astype(np.float32)
+    e, pc, pm = make_generic_engine(chfak, n, neck=neck, dropout=0.3, use_graph=True)
+    masks = _export_masks(e, 4 * n, chfak, neck)
+    losses = e.phase2_step(torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(Y).to(dev)).cpu().numpy()
+    sl = {"B": slice(0, n), "A": slice(n, 2 * n), "rep": slice(2 * n, 3 * n), "inj": slice(3 * n, 4 * n)}
+    omasks = [[m[sl[k]].double() for m in masks] for k in ("A", "B", "rep", "inj")]
+    dd = lambda P: {k: v.double() for k, v in P.items()}
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    rec = orc.train_phase2(dd(pc), dd(pm), [(orc.u8_to_nchw(A).double(), orc.u8_to_nchw(B).double(), torch.from_numpy(Y).double())], steps=1,
+                           p=0.3, training=True, masks=omasks)[0]
+    flips = _pool_pick_flips(e, pc, n, 4 * n, e.x3)       # the images that carry the critic's weight gradients: [A | rep | inj]
+    assert sum(c for c, _ in flips) <= 16 and all(g < 2e-6 for _, g in flips), f"pool picks differ on cells that are not near ties: {flips}"
+    deepest = max([i for i, (c, _) in enumerate(flips) if c], default=-1)
+    loose = {f"{k}.weight" for k in ("features.0", "features.3", "features.6", "features.10")[:deepest + 1]}
+    loose |= {f"{k}.bias" for k in ("features.0", "features.3", "features.6", "features.10")[:max(deepest, 0)]}
+    parts = rec["parts"]
+    np.testing.assert_allclose(losses[:4], [parts["critic"], parts["replace"], parts["inject"], parts["norm"]], rtol=1e-3)
+    gc, gm = e.lc.unflatten(e.gc), e.lm.unflatten(e.gm)
+    for k, v in rec["grads_c"].items():
+        rel_close(gc[k].cpu().numpy(), v.numpy(), f"chfak 5 n=128 critic grad {k}", atol_scale=2e-3 if k in loose else 2e-5)
+    for k, v in rec["grads_m"].items():
+        rel_close(gm[k].cpu().numpy(), v.numpy(), f"chfak 5 n=128 masker grad {k}")
+    # Adam's first step is lr * g / (|g| + eps), eps = 1e-8: where |g| is within fp32 noise of zero (< 1e-4 of the tensor's maximum) the step is
+    # anything in [-lr, lr] -- those elements are checked for that bound, every other element against the oracle's parameter
+    for rec_p, rec_g, state, p0, who in ((rec["params_c"], rec["grads_c"], e.critic_state(), pc, "critic"),
+                                         (rec["params_m"], rec["grads_m"], e.masker_state(), pm, "masker")):
+        for k, v in rec_p.items():
+            if who == "critic" and k in loose:
+                continue
+            got, g64 = state[k].cpu().numpy(), np.abs(rec_g[k].numpy())
+            firm = g64 >= 1e-4 * g64.max()
+            assert firm.mean() > 0.5
+            rel_close(got[firm], v.numpy()[firm], f"chfak 5 n=128 {who} {k} after the step", rtol=1e-3, atol_scale=1e-4)
+            assert (np.abs(got - p0[k].numpy())[~firm] <= 1e-3 * (1 + 1e-3)).all()
 
 
 def test_generic_phase2_separate_critic_vs_oracle():
