@@ -13,9 +13,11 @@ from oracle import hourglass_ref as orc
 REL_REPORT = {}       # what -> worst PURE relative error over the elements above 1 % of the tensor's maximum (summary test below)
 
 
-def rel_close(got, ref, what, rtol=1e-3, atol_scale=2e-5):
+def rel_close(got, ref, what, rtol=1e-3, atol_scale=2e-5, report=True):
     """|got - ref| <= rtol |ref| + atol_scale max|ref| elementwise.  The absolute term only covers values near zero; the worst
-    pure-relative error of the elements that carry the tensor (>= 1 % of its maximum) is recorded and shown on failure."""
+    pure-relative error of the elements that carry the tensor (>= 1 % of its maximum) is recorded and shown on failure.
+    report = False: the comparison is not entered into the summary of test_zz_rel_summary.py (a tensor whose difference from the
+    checker is a counted discrete effect -- pool picks of near-tied cells at fp32 vs float64 -- not rounding)."""
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     assert got.shape == ref.shape, f"{what}: shape {got.shape} vs {ref.shape}"
@@ -24,7 +26,8 @@ def rel_close(got, ref, what, rtol=1e-3, atol_scale=2e-5):
     err = np.abs(got - ref)
     big = np.abs(ref) >= 1e-2 * mx
     worst_rel = float((err[big] / np.abs(ref[big])).max()) if big.any() else 0.0
-    REL_REPORT[what] = max(REL_REPORT.get(what, 0.0), worst_rel)
+    if report:
+        REL_REPORT[what] = max(REL_REPORT.get(what, 0.0), worst_rel)
     bad = err > (rtol * np.abs(ref) + atol)
     assert not bad.any(), (f"{what}: {bad.sum()}/{bad.size} outside tol; max err {err.max():.3e} "
                            f"(ref max {np.abs(ref).max():.3e}) at {np.unravel_index(err.argmax(), err.shape)}; "
