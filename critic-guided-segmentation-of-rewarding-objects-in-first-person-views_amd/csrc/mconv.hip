@@ -548,6 +548,14 @@ __global__ void __launch_bounds__(256, 2) mask_infer_kernel(MaskInferParams P) {
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half8m_t __attribute__((ext_vector_type(8)));
+// (round 6) masker.0 on v_mfma_f32_16x16x32_f16 (K = 32 per instruction: lane (l15, kq) holds k = 8 kq + j): the image's nine taps x (r, g, b, 0)
+// = 36 k-values are two instructions (taps (2 kq, 2 kq + 1) -- two 8-byte LDS reads; tap 8 + zero weights -- one), the folded o0 operand
+// (fold row a, fold column b, 8 channels = 32) ONE instruction fed by one 16-byte LDS read per lane (a = kq >> 1, b = kq & 1): 3 matrix
+// instructions + 4 LDS reads per 16 pixels where the K = 16 form ran 5 + 5.  Same products, same fp32 accumulator; only the order of the sum differs.
+#ifndef MIF16_K32
+#define MIF16_K32 0      // (A/B r06_k32, three interleaved runs at batch 2048: 0.1869 ms with the K = 32 form, 0.1818 with the K = 16 form -- see DESIGN.md)
+#endif
 
 // (round 5) The kernel was VALU-issue bound (SQ counters, profiles/r05_d_c4_sq.txt: 535 VALU instructions per wave and tile, 0.8 of
 // the SIMDs' issue slots), a third of them the per-PIXEL staging of the uint8 frame.  Fast forms, taken when the operands allow:
@@ -602,6 +610,32 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
                     }
                 wo[px][a][c] = (_Float16)v;
             }
+    [[maybe_unused]] half8m_t wimg32[2], wo32[2];      // K = 32 form: image taps (2 kq, 2 kq + 1) | tap 8;  o0: [px], k = (a = kq >> 1, b = kq & 1, 8 channels)
+    if constexpr (MIF16_K32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = 2 * kq + (j >> 2), c = j & 3;
+            wimg32[0][j] = (_Float16)(c < 3 ? wscale * P.w0[(t * 11 + (c < 3 ? c : 0)) * 16 + l15] : 0.f);
+            wimg32[1][j] = (_Float16)((kq == 0 && j < 3) ? wscale * P.w0[(8 * 11 + (j < 3 ? j : 0)) * 16 + l15] : 0.f);
+        }
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const int a = kq >> 1, b = kq & 1;
+                float v = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const bool iny = py == 0 ? (a == 0 ? ky == 0 : ky >= 1) : (a == 0 ? ky <= 1 : ky == 2);
+                        const bool inx = px == 0 ? (b == 0 ? kx == 0 : kx >= 1) : (b == 0 ? kx <= 1 : kx == 2);
+                        const float w = P.w0[((ky * 3 + kx) * 11 + 3 + ch) * 16 + l15];
+                        v += (iny && inx) ? w : 0.f;
+                    }
+                wo32[px][ch] = (_Float16)v;
+            }
+    }
     const float bias2 = P.b2[0];
     float b0r[4];
     half4_t w2a;                       // masker.2 as the A operand of the P instruction: m = l15 = tap (9 of 16 rows), k = 4*kq + c = channel
@@ -629,6 +663,7 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
     int toff[3];
 #pragma unroll
     for (int m = 0; m < 3; ++m) { int t = 4 * m + kq; t = t < 9 ? t : 8; toff[m] = ((t / 3) * IC + t % 3) * 4; }
+    [[maybe_unused]] const int toffa = (((2 * kq) / 3) * IC + (2 * kq) % 3) * 4, toffb = (((2 * kq + 1) / 3) * IC + (2 * kq + 1) % 3) * 4, toff8 = (2 * IC + 2) * 4;
 
     __builtin_amdgcn_s_waitcnt(0);     // the preloads above land HERE: a first use inside the tile loop would wait with vmcnt(0) and drain the prefetch
     // Staging: ALL of a tile's global loads are issued back to back into registers (fetch), then converted and written to LDS
@@ -740,15 +775,24 @@ __global__ void __launch_bounds__(256, 4) mask_infer_f16_kernel(MaskInferParams 
         for (int t = 0; t < 10; ++t) {
             const int jj = t >> 1, px = t & 1;
             frag4 acc = frag4{b0r[0], b0r[1], b0r[2], b0r[3]};             // D[oc = 4 kq + r][pixel = l15], from the bias
+            if constexpr (MIF16_K32) {
+                const _Float16* ip = ximg + ibase + (2 * jj * IC + px) * 4;
+                const half4_t t0 = *(const half4_t*)(ip + toffa), t1 = *(const half4_t*)(ip + toffb), t8 = *(const half4_t*)(ip + toff8);
+                const half8m_t o8 = *(const half8m_t*)(xo + (16 * hf + l15) * 8 + ((jj + (kq >> 1) + 1) * LC + px + (kq & 1)) * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wimg32[0], __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wimg32[1], __builtin_shufflevector(t8, t8, 0, 1, 2, 3, 4, 5, 6, 7), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wo32[px], o8, acc, 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const half4_t a = *(const half4_t*)(ximg + ibase + (2 * jj * IC + px) * 4 + toff[m]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wimg[m], a, acc, 0, 0, 0);
-            }
+                for (int m = 0; m < 3; ++m) {
+                    const half4_t a = *(const half4_t*)(ximg + ibase + (2 * jj * IC + px) * 4 + toff[m]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wimg[m], a, acc, 0, 0, 0);
+                }
 #pragma unroll
-            for (int a2 = 0; a2 < 2; ++a2) {
-                const half4_t a = *(const half4_t*)(xo + obase + ((jj + a2 + 1) * LC + px) * 8);
-                acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wo[px][a2], a, acc, 0, 0, 0);
+                for (int a2 = 0; a2 < 2; ++a2) {
+                    const half4_t a = *(const half4_t*)(xo + obase + ((jj + a2 + 1) * LC + px) * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(wo[px][a2], a, acc, 0, 0, 0);
+                }
             }
             half4_t hv = __builtin_convertvector(acc, half4_t);
             hv = __builtin_elementwise_max(hv, hv * (_Float16)0.01f);      // LeakyReLU on the packed halves
