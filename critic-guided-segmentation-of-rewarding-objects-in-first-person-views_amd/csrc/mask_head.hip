@@ -67,7 +67,11 @@ struct MHeadGeo {
     static constexpr int W4P = 24 * 16 * 16;                           // pair-folded masker.0 weights [4x6 pos][oc][2x8]
     static constexpr int LR = TH / 2 + 2, LC = W / 2 + 2;              // o0 tile at its own resolution
     static constexpr int XIMG = W0 ? TRA * PW * 4 : 0, XO = W0 ? LR * LC * 8 : 0;   // masker.0 inputs (image [r,g,b,0])
-    static constexpr int FLOATS = 2 * XT + XIMG + XO + W4P + DZ;      // the dH tile is double buffered
+    // (round 6) ONE workgroup barrier per tile: the dzpre tile and masker.0's input tiles are double buffered like the dH tile, so the builder
+    // waves write tile i + 1's dzpre and tile i's inputs at the END of their phase (into the buffers nobody reads in this iteration) and the
+    // barrier that used to separate "dzpre tile -> LDS" from the rebuild is gone -- by the stamps the matrix waves stood 0.9 k cycles of a
+    // 13.7 k tile at it while the builders staged.  134.7 -> 155.0 KB of LDS (one workgroup per CU either way).
+    static constexpr int FLOATS = 2 * XT + 2 * XIMG + 2 * XO + W4P + 2 * DZ;      // every tile buffer is double buffered
     static constexpr size_t LDS = (size_t)((FLOATS + 3) / 4) * 16;
     // reduction buffers (floats into the dH tiles, used after the last tile)
     static constexpr int RED2 = 0, REDA = 1024, REDB = REDA + 4 * 32 * 16, RED_END = REDB + 4 * 4 * 32 * 16;
@@ -77,7 +81,7 @@ struct MHeadGeo {
 struct MHeadLds { float *xt0, *ximg, *xo, *w4p, *dz; };
 
 // ---------------------------------------------------------------------------------------------------------------
-// Builder waves (threads 0..255).  Per tile: [phase 1] dzpre tile -> LDS | barrier | [phase 2] rebuild dH | barrier
+// Builder waves (threads 0..255).  Per tile i: rebuild dH(i) from dzpre buffer i & 1, then dzpre(i + 1) and masker.0's inputs of tile i -> LDS | barrier
 // ---------------------------------------------------------------------------------------------------------------
 template <int TH, bool WG, bool W0, int SRC>
 __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MHeadLds& L, const int btid, const int T,
@@ -151,15 +155,16 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             dzr[it] = P.dzpre[in ? (n0 * H + y) * W + x : 0];
         }
     };
-    auto store_dz = [&](int tile) {
+    auto store_dz = [&](int tile, int buf) {
         const int row0 = (tile % G::STRIPS) * TH;
+        float* const dzb = L.dz + buf * G::DZ;
 #pragma unroll
         for (int it = 0; it < DIT; ++it) {
             int e = btid + it * 256;
             e = e < G::DZ ? e : G::DZ - 1;
             int y = row0 + e / DZW - 2, x = e % DZW - 2;
             bool in = y >= 0 && y < H && x >= 0 && x < W;
-            L.dz[e] = in ? dzr[it] : 0.f;
+            dzb[e] = in ? dzr[it] : 0.f;
         }
     };
 
@@ -195,8 +200,10 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             rb[it] = ((const float4*)P.o0)[in ? ((n0 * (H / 2) + ly) * (W / 2) + lx) * 2 + half : 0];
         }
     };
-    auto commit_x = [&](int tile) {
+    auto commit_x = [&](int tile, int buf) {
         const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
+        float4* const ximg4 = (float4*)(L.ximg + buf * G::XIMG);
+        float4* const xo4 = (float4*)(L.xo + buf * G::XO);
 #pragma unroll
         for (int it = 0; it < ITA; ++it) {
             int e = btid + it * 256; e = e < NPIX ? e : NPIX - 1;
@@ -211,7 +218,7 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
                 v = make_float4((float)(b3 & 255u) * sc, (float)((b3 >> 8) & 255u) * sc, (float)((b3 >> 16) & 255u) * sc, 0.f);
             }
             v.w = 0.f;
-            ((float4*)L.ximg)[e] = in ? v : f4zero();
+            ximg4[e] = in ? v : f4zero();
         }
 #pragma unroll
         for (int it = 0; it < ITB; ++it) {
@@ -219,26 +226,23 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             int pc = (e >> 1) % LC, pr = (e >> 1) / LC;
             int ly = row0 / 2 + pr - 1, lx = pc - 1;
             bool in = ly >= 0 && ly < H / 2 && lx >= 0 && lx < W / 2;
-            ((float4*)L.xo)[e] = in ? rb[it] : f4zero();       // [pr][pc][8]: e = (pr*LC + pc)*2 + half
+            xo4[e] = in ? rb[it] : f4zero();       // [pr][pc][8]: e = (pr*LC + pc)*2 + half
         }
     };
     load_dz(tile_of(0));
     load_h(tile_of(0));
+    store_dz(tile_of(0), 0);
+    __syncthreads();                                       // once per workgroup (the matrix waves run the same one): tile 0's dzpre is in LDS
 
     [[maybe_unused]] unsigned long long tp = MH_T(), s_p1 = 0, s_w1 = 0, s_p2 = 0, s_w2 = 0;
     for (int i = 0; i <= T; ++i) {
-        store_dz(tile_of(i));
-        if constexpr (W0) {
-            if (i > 0) commit_x(tile_of(i - 1));           // read by the matrix waves' weight-gradient GEMM of tile i-1 in this iteration's phase 2
-        }
-        [[maybe_unused]] const unsigned long long ta = MH_T();
-        __syncthreads();                                   // barrier 1 of tile i
         [[maybe_unused]] const unsigned long long tb = MH_T();
+        [[maybe_unused]] unsigned long long tc = tb;
         if (i < T) {
             const int tile = tile_of(i);
             const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
             float* xt = L.xt0 + (i & 1) * G::XT;
-            const float* dz = L.dz;
+            const float* dz = L.dz + (i & 1) * G::DZ;
             load_dz(tile_of(i + 1));      // in flight during the rebuild
             if constexpr (W0) fetch_x(tile);               // committed in the next phase 1
             __builtin_amdgcn_sched_barrier(0);
@@ -336,10 +340,16 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
             }
             load_h(tile_of(i + 1));       // in flight until the next rebuild (requested at the START of this rebuild into a second register set, it
                                           // measured no faster: the rebuild does not wait for memory)
+            tc = MH_T();
+            // the NEXT tile's dzpre (requested at the start of this rebuild) and THIS tile's masker.0 inputs (for the matrix waves' weight-gradient
+            // GEMM of tile i in the next iteration) go into the buffers of parity i + 1 / i: the matrix waves read the inputs of parity i - 1 now,
+            // this thread's neighbours the dzpre of parity i -- the barrier below is the only one of the tile
+            store_dz(tile_of(i + 1), (i + 1) & 1);
+            if constexpr (W0) commit_x(tile, i & 1);
         }
-        [[maybe_unused]] const unsigned long long tc = MH_T();
-        __syncthreads();                                   // barrier 2 of tile i
-        if (CGS_STAMP_PTR(P.dbg)) { const unsigned long long td = MH_T(); s_p1 += ta - tp; s_w1 += tb - ta; s_p2 += tc - tb; s_w2 += td - tc; tp = td; }
+        [[maybe_unused]] const unsigned long long te = MH_T();
+        __syncthreads();                                   // the barrier of tile i
+        if (CGS_STAMP_PTR(P.dbg)) { const unsigned long long td = MH_T(); s_p1 += te - tc; s_p2 += tc - tb; s_w2 += td - te; tp = td; }
     }
     if (CGS_STAMP_PTR(P.dbg) && btid == 0) {
         unsigned long long* o = CGS_STAMP_PTR(P.dbg) + (size_t)bid * 16;
@@ -369,8 +379,8 @@ __device__ __forceinline__ void mask_head_builder(const MHeadParams& P, const MH
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Matrix waves (threads 256..511; mtid = 0..255).  Per tile i: [phase 1] nothing (round 6: the builder waves stage masker.0's inputs) | barrier |
-// [phase 2] data-gradient and weight-gradient GEMMs of tile i-1 | barrier
+// Matrix waves (threads 256..511; mtid = 0..255).  Per tile i: data-gradient and weight-gradient GEMMs of tile i-1 (round 6: the builder waves
+// stage masker.0's inputs) | barrier
 // ---------------------------------------------------------------------------------------------------------------
 template <int TH, bool W0, int SRC>
 __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHeadLds& L, const int mtid, const int T,
@@ -399,15 +409,17 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     const float m1 = (16 + l15 < 27) ? 1.f : 0.f, m0 = (16 + l15 == 27) ? 1.f : 0.f;   // second row block: valid / bias / pad
 
     [[maybe_unused]] unsigned long long tp = MH_T(), s_p1 = 0, s_w1 = 0, s_dg = 0, s_wg = 0, s_w2 = 0, tm = 0;
+    __syncthreads();                                       // (the builders' once-per-workgroup barrier behind tile 0's dzpre)
     for (int i = 0; i <= T; ++i) {
-        // (phase 1 of the matrix waves is empty since round 6: the builder waves stage masker.0's input tiles)
+        // (the matrix waves stage nothing since round 6 -- the builder waves stage masker.0's input tiles -- and meet the builders at ONE barrier per tile)
         [[maybe_unused]] const unsigned long long ta = MH_T();
-        __syncthreads();                                   // barrier 1 of tile i
-        [[maybe_unused]] const unsigned long long tb = MH_T();
+        [[maybe_unused]] const unsigned long long tb = ta;
         if (i > 0) {
             const int tile = tile_of(i - 1);
             const int n0 = tile / G::STRIPS, row0 = (tile % G::STRIPS) * TH;
             const float* xt = L.xt0 + ((i - 1) & 1) * G::XT;
+            [[maybe_unused]] const float* const ximg = L.ximg + ((i - 1) & 1) * G::XIMG;
+            [[maybe_unused]] const float* const xo = L.xo + ((i - 1) & 1) * G::XO;
             // Operands come from LDS one group AHEAD of the MFMAs that use them (register double buffer): a wave issues
             // in order, so reads placed after a group's MFMAs would only start once the last of them has issued and the
             // matrix pipe would idle for a full LDS round trip per group.  A group must stay below 16 LDS instructions:
@@ -490,11 +502,11 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int u = 0; u < UU; ++u) ai[buf][u][q] = L.ximg[ib + rimg[q] + (yl * PW + px + 8 * (s0 + u)) * 4];
+                        for (int u = 0; u < UU; ++u) ai[buf][u][q] = ximg[ib + rimg[q] + (yl * PW + px + 8 * (s0 + u)) * 4];
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int u = 0; u < UU; ++u) ao[buf][u][q] = L.xo[ob + ((mwave + q + py) * LC + px + 4 * (s0 + u)) * 8];
+                        for (int u = 0; u < UU; ++u) ao[buf][u][q] = xo[ob + ((mwave + q + py) * LC + px + 4 * (s0 + u)) * 8];
                 };
                 ld(0, 0);
 #pragma unroll
@@ -517,10 +529,10 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
             }
         }
         [[maybe_unused]] const unsigned long long tc = MH_T();
-        __syncthreads();                                   // barrier 2 of tile i
+        __syncthreads();                                   // the barrier of tile i
         if (CGS_STAMP_PTR(P.dbg)) {
             const unsigned long long td = MH_T();
-            s_p1 += ta - tp; s_w1 += tb - ta; s_w2 += td - tc; tp = td;
+            s_w2 += td - tc; tp = td;
             if (i > 0) { s_dg += tm - tb; s_wg += tc - tm; } else s_dg += tc - tb;
         }
     }
@@ -554,10 +566,10 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     extern __shared__ __attribute__((aligned(16))) float4 smem[];
     MHeadLds L;
     L.xt0 = (float*)smem;              // dH tiles [2][TRA][PW][PS]
-    L.ximg = L.xt0 + 2 * G::XT;        // masker.0 image tile [TRA][PW][r,g,b,0] (W0)
-    L.xo = L.ximg + G::XIMG;           // masker.0 low-resolution input tile [LR][LC][8] (W0)
-    L.w4p = L.xo + G::XO;              // pair-folded weights [u 0..3][v6 0..5][oc][8*g + c]
-    L.dz = L.w4p + G::W4P;             // dzpre tile with a 2-pixel halo
+    L.ximg = L.xt0 + 2 * G::XT;        // masker.0 image tiles [2][TRA][PW][r,g,b,0] (W0)
+    L.xo = L.ximg + 2 * G::XIMG;       // masker.0 low-resolution input tiles [2][LR][LC][8] (W0)
+    L.w4p = L.xo + 2 * G::XO;          // pair-folded weights [u 0..3][v6 0..5][oc][8*g + c]
+    L.dz = L.w4p + G::W4P;             // dzpre tiles [2] with a 2-pixel halo
     const int tid = threadIdx.x;
     [[maybe_unused]] const unsigned long long t_start = MH_T();
 
@@ -603,7 +615,7 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     const int grid = gridDim.x, bid = blockIdx.x;
     const int T = (P.ntiles - bid + grid - 1) / grid;      // tiles of this workgroup: bid, bid+grid, ...
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) { CGS_STAMP_PTR(P.dbg)[(size_t)bid * 16 + 5] = t_start; CGS_STAMP_PTR(P.dbg)[(size_t)bid * 16 + 6] = MH_T(); }
-    // SCALAR role branch: whole waves take one side, both sides execute 2*(T+1) workgroup barriers
+    // SCALAR role branch: whole waves take one side, both sides execute 1 + (T+1) workgroup barriers
     if (__builtin_amdgcn_readfirstlane(tid) < 256) mask_head_builder<TH, WG, W0, SRC>(P, L, tid, T, bid, grid);
     else mask_head_matrix<TH, W0, SRC>(P, L, tid - 256, T, bid, grid);
     __syncthreads();
