@@ -193,9 +193,15 @@ __global__ void __launch_bounds__(256) CGS_MIX_OCC enc0_bwd_mix_kernel(WgradPara
     const int bm = bx - ((R1 && bx >= r_lo) ? nbw1 : 0);       // index among the launch's own roles
     if (bm < nbw) {
         constexpr int SLAB = (9 * 3 + 1) * 8;
+#ifdef CGS_WHATIF_MIX_NOW      // (timing experiments only: wrong results) one role of the launch compiled out
+        if (pw.n >= 0) return;
+#endif
         wgrad_dispatch<CWG, SPARSE>(pw, bm, nbw, pw.ntiles, pw.slab + (size_t)bm * SLAB, smem);
         return;
     }
+#ifdef CGS_WHATIF_MIX_NOD
+    if (pw.n >= 0) return;
+#endif
     const int bid = bm - nbw;
     pd.mix_a = M.a; pd.mix_b = M.b; pd.mix_z = M.z; pd.mix_dz = M.dzpre; pd.mix_l1s = M.l1s; pd.mix_l2s = M.l2s; pd.mix_vf_pred = M.vf_pred;
     pd.mix_inject = M.inject;
