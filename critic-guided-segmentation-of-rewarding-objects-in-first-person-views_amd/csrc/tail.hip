@@ -17,6 +17,7 @@
 // Dropout: the same Philox indexing as the per-layer kernels (site, element / 4 + base), so cgs_dropout_mask exports the
 // masks these kernels draw.
 #include "tail4.h"
+#include "tail_h16.h"
 #include "head_wgrad.h"
 #include "wgrad_dec0.h"
 #include "conv_body.h"
@@ -116,8 +117,10 @@ using X2P = TileP<8, 8, 8, 8, 84>;        // dropout(e2)
 // ENC0 (with FUSED): 1 / 2 = features.0 of the image as well (uint8 frames / the virtual replaced | injected mixes: four 16-row strips,
 // conv3x3_body_pipe<FEnc0U8P / FEnc0MixP>; e0 + am0 to memory as before, features.3 reads that e0 back): the whole critic forward of an
 // image in one workgroup.
-template <bool FUSED, int ENC0 = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) tail_enc_fwd_kernel(TailEncFwdParams P, ConvParams PC, ConvParams PC0) {
+// H16 (round 6, config 4, stand-alone form only): features.6 / features.10 with fp16 operands on v_mfma_f32_16x16x16_f16 (tail_h16.h)
+template <bool FUSED, int ENC0 = 0, bool H16 = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H16 ? 3 : 4, H16 ? 3 : 4))) tail_enc_fwd_kernel(TailEncFwdParams P, ConvParams PC, ConvParams PC0) {
+    static_assert(!H16 || (!FUSED && ENC0 == 0), "fp16 operands: the stand-alone inference form");
     extern __shared__ __attribute__((aligned(16))) float4 conv_smem[];       // FUSED: the convolution's tiles + weights
     __shared__ __attribute__((aligned(16))) float x1[X1P::FLOATS];
     __shared__ __attribute__((aligned(16))) float x2[X2P::FLOATS];
@@ -157,9 +160,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         conv3x3_body_pipe<FEnc1P>(PC, 2 * (int)blockIdx.x, conv_smem, PoolLds{x1, X1P::PITCH, X1P::PS});
     }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_memtime();
-    float wr6[2][5], wr10[1][5];
-    fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
-    fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
+    [[maybe_unused]] float wr6[H16 ? 1 : 2][5], wr10[1][5];
+    [[maybe_unused]] th4_t w6h[5], w10h[5];
+    [[maybe_unused]] int off6[5], off10[5];
+    if constexpr (H16) {
+        const int l15w = lane & 15;
+        h16_fill_w<8, 5, 1>(w6h, lane, 0, l15w < 8, [&](int tap, int c) { return P.w.w6[(tap * 8 + c) * 8 + (l15w & 7)]; });
+        h16_fill_w<8, 5, 1>(w10h, lane, 0, true, [&](int tap, int c) { return P.w.w10[(tap * 8 + c) * 16 + l15w]; });
+        h16_fill_off<X1P, 8, 5, 1>(off6, lane, 0);
+        h16_fill_off<X2P, 8, 5, 1>(off10, lane, 0);
+    } else {
+        fill_wreg<2, 5, 72>(wr6, lane, [&](int step, int co) { return P.w.w6[step * 8 + co]; });
+        fill_wreg<1, 5, 72>(wr10, lane, [&](int step, int co) { return P.w.w10[step * 16 + 4 * wave + co]; });
+    }
     if (CGS_STAMP_PTR(P.dbg) && tid == 0) CGS_STAMP_PTR(P.dbg)[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memtime();
     float w1r[4], wpr[4];
 #pragma unroll
@@ -190,7 +203,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         }
         TAIL_STAMP(2);
         // ---- features.6 + ReLU + pool: this wave's 64 pixels, all 8 channels ----
-        {
+        if constexpr (H16) {
+            // four 16-pixel tiles per wave; D[pixel 4 kq + r][channel l15]: a lane's four values are one 2x2 quad = one pooled pixel
+            const int l15 = lane & 15, kq = lane >> 4;
+            const float b6v = b6c[l15 & 7];
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                const int t = wave + 4 * u;
+                int y, x;
+                h16_tile_px<16>(t, l15, y, x);
+                const frag4 acc = h16_conv<5>(x1 + X1P::at(y - 1, x - 1), off6, w6h, frag4{0.f, 0.f, 0.f, 0.f});
+                uint32_t idx;
+                const float m = pool_quad(acc, b6v, idx);
+                const int q = 4 * t + kq;
+                const uint32_t word = pack_nibbles(idx, l15);       // (lanes 8 .. 15 of a row hold padding columns: their group's word is never stored)
+                if (l15 < 8) {
+                    P.e2[((size_t)img * 64 + q) * 8 + l15] = m;
+                    x2[X2P::at(q >> 3, q & 7) + l15] = m;
+                    if (l15 == 0) P.am2[(size_t)img * 64 + q] = word;
+                }
+            }
+        } else {
             frag4 a6[2] = {frag4{0.f, 0.f, 0.f, 0.f}, frag4{0.f, 0.f, 0.f, 0.f}};
             conv_px<X1P, 0, 8, 8, 0, 2, 5>(a6, x1, pa.y, pa.x, wr6);
             float m[8];
@@ -231,7 +264,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         __syncthreads();
         TAIL_STAMP(4);
         // ---- features.10 + ReLU + pool: all 64 pixels of the 8x8 map, this wave's 4 output channels ----
-        {
+        if constexpr (H16) {
+            // one 16-pixel tile per wave, all 16 output channels (column l15)
+            const int l15 = lane & 15, kq = lane >> 4;
+            int y, x;
+            h16_tile_px<8>(wave, l15, y, x);
+            const frag4 acc = h16_conv<5>(x2 + X2P::at(y - 1, x - 1), off10, w10h, frag4{0.f, 0.f, 0.f, 0.f});
+            uint32_t idx;
+            const float m = pool_quad(acc, b10c[l15], idx);
+            const int q = 4 * wave + kq;                             // pooled pixel of the 4x4 map
+            const uint32_t word = pack_nibbles(idx, l15);           // channels 8 g .. 8 g + 7: word g of the pixel
+            P.e3[((size_t)img * 16 + q) * 16 + l15] = m;
+            xs[q * 16 + l15] = m;                                   // (eval mode: no Dropout in front of features.14)
+            if ((l15 & 7) == 0) P.am3[((size_t)img * 16 + q) * 2 + (l15 >> 3)] = word;
+        } else {
             frag4 a10[1] = {frag4{0.f, 0.f, 0.f, 0.f}};
             conv_px<X2P, 0, 8, 8, 0, 1, 5>(a10, x2, pb.y, pb.x, wr10);
             float m[4];
@@ -330,6 +376,21 @@ extern "C" int cgs_tail_enc_fwd(int32_t n, const cgs_tail_enc_weights* w, const 
     TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, drop_e2, drop_e3, drop_h1, n, tail_blocks(n, tail_fwd_cap()), g_tail_stamps ? g_tail_stamps + 0 * 2048 * 16 : nullptr};
     const int blocks = P.nblocks;
     hipLaunchKernelGGL((tail_enc_fwd_kernel<false, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, ConvParams{});
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// cgs_tail_enc_fwd in eval mode with fp16 OPERANDS in features.6 / features.10 (fp32 accumulation, fp32 tensors in and out; BASELINE config 4:
+// the -process path with fp16 conv kernels, nets.py:176-194 in eval mode).  Dropout is not supported here: CGS_ERR_UNSUPPORTED when any p > 0.
+extern "C" int cgs_tail_enc_fwd_h16(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
+                                    uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !am2 || !e3 || !am3 || !e4 || !h1 || !pred) return CGS_ERR_BADARG;
+    if (!w->w6 || !w->b6 || !w->w10 || !w->b10 || !w->w14 || !w->b14 || !w->wl1 || !w->bl1 || !w->wl2 || !w->bl2) return CGS_ERR_BADARG;
+    if (o4 && (!w->wpw || !w->bpw)) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const cgs_dropout nd{};
+    TailEncFwdParams P{*w, e1, e2, am2, e3, am3, e4, h1, pred, o4, nd, nd, nd, n, tail_blocks(n, 768), nullptr};      // (three workgroups per CU)
+    hipLaunchKernelGGL((tail_enc_fwd_kernel<false, 0, true>), dim3(P.nblocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{}, ConvParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
@@ -436,14 +497,17 @@ using T1F = TileP<16, 16, 16, 16, 292>;     // cat(e1, up(o2)) of the forward de
 
 // FUSED (round 4): one workgroup per image; after the tail stages (o1 written) the same workgroup runs dec_model.0 of ITS image
 // (conv3x3_body_pipe<FDec0P>: cat(e0, up(o1)) -> o0), every other co-resident workgroup ~4 us late (cgs_stagger).
-template <bool FUSED>
+// H16 (round 6, config 4, stand-alone form only): the three layers with fp16 operands on v_mfma_f32_16x16x16_f16 (tail_h16.h)
+template <bool FUSED, bool H16 = false>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) tail_dec_fwd_kernel(TailDecFwdParams P, ConvParams PC) {
+    static_assert(!H16 || !FUSED, "fp16 operands: the stand-alone inference form");
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailDecFwdParams) + sizeof(ConvParams)>();
     extern __shared__ __attribute__((aligned(16))) float4 dec_conv_smem[];     // FUSED: dec_model.0's tiles + weights
     __shared__ __attribute__((aligned(16))) float t1[T1F::FLOATS];
     __shared__ __attribute__((aligned(16))) float t2[T8x24::FLOATS];
     __shared__ __attribute__((aligned(16))) float t3[T4x48::FLOATS];
-    __shared__ __attribute__((aligned(16))) float w2s[216 * 8];
+    __shared__ __attribute__((aligned(16))) float w2s[14 * 64 * 2];       // dec_model.2's weights [216][8] (H16: the fp16 operand table [14][64] x 8 bytes)
+    static_assert(14 * 64 * 2 >= 216 * 8, "either form fits");
     __shared__ float part[4][16][16];       // dec_model.3: the waves split K, partial [pixel][co]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if ((int)blockIdx.x == P.nblocks) {          // the rider workgroup (launched only when m0_pack is given)
@@ -469,15 +533,39 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     //  in front of the register images' loads -- three dependent round trips per workgroup, the whole launch in lockstep)
     const float4 w2a = ((const float4*)P.w.w2)[tid], w2b = ((const float4*)P.w.w2)[tid + 256 < 216 * 8 / 4 ? tid + 256 : 0];      // (scalars: a small array here lands in scratch)
     // dec_model.1 on v_mfma_f32_4x4x1 with lane = pixel (tail4.h): both channel groups' weights in 18 registers
-    float wr1[2][9];
-    fill_wreg<2, 9, 144>(wr1, lane, [&](int step, int co) { return P.w.w1[step * 8 + co]; });
+    [[maybe_unused]] float wr1[2][H16 ? 1 : 9];
+    // H16: dec_model.3's 27 instructions dealt to the waves (i = wave, wave + 4, ...), dec_model.2's 14 and dec_model.1's 9 per tile in every wave
+    // (dec_model.3's and dec_model.1's operands in registers -- 16- and 48-channel taps: their A offsets fold to constants + 4 kq --, dec_model.2's
+    //  in an LDS table [14][64 lanes] in place of the fp32 weights: one tile per wave and image reads it once)
+    [[maybe_unused]] th4_t w3h[7], w1h[9];
+    [[maybe_unused]] int off2[14];
+    [[maybe_unused]] th4_t w2t[H16 ? 4 : 1];          // this thread's entries of the table (14 x 64 = 3.5 x 256)
+    if constexpr (H16) {
+        h16_fill_w<48, 7, 4>(w3h, lane, wave, true, [&](int tap, int c) { return P.w.w3[(tap * 48 + c) * 16 + l15]; });
+        h16_fill_w<16, 9, 1>(w1h, lane, 0, l15 < 8, [&](int tap, int c) { return P.w.w1[(tap * 16 + c) * 8 + (l15 & 7)]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + 256 * r, i = e >> 6, ln = e & 63;       // (i = 14, 15: zero operands, never stored)
+            w2t[r] = h16_w1<24>(i, ln >> 4, (ln & 15) < 8, [&](int tap, int c) { return P.w.w2[(tap * 24 + c) * 8 + (ln & 7)]; });
+        }
+        h16_fill_off<T8x24, 24, 14, 1>(off2, lane, 0);
+    } else {
+        fill_wreg<2, 9, 144>(wr1, lane, [&](int step, int co) { return P.w.w1[step * 8 + co]; });
+    }
     const float b2 = P.w.b2[l15 & 7];
+    [[maybe_unused]] const float b1v = P.w.b1[l15 & 7];
     __builtin_amdgcn_sched_barrier(0);       // (the loads above stay above: the scheduler sinks them to their first use otherwise)
     tilep_zero<T1F>(t1, tid);
     tile_zero<T8x24>(t2, tid);
     tile_zero<T4x48>(t3, tid);
-    ((float4*)w2s)[tid] = w2a;
-    if (tid + 256 < 216 * 8 / 4) ((float4*)w2s)[tid + 256] = w2b;
+    if constexpr (H16) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (tid + 256 * r < 14 * 64) ((th4_t*)w2s)[tid + 256 * r] = w2t[r];
+    } else {
+        ((float4*)w2s)[tid] = w2a;
+        if (tid + 256 < 216 * 8 / 4) ((float4*)w2s)[tid + 256] = w2b;
+    }
     const PxPos pa = px16(wave, lane);
     const cgs_cptr b1c = cgs_to_const(P.w.b1);
     __syncthreads();
@@ -508,7 +596,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
         TAIL_STAMP(2);
         // ---- dec_model.3: one 16-pixel tile, K = 9 x 48; wave w takes channels 12w .. 12w+11 of every tap ----
-        {
+        if constexpr (H16) {
+            int y, x;
+            h16_tile_px<4>(0, l15, y, x);
+            const frag4 acc = h16_conv_f<7>(t3 + T4x48::at(y - 1, x - 1) + 4 * kq, [&](int n) { return h16_off<T4x48, 48>(wave + 4 * n, 0); },
+                                             [&](int n) { return w3h[n]; }, frag4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[wave][4 * kq + j][l15] = acc[j];
+        } else {
             const int q = l15 >> 2, y = 2 * (q >> 1) + ((l15 >> 1) & 1), x = 2 * (q & 1) + (l15 & 1);
             const int abase = (y * T4x48::PW + x) * 48 + 12 * wave + kq;
             const float* wg = P.w.w3 + (12 * wave + kq) * 16 + l15;
@@ -536,26 +631,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         __syncthreads();
         TAIL_STAMP(4);
         // ---- dec_model.2: 4 tiles ----
-        conv_tiles<T8x24, 0, 24, 1>(
-            t2, [&](int tap, int c, int) { return w2s[(tap * 24 + c) * 8 + (l15 & 7)]; },
-            [&](int q, const frag4 (&acc)[1]) {
-                if (l15 < 8) {
-                    const int qy = q >> 2, qx = q & 3;
+        auto epi2 = [&](int q, const frag4 (&acc)[1]) {
+            if (l15 < 8) {
+                const int qy = q >> 2, qx = q & 3;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int y = 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
-                        const float v = acc[0][j] + b2;
-                        P.o2[((size_t)img * 64 + y * 8 + x) * 8 + l15] = v;
+                for (int j = 0; j < 4; ++j) {
+                    const int y = 2 * qy + (j >> 1), x = 2 * qx + (j & 1);
+                    const float v = acc[0][j] + b2;
+                    P.o2[((size_t)img * 64 + y * 8 + x) * 8 + l15] = v;
 #pragma unroll
-                        for (int d = 0; d < 4; ++d) t1[T1F::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + l15] = v;
-                    }
+                    for (int d = 0; d < 4; ++d) t1[T1F::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + l15] = v;
                 }
-            },
-            wave, lane_i);
+            }
+        };
+        if constexpr (H16) {
+            int y, x;
+            h16_tile_px<8>(wave, l15, y, x);
+            const frag4 acc[1] = {h16_conv_f<14>(t2 + T8x24::at(y - 1, x - 1), [&](int n) { return off2[n]; },
+                                               [&](int n) { return ((const th4_t*)w2s)[n * 64 + lane_i]; }, frag4{0.f, 0.f, 0.f, 0.f})};
+            epi2(4 * wave + kq, acc);
+        } else {
+            conv_tiles<T8x24, 0, 24, 1>(t2, [&](int tap, int c, int) { return w2s[(tap * 24 + c) * 8 + (l15 & 7)]; }, epi2, wave, lane_i);
+        }
         __syncthreads();
         TAIL_STAMP(5);
         // ---- dec_model.1: this wave's 64 pixels, all 8 channels ----
-        {
+        if constexpr (H16) {
+            // four 16-pixel tiles per wave; D[pixel 4 kq + j][channel l15]: lanes l15 < 8 store their channel of the quad's four pixels
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u) {
+                const int t = wave + 4 * u;
+                int y, x;
+                h16_tile_px<16>(t, l15, y, x);
+                const frag4 acc = h16_conv_f<9>(t1 + T1F::at(y - 1, x - 1) + 4 * kq, [&](int n) { return h16_off<T1F, 16>(n, 0); },
+                                                 [&](int n) { return w1h[n]; }, frag4{b1v, b1v, b1v, b1v});
+                if (l15 < 8) {
+                    const int q = 4 * t + kq, qy = q >> 3, qx = q & 7;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        P.o1[((size_t)img * 256 + (2 * qy + (j >> 1)) * 16 + 2 * qx + (j & 1)) * 8 + l15] = acc[j];
+                }
+            }
+        } else {
             frag4 a[2] = {frag4{b1c[0], b1c[1], b1c[2], b1c[3]}, frag4{b1c[4], b1c[5], b1c[6], b1c[7]}};
             conv_px<T1F, 0, 16, 16, 0, 2, 9, false, true>(a, t1, pa.y, pa.x, wr1);
             float4* dst = (float4*)(P.o1 + ((size_t)img * 256 + pa.y * 16 + pa.x) * 8);
@@ -602,6 +719,20 @@ extern "C" int cgs_tail_dec_fwd_dec0(int32_t n, const cgs_tail_dec_weights* w, c
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(conv_lds_bytes<FDec0P>()));
     if (attr != hipSuccess) return (int)attr;
     hipLaunchKernelGGL(tail_dec_fwd_kernel<true>, dim3(n + (m0_pack ? 1 : 0)), dim3(256), lds, (hipStream_t)stream, P, PC);
+    CGS_HIP_CHECK_LAUNCH();
+    return CGS_OK;
+}
+
+// cgs_tail_dec_fwd with fp16 OPERANDS in dec_model.3 / .2 / .1 (fp32 accumulation, fp32 tensors in and out; BASELINE config 4: nets.py:501-513 in
+// the -process path with fp16 conv kernels)
+extern "C" int cgs_tail_dec_fwd_h16(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                                    const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream) {
+    if (n < 0 || !w || !e1 || !e2 || !e3 || !o4 || !o3 || !o2 || !o1) return CGS_ERR_BADARG;
+    if (!w->w3 || !w->b3 || !w->w2 || !w->b2 || !w->w1 || !w->b1) return CGS_ERR_BADARG;
+    if (n == 0) return CGS_OK;
+    const int blocks = tail_blocks(n, tail_dec_fwd_cap());
+    TailDecFwdParams P{*w, e1, e2, e3, o4, o3, o2, o1, n, blocks, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((tail_dec_fwd_kernel<false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, P, ConvParams{});
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }

@@ -15,6 +15,7 @@ typedef float frag4 __attribute__((ext_vector_type(4)));
 template <int H_, int W_, int PCI_>
 struct Tile {
     static constexpr int H = H_, W = W_, PCI = PCI_, PW = W_ + 2, PH = H_ + 2, FLOATS = PH * PW * PCI_;
+    static constexpr int PS = PCI_, PITCH = (W_ + 2) * PCI_;      // (the names TileP uses: floats per pixel slot / per tile row)
     // interior pixel (y, x) -> float offset of its channel 0
     __device__ static __forceinline__ int at(int y, int x) { return ((y + 1) * PW + (x + 1)) * PCI; }
 };

@@ -267,6 +267,13 @@ int cgs_critic_fwd_fused(int32_t n, const cgs_tail_enc_weights* w, const void* x
                          cgs_dropout drop_h1, cgs_stream_t stream);
 int cgs_tail_dec_fwd(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                      const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
+/* (round 6, BASELINE config 4: main.py:1130-1151 with fp16 conv kernels) cgs_tail_enc_fwd in eval mode / cgs_tail_dec_fwd with fp16 OPERANDS in
+ * their 3x3 layers (features.6 / .10, nets.py:176-183; dec_model.3 / .2 / .1, nets.py:503-513) on v_mfma_f32_16x16x16_f16: fp32 accumulation,
+ * fp32 tensors in and out, the Linear layers and the head in fp32.  Used by the fused fp16 inference path only (engine.infer(fp16=True)).   */
+int cgs_tail_enc_fwd_h16(int32_t n, const cgs_tail_enc_weights* w, const float* e1, float* e2, uint32_t* am2, float* e3,
+                         uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_stream_t stream);
+int cgs_tail_dec_fwd_h16(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
+                         const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
 /* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
  * forward's weight registers m0_pack [40 * 64] (cgs_mask_train_fwd_packed).                                                     */
 int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,

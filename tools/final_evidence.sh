@@ -1,10 +1,14 @@
 #!/bin/bash
-# usage (GPU box): tools/final_evidence.sh TAG   -> everything the round's profiles/ files are made from, under gpurun_out/final/
+# usage (GPU box): tools/final_evidence.sh TAG [a|b|all]   -> everything the round's profiles/ files are made from, under gpurun_out/final/
+# (a = smoke + counter passes + kernel profiles, b = the bench lines + scaling; two gpurun calls of <= 20 min each; b expects a's counter
+#  summaries already stored under profiles/ by tools/store_evidence.sh TAG a)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
-tag=r05_${1:-x}
+tag=r06_${1:-x}
+part=${2:-all}
 mkdir -p $out
 cd $root
+if [ "$part" != "b" ]; then
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1 || { tail -5 $out/smoke.log; exit 1; }
 tools/sq_counters.sh final/pmc || exit 1
 python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.csv && python tools/traffic_from_counters.py gpurun_out/final/sq_counters.csv gpurun_out/final/traffic.json 512
@@ -17,6 +21,15 @@ tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_tra
 cp $out/traffic.json profiles/${tag}_traffic.json && sed -i "s#gpurun_out/final/sq_counters.csv#profiles/${tag}_sq_counters.csv#" profiles/${tag}_traffic.json
 cp $out/sq_counters.csv profiles/${tag}_sq_counters.csv
 cp $out/side_traffic.json profiles/${tag}_side_traffic.json
+tools/prof.sh final/prof || exit 1
+tools/prof_generic.sh final/prof_chfak5 > $out/prof_chfak5.txt 2>&1 || exit 1
+tools/prof_infer.sh final/prof_infer_f16 --fp16 > $out/prof_infer_f16.txt 2>&1 || exit 1
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_config5_train -o runc -- python3 $root/bench.py --config 5 --mode train --steps 10 --warmup 2 --prime-s 0 > $out/prof_config5_train.log 2>&1 ) || exit 1
+# SQ counters of the chfak-5 step and of config 4
+tools/sq_quick.sh final/sq_c5 --chfak 5 --mode train > $out/sq_c5.log 2>&1 && python tools/sq_any.py gpurun_out/final/sq_c5 > $out/sq_chfak5.txt 2>&1
+tools/sq_quick.sh final/sq_c4 --mode infer --fp16 --batch 2048 > $out/sq_c4.log 2>&1 && python tools/sq_any.py gpurun_out/final/sq_c4 > $out/sq_config4.txt 2>&1
+fi
+if [ "$part" != "a" ]; then
 # the default line (200 steps) and the driver's command, both with the side block and the CPU baseline
 python bench.py > $out/bench.json 2> $out/bench.err || exit 1
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd.json 2>/dev/null || exit 1
@@ -28,9 +41,8 @@ python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 > $out/bench_inf
 python bench.py --mode infer --batch 2048 --steps 50 --warmup 5 --fp16-mask-head > $out/bench_infer2048_f16head.json 2>/dev/null || exit 1
 python bench.py --mode cli-train > $out/bench_cli_train.json 2>/dev/null || exit 1
 python bench.py --mode phase1 > $out/bench_phase1.json 2>/dev/null || exit 1
+# the driver's N > 1 launch form, rehearsed on ONE rank (RCCL group of one)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_torchrun1.json 2>$out/bench_torchrun1.err || exit 1
 python tools/scaling.py --out $out/scaling.json 128 256 512 1024 > $out/scaling.txt 2>&1 || exit 1
-tools/prof.sh final/prof || exit 1
-tools/prof_generic.sh final/prof_chfak5 > $out/prof_chfak5.txt 2>&1 || exit 1
-tools/prof_infer.sh final/prof_infer_f16 --fp16 > $out/prof_infer_f16.txt 2>&1 || exit 1
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_config5_train -o runc -- python3 $root/bench.py --config 5 --mode train --steps 10 --warmup 2 --prime-s 0 > $out/prof_config5_train.log 2>&1 ) || exit 1
 tail -1 $out/bench.json | cut -c1-300
+fi
