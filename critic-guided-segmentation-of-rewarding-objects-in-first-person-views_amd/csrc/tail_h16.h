@@ -1,6 +1,6 @@
 // (round 6, BASELINE config 4: "-process inference-only, fp16 conv kernels") The tail kernels' 3x3 layers with fp16 OPERANDS on
 // v_mfma_f32_16x16x16_f16, fp32 accumulation: at batch 2048 the stand-alone decoder tail is bound by the fp32 matrix pipe (SQ counters,
-// profiles/r06_a_infer2048_fp16_sq_counters.txt: 35.9 us at 0.60 busy -- dependent chains of v_mfma_f32_16x16x4_f32, 32 cycles each, on
+// profiles/r06_config4_sq_table_before_f16_tails.txt: 35.9 us at 0.60 busy -- dependent chains of v_mfma_f32_16x16x4_f32, 32 cycles each, on
 // half-empty tiles), not by latency as at the training batch.  The fp32 LDS tiles, the epilogues and every output tensor stay as they are;
 // only the multiply changes: a lane reads FOUR consecutive channels of its pixel at a tap (one 16-byte LDS read), converts them to halves
 // (two v_cvt_pk) and one instruction covers 16 values of the flattened (tap, channel) index -- 4 x fewer matrix instructions, each a quarter
