@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcgs_hip.so")
-SOURCES = ["conv_fwd.hip", "conv_wgrad.hip", "wgrad_dec0.hip", "conv_bwd_both.hip", "mconv.hip", "mask_head.hip", "mask_fwd.hip", "head.hip", "elementwise.hip", "tail.hip", "gen.hip", "gen4.hip", "gen_train.hip", "gen_f16.hip", "gen_bf16_train.hip", "hconv.hip", "hwgrad.hip", "bn.hip", "gen_enc0.hip"]
+SOURCES = ["conv_fwd.hip", "conv_wgrad.hip", "wgrad_dec0.hip", "conv_bwd_both.hip", "mconv.hip", "mask_head.hip", "mask_fwd.hip", "head.hip", "elementwise.hip", "tail.hip", "tail_infer.hip", "gen.hip", "gen4.hip", "gen_train.hip", "gen_f16.hip", "gen_bf16_train.hip", "hconv.hip", "hwgrad.hip", "bn.hip", "gen_enc0.hip"]
 HEADERS = ["cgs_common.h", "head_wgrad.h", "conv_tile.h", "conv_body.h", "wgrad_body.h", "head_body.h", "tail_common.h", "tail4.h", "tail_h16.h", "gen_common.h", "gen4_common.h", "gen_wgrad_rows.h", "gen_wgrad_fold.h", "wgrad_dec0.h", "wgrad_sparse.h", os.path.join(REPO, "include", "cgs_hip.h")]
 ARCH = "gfx950"
 # conv_fwd / conv_bwd_both: no SLP vectorisation -- measured on the real step (profiles/r02_slp_ab_*.txt): with it the compiler pairs

@@ -30,7 +30,9 @@ def _align4(x):
 
 GATHER_ONE_LAUNCH = os.environ.get("CGS_GATHER_ONE_LAUNCH", "1") != "0"
 PHASE1_FUSED_TAIL = os.environ.get("CGS_PHASE1_FUSED_TAIL", "1") != "0"      # (A/B switch: phase 1 with phase 2's fused step tail)
-F16_TAILS = os.environ.get("CGS_F16_TAILS", "1") != "0"      # (A/B switch: config 4's tail launches with fp16 operands, csrc/tail_h16.h; 0 = the fp32 tail kernels)
+# config 4's layers between features.3 and dec_model.0: "fused" = one launch per image on fp16 tiles (csrc/tail_infer.hip), "1" = the two tail launches
+# with fp16 operands (csrc/tail_h16.h), "0" = the fp32 tail kernels (A/B switch)
+F16_TAILS = os.environ.get("CGS_F16_TAILS", "fused")
 
 
 class HourglassEngine:
@@ -565,18 +567,25 @@ class HourglassEngine:
         _lib.call("cgs_f16_enc1_fwd", b, _P(ws["e0"]), wc("features.3.weight"), wc("features.3.bias"), _P(ws["e1"]), _S())
         tw = hg.tail_enc_weights(self.fc, self.lc, (mp + 4 * self.lm.off("dec_model.4.weight"), mp + 4 * self.lm.off("dec_model.4.bias")))
         # (round 6) the tails' 3x3 layers with fp16 operands too (csrc/tail_h16.h): at this batch the fp32 decoder tail was bound by the fp32 matrix pipe
-        if F16_TAILS:
+        if F16_TAILS == "fused":
+            td = hg.tail_dec_weights(self.fm, self.lm) if want_mask else None
+            _lib.call("cgs_tail_infer_h16", b, C.byref(tw), C.byref(td) if want_mask else None, _P(ws["e1"]), _P(pred),
+                      _P(ws["o1"]) if want_mask else None, _S())
+            if not want_mask:
+                return pred, None
+        elif F16_TAILS != "0":
             _lib.call("cgs_tail_enc_fwd_h16", b, C.byref(tw), _P(ws["e1"]), _P(ws["e2"]), _P(ws["am2"]), _P(ws["e3"]), _P(ws["am3"]), _P(ws["e4"]),
                       _P(ws["h1"]), _P(pred), _P(ws["o4"]) if want_mask else None, _S())
         else:
             nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
             _lib.call("cgs_tail_enc_fwd", b, C.byref(tw), _P(ws["e1"]), _P(ws["e2"]), _P(ws["am2"]), _P(ws["e3"]), _P(ws["am3"]), _P(ws["e4"]),
                       _P(ws["h1"]), _P(pred), _P(ws["o4"]) if want_mask else None, nd, nd, nd, _S())
-        if not want_mask:
-            return pred, None
-        td = hg.tail_dec_weights(self.fm, self.lm)
-        _lib.call("cgs_tail_dec_fwd_h16" if F16_TAILS else "cgs_tail_dec_fwd", b, C.byref(td), _P(ws["e1"]), _P(ws["e2"]), _P(ws["e3"]), _P(ws["o4"]),
-                  _P(ws["o3"]), _P(ws["o2"]), _P(ws["o1"]), _S())
+        if F16_TAILS != "fused":
+            if not want_mask:
+                return pred, None
+            td = hg.tail_dec_weights(self.fm, self.lm)
+            _lib.call("cgs_tail_dec_fwd_h16" if F16_TAILS != "0" else "cgs_tail_dec_fwd", b, C.byref(td), _P(ws["e1"]), _P(ws["e2"]), _P(ws["e3"]), _P(ws["o4"]),
+                      _P(ws["o3"]), _P(ws["o2"]), _P(ws["o1"]), _S())
         _lib.call("cgs_f16_dec0_fwd", b, _P(ws["e0"]), _P(ws["o1"]), wm("dec_model.0.weight"), wm("dec_model.0.bias"), _P(ws["o0"]), _S())
         Z = torch.empty((b, 64, 64), device=dev, dtype=torch.float32)
         _lib.call("cgs_mask_infer_fwd_f16o", b, _lib.SRC_U8, _P(X), _P(ws["o0"]), wm("masker.0.weight"), wm("masker.0.bias"), wm("masker.2.weight"),

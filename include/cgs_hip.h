@@ -274,6 +274,11 @@ int cgs_tail_enc_fwd_h16(int32_t n, const cgs_tail_enc_weights* w, const float* 
                          uint32_t* am3, float* e4, float* h1, float* pred, float* o4, cgs_stream_t stream);
 int cgs_tail_dec_fwd_h16(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
                          const float* o4, float* o3, float* o2, float* o1, cgs_stream_t stream);
+/* (round 6) Both of them in ONE launch, one workgroup per image, storing only what the -process path consumes (nets.py:176-194 + 501-513 in eval
+ * mode; csrc/tail_infer.hip): e1 [n,16,16,8] -> pred [n] and o1 [n,16,16,8] (both fp32); the tiles between the layers hold halves and never leave
+ * the workgroup.  wd = NULL and o1 = NULL: the critic alone.                                                                                  */
+int cgs_tail_infer_h16(int32_t n, const cgs_tail_enc_weights* we, const cgs_tail_dec_weights* wd, const float* e1, float* pred, float* o1,
+                       cgs_stream_t stream);
 /* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
  * forward's weight registers m0_pack [40 * 64] (cgs_mask_train_fwd_packed).                                                     */
 int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,
