@@ -46,11 +46,13 @@ typedef __bf16 bbf16x8_t __attribute__((ext_vector_type(8)));
 
 // 16-bit element of the tile / operands: IEEE half (config 4) or bfloat16 (config 5)
 struct ElF16 {
+    static constexpr bool IS_F16 = true;
     using V8 = half8_t; using V4 = half4h_t; using S = _Float16;
     __device__ static __forceinline__ S cvt(float f) { return (_Float16)f; }
     __device__ static __forceinline__ frag4 mfma(V8 a, V8 b, frag4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 struct ElBF16 {
+    static constexpr bool IS_F16 = false;
     using V8 = bshort8_t; using V4 = bshort4_t; using S = short;
     __device__ static __forceinline__ S cvt(float f) { return (short)__builtin_bit_cast(unsigned short, (__bf16)f); }
     __device__ static __forceinline__ frag4 mfma(V8 a, V8 b, frag4 c) {
@@ -98,6 +100,12 @@ struct H5Cfg {
     static constexpr size_t lds = (size_t)((PH * PW * CIN + 7) & ~7) * 2;
 };
 
+// (round 6, config 4) uint8 frames into an fp16 tile WITHOUT conversions: v_perm_b32 places a byte under the exponent byte 0x3C (= 1 + b / 1024, exact),
+// one packed subtract of 1 leaves b / 1024 (as mask_infer_f16_kernel stages its frame tile, round 5); the 1024 / 255 goes into the layer's image
+// weights.  18 vector instructions per four pixels instead of ~60 (12 x byte extract + int -> float + scale + fp16 conversion, 4 packs).
+#ifndef H5_U8_PERM
+#define H5_U8_PERM 1
+#endif
 template <class C>
 __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(H5Params)>();
@@ -137,7 +145,9 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
             // (unconditional load + select: `idx >= 0 ? P.w[idx] : 0` is a branch around the load, and every one of the 8 NM NP loads is then
             //  waited for before the next is issued -- up to 72 dependent L1 / L2 round trips at the start of every workgroup)
             const float wv = P.w[idx >= 0 ? idx : 0];
-            wa[h][g][j] = EL::cvt(idx >= 0 ? wv : 0.f);
+            // (H5_U8_PERM: the uint8 frame's tile holds b / 1024, not b / 255)
+            const float wsc = (H5_U8_PERM && EL::IS_F16 && CA == 4 && CIN == 4 && !C::DGRAD && c < CA) ? 1024.f / 255.f : 1.f;
+            wa[h][g][j] = EL::cvt(idx >= 0 ? wv * wsc : 0.f);
         }
     float br[4] = {0.f, 0.f, 0.f, 0.f};
     float bl = 0.f;
@@ -196,7 +206,10 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
                 const bool in = r < PH && y >= 0 && y < HW;
                 const size_t gi = in ? (((size_t)img * HW + y) * HW + g * 4) * 3 / 4 : 0;
-                if (P.a_f32 == 2) {             // virtual mixes (main.py:395,406): image img < n / 2 = A (1 - Z) + Z B of frame pair img, else B (1 - Z) + Z A
+                if constexpr (H5_U8_PERM && EL::IS_F16 && CIN == 4) {      // (the fp16 instance: uint8 frames only, see commit below)
+                    const uint32_t* su = (const uint32_t*)P.a;
+                    ra[i][0] = make_float4(__uint_as_float(su[gi]), __uint_as_float(su[gi + 1]), __uint_as_float(su[gi + 2]), 0.f);
+                } else if (P.a_f32 == 2) {             // virtual mixes (main.py:395,406): image img < n / 2 = A (1 - Z) + Z B of frame pair img, else B (1 - Z) + Z A
                     const int half = P.n >> 1, is = img < half ? img : img - half;
                     const size_t gs = in ? (((size_t)is * HW + y) * HW + g * 4) : 0;
                     const uint32_t* sa = (const uint32_t*)P.mix_a + gs * 3 / 4;
@@ -288,6 +301,27 @@ __global__ void __launch_bounds__(256) h5conv_kernel(H5Params P) {
                 const int g = e % GW, r = e / GW, y = row0 + r - 1;
                 if (r >= PH) continue;
                 const bool in = y >= 0 && y < HW;
+                if constexpr (H5_U8_PERM && EL::IS_F16 && CIN == 4) {
+                    {          // four uint8 pixels = three dwords -> four (r, g, b, 0) half quadruples (the fp16 instance only ever reads uint8 frames:
+                               // cgs_f16_enc0_fwd; a run-time test of P.a_f32 here kept both forms' registers alive: 128 instead of 120, three waves per SIMD)
+                        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                        const uint32_t e0 = in ? __float_as_uint(ra[i][0].x) : 0u, e1 = in ? __float_as_uint(ra[i][0].y) : 0u,
+                                       e2 = in ? __float_as_uint(ra[i][0].z) : 0u;      // rows outside the image: zero bytes -> 0.0
+                        const uint32_t q1 = __builtin_amdgcn_alignbyte(e1, e0, 3), q2 = __builtin_amdgcn_alignbyte(e2, e1, 2);
+                        constexpr uint32_t K = 0x3C3C3C3Cu;       // selectors 0 .. 3: bytes of the pixel dword; 4: 0x3C; 0x0c: 0x00
+                        auto cv = [&](uint32_t q, uint32_t sel_rg, uint32_t sel_b) {
+                            const h2_t rg = __builtin_bit_cast(h2_t, __builtin_amdgcn_perm(K, q, sel_rg)) - h2_t{(_Float16)1.f, (_Float16)1.f};
+                            const h2_t b0 = __builtin_bit_cast(h2_t, __builtin_amdgcn_perm(K, q, sel_b)) - h2_t{(_Float16)1.f, (_Float16)0.f};
+                            return make_uint2(__builtin_bit_cast(uint32_t, rg), __builtin_bit_cast(uint32_t, b0));
+                        };
+                        uint2* d = (uint2*)(tile + ((size_t)r * PW + 1 + 4 * g) * CIN);
+                        d[0] = cv(e0, 0x04010400u, 0x0c0c0402u);
+                        d[1] = cv(q1, 0x04010400u, 0x0c0c0402u);
+                        d[2] = cv(q2, 0x04010400u, 0x0c0c0402u);
+                        d[3] = cv(e2, 0x04020401u, 0x0c0c0403u);
+                        continue;
+                    }
+                }
                 float f[12];
                 if (P.a_f32 == 2) {             // (the formula of cgs_mix_fwd: the fp32 mix it used to write, up to FMA contraction)
                     const uint32_t da[3] = {__float_as_uint(ra[i][0].x), __float_as_uint(ra[i][0].y), __float_as_uint(ra[i][0].z)};
@@ -511,7 +545,7 @@ using H5Dec1DL = H5Cfg< 32, 32,  8, 0,  8, 16,  8, 8, true,  EPI_POOLSUM,   CGS_
 
 extern "C" int cgs_f16_enc0_fwd(int32_t n, const uint8_t* x_u8, const float* w_hwio, const float* bias, void* e0_f16, cgs_stream_t stream) {
     if (n < 0 || !x_u8 || !w_hwio || !bias || !e0_f16) return CGS_ERR_BADARG;
-    return h5_launch<H4Enc0F>(H5Params{x_u8, nullptr, w_hwio, bias, e0_f16, nullptr, nullptr, n, 0, 0}, (hipStream_t)stream);
+    return h5_launch<H4Enc0F>(H5Params{x_u8, nullptr, w_hwio, bias, e0_f16, nullptr, nullptr, n, 0, 0 /* a_f32: this instance reads uint8 frames only (H5_U8_PERM) */}, (hipStream_t)stream);
 }
 
 extern "C" int cgs_f16_enc1_fwd(int32_t n, const void* e0_f16, const float* w_hwio, const float* bias, float* e1_f32, cgs_stream_t stream) {
