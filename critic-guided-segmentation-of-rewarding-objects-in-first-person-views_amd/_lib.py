@@ -97,6 +97,7 @@ SIGNATURES = {
     "cgs_tail_enc_fwd_h16": (i32, [i32, C.POINTER(TailEncWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_tail_dec_fwd_h16": (i32, [i32, C.POINTER(TailDecWeights), vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_tail_infer_h16": (i32, [i32, C.POINTER(TailEncWeights), C.POINTER(TailDecWeights), vp, vp, vp, vp]),
+    "cgs_f16_enc1_tail_infer": (i32, [i32, vp, vp, vp, C.POINTER(TailEncWeights), C.POINTER(TailDecWeights), vp, vp, vp]),
     "cgs_tail_dec_fwd_pack": (i32, [i32, C.POINTER(TailDecWeights), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "cgs_tail_enc_bwd_slabs": (i32, [i32]),
     "cgs_tail_enc_bwd": (i32, [i32, C.POINTER(TailEncWeights)] + [vp] * 10 + [f32, i32] + [vp] * 4 + [i32] + [vp] * 4 + [Dropout, Dropout, Dropout, vp]),

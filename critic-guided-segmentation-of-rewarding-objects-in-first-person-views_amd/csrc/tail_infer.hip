@@ -29,6 +29,7 @@ struct HTile {
 using HT1 = HTile<16, 16, 16>;      // cat(e1, up(o2))
 using HT2 = HTile<8, 8, 24>;        // cat(e2, up(o3))
 using HT3 = HTile<4, 4, 48>;        // cat(e3, up4(o4))
+using HT0 = HTile<16, 32, 8>;        // ENC1: a 16-row strip of e0 (18 x 34 pixels with the halo)
 
 template <class T>
 __device__ __forceinline__ void htile_zero(_Float16* t, int tid) {
@@ -72,13 +73,11 @@ struct TailInferParams {
     cgs_tail_dec_weights wd;
     const float* e1; float* pred; float* o1;
     int n, nblocks;
+    const float4* e0; const float* w3e; const float* b3e;      // ENC1: features.3 in front (e0 fp16 [n,32,32,8], one float4 per pixel)
 };
 
 #ifndef CGS_TAIL_INFER_W6_LDS
 #define CGS_TAIL_INFER_W6_LDS 0   // features.6's operands in an LDS table instead of 10 registers (for the 128-register build)
-#endif
-#ifndef CGS_TAIL_INFER_LATE_PREFETCH
-#define CGS_TAIL_INFER_LATE_PREFETCH 0   // the next image's e1 requested behind dec_model.3 instead of at the top of the image (8 registers less in the first stages)
 #endif
 #ifndef CGS_TAIL_INFER_OCC
 #define CGS_TAIL_INFER_OCC 3      // workgroups per CU (waves per SIMD) the kernel is compiled for.  Measured (r06_ti*.ab.txt, config 4 at batch 2048): 3 (168
@@ -86,13 +85,17 @@ struct TailInferParams {
                                   // LDS and the next image's loads late) 0.1621 .. 0.1711 ms
 #endif
 
-// DEC = false: the critic alone (infer(want_mask = False))
-template <bool DEC>
+// DEC = false: the critic alone (infer(want_mask = False)).
+// ENC1: features.3 (8 -> 8 at 32x32 + ReLU + MaxPool2d(2), nets.py:173-175) of the image in front, from the fp16 e0 that cgs_f16_enc0_fwd wrote: two 16-row
+// strips through a 9.6 KB LDS tile, the pooled map straight into tile 1 -- e1 is never stored and the cgs_f16_enc1_fwd launch disappears.
+template <bool DEC, bool ENC1>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TAIL_INFER_OCC, CGS_TAIL_INFER_OCC))) tail_infer_h16_kernel(TailInferParams P) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(TailInferParams)>();
     __shared__ __attribute__((aligned(16))) _Float16 t1[HT1::HALVES];
     __shared__ __attribute__((aligned(16))) _Float16 t2[HT2::HALVES];
     __shared__ __attribute__((aligned(16))) _Float16 t3[HT3::HALVES];
+    __shared__ __attribute__((aligned(16))) _Float16 t0[ENC1 ? HT0::HALVES : 8];
+    __shared__ __attribute__((aligned(16))) th4_t w3et[ENC1 ? 5 * 64 : 1];       // features.3's operands
     __shared__ __attribute__((aligned(16))) th4_t w10t[5 * 64];                 // features.10's operands (one tile per wave and image)
     __shared__ __attribute__((aligned(16))) th4_t w6t[CGS_TAIL_INFER_W6_LDS ? 5 * 64 : 1];
     __shared__ __attribute__((aligned(16))) th4_t w2t[DEC ? 14 * 64 : 1];       // dec_model.2's (one tile per wave and image)
@@ -103,8 +106,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
     const int o = tid & 31, kg = tid >> 5;
     int img = blockIdx.x;
-    float4 pe[2] = {f4zero(), f4zero()};
-    if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
+    float4 pe[ENC1 ? 3 : 2] = {f4zero(), f4zero()};
+    // ENC1: strip s of image im = e0 rows 16 s - 1 .. 16 s + 16 (576 pixels of 16 bytes: 2.25 per thread); rows outside the image are zeroed at the commit
+    auto fetch_strip = [&](int im, int sidx) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = tid + 256 * r, rr = e >> 5, x = e & 31, y = 16 * sidx - 1 + rr;
+            const bool in = e < 576 && y >= 0 && y < 32;
+            pe[ENC1 ? r : 0] = P.e0[in ? ((size_t)im * 32 + y) * 32 + x : 0];
+        }
+    };
+    auto commit_strip = [&](int sidx) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = tid + 256 * r, rr = e >> 5, x = e & 31, y = 16 * sidx - 1 + rr;
+            if (e < 576) *(float4*)(t0 + rr * HT0::PITCH + (x + 1) * HT0::PS) = (y >= 0 && y < 32) ? pe[ENC1 ? r : 0] : f4zero();
+        }
+    };
+    if constexpr (ENC1) {
+        if (img < P.n) fetch_strip(img, 0);
+    } else {
+        if (img < P.n) { pe[0] = ((const float4*)P.e1)[(size_t)img * 512 + tid]; pe[1] = ((const float4*)P.e1)[(size_t)img * 512 + tid + 256]; }
+    }
 
     // ---- once per workgroup, in TWO batches of loads (all at once they are 116 floats in flight per lane: spills at 128 registers): first the
     //      operand tables (36 loads -> LDS) and the tiles' zeroes (the halos stay zero: every interior element is rewritten per image), then the
@@ -120,10 +143,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
         return tap_hi ? ob : oa;
     };
     {
-        th4_t tab10[2], tab6[2], tab2[DEC ? 4 : 1], tab1[DEC ? 3 : 1];
+        th4_t tab10[2], tab6[2], tab3e[2], tab2[DEC ? 4 : 1], tab1[DEC ? 3 : 1];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int e = tid + 256 * r, i = e >> 6, ln = e & 63;
+            if constexpr (ENC1) tab3e[r] = h16_w1<8>(i, ln >> 4, (ln & 15) < 8, [&](int tap, int c) { return P.w3e[(tap * 8 + c) * 8 + (ln & 7)]; });
             tab10[r] = h16_w1<8>(i, ln >> 4, true, [&](int tap, int c) { return P.we.w10[(tap * 8 + c) * 16 + (ln & 15)]; });
             if constexpr (CGS_TAIL_INFER_W6_LDS)
                 tab6[r] = h16_w1<8>(i, ln >> 4, (ln & 15) < 8, [&](int tap, int c) { return P.we.w6[(tap * 8 + c) * 8 + (ln & 7)]; });
@@ -143,10 +167,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
         htile_zero<HT1>(t1, tid);
         htile_zero<HT2>(t2, tid);
         htile_zero<HT3>(t3, tid);
+        if constexpr (ENC1) htile_zero<HT0>(t0, tid);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
             if (tid + 256 * r < 5 * 64) {
                 w10t[tid + 256 * r] = tab10[r];
+                if constexpr (ENC1) w3et[tid + 256 * r] = tab3e[r];
                 if constexpr (CGS_TAIL_INFER_W6_LDS) w6t[tid + 256 * r] = tab6[r];
             }
         if constexpr (DEC) {
@@ -183,6 +209,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
         wpr[j] = DEC ? P.we.wpw[(kg * 4 + j) * 32 + o] : 0.f;
     }
     const float b6v = P.we.b6[l15 & 7], b10v = P.we.b10[l15];
+    [[maybe_unused]] const float b3ev = ENC1 ? P.b3e[l15 & 7] : 0.f;
     if (tid < 32) b14s[o] = P.we.b14[o];
     const float bl1 = P.we.bl1[o], wl2 = P.we.wl2[o], bl2 = P.we.bl2[0], bpw = DEC ? P.we.bpw[o] : 0.f;
     [[maybe_unused]] const float b2v = DEC ? P.wd.b2[l15 & 7] : 0.f, b1v = DEC ? P.wd.b1[l15 & 7] : 0.f;
@@ -192,6 +219,29 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
         int lz = 0;                         // opaque zero: keeps the lane-only LDS addresses from being hoisted out of the image loop
         asm volatile("" : "+v"(lz));
         const int lane_i = lane + lz;
+        if constexpr (ENC1) {
+            // ---- features.3 + ReLU + pool, two 16-row strips: commit | barrier | (the other strip's loads) | 8 tiles per wave | barrier ----
+#pragma unroll 1
+            for (int sidx = 0; sidx < 2; ++sidx) {
+                commit_strip(sidx);
+                __syncthreads();
+                if (sidx == 0) fetch_strip(img, 1);
+                else if (img + P.nblocks < P.n) fetch_strip(img + P.nblocks, 0);
+#pragma unroll 1
+                for (int u = 0; u < 8; ++u) {
+                    const int t = wave + 4 * u;
+                    int y, x;
+                    h16_tile_px<32>(t, l15, y, x);
+                    const frag4 acc = hh_conv<5>(t0 + HT0::at(y - 1, x - 1) + cq8, [&](int n) { return off8(HT0{}, n); },
+                                                 [&](int n) { return w3et[n * 64 + lane_i]; }, frag4{0.f, 0.f, 0.f, 0.f});
+                    uint32_t idx;
+                    const float m = pool_quad(acc, b3ev, idx);
+                    const int q = 4 * t + kq;                  // pool window of the strip: 8 rows of 16
+                    if (l15 < 8) t1[HT1::at(8 * sidx + (q >> 4), q & 15) + l15] = (_Float16)m;
+                }
+                __syncthreads();
+            }
+        } else {
         // ---- e1 -> the skip channels of tile 1 (512 float4 -> 512 x 4 halves); then the next image's loads ----
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -205,7 +255,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
                 pe[1] = ((const float4*)P.e1)[(size_t)(img + P.nblocks) * 512 + tid + 256];
             }
         };
-        if constexpr (!CGS_TAIL_INFER_LATE_PREFETCH || !DEC) prefetch_next();
+        prefetch_next();
+        }
         // ---- features.6 + ReLU + pool: four 16-pixel tiles per wave; a lane's four values are one 2x2 quad = one pooled pixel -> tile 2 ----
 #pragma unroll 1
         for (int u = 0; u < 4; ++u) {
@@ -302,7 +353,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
                 for (int d = 0; d < 4; ++d) t2[HT2::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + co] = v;
             }
             __syncthreads();
-            if constexpr (CGS_TAIL_INFER_LATE_PREFETCH) prefetch_next();
             // ---- dec_model.2: one tile per wave -> the upsampled channels of tile 1 ----
             {
                 int y, x;
@@ -343,18 +393,38 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
 
 }  // namespace
 
-// e1 [n,16,16,8] fp32 -> pred [n] and (wd / o1 given) o1 [n,16,16,8] fp32: the launches cgs_tail_enc_fwd_h16 + cgs_tail_dec_fwd_h16 in one, nothing
-// else stored.  wd = NULL / o1 = NULL: the critic alone.
-extern "C" int cgs_tail_infer_h16(int32_t n, const cgs_tail_enc_weights* we, const cgs_tail_dec_weights* wd, const float* e1, float* pred,
-                                  float* o1, cgs_stream_t stream) {
-    if (n < 0 || !we || !e1 || !pred || ((wd != nullptr) != (o1 != nullptr))) return CGS_ERR_BADARG;
+static int tail_infer_launch(int32_t n, const cgs_tail_enc_weights* we, const cgs_tail_dec_weights* wd, const float* e1, const void* e0_f16,
+                             const float* w3e, const float* b3e, float* pred, float* o1, cgs_stream_t stream) {
+    if (n < 0 || !we || !pred || ((wd != nullptr) != (o1 != nullptr))) return CGS_ERR_BADARG;
     if (!we->w6 || !we->b6 || !we->w10 || !we->b10 || !we->w14 || !we->b14 || !we->wl1 || !we->bl1 || !we->wl2 || !we->bl2) return CGS_ERR_BADARG;
     if (wd && (!we->wpw || !we->bpw || !wd->w3 || !wd->b3 || !wd->w2 || !wd->b2 || !wd->w1 || !wd->b1)) return CGS_ERR_BADARG;
     if (n == 0) return CGS_OK;
     const int cap = 256 * CGS_TAIL_INFER_OCC, blocks = n < cap ? n : cap;
-    TailInferParams P{*we, wd ? *wd : cgs_tail_dec_weights{}, e1, pred, o1, n, blocks};
-    if (wd) hipLaunchKernelGGL(tail_infer_h16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(tail_infer_h16_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, P);
+    TailInferParams P{*we, wd ? *wd : cgs_tail_dec_weights{}, e1, pred, o1, n, blocks, (const float4*)e0_f16, w3e, b3e};
+    const hipStream_t st = (hipStream_t)stream;
+    if (e0_f16) {
+        if (wd) hipLaunchKernelGGL((tail_infer_h16_kernel<true, true>), dim3(blocks), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((tail_infer_h16_kernel<false, true>), dim3(blocks), dim3(256), 0, st, P);
+    } else {
+        if (wd) hipLaunchKernelGGL((tail_infer_h16_kernel<true, false>), dim3(blocks), dim3(256), 0, st, P);
+        else hipLaunchKernelGGL((tail_infer_h16_kernel<false, false>), dim3(blocks), dim3(256), 0, st, P);
+    }
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
+}
+
+// e1 [n,16,16,8] fp32 -> pred [n] and (wd / o1 given) o1 [n,16,16,8] fp32: the launches cgs_tail_enc_fwd_h16 + cgs_tail_dec_fwd_h16 in one, nothing
+// else stored.  wd = NULL / o1 = NULL: the critic alone.
+extern "C" int cgs_tail_infer_h16(int32_t n, const cgs_tail_enc_weights* we, const cgs_tail_dec_weights* wd, const float* e1, float* pred,
+                                  float* o1, cgs_stream_t stream) {
+    if (!e1) return CGS_ERR_BADARG;
+    return tail_infer_launch(n, we, wd, e1, nullptr, nullptr, nullptr, pred, o1, stream);
+}
+
+// ... with features.3 in front (cgs_f16_enc1_fwd + cgs_tail_infer_h16 in one launch): e0 fp16 [n,32,32,8] (what cgs_f16_enc0_fwd writes), w3 / b3 =
+// features.3's HWIO weights [3][3][8][8] and bias (nets.py:173-175 in eval mode, fp16 operands)
+extern "C" int cgs_f16_enc1_tail_infer(int32_t n, const void* e0_f16, const float* w3, const float* b3, const cgs_tail_enc_weights* we,
+                                       const cgs_tail_dec_weights* wd, float* pred, float* o1, cgs_stream_t stream) {
+    if (!e0_f16 || !w3 || !b3) return CGS_ERR_BADARG;
+    return tail_infer_launch(n, we, wd, nullptr, e0_f16, w3, b3, pred, o1, stream);
 }

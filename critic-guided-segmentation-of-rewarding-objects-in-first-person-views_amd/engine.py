@@ -30,8 +30,11 @@ def _align4(x):
 
 GATHER_ONE_LAUNCH = os.environ.get("CGS_GATHER_ONE_LAUNCH", "1") != "0"
 PHASE1_FUSED_TAIL = os.environ.get("CGS_PHASE1_FUSED_TAIL", "1") != "0"      # (A/B switch: phase 1 with phase 2's fused step tail)
-# config 4's layers between features.3 and dec_model.0: "fused" = one launch per image on fp16 tiles (csrc/tail_infer.hip), "1" = the two tail launches
-# with fp16 operands (csrc/tail_h16.h), "0" = the fp32 tail kernels (A/B switch)
+# config 4's layers between features.0 and dec_model.0: "fused1" = features.3 .. dec_model.1 in one launch per image on fp16 tiles (csrc/tail_infer.hip),
+# "fused" = features.3 as a launch of its own (cgs_f16_enc1_fwd) + that kernel from features.6 on, "1" = ... + the two tail launches with fp16 operands
+# (csrc/tail_h16.h), "0" = ... + the fp32 tail kernels (A/B switch)
+# Measured at batch 2048 (profiles/r06_config4_fused_tail_ab.txt, r06_config4_enc1_in_tail_ab.txt): "0" 0.1819 ms, "1" 0.1685, "fused" 0.1562, "fused1" 0.1612 --
+# features.3 is a throughput-bound convolution: inside the per-image latency chain (three workgroups per CU) it costs more than as a launch of its own.
 F16_TAILS = os.environ.get("CGS_F16_TAILS", "fused")
 
 
@@ -564,10 +567,17 @@ class HourglassEngine:
         wc = lambda k: C.c_void_p(cp + 4 * self.lc.off(k))
         wm = lambda k: C.c_void_p(mp + 4 * self.lm.off(k))
         _lib.call("cgs_f16_enc0_fwd", b, _P(X), wc("features.0.weight"), wc("features.0.bias"), _P(ws["e0"]), _S())
-        _lib.call("cgs_f16_enc1_fwd", b, _P(ws["e0"]), wc("features.3.weight"), wc("features.3.bias"), _P(ws["e1"]), _S())
+        if F16_TAILS != "fused1":
+            _lib.call("cgs_f16_enc1_fwd", b, _P(ws["e0"]), wc("features.3.weight"), wc("features.3.bias"), _P(ws["e1"]), _S())
         tw = hg.tail_enc_weights(self.fc, self.lc, (mp + 4 * self.lm.off("dec_model.4.weight"), mp + 4 * self.lm.off("dec_model.4.bias")))
         # (round 6) the tails' 3x3 layers with fp16 operands too (csrc/tail_h16.h): at this batch the fp32 decoder tail was bound by the fp32 matrix pipe
-        if F16_TAILS == "fused":
+        if F16_TAILS == "fused1":
+            td = hg.tail_dec_weights(self.fm, self.lm) if want_mask else None
+            _lib.call("cgs_f16_enc1_tail_infer", b, _P(ws["e0"]), wc("features.3.weight"), wc("features.3.bias"), C.byref(tw),
+                      C.byref(td) if want_mask else None, _P(pred), _P(ws["o1"]) if want_mask else None, _S())
+            if not want_mask:
+                return pred, None
+        elif F16_TAILS == "fused":
             td = hg.tail_dec_weights(self.fm, self.lm) if want_mask else None
             _lib.call("cgs_tail_infer_h16", b, C.byref(tw), C.byref(td) if want_mask else None, _P(ws["e1"]), _P(pred),
                       _P(ws["o1"]) if want_mask else None, _S())
@@ -580,7 +590,7 @@ class HourglassEngine:
             nd = _lib.Dropout(0.0, 0, 0, None, 0, 0)
             _lib.call("cgs_tail_enc_fwd", b, C.byref(tw), _P(ws["e1"]), _P(ws["e2"]), _P(ws["am2"]), _P(ws["e3"]), _P(ws["am3"]), _P(ws["e4"]),
                       _P(ws["h1"]), _P(pred), _P(ws["o4"]) if want_mask else None, nd, nd, nd, _S())
-        if F16_TAILS != "fused":
+        if F16_TAILS not in ("fused", "fused1"):
             if not want_mask:
                 return pred, None
             td = hg.tail_dec_weights(self.fm, self.lm)

@@ -279,6 +279,10 @@ int cgs_tail_dec_fwd_h16(int32_t n, const cgs_tail_dec_weights* w, const float* 
  * the workgroup.  wd = NULL and o1 = NULL: the critic alone.                                                                                  */
 int cgs_tail_infer_h16(int32_t n, const cgs_tail_enc_weights* we, const cgs_tail_dec_weights* wd, const float* e1, float* pred, float* o1,
                        cgs_stream_t stream);
+/* ... and features.3 in front of it (cgs_f16_enc1_fwd + cgs_tail_infer_h16 in one launch; nets.py:173-175 in eval mode): e0 fp16 [n,32,32,8] as
+ * cgs_f16_enc0_fwd writes it, w3 / b3 = features.3's HWIO weights and bias; e1 is never stored.                                              */
+int cgs_f16_enc1_tail_infer(int32_t n, const void* e0_f16, const float* w3, const float* b3, const cgs_tail_enc_weights* we,
+                            const cgs_tail_dec_weights* wd, float* pred, float* o1, cgs_stream_t stream);
 /* cgs_tail_dec_fwd + (m0_pack != NULL) one extra workgroup that packs masker.0's HWIO weights w_m0 [9][11][16] into the mask head
  * forward's weight registers m0_pack [40 * 64] (cgs_mask_train_fwd_packed).                                                     */
 int cgs_tail_dec_fwd_pack(int32_t n, const cgs_tail_dec_weights* w, const float* e1, const float* e2, const float* e3,

@@ -224,6 +224,31 @@ def test_config4_batch2048_fp16_inference_vs_fp32_oracle(g1):
         assert ((Z.cpu().numpy() > 0.5) != (rz > 0.5)).mean() < 1e-3
 
 
+def test_config4_tail_launch_forms_agree(g1, monkeypatch):
+    """The four forms of the fused fp16 inference path between features.0 and dec_model.0 (engine.F16_TAILS: fp32 tail kernels, the two tail launches
+    with fp16 operands -- csrc/tail_h16.h --, one launch per image on fp16 tiles -- csrc/tail_infer.hip, the default --, and that launch with
+    features.3 in front) against each other: same frames, same weights; they differ by fp16 roundings of the 16x16-and-smaller maps only."""
+    from cgs_amd import engine
+    dev = torch.device("cuda:0")
+    pc, pm = g1
+    e = engine.HourglassEngine(8, dropout=0.0)
+    e.load_state(pc, pm)
+    rs = np.random.RandomState(4)
+    x = torch.from_numpy(rs.randint(0, 256, (300, 64, 64, 3)).astype(np.uint8)).to(dev)      # (300: not a multiple of anything the kernels tile by)
+    out = {}
+    for form in ("0", "1", "fused", "fused1"):
+        monkeypatch.setattr(engine, "F16_TAILS", form)
+        p, z = e.infer(x, fp16=True)
+        p2, _ = e.infer(x, fp16=True, want_mask=False)
+        assert torch.equal(p, p2), form            # the critic-only instance computes the same values
+        out[form] = (p.cpu().numpy().astype(np.float64), z.cpu().numpy().astype(np.float64))
+    for form in ("1", "fused", "fused1"):
+        dp = np.abs(out[form][0] - out["0"][0]).max()
+        dz = np.abs(out[form][1] - out["0"][1]).max()
+        print(f"config 4 tails, form {form!r} vs the fp32 tail kernels: |dpred| max {dp:.2e}, |dZ| max {dz:.2e}")
+        assert dp < 2e-5 and dz < 5e-5, form
+
+
 def test_legacy_unet_trains_through_the_module_vs_reference_capture(golden):
     """nets.Unet(upsample=False) under autograd (nets.py:356-449, built at TrainHandler.py:159-161): one
     training step of the REFERENCE class (loss = MSE(mask, target) + MSE(critic value, target), captured by make_golden.py) --
