@@ -24,6 +24,7 @@ PARITY UNPINNED: there is no reference counterpart; tests compare against the bu
 (oracle/hourglass_ref.py, hourglass128_apply / hourglass128_phase2_loss) with a stated bf16 tolerance.  Not wired into main.py (the
 reference's CLI has no such size); `bench.py --config 5 [--mode train]` measures it."""
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -35,6 +36,7 @@ from . import parallel
 from .generic import _ACT, _p, _s
 
 TAIL = True                 # the 16x16-and-smaller layers of chfak 1 (same shapes as the 64x64 model's) on the fp32 per-image tail kernels (csrc/tail.hip)
+TAIL_INFER_H16 = os.environ.get("CGS_C5_TAIL_H16", "1") != "0"      # inference: the two tail launches as ONE, on fp16 tiles (csrc/tail_infer.hip; A/B switch)
 H5CONV = True               # the 128x128 layers of chfak 1 (masker.0 / masker.2 forward, the three data gradients) on h5conv_kernel (csrc/hconv.hip)
 MIX_VIRTUAL = True          # the two mixes are formed inside features.0's forward / weight-gradient staging (no fp32 mix tensor, no mix kernel)
 MIX_BWD_FUSED = True        # features.0's image gradient of the two mixes + cgs_mix_bwd as one kernel (cgs_bf16_enc0_bwd_mix)
@@ -260,13 +262,16 @@ class Hourglass128:
                 src = self._conv(ENC_KEYS[i], src, None, d[i], act="relu", pool=True)
                 e.append(src)
             e2 = self._conv("features.6", src, None, d[2], act="relu", pool=True, out_f32=True)
-            e3, am3, e4, am4, e5, h1, pred, o5 = f32(n, 8, 8, 8), i32(n, 8, 8, 1), f32(n, 4, 4, 16), i32(n, 4, 4, 2), f32(n, 32), f32(n, 32), f32(n), f32(n, 32)
-            tw = self._tail_enc_w(True)
-            _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(e2), _p(e3), _p(am3), _p(e4), _p(am4), _p(e5), _p(h1), _p(pred), _p(o5),
-                      _NODROP, _NODROP, _NODROP, _s())
-            o4, o3, o2 = f32(n, 4, 4, 16), f32(n, 8, 8, 8), f32(n, 16, 16, 8)
-            tdw = self._tail_dec_w()
-            _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(e2), _p(e3), _p(e4), _p(o5), _p(o4), _p(o3), _p(o2), _s())
+            tw, tdw = self._tail_enc_w(True), self._tail_dec_w()
+            if TAIL_INFER_H16:      # (round 6) both of them in one launch per image on fp16 LDS tiles (csrc/tail_infer.hip, written for config 4)
+                pred, o2 = f32(n), f32(n, 16, 16, 8)
+                _lib.call("cgs_tail_infer_h16", n, C.byref(tw), C.byref(tdw), _p(e2), _p(pred), _p(o2), _s())
+            else:
+                e3, am3, e4, am4, e5, h1, pred, o5 = f32(n, 8, 8, 8), i32(n, 8, 8, 1), f32(n, 4, 4, 16), i32(n, 4, 4, 2), f32(n, 32), f32(n, 32), f32(n), f32(n, 32)
+                _lib.call("cgs_tail_enc_fwd", n, C.byref(tw), _p(e2), _p(e3), _p(am3), _p(e4), _p(am4), _p(e5), _p(h1), _p(pred), _p(o5),
+                          _NODROP, _NODROP, _NODROP, _s())
+                o4, o3, o2 = f32(n, 4, 4, 16), f32(n, 8, 8, 8), f32(n, 16, 16, 8)
+                _lib.call("cgs_tail_dec_fwd", n, C.byref(tdw), _p(e2), _p(e3), _p(e4), _p(o5), _p(o4), _p(o3), _p(o2), _s())
             if H5CONV:      # dec_model.1 reads the tail kernel's fp32 o2 directly
                 o = o2
             else:
