@@ -15,7 +15,7 @@ python tools/sq_counters.py gpurun_out/final/pmc gpurun_out/final/sq_counters.cs
 # counter traffic of the side workloads (FETCH_SIZE / WRITE_SIZE passes only)
 tools/side_pmc.sh final/pmc_c4 --mode infer --fp16 --batch 2048 && python tools/side_traffic.py gpurun_out/final/pmc_c4 mask_infer config4_fp16_infer_batch2048 $out/side_traffic.json
 tools/side_pmc.sh final/pmc_c5t --config 5 --mode train && python tools/side_traffic.py gpurun_out/final/pmc_c5t adam_kernel config5_train_batch256 $out/side_traffic.json
-tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "tail_dec_fwd_kernel<false" config5_infer_batch256 $out/side_traffic.json
+tools/side_pmc.sh final/pmc_c5i --config 5 --mode infer && python tools/side_traffic.py gpurun_out/final/pmc_c5i "tail_infer_h16_kernel" config5_infer_batch256 $out/side_traffic.json
 # the counter summaries go into THIS copy's profiles/ before the bench lines are taken: bench.py reads the newest profiles/r*_traffic.json and says whether
 # its source hash is the build's (tools/store_evidence.sh stores the same files in the build container afterwards)
 cp $out/traffic.json profiles/${tag}_traffic.json && sed -i "s#gpurun_out/final/sq_counters.csv#profiles/${tag}_sq_counters.csv#" profiles/${tag}_traffic.json
