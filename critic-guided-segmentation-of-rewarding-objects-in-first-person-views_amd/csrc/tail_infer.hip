@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
     if (tid < 32) b14s[o] = P.we.b14[o];
     const float bl1 = P.we.bl1[o], wl2 = P.we.wl2[o], bl2 = P.we.bl2[0], bpw = DEC ? P.we.bpw[o] : 0.f;
     [[maybe_unused]] const float b2v = DEC ? P.wd.b2[l15 & 7] : 0.f, b1v = DEC ? P.wd.b1[l15 & 7] : 0.f;
+    [[maybe_unused]] const float b3c = DEC ? P.wd.b3[tid & 15] : 0.f;      // (dec_model.3's bias of the sum stage's thread: a load per image there sat on the chain)
     __syncthreads();
 
     for (; img < P.n; img += P.nblocks) {
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CGS_TA
             {
                 const int i = tid >> 4, co = tid & 15;                       // tile pixel i = 4 * quad + 2 * dy + dx
                 const int q = i >> 2, y = 2 * (q >> 1) + ((i >> 1) & 1), x = 2 * (q & 1) + (i & 1);
-                const _Float16 v = (_Float16)(((part[0][i][co] + part[1][i][co]) + (part[2][i][co] + part[3][i][co])) + P.wd.b3[co]);
+                const _Float16 v = (_Float16)(((part[0][i][co] + part[1][i][co]) + (part[2][i][co] + part[3][i][co])) + b3c);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) t2[HT2::at(2 * y + (d >> 1), 2 * x + (d & 1)) + 8 + co] = v;
             }
