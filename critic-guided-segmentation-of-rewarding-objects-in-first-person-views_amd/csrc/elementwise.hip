@@ -179,41 +179,67 @@ __global__ void __launch_bounds__(256) phase1_loss_kernel(int n, const float* __
     if (threadIdx.x == 0) losses[0] = (red[0] + red[1] + red[2] + red[3]) * inv_n;
 }
 
-// grid = (ceil(max_count/32), njobs); block = 32 columns (one 128-byte line per slab row) x 32 slab lanes, up to 16
-// independent partial sums per thread in flight.  The longest job (2048 slabs) sets the kernel's duration: 64 rows per
-// thread = 4 rounds of loads.
+// grid = (ceil(max_count/128), njobs); block = 32 column lanes x 32 slab lanes, up to 16 independent partial sums per column in flight.  A column lane
+// covers FOUR consecutive columns (one 16-byte load per slab row: 512 bytes per row and wave-half) when the job's rows are 16-byte aligned (round 6: the
+// shape-generic layers' 130 MB of slab rows went through 128-byte row segments at 1.6 TB/s), else -- or for the last columns of a row -- one column per
+// pass, four passes.  Every column's sum is formed in the same order either way (bitwise equal to the one-column form).  The longest job (2048 slabs)
+// sets the kernel's duration: 64 rows per thread = 4 rounds of loads.
+template <int V>
+__device__ __forceinline__ void reduce_slabs_cols(const cgs_reduce_job& j, int i0, int sl, float (&out)[V]) {
+    constexpr int SL = 32;
+    typedef float vec_t __attribute__((ext_vector_type(V)));
+    vec_t s[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u] = vec_t(0.f);
+    const float* p = j.slab + i0;
+    auto ld = [&](int row) { return *(const vec_t*)(p + (size_t)row * j.stride); };
+    int b = sl;
+    for (; b + 15 * SL < j.nslab; b += 16 * SL) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s[u] += ld(b + u * SL);
+    }
+    for (; b + 3 * SL < j.nslab; b += 4 * SL) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s[u] += ld(b + u * SL);
+    }
+    for (; b < j.nslab; b += SL) s[0] += ld(b);
+    const vec_t t = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
+                    (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
+#pragma unroll
+    for (int c = 0; c < V; ++c) out[c] = t[c];
+}
+
 __global__ void __launch_bounds__(1024) reduce_slabs_kernel(const cgs_reduce_job* __restrict__ jobs, uint64_t* step) {
     constexpr int SL = 32;
-    __shared__ float red[SL][33];
+    __shared__ float red[4][SL][33];
     const cgs_reduce_job j = jobs[blockIdx.y];
     if (step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *step += 1ull;
-    if (blockIdx.x * 32 >= j.count) return;
+    if (blockIdx.x * 128 >= j.count) return;
     const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + col;
-    float s[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) s[u] = 0.f;
-    if (i < j.count) {
-        const float* p = j.slab + i;
-        int b = sl;
-        for (; b + 15 * SL < j.nslab; b += 16 * SL) {
-#pragma unroll
-            for (int u = 0; u < 16; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
+    const bool v4 = (((size_t)j.slab & 15) == 0) && (j.stride & 3) == 0;          // (uniform per workgroup)
+    const int i4 = blockIdx.x * 128 + 4 * col;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (v4 && i4 + 3 < j.count) {
+        reduce_slabs_cols<4>(j, i4, sl, v);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            float one[1] = {0.f};
+            if (i4 + c < j.count) reduce_slabs_cols<1>(j, i4 + c, sl, one);
+            v[c] = one[0];
         }
-        for (; b + 3 * SL < j.nslab; b += 4 * SL) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s[u] += p[(size_t)(b + u * SL) * j.stride];
-        }
-        for (; b < j.nslab; b += SL) s[0] += p[(size_t)b * j.stride];
     }
-    red[sl][col] = (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]))) +
-                   (((s[8] + s[9]) + (s[10] + s[11])) + ((s[12] + s[13]) + (s[14] + s[15])));
-    __syncthreads();
-    if (sl == 0 && i < j.count) {
-        float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < SL; ++k) t += red[k][col];
-        j.dst[i] = j.accumulate ? j.dst[i] + t : t;
+    for (int c = 0; c < 4; ++c) red[c][sl][col] = v[c];
+    __syncthreads();
+    if (sl < 4) {                      // slab lane c sums column 4 col + c over the 32 slab lanes
+        const int c = sl, i = i4 + c;
+        if (i < j.count) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < SL; ++k) t += red[c][k][col];
+            j.dst[i] = j.accumulate ? j.dst[i] + t : t;
+        }
     }
 }
 
@@ -325,7 +351,7 @@ extern "C" int cgs_phase1_loss(int32_t n, const float* pred, const float* y, int
 extern "C" int cgs_reduce_slabs(const cgs_reduce_job* jobs, int32_t njobs, int32_t max_count, uint64_t* step,
                                 cgs_stream_t stream) {
     if (!jobs || njobs <= 0 || max_count <= 0) return CGS_ERR_BADARG;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 31) / 32, njobs), dim3(1024), 0, (hipStream_t)stream, jobs, step);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_count + 127) / 128, njobs), dim3(1024), 0, (hipStream_t)stream, jobs, step);
     CGS_HIP_CHECK_LAUNCH();
     return CGS_OK;
 }
