@@ -234,19 +234,26 @@ def test_config4_tail_launch_forms_agree(g1, monkeypatch):
     e = engine.HourglassEngine(8, dropout=0.0)
     e.load_state(pc, pm)
     rs = np.random.RandomState(4)
-    x = torch.from_numpy(rs.randint(0, 256, (300, 64, 64, 3)).astype(np.uint8)).to(dev)      # (300: not a multiple of anything the kernels tile by)
-    out = {}
-    for form in ("0", "1", "fused", "fused1"):
-        monkeypatch.setattr(engine, "F16_TAILS", form)
-        p, z = e.infer(x, fp16=True)
-        p2, _ = e.infer(x, fp16=True, want_mask=False)
-        assert torch.equal(p, p2), form            # the critic-only instance computes the same values
-        out[form] = (p.cpu().numpy().astype(np.float64), z.cpu().numpy().astype(np.float64))
-    for form in ("1", "fused", "fused1"):
-        dp = np.abs(out[form][0] - out["0"][0]).max()
-        dz = np.abs(out[form][1] - out["0"][1]).max()
-        print(f"config 4 tails, form {form!r} vs the fp32 tail kernels: |dpred| max {dp:.2e}, |dZ| max {dz:.2e}")
-        assert dp < 2e-5 and dz < 5e-5, form
+    xall = torch.from_numpy(rs.randint(0, 256, (1100, 64, 64, 3)).astype(np.uint8)).to(dev)
+    for b in (1, 3, 300, 1100):      # (ragged: not multiples of anything the kernels tile by; 1100 = more images than persistent workgroups)
+        x = xall[:b].contiguous()
+        out = {}
+        for form in ("0", "1", "fused", "fused1"):
+            monkeypatch.setattr(engine, "F16_TAILS", form)
+            p, z = e.infer(x, fp16=True)
+            p2, _ = e.infer(x, fp16=True, want_mask=False)
+            assert torch.equal(p, p2), form            # the critic-only instance computes the same values
+            out[form] = (p.cpu().numpy().astype(np.float64), z.cpu().numpy().astype(np.float64))
+        for form in ("1", "fused", "fused1"):
+            dp = np.abs(out[form][0] - out["0"][0]).max()
+            dz = np.abs(out[form][1] - out["0"][1]).max()
+            print(f"config 4 tails, batch {b}, form {form!r} vs the fp32 tail kernels: |dpred| max {dp:.2e}, |dZ| max {dz:.2e}")
+            assert dp < 2e-5 and dz < 5e-5, (b, form)
+        # a batch is the concatenation of its images: image 0 of every batch equals the one-image batch's result bit for bit
+        if b == 1:
+            first = out["fused"]
+        else:
+            assert out["fused"][0][0] == first[0][0] and np.array_equal(out["fused"][1][0], first[1][0]), b
 
 
 def test_legacy_unet_trains_through_the_module_vs_reference_capture(golden):
