@@ -57,6 +57,9 @@ extern "C" int dbg_mask_head_stamps(unsigned long long* stamps) { g_mh_stamps = 
 #ifndef MH_INTERLEAVE
 #define MH_INTERLEAVE 1
 #endif
+#ifndef MH_DGRAD4
+#define MH_DGRAD4 1    // (round 6) masker.0's data gradient on v_mfma_f32_4x4x1 with lane = low-resolution pixel (no padded window positions): see mask_head_matrix
+#endif
 #ifndef MH_DZWIN
 #define MH_DZWIN 1     // (round 6) builder: rolling 3x3 dzpre window in registers (36 instead of 100 LDS reads per tile and thread)
 #endif
@@ -64,7 +67,7 @@ template <int TH, bool W0>
 struct MHeadGeo {
     static constexpr int H = 64, W = 64, TRA = TH + 2, PW = W + 2, PS = 17, DZW = W + 4, DZR = TH + 4, STRIPS = H / TH;
     static constexpr int XT = TRA * PW * PS, DZ = DZR * DZW;
-    static constexpr int W4P = 24 * 16 * 16;                           // pair-folded masker.0 weights [4x6 pos][oc][2x8]
+    static constexpr int W4P = MH_DGRAD4 ? 16 * 16 * 8 : 24 * 16 * 16;  // folded masker.0 weights: [4x4 pos][oc][8] (MH_DGRAD4) / pair-folded [4x6 pos][oc][2x8]
     static constexpr int LR = TH / 2 + 2, LC = W / 2 + 2;              // o0 tile at its own resolution
     static constexpr int XIMG = W0 ? TRA * PW * 4 : 0, XO = W0 ? LR * LC * 8 : 0;   // masker.0 inputs (image [r,g,b,0])
     // (round 6) ONE workgroup barrier per tile: the dzpre tile and masker.0's input tiles are double buffered like the dH tile, so the builder
@@ -408,6 +411,20 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
     }
     const float m1 = (16 + l15 < 27) ? 1.f : 0.f, m0 = (16 + l15 == 27) ? 1.f : 0.f;   // second row block: valid / bias / pad
 
+    // MH_DGRAD4 (round 6): the data gradient  d_o0[q][c] = sum_{u,v < 4} sum_oc dH[2 q + (u - 1, v - 1)][oc] W4[u][v][oc][c]  with lane = low-resolution
+    // pixel q on v_mfma_f32_4x4x1 (A = four output-channel weights broadcast from block abid = oc of weight register (u, v), B = the lane's dH value):
+    // 256 (position, oc) steps x 2 channel groups = 512 instructions of 8 cycles per 64 pixels = 2048 matrix cycles per low-resolution row, where the
+    // pair form (16 pairs x 2 x 8 columns, K = the 4 x 6 union window: a third of it zero weights) ran 96 x 32 = 3072.  Waves 0 / 1 take two
+    // low-resolution rows each (64 lanes = 64 pixels) and a smaller share of the weight gradient's chunks, waves 2 / 3 the larger share.
+    [[maybe_unused]] float w4r[2][16];
+    if constexpr (MH_DGRAD4) {
+        if (mwave < 2) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) w4r[g][k] = L.w4p[(k * 16 + (lane >> 2)) * 8 + 4 * g + (lane & 3)];
+        }
+    }
     [[maybe_unused]] unsigned long long tp = MH_T(), s_p1 = 0, s_w1 = 0, s_dg = 0, s_wg = 0, s_w2 = 0, tm = 0;
     __syncthreads();                                       // (the builders' once-per-workgroup barrier behind tile 0's dzpre)
     for (int i = 0; i <= T; ++i) {
@@ -427,7 +444,33 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
 #ifdef MH_WHATIF_NODGRAD
             if (P.n < 0)
 #endif
-            {
+            if constexpr (MH_DGRAD4) {
+                if (mwave < 2) {
+                    const int qyl = 2 * mwave + (lane >> 5), qx = lane & 31;
+                    const float* bp = xt + ((2 * qyl) * PW + 2 * qx) * PS;      // window position (0, 0) of this lane's pixel, channel 0
+                    frag4 d0 = frag4{0.f, 0.f, 0.f, 0.f}, d1 = frag4{0.f, 0.f, 0.f, 0.f};
+                    float bv[2][16];
+                    auto ldp = [&](int k, int buf) {                           // the 16 channels of window position k = (u, v)
+#pragma unroll
+                        for (int oc = 0; oc < 16; ++oc) bv[buf][oc] = bp[((k >> 2) * PW + (k & 3)) * PS + oc];
+                    };
+                    ldp(0, 0);
+                    static_for<16>([&](auto K) {
+                        constexpr int k = decltype(K)::value;
+                        if constexpr (k + 1 < 16) ldp(k + 1, (k + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        static_for<16>([&](auto OC) {
+                            constexpr int oc = decltype(OC)::value;
+                            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4r[0][k], bv[k & 1][oc], d0, 4, oc, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w4r[1][k], bv[k & 1][oc], d1, 4, oc, 0);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    float4* o = (float4*)(P.d_o0 + ((size_t)(n0 * 32 + row0 / 2 + qyl) * 32 + qx) * 8);
+                    o[0] = make_float4(d0[0], d0[1], d0[2], d0[3]);
+                    o[1] = make_float4(d1[0], d1[1], d1[2], d1[3]);
+                }
+            } else {
                 // data gradient of low-res row qyl = mwave: lane pair i = l15 covers low-res pixels 2i (columns 0-7 of the
                 // tile) and 2i+1 (columns 8-15); window = rows 2qyl-1..2qyl+2, columns 4i-1..4i+4 of dH
                 const int qyl = mwave;
@@ -492,39 +535,53 @@ __device__ __forceinline__ void mask_head_matrix(const MHeadParams& P, const MHe
                 constexpr int UU = 2, CPP = 8 / UU, NCH = 4 * CPP;
                 const int bb = (PW + 1 + 2 * kq) * PS + l15;              // dH: ((yl+1)*PW + 1 + 2*(4s+kq) + px)*PS + l15
                 const int ib = (2 * kq) * 4;                               // image: ((yl+ky)*PW + 2*(4s+kq) + px + kx)*4 + c
-                const int ob = kq * 8 + l15;                               // o0: ((mwave+a+py)*LC + 4s + kq + b + px)*8 + cb
+                const int ob = kq * 8 + l15;                               // o0: ((rp+a+py)*LC + 4s + kq + b + px)*8 + cb
                 float ai[2][UU][2], ao[2][UU][2], b[2][UU];
-                auto ld = [&](int ch, int buf) {
-                    const int py = ch / (2 * CPP), px = (ch / CPP) & 1, s0 = UU * (ch % CPP);
-                    const int yl = 2 * mwave + py;
+                // A HALF = the 8 chunks (px = 0 / 1, s0 = 0, 2, 4, 6) of one row (row pair rp, row parity py): 64 matrix instructions.  The tile's 8
+                // halves hh = 2 rp + py are dealt to the waves: two each, or -- MH_DGRAD4: waves 0 / 1 also carry the data gradient (4096 matrix
+                // cycles) -- 1 / 1 / 3 / 3, so every wave issues 6144 matrix cycles per tile.  py is a template value of the half (the accumulator
+                // arrays must be indexed statically), chosen by a wave-uniform branch.
+                auto do_half = [&](int rp, auto PY) {
+                    constexpr int py = decltype(PY)::value;
+                    const int yl = 2 * rp + py;
+                    auto ld = [&](int ch, int buf) {              // ch = 0 .. 7: px = ch / CPP, two k-steps from s0 = UU (ch % CPP)
+                        const int px = ch / CPP, s0 = UU * (ch % CPP);
 #pragma unroll
-                    for (int u = 0; u < UU; ++u) b[buf][u] = xt[bb + (yl * PW + px + 8 * (s0 + u)) * PS];
+                        for (int u = 0; u < UU; ++u) b[buf][u] = xt[bb + (yl * PW + px + 8 * (s0 + u)) * PS];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                        for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int u = 0; u < UU; ++u) ai[buf][u][q] = ximg[ib + rimg[q] + (yl * PW + px + 8 * (s0 + u)) * 4];
+                            for (int u = 0; u < UU; ++u) ai[buf][u][q] = ximg[ib + rimg[q] + (yl * PW + px + 8 * (s0 + u)) * 4];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q)
+                        for (int q = 0; q < 2; ++q)
 #pragma unroll
-                        for (int u = 0; u < UU; ++u) ao[buf][u][q] = xo[ob + ((mwave + q + py) * LC + px + 4 * (s0 + u)) * 8];
-                };
-                ld(0, 0);
+                            for (int u = 0; u < UU; ++u) ao[buf][u][q] = xo[ob + ((rp + q + py) * LC + px + 4 * (s0 + u)) * 8];
+                    };
+                    ld(0, 0);
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    if (ch + 1 < NCH) ld(ch + 1, (ch + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int py = ch / (2 * CPP), px = (ch / CPP) & 1;
+                    for (int ch = 0; ch < 2 * CPP; ++ch) {
+                        if (ch + 1 < 2 * CPP) ld(ch + 1, (ch + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int px = ch / CPP;
 #pragma unroll
-                    for (int u = 0; u < UU; ++u) {
-                        const float bv = b[ch & 1][u];
-                        // rows past the 27 image rows (bias row: constant 1, padding: 0) as arithmetic at the point of use:
-                        // the load stays unconditional and pairs into ds_read2
-                        accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[ch & 1][u][0], bv, accA[0], 0, 0, 0);
-                        accA[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(ai[ch & 1][u][1], m1, m0), bv, accA[1], 0, 0, 0);
-                        accB[py][px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][0], bv, accB[py][px][0], 0, 0, 0);
-                        accB[py][px][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][1], bv, accB[py][px][1], 0, 0, 0);
+                        for (int u = 0; u < UU; ++u) {
+                            const float bv = b[ch & 1][u];
+                            // rows past the 27 image rows (bias row: constant 1, padding: 0) as arithmetic at the point of use:
+                            // the load stays unconditional and pairs into ds_read2
+                            accA[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai[ch & 1][u][0], bv, accA[0], 0, 0, 0);
+                            accA[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(fmaf(ai[ch & 1][u][1], m1, m0), bv, accA[1], 0, 0, 0);
+                            accB[py][px][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][0], bv, accB[py][px][0], 0, 0, 0);
+                            accB[py][px][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ao[ch & 1][u][1], bv, accB[py][px][1], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                };
+                const int h_lo = MH_DGRAD4 ? (mwave < 2 ? mwave : 2 + 3 * (mwave - 2)) : 2 * mwave;
+                const int h_n = MH_DGRAD4 ? (mwave < 2 ? 1 : 3) : 2;
+#pragma unroll 1
+                for (int hh = h_lo; hh < h_lo + h_n; ++hh) {
+                    if (hh & 1) do_half(hh >> 1, std::integral_constant<int, 1>{});
+                    else do_half(hh >> 1, std::integral_constant<int, 0>{});
                 }
             }
         }
@@ -579,11 +636,16 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
     static_assert(G::W4P % 512 == 0 && G::W4P / 512 <= 12, "table rounds");
     {
         float wv[G::W4P / 512][4];
+        // entry e -> (window position (u, v), oc, output column): MH_DGRAD4: [pos 4x4][oc][c];  else pair-folded [pos 4x6][oc][8 g + c], pixel g of the
+        // pair sees window column v6 as v = v6 - 2 g
+        auto decode = [&](int e, int& u, int& v, int& oc, int& c) {
+            if constexpr (MH_DGRAD4) { c = e & 7; oc = (e >> 3) & 15; const int pos = e >> 7; u = pos >> 2; v = pos & 3; }
+            else { const int col = e & 15, pos = e >> 8; oc = (e >> 4) & 15; u = pos / 6; c = col & 7; v = pos % 6 - 2 * (col >> 3); }
+        };
 #pragma unroll
         for (int k = 0; k < G::W4P / 512; ++k) {
-            const int e = tid + 512 * k;
-            const int col = e & 15, oc = (e >> 4) & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
-            const int g = col >> 3, c = col & 7, v = v6 - 2 * g;      // pixel g of the pair sees window column v6 as v
+            int u, v, oc, c;
+            decode(tid + 512 * k, u, v, oc, c);
 #pragma unroll
             for (int ab = 0; ab < 4; ++ab) {
                 const int ky = (ab >> 1) + 2 - u, kx = (ab & 1) + 2 - v;
@@ -593,17 +655,16 @@ __global__ void __launch_bounds__(512) mask_head_kernel(MHeadParams P) {
         }
 #pragma unroll
         for (int k = 0; k < G::W4P / 512; ++k) {
-            const int e = tid + 512 * k;
-            const int col = e & 15, pos = e >> 8, u = pos / 6, v6 = pos % 6;
-            const int g = col >> 3, v = v6 - 2 * g;
-            float s = 0.f;
+            int u, v, oc, c;
+            decode(tid + 512 * k, u, v, oc, c);
+            float sm = 0.f;
 #pragma unroll
             for (int ab = 0; ab < 4; ++ab) {
                 const int ky = (ab >> 1) + 2 - u, kx = (ab & 1) + 2 - v;
                 const bool ok = v >= 0 && v <= 3 && ky >= 0 && ky <= 2 && kx >= 0 && kx <= 2;
-                s += ok ? wv[k][ab] : 0.f;
+                sm += ok ? wv[k][ab] : 0.f;
             }
-            L.w4p[e] = s;
+            L.w4p[tid + 512 * k] = sm;
         }
     }
     for (int e = tid; e < 2 * TRA * 2 * 16; e += 512) {      // zero halo columns of both dH tiles (never written again)
