@@ -120,8 +120,24 @@ __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
 #ifndef G4_WPE_SMALL
 #define G4_WPE_SMALL 4
 #endif
-template <int NG, int FOLD>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL, NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL))) gen4_conv3x3_kernel(Gen4Params P) {
+// VEC = 1 (round 6; launcher: FOLD = 0, NG >= 8, a vector source -- fp32 with ca % 4 == 0, or the pooled map + argmax): only those loaders are
+// instantiated and the chunk loop is peeled (every chunk but the last has 16 channels: ONE tap nest in the loop body, the accumulators stay in one
+// register set) -- the instance fits 128 registers, FOUR workgroups per CU with one tile buffer.
+#ifndef G4_VEC
+#define G4_VEC 1
+#endif
+#ifndef G4_VEC_BATCH
+#define G4_VEC_BATCH 3
+#endif
+#ifndef G4_VEC_S2D
+#define G4_VEC_S2D 1
+#endif
+#ifndef G4_WPE_VEC
+#define G4_WPE_VEC 4
+#endif
+template <int NG, bool VEC> constexpr int g4_wpe() { return VEC ? G4_WPE_VEC : (NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL); }
+template <int NG, int FOLD, bool VEC = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g4_wpe<NG, VEC>(), g4_wpe<NG, VEC>()))) gen4_conv3x3_kernel(Gen4Params P) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(Gen4Params)>();
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,7 +155,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     // FOLD: B's tile = (th / 2 + 2) x (W / 2 + 2) low-resolution pixels per image part, in the same buffers (A's chunks are done by then)
     const int pwb = (P.hw >> 1) + 2, rowsb = P.imgs * ((P.th >> 1) + 2), pstrideb = rowsb * pwb;
     const G4Geo geob{P.n, P.hw >> 1, P.lw - 1, P.imgs, P.th >> 1};
-    auto stage = [&](float4* dst, int ch, int ltid) {      // channel-planar tile: dst[(plane * rows + row) * pw + col], col 0 = left halo
+    auto stage = [&](float4* dst, int ch, int ltid) __attribute__((always_inline)) {      // channel-planar tile: dst[(plane * rows + row) * pw + col], col 0 = left halo
         if constexpr (FOLD == 2) {
             gen4_stage_s2d(G4Dst{dst, pstride, P.pw, 1, 1}, (const float*)S.a, S.ca, S.cb, geo, img0, row0, ch * GEN_KC, ltid);
         } else if constexpr (FOLD == 1) {
@@ -152,6 +168,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
                 // the halo columns of THIS layout (the buffer held full-resolution chunks before)
                 for (int e = ltid; e < 4 * rowsb * 2; e += 256) dst[(e >> 1) * pwb + ((e & 1) ? pwb - 1 : 0)] = f4zero();
             }
+        } else if constexpr (VEC) {
+            const G4Dst D{dst, pstride, P.pw, 1, 1};
+            if (S.mode == GEN_SRC_POOLEXP) gen4_stage<GEN_K_POOLEXP, false, false, G4_VEC_BATCH>(D, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+            else if (S.cb > 0) gen4_stage<GEN_K_F32V4, true, false, G4_VEC_BATCH>(D, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
+            else gen4_stage<GEN_K_F32V4, false, false, G4_VEC_BATCH>(D, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
         } else {
             gen4_stage_any(G4Dst{dst, pstride, P.pw, 1, 1}, S, geo, 1, img0, row0, ch * GEN_KC, 4, ltid);
         }
@@ -162,7 +183,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     // npass * NG groups per (chunk, tap) (zero past the layer's last), so group g is an immediate offset of 256 g bytes
     const int ngp = P.npass * NG;
     const float* wlane = P.wp + (size_t)g0 * 64 + lane;
-    auto wload = [&](float (&dst)[NG], int ct) {          // ct = chunk * 9 + tap
+    auto wload = [&](float (&dst)[NG], int ct) __attribute__((always_inline)) {          // ct = chunk * 9 + tap
         const float* q = wlane + (size_t)(ct * ngp) * 64;
 #pragma unroll
         for (int g = 0; g < NG; ++g) dst[g] = q[g * 64];
@@ -189,10 +210,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
         tile[r * P.pw + (side ? W + 1 : 0)] = f4zero();
     }
 
-    frag4 acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = frag4{0.f, 0.f, 0.f, 0.f};
-
     // Two tile buffers (dbuf): chunk c + 1 is staged BEFORE chunk c multiplies, one barrier per chunk -- a wave's staging (global
     // latency, address arithmetic) then overlaps the other waves' matrix instructions instead of standing between two barriers.
     float4* const tile0 = g4sm;
@@ -202,7 +219,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
         stage(tile0, 0, ltid);
         __syncthreads();
     }
-    for (int ch = 0; ch < nchunk; ++ch) {
+    frag4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = frag4{0.f, 0.f, 0.f, 0.f};
+    auto chunk = [&](int ch, auto FULLC) __attribute__((always_inline)) {      // FULLC: the chunk has 16 channels by construction
         int ltid = tid;                         // opaque per chunk: keeps the staging addresses from being hoisted out of the loop
         asm volatile("" : "+v"(ltid));
         if (P.dbuf) {
@@ -229,14 +249,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
         // Taps as a REAL loop, two per trip (static rotation of the weight registers): the unrolled 9-tap body is 1440 matrix
         // instructions -- more code than the instruction cache holds with four workgroups at different places in it.  A tap's
         // weights are requested one tap ahead; its plane reads (one LDS round trip per tap) hide behind the other waves.
-        auto taps = [&](auto NPC) {
+        auto taps = [&](auto NPC) __attribute__((always_inline)) {
             constexpr int NP = decltype(NPC)::value;
-            auto readx = [&](float4 (&xr)[NP], int tap) {
+            auto readx = [&](float4 (&xr)[NP], int tap) __attribute__((always_inline)) {
                 const int a0 = lbase + (tap / 3 - 1) * P.pw + (tap % 3 - 1);
 #pragma unroll
                 for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * pstride + a0];
             };
-            auto mac = [&](const float (&w)[NG], const float4 (&xr)[NP]) {
+            auto mac = [&](const float (&w)[NG], const float4 (&xr)[NP]) __attribute__((always_inline)) {
                 t4_static_for<NP>([&](auto PL) {
                     constexpr int pl = decltype(PL)::value;
                     t4_static_for<4>([&](auto CC) {
@@ -268,7 +288,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
                 mac(w0, xr);
             } else if constexpr (FOLD) {
                 // the four folds (a, b) of this wave's parity: slots ct0 .. ct0 + 3; the next chunk's first slot lands in w0 behind the last
-                auto readb = [&](float4 (&xr)[NP], int ab) {
+                auto readb = [&](float4 (&xr)[NP], int ab) __attribute__((always_inline)) {
                     const int a0 = lbase + (ab >> 1) * bpw + (ab & 1);
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) xr[pl] = tile[pl * bstride + a0];
@@ -289,10 +309,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
                 }
             }
         };
-        if (np == 4) taps(std::integral_constant<int, 4>{});
-        else if (np == 3) taps(std::integral_constant<int, 3>{});
-        else if (np == 2) taps(std::integral_constant<int, 2>{});
-        else taps(std::integral_constant<int, 1>{});
+        if constexpr (decltype(FULLC)::value) taps(std::integral_constant<int, 4>{});
+        else {
+            if (np == 4) taps(std::integral_constant<int, 4>{});
+            else if (np == 3) taps(std::integral_constant<int, 3>{});
+            else if (np == 2) taps(std::integral_constant<int, 2>{});
+            else taps(std::integral_constant<int, 1>{});
+        }
         if (!bch && ch + 1 < nchunk) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) w0[g] = w1[g];
@@ -300,6 +323,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
         if (ch < 3) G4_STAMP(4 + 5 * ch);
         __syncthreads();
         if (ch < 3) G4_STAMP(5 + 5 * ch);
+    };
+    if constexpr (VEC && FOLD == 2) {
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::true_type{});
+    } else if constexpr (VEC) {
+        for (int ch = 0; ch + 1 < nchunk; ++ch) chunk(ch, std::true_type{});
+        chunk(nchunk - 1, std::false_type{});
+    } else {
+        for (int ch = 0; ch < nchunk; ++ch) chunk(ch, std::false_type{});
     }
 
     // ---- epilogue: activation, (max-pool + argmax byte | addend), NHWC stores through LDS ----
@@ -310,7 +341,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 
     ngv = ngv < NG ? ngv : NG;
     const bool vec = !(P.co & 3);
     float* ot = (float*)g4sm;                    // the tile area is free now (barrier above)
-    constexpr int pitch = 4 * NG + 4;
+    constexpr int pitch = VEC && NG == 10 ? 40 : 4 * NG + 4;      // (VEC, 10 groups: 256 x 40 floats = the 40 KB a workgroup has at four per CU)
     const float slope = P.slope;
     auto epilogue = [&](auto ACT) {
         constexpr int act = decltype(ACT)::value;
@@ -581,15 +612,24 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     // the epilogue reuses the area for 256 pixels x (4 ng + 4) floats (pooling included: the cells' maxima are taken by the copy-out threads)
     const size_t tile_bytes = (size_t)4 * P.rows * P.pw * sizeof(float4);
     const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
-    const size_t budget = (size_t)(160 * 1024) / (ng >= 8 ? G4_WPE_BIG : G4_WPE_SMALL) - 512;
+    const bool vec = G4_VEC && ng >= 8 &&
+                     ((!L.fold && (L.src.mode == GEN_SRC_POOLEXP || (L.src.mode == GEN_SRC_F32 && !(L.src.ca & 3)))) || (L.fold == 2 && G4_VEC_S2D));
+    const int wpe = vec ? G4_WPE_VEC : (ng >= 8 ? G4_WPE_BIG : G4_WPE_SMALL);
+    const size_t budget = vec && wpe == 4 ? (size_t)40960 : (size_t)(160 * 1024) / wpe - 512;
     P.dbuf = ((cp > GEN_KC || L.fold) && 2 * tile_bytes <= budget) ? 1 : 0;
     size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
-    const size_t epi = (size_t)256 * (4 * ng + 4) * sizeof(float);
+    const size_t epi = (size_t)256 * (vec && ng == 10 ? 40 : 4 * ng + 4) * sizeof(float);
     lds = lds > epi ? lds : epi;
     const dim3 grid(tiles * P.npass);
     if (L.fold == 2) {
         // src = the s2d view: a = dY [n, 2 hw, 2 hw, ca], cb = the parity block width (ca rounded up to 16)
         if (L.pool || L.out2 || L.src.mode != GEN_SRC_F32 || (L.src.ca & 3) || (L.src.cb & 15) || L.src.cb < L.src.ca || hw > 32) return CGS_ERR_UNSUPPORTED;
+        if (vec) {
+            if (ng == 8) hipLaunchKernelGGL((gen4_conv3x3_kernel<8, 2, true>), grid, dim3(256), lds, st, P);
+            else hipLaunchKernelGGL((gen4_conv3x3_kernel<10, 2, true>), grid, dim3(256), lds, st, P);
+            CGS_HIP_CHECK_LAUNCH();
+            return CGS_OK;
+        }
 #define G4_LAUNCH_S(NG_) hipLaunchKernelGGL((gen4_conv3x3_kernel<NG_, 2>), grid, dim3(256), lds, st, P)
         switch (ng) {
             case 1: G4_LAUNCH_S(1); break;
@@ -616,6 +656,12 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
             default: G4_LAUNCH_F(10); break;
         }
 #undef G4_LAUNCH_F
+        CGS_HIP_CHECK_LAUNCH();
+        return CGS_OK;
+    }
+    if (vec) {
+        if (ng == 8) hipLaunchKernelGGL((gen4_conv3x3_kernel<8, 0, true>), grid, dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((gen4_conv3x3_kernel<10, 0, true>), grid, dim3(256), lds, st, P);
         CGS_HIP_CHECK_LAUNCH();
         return CGS_OK;
     }
