@@ -135,9 +135,14 @@ __global__ void __launch_bounds__(256) gen4_pack_batch_kernel(Gen4PackBatch B) {
 #ifndef G4_WPE_VEC
 #define G4_WPE_VEC 4
 #endif
-template <int NG, bool VEC> constexpr int g4_wpe() { return VEC ? G4_WPE_VEC : (NG >= 8 ? G4_WPE_BIG : G4_WPE_SMALL); }
+#ifndef G4_WPE_TINY
+#define G4_WPE_TINY 5
+#endif
+// (the narrow folded instances fit 96 registers: five workgroups per CU)
+constexpr bool g4_tiny(int ng, int fold) { return ng <= 4 && fold >= 1; }
+template <int NG, int FOLD, bool VEC> constexpr int g4_wpe() { return VEC ? G4_WPE_VEC : (NG >= 8 ? G4_WPE_BIG : (g4_tiny(NG, FOLD) ? G4_WPE_TINY : G4_WPE_SMALL)); }
 template <int NG, int FOLD, bool VEC = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g4_wpe<NG, VEC>(), g4_wpe<NG, VEC>()))) gen4_conv3x3_kernel(Gen4Params P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(g4_wpe<NG, FOLD, VEC>(), g4_wpe<NG, FOLD, VEC>()))) gen4_conv3x3_kernel(Gen4Params P) {
     if (CGS_KARG_PREFETCH) cgs_kernarg_prefetch<sizeof(Gen4Params)>();
     extern __shared__ __attribute__((aligned(16))) float4 g4sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -614,7 +619,7 @@ int gen4_conv_launch(const Gen4Launch& L, hipStream_t st) {
     const int cp = ((L.src.ca + 3) & ~3) + L.src.cb;
     const bool vec = G4_VEC && ng >= 8 &&
                      ((!L.fold && (L.src.mode == GEN_SRC_POOLEXP || (L.src.mode == GEN_SRC_F32 && !(L.src.ca & 3)))) || (L.fold == 2 && G4_VEC_S2D));
-    const int wpe = vec ? G4_WPE_VEC : (ng >= 8 ? G4_WPE_BIG : G4_WPE_SMALL);
+    const int wpe = vec ? G4_WPE_VEC : (ng >= 8 ? G4_WPE_BIG : (g4_tiny(ng, L.fold) ? G4_WPE_TINY : G4_WPE_SMALL));
     const size_t budget = vec && wpe == 4 ? (size_t)40960 : (size_t)(160 * 1024) / wpe - 512;
     P.dbuf = ((cp > GEN_KC || L.fold) && 2 * tile_bytes <= budget) ? 1 : 0;
     size_t lds = tile_bytes * (P.dbuf ? 2 : 1);
