@@ -49,6 +49,12 @@ def _ref_conv(a, b, ups, w_hwio, bias, act, slope, pool):
     (2, 32, 8, 0, 1, 6, "relu", True, False),        # pooled, channel count not a multiple of 4 (scalar epilogue)
     (2, 32, 12, 0, 1, 43, "none", False, False),     # 11 groups: two passes, scalar copy-out
     (2, 16, 160, 0, 1, 160, "relu", True, False),    # ten chunks, four passes
+    # the four-workgroups-per-CU instances (8 / 10 groups, fp32 source of whole quads) at the map sizes chfak 5 does not send them
+    (2, 64, 8, 0, 1, 32, "relu", False, False),      # 64 x 64, eight groups, ONE half-empty chunk (the peeled loop runs its last chunk only)
+    (2, 64, 40, 0, 1, 40, "relu", True, False),      # 64 x 64, ten groups, pooled (epilogue pitch 40)
+    (3, 16, 16, 0, 1, 32, "none", False, False),     # one full chunk
+    (21, 4, 32, 0, 1, 40, "relu", False, False),     # sixteen images per tile (ragged: 21), two full chunks
+    (5, 8, 36, 16, 2, 72, "none", False, False),     # second source through the vector loader, two passes of nine groups -> 10-group instance
 ])
 def test_gen4_forward_matches_float64_conv2d(n, hw, ca, cb, ups, co, act, pool, u8):
     from cgs_amd import generic as gen
@@ -117,6 +123,9 @@ def test_gen4_folded_upsample_forward(n, hw, ca, cb, co, act, u8):
     (19, 4, 48, 16, False),
     (2, 64, 43, 16, False),     # masker.0: d cat(image, decoder channels)
     (3, 16, 80, 40, False),
+    (2, 64, 40, 8, False),      # ten output groups at 64 x 64 from an 8-channel dY (four-per-CU instance, one half-empty chunk)
+    (2, 64, 32, 40, True),      # eight groups, pooled gradient source at 64 x 64
+    (21, 4, 32, 48, False),     # sixteen images per tile, three chunks
 ])
 def test_gen4_data_gradient_matches_autograd(n, hw, ci, co, pooled):
     """cgs_gen_conv_pack_weights(transposed = 1) + cgs_gen_conv3x3_bwd_data vs float64 autograd of conv2d (+ ReLU + max-pool), with the
@@ -157,6 +166,8 @@ def test_gen4_data_gradient_matches_autograd(n, hw, ci, co, pooled):
     (2, 32, 16, 16, 16),       # chfak 2
     (1, 64, 3, 24, 8),         # eight dY channels: a half-empty chunk per block; six output groups
     (3, 32, 8, 44, 12),        # eleven output groups: two passes
+    (2, 16, 16, 32, 16),       # eight output groups (four-per-CU instance of the s2d form), 8 x 8 cells, four images per tile (ragged: 2)
+    (3, 64, 4, 32, 20),        # 32 x 32 cells, parity blocks of 20 channels padded to 32
 ])
 def test_gen4_up2_data_gradient_vs_float64_autograd(n, hw, ca, cb, co):
     """cgs_gen_conv3x3_bwd_data_up2: the gradient of conv3x3(cat(A, nearest-up_2(B))) w.r.t. B (nets.py:501-517 under autograd), from the
