@@ -12,6 +12,7 @@
 //     results leave through a per-wave LDS block in full lines.
 // Same results as the generic kernel up to the summation order (fp32 FMA chains either way); parity through the chfak != 1 captures.
 #include <type_traits>
+#include <utility>
 #include "gen_common.h"
 
 namespace {
@@ -234,6 +235,13 @@ struct GEnc0WgParams {
     int n, a_is_u8, nstrips;
 };
 
+#ifndef GC0W_UNROLL
+#define GC0W_UNROLL 1
+#endif
+template <class F, int... Is>
+__device__ __forceinline__ void genc0_static_for_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void genc0_static_for(F&& f) { genc0_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 template <int NG>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) genc0_wgrad_kernel(GEnc0WgParams P) {
     constexpr int CO = 4 * NG, TW = 66, TH = 8, TROWS = TH + 2, NQW = (NG + 3) / 4;      // NQW: column quads per wave (at most)
@@ -258,6 +266,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
     for (int e = tid; e < TROWS * 2; e += 256) tile[(e >> 1) * TW + ((e & 1) ? TW - 1 : 0)] = f4zero();      // halo columns
     __syncthreads();
+#if GC0W_UNROLL
+    // per-lane operand bases of step 0 (pixel b of tile row 0): the steps add compile-time offsets
+    const float* apx[7];
+    const float* dpx[NQW];
+    const uint8_t* mpx[NQW];
+#pragma unroll
+    for (int rq = 0; rq < 7; ++rq) apx[rq] = (const float*)(tile + b) + aoff[rq];
+#pragma unroll
+    for (int q = 0; q < NQW; ++q) {
+        const int cq = wave + 4 * q, col0 = (b >> 1) * CO + 4 * (cq < NG ? cq : 0) + i;      // (past NG: a valid address, never multiplied)
+        dpx[q] = des + col0; mpx[q] = ams + col0;
+    }
+    const uint32_t pos_even = (uint32_t)(b & 1), pos_odd = 2u + (uint32_t)(b & 1);
+#endif
 
     for (int strip = blockIdx.x; strip < P.nstrips; strip += gridDim.x) {
         const int img = strip >> 3, row0 = (strip & 7) * TH;
@@ -309,6 +331,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
         // ---- 16-pixel steps: 16 consecutive pixels of a row; block b = pixel x0 + b.  Two operand sets: the LDS reads of step s + 1 are in flight
         //      behind the matrix instructions of step s (left to the compiler the reads of a step were waited for in front of its own
         //      instructions: matrix pipe busy 0.33, waves waiting 0.54 of their cycles) ----
+        auto mfmas = [&](const float (&av)[7], const float (&bv)[NQW], const uint32_t (&bm)[NQW + 1]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) {
+                if (wave + 4 * q < NG) {                            // (wave-uniform)
+                    const float v = bm[q] == bm[NQW] ? bv[q] : 0.f;
+#pragma unroll
+                    for (int rq = 0; rq < 7; ++rq) acc[q][rq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rq], v, acc[q][rq], 0, 0, 0);
+                }
+            }
+        };
+#if GC0W_UNROLL
+        // (round 6) The 32 steps of a strip as straight-line code: a step's place in the strip is a compile-time constant, so every LDS read is
+        // a per-lane base register (set once per workgroup) + an IMMEDIATE offset and the select's position code one of two per-lane registers --
+        // 6 vector instructions per step beside its <= 21 matrix instructions where the loop form spent 30 on addresses (fp32 matrix and vector
+        // instructions of a SIMD do not overlap: the kernel ran at 0.35 matrix-pipe busy).  Same operands in the same order: bitwise the same sums.
+        auto load_at = [&](auto SC, float (&av)[7], float (&bv)[NQW], uint32_t (&bm)[NQW + 1]) __attribute__((always_inline)) {
+            constexpr int s = decltype(SC)::value, y = s >> 2, xs = (s & 3) * 16;
+#pragma unroll
+            for (int rq = 0; rq < 7; ++rq) av[rq] = apx[rq][(y * TW + xs) * 4];
+            constexpr int cellc = (y >> 1) * 32 + (xs >> 1);
+            bm[NQW] = (y & 1) ? pos_odd : pos_even;
+#pragma unroll
+            for (int q = 0; q < NQW; ++q) { bv[q] = dpx[q][cellc * CO]; bm[q] = mpx[q][cellc * CO]; }
+        };
+        {
+            float a0[7], a1[7], b0[NQW], b1[NQW];
+            uint32_t m0[NQW + 1], m1[NQW + 1];
+            load_at(std::integral_constant<int, 0>{}, a0, b0, m0);
+            genc0_static_for<TH * 2>([&](auto KC) {
+                constexpr int s = 2 * decltype(KC)::value;
+                load_at(std::integral_constant<int, s + 1>{}, a1, b1, m1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a0, b0, m0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_at(std::integral_constant<int, (s + 2 < TH * 4 ? s + 2 : s)>{}, a0, b0, m0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(a1, b1, m1);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+#else
         auto load_ops = [&](int s, float (&av)[7], float (&bv)[NQW], uint32_t (&bm)[NQW + 1]) __attribute__((always_inline)) {
             const int y = s >> 2, x = (s & 3) * 16 + b;
             const float* px = (const float*)(tile + y * TW + x);    // tap (0,0) of the pixel's 3x3 window (tile row 0 = image row row0 - 1)
@@ -321,16 +384,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 const int cq = wave + 4 * q;                        // this wave's column quad (past NG: a valid address, never multiplied)
                 const int col = cell * CO + 4 * (cq < NG ? cq : 0) + i;
                 bv[q] = des[col]; bm[q] = ams[col];
-            }
-        };
-        auto mfmas = [&](const float (&av)[7], const float (&bv)[NQW], const uint32_t (&bm)[NQW + 1]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < NQW; ++q) {
-                if (wave + 4 * q < NG) {                            // (wave-uniform)
-                    const float v = bm[q] == bm[NQW] ? bv[q] : 0.f;
-#pragma unroll
-                    for (int rq = 0; rq < 7; ++rq) acc[q][rq] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rq], v, acc[q][rq], 0, 0, 0);
-                }
             }
         };
         {
@@ -349,6 +402,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#endif
         __syncthreads();
     }
     // ---- add the 16 blocks (lanes with equal lane & 3), one slab row per workgroup: D_b[r][j] -> row 4 rq + r, column 4 cq + j (j = lane & 3) ----
