@@ -13,6 +13,9 @@
 // NARROW (ca <= 3: masker.0's frames): A's 9 ca <= 27 rows (two more row blocks per wave, the full-resolution frame tile beside the others)
 // and the bias row (the sum of the B operand) come from this kernel too -- the row-block kernel would stage all of dY a second time for them.
 #pragma once
+#ifndef GWF_OPAQUE
+#define GWF_OPAQUE 0
+#endif
 
 struct GenWfParams {
     const void* a; int a_u8;              // NARROW only: A [n,hw,hw,ca] (ca <= 3: the frames), fp32 or uint8 (/255)
@@ -96,7 +99,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     [[maybe_unused]] uint8_t st8[KA > 0 ? KA : 1][3];                     // NARROW, uint8 frames: the raw bytes (converted in store(): v_cvt_f32_ubyte0 needs no mask)
     auto issue = [&](int u) __attribute__((always_inline)) {
         int ltid = tid;
-        asm volatile("" : "+v"(ltid));
+        if (GWF_OPAQUE || (NARROW && NCOB == 3 && RB >= 8)) asm volatile("" : "+v"(ltid));
         const int img = u / P.parts, row0 = (u % P.parts) * th, yb0 = (row0 >> 1) - 1;
         // (no branch around a load and no use of a loaded value before the last load is issued)
 #pragma unroll
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(512) gen_wgrad_fold_kernel(GenWfParams P) {
     };
     auto store = [&](int bf, int u) __attribute__((always_inline)) {
         int ltid = tid;
-        asm volatile("" : "+v"(ltid));
+        if (GWF_OPAQUE || (NARROW && NCOB == 3 && RB >= 8)) asm volatile("" : "+v"(ltid));
         const int row0 = (u % P.parts) * th, yb0 = (row0 >> 1) - 1;
         float* tb = sm + bf * BUF;
         float* td = tb + BTF;
